@@ -1,0 +1,150 @@
+"""CPU oracle of the FCGF-style sparse ResUNet forward (torch on CPU, fp32).
+
+TEST INFRASTRUCTURE.  **Parity unpinned** (MinkowskiEngine absent, see ``oracle/coords.py``).
+
+Restates ``ResUNet2.forward`` (model/resunet.py:142-193) and ``BasicBlockBase.forward``
+(model/residual_block.py:37-53) on top of the output-stationary neighbour tables of
+``oracle.coords``.  Each sparse convolution is evaluated the way MinkowskiEngine does it - per
+kernel offset: gather the input rows of that offset's pairs, multiply by ``W[k]``, scatter-add into
+the output rows - and batch norm is applied un-folded in eval mode (model/common.py:4-6,
+``torch.nn.BatchNorm1d`` with eps = 1e-5).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import coords as oc
+
+BN_EPS = 1e-5
+
+# class name -> (CHANNELS, TR_CHANNELS), model/resunet.py:12-13,196-231
+CHANNEL_TABLES = {
+    "ResUNet2": ((None, 32, 64, 128, 256), (None, 32, 64, 64, 128)),
+    "ResUNetBN2": ((None, 32, 64, 128, 256), (None, 32, 64, 64, 128)),
+    "ResUNetBN2B": ((None, 32, 64, 128, 256), (None, 64, 64, 64, 64)),
+    "ResUNetBN2C": ((None, 32, 64, 128, 256), (None, 64, 64, 64, 128)),
+    "ResUNetBN2D": ((None, 32, 64, 128, 256), (None, 64, 64, 128, 128)),
+    "ResUNetBN2E": ((None, 128, 128, 128, 256), (None, 64, 128, 128, 128)),
+    "ResUNetFatBN": ((None, 32, 64, 128, 256), (None, 128, 128, 128, 256)),
+}
+
+
+def _t(x):
+    return x if isinstance(x, torch.Tensor) else torch.from_numpy(np.asarray(x))
+
+
+def sparse_conv(x: torch.Tensor, nbr: np.ndarray, W: torch.Tensor) -> torch.Tensor:
+    """``out[o] = sum_k x[nbr[k,o]] @ W[k]`` via per-offset gather -> matmul -> index_add."""
+    K, n_out = nbr.shape
+    out = torch.zeros((n_out, W.shape[2]), dtype=x.dtype)
+    for k in range(K):
+        o = np.nonzero(nbr[k] >= 0)[0]
+        if len(o) == 0:
+            continue
+        i = torch.from_numpy(nbr[k][o].astype(np.int64))
+        out.index_add_(0, torch.from_numpy(o), x[i] @ W[k])
+    return out
+
+
+def batch_norm(x, sd, name):
+    """Eval-mode ``MinkowskiBatchNorm`` (model/common.py:6)."""
+    w, b = _t(sd[f"{name}.bn.weight"]).float(), _t(sd[f"{name}.bn.bias"]).float()
+    m, v = _t(sd[f"{name}.bn.running_mean"]).float(), _t(sd[f"{name}.bn.running_var"]).float()
+    return (x - m) / torch.sqrt(v + BN_EPS) * w + b
+
+
+def _kernel(sd, name):
+    w = _t(sd[f"{name}.kernel"]).float()
+    return w[None] if w.dim() == 2 else w       # 1x1 convs store a 2-D kernel
+
+
+def basic_block(x, nbr, sd, name):
+    """model/residual_block.py:37-53 (downsample is always None, model/resunet.py:41-42)."""
+    out = sparse_conv(x, nbr, _kernel(sd, f"{name}.conv1"))
+    out = torch.relu(batch_norm(out, sd, f"{name}.norm1"))
+    out = sparse_conv(out, nbr, _kernel(sd, f"{name}.conv2"))
+    out = batch_norm(out, sd, f"{name}.norm2")
+    return torch.relu(out + x)
+
+
+def resunet_forward(sd: dict, coords: np.ndarray, feats, normalize_feature=True,
+                    conv1_kernel_size=5, maps=None, return_intermediate=False):
+    """Forward of ``ResUNet2`` (any BN channel table - shapes come from ``sd``).
+
+    ``coords int [N,4] (b,x,y,z)``, ``feats f32 [N,C_in]`` -> ``f32 [N,C_out]`` in input row order.
+    """
+    if maps is None:
+        maps = oc.build_maps(coords, conv1_kernel_size)
+    s1, down, up = maps["s1"], maps["down"], maps["up"]
+    ident = lambda n: np.arange(n, dtype=np.int32)[None, :]
+    x = _t(feats).float()
+    inter = {}
+
+    # encoder (model/resunet.py:143-161)
+    out_s1 = batch_norm(sparse_conv(x, maps["k5"], _kernel(sd, "conv1")), sd, "norm1")
+    out_s1 = basic_block(out_s1, s1[0], sd, "block1")
+    out = torch.relu(out_s1)
+    out_s2 = batch_norm(sparse_conv(out, down[0], _kernel(sd, "conv2")), sd, "norm2")
+    out_s2 = basic_block(out_s2, s1[1], sd, "block2")
+    out = torch.relu(out_s2)
+    out_s4 = batch_norm(sparse_conv(out, down[1], _kernel(sd, "conv3")), sd, "norm3")
+    out_s4 = basic_block(out_s4, s1[2], sd, "block3")
+    out = torch.relu(out_s4)
+    out_s8 = batch_norm(sparse_conv(out, down[2], _kernel(sd, "conv4")), sd, "norm4")
+    out_s8 = basic_block(out_s8, s1[3], sd, "block4")
+    out = torch.relu(out_s8)
+    inter.update(out_s1=out_s1, out_s2=out_s2, out_s4=out_s4, out_s8=out_s8)
+
+    # decoder (model/resunet.py:163-186); ME.cat order is [decoder | skip]
+    out = batch_norm(sparse_conv(out, up[2], _kernel(sd, "conv4_tr")), sd, "norm4_tr")
+    out_s4_tr = torch.relu(basic_block(out, s1[2], sd, "block4_tr"))
+    out = torch.cat([out_s4_tr, out_s4], 1)
+    out = batch_norm(sparse_conv(out, up[1], _kernel(sd, "conv3_tr")), sd, "norm3_tr")
+    out_s2_tr = torch.relu(basic_block(out, s1[1], sd, "block3_tr"))
+    out = torch.cat([out_s2_tr, out_s2], 1)
+    out = batch_norm(sparse_conv(out, up[0], _kernel(sd, "conv2_tr")), sd, "norm2_tr")
+    out_s1_tr = torch.relu(basic_block(out, s1[0], sd, "block2_tr"))
+    out = torch.cat([out_s1_tr, out_s1], 1)
+    inter.update(out_s4_tr=out_s4_tr, out_s2_tr=out_s2_tr, out_s1_tr=out_s1_tr)
+    n = out.shape[0]
+    out = torch.relu(sparse_conv(out, ident(n), _kernel(sd, "conv1_tr")))
+    out = sparse_conv(out, ident(n), _kernel(sd, "final")) + _t(sd["final.bias"]).float().reshape(1, -1)
+    inter["pre_norm"] = out
+    if normalize_feature:
+        # model/resunet.py:187-191 - no epsilon: a zero row yields NaN, as in the reference
+        out = out / torch.norm(out, p=2, dim=1, keepdim=True)
+    if return_intermediate:
+        return out, inter, maps
+    return out
+
+
+def work_model(stats: dict, sd: dict) -> dict:
+    """Algorithmic FLOPs / bytes of one forward from realised map sizes (SURVEY.md §8d formulas):
+    ``FLOP = 2 pairs Cin Cout``; ``gather_bytes = pairs (4 Cin + 8) + 4 N_out Cout + 4 K Cin Cout``;
+    ``compulsory_bytes = 4 (N_in Cin + N_out Cout) + 8 pairs + 4 K Cin Cout``."""
+    n = stats["rows"]
+    layers = []
+
+    def add(name, pairs, n_in, n_out):
+        w = _kernel(sd, name)
+        K, ci, co = w.shape
+        layers.append({
+            "name": name, "pairs": pairs, "flop": 2 * pairs * ci * co,
+            "gather_bytes": pairs * (4 * ci + 8) + 4 * n_out * co + 4 * K * ci * co,
+            "compulsory_bytes": 4 * (n_in * ci + n_out * co) + 8 * pairs + 4 * K * ci * co,
+        })
+
+    add("conv1", stats["pairs_k5"], n[0], n[0])
+    for lvl, blk in ((0, "block1"), (1, "block2"), (2, "block3"), (3, "block4"),
+                     (2, "block4_tr"), (1, "block3_tr"), (0, "block2_tr")):
+        for c in ("conv1", "conv2"):
+            add(f"{blk}.{c}", stats["pairs_s1"][lvl], n[lvl], n[lvl])
+    for i, name in enumerate(("conv2", "conv3", "conv4")):
+        add(name, stats["pairs_down"][i], n[i], n[i + 1])
+    for i, name in ((2, "conv4_tr"), (1, "conv3_tr"), (0, "conv2_tr")):
+        add(name, stats["pairs_up"][i], n[i + 1], n[i])
+    add("conv1_tr", n[0], n[0], n[0])
+    add("final", n[0], n[0], n[0])
+    tot = {k: sum(l[k] for l in layers) for k in ("flop", "gather_bytes", "compulsory_bytes")}
+    return {"layers": layers, **tot}

@@ -1,0 +1,57 @@
+"""Deterministic inputs shared by ``make_golden.py`` (which runs the reference on them) and the
+tests (which run the oracle / the HIP path on them).  Only PCG64 uniform doubles, element-wise IEEE
+operations and explicit left-to-right accumulation are used, so the arrays are bit-reproducible on
+any machine and the fixtures only have to store the reference's OUTPUTS."""
+import numpy as np
+
+
+def _u(seed, *shape):
+    return np.random.Generator(np.random.PCG64(seed)).random(shape)
+
+
+def _normal(seed, *shape):
+    u = _u(seed, 2, *shape)
+    return np.sqrt(-2.0 * np.log(1.0 - u[0])) * np.cos(2.0 * np.pi * u[1])
+
+
+def _rownorm(x):
+    acc = np.zeros(x.shape[0])
+    for c in range(x.shape[1]):
+        acc = acc + x[:, c] * x[:, c]
+    return x / np.sqrt(acc)[:, None]
+
+
+def unit_feats(seed, n, c=32):
+    return _rownorm(_normal(seed, n, c)).astype(np.float32)
+
+
+def nn_case(seed, n0, n1, c=32, noise=0.35):
+    """F0 random unit rows; F1 = noisy copies of a random subset of F0 plus distractors."""
+    F0 = _normal(seed, n0, c)
+    src = (_u(seed + 1, n1) * n0).astype(np.int64)
+    F1 = F0[src] + noise * _normal(seed + 2, n1, c)
+    return _rownorm(F0).astype(np.float32), _rownorm(F1).astype(np.float32)
+
+
+def rot_zyx(rx, ry, rz):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def rigid(rx, ry, rz, tx, ty, tz):
+    T = np.eye(4)
+    T[:3, :3] = rot_zyx(rx, ry, rz)
+    T[:3, 3] = (tx, ty, tz)
+    return T
+
+
+def corr_case(seed, n, T, inlier_frac, noise=0.02, extent=(60.0, 60.0, 6.0)):
+    """Correspondences ``p1 ~ T p0`` with a fraction of gross outliers (uniform in the scene box)."""
+    p0 = (_u(seed, n, 3) - 0.5) * np.array(extent)
+    p1 = p0 @ T[:3, :3].T + T[:3, 3] + noise * _normal(seed + 1, n, 3)
+    out = _u(seed + 2, n) >= inlier_frac
+    p1[out] = (_u(seed + 3, n, 3)[out] - 0.5) * np.array(extent)
+    return p0.astype(np.float32), p1.astype(np.float32), ~out

@@ -1,0 +1,141 @@
+"""Generate the golden OUTPUT vectors by running the reference's own importable functions.
+
+Run in the build container only (``python tests/golden/make_golden.py``): it imports
+``/root/reference`` read-only.  MinkowskiEngine / open3d are imported by some reference modules at
+module top but not used by the functions exercised here, so empty ``sys.modules`` stubs stand in for
+them.  Nothing of the reference is copied: the fixtures hold inputs' seeds and the
+reference's numeric outputs only.
+
+  g1_nn.npz      lib.eval.find_nn_gpu / lib.metrics.pdist
+  g2_irls.npz    util.transform_estimation.est_quad_linear_robust
+  g3_kabsch.npz  scripts.SC2_PCR.common.rigid_transform_3d
+  g4_sc2pcr.npz  scripts.SC2_PCR.SC2_PCR.Matcher.SC2_PCR / cal_leading_eigenvector (KITTI config)
+  g5_se3.npz     scripts.SC2_PCR.utils.SE3.transform / integrate_trans
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+sys.path.insert(0, HERE)
+sys.path.insert(0, REF)
+for name in ("open3d", "MinkowskiEngine"):
+    sys.modules.setdefault(name, types.ModuleType(name))
+
+import _inputs as gi  # noqa: E402
+from lib.eval import find_nn_gpu  # noqa: E402
+from lib.metrics import pdist  # noqa: E402
+from util.transform_estimation import est_quad_linear_robust  # noqa: E402
+from scripts.SC2_PCR.common import rigid_transform_3d  # noqa: E402
+from scripts.SC2_PCR.SC2_PCR import Matcher  # noqa: E402
+from scripts.SC2_PCR.utils.SE3 import transform, integrate_trans  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def g1():
+    out = {}
+    for tag, (seed, n0, n1) in {"big": (11, 5000, 5000), "odd": (12, 257, 129), "wide": (13, 300, 4000)}.items():
+        F0, F1 = gi.nn_case(seed, n0, n1)
+        t0, t1 = torch.from_numpy(F0), torch.from_numpy(F1)
+        inds, d = find_nn_gpu(t0, t1, nn_max_n=500, return_distance=True)
+        inds2, d2 = find_nn_gpu(t0, t1, nn_max_n=-1, return_distance=True)
+        assert torch.equal(inds, inds2), "nn_max_n must not change the result"
+        out[f"{tag}_meta"] = np.array([seed, n0, n1])
+        out[f"{tag}_inds"] = inds.numpy().astype(np.int32)
+        out[f"{tag}_d2"] = d.numpy()[:, 0]
+        indsL, dL = find_nn_gpu(t0, t1, nn_max_n=500, return_distance=True, dist_type="L2")
+        out[f"{tag}_inds_l2"] = indsL.numpy().astype(np.int32)
+        out[f"{tag}_d_l2"] = dL.numpy()[:, 0]
+    A, B = gi.nn_case(14, 16, 8)
+    out["small_pdist_sq"] = pdist(torch.from_numpy(A), torch.from_numpy(B), "SquareL2").numpy()
+    out["small_pdist_l2"] = pdist(torch.from_numpy(A), torch.from_numpy(B), "L2").numpy()
+    np.savez_compressed(os.path.join(HERE, "g1_nn.npz"), **out)
+
+
+IRLS_CASES = [  # (seed, n, inlier_frac, use_weight, T params)
+    (21, 5000, 1.0, False, (0.02, -0.03, 0.30, 2.0, -0.5, 0.1)),
+    (22, 5000, 0.7, False, (0.01, 0.02, -0.10, 1.0, 0.3, -0.05)),
+    (23, 5000, 0.4, False, (-0.02, 0.01, 0.05, 0.5, 0.2, 0.02)),
+    (24, 3000, 0.7, True, (0.03, 0.00, 0.15, -1.2, 0.4, 0.0)),
+    (25, 777, 0.9, True, (0.0, 0.0, 0.0, 0.0, 0.0, 0.0)),
+]
+
+
+def g2():
+    out = {"cases": np.array(json.dumps(IRLS_CASES))}
+    for i, (seed, n, frac, use_w, tp) in enumerate(IRLS_CASES):
+        p0, p1, _ = gi.corr_case(seed, n, gi.rigid(*tp), frac)
+        w = None
+        if use_w:
+            w = torch.from_numpy((0.05 + 0.95 * gi._u(seed + 9, n, 1)).astype(np.float32))
+        T = est_quad_linear_robust(torch.from_numpy(p0), torch.from_numpy(p1), w)
+        out[f"T{i}"] = T.numpy()
+    np.savez_compressed(os.path.join(HERE, "g2_irls.npz"), **out)
+
+
+KABSCH_CASES = [  # (seed, bs, n, kind)
+    (31, 1, 5000, "weighted"), (32, 1000, 20, "weighted"), (33, 64, 20, "zeros"),
+    (34, 8, 50, "none"), (35, 4, 30, "reflect"), (36, 16, 3, "weighted"),
+]
+
+
+from make_golden_inputs import kabsch_inputs  # noqa: E402
+
+
+def g3():
+    out = {"cases": np.array(json.dumps(KABSCH_CASES))}
+    for i, case in enumerate(KABSCH_CASES):
+        A, B, w = kabsch_inputs(*case)
+        T = rigid_transform_3d(torch.from_numpy(A), torch.from_numpy(B),
+                               None if w is None else torch.from_numpy(w.copy()))
+        out[f"T{i}"] = T.numpy()
+    np.savez_compressed(os.path.join(HERE, "g3_kabsch.npz"), **out)
+
+
+SC2_CASES = [  # (seed, n, inlier_frac, T params)
+    (41, 2000, 0.10, (0.01, -0.02, 0.12, 12.0, 0.4, 0.1)),
+    (42, 2000, 0.30, (-0.02, 0.01, -0.08, 7.0, -0.3, 0.0)),
+    (43, 2000, 0.60, (0.00, 0.03, 0.17, 18.0, 0.2, -0.1)),
+    (44, 500, 0.50, (0.02, 0.00, 0.05, 5.0, 0.0, 0.0)),
+]
+KITTI_CFG = dict(inlier_threshold=0.6, num_node=8000, use_mutual=False, d_thre=0.1,
+                 num_iterations=20, ratio=0.2, nms_radius=0.6, max_points=8000, k1=30, k2=20)
+
+
+def g4():
+    out = {"cases": np.array(json.dumps(SC2_CASES)), "cfg": np.array(json.dumps(KITTI_CFG))}
+    m = Matcher(**KITTI_CFG)
+    for i, (seed, n, frac, tp) in enumerate(SC2_CASES):
+        p0, p1, inl = gi.corr_case(seed, n, gi.rigid(*tp), frac, noise=0.03)
+        T, fit = m.SC2_PCR(torch.from_numpy(p0)[None], torch.from_numpy(p1)[None])
+        out[f"T{i}"] = T[0].numpy()
+        out[f"fitmax{i}"] = np.array(float(fit.max()))
+    # leading eigenvector of a fixed symmetric non-negative 256x256 matrix
+    M = gi._u(45, 256, 256)
+    M = ((M + M.T) * 0.5).astype(np.float32)
+    np.fill_diagonal(M, 0)
+    out["eig_vec"] = m.cal_leading_eigenvector(torch.from_numpy(M)[None])[0].numpy()
+    np.savez_compressed(os.path.join(HERE, "g4_sc2pcr.npz"), **out)
+
+
+def g5():
+    pts = ((gi._u(51, 3, 40, 3) - 0.5) * 10).astype(np.float32)
+    R = np.stack([gi.rot_zyx(*((gi._u(52 + b, 3) - 0.5) * 2)) for b in range(3)]).astype(np.float32)
+    t = ((gi._u(55, 3, 3, 1) - 0.5) * 5).astype(np.float32)
+    T = integrate_trans(torch.from_numpy(R), torch.from_numpy(t))
+    out = {"T": T.numpy(), "warped": transform(torch.from_numpy(pts), T).numpy(),
+           "warped0": transform(torch.from_numpy(pts[0]), T[0]).numpy()}
+    np.savez_compressed(os.path.join(HERE, "g5_se3.npz"), **out)
+
+
+if __name__ == "__main__":
+    for fn in (g1, g2, g3, g4, g5):
+        fn()
+        print("wrote", fn.__name__)

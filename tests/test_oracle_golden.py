@@ -1,0 +1,155 @@
+"""Pin the CPU oracle against golden vectors produced by the reference's own functions
+(tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import _inputs as gi
+from oracle import matching as om
+from oracle import pose as op
+from oracle import sc2pcr as osc
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+# ----------------------------------------------------------------------------- G1
+@pytest.mark.parametrize("tag", ["big", "odd", "wide"])
+def test_find_nn_matches_reference(golden_dir, tag):
+    g = _load(golden_dir, "g1_nn.npz")
+    seed, n0, n1 = (int(v) for v in g[f"{tag}_meta"])
+    F0, F1 = gi.nn_case(seed, n0, n1)
+    inds, d2 = om.find_nn(F0, F1, nn_max_n=500, return_distance=True)
+    ref_i, ref_d = g[f"{tag}_inds"].astype(np.int64), g[f"{tag}_d2"]
+    # distances agree to fp32 round-off of a 32-term sum
+    np.testing.assert_allclose(d2[:, 0], ref_d, rtol=0, atol=4e-6)
+    # tie audit: indices may differ only where the runner-up is within round-off of the winner
+    diff = np.nonzero(inds != ref_i)[0]
+    assert len(diff) <= max(2, n0 // 1000), f"{len(diff)} index mismatches"
+    for i in diff:
+        D = om.sqdist_rows(F0[i:i + 1], F1)[0]
+        assert abs(D[inds[i]] - D[ref_i[i]]) <= 4e-6
+    # 'L2' variant
+    indsL, dL = om.find_nn(F0, F1, return_distance=True, dist_type="L2")
+    np.testing.assert_allclose(dL[:, 0], g[f"{tag}_d_l2"], rtol=0, atol=4e-6)
+    assert (indsL != g[f"{tag}_inds_l2"]).sum() <= max(2, n0 // 1000)
+
+
+def test_pdist_matches_reference(golden_dir):
+    g = _load(golden_dir, "g1_nn.npz")
+    A, B = gi.nn_case(14, 16, 8)
+    np.testing.assert_allclose(om.pdist(A, B, "SquareL2"), g["small_pdist_sq"], atol=2e-6)
+    np.testing.assert_allclose(om.pdist(A, B, "L2"), g["small_pdist_l2"], atol=2e-6)
+
+
+def test_find_nn_tie_goes_to_lowest_index():
+    F1 = np.zeros((5, 4), np.float32)
+    F1[1] = F1[3] = [1, 0, 0, 0]
+    F0 = np.array([[1, 0, 0, 0], [0, 0, 0, 0]], np.float32)
+    assert om.find_nn(F0, F1).tolist() == [1, 0]
+
+
+# ----------------------------------------------------------------------------- G2
+def test_irls_matches_reference(golden_dir):
+    g = _load(golden_dir, "g2_irls.npz")
+    cases = json.loads(str(g["cases"]))
+    for i, (seed, n, frac, use_w, tp) in enumerate(cases):
+        p0, p1, _ = gi.corr_case(seed, n, gi.rigid(*tp), frac)
+        w = None
+        if use_w:
+            w = torch.from_numpy((0.05 + 0.95 * gi._u(seed + 9, n, 1)).astype(np.float32))
+        T = op.est_quad_linear_robust(torch.from_numpy(p0), torch.from_numpy(p1), w).numpy()
+        np.testing.assert_allclose(T, g[f"T{i}"], rtol=0, atol=2e-5, err_msg=f"case {i}")
+
+
+# ----------------------------------------------------------------------------- G3
+def well_conditioned(A, B, w, tol=1e-3):
+    """Kabsch is ill-posed when the (weighted, centred) points are nearly collinear: the second
+    singular value of H vanishes and round-off decides the rotation about the line.  Such batch
+    elements (one 3-point case in the fixture) are excluded from element-wise comparison."""
+    w = np.ones(A.shape[:2], np.float32) if w is None else w
+    ws = w.sum(1, keepdims=True)[:, :, None] + 1e-6
+    Am = A - (A * w[:, :, None]).sum(1, keepdims=True) / ws
+    Bm = B - (B * w[:, :, None]).sum(1, keepdims=True) / ws
+    H = np.einsum("bni,bnj->bij", Am, w[:, :, None] * Bm).astype(np.float64)
+    s = np.linalg.svd(H, compute_uv=False)
+    return s[:, 1] > tol * s[:, 0]
+
+
+def test_kabsch_matches_reference(golden_dir):
+    from make_golden_inputs import kabsch_inputs
+    g = _load(golden_dir, "g3_kabsch.npz")
+    cases = json.loads(str(g["cases"]))
+    for i, case in enumerate(cases):
+        A, B, w = kabsch_inputs(*case)
+        T = op.rigid_transform_3d(torch.from_numpy(A), torch.from_numpy(B),
+                                  None if w is None else torch.from_numpy(w)).numpy()
+        ok = well_conditioned(A, B, w)
+        assert ok.mean() > 0.9
+        np.testing.assert_allclose(T[ok], g[f"T{i}"][ok], rtol=0, atol=5e-4, err_msg=f"case {i} {case}")
+        R = T[:, :3, :3]
+        np.testing.assert_allclose(np.linalg.det(R), 1.0, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------- G4
+def test_sc2pcr_matches_reference(golden_dir):
+    g = _load(golden_dir, "g4_sc2pcr.npz")
+    cases = json.loads(str(g["cases"]))
+    cfg = json.loads(str(g["cfg"]))
+    assert cfg == osc.KITTI_CFG
+    m = osc.Matcher(**cfg)
+    for i, (seed, n, frac, tp) in enumerate(cases):
+        p0, p1, _ = gi.corr_case(seed, n, gi.rigid(*tp), frac, noise=0.03)
+        T, fit = m.SC2_PCR(torch.from_numpy(p0)[None], torch.from_numpy(p1)[None])
+        np.testing.assert_allclose(T[0].numpy(), g[f"T{i}"], rtol=0, atol=2e-4, err_msg=f"case {i}")
+        assert float(fit.max()) == pytest.approx(float(g[f"fitmax{i}"]), abs=2)
+        # and the recovered pose is the planted one
+        np.testing.assert_allclose(T[0].numpy(), gi.rigid(*tp), atol=0.05)
+
+
+def test_leading_eigenvector_matches_reference(golden_dir):
+    g = _load(golden_dir, "g4_sc2pcr.npz")
+    M = gi._u(45, 256, 256)
+    M = ((M + M.T) * 0.5).astype(np.float32)
+    np.fill_diagonal(M, 0)
+    v = osc.Matcher(**osc.KITTI_CFG).cal_leading_eigenvector(torch.from_numpy(M)[None])[0].numpy()
+    np.testing.assert_allclose(v, g["eig_vec"], atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- G5
+def test_se3_helpers_match_reference(golden_dir):
+    g = _load(golden_dir, "g5_se3.npz")
+    pts = ((gi._u(51, 3, 40, 3) - 0.5) * 10).astype(np.float32)
+    R = np.stack([gi.rot_zyx(*((gi._u(52 + b, 3) - 0.5) * 2)) for b in range(3)]).astype(np.float32)
+    t = ((gi._u(55, 3, 3, 1) - 0.5) * 5).astype(np.float32)
+    T = op.integrate_trans(torch.from_numpy(R), torch.from_numpy(t))
+    np.testing.assert_array_equal(T.numpy(), g["T"])
+    np.testing.assert_allclose(op.transform(torch.from_numpy(pts), T).numpy(), g["warped"], atol=1e-6)
+    np.testing.assert_allclose(op.transform(torch.from_numpy(pts[0]), T[0]).numpy(), g["warped0"], atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- G6 (hand-computed)
+def test_metrics_hand_cases():
+    T = np.eye(4, dtype=np.float32)
+    assert op.registration_errors(T, T) == (0.0, 0.0, True)
+    a = np.deg2rad(3.0)
+    Tr = np.eye(4, dtype=np.float32)
+    Tr[:3, :3] = gi.rot_zyx(0, 0, a)
+    Tr[:3, 3] = (1.0, 0.0, 0.0)
+    rte, rre, ok = op.registration_errors(Tr, T)
+    assert rte == pytest.approx(1.0) and rre == pytest.approx(a, abs=2e-4) and ok
+    Tr[:3, 3] = (2.5, 0, 0)
+    assert op.registration_errors(Tr, T)[2] is False          # RTE >= 2 m
+    Tr[:3, :3] = gi.rot_zyx(0, 0, np.deg2rad(6.0))
+    Tr[:3, 3] = 0
+    assert op.registration_errors(Tr, T)[2] is False          # RRE >= 5 deg
+    # the diagonal clamp keeps arccos finite when round-off pushes the trace above 3
+    Tb = np.eye(4, dtype=np.float32)
+    Tb[:3, :3] *= np.float32(1.0000002)
+    assert not np.isnan(op.registration_errors(Tb, T)[1])
+    d = op.evaluate_nn_dist(np.zeros((2, 3)), np.array([[3.0, 4.0, 0.0], [0, 0, 0]]), np.eye(4))
+    np.testing.assert_allclose(d, [np.sqrt(25 + 1e-6), 1e-3], rtol=1e-6)
