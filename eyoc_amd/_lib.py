@@ -1,0 +1,157 @@
+"""ctypes binding of ``libeyoc_hip.so`` (declared in ``include/eyoc_hip.h``).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails this module
+raises.  ``torch`` is used only to own device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libeyoc_hip.so")
+
+MAX_LEVELS = 4
+MAP_S1, MAP_DOWN, MAP_UP = 0, 1, 2
+
+
+class MapsInfo(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("rows", C.c_int32 * MAX_LEVELS),
+                ("pairs_s1", C.c_int64 * MAX_LEVELS), ("pairs_down", C.c_int64 * MAX_LEVELS),
+                ("pairs_up", C.c_int64 * MAX_LEVELS), ("pairs_conv1", C.c_int64)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("conv1_kernel_size", C.c_int32),
+                ("normalize_feature", C.c_int32), ("channels", C.c_int32 * 5), ("tr_channels", C.c_int32 * 5),
+                ("bn_eps", C.c_float)]
+
+
+class LayerParams(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("kernel", C.POINTER(C.c_float)), ("K", C.c_int32), ("cin", C.c_int32),
+                ("cout", C.c_int32), ("bias", C.POINTER(C.c_float)), ("bn_weight", C.POINTER(C.c_float)),
+                ("bn_bias", C.POINTER(C.c_float)), ("bn_mean", C.POINTER(C.c_float)),
+                ("bn_var", C.POINTER(C.c_float))]
+
+
+class RansacParams(C.Structure):
+    _fields_ = [("max_distance", C.c_float), ("edge_similarity", C.c_float), ("max_iteration", C.c_int32),
+                ("seed", C.c_uint32)]
+
+
+class RansacResult(C.Structure):
+    _fields_ = [("T", C.c_float * 16), ("inliers", C.c_int32), ("best_hypothesis", C.c_int32),
+                ("survivors", C.c_int32), ("inlier_rmse", C.c_float)]
+
+
+class Sc2pcrParams(C.Structure):
+    _fields_ = [("inlier_threshold", C.c_float), ("d_thre", C.c_float), ("ratio", C.c_float),
+                ("nms_radius", C.c_float), ("num_iterations", C.c_int32), ("max_points", C.c_int32),
+                ("k1", C.c_int32), ("k2", C.c_int32)]
+
+
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+# name -> (restype, argtypes); every symbol include/eyoc_hip.h declares
+PROTOTYPES = {
+    "eyoc_version": (_i, []),
+    "eyoc_last_error": (C.c_char_p, []),
+    "eyoc_create": (_i, [_i, C.POINTER(_vp)]),
+    "eyoc_destroy": (_i, [_vp]),
+    "eyoc_maps_workspace_bytes": (_sz, [_i]),
+    "eyoc_maps_build": (_i, [_vp, _vp, _i, _vp, _sz, _vp, C.POINTER(_vp)]),
+    "eyoc_maps_free": (_i, [_vp]),
+    "eyoc_maps_rows": (_i, [_vp, _i]),
+    "eyoc_maps_coords": (_vp, [_vp, _i]),
+    "eyoc_maps_table": (_vp, [_vp, _i, _i]),
+    "eyoc_maps_copy_coords": (_i, [_vp, _i, _vp, _vp]),
+    "eyoc_maps_copy_table": (_i, [_vp, _i, _i, _vp, _vp]),
+    "eyoc_maps_info": (_i, [_vp, _vp, _i, _vp, C.POINTER(MapsInfo)]),
+    "eyoc_spconv_packed_floats": (_sz, [_i, _i, _i]),
+    "eyoc_spconv_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "eyoc_spconv": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp]),
+    "eyoc_model_blob_floats": (_sz, [C.POINTER(ModelDesc)]),
+    "eyoc_model_create": (_i, [_vp, C.POINTER(ModelDesc), C.POINTER(LayerParams), _i, _vp, _sz, C.POINTER(_vp)]),
+    "eyoc_model_destroy": (_i, [_vp]),
+    "eyoc_model_workspace_bytes": (_sz, [_vp, _vp]),
+    "eyoc_model_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "eyoc_model_num_layers": (_i, [_vp]),
+    "eyoc_model_layer_work": (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "eyoc_model_set_timing": (_i, [_vp, _i]),
+    "eyoc_model_layer_ms": (_i, [_vp, C.POINTER(C.c_float)]),
+    "eyoc_knn1": (_i, [_vp, _vp, _vp, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i, _i, _vp, _vp, _vp]),
+    "eyoc_pdist": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "eyoc_kabsch_batched": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "eyoc_irls_quad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "eyoc_ransac": (_i, [_vp, _vp, _vp, _vp, _i, C.POINTER(RansacParams), _vp, _vp]),
+    "eyoc_sc2pcr_workspace_bytes": (_sz, [_i, C.POINTER(Sc2pcrParams)]),
+    "eyoc_sc2pcr": (_i, [_vp, _vp, _vp, _i, C.POINTER(Sc2pcrParams), _vp, _vp, _vp, _sz, _vp]),
+}
+
+
+class EyocError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+_ctx = {}
+
+
+def load():
+    """Load the shared library (no GPU needed) and attach prototypes.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise EyocError(
+                    f"{LIB_PATH} not found: build it with `python -m eyoc_amd.build` (hipcc, gfx950). "
+                    "There is no CPU fallback for this path.")
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in PROTOTYPES.items():
+                fn = getattr(lib, name)
+                fn.restype, fn.argtypes = res, args
+            _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().eyoc_last_error().decode("utf-8", "replace")
+        raise EyocError(f"{what or 'libeyoc_hip'} failed ({rc}): {msg}")
+
+
+def ctx(device_index: int | None = None):
+    """The per-(process, device) ``eyoc_ctx*``."""
+    import torch
+    if not torch.cuda.is_available():
+        raise EyocError("no GPU visible: the EYOC hot path runs on MI355X only (no CPU fallback)")
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    if device_index not in _ctx:
+        lib = load()
+        h = C.c_void_p()
+        check(lib.eyoc_create(int(device_index), C.byref(h)), "eyoc_create")
+        _ctx[device_index] = h
+    return _ctx[device_index]
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def workspace(nbytes: int, device):
+    """256-byte aligned device workspace owned by torch's caching allocator."""
+    import torch
+    t = torch.empty(max(int(nbytes), 256) + 256, dtype=torch.uint8, device=device)
+    off = (-t.data_ptr()) % 256
+    return t[off:off + max(int(nbytes), 256)]

@@ -1,0 +1,117 @@
+// Shared internals of libeyoc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/eyoc_hip.h"
+
+namespace eyoc {
+
+void set_error(const char* fmt, ...);
+
+#define EYOC_CHECK_HIP(expr)                                                               \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      eyoc::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,    \
+                      __LINE__);                                                           \
+      return EYOC_ERR_HIP;                                                                 \
+    }                                                                                      \
+  } while (0)
+
+#define EYOC_REQUIRE(cond, code, ...)  \
+  do {                                 \
+    if (!(cond)) {                     \
+      eyoc::set_error(__VA_ARGS__);    \
+      return (code);                   \
+    }                                  \
+  } while (0)
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// carve typed arrays out of a caller-owned workspace
+struct Carver {
+  char* base;
+  size_t off = 0, cap;
+  Carver(void* p, size_t bytes) : base((char*)p), cap(bytes) {}
+  template <typename T>
+  T* take(size_t count) {
+    size_t o = align_up(off);
+    off = o + count * sizeof(T);
+    return (T*)(base ? base + o : nullptr);
+  }
+  bool ok() const { return off <= cap; }
+};
+
+}  // namespace eyoc
+
+struct eyoc_ctx {
+  int device = 0;
+  // grow-only scratch owned by the ctx (knn packed minima, ransac survivor lists, reductions)
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  // pinned host staging for small read-backs
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
+  int ensure_scratch(size_t bytes);
+};
+
+// ---------------------------------------------------------------------------------------------
+// coordinate keys and the open-addressing hash shared by coordmap.hip and spconv.hip (conv1)
+// ---------------------------------------------------------------------------------------------
+namespace eyoc {
+
+constexpr unsigned long long KEY_EMPTY = 0xFFFFFFFFFFFFFFFFull;
+constexpr int COORD_BIAS = 1 << 17;   // |coordinate| < 2^17
+constexpr int VAL_UNSET = 0x7F7F7F7F;  // hipMemset(0x7F)
+
+struct HashTable {
+  unsigned long long* keys;
+  int* vals;
+  unsigned int mask;  // capacity - 1 (capacity is a power of two)
+};
+
+__host__ __device__ inline unsigned long long pack_key(int b, int x, int y, int z) {
+  return ((unsigned long long)(unsigned)b << 54) |
+         ((unsigned long long)((unsigned)(x + COORD_BIAS) & 0x3FFFFu) << 36) |
+         ((unsigned long long)((unsigned)(y + COORD_BIAS) & 0x3FFFFu) << 18) |
+         ((unsigned long long)((unsigned)(z + COORD_BIAS) & 0x3FFFFu));
+}
+
+__host__ __device__ inline unsigned int hash_key(unsigned long long k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return (unsigned int)k;
+}
+
+__device__ inline int hash_lookup(const HashTable& t, unsigned long long key) {
+  unsigned int s = hash_key(key) & t.mask;
+  while (true) {
+    unsigned long long k = t.keys[s];
+    if (k == key) return t.vals[s];
+    if (k == KEY_EMPTY) return -1;
+    s = (s + 1) & t.mask;
+  }
+}
+
+}  // namespace eyoc
+
+struct eyoc_maps {
+  int n_levels = 0;
+  int rows[EYOC_MAX_LEVELS] = {0, 0, 0, 0};
+  int32_t* coords[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};  // [rows,4]
+  eyoc::HashTable table[EYOC_MAX_LEVELS];
+  int32_t* nbr_s1[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};    // [27][rows[l]]
+  int32_t* nbr_down[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};  // [l]: [27][rows[l+1]]
+  int32_t* nbr_up[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};    // [l]: [27][rows[l]]
+};

@@ -1,0 +1,379 @@
+// Coordinate maps and rulebooks: the device-side replacement of MinkowskiEngine's coordinate
+// manager for the ResUNet path (ME.SparseTensor at scripts/test_kitti.py:143-148; the kernel maps
+// behind model/resunet.py:31-116 and model/residual_block.py:23-33).
+//
+//  * keys: (batch,x,y,z) packed into 64 bits, open addressing (linear probing, load <= 0.5) in HBM;
+//    insertion is atomicCAS on the key + atomicMin on the value, so the value of a slot is the
+//    smallest row index that mapped to it - this makes "first occurrence" deterministic.
+//  * level l+1 = unique floor(c / 2ts) * 2ts of level l: insert coarse keys, flag the rows that won
+//    their slot, exclusive-scan the flags, compact -> coarse rows ordered by first occurrence.
+//  * rulebooks are output-stationary tables nbr[27][n_out] (k-major so that the 64 rows of a wave
+//    read/write one contiguous segment per offset).
+#include "common.h"
+
+using namespace eyoc;
+
+namespace {
+
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_TILE = SCAN_ITEMS * SCAN_BLOCK;  // 2048 flags per block
+
+__device__ inline void coarse_coord(const int32_t* c, int ts2, int& b, int& x, int& y, int& z) {
+  const int m = ~(ts2 - 1);  // ts2 is a power of two: floor to a multiple of ts2, also for negatives
+  b = c[0]; x = c[1] & m; y = c[2] & m; z = c[3] & m;
+}
+
+// ts2 == 1: keys of the rows themselves.  err[0] counts out-of-range coordinates.
+__global__ void k_insert(const int32_t* __restrict__ coords, int n, int ts2, HashTable t, int* __restrict__ slot_out,
+                         int* __restrict__ err) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int b, x, y, z;
+  coarse_coord(coords + 4 * (size_t)i, ts2, b, x, y, z);
+  constexpr int LIM = COORD_BIAS - 16;  // margin: neighbour probes reach +-8 voxels at tensor stride 8
+  if (b < 0 || b >= 1024 || x < -LIM || x >= LIM || y < -LIM || y >= LIM || z < -LIM || z >= LIM) {
+    atomicAdd(&err[0], 1);
+    if (slot_out) slot_out[i] = 0;
+    return;
+  }
+  const unsigned long long key = pack_key(b, x, y, z);
+  unsigned int s = hash_key(key) & t.mask;
+  while (true) {
+    unsigned long long prev = atomicCAS(&t.keys[s], KEY_EMPTY, key);
+    if (prev == KEY_EMPTY || prev == key) break;
+    s = (s + 1) & t.mask;
+  }
+  atomicMin(&t.vals[s], i);
+  if (slot_out) slot_out[i] = (int)s;
+}
+
+// flag[i] = 1 iff row i is the first row of its slot; for ts2 == 1 any 0 flag is a duplicate row
+__global__ void k_flag(const int* __restrict__ slot, const int* __restrict__ vals, int n, int* __restrict__ flag,
+                       int* __restrict__ dup) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int f = vals[slot[i]] == i;
+  flag[i] = f;
+  if (dup && !f) atomicAdd(dup, 1);
+}
+
+__device__ inline int block_exclusive_scan(int v, int* total) {
+  __shared__ int wave_sum[SCAN_BLOCK / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) wave_sum[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_BLOCK / 64; ++w) {
+    int s = wave_sum[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_partials(const int* __restrict__ flag, int n, int* __restrict__ partial) {
+  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) s += (base + j < n) ? flag[base + j] : 0;
+  int tot;
+  block_exclusive_scan(s, &tot);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of partial[0..nb) in place, total -> *total
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_top(int* __restrict__ partial, int nb, int* __restrict__ total) {
+  int carry = 0;
+  for (int b0 = 0; b0 < nb; b0 += SCAN_BLOCK) {
+    int i = b0 + threadIdx.x;
+    int v = i < nb ? partial[i] : 0;
+    int tot;
+    int ex = block_exclusive_scan(v, &tot);
+    if (i < nb) partial[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+// compaction: first rows write their coarse coordinate at pos and re-label their slot with it
+__global__ __launch_bounds__(SCAN_BLOCK) void k_compact(const int* __restrict__ flag, const int* __restrict__ partial,
+                                                        const int* __restrict__ slot, const int32_t* __restrict__ coords,
+                                                        int n, int ts2, int32_t* __restrict__ coords_out,
+                                                        int* __restrict__ vals) {
+  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  int f[SCAN_ITEMS];
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    f[j] = (base + j < n) ? flag[base + j] : 0;
+    s += f[j];
+  }
+  int tot;
+  int pos = partial[blockIdx.x] + block_exclusive_scan(s, &tot);
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    if (f[j]) {
+      const int i = base + j;
+      int b, x, y, z;
+      coarse_coord(coords + 4 * (size_t)i, ts2, b, x, y, z);
+      int4 c = make_int4(b, x, y, z);
+      reinterpret_cast<int4*>(coords_out)[pos] = c;
+      vals[slot[i]] = pos;
+      ++pos;
+    }
+  }
+}
+
+// nbr[k][o] = row of table_in at c_out[o] + sign * off_k * step
+__global__ void k_neighbours(const int32_t* __restrict__ coords_out, int n_out, HashTable tin, int step, int sign,
+                             int32_t* __restrict__ nbr) {
+  int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n_out) return;
+  const int4 c = reinterpret_cast<const int4*>(coords_out)[o];
+  const int d = sign * step;
+#pragma unroll 1
+  for (int k = 0; k < 27; ++k) {
+    const int dx = (k % 3 - 1) * d, dy = ((k / 3) % 3 - 1) * d, dz = (k / 9 - 1) * d;
+    nbr[(size_t)k * n_out + o] = hash_lookup(tin, pack_key(c.x, c.y + dx, c.z + dy, c.w + dz));
+  }
+}
+
+__global__ void k_count_valid(const int32_t* __restrict__ t, long long n, unsigned long long* __restrict__ out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  unsigned int c = 0;
+  for (; i < n; i += stride) c += t[i] >= 0;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
+__global__ void k_count_region(const int32_t* __restrict__ coords, int n, HashTable t, int ks,
+                               unsigned long long* __restrict__ out) {
+  int o = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned int c = 0;
+  if (o < n) {
+    const int4 p = reinterpret_cast<const int4*>(coords)[o];
+    const int r = ks / 2;
+    for (int dz = -r; dz <= r; ++dz)
+      for (int dy = -r; dy <= r; ++dy)
+        for (int dx = -r; dx <= r; ++dx) c += hash_lookup(t, pack_key(p.x, p.y + dx, p.z + dy, p.w + dz)) >= 0;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
+unsigned int table_capacity(int n) {
+  unsigned int cap = 1024;
+  while (cap < 2u * (unsigned)n) cap <<= 1;
+  return cap;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t eyoc_maps_workspace_bytes(int n_rows) {
+  if (n_rows < 0) return 0;
+  const size_t n = (size_t)n_rows;
+  const size_t cap = table_capacity(n_rows);
+  size_t b = 0;
+  b += EYOC_MAX_LEVELS * (align_up(cap * 8) + align_up(cap * 4));   // hash tables
+  b += EYOC_MAX_LEVELS * align_up(n * 16);                           // coordinates
+  b += 10 * align_up(n * 27 * 4);                                    // 4 s1 + 3 down + 3 up tables
+  b += 3 * align_up(n * 4) + align_up((n / SCAN_TILE + 2) * 4);      // slot, flag, partial sums
+  b += 4096;                                                         // counters
+  return b + 64 * 256;
+}
+
+int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, size_t ws_bytes, void* stream,
+                    eyoc_maps** out) {
+  EYOC_REQUIRE(ctx && out && ws, EYOC_ERR_INVALID, "eyoc_maps_build: NULL argument");
+  EYOC_REQUIRE(n > 0 && coords_dev, EYOC_ERR_INVALID, "eyoc_maps_build: empty coordinate set (n=%d)", n);
+  EYOC_REQUIRE(((uintptr_t)ws & 255) == 0, EYOC_ERR_INVALID, "eyoc_maps_build: workspace must be 256-byte aligned");
+  EYOC_REQUIRE(ws_bytes >= eyoc_maps_workspace_bytes(n), EYOC_ERR_WORKSPACE,
+               "eyoc_maps_build: workspace %zu < required %zu bytes", ws_bytes, eyoc_maps_workspace_bytes(n));
+  hipStream_t st = (hipStream_t)stream;
+  Carver cv(ws, ws_bytes);
+  eyoc_maps* m = new eyoc_maps();
+  m->n_levels = EYOC_MAX_LEVELS;
+  int* counters = cv.take<int>(64);       // [0] range errors, [1] duplicates, [2+l] coarse totals
+  int* slot = cv.take<int>(n);
+  int* flag = cv.take<int>(n);
+  int* partial = cv.take<int>(n / SCAN_TILE + 2);
+  int* host = (int*)ctx->pinned;
+#define FAIL_HIP(expr)                                                                       \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);  \
+      delete m;                                                                              \
+      return EYOC_ERR_HIP;                                                                   \
+    }                                                                                        \
+  } while (0)
+
+  FAIL_HIP(hipMemsetAsync(counters, 0, 64 * sizeof(int), st));
+  // ---- level 0: the caller's rows, in the caller's order
+  m->rows[0] = n;
+  m->coords[0] = cv.take<int32_t>((size_t)n * 4);
+  FAIL_HIP(hipMemcpyAsync(m->coords[0], coords_dev, (size_t)n * 16, hipMemcpyDeviceToDevice, st));
+  for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
+    // table of THIS level is built from the previous level's rows (or the input for l == 0)
+    const int n_src = l == 0 ? n : m->rows[l - 1];
+    const int32_t* src = l == 0 ? m->coords[0] : m->coords[l - 1];
+    const int ts2 = 1 << l;
+    const unsigned int cap = table_capacity(n_src);
+    HashTable& t = m->table[l];
+    t.keys = cv.take<unsigned long long>(cap);
+    t.vals = cv.take<int>(cap);
+    t.mask = cap - 1;
+    FAIL_HIP(hipMemsetAsync(t.keys, 0xFF, (size_t)cap * 8, st));
+    FAIL_HIP(hipMemsetAsync(t.vals, 0x7F, (size_t)cap * 4, st));
+    hipLaunchKernelGGL(k_insert, dim3(cdiv(n_src, 256)), dim3(256), 0, st, src, n_src, ts2, t, slot, counters);
+    hipLaunchKernelGGL(k_flag, dim3(cdiv(n_src, 256)), dim3(256), 0, st, slot, t.vals, n_src, flag,
+                       l == 0 ? counters + 1 : (int*)nullptr);
+    if (l == 0) {
+      FAIL_HIP(hipMemcpyAsync(host, counters, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+      FAIL_HIP(hipStreamSynchronize(st));
+      if (host[0] != 0) {
+        set_error("eyoc_maps_build: %d coordinate rows outside the supported key range (|c| < 2^17 - 16, 0 <= batch < 1024)", host[0]);
+        delete m;
+        return EYOC_ERR_RANGE;
+      }
+      if (host[1] != 0) {
+        set_error("eyoc_maps_build: %d duplicate coordinate rows (a sparse tensor needs unique coordinates)", host[1]);
+        delete m;
+        return EYOC_ERR_DUPLICATE;
+      }
+      continue;  // level-0 values already are the row indices
+    }
+    const int nb = cdiv(n_src, SCAN_TILE);
+    hipLaunchKernelGGL(k_scan_partials, dim3(nb), dim3(SCAN_BLOCK), 0, st, flag, n_src, partial);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, st, partial, nb, counters + 2 + l);
+    FAIL_HIP(hipMemcpyAsync(host, counters + 2 + l, sizeof(int), hipMemcpyDeviceToHost, st));
+    FAIL_HIP(hipStreamSynchronize(st));
+    m->rows[l] = host[0];
+    m->coords[l] = cv.take<int32_t>((size_t)m->rows[l] * 4);
+    hipLaunchKernelGGL(k_compact, dim3(nb), dim3(SCAN_BLOCK), 0, st, flag, partial, slot, src, n_src, ts2,
+                       m->coords[l], t.vals);
+  }
+  // ---- rulebooks
+  for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
+    const int nl = m->rows[l];
+    const int ts = 1 << l;
+    m->nbr_s1[l] = cv.take<int32_t>((size_t)27 * nl);
+    hipLaunchKernelGGL(k_neighbours, dim3(cdiv(nl, 256)), dim3(256), 0, st, m->coords[l], nl, m->table[l], ts, 1,
+                       m->nbr_s1[l]);
+    if (l + 1 < EYOC_MAX_LEVELS) {
+      const int nc = m->rows[l + 1];
+      // strided conv ts -> 2ts: for coarse row v the fine row at c_v + off * ts
+      m->nbr_down[l] = cv.take<int32_t>((size_t)27 * nc);
+      hipLaunchKernelGGL(k_neighbours, dim3(cdiv(nc, 256)), dim3(256), 0, st, m->coords[l + 1], nc, m->table[l], ts,
+                         1, m->nbr_down[l]);
+      // transposed conv 2ts -> ts: for fine row u the coarse row at c_u - off * ts
+      m->nbr_up[l] = cv.take<int32_t>((size_t)27 * nl);
+      hipLaunchKernelGGL(k_neighbours, dim3(cdiv(nl, 256)), dim3(256), 0, st, m->coords[l], nl, m->table[l + 1], ts,
+                         -1, m->nbr_up[l]);
+    }
+  }
+  FAIL_HIP(hipGetLastError());
+#undef FAIL_HIP
+  if (!cv.ok()) {
+    set_error("eyoc_maps_build: internal workspace accounting error (%zu > %zu)", cv.off, cv.cap);
+    delete m;
+    return EYOC_ERR_WORKSPACE;
+  }
+  *out = m;
+  return EYOC_OK;
+}
+
+int eyoc_maps_free(eyoc_maps* maps) {
+  delete maps;
+  return EYOC_OK;
+}
+
+int eyoc_maps_rows(const eyoc_maps* maps, int level) {
+  if (!maps || level < 0 || level >= maps->n_levels) return -1;
+  return maps->rows[level];
+}
+
+const int32_t* eyoc_maps_coords(const eyoc_maps* maps, int level) {
+  if (!maps || level < 0 || level >= maps->n_levels) return nullptr;
+  return maps->coords[level];
+}
+
+const int32_t* eyoc_maps_table(const eyoc_maps* maps, int kind, int level) {
+  if (!maps || level < 0 || level >= maps->n_levels) return nullptr;
+  switch (kind) {
+    case EYOC_MAP_S1: return maps->nbr_s1[level];
+    case EYOC_MAP_DOWN: return level + 1 < maps->n_levels ? maps->nbr_down[level] : nullptr;
+    case EYOC_MAP_UP: return level + 1 < maps->n_levels ? maps->nbr_up[level] : nullptr;
+    default: return nullptr;
+  }
+}
+
+int eyoc_maps_copy_coords(const eyoc_maps* maps, int level, int32_t* out_dev, void* stream) {
+  const int32_t* src = eyoc_maps_coords(maps, level);
+  EYOC_REQUIRE(src && out_dev, EYOC_ERR_INVALID, "eyoc_maps_copy_coords: bad level %d or NULL output", level);
+  EYOC_CHECK_HIP(hipMemcpyAsync(out_dev, src, (size_t)maps->rows[level] * 16, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return EYOC_OK;
+}
+
+int eyoc_maps_copy_table(const eyoc_maps* maps, int kind, int level, int32_t* out_dev, void* stream) {
+  const int32_t* src = eyoc_maps_table(maps, kind, level);
+  EYOC_REQUIRE(src && out_dev, EYOC_ERR_INVALID, "eyoc_maps_copy_table: bad kind %d / level %d or NULL output", kind, level);
+  const int n_out = kind == EYOC_MAP_DOWN ? maps->rows[level + 1] : maps->rows[level];
+  EYOC_CHECK_HIP(hipMemcpyAsync(out_dev, src, (size_t)n_out * 27 * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return EYOC_OK;
+}
+
+int eyoc_maps_info(eyoc_ctx* ctx, const eyoc_maps* m, int conv1_ks, void* stream, eyoc_maps_info_t* info) {
+  EYOC_REQUIRE(ctx && m && info, EYOC_ERR_INVALID, "eyoc_maps_info: NULL argument");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = ctx->ensure_scratch(64 * sizeof(unsigned long long));
+  if (rc) return rc;
+  unsigned long long* cnt = (unsigned long long*)ctx->scratch;
+  EYOC_CHECK_HIP(hipMemsetAsync(cnt, 0, 64 * sizeof(unsigned long long), st));
+  memset(info, 0, sizeof(*info));
+  info->n_levels = m->n_levels;
+  auto count = [&](const int32_t* t, long long n, int slot) {
+    if (!t || n == 0) return;
+    int blocks = (int)((n + 1023) / 1024);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_count_valid, dim3(blocks), dim3(256), 0, st, t, n, cnt + slot);
+  };
+  for (int l = 0; l < m->n_levels; ++l) {
+    info->rows[l] = m->rows[l];
+    count(m->nbr_s1[l], 27ll * m->rows[l], l);
+    if (l + 1 < m->n_levels) {
+      count(m->nbr_down[l], 27ll * m->rows[l + 1], 8 + l);
+      count(m->nbr_up[l], 27ll * m->rows[l], 16 + l);
+    }
+  }
+  if (conv1_ks > 0)
+    hipLaunchKernelGGL(k_count_region, dim3(cdiv(m->rows[0], 256)), dim3(256), 0, st, m->coords[0], m->rows[0],
+                       m->table[0], conv1_ks, cnt + 24);
+  unsigned long long* host = (unsigned long long*)ctx->pinned;
+  EYOC_CHECK_HIP(hipMemcpyAsync(host, cnt, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  EYOC_CHECK_HIP(hipStreamSynchronize(st));
+  for (int l = 0; l < m->n_levels; ++l) {
+    info->pairs_s1[l] = (int64_t)host[l];
+    info->pairs_down[l] = (int64_t)host[8 + l];
+    info->pairs_up[l] = (int64_t)host[16 + l];
+  }
+  info->pairs_conv1 = (int64_t)host[24];
+  return EYOC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,310 @@
+// ResUNet2 family (ResUNetBN2C in production): weight packing and the forward schedule.
+// Mirrors ResUNet2.__init__/forward (model/resunet.py:18-193) and BasicBlockBase.forward
+// (model/residual_block.py:37-53) with every batch norm folded into the convolution before it
+// (eval mode, model/common.py:4-6) and every ReLU / residual add / concat fused into a conv epilogue.
+#include <cmath>
+
+#include "spconv.h"
+
+using namespace eyoc;
+
+namespace {
+
+enum MapSel { M_CONV1, M_S1, M_DOWN, M_UP, M_IDENT };
+
+struct LayerPlan {
+  std::string name;      // conv name in the state_dict ("block2.conv1")
+  std::string norm;      // norm folded into it ("" = none)
+  int K, cin, cout;
+  MapSel map;
+  int level;             // table level (fine level for DOWN/UP); rows of the OUTPUT for S1
+  int out_level;         // level whose row count is n_out
+  int in_buf, in_col, out_buf, out_col, res_buf;  // buffer ids (-1 none)
+  int relu, l2norm, has_bias;
+  size_t w_off = 0, b_off = 0;  // float offsets into the blob
+};
+
+// activation buffers
+enum Buf { B_IN = 0, B_X1, B_T1, B_CAT1, B_X2, B_T2, B_CAT2, B_X4, B_T4, B_CAT4, B_X8, B_T8, B_Y8, B_D4, B_DT4, B_D2,
+           B_DT2, B_D1, B_DT1, B_H, B_OUT, B_COUNT };
+
+struct BufPlan { int level, width; };
+
+size_t pad64(size_t v) { return (v + 63) / 64 * 64; }
+
+}  // namespace
+
+struct eyoc_model {
+  eyoc_model_desc desc;
+  std::vector<LayerPlan> layers;
+  BufPlan bufs[B_COUNT];
+  float* blob = nullptr;
+  size_t blob_floats = 0;
+  int timing = 0;
+  std::vector<hipEvent_t> events;
+  int events_valid = 0;
+};
+
+namespace {
+
+void build_plan(const eyoc_model_desc& d, std::vector<LayerPlan>& L, BufPlan* bufs) {
+  const int* C = d.channels;
+  const int* T = d.tr_channels;
+  const int K1 = d.conv1_kernel_size * d.conv1_kernel_size * d.conv1_kernel_size;
+  bufs[B_IN] = {0, d.in_channels};
+  bufs[B_X1] = {0, C[1]}; bufs[B_T1] = {0, C[1]}; bufs[B_CAT1] = {0, T[2] + C[1]};
+  bufs[B_X2] = {1, C[2]}; bufs[B_T2] = {1, C[2]}; bufs[B_CAT2] = {1, T[3] + C[2]};
+  bufs[B_X4] = {2, C[3]}; bufs[B_T4] = {2, C[3]}; bufs[B_CAT4] = {2, T[4] + C[3]};
+  bufs[B_X8] = {3, C[4]}; bufs[B_T8] = {3, C[4]}; bufs[B_Y8] = {3, C[4]};
+  bufs[B_D4] = {2, T[4]}; bufs[B_DT4] = {2, T[4]};
+  bufs[B_D2] = {1, T[3]}; bufs[B_DT2] = {1, T[3]};
+  bufs[B_D1] = {0, T[2]}; bufs[B_DT1] = {0, T[2]};
+  bufs[B_H] = {0, T[1]};
+  bufs[B_OUT] = {0, d.out_channels};
+
+  auto conv = [&](const char* name, const char* norm, int K, int cin, int cout, MapSel map, int level, int out_level,
+                  int in_buf, int in_col, int out_buf, int out_col, int res_buf, int relu) {
+    LayerPlan p;
+    p.name = name; p.norm = norm; p.K = K; p.cin = cin; p.cout = cout; p.map = map; p.level = level;
+    p.out_level = out_level; p.in_buf = in_buf; p.in_col = in_col; p.out_buf = out_buf; p.out_col = out_col;
+    p.res_buf = res_buf; p.relu = relu; p.l2norm = 0; p.has_bias = 0;
+    L.push_back(p);
+  };
+  auto block = [&](const std::string& name, int c, int level, int x_buf, int t_buf, int out_buf, int out_col) {
+    conv((name + ".conv1").c_str(), (name + ".norm1").c_str(), 27, c, c, M_S1, level, level, x_buf, 0, t_buf, 0, -1, 1);
+    conv((name + ".conv2").c_str(), (name + ".norm2").c_str(), 27, c, c, M_S1, level, level, t_buf, 0, out_buf, out_col,
+         x_buf, 1);
+  };
+  // encoder (model/resunet.py:143-161)
+  conv("conv1", "norm1", K1, d.in_channels, C[1], M_CONV1, 0, 0, B_IN, 0, B_X1, 0, -1, 0);
+  block("block1", C[1], 0, B_X1, B_T1, B_CAT1, T[2]);
+  conv("conv2", "norm2", 27, C[1], C[2], M_DOWN, 0, 1, B_CAT1, T[2], B_X2, 0, -1, 0);
+  block("block2", C[2], 1, B_X2, B_T2, B_CAT2, T[3]);
+  conv("conv3", "norm3", 27, C[2], C[3], M_DOWN, 1, 2, B_CAT2, T[3], B_X4, 0, -1, 0);
+  block("block3", C[3], 2, B_X4, B_T4, B_CAT4, T[4]);
+  conv("conv4", "norm4", 27, C[3], C[4], M_DOWN, 2, 3, B_CAT4, T[4], B_X8, 0, -1, 0);
+  block("block4", C[4], 3, B_X8, B_T8, B_Y8, 0);
+  // decoder (model/resunet.py:163-186); ME.cat order is [decoder | skip]
+  conv("conv4_tr", "norm4_tr", 27, C[4], T[4], M_UP, 2, 2, B_Y8, 0, B_D4, 0, -1, 0);
+  block("block4_tr", T[4], 2, B_D4, B_DT4, B_CAT4, 0);
+  conv("conv3_tr", "norm3_tr", 27, C[3] + T[4], T[3], M_UP, 1, 1, B_CAT4, 0, B_D2, 0, -1, 0);
+  block("block3_tr", T[3], 1, B_D2, B_DT2, B_CAT2, 0);
+  conv("conv2_tr", "norm2_tr", 27, C[2] + T[3], T[2], M_UP, 0, 0, B_CAT2, 0, B_D1, 0, -1, 0);
+  block("block2_tr", T[2], 0, B_D1, B_DT1, B_CAT1, 0);
+  conv("conv1_tr", "", 1, C[1] + T[2], T[1], M_IDENT, 0, 0, B_CAT1, 0, B_H, 0, -1, 1);
+  conv("final", "", 1, T[1], d.out_channels, M_IDENT, 0, 0, B_H, 0, B_OUT, 0, -1, 0);
+  L.back().has_bias = 1;
+  L.back().l2norm = d.normalize_feature ? 1 : 0;
+  size_t off = 0;
+  for (auto& p : L) {
+    p.w_off = off;
+    off += pad64((size_t)p.K * p.cin * p.cout);
+    p.b_off = off;
+    off += pad64((size_t)p.cout);
+  }
+}
+
+size_t plan_blob_floats(const std::vector<LayerPlan>& L) { return L.empty() ? 0 : L.back().b_off + pad64(L.back().cout); }
+
+const eyoc_layer_params* find_layer(const eyoc_layer_params* layers, int n, const std::string& name) {
+  for (int i = 0; i < n; ++i)
+    if (layers[i].name && name == layers[i].name) return &layers[i];
+  return nullptr;
+}
+
+int check_desc(const eyoc_model_desc* d) {
+  EYOC_REQUIRE(d, EYOC_ERR_INVALID, "model: NULL desc");
+  EYOC_REQUIRE(d->in_channels >= 1 && d->in_channels <= 64, EYOC_ERR_INVALID, "model: in_channels %d", d->in_channels);
+  EYOC_REQUIRE(d->out_channels == 32 || d->out_channels == 64 || d->out_channels == 128, EYOC_ERR_INVALID,
+               "model: out_channels %d not in {32,64,128}", d->out_channels);
+  EYOC_REQUIRE(d->conv1_kernel_size == 1 || d->conv1_kernel_size == 3 || d->conv1_kernel_size == 5 ||
+               d->conv1_kernel_size == 7, EYOC_ERR_INVALID, "model: conv1_kernel_size %d", d->conv1_kernel_size);
+  for (int i = 1; i <= 4; ++i) {
+    const int c = d->channels[i], t = d->tr_channels[i];
+    EYOC_REQUIRE(c == 32 || c == 64 || c == 128 || c == 256, EYOC_ERR_INVALID, "model: CHANNELS[%d] = %d", i, c);
+    EYOC_REQUIRE(t == 32 || t == 64 || t == 128 || t == 256, EYOC_ERR_INVALID, "model: TR_CHANNELS[%d] = %d", i, t);
+  }
+  EYOC_REQUIRE(d->channels[1] <= 128, EYOC_ERR_INVALID, "model: CHANNELS[1] = %d > 128", d->channels[1]);
+  return EYOC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t eyoc_model_blob_floats(const eyoc_model_desc* desc) {
+  if (check_desc(desc) != EYOC_OK) return 0;
+  std::vector<LayerPlan> L;
+  BufPlan bufs[B_COUNT];
+  build_plan(*desc, L, bufs);
+  return plan_blob_floats(L);
+}
+
+int eyoc_model_create(eyoc_ctx* ctx, const eyoc_model_desc* desc, const eyoc_layer_params* layers, int n_layers,
+                      float* blob_dev, size_t blob_floats, eyoc_model** out) {
+  EYOC_REQUIRE(ctx && out && blob_dev, EYOC_ERR_INVALID, "eyoc_model_create: NULL argument");
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  eyoc_model* m = new eyoc_model();
+  m->desc = *desc;
+  build_plan(*desc, m->layers, m->bufs);
+  m->blob = blob_dev;
+  m->blob_floats = plan_blob_floats(m->layers);
+  if (blob_floats < m->blob_floats || ((uintptr_t)blob_dev & 255) != 0) {
+    set_error("eyoc_model_create: blob of %zu floats (256-byte aligned) required, got %zu at %p", m->blob_floats,
+              blob_floats, (void*)blob_dev);
+    delete m;
+    return EYOC_ERR_INVALID;
+  }
+  if (layers) {
+    std::vector<float> host(m->blob_floats, 0.0f);
+    for (auto& p : m->layers) {
+      const eyoc_layer_params* cv = find_layer(layers, n_layers, p.name);
+      if (!cv || !cv->kernel || cv->K != p.K || cv->cin != p.cin || cv->cout != p.cout) {
+        set_error("eyoc_model_create: layer '%s' missing or shape mismatch (expected K=%d cin=%d cout=%d, got %d %d %d)",
+                  p.name.c_str(), p.K, p.cin, p.cout, cv ? cv->K : -1, cv ? cv->cin : -1, cv ? cv->cout : -1);
+        delete m;
+        return EYOC_ERR_INVALID;
+      }
+      std::vector<float> scale(p.cout, 1.0f), shift(p.cout, 0.0f);
+      if (!p.norm.empty()) {
+        const eyoc_layer_params* bn = find_layer(layers, n_layers, p.norm);
+        if (!bn || !bn->bn_weight || !bn->bn_bias || !bn->bn_mean || !bn->bn_var || bn->cout != p.cout) {
+          set_error("eyoc_model_create: norm '%s' missing or wrong width", p.norm.c_str());
+          delete m;
+          return EYOC_ERR_INVALID;
+        }
+        for (int c = 0; c < p.cout; ++c) {
+          const float s = bn->bn_weight[c] / std::sqrt(bn->bn_var[c] + desc->bn_eps);
+          scale[c] = s;
+          shift[c] = bn->bn_bias[c] - bn->bn_mean[c] * s;
+        }
+      }
+      if (p.has_bias && cv->bias)
+        for (int c = 0; c < p.cout; ++c) shift[c] += cv->bias[c];
+      float* w = host.data() + p.w_off;
+      if (p.map == M_CONV1) {  // plain [K][cin][cout] with the scale folded in
+        for (size_t i = 0; i < (size_t)p.K * p.cin * p.cout; ++i) w[i] = cv->kernel[i] * scale[i % p.cout];
+      } else {
+        rc = eyoc_spconv_pack_weights(cv->kernel, scale.data(), p.K, p.cin, p.cout, w);
+        if (rc) { delete m; return rc; }
+      }
+      memcpy(host.data() + p.b_off, shift.data(), p.cout * sizeof(float));
+    }
+    hipError_t e = hipMemcpy(blob_dev, host.data(), m->blob_floats * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      set_error("eyoc_model_create: weight upload failed: %s", hipGetErrorString(e));
+      delete m;
+      return EYOC_ERR_HIP;
+    }
+  }
+  *out = m;
+  return EYOC_OK;
+}
+
+int eyoc_model_destroy(eyoc_model* m) {
+  if (!m) return EYOC_OK;
+  for (auto e : m->events) (void)hipEventDestroy(e);
+  delete m;
+  return EYOC_OK;
+}
+
+size_t eyoc_model_workspace_bytes(const eyoc_model* m, const eyoc_maps* maps) {
+  if (!m || !maps) return 0;
+  size_t b = 0;
+  for (int i = B_X1; i < B_OUT; ++i) b += align_up((size_t)maps->rows[m->bufs[i].level] * m->bufs[i].width * sizeof(float));
+  return b + 256;
+}
+
+int eyoc_model_num_layers(const eyoc_model* m) { return m ? (int)m->layers.size() : 0; }
+
+int eyoc_model_set_timing(eyoc_model* m, int on) {
+  EYOC_REQUIRE(m, EYOC_ERR_INVALID, "eyoc_model_set_timing: NULL model");
+  m->timing = on ? 1 : 0;
+  m->events_valid = 0;
+  if (on && m->events.empty()) {
+    m->events.resize(m->layers.size() + 1);
+    for (auto& e : m->events) EYOC_CHECK_HIP(hipEventCreate(&e));
+  }
+  return EYOC_OK;
+}
+
+int eyoc_model_layer_ms(eyoc_model* m, float* ms) {
+  EYOC_REQUIRE(m && ms, EYOC_ERR_INVALID, "eyoc_model_layer_ms: NULL argument");
+  EYOC_REQUIRE(m->timing && m->events_valid, EYOC_ERR_INVALID, "eyoc_model_layer_ms: no timed forward recorded");
+  EYOC_CHECK_HIP(hipEventSynchronize(m->events.back()));
+  for (size_t i = 0; i < m->layers.size(); ++i) EYOC_CHECK_HIP(hipEventElapsedTime(&ms[i], m->events[i], m->events[i + 1]));
+  return EYOC_OK;
+}
+
+int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* maps, const float* feats_dev, float* out_dev,
+                       void* ws, size_t ws_bytes, void* stream) {
+  EYOC_REQUIRE(ctx && mc && maps && feats_dev && out_dev && ws, EYOC_ERR_INVALID, "eyoc_model_forward: NULL argument");
+  EYOC_REQUIRE(ws_bytes >= eyoc_model_workspace_bytes(mc, maps), EYOC_ERR_WORKSPACE,
+               "eyoc_model_forward: workspace %zu < required %zu bytes", ws_bytes, eyoc_model_workspace_bytes(mc, maps));
+  EYOC_REQUIRE(((uintptr_t)ws & 255) == 0, EYOC_ERR_INVALID, "eyoc_model_forward: workspace must be 256-byte aligned");
+  eyoc_model* m = const_cast<eyoc_model*>(mc);
+  hipStream_t st = (hipStream_t)stream;
+  float* buf[B_COUNT];
+  Carver cv(ws, ws_bytes);
+  buf[B_IN] = const_cast<float*>(feats_dev);
+  buf[B_OUT] = out_dev;
+  for (int i = B_X1; i < B_OUT; ++i) buf[i] = cv.take<float>((size_t)maps->rows[m->bufs[i].level] * m->bufs[i].width);
+  if (m->timing) EYOC_CHECK_HIP(hipEventRecord(m->events[0], st));
+  for (size_t li = 0; li < m->layers.size(); ++li) {
+    const LayerPlan& p = m->layers[li];
+    const int n_out = maps->rows[p.out_level];
+    int rc;
+    if (p.map == M_CONV1) {
+      Conv1Args a;
+      a.coords = maps->coords[0]; a.n = n_out; a.table = maps->table[0]; a.ks = m->desc.conv1_kernel_size;
+      a.in = buf[p.in_buf]; a.cin = p.cin; a.w = m->blob + p.w_off; a.bias = m->blob + p.b_off; a.cout = p.cout;
+      a.out = buf[p.out_buf] + p.out_col; a.ld_out = m->bufs[p.out_buf].width;
+      rc = launch_conv1(a, st);
+    } else {
+      SpconvArgs a;
+      a.nbr = p.map == M_S1 ? maps->nbr_s1[p.level] : p.map == M_DOWN ? maps->nbr_down[p.level]
+              : p.map == M_UP ? maps->nbr_up[p.level] : nullptr;
+      a.K = p.K; a.n_out = n_out;
+      a.in = buf[p.in_buf] + p.in_col; a.ld_in = m->bufs[p.in_buf].width; a.cin = p.cin;
+      a.w = m->blob + p.w_off; a.cout = p.cout; a.bias = m->blob + p.b_off;
+      a.res = p.res_buf >= 0 ? buf[p.res_buf] : nullptr; a.ld_res = p.res_buf >= 0 ? m->bufs[p.res_buf].width : 0;
+      a.relu = p.relu; a.l2norm = p.l2norm;
+      a.out = buf[p.out_buf] + p.out_col; a.ld_out = m->bufs[p.out_buf].width;
+      rc = launch_spconv(a, st);
+    }
+    if (rc) return rc;
+    if (m->timing) EYOC_CHECK_HIP(hipEventRecord(m->events[li + 1], st));
+  }
+  if (m->timing) m->events_valid = 1;
+  return EYOC_OK;
+}
+
+int eyoc_model_layer_work(eyoc_ctx* ctx, const eyoc_model* m, const eyoc_maps* maps, void* stream, const char** names,
+                          int64_t* pairs, double* flops, double* gather_bytes, double* compulsory_bytes) {
+  EYOC_REQUIRE(ctx && m && maps, EYOC_ERR_INVALID, "eyoc_model_layer_work: NULL argument");
+  eyoc_maps_info_t info;
+  int rc = eyoc_maps_info(ctx, maps, m->desc.conv1_kernel_size, stream, &info);
+  if (rc) return rc;
+  for (size_t li = 0; li < m->layers.size(); ++li) {
+    const LayerPlan& p = m->layers[li];
+    const double n_out = maps->rows[p.out_level];
+    double n_in = n_out, pr = 0;
+    switch (p.map) {
+      case M_CONV1: pr = (double)info.pairs_conv1; break;
+      case M_S1: pr = (double)info.pairs_s1[p.level]; break;
+      case M_DOWN: pr = (double)info.pairs_down[p.level]; n_in = maps->rows[p.level]; break;
+      case M_UP: pr = (double)info.pairs_up[p.level]; n_in = maps->rows[p.level + 1]; break;
+      case M_IDENT: pr = n_out; break;
+    }
+    const double wbytes = 4.0 * p.K * p.cin * p.cout;
+    if (names) names[li] = p.name.c_str();
+    if (pairs) pairs[li] = (int64_t)pr;
+    if (flops) flops[li] = 2.0 * pr * p.cin * p.cout;
+    if (gather_bytes) gather_bytes[li] = pr * (4.0 * p.cin + 8.0) + 4.0 * n_out * p.cout + wbytes;
+    if (compulsory_bytes) compulsory_bytes[li] = 4.0 * (n_in * p.cin + n_out * p.cout) + 8.0 * pr + wbytes;
+  }
+  return EYOC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,45 @@
+// Internal interface of the sparse-convolution kernels (spconv.hip) used by model.hip.
+#pragma once
+#include "common.h"
+
+namespace eyoc {
+
+constexpr int SPCONV_CC = 32;  // input channels staged per weight tile
+
+inline int spconv_ct(int cout) { return cout >= 128 ? 128 : cout; }  // output channels per block
+
+struct SpconvArgs {
+  const int32_t* nbr;   // [K][n_out] or NULL (identity, K == 1)
+  int K, n_out;
+  const float* in;      // rows of ld_in floats; the layer reads columns [0, cin)
+  int ld_in, cin;
+  const float* w;       // packed weights (eyoc_spconv_pack_weights)
+  int cout;
+  const float* bias;    // [cout] or NULL
+  const float* res;     // residual rows (ld_res floats) or NULL
+  int ld_res;
+  int relu;
+  int l2norm;           // divide every output row by its 2-norm (needs cout <= 128); no epsilon
+  float* out;           // rows of ld_out floats; the layer writes columns [0, cout)
+  int ld_out;
+};
+
+int launch_spconv(const SpconvArgs& a, hipStream_t st);
+
+// first convolution: K = ks^3 offsets probed straight from the level-0 hash table (C_in is tiny)
+struct Conv1Args {
+  const int32_t* coords;  // [n,4]
+  int n;
+  HashTable table;
+  int ks;
+  const float* in;        // [n, cin]
+  int cin;
+  const float* w;         // [K][cin][cout] with the BN scale folded in
+  const float* bias;      // [cout]
+  int cout;               // 32 <= cout <= 128, multiple of 32
+  float* out;             // rows of ld_out floats
+  int ld_out;
+};
+int launch_conv1(const Conv1Args& a, hipStream_t st);
+
+}  // namespace eyoc

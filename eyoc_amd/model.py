@@ -1,0 +1,289 @@
+"""ResUNet2 family and ``load_model`` with the reference's constructor / ``__call__`` surface.
+
+Mirrors ``model/resunet.py:10-251`` (``ResUNet2`` and its BN channel-table subclasses),
+``model/residual_block.py:9-61`` (parameter names of ``BasicBlockBN``), ``model/common.py:4-6`` and the
+name registry of ``model/__init__.py:8-30``.  Parameters carry MinkowskiEngine's ``state_dict`` names
+(``conv1.kernel [K,Cin,Cout]``, ``norm1.bn.weight``, ``block1.conv1.kernel``, ``final.bias [1,Cout]`` ...)
+so ``model.load_state_dict(torch.load(...)['state_dict'])`` works as in ``scripts/test_kitti.py:90-91``.
+
+Only the eval-mode forward exists (the path EYOC's test / labelling code uses); it runs entirely in
+``libeyoc_hip.so``: the parameters are folded (BN into conv) and packed once per weight version into a
+single device blob, which is also what ``eyoc_amd.dist`` broadcasts between ranks.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .sparse_tensor import SparseTensor
+
+
+class _Conv(nn.Module):
+    """Parameter holder named like ``ME.MinkowskiConvolution``: ``kernel`` (+ ``bias [1,C]``)."""
+
+    def __init__(self, K, cin, cout, bias=False):
+        super().__init__()
+        shape = (cin, cout) if K == 1 else (K, cin, cout)
+        self.kernel = nn.Parameter(torch.randn(shape) * float(np.sqrt(2.0 / (K * cin))))
+        self.bias = nn.Parameter(torch.zeros(1, cout)) if bias else None
+        self.K, self.cin, self.cout = K, cin, cout
+
+
+class _Norm(nn.Module):
+    """``ME.MinkowskiBatchNorm`` keeps its ``nn.BatchNorm1d`` under ``.bn`` (model/common.py:6)."""
+
+    def __init__(self, c, momentum):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(c, momentum=momentum)
+
+
+class _Block(nn.Module):
+    """``BasicBlockBN`` (model/residual_block.py:9-35): conv1, norm1, conv2, norm2."""
+
+    def __init__(self, c, momentum):
+        super().__init__()
+        self.conv1 = _Conv(27, c, c)
+        self.norm1 = _Norm(c, momentum)
+        self.conv2 = _Conv(27, c, c)
+        self.norm2 = _Norm(c, momentum)
+
+
+class ResUNet2(nn.Module):
+    NORM_TYPE = None
+    BLOCK_NORM_TYPE = 'BN'
+    CHANNELS = [None, 32, 64, 128, 256]
+    TR_CHANNELS = [None, 32, 64, 64, 128]
+
+    def __init__(self, in_channels=3, out_channels=32, bn_momentum=0.1, normalize_feature=None,
+                 conv1_kernel_size=None, D=3):
+        super().__init__()
+        if D != 3:
+            raise ValueError("only D=3 is supported")
+        if self.NORM_TYPE != 'BN' or self.BLOCK_NORM_TYPE != 'BN':
+            # ResUNet2 itself has NORM_TYPE None (get_norm would raise in the reference too);
+            # the IN variants need instance norm, which is outside the hot path
+            raise NotImplementedError(f"{type(self).__name__}: only batch-norm variants are implemented")
+        if conv1_kernel_size is None:
+            raise ValueError("conv1_kernel_size is required (config.py:84 default is 5)")
+        Cn, T = self.CHANNELS, self.TR_CHANNELS
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.conv1_kernel_size = conv1_kernel_size
+        self.normalize_feature = normalize_feature
+        m = bn_momentum
+        self.conv1 = _Conv(conv1_kernel_size ** 3, in_channels, Cn[1]); self.norm1 = _Norm(Cn[1], m)
+        self.block1 = _Block(Cn[1], m)
+        self.conv2 = _Conv(27, Cn[1], Cn[2]); self.norm2 = _Norm(Cn[2], m); self.block2 = _Block(Cn[2], m)
+        self.conv3 = _Conv(27, Cn[2], Cn[3]); self.norm3 = _Norm(Cn[3], m); self.block3 = _Block(Cn[3], m)
+        self.conv4 = _Conv(27, Cn[3], Cn[4]); self.norm4 = _Norm(Cn[4], m); self.block4 = _Block(Cn[4], m)
+        self.conv4_tr = _Conv(27, Cn[4], T[4]); self.norm4_tr = _Norm(T[4], m); self.block4_tr = _Block(T[4], m)
+        self.conv3_tr = _Conv(27, Cn[3] + T[4], T[3]); self.norm3_tr = _Norm(T[3], m); self.block3_tr = _Block(T[3], m)
+        self.conv2_tr = _Conv(27, Cn[2] + T[3], T[2]); self.norm2_tr = _Norm(T[2], m); self.block2_tr = _Block(T[2], m)
+        self.conv1_tr = _Conv(1, Cn[1] + T[2], T[1])
+        self.final = _Conv(1, T[1], out_channels, bias=True)
+        self._handle = None      # eyoc_model*
+        self._blob = None        # packed weights (device tensor, float32)
+        self._packed_device = None
+        self._timing = False
+
+    # ------------------------------------------------------------------ packing
+    def _desc(self):
+        d = _lib.ModelDesc()
+        d.in_channels, d.out_channels = self.in_channels, self.out_channels
+        d.conv1_kernel_size = self.conv1_kernel_size
+        d.normalize_feature = 1 if self.normalize_feature else 0
+        for i in range(1, 5):
+            d.channels[i], d.tr_channels[i] = self.CHANNELS[i], self.TR_CHANNELS[i]
+        d.bn_eps = 1e-5
+        return d
+
+    def _invalidate(self):
+        if self._handle is not None:
+            _lib.load().eyoc_model_destroy(self._handle)
+        self._handle, self._blob, self._packed_device = None, None, None
+
+    def load_state_dict(self, state_dict, strict=True):
+        out = super().load_state_dict(state_dict, strict=strict)
+        self._invalidate()
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._invalidate()
+        return out
+
+    def blob_floats(self) -> int:
+        d = self._desc()
+        return int(_lib.load().eyoc_model_blob_floats(C.byref(d)))
+
+    def _layer_params(self):
+        """Host-side (numpy) view of every parameter under its ME name; keeps arrays alive."""
+        keep, items = [], []
+        fptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+
+        def arr(t):
+            a = np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
+            keep.append(a)
+            return a
+
+        for name, mod in self.named_modules():
+            if isinstance(mod, _Conv):
+                lp = _lib.LayerParams()
+                lp.name = name.encode()
+                lp.kernel = fptr(arr(mod.kernel))
+                lp.K, lp.cin, lp.cout = mod.K, mod.cin, mod.cout
+                if mod.bias is not None:
+                    lp.bias = fptr(arr(mod.bias.reshape(-1)))
+                items.append(lp)
+            elif isinstance(mod, _Norm):
+                lp = _lib.LayerParams()
+                lp.name = name.encode()
+                lp.cout = mod.bn.num_features
+                lp.bn_weight, lp.bn_bias = fptr(arr(mod.bn.weight)), fptr(arr(mod.bn.bias))
+                lp.bn_mean, lp.bn_var = fptr(arr(mod.bn.running_mean)), fptr(arr(mod.bn.running_var))
+                items.append(lp)
+        return (_lib.LayerParams * len(items))(*items), len(items), keep
+
+    def pack(self, device=None, blob: torch.Tensor | None = None, from_blob=False):
+        """(Re)create the device-side model.  ``from_blob=True`` adopts an already packed blob (the
+        receiving side of the weight broadcast) instead of packing this module's parameters."""
+        lib = _lib.load()
+        device = torch.device(device) if device is not None else self.final.kernel.device
+        if device.type != "cuda":
+            raise _lib.EyocError("the model runs on the GPU only: call model.to('cuda') first")
+        self._invalidate()
+        n = self.blob_floats()
+        if blob is None:
+            blob = torch.zeros(n + 64, dtype=torch.float32, device=device)
+            off = ((-blob.data_ptr()) % 256) // 4
+            blob = blob[off:off + n]
+        d = self._desc()
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            if from_blob:
+                rc = lib.eyoc_model_create(_lib.ctx(device.index), C.byref(d), None, 0, _lib.ptr(blob), blob.numel(),
+                                           C.byref(h))
+            else:
+                layers, nl, keep = self._layer_params()
+                rc = lib.eyoc_model_create(_lib.ctx(device.index), C.byref(d), layers, nl, _lib.ptr(blob),
+                                           blob.numel(), C.byref(h))
+        _lib.check(rc, "eyoc_model_create")
+        self._handle, self._blob, self._packed_device = h, blob, device
+        if self._timing:
+            _lib.check(lib.eyoc_model_set_timing(h, 1), "eyoc_model_set_timing")
+        return blob
+
+    @property
+    def weight_blob(self):
+        if self._handle is None:
+            self.pack()
+        return self._blob
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: SparseTensor) -> SparseTensor:
+        if self.training:
+            raise NotImplementedError("training-mode forward (batch statistics, autograd) is outside the "
+                                      "registration hot path; call model.eval()")
+        if not isinstance(x, SparseTensor):
+            raise TypeError("expected an eyoc_amd.SparseTensor")
+        if x.F.shape[1] != self.in_channels:
+            raise ValueError(f"features have {x.F.shape[1]} channels, model expects {self.in_channels}")
+        dev = x.device
+        if self._handle is None or self._packed_device != dev:
+            self.pack(dev)
+        lib = _lib.load()
+        cm = x.coordinate_manager
+        maps = cm.maps()
+        out = torch.empty((len(x), self.out_channels), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            ws = _lib.workspace(lib.eyoc_model_workspace_bytes(self._handle, maps), dev)
+            _lib.check(lib.eyoc_model_forward(_lib.ctx(dev.index), self._handle, maps, _lib.ptr(x.F), _lib.ptr(out),
+                                              _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "eyoc_model_forward")
+        return SparseTensor(out, coordinate_map_key=x.coordinate_map_key, coordinate_manager=cm)
+
+    # ------------------------------------------------------------------ measurement hooks
+    def set_timing(self, on: bool):
+        self._timing = bool(on)
+        if self._handle is not None:
+            _lib.check(_lib.load().eyoc_model_set_timing(self._handle, 1 if on else 0), "eyoc_model_set_timing")
+
+    def layer_ms(self):
+        lib = _lib.load()
+        n = lib.eyoc_model_num_layers(self._handle)
+        ms = (C.c_float * n)()
+        _lib.check(lib.eyoc_model_layer_ms(self._handle, ms), "eyoc_model_layer_ms")
+        return list(ms)
+
+    def layer_work(self, x: SparseTensor):
+        """Per-layer algorithmic work for the geometry of ``x`` (SURVEY.md §8d formulas)."""
+        lib = _lib.load()
+        if self._handle is None:
+            self.pack(x.device)
+        n = lib.eyoc_model_num_layers(self._handle)
+        names = (C.c_char_p * n)()
+        pairs = (C.c_int64 * n)()
+        fl, gb, cb = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+        with torch.cuda.device(x.device):
+            _lib.check(lib.eyoc_model_layer_work(_lib.ctx(x.device.index), self._handle, x.coordinate_manager.maps(),
+                                                 _lib.stream_ptr(), names, pairs, fl, gb, cb), "eyoc_model_layer_work")
+        return [{"name": names[i].decode(), "pairs": int(pairs[i]), "flop": fl[i], "gather_bytes": gb[i],
+                 "compulsory_bytes": cb[i]} for i in range(n)]
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                _lib.load().eyoc_model_destroy(self._handle)
+        except Exception:
+            pass
+
+
+class ResUNetBN2(ResUNet2):
+    NORM_TYPE = 'BN'
+
+
+class ResUNetBN2B(ResUNet2):
+    NORM_TYPE = 'BN'
+    CHANNELS = [None, 32, 64, 128, 256]
+    TR_CHANNELS = [None, 64, 64, 64, 64]
+
+
+class ResUNetBN2C(ResUNet2):
+    NORM_TYPE = 'BN'
+    CHANNELS = [None, 32, 64, 128, 256]
+    TR_CHANNELS = [None, 64, 64, 64, 128]
+
+
+class ResUNetBN2D(ResUNet2):
+    NORM_TYPE = 'BN'
+    CHANNELS = [None, 32, 64, 128, 256]
+    TR_CHANNELS = [None, 64, 64, 128, 128]
+
+
+class ResUNetBN2E(ResUNet2):
+    NORM_TYPE = 'BN'
+    CHANNELS = [None, 128, 128, 128, 256]
+    TR_CHANNELS = [None, 64, 128, 128, 128]
+
+
+class ResUNetFatBN(ResUNet2):
+    NORM_TYPE = 'BN'
+    CHANNELS = [None, 32, 64, 128, 256]
+    TR_CHANNELS = [None, 128, 128, 128, 256]
+
+
+MODELS = [ResUNet2, ResUNetBN2, ResUNetBN2B, ResUNetBN2C, ResUNetBN2D, ResUNetBN2E, ResUNetFatBN]
+
+
+def load_model(name):
+    """model/__init__.py:16-30 - class lookup by name; ``None`` (and a log line) if unknown."""
+    mdict = {m.__name__: m for m in MODELS}
+    if name not in mdict:
+        logging.info(f'Invalid model index. You put {name}. Options are:')
+        for m in MODELS:
+            logging.info('\t* {}'.format(m.__name__))
+        return None
+    return mdict[name]

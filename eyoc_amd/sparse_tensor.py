@@ -1,0 +1,135 @@
+"""``SparseTensor`` with the slice of MinkowskiEngine's interface the EYOC hot path touches.
+
+Call sites mirrored: ``ME.SparseTensor(feats.to(device), coordinates=coords.to(device))``
+(scripts/test_kitti.py:143-148, util/transform_estimation.py:128-131), ``.F`` (test_kitti.py:146,150),
+``ME.SparseTensor(F, coordinate_map_key=..., coordinate_manager=...)`` (model/resunet.py:187-191) and
+``.decomposed_coordinates_and_features`` (lib/trainer.py:1288-1291).
+
+The coordinate manager owns the device-side coordinate maps / rulebooks (``eyoc_maps``), built once
+per coordinate set and shared by every layer of a forward pass.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class CoordinateManager:
+    """Holds ``coords int32 [N,4]`` on the device plus the lazily built ``eyoc_maps`` handle."""
+
+    def __init__(self, coordinates: torch.Tensor):
+        if coordinates.dim() != 2 or coordinates.shape[1] != 4:
+            raise ValueError(f"coordinates must be [N,4] (batch,x,y,z), got {tuple(coordinates.shape)}")
+        if not coordinates.is_cuda:
+            raise _lib.EyocError("SparseTensor coordinates must live on the GPU (no CPU path)")
+        self.coordinates = coordinates.to(torch.int32).contiguous()
+        self._maps = None
+        self._ws = None
+
+    @property
+    def device(self):
+        return self.coordinates.device
+
+    def maps(self):
+        if self._maps is None:
+            lib = _lib.load()
+            n = self.coordinates.shape[0]
+            with torch.cuda.device(self.device):
+                self._ws = _lib.workspace(lib.eyoc_maps_workspace_bytes(n), self.device)
+                h = C.c_void_p()
+                _lib.check(lib.eyoc_maps_build(_lib.ctx(self.device.index), _lib.ptr(self.coordinates), n,
+                                               _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr(), C.byref(h)),
+                           "eyoc_maps_build")
+            self._maps = h
+        return self._maps
+
+    def rows(self, level: int) -> int:
+        return int(_lib.load().eyoc_maps_rows(self.maps(), level))
+
+    def level_coordinates(self, level: int) -> torch.Tensor:
+        """Copy of the level's coordinates ``int32 [rows,4]`` (diagnostics / tests)."""
+        n = self.rows(level)
+        out = torch.empty((n, 4), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().eyoc_maps_copy_coords(self.maps(), level, _lib.ptr(out), _lib.stream_ptr()),
+                       "eyoc_maps_copy_coords")
+        return out
+
+    def table(self, kind: int, level: int) -> torch.Tensor:
+        """Copy of a rulebook ``int32 [27, n_out]`` (diagnostics / tests)."""
+        n_out = {0: self.rows(level), 1: self.rows(level + 1), 2: self.rows(level)}[kind]
+        out = torch.empty((27, n_out), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().eyoc_maps_copy_table(self.maps(), kind, level, _lib.ptr(out), _lib.stream_ptr()),
+                       "eyoc_maps_copy_table")
+        return out
+
+    def info(self, conv1_kernel_size: int = 0) -> dict:
+        info = _lib.MapsInfo()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().eyoc_maps_info(_lib.ctx(self.device.index), self.maps(), conv1_kernel_size,
+                                                  _lib.stream_ptr(), C.byref(info)), "eyoc_maps_info")
+        L = info.n_levels
+        return {"rows": list(info.rows[:L]), "pairs_s1": list(info.pairs_s1[:L]),
+                "pairs_down": list(info.pairs_down[:L - 1]), "pairs_up": list(info.pairs_up[:L - 1]),
+                "pairs_conv1": int(info.pairs_conv1)}
+
+    def __del__(self):
+        try:
+            if self._maps is not None:
+                _lib.load().eyoc_maps_free(self._maps)
+                self._maps = None
+        except Exception:
+            pass
+
+
+class SparseTensor:
+    def __init__(self, features: torch.Tensor, coordinates: torch.Tensor | None = None, device=None,
+                 coordinate_map_key=None, coordinate_manager: CoordinateManager | None = None, **_unused):
+        if device is not None:
+            features = features.to(device)
+            if coordinates is not None:
+                coordinates = coordinates.to(device)
+        if coordinate_manager is None:
+            if coordinates is None:
+                raise ValueError("either coordinates or coordinate_manager is required")
+            coordinate_manager = CoordinateManager(coordinates)
+        if features.dim() != 2 or features.shape[0] != coordinate_manager.coordinates.shape[0]:
+            raise ValueError("features must be [N,C] with one row per coordinate")
+        if not features.is_cuda:
+            raise _lib.EyocError("SparseTensor features must live on the GPU (no CPU path)")
+        self._F = features.to(torch.float32).contiguous()
+        self.coordinate_manager = coordinate_manager
+        self.coordinate_map_key = coordinate_map_key if coordinate_map_key is not None else (1, 1, 1)
+
+    @property
+    def F(self):
+        return self._F
+
+    @property
+    def C(self):
+        return self.coordinate_manager.coordinates
+
+    @property
+    def device(self):
+        return self._F.device
+
+    def __len__(self):
+        return self._F.shape[0]
+
+    @property
+    def decomposed_coordinates_and_features(self):
+        """Per-batch-index lists ``(coords int32 [n_b,3], feats [n_b,C])`` (lib/trainer.py:1288-1291)."""
+        b = self.C[:, 0]
+        coords, feats = [], []
+        for i in range(int(b.max().item()) + 1 if len(b) else 0):
+            m = b == i
+            coords.append(self.C[m][:, 1:])
+            feats.append(self._F[m])
+        return coords, feats
+
+    def __repr__(self):
+        return f"SparseTensor(N={len(self)}, C={self._F.shape[1]}, device={self.device})"

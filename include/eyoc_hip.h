@@ -1,0 +1,226 @@
+/*
+ * eyoc_hip.h - C ABI of libeyoc_hip.so, the MI355X (gfx950) implementation of EYOC's registration
+ * hot path.  The reference (liuQuan98/EYOC) has no FFI of its own for this path: its Python calls
+ * land in MinkowskiEngine / PyTorch / Open3D.  Every entry point below names the reference call
+ * site it stands in for (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative eyoc_status on failure;
+ *     eyoc_last_error() returns a thread-local message for the last failure on this thread;
+ *   - "dev" pointers are device (HBM) pointers owned by the caller; the library never frees them;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises
+ *     unless stated (eyoc_maps_build does: it must learn the data-dependent level sizes);
+ *   - one eyoc_ctx per (process, device); a ctx is not re-entrant (one stream at a time).
+ *   - floating point is fp32 throughout (the reference's dtype); indices are int32 on the device
+ *     side and int64 where the reference hands int64 to its callers.
+ */
+#ifndef EYOC_HIP_H
+#define EYOC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct eyoc_ctx eyoc_ctx;
+typedef struct eyoc_maps eyoc_maps;
+typedef struct eyoc_model eyoc_model;
+
+typedef enum {
+  EYOC_OK = 0,
+  EYOC_ERR_INVALID = -1,     /* bad argument / unsupported shape            */
+  EYOC_ERR_HIP = -2,         /* a HIP runtime call failed                   */
+  EYOC_ERR_WORKSPACE = -3,   /* caller-provided workspace too small         */
+  EYOC_ERR_DUPLICATE = -4,   /* duplicate coordinates in a sparse tensor    */
+  EYOC_ERR_RANGE = -5        /* coordinate / batch index out of key range   */
+} eyoc_status;
+
+#define EYOC_MAX_LEVELS 4
+#define EYOC_VERSION 100
+
+/* ------------------------------------------------------------------------------------------------
+ * context
+ * --------------------------------------------------------------------------------------------- */
+int eyoc_version(void);
+const char* eyoc_last_error(void);
+int eyoc_create(int device, eyoc_ctx** out);
+int eyoc_destroy(eyoc_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------------
+ * coordinate maps + rulebooks
+ *   replaces: ME.SparseTensor(features, coordinates=) and the coordinate manager it creates
+ *             (scripts/test_kitti.py:143-148, util/transform_estimation.py:128-131), and the kernel
+ *             maps MinkowskiConvolution / MinkowskiConvolutionTranspose build on first use
+ *             (model/resunet.py:31-116, model/residual_block.py:23-33).
+ *   coords: int32 [n,4] = (batch, x, y, z), unique rows; |x|,|y|,|z| < 2^17, 0 <= batch < 1024.
+ *   Builds the 4 levels (tensor stride 1,2,4,8) and, per level, output-stationary neighbour tables
+ *   nbr[27][n_out] (int32 input row or -1): stride-1 (EYOC_MAP_S1), strided ts->2ts
+ *   (EYOC_MAP_DOWN, indexed by the fine level) and transposed 2ts->ts (EYOC_MAP_UP, indexed by the
+ *   fine level).  Kernel offsets enumerate x fastest.  Row order of level 0 is the input order;
+ *   coarser levels are ordered by first occurrence.
+ *   The workspace (eyoc_maps_workspace_bytes(n) bytes, 256-byte aligned) is owned by the caller and
+ *   must outlive the maps object.  This call synchronises `stream` (3 small read-backs).
+ * --------------------------------------------------------------------------------------------- */
+typedef enum { EYOC_MAP_S1 = 0, EYOC_MAP_DOWN = 1, EYOC_MAP_UP = 2 } eyoc_map_kind;
+
+typedef struct {
+  int32_t n_levels;
+  int32_t rows[EYOC_MAX_LEVELS];        /* N1, N2, N4, N8                                   */
+  int64_t pairs_s1[EYOC_MAX_LEVELS];    /* valid entries of each stride-1 table             */
+  int64_t pairs_down[EYOC_MAX_LEVELS];  /* [l] = table level l -> l+1 (l < n_levels-1)      */
+  int64_t pairs_up[EYOC_MAX_LEVELS];    /* [l] = table level l+1 -> l                       */
+  int64_t pairs_conv1;                  /* valid (row, offset) pairs of the first conv      */
+} eyoc_maps_info_t;
+
+size_t eyoc_maps_workspace_bytes(int n_rows);
+int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n_rows, void* workspace_dev,
+                    size_t workspace_bytes, void* stream, eyoc_maps** out);
+int eyoc_maps_free(eyoc_maps* maps);
+int eyoc_maps_rows(const eyoc_maps* maps, int level);
+/* device pointers into the workspace; valid while the maps object lives */
+const int32_t* eyoc_maps_coords(const eyoc_maps* maps, int level);             /* [rows,4]        */
+const int32_t* eyoc_maps_table(const eyoc_maps* maps, int kind, int level);    /* [27][n_out]     */
+/* stream-ordered device-to-device copies of the same arrays into caller-owned buffers */
+int eyoc_maps_copy_coords(const eyoc_maps* maps, int level, int32_t* out_dev, void* stream);
+int eyoc_maps_copy_table(const eyoc_maps* maps, int kind, int level, int32_t* out_dev, void* stream);
+/* counts valid pairs (one reduction per table + a sync); conv1_kernel_size 0 skips pairs_conv1 */
+int eyoc_maps_info(eyoc_ctx* ctx, const eyoc_maps* maps, int conv1_kernel_size, void* stream,
+                   eyoc_maps_info_t* info);
+
+/* ------------------------------------------------------------------------------------------------
+ * one sparse convolution layer (unit tests, profiling)
+ *   replaces: one MinkowskiConvolution / MinkowskiConvolutionTranspose forward with the batch norm
+ *             that follows it folded in, plus the residual add / ReLU / concat write around it
+ *             (model/residual_block.py:37-53, model/resunet.py:142-186).
+ *   out[o, :] = act( sum_k in[nbr[k][o], :] @ W[k] + bias (+ res[o, :]) ),  nbr == NULL: K must be
+ *   1 and the map is the identity (1x1 convolution).  cin % 32 == 0, cout in {32,64,128,256}.
+ *   Weights must be in the packed layout produced by eyoc_spconv_pack_weights (host side).
+ * --------------------------------------------------------------------------------------------- */
+size_t eyoc_spconv_packed_floats(int K, int cin, int cout);
+int eyoc_spconv_pack_weights(const float* w_host /*[K,cin,cout]*/, const float* scale_host /*[cout]|NULL*/,
+                             int K, int cin, int cout, float* packed_host);
+int eyoc_spconv(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, const float* in_dev,
+                int ld_in, int cin, const float* wpacked_dev, int cout, const float* bias_dev,
+                const float* res_dev, int ld_res, int relu, float* out_dev, int ld_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ResUNet2 family (ResUNetBN2C in production)
+ *   replaces: Model(in_channels, out_channels, bn_momentum=, conv1_kernel_size=, normalize_feature=)
+ *             + load_state_dict + eval + __call__   (model/resunet.py:18-193,
+ *             scripts/test_kitti.py:83-93,143-150).
+ *   Layers are matched by MinkowskiEngine state_dict names: "conv1", "norm1", "block1.conv1",
+ *   "block1.norm1", ... "conv1_tr", "final".  Batch norms are folded into the preceding
+ *   convolution (eval mode, eps = bn_eps).
+ *   The packed weights live in a caller-owned device blob of eyoc_model_blob_floats() floats so it
+ *   can be broadcast between ranks: rank 0 passes `layers`, the others pass layers == NULL after
+ *   receiving the blob.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t in_channels, out_channels, conv1_kernel_size, normalize_feature;
+  int32_t channels[5];     /* CHANNELS    = [-, 32, 64, 128, 256] for BN2C (index 0 unused) */
+  int32_t tr_channels[5];  /* TR_CHANNELS = [-, 64, 64, 64, 128]  for BN2C                   */
+  float bn_eps;            /* 1e-5 */
+} eyoc_model_desc;
+
+typedef struct {
+  const char* name;        /* "conv1", "block2.conv1", "final", "norm1", "block2.norm2", ... */
+  const float* kernel;     /* conv: [K,cin,cout] (K==1 may be [cin,cout]); NULL for norms    */
+  int32_t K, cin, cout;
+  const float* bias;       /* conv bias [cout] or NULL (only "final")                        */
+  const float* bn_weight;  /* norm entries: gamma, beta, running_mean, running_var [c]       */
+  const float* bn_bias;
+  const float* bn_mean;
+  const float* bn_var;
+} eyoc_layer_params;
+
+size_t eyoc_model_blob_floats(const eyoc_model_desc* desc);
+int eyoc_model_create(eyoc_ctx* ctx, const eyoc_model_desc* desc, const eyoc_layer_params* layers,
+                      int n_layers, float* blob_dev, size_t blob_floats, eyoc_model** out);
+int eyoc_model_destroy(eyoc_model* model);
+size_t eyoc_model_workspace_bytes(const eyoc_model* model, const eyoc_maps* maps);
+/* feats_dev f32 [N1, in_channels] -> out_dev f32 [N1, out_channels], rows in input order */
+int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* model, const eyoc_maps* maps,
+                       const float* feats_dev, float* out_dev, void* workspace_dev,
+                       size_t workspace_bytes, void* stream);
+/* per-layer algorithmic work of the last forward geometry (SURVEY.md 8d formulas); arrays of
+ * eyoc_model_num_layers() entries, any may be NULL */
+int eyoc_model_num_layers(const eyoc_model* model);
+int eyoc_model_layer_work(eyoc_ctx* ctx, const eyoc_model* model, const eyoc_maps* maps, void* stream,
+                          const char** names, int64_t* pairs, double* flops, double* gather_bytes,
+                          double* compulsory_bytes);
+/* when `on`, eyoc_model_forward brackets every layer with hipEvents on `stream` and
+ * eyoc_model_layer_ms returns the per-layer durations of the last forward (synchronises) */
+int eyoc_model_set_timing(eyoc_model* model, int on);
+int eyoc_model_layer_ms(eyoc_model* model, float* ms /*[num_layers]*/);
+
+/* ------------------------------------------------------------------------------------------------
+ * feature matching
+ *   replaces: lib.eval.find_nn_gpu + lib.metrics.pdist (lib/eval.py:18-48, lib/metrics.py:22-29)
+ *             and the nearest-neighbour step of Matcher.match_pair (scripts/SC2_PCR/SC2_PCR.py:296-298).
+ *   For every row of A the index of the nearest row of B.  dist_type 0: squared L2 (difference
+ *   form, fp32, channels left to right, no FMA - bit-exact with oracle/matching.py); 1: L2 =
+ *   sqrt(d2 + 1e-7); ties go to the lowest index.  Segmented form: nseg independent problems,
+ *   rows [seg_a[s], seg_a[s+1]) of A against rows [seg_b[s], seg_b[s+1]) of B; indices are local to
+ *   the B segment.  seg arrays are HOST arrays; nseg <= 64.  c <= 128.
+ * --------------------------------------------------------------------------------------------- */
+int eyoc_knn1(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c, const int32_t* seg_a,
+              const int32_t* seg_b, int nseg, int dist_type, int64_t* idx_dev, float* dist_dev,
+              void* stream);
+
+/* replaces: lib.metrics.pdist (lib/metrics.py:22-29): dense out f32 [n,m]; same arithmetic as eyoc_knn1 */
+int eyoc_pdist(eyoc_ctx* ctx, const float* A_dev, int n, const float* B_dev, int m, int c, int dist_type,
+               float* out_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * pose solvers
+ * --------------------------------------------------------------------------------------------- */
+/* replaces: rigid_transform_3d (scripts/SC2_PCR/common.py:7-45).  A,B f32 [bs,n,3], w f32 [bs,n] or
+ * NULL -> T f32 [bs,4,4] with B ~ R A + t.  Weighted centroids use the reference's 1e-6 epsilon. */
+int eyoc_kabsch_batched(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, const float* w_dev,
+                        int bs, int n, float* T_dev, void* stream);
+/* replaces: est_quad_linear_robust (util/transform_estimation.py:89-116).  p0,p1 f32 [n,3],
+ * w f32 [n] or NULL -> T f32 [4,4]. */
+int eyoc_irls_quad(eyoc_ctx* ctx, const float* p0_dev, const float* p1_dev, const float* w_dev, int n,
+                   int iters, float* T_dev, void* stream);
+
+/* replaces: o3d.pipelines.registration.registration_ransac_based_on_feature_matching(..., 4,
+ * [EdgeLength(0.9), Distance(d)], RANSACConvergenceCriteria(4000000, 10000))
+ * (scripts/test_kitti.py:169-177) given the feature correspondences.  Hypothesis h samples
+ * correspondences with the counter hash documented in oracle/ransac.py. */
+typedef struct {
+  float max_distance;        /* config.voxel_size * 1.0  */
+  float edge_similarity;     /* 0.9                      */
+  int32_t max_iteration;     /* 4000000                  */
+  uint32_t seed;
+} eyoc_ransac_params;
+
+typedef struct {
+  float T[16];               /* row-major 4x4            */
+  int32_t inliers;
+  int32_t best_hypothesis;   /* -1 when nothing survived */
+  int32_t survivors;
+  float inlier_rmse;
+} eyoc_ransac_result;
+
+/* src f32 [n,3], tgt f32 [m,3], corr_tgt int64 [n] (target index for source point i);
+ * result_dev points to one eyoc_ransac_result in device memory. */
+int eyoc_ransac(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int64_t* corr_tgt_dev,
+                int n, const eyoc_ransac_params* params, eyoc_ransac_result* result_dev, void* stream);
+
+/* replaces: Matcher.SC2_PCR (scripts/SC2_PCR/SC2_PCR.py:307-384) for bs == 1.
+ * src,tgt f32 [n,3] matched correspondences -> T f32 [4,4], seedwise_fitness f32 [int(ratio*n)]. */
+typedef struct {
+  float inlier_threshold, d_thre, ratio, nms_radius;
+  int32_t num_iterations, max_points, k1, k2;
+} eyoc_sc2pcr_params;
+size_t eyoc_sc2pcr_workspace_bytes(int n, const eyoc_sc2pcr_params* params);
+int eyoc_sc2pcr(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, int n,
+                const eyoc_sc2pcr_params* params, float* T_dev, float* fitness_dev,
+                void* workspace_dev, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EYOC_HIP_H */

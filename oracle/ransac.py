@@ -67,6 +67,9 @@ def ransac(src: np.ndarray, tgt: np.ndarray, corr_tgt: np.ndarray, max_distance:
 
     Returns ``dict(T f64[4,4], inliers int, rmse float, best_h int, survivors int)``.
     """
+    # the C ABI carries both thresholds as fp32 (eyoc_ransac_params); mirror that rounding
+    max_distance = float(np.float32(max_distance))
+    edge_similarity = float(np.float32(edge_similarity))
     S_all = np.asarray(src, np.float64)
     T_all = np.asarray(tgt, np.float64)[np.asarray(corr_tgt)]
     n = len(S_all)
@@ -100,6 +103,7 @@ def ransac(src: np.ndarray, tgt: np.ndarray, corr_tgt: np.ndarray, max_distance:
             err2 = np.where(inl, d * d, 0.0).sum(1)
             with np.errstate(invalid="ignore", divide="ignore"):
                 rmse = np.where(cntc > 0, np.sqrt(err2 / np.maximum(cntc, 1)), np.inf)
+            rmse = rmse.astype(np.float32).astype(np.float64)   # the device ranks by the fp32 RMSE
             for j in range(len(Tc)):
                 key = (int(cntc[j]), float(rmse[j]), int(h0 + cand[c0 + j]))
                 if key[0] > best[0] or (key[0] == best[0] and (key[1] < best[1] or

@@ -1,0 +1,99 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU, exports every
+symbol ``include/eyoc_hip.h`` declares, and its host-side helpers behave.  No device compute."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from eyoc_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "eyoc_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(eyoc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_is_built_in_tree():
+    assert os.path.exists(_lib.LIB_PATH), "run `python -m eyoc_amd.build`"
+    assert os.path.dirname(_lib.LIB_PATH).startswith(ROOT)
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = _lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in eyoc_hip.h but not exported"
+        assert s in _lib.PROTOTYPES, f"{s} has no ctypes prototype"
+    assert set(_lib.PROTOTYPES) <= set(syms)
+    assert lib.eyoc_version() == 100
+
+
+def test_struct_sizes_match_header():
+    assert C.sizeof(_lib.RansacResult) == 16 * 4 + 4 * 4
+    assert C.sizeof(_lib.RansacParams) == 16
+    assert C.sizeof(_lib.Sc2pcrParams) == 32
+    assert C.sizeof(_lib.ModelDesc) == 4 * 4 + 5 * 4 + 5 * 4 + 4
+    assert C.sizeof(_lib.MapsInfo) == 8 + 4 * 4 + (3 * 4 + 1) * 8
+
+
+def test_pack_weights_layout():
+    """packed[k][slice][cc][nt][jq][lane][e] = W[k][cc*32 + (lane>>4)*8 + jq*4 + e][slice*CT + nt*16 + (lane&15)] * s"""
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    for K, cin, cout in ((3, 64, 32), (2, 32, 256), (1, 96, 64)):
+        W = rng.normal(size=(K, cin, cout)).astype(np.float32)
+        s = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+        out = np.zeros(K * cin * cout, np.float32)
+        assert lib.eyoc_spconv_packed_floats(K, cin, cout) == out.size
+        rc = lib.eyoc_spconv_pack_weights(W.ctypes.data, s.ctypes.data, K, cin, cout, out.ctypes.data)
+        assert rc == 0
+        CT = min(cout, 128)
+        P = out.reshape(K, cout // CT, cin // 32, CT // 16, 2, 64, 4)
+        lane = np.arange(64)
+        for k, sl, cc, nt, jq, e in ((0, 0, 0, 0, 0, 0), (K - 1, cout // CT - 1, cin // 32 - 1, CT // 16 - 1, 1, 3)):
+            ci = cc * 32 + (lane >> 4) * 8 + jq * 4 + e
+            co = sl * CT + nt * 16 + (lane & 15)
+            np.testing.assert_array_equal(P[k, sl, cc, nt, jq, :, e], W[k, ci, co] * s[co])
+        assert np.isclose(np.sort(out), np.sort((W * s).ravel())).all()     # a permutation, nothing lost
+    assert lib.eyoc_spconv_pack_weights(W.ctypes.data, None, 1, 30, 64, out.ctypes.data) != 0
+    assert b"unsupported shape" in lib.eyoc_last_error()
+
+
+def test_model_blob_size_matches_parameter_count():
+    lib = _lib.load()
+    d = _lib.ModelDesc()
+    d.in_channels, d.out_channels, d.conv1_kernel_size, d.normalize_feature = 1, 32, 5, 1
+    for i, (c, t) in enumerate(zip((0, 32, 64, 128, 256), (0, 64, 64, 64, 128))):
+        d.channels[i], d.tr_channels[i] = c, t
+    d.bn_eps = 1e-5
+    n = lib.eyoc_model_blob_floats(C.byref(d))
+    assert n >= 8748960 + 32          # conv weights + final bias
+    assert n < 8748960 + 23 * 64 * 8  # padding only
+    d.out_channels = 48
+    assert lib.eyoc_model_blob_floats(C.byref(d)) == 0
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "eyoc_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import eyoc_amd
+    with pytest.raises(eyoc_amd.EyocError):
+        eyoc_amd.find_nn_gpu(torch.zeros(4, 32), torch.zeros(4, 32))
+    with pytest.raises(eyoc_amd.EyocError):
+        eyoc_amd.SparseTensor(torch.ones(3, 1), coordinates=torch.zeros(3, 4, dtype=torch.int32))

@@ -1,0 +1,72 @@
+"""GPU parity: coordinate maps and rulebooks built by the HIP library vs the oracle (integer work:
+bit-exact, including row order)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def random_cloud(seed, n, extent=40, batch=1):
+    rng = np.random.default_rng(seed)
+    out = []
+    for b in range(batch):
+        c = np.unique(rng.integers(-extent, extent, size=(n, 3)) // np.array([1, 1, 4]), axis=0)
+        rng.shuffle(c)
+        out.append(c.astype(np.int32))
+    from eyoc_amd import synthetic as syn
+    return syn.batch_coords(out)
+
+
+def check_against_oracle(coords):
+    import eyoc_amd
+    from eyoc_amd import _lib
+    from oracle import coords as oc
+    cm = eyoc_amd.CoordinateManager(torch.from_numpy(coords).cuda())
+    maps = oc.build_maps(coords, conv1_kernel_size=5)
+    info = cm.info(conv1_kernel_size=5)
+    st = oc.map_stats(maps)
+    assert info["rows"] == st["rows"]
+    assert info["pairs_s1"] == st["pairs_s1"] and info["pairs_down"] == st["pairs_down"]
+    assert info["pairs_up"] == st["pairs_up"] and info["pairs_conv1"] == st["pairs_k5"]
+    for l in range(4):
+        np.testing.assert_array_equal(cm.level_coordinates(l).cpu().numpy(), maps["cm"][l].coords)
+        np.testing.assert_array_equal(cm.table(_lib.MAP_S1, l).cpu().numpy(), maps["s1"][l])
+        if l < 3:
+            np.testing.assert_array_equal(cm.table(_lib.MAP_DOWN, l).cpu().numpy(), maps["down"][l])
+            np.testing.assert_array_equal(cm.table(_lib.MAP_UP, l).cpu().numpy(), maps["up"][l])
+    return info
+
+
+def test_maps_small_random_cloud():
+    check_against_oracle(random_cloud(0, 3000))
+
+
+def test_maps_batched_clouds_do_not_mix():
+    info = check_against_oracle(random_cloud(1, 2500, batch=3))
+    assert info["rows"][0] > 5000
+
+
+def test_maps_negative_coordinates_and_tiny_inputs():
+    coords = np.array([[0, -1, -1, -1], [0, -2, 0, 1], [0, 0, 0, 0], [1, 0, 0, 0], [1, 1, 0, 0], [0, -9, 7, -8]], np.int32)
+    check_against_oracle(coords)
+    check_against_oracle(np.array([[0, 5, 5, 5]], np.int32))
+
+
+def test_maps_synthetic_kitti_cloud():
+    from eyoc_amd import synthetic as syn
+    p = syn.make_pair(0)
+    info = check_against_oracle(syn.batch_coords([p["coords0"], p["coords1"]]))
+    assert 57000 <= info["rows"][0] <= 66000
+
+
+def test_maps_reject_duplicates_and_out_of_range():
+    import eyoc_amd
+    dup = torch.tensor([[0, 1, 2, 3], [0, 4, 5, 6], [0, 1, 2, 3]], dtype=torch.int32).cuda()
+    with pytest.raises(eyoc_amd.EyocError, match="duplicate"):
+        eyoc_amd.CoordinateManager(dup).maps()
+    far = torch.tensor([[0, 1 << 17, 0, 0]], dtype=torch.int32).cuda()
+    with pytest.raises(eyoc_amd.EyocError, match="range"):
+        eyoc_amd.CoordinateManager(far).maps()
+    with pytest.raises(eyoc_amd.EyocError):
+        eyoc_amd.CoordinateManager(torch.zeros((0, 4), dtype=torch.int32).cuda()).maps()

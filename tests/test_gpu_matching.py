@@ -1,0 +1,114 @@
+"""GPU parity: feature nearest neighbour / pdist through the C ABI vs the oracle (bit-exact) and vs
+the reference's golden vectors (tie audit)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import _inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+
+def _golden(name):
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+
+
+@pytest.mark.parametrize("tag", ["big", "odd", "wide"])
+def test_find_nn_gpu_bit_exact_vs_oracle_and_golden(tag):
+    import eyoc_amd
+    from oracle import matching as om
+    g = _golden("g1_nn.npz")
+    seed, n0, n1 = (int(v) for v in g[f"{tag}_meta"])
+    F0, F1 = gi.nn_case(seed, n0, n1)
+    inds, d = eyoc_amd.find_nn_gpu(torch.from_numpy(F0).cuda(), torch.from_numpy(F1).cuda(), nn_max_n=500,
+                                   return_distance=True)
+    assert inds.dtype == torch.int64 and not inds.is_cuda and d.shape == (n0, 1)
+    o_i, o_d = om.find_nn(F0, F1, return_distance=True)
+    np.testing.assert_array_equal(inds.numpy(), o_i)                      # indices: bit-exact
+    np.testing.assert_array_equal(d.numpy().view(np.uint32), o_d.view(np.uint32))   # distances: bit-exact
+    ref = g[f"{tag}_inds"].astype(np.int64)
+    diff = np.nonzero(inds.numpy() != ref)[0]
+    assert len(diff) <= max(2, n0 // 1000)
+    for i in diff:                                                         # only genuine near-ties may differ
+        D = om.sqdist_rows(F0[i:i + 1], F1)[0]
+        assert abs(D[inds[i]] - D[ref[i]]) <= 4e-6
+    # L2 variant
+    indsL, dL = eyoc_amd.find_nn_gpu(torch.from_numpy(F0).cuda(), torch.from_numpy(F1).cuda(), return_distance=True,
+                                     dist_type="L2")
+    oL_i, oL_d = om.find_nn(F0, F1, return_distance=True, dist_type="L2")
+    np.testing.assert_array_equal(indsL.numpy(), oL_i)
+    np.testing.assert_array_equal(dL.numpy().view(np.uint32), oL_d.view(np.uint32))
+
+
+@pytest.mark.parametrize("c", [16, 64, 128])
+def test_find_nn_other_feature_dims(c):
+    import eyoc_amd
+    from oracle import matching as om
+    F0, F1 = gi.nn_case(70 + c, 333, 777, c=c)
+    inds = eyoc_amd.find_nn_gpu(torch.from_numpy(F0).cuda(), torch.from_numpy(F1).cuda())
+    np.testing.assert_array_equal(inds.numpy(), om.find_nn(F0, F1))
+
+
+def test_find_nn_ties_and_edge_shapes():
+    import eyoc_amd
+    F1 = torch.zeros(600, 32)
+    F1[5] = F1[300] = F1[599] = 1.0                       # three identical candidates in different tiles/waves
+    F0 = torch.ones(3, 32)
+    assert eyoc_amd.find_nn_gpu(F0.cuda(), F1.cuda()).tolist() == [5, 5, 5]
+    assert eyoc_amd.find_nn_gpu(torch.zeros(1, 32).cuda(), F1.cuda()).tolist() == [0]
+    assert eyoc_amd.find_nn_gpu(torch.zeros(0, 32).cuda(), F1.cuda()).shape == (0,)
+    with pytest.raises(eyoc_amd.EyocError):
+        eyoc_amd.find_nn_gpu(torch.zeros(4, 24).cuda(), torch.zeros(4, 24).cuda())   # unsupported width
+    with pytest.raises(NotImplementedError):
+        eyoc_amd.find_nn_gpu(F0.cuda(), F1.cuda(), dist_type="cosine")
+
+
+def test_segmented_knn_equals_per_segment_calls():
+    import eyoc_amd
+    from oracle import matching as om
+    rng = np.random.default_rng(0)
+    sizes_a, sizes_b = [100, 1, 257, 64], [300, 50, 129, 1000]
+    A = [gi.unit_feats(90 + i, n) for i, n in enumerate(sizes_a)]
+    B = [gi.unit_feats(95 + i, n) for i, n in enumerate(sizes_b)]
+    seg_a, seg_b = np.cumsum([0] + sizes_a), np.cumsum([0] + sizes_b)
+    idx, dist = eyoc_amd.knn1_segmented(torch.from_numpy(np.concatenate(A)).cuda(), torch.from_numpy(np.concatenate(B)).cuda(),
+                                        seg_a, seg_b)
+    for s in range(4):
+        oi, od = om.find_nn(A[s], B[s], return_distance=True)
+        np.testing.assert_array_equal(idx[seg_a[s]:seg_a[s + 1]].cpu().numpy(), oi)
+        np.testing.assert_array_equal(dist[seg_a[s]:seg_a[s + 1]].cpu().numpy(), od[:, 0])
+
+
+def test_pdist_matches_oracle_and_golden():
+    import eyoc_amd
+    from oracle import matching as om
+    g = _golden("g1_nn.npz")
+    A, B = gi.nn_case(14, 16, 8)
+    for dt, key in (("SquareL2", "small_pdist_sq"), ("L2", "small_pdist_l2")):
+        out = eyoc_amd.pdist(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(), dt).cpu().numpy()
+        np.testing.assert_array_equal(out, om.pdist(A, B, dt))
+        np.testing.assert_allclose(out, g[key], atol=2e-6)
+
+
+def test_find_corr_and_random_sample_glue():
+    import eyoc_amd
+    from oracle import matching as om
+    F0, F1 = gi.nn_case(33, 900, 800)
+    xyz0 = torch.from_numpy(gi._u(34, 900, 3).astype(np.float32))
+    xyz1 = torch.from_numpy(gi._u(35, 800, 3).astype(np.float32))
+    a0, a1 = eyoc_amd.find_corr(xyz0, xyz1, torch.from_numpy(F0).cuda(), torch.from_numpy(F1).cuda(), subsample_size=500,
+                                rng=np.random.RandomState(7))
+    r = np.random.RandomState(7)
+    i0, i1 = r.choice(900, 500, replace=False), r.choice(800, 500, replace=False)
+    b0, b1 = om.find_corr(xyz0.numpy(), xyz1.numpy(), F0, F1, 500, inds0=i0, inds1=i1)
+    np.testing.assert_array_equal(a0.numpy(), b0)
+    np.testing.assert_array_equal(a1.numpy(), b1)
+    # no sub-sampling when the cloud is small
+    c0, c1 = eyoc_amd.find_corr(xyz0, xyz1, torch.from_numpy(F0).cuda(), torch.from_numpy(F1).cuda(), subsample_size=5000)
+    assert c0.shape == (900, 3) and c1.shape == (900, 3)
+    p, f = eyoc_amd.random_sample(xyz0.numpy(), torch.from_numpy(F0), 1200, rng=np.random.RandomState(1))
+    assert p.shape == (1200, 3) and f.shape == (1200, 32)
+    p, f = eyoc_amd.random_sample(xyz0.numpy(), torch.from_numpy(F0), 900)
+    assert p.shape == (900, 3)

@@ -1,0 +1,110 @@
+"""GPU parity: pose solvers (Kabsch, IRLS, RANSAC) through the C ABI vs the oracle and vs the
+reference's golden vectors.  Floating point tolerance: 1e-4 on pose entries (north_star)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import _inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+
+def _golden(name):
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+
+
+def test_rigid_transform_3d_vs_golden():
+    import eyoc_amd
+    from make_golden_inputs import kabsch_inputs
+    from test_oracle_golden import well_conditioned
+    g = _golden("g3_kabsch.npz")
+    for i, case in enumerate(json.loads(str(g["cases"]))):
+        A, B, w = kabsch_inputs(*case)
+        T = eyoc_amd.rigid_transform_3d(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(),
+                                        None if w is None else torch.from_numpy(w).cuda())
+        assert T.is_cuda and T.shape == (A.shape[0], 4, 4)
+        T = T.cpu().numpy()
+        ok = well_conditioned(A, B, w)
+        np.testing.assert_allclose(T[ok], g[f"T{i}"][ok], rtol=0, atol=5e-4, err_msg=f"case {i} {case}")
+        np.testing.assert_allclose(np.linalg.det(T[:, :3, :3]), 1.0, atol=1e-5)
+        np.testing.assert_array_equal(T[:, 3], np.tile([0, 0, 0, 1], (len(T), 1)))
+    # CPU inputs are uploaded and the result comes back on the CPU
+    Tc = eyoc_amd.rigid_transform_3d(torch.from_numpy(A), torch.from_numpy(B), None)
+    assert not Tc.is_cuda
+
+
+def test_rigid_transform_degenerate_inputs():
+    import eyoc_amd
+    A = torch.rand(3, 10, 3).cuda()
+    w0 = torch.zeros(3, 10).cuda()
+    T = eyoc_amd.rigid_transform_3d(A, A + 1.0, w0).cpu().numpy()       # no weight at all -> identity rotation
+    np.testing.assert_allclose(T[:, :3, :3], np.tile(np.eye(3), (3, 1, 1)), atol=1e-6)
+    line = torch.stack([torch.linspace(0, 1, 10)] * 3, 1)[None].cuda()   # collinear points: still a rotation
+    T = eyoc_amd.rigid_transform_3d(line, line, None).cpu().numpy()
+    assert np.isfinite(T).all() and abs(np.linalg.det(T[0, :3, :3]) - 1) < 1e-5
+
+
+def test_est_quad_linear_robust_vs_golden():
+    import eyoc_amd
+    g = _golden("g2_irls.npz")
+    for i, (seed, n, frac, use_w, tp) in enumerate(json.loads(str(g["cases"]))):
+        p0, p1, _ = gi.corr_case(seed, n, gi.rigid(*tp), frac)
+        w = None
+        if use_w:
+            w = torch.from_numpy((0.05 + 0.95 * gi._u(seed + 9, n, 1)).astype(np.float32))
+        T = eyoc_amd.est_quad_linear_robust(torch.from_numpy(p0), torch.from_numpy(p1), w)
+        assert T.shape == (4, 4) and not T.is_cuda          # CPU in -> CPU out, like the reference
+        np.testing.assert_allclose(T.numpy(), g[f"T{i}"], rtol=0, atol=1e-4, err_msg=f"case {i}")
+    assert eyoc_amd.estimate_transform is eyoc_amd.est_quad_linear_robust
+
+
+def test_ransac_matches_oracle_hypothesis_for_hypothesis():
+    import eyoc_amd
+    from oracle import ransac as orn
+    T = gi.rigid(0.01, -0.02, 0.15, 9.0, 0.5, 0.1)
+    for seed, n, frac, H in ((61, 2000, 0.3, 200000), (62, 5000, 0.15, 400000)):
+        p0, p1, inl = gi.corr_case(seed, n, T, frac, noise=0.03)
+        corr = torch.arange(n, dtype=torch.int64)
+        res = eyoc_amd.ransac_from_correspondences(torch.from_numpy(p0), torch.from_numpy(p1), corr, 0.3, H, seed=3)
+        ref = orn.ransac(p0, p1, np.arange(n), 0.3, H, seed=3)
+        assert res.survivors == ref["survivors"]
+        assert res.best_hypothesis == ref["best_h"]
+        assert res.inliers == ref["inliers"]
+        assert res.fitness == pytest.approx(ref["fitness"])
+        assert res.inlier_rmse == pytest.approx(ref["rmse"], rel=1e-5)
+        np.testing.assert_allclose(res.transformation, ref["T"], atol=1e-5)
+        np.testing.assert_allclose(res.transformation[:3, :3], T[:3, :3], atol=0.03)
+
+
+def test_ransac_no_survivor_and_permuted_correspondences():
+    import eyoc_amd
+    from oracle import ransac as orn
+    rng = np.random.default_rng(0)
+    p0 = rng.uniform(-30, 30, (500, 3)).astype(np.float32)
+    p1 = rng.uniform(-30, 30, (700, 3)).astype(np.float32)          # pure outliers
+    corr = torch.from_numpy(rng.integers(0, 700, 500))
+    res = eyoc_amd.ransac_from_correspondences(torch.from_numpy(p0), torch.from_numpy(p1), corr, 0.05, 20000, seed=1)
+    ref = orn.ransac(p0, p1, corr.numpy(), 0.05, 20000, seed=1)
+    assert res.survivors == ref["survivors"]
+    if ref["survivors"] == 0:
+        assert res.best_hypothesis == -1 and res.inliers == 0
+        np.testing.assert_array_equal(res.transformation, np.eye(4))
+
+
+def test_feature_matching_ransac_end_to_end():
+    import eyoc_amd
+    T = gi.rigid(0.0, 0.01, -0.1, 6.0, -0.4, 0.05)
+    p0, p1, inl = gi.corr_case(71, 3000, T, 1.0, noise=0.02)
+    F0 = gi.unit_feats(72, 3000)
+    perm = np.random.default_rng(1).permutation(3000)
+    F1 = F0[perm].copy()
+    F1[::3] = gi.unit_feats(73, 3000)[::3]                           # a third of the descriptors are junk
+    res = eyoc_amd.registration_ransac_based_on_feature_matching(p0, p1[perm], torch.from_numpy(F0),
+                                                                 torch.from_numpy(F1), False, 0.3,
+                                                                 criteria=(100000, 10000), seed=5)
+    rte, rre, ok = eyoc_amd.registration_errors(res.transformation, T)
+    assert ok and rte < 0.1 and rre < np.deg2rad(0.5)
+    assert res.fitness > 0.5
