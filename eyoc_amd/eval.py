@@ -43,6 +43,10 @@ def knn1_segmented(A: torch.Tensor, B: torch.Tensor, seg_a, seg_b, dist_type="Sq
     sb = (C.c_int32 * (nseg + 1))(*[int(v) for v in seg_b])
     idx = torch.empty(A.shape[0], dtype=torch.int64, device=A.device)
     dist = torch.empty(A.shape[0], dtype=torch.float32, device=A.device)
+    if A.shape[0] == 0:
+        return (idx, dist) if return_distance else idx
+    if A.shape[1] != B.shape[1]:
+        raise ValueError("feature dimensions differ")
     with torch.cuda.device(A.device):
         _lib.check(_lib.load().eyoc_knn1(_lib.ctx(A.device.index), _lib.ptr(A), _lib.ptr(B), A.shape[1], sa, sb, nseg,
                                          _DIST[dist_type], _lib.ptr(idx), _lib.ptr(dist), _lib.stream_ptr()),
