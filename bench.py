@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""Benchmark of the registration hot path on synthetic KITTI-shaped pairs.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One step = one pass of the hot path over a batch of ``--pairs`` (default 8) synthetic ~30k-voxel pairs
+already resident in HBM: coordinate maps + rulebooks for the 2P clouds, the batched ResUNetBN2C
+forward, the 5000x5000 feature nearest-neighbour search of every pair and 4-point RANSAC with the
+reference's 4,000,000 hypotheses per pair, and the device->host copy of the P poses.
+Pairs are independent, so ranks take disjoint pairs (weak scaling: per-GPU work is fixed); the only
+collective is the one-off broadcast of the packed weights.
+
+The JSON line carries, besides the driver's contract fields,
+  roofline      the sparse-convolution kernels (spconv_kernel<...>, 22 launches per forward) summed:
+                algorithmic gather bytes (SURVEY.md 8d formula, from the realised rulebook sizes)
+                over their hipEvent-measured durations inside the timed steps, against 8 TB/s HBM;
+                `mfma` gives the same kernels' fp32 FLOP/s against the 157.3 TFLOP/s matrix peak;
+  cpu_baseline  the CPU oracle (a port of the reference algorithms; the reference's own sparse conv
+                and RANSAC live in MinkowskiEngine / Open3D, which cannot run here) timed on the
+                host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import eyoc_amd  # noqa: E402
+from eyoc_amd import dist as edist  # noqa: E402
+from eyoc_amd import synthetic as syn  # noqa: E402
+from eyoc_amd.harness import DeviceBatch, RegistrationConfig, RegistrationPipeline  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_16x16x4_f32 dense peak
+
+
+def build_model(device, rank):
+    sd = syn.make_weights()
+    Model = eyoc_amd.load_model("ResUNetBN2C")
+    model = Model(1, 32, bn_momentum=0.05, conv1_kernel_size=5, normalize_feature=True)
+    if rank == 0:
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model = model.to(device).eval()
+    edist.broadcast_model(model, device, src=0)
+    return model, sd
+
+
+def usable_cores():
+    """Host threads this process may really use: affinity mask capped by the cgroup CPU quota (the GPU
+    box reports 256 CPUs but grants 16; 256 OpenMP threads on a 16-CPU quota slow torch down ~100x)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(pair, sd, sample_hyp=200000, full_hyp=4000000):
+    """Oracle timed on the host: 2 forwards + 5000x5000 NN + a slice of the RANSAC hypotheses."""
+    from oracle import matching as om
+    from oracle import ransac as orn
+    from oracle import resunet as orr
+    torch.set_num_threads(usable_cores())
+    t0 = time.perf_counter()
+    F = []
+    for i in (0, 1):
+        F.append(orr.resunet_forward(sd, syn.batch_coords([pair[f"coords{i}"]]), pair[f"feats{i}"]).numpy())
+    t_feat = time.perf_counter() - t0
+    i0 = syn.subsample_indices(0, len(F[0]))
+    i1 = syn.subsample_indices(1, len(F[1]))
+    t0 = time.perf_counter()
+    nn = om.find_nn(F[0][i0], F[1][i1])
+    t_nn = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    orn.ransac(pair["xyz0"][i0], pair["xyz1"][i1], nn, 0.3, sample_hyp, seed=0)
+    t_ransac = (time.perf_counter() - t0) * (full_hyp / sample_hyp)
+    total = t_feat + t_nn + t_ransac
+    return {"value": 1.0 / total, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": (f"1 pair: 2 oracle forwards ({t_feat:.2f} s) + 5000x5000 NN ({t_nn:.2f} s) + "
+                       f"{sample_hyp} of {full_hyp} RANSAC hypotheses (time x{full_hyp // sample_hyp} = {t_ransac:.1f} s)")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=8, help="pairs per step per GPU")
+    ap.add_argument("--ransac-iters", type=int, default=4000000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
+    args = ap.parse_args()
+
+    t_start = time.perf_counter()
+
+    def log(msg):
+        if args.verbose:
+            print(f"[bench +{time.perf_counter() - t_start:7.2f}s] {msg}", file=sys.stderr, flush=True)
+
+    rank, local_rank, world = edist.init()
+    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    model, sd = build_model(device, rank)
+    log("model packed")
+    cfg = RegistrationConfig(ransac_max_iteration=args.ransac_iters)
+    pipe = RegistrationPipeline(model, cfg)
+
+    # synthetic inputs: rank r owns pairs r, r + world, ... (round-robin over a virtual split)
+    seeds = [rank + world * j for j in range(args.pairs)]
+    pairs = [syn.make_pair(s) for s in seeds]
+    batch = DeviceBatch(pairs, seeds, device, cfg.n_points)
+    torch.cuda.synchronize()
+    log(f"inputs resident: {batch.voxels} voxels in {2 * args.pairs} clouds")
+
+    for i in range(args.warmup):
+        pipe.register(batch)
+        log(f"warmup {i} done")
+    model.set_timing(True)
+    n_layers = None
+    layer_ms = None
+    edist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    results = None
+    for _ in range(args.steps):
+        results = pipe.register(batch)
+        ms = np.array(model.layer_ms())         # events were recorded on the launch stream; read after the step's sync
+        layer_ms = ms if layer_ms is None else layer_ms + ms
+        log(f"step done ({ms.sum():.2f} ms in forward kernels)")
+    edist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed = edist.max_over_ranks(elapsed, device)
+    model.set_timing(False)
+
+    # algorithmic work of one forward on this batch geometry
+    x = eyoc_amd.SparseTensor(batch.feats, coordinates=batch.coords)
+    work = model.layer_work(x)
+    conv = [i for i, w in enumerate(work) if w["name"] != "conv1"]      # the spconv_kernel launches
+    gather = sum(work[i]["gather_bytes"] for i in conv)
+    flops = sum(work[i]["flop"] for i in conv)
+    conv_ms = float(sum(layer_ms[i] for i in conv)) / args.steps
+    fwd_ms = float(layer_ms.sum()) / args.steps
+    rows = x.coordinate_manager.info()["rows"]
+    evals = pipe.evaluate(batch, results)
+
+    if rank == 0:
+        total_pairs = args.pairs * args.steps * world
+        achieved = gather / (conv_ms * 1e-3) / 1e9
+        out = {
+            "metric": "registered pairs/sec (30k-voxel KITTI pairs)",
+            "value": total_pairs / elapsed, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.pairs} synthetic 30 cm KITTI-shaped pairs per step per GPU "
+                                   f"(mean {batch.voxels // (2 * args.pairs)} voxels/cloud, ResUNetBN2C random-init, "
+                                   f"5000-point NN, RANSAC {args.ransac_iters} hypotheses/pair)",
+                       "pairs_per_step": args.pairs, "parallelism": f"pairs sharded over {world} GPU(s)",
+                       "voxels_per_level": rows},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "spconv_kernel<CT,BM,NW> (22 launches per forward, summed)",
+                         "algorithmic_bytes_per_forward": gather, "ms_per_forward": conv_ms},
+            "mfma": {"achieved": flops / (conv_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": flops / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "flop_per_forward": flops},
+            "forward_ms_per_step": fwd_ms,
+            "success_rate": float(np.mean([e["success"] for e in evals])),
+        }
+        log("timed region done; cpu baseline next")
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pairs[0], sd)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,128 @@
+"""The evaluation loop of the reference, batched: ``scripts/test_kitti.py:130-225`` processes one pair
+per iteration (two batch-1 forwards, NN, registration, metrics); here ``P`` pairs share one batched
+forward (the batch column keeps their neighbourhoods apart, exactly as ``sparse_collate`` stacks
+clouds, lib/data_loaders.py:65-66), one segmented NN launch, and ``P`` registration launches.
+
+Differences from the reference that are deliberate and documented in DESIGN.md:
+  * the NN of the 5000-point sample sets is computed once and feeds both the ``dists_nn`` diagnostic
+    and the registration (the reference computes it twice on two different random sub-samples);
+  * the random draws are injectable / seeded.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import registration as reg
+from .eval import knn1_segmented
+from .metrics import registration_errors
+from .sparse_tensor import SparseTensor
+from .synthetic import batch_coords, subsample_indices
+
+
+@dataclass
+class RegistrationConfig:
+    """The hot-path subset of the reference's flags (config.py:82-86,102,125; scripts/test_kitti.py:240-292)."""
+    model: str = "ResUNetBN2C"
+    model_n_out: int = 32
+    conv1_kernel_size: int = 5
+    normalize_feature: bool = True
+    bn_momentum: float = 0.05
+    voxel_size: float = 0.3
+    n_points: int = 5000                 # scripts/test_kitti.py:156
+    use_RANSAC: bool = True
+    ransac_max_iteration: int = 4000000  # scripts/test_kitti.py:176
+    rte_thresh: float = 2.0
+    rre_thresh: float = 5.0
+    sc2pcr: dict = field(default_factory=lambda: dict(
+        inlier_threshold=0.6, num_node=8000, use_mutual=False, d_thre=0.1, num_iterations=20, ratio=0.2,
+        nms_radius=0.6, max_points=8000, k1=30, k2=20))   # scripts/SC2_PCR/config_json/config_KITTI.json
+
+
+class DeviceBatch:
+    """``P`` pairs resident in HBM: batched coordinates/features for the 2P clouds, the voxel centres'
+    points, and the (seeded) sample indices of ``random_sample`` (scripts/test_kitti.py:159-160)."""
+
+    def __init__(self, pairs, seeds, device, n_points=5000):
+        self.P = len(pairs)
+        clouds, feats, self.sizes = [], [], []
+        for p in pairs:
+            for i in (0, 1):
+                clouds.append(p[f"coords{i}"])
+                feats.append(p[f"feats{i}"])
+                self.sizes.append(len(p[f"coords{i}"]))
+        self.offsets = np.concatenate([[0], np.cumsum(self.sizes)])
+        self.coords = torch.from_numpy(batch_coords(clouds)).to(device)
+        self.feats = torch.from_numpy(np.concatenate(feats, 0)).to(device)
+        self.T_gt = [np.asarray(p["T_gt"], np.float32) for p in pairs]
+        sel0, sel1, xyz0, xyz1, self.counts = [], [], [], [], []
+        for j, (p, seed) in enumerate(zip(pairs, seeds)):
+            for i, (sel, xyz) in enumerate(((sel0, xyz0), (sel1, xyz1))):
+                n = self.sizes[2 * j + i]
+                if n >= n_points:
+                    idx = subsample_indices(seed * 2 + i, n, n_points)
+                else:                        # random_sample with replacement when the cloud is small
+                    idx = np.random.default_rng(seed * 2 + i + 10**6).choice(n, n_points)
+                sel.append(idx + self.offsets[2 * j + i])
+                xyz.append(p[f"xyz{i}"][idx])
+            self.counts.append(n_points)
+        self.sel0 = torch.from_numpy(np.concatenate(sel0)).to(device)
+        self.sel1 = torch.from_numpy(np.concatenate(sel1)).to(device)
+        self.xyz0 = torch.from_numpy(np.stack(xyz0)).to(device)      # [P, n_points, 3]
+        self.xyz1 = torch.from_numpy(np.stack(xyz1)).to(device)
+        self.seg = np.arange(self.P + 1) * n_points
+        self.n_points = n_points
+
+    @property
+    def voxels(self):
+        return int(self.offsets[-1])
+
+
+class RegistrationPipeline:
+    def __init__(self, model, config: RegistrationConfig | None = None):
+        self.model = model
+        self.cfg = config or RegistrationConfig()
+        self.matcher = None if self.cfg.use_RANSAC else reg.Matcher(**self.cfg.sc2pcr)
+
+    @torch.no_grad()
+    def features(self, batch: DeviceBatch) -> SparseTensor:
+        """scripts/test_kitti.py:141-150 for all 2P clouds at once (the maps are rebuilt per call, like
+        the reference rebuilds its coordinate manager for every SparseTensor)."""
+        return self.model(SparseTensor(batch.feats, coordinates=batch.coords))
+
+    @torch.no_grad()
+    def register(self, batch: DeviceBatch, seed: int = 0, return_device=False):
+        """One pass of the hot path over ``P`` pairs -> ``T f32 [P,4,4]`` (host) and per-pair stats."""
+        F = self.features(batch).F
+        F0, F1 = F.index_select(0, batch.sel0), F.index_select(0, batch.sel1)
+        nn_idx = knn1_segmented(F0, F1, batch.seg, batch.seg, "SquareL2", return_distance=False)
+        n = batch.n_points
+        out = []
+        if self.cfg.use_RANSAC:
+            for p in range(batch.P):
+                out.append(reg.ransac_from_correspondences(
+                    batch.xyz0[p], batch.xyz1[p], nn_idx[p * n:(p + 1) * n], self.cfg.voxel_size * 1.0,
+                    self.cfg.ransac_max_iteration, seed=seed + p, as_device_result=True))
+            res = torch.stack(out)                                   # [P, 84] bytes on the device
+            if return_device:
+                return res
+            host = res.cpu()
+            return [reg.decode_ransac_result(host[p], n) for p in range(batch.P)]
+        results = []
+        for p in range(batch.P):
+            idx = nn_idx[p * n:(p + 1) * n]
+            T, fit = self.matcher.SC2_PCR(batch.xyz0[p][None], batch.xyz1[p].index_select(0, idx)[None])
+            results.append(T[0])
+        T = torch.stack(results)
+        return T if return_device else [reg.RegistrationResult(t.cpu().numpy().astype(np.float64), 0.0, 0.0) for t in T]
+
+    def evaluate(self, batch: DeviceBatch, results):
+        """RTE / RRE / success per pair (scripts/test_kitti.py:187-211)."""
+        rows = []
+        for p, r in enumerate(results):
+            rte, rre, ok = registration_errors(r.transformation.astype(np.float32), batch.T_gt[p],
+                                               self.cfg.rte_thresh, self.cfg.rre_thresh)
+            rows.append({"rte": rte, "rre_deg": float(np.rad2deg(rre)), "success": ok})
+        return rows
