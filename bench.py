@@ -157,6 +157,12 @@ def main():
     rows = x.coordinate_manager.info()["rows"]
     evals = pipe.evaluate(batch, results)
 
+    if rank == 0 and args.verbose:
+        print(f"{'layer':18s} {'ms':>8s} {'GFLOP':>8s} {'TFLOP/s':>8s} {'gatherGB/s':>10s} {'pairs':>10s}", file=sys.stderr)
+        for i, w in enumerate(work):
+            ms_i = layer_ms[i] / args.steps
+            print(f"{w['name']:18s} {ms_i:8.3f} {w['flop'] / 1e9:8.2f} {w['flop'] / ms_i / 1e9:8.2f} "
+                  f"{w['gather_bytes'] / ms_i / 1e6:10.1f} {w['pairs']:10d}", file=sys.stderr)
     if rank == 0:
         total_pairs = args.pairs * args.steps * world
         achieved = gather / (conv_ms * 1e-3) / 1e9

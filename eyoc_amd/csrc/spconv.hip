@@ -28,12 +28,13 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int CC = SPCONV_CC;
 constexpr int KMAX = 27;
 
-template <int CT, int BM, int NW>
+template <int CT, int BM, int NW, int CC>
 struct Cfg {
   static constexpr int NT = CT / 16;               // 16-column tiles per block
+  static constexpr int JQ = CC / 16;               // ds_read_b128 B-fragment groups per column tile
+  static constexpr int APL = CC / 4;               // A floats per lane per 16-pair chunk
   static constexpr int MAXCH = BM / 16 / NW;       // 16-pair chunks per wave per offset (worst case)
   static constexpr int THREADS = NW * 64;
   static constexpr int TILE_FLOATS = CC * CT;      // one packed weight tile
@@ -43,16 +44,19 @@ struct Cfg {
   static constexpr int OFF_PAIR_OUT = OFF_PAIR_IN + KMAX * BM * 4;        // u8  [KMAX][BM]
   static constexpr int OFF_CNT = OFF_PAIR_OUT + KMAX * BM;                // int [KMAX + 1 + KMAX]
   static constexpr int OFF_W = (OFF_CNT + (2 * KMAX + 8) * 4 + 15) / 16 * 16;  // float [2][TILE_FLOATS]
-  static constexpr int OFF_ACC = OFF_W + 2 * TILE_FLOATS * 4;             // float [BM][ACC_LD]
+  // two weight buffers (one barrier per iteration) unless that would push the block past half the
+  // CU's 160 KB of LDS and cost the second resident workgroup; then one buffer and two barriers
+  static constexpr bool DB = OFF_W + 2 * TILE_FLOATS * 4 + BM * ACC_LD * 4 + BM * 4 <= 80 * 1024;
+  static constexpr int OFF_ACC = OFF_W + (DB ? 2 : 1) * TILE_FLOATS * 4;  // float [BM][ACC_LD]
   static constexpr int OFF_NORM = OFF_ACC + BM * ACC_LD * 4;              // float [BM]
   static constexpr int LDS_BYTES = OFF_NORM + BM * 4;
-  static_assert(WPT >= 1 && WPT * 4 * THREADS == TILE_FLOATS, "weight tile must divide evenly");
+  static_assert((WPT == 1 || WPT == 2 || WPT == 3 || WPT == 4 || WPT == 8) && WPT * 4 * THREADS == TILE_FLOATS, "weight tile must divide evenly");
   static_assert(MAXCH >= 1, "BM too small for the wave count");
 };
 
-template <int CT, int BM, int NW>
-__global__ __launch_bounds__(NW * 64) void spconv_kernel(SpconvArgs a) {
-  using C = Cfg<CT, BM, NW>;
+template <int CT, int BM, int NW, int CC>
+__global__ __launch_bounds__(NW * 64, 2) void spconv_kernel(SpconvArgs a) {
+  using C = Cfg<CT, BM, NW, CC>;
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
   int* pair_in = reinterpret_cast<int*>(smem + C::OFF_PAIR_IN);
   unsigned char* pair_out = smem + C::OFF_PAIR_OUT;
@@ -113,60 +117,91 @@ __global__ __launch_bounds__(NW * 64) void spconv_kernel(SpconvArgs a) {
     return wbase + ((size_t)(k * n_slices + slice) * ncc + cc) * (C::TILE_FLOATS / 4);
   };
 
-  float4 wreg[C::WPT];
-  if (n_iter > 0) {
-    const float4* src = tile_ptr(0);
-#pragma unroll
-    for (int i = 0; i < C::WPT; ++i) wreg[i] = src[tid + i * C::THREADS];
-    float4* dst = reinterpret_cast<float4*>(wt);
-#pragma unroll
-    for (int i = 0; i < C::WPT; ++i) dst[tid + i * C::THREADS] = wreg[i];
-  }
-  __syncthreads();
-
   f32x4 accreg[C::MAXCH][C::NT];
   const int r16 = lane & 15, g = lane >> 4;
 
-  for (int it = 0; it < n_iter; ++it) {
-    const int k = act[it / ncc], cc = it % ncc, buf = it & 1;
-    {  // prefetch the next weight tile into registers (the last iteration re-reads its own tile:
-       // an unconditional load/store pair keeps wreg in VGPRs instead of scratch)
-      const float4* src = tile_ptr(min(it + 1, n_iter - 1));
+  // A fragments of iteration `it`: lane (r16, g) holds channels [cc*CC + g*APL, +APL) of pair chunk*16 + r16
+  auto gather_a = [&](int it, float (&dst)[C::MAXCH][C::APL]) {
+    const int k = act[it / ncc], cc = it % ncc;
+    const int count = cnt[k];
+    const int nch = (count + 15) >> 4;
 #pragma unroll
-      for (int i = 0; i < C::WPT; ++i) wreg[i] = src[tid + i * C::THREADS];
+    for (int c = 0; c < C::MAXCH; ++c) {
+      const int p = (wave + NW * c) * 16 + r16;
+      if (wave + NW * c < nch && p < count) {
+        const int in_row = pair_in[k * BM + p];
+        const float4* src = reinterpret_cast<const float4*>(a.in + (size_t)in_row * a.ld_in + cc * CC + g * C::APL);
+#pragma unroll
+        for (int q = 0; q < C::APL / 4; ++q) {
+          const float4 v = src[q];
+          dst[c][4 * q] = v.x; dst[c][4 * q + 1] = v.y; dst[c][4 * q + 2] = v.z; dst[c][4 * q + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < C::APL; ++e) dst[c][e] = 0.0f;
+      }
+    }
+  };
+
+  if (n_iter > 0) {   // block-uniform; keeps every staging array's definition and uses in one region
+  // weight-tile staging registers: named scalars, not an array (an indexed array here sometimes
+  // stays an alloca -> scratch, which serialises the prefetch behind s_waitcnt + scratch_store)
+  float4 w0, w1, w2, w3, w4, w5, w6, w7;
+  auto load_w = [&](const float4* src) {
+    w0 = src[tid];
+    if constexpr (C::WPT > 1) w1 = src[tid + C::THREADS];
+    if constexpr (C::WPT > 2) w2 = src[tid + 2 * C::THREADS];
+    if constexpr (C::WPT > 3) w3 = src[tid + 3 * C::THREADS];
+    if constexpr (C::WPT > 4) {
+      w4 = src[tid + 4 * C::THREADS]; w5 = src[tid + 5 * C::THREADS];
+      w6 = src[tid + 6 * C::THREADS]; w7 = src[tid + 7 * C::THREADS];
+    }
+  };
+  auto store_w = [&](float4* dst) {
+    dst[tid] = w0;
+    if constexpr (C::WPT > 1) dst[tid + C::THREADS] = w1;
+    if constexpr (C::WPT > 2) dst[tid + 2 * C::THREADS] = w2;
+    if constexpr (C::WPT > 3) dst[tid + 3 * C::THREADS] = w3;
+    if constexpr (C::WPT > 4) {
+      dst[tid + 4 * C::THREADS] = w4; dst[tid + 5 * C::THREADS] = w5;
+      dst[tid + 6 * C::THREADS] = w6; dst[tid + 7 * C::THREADS] = w7;
+    }
+  };
+  load_w(tile_ptr(0));
+  store_w(reinterpret_cast<float4*>(wt));
+  float a_nxt[C::MAXCH][C::APL];
+  gather_a(0, a_nxt);
+  __syncthreads();
+
+  for (int it = 0; it < n_iter; ++it) {
+    const int k = act[it / ncc], cc = it % ncc, buf = C::DB ? (it & 1) : 0;
+    float av[C::MAXCH][C::APL];
+#pragma unroll
+    for (int c = 0; c < C::MAXCH; ++c)
+#pragma unroll
+      for (int e = 0; e < C::APL; ++e) av[c][e] = a_nxt[c][e];
+    {  // software pipeline: next weight tile -> registers, next A fragments -> registers; both land
+       // while this iteration's MFMAs run (the last iteration re-reads its own operands: an
+       // unconditional load/store pair keeps the staging registers out of scratch)
+      const int nx = min(it + 1, n_iter - 1);
+      load_w(tile_ptr(nx));
+      gather_a(nx, a_nxt);
     }
     const int count = cnt[k];
     const int nch = (count + 15) >> 4;
-    // gather A fragments: lane (r16, g) holds channels [cc*32 + g*8, +8) of pair chunk*16 + r16
-    float av[C::MAXCH][8];
+    if (wave < nch) {  // this wave owns at least one chunk of this offset
+      if (cc == 0) {
 #pragma unroll
-    for (int c = 0; c < C::MAXCH; ++c) {
-      const int chunk = wave + NW * c;
-      if (chunk < nch) {
-        const int p = chunk * 16 + r16;
-        if (p < count) {
-          const int in_row = pair_in[k * BM + p];
-          const float4* src = reinterpret_cast<const float4*>(a.in + (size_t)in_row * a.ld_in + cc * CC + g * 8);
-          const float4 v0 = src[0], v1 = src[1];
-          av[c][0] = v0.x; av[c][1] = v0.y; av[c][2] = v0.z; av[c][3] = v0.w;
-          av[c][4] = v1.x; av[c][5] = v1.y; av[c][6] = v1.z; av[c][7] = v1.w;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) av[c][e] = 0.0f;
-        }
-        if (cc == 0) {
+        for (int c = 0; c < C::MAXCH; ++c)
 #pragma unroll
           for (int nt = 0; nt < C::NT; ++nt) accreg[c][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
       }
-    }
-    if (wave < nch) {  // this wave owns at least one chunk of this offset
       const float4* wl = reinterpret_cast<const float4*>(wt + buf * C::TILE_FLOATS);
 #pragma unroll
-      for (int jq = 0; jq < 2; ++jq) {
+      for (int jq = 0; jq < C::JQ; ++jq) {
 #pragma unroll
         for (int nt = 0; nt < C::NT; ++nt) {
-          const float4 b = wl[(nt * 2 + jq) * 64 + lane];
+          const float4 b = wl[(nt * C::JQ + jq) * 64 + lane];
 #pragma unroll
           for (int c = 0; c < C::MAXCH; ++c) {
             if (wave + NW * c < nch) {
@@ -196,13 +231,11 @@ __global__ __launch_bounds__(NW * 64) void spconv_kernel(SpconvArgs a) {
         }
       }
     }
-    {
-      float4* dst = reinterpret_cast<float4*>(wt + (buf ^ 1) * C::TILE_FLOATS);
-#pragma unroll
-      for (int i = 0; i < C::WPT; ++i) dst[tid + i * C::THREADS] = wreg[i];
-    }
+    if (!C::DB) __syncthreads();   // everyone is done reading the single weight buffer
+    store_w(reinterpret_cast<float4*>(wt + (C::DB ? (buf ^ 1) : 0) * C::TILE_FLOATS));
     __syncthreads();
   }
+  }  // n_iter > 0
 
   // ---- epilogue
   constexpr int C4 = CT / 4;
@@ -253,26 +286,26 @@ __global__ __launch_bounds__(NW * 64) void spconv_kernel(SpconvArgs a) {
   }
 }
 
-template <int CT, int BM, int NW>
+template <int CT, int BM, int NW, int CC>
 void launch_cfg(const SpconvArgs& a, hipStream_t st) {
   dim3 grid(cdiv(a.n_out, BM), a.cout / CT);
-  hipLaunchKernelGGL((spconv_kernel<CT, BM, NW>), grid, dim3(NW * 64), 0, st, a);
+  hipLaunchKernelGGL((spconv_kernel<CT, BM, NW, CC>), grid, dim3(NW * 64), 0, st, a);
 }
 
-template <int CT>
+template <int CT, int CC>
 void launch_ct(const SpconvArgs& a, hipStream_t st) {
   // enough workgroups to cover the 256 CUs a few times over, otherwise shrink the row tile
   const long long slices = a.cout / CT;
   if constexpr (CT <= 64) {
     if ((long long)cdiv(a.n_out, 128) * slices >= 1024) {
-      launch_cfg<CT, 128, 4>(a, st);
+      launch_cfg<CT, 128, 4, CC>(a, st);
       return;
     }
   }
   if ((long long)cdiv(a.n_out, 64) * slices >= 512) {
-    launch_cfg<CT, 64, 4>(a, st);
+    launch_cfg<CT, 64, 4, CC>(a, st);
   } else {
-    launch_cfg<CT, 32, 2>(a, st);
+    launch_cfg<CT, 32, 2, CC>(a, st);
   }
 }
 
@@ -332,7 +365,7 @@ namespace eyoc {
 int launch_spconv(const SpconvArgs& a, hipStream_t st) {
   EYOC_REQUIRE(a.in && a.w && a.out, EYOC_ERR_INVALID, "spconv: NULL tensor");
   EYOC_REQUIRE(a.n_out >= 0, EYOC_ERR_INVALID, "spconv: n_out %d", a.n_out);
-  EYOC_REQUIRE(a.cin > 0 && a.cin % CC == 0, EYOC_ERR_INVALID, "spconv: C_in %d must be a multiple of %d", a.cin, CC);
+  EYOC_REQUIRE(a.cin > 0 && a.cin % 32 == 0, EYOC_ERR_INVALID, "spconv: C_in %d must be a multiple of 32", a.cin);
   EYOC_REQUIRE(a.cout == 32 || a.cout == 64 || a.cout == 128 || a.cout == 256, EYOC_ERR_INVALID,
                "spconv: C_out %d not in {32,64,128,256}", a.cout);
   EYOC_REQUIRE(a.K >= 1 && a.K <= KMAX, EYOC_ERR_INVALID, "spconv: K %d not in [1,%d]", a.K, KMAX);
@@ -343,10 +376,11 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
                EYOC_ERR_INVALID, "spconv: pointers must be 16-byte aligned");
   EYOC_REQUIRE(!a.l2norm || a.cout <= 128, EYOC_ERR_INVALID, "spconv: l2norm needs C_out <= 128");
   if (a.n_out == 0) return EYOC_OK;
+  const bool wide = spconv_cc(a.cin, a.cout) == 64;
   switch (spconv_ct(a.cout)) {
-    case 32: launch_ct<32>(a, st); break;
-    case 64: launch_ct<64>(a, st); break;
-    default: launch_ct<128>(a, st); break;
+    case 32: wide ? launch_ct<32, 64>(a, st) : launch_ct<32, 32>(a, st); break;
+    case 64: wide ? launch_ct<64, 64>(a, st) : launch_ct<64, 32>(a, st); break;
+    default: launch_ct<128, 32>(a, st); break;
   }
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
@@ -376,21 +410,23 @@ extern "C" {
 
 size_t eyoc_spconv_packed_floats(int K, int cin, int cout) { return (size_t)K * cin * cout; }
 
-// packed[k][slice][cc][nt][jq][lane][e] = W[k][cc*32 + (lane>>4)*8 + jq*4 + e][slice*CT + nt*16 + (lane&15)] * scale[col]
+// packed[k][slice][cc][nt][jq][lane][e] = W[k][cc*CC + (lane>>4)*(CC/4) + jq*4 + e][slice*CT + nt*16 + (lane&15)] * scale[col]
+// with CT = spconv_ct(cout), CC = spconv_cc(cin, cout): one [cc] entry is exactly the LDS image of a weight tile.
 int eyoc_spconv_pack_weights(const float* w, const float* scale, int K, int cin, int cout, float* packed) {
   EYOC_REQUIRE(w && packed, EYOC_ERR_INVALID, "pack_weights: NULL argument");
-  EYOC_REQUIRE(cin % CC == 0 && (cout == 32 || cout == 64 || cout == 128 || cout == 256), EYOC_ERR_INVALID,
+  EYOC_REQUIRE(cin > 0 && cin % 32 == 0 && (cout == 32 || cout == 64 || cout == 128 || cout == 256), EYOC_ERR_INVALID,
                "pack_weights: unsupported shape C_in %d C_out %d", cin, cout);
-  const int CT = spconv_ct(cout), n_slices = cout / CT, ncc = cin / CC, NT = CT / 16;
+  const int CT = spconv_ct(cout), CC = spconv_cc(cin, cout);
+  const int n_slices = cout / CT, ncc = cin / CC, NT = CT / 16, JQ = CC / 16, APL = CC / 4;
   size_t q = 0;
   for (int k = 0; k < K; ++k)
     for (int s = 0; s < n_slices; ++s)
       for (int cc = 0; cc < ncc; ++cc)
         for (int nt = 0; nt < NT; ++nt)
-          for (int jq = 0; jq < 2; ++jq)
+          for (int jq = 0; jq < JQ; ++jq)
             for (int lane = 0; lane < 64; ++lane)
               for (int e = 0; e < 4; ++e) {
-                const int ci = cc * CC + (lane >> 4) * 8 + jq * 4 + e;
+                const int ci = cc * CC + (lane >> 4) * APL + jq * 4 + e;
                 const int co = s * CT + nt * 16 + (lane & 15);
                 const float v = w[((size_t)k * cin + ci) * cout + co];
                 packed[q++] = scale ? v * scale[co] : v;
