@@ -5,9 +5,8 @@
 namespace eyoc {
 
 inline int spconv_ct(int cout) { return cout >= 128 ? 128 : cout; }  // output channels per block
-// input channels staged per weight tile: 64 where the tile (CC x CT floats, double buffered) still
-// leaves room for two workgroups per CU, else 32
-inline int spconv_cc(int cin, int cout) { return (cin % 64 == 0 && spconv_ct(cout) <= 64) ? 64 : 32; }
+// input channels per staged item: 64 whenever C_in allows it (half as many barriers), else 32
+inline int spconv_cc(int cin, int /*cout*/) { return cin % 64 == 0 ? 64 : 32; }
 
 struct SpconvArgs {
   const int32_t* nbr;   // [K][n_out] or NULL (identity, K == 1)

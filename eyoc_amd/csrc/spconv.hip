@@ -20,6 +20,8 @@
 //      once, so no atomics are needed and the summation order (k ascending) is deterministic.
 //   4. epilogue from LDS: + bias (folded BN shift) (+ residual) -> ReLU -> (row L2 normalisation)
 //      -> coalesced float4 row stores at the layer's column offset inside a concat buffer.
+#include <type_traits>
+
 #include "spconv.h"
 
 using namespace eyoc;
@@ -32,42 +34,61 @@ constexpr int KMAX = 27;
 
 template <int CT, int BM, int NW, int CC>
 struct Cfg {
-  static constexpr int NT = CT / 16;               // 16-column tiles per block
-  static constexpr int JQ = CC / 16;               // ds_read_b128 B-fragment groups per column tile
-  static constexpr int APL = CC / 4;               // A floats per lane per 16-pair chunk
-  static constexpr int MAXCH = BM / 16 / NW;       // 16-pair chunks per wave per offset (worst case)
   static constexpr int THREADS = NW * 64;
-  static constexpr int TILE_FLOATS = CC * CT;      // one packed weight tile
-  static constexpr int WPT = TILE_FLOATS / 4 / THREADS;  // float4 per thread per tile
-  static constexpr int ACC_LD = CT + 4;            // padded accumulator row (keeps float4 alignment)
-  static constexpr int OFF_PAIR_IN = 0;                                   // int [KMAX][BM]
-  static constexpr int OFF_PAIR_OUT = OFF_PAIR_IN + KMAX * BM * 4;        // u8  [KMAX][BM]
-  static constexpr int OFF_CNT = OFF_PAIR_OUT + KMAX * BM;                // int [KMAX + 1 + KMAX]
-  static constexpr int OFF_W = (OFF_CNT + (2 * KMAX + 8) * 4 + 15) / 16 * 16;  // float [2][TILE_FLOATS]
-  // two weight buffers (one barrier per iteration) unless that would push the block past half the
-  // CU's 160 KB of LDS and cost the second resident workgroup; then one buffer and two barriers
-  static constexpr bool DB = OFF_W + 2 * TILE_FLOATS * 4 + BM * ACC_LD * 4 + BM * 4 <= 80 * 1024;
-  static constexpr int OFF_ACC = OFF_W + (DB ? 2 : 1) * TILE_FLOATS * 4;  // float [BM][ACC_LD]
-  static constexpr int OFF_NORM = OFF_ACC + BM * ACC_LD * 4;              // float [BM]
+  static constexpr int NTILES = CT / 16;                       // 16-column tiles per block
+  static constexpr int NWN = NW < NTILES ? NW : NTILES;        // waves along the output channels
+  static constexpr int NWM = NW / NWN;                         // waves along the pair chunks
+  static constexpr int NTW = NTILES / NWN;                     // column tiles per wave
+  static constexpr int SUB = BM < 64 ? BM : 64;                // pairs staged per item (<= 4 chunks)
+  static constexpr int SCH = SUB / 16;                         // chunks per item
+  static constexpr int MAXCW = SCH / NWM;                      // chunks per wave per item
+  static constexpr int GCH = (SCH + NW - 1) / NW;              // chunks each wave gathers per item
+  static constexpr int JQ = CC / 16;                           // 4-channel groups per lane group
+  static constexpr int P = CC / 4;                             // 16-byte pieces per staged row
+  static constexpr int RPI = 64 / P;                           // rows covered by one gather instruction
+  static constexpr int NI = 16 / RPI;                          // gather instructions per chunk
+  static constexpr int TILE_FLOATS = CC * CT;                  // one packed weight tile
+  static constexpr int ACC_LD = CT + 4;                        // padded accumulator row (keeps float4 alignment)
+  static constexpr int MAX_ITEMS = KMAX * (BM / SUB);
+  static constexpr int OFF_PAIR_IN = 0;                                      // int [KMAX][BM]
+  static constexpr int OFF_PAIR_OUT = OFF_PAIR_IN + KMAX * BM * 4;           // u8  [KMAX][BM]
+  static constexpr int OFF_CNT = OFF_PAIR_OUT + KMAX * BM;                   // int [KMAX] counts + [1] n_items
+  static constexpr int OFF_ITEMS = OFF_CNT + (KMAX + 1) * 4;                 // u16 [MAX_ITEMS]
+  static constexpr int OFF_A = (OFF_ITEMS + MAX_ITEMS * 2 + 15) / 16 * 16;   // float [SUB][CC] (XOR-swizzled pieces)
+  static constexpr int OFF_ACC = OFF_A + SUB * CC * 4;                       // float [BM][ACC_LD]
+  static constexpr int OFF_NORM = OFF_ACC + BM * ACC_LD * 4;                 // float [BM]
   static constexpr int LDS_BYTES = OFF_NORM + BM * 4;
-  static_assert((WPT == 1 || WPT == 2 || WPT == 3 || WPT == 4 || WPT == 8) && WPT * 4 * THREADS == TILE_FLOATS, "weight tile must divide evenly");
-  static_assert(MAXCH >= 1, "BM too small for the wave count");
+  static_assert(NWN * NWM == NW && NTW * NWN == NTILES && MAXCW >= 1 && MAXCW * NWM == SCH, "wave grid must tile the block");
+  static_assert(BM % SUB == 0 && BM <= 256, "BM must be a multiple of SUB and fit the u8 local row index");
 };
 
+// One workgroup = BM output rows x CT output channels.  Waves split the OUTPUT CHANNELS (and, when
+// CT is narrow, the pair chunks): every wave then has the same MFMA count for every offset, however
+// few pairs the offset has, so nobody idles at the per-item barriers.  Per item (offset k, <= 64
+// compacted pairs, one C_in slice):
+//   - the input rows of the pairs are gathered cooperatively with full-row coalesced loads
+//     (consecutive lanes read consecutive 16 B of one row) into registers one item ahead, then into
+//     an LDS tile whose 16-byte pieces are XOR-swizzled by the row so that the MFMA A-fragment reads
+//     (ds_read_b128, lane = (row, channel group)) are bank-conflict free without padding;
+//   - each wave reads ITS slice of W[k] (host-packed in B-fragment order) straight from L2 into
+//     registers, one item ahead - weights never go through LDS;
+//   - v_mfma_f32_16x16x4_f32 over the chunk x column-tile grid, independent accumulators back to back;
+//   - after the last C_in slice the products are added to the LDS accumulator rows of their outputs.
 template <int CT, int BM, int NW, int CC>
 __global__ __launch_bounds__(NW * 64, 2) void spconv_kernel(SpconvArgs a) {
   using C = Cfg<CT, BM, NW, CC>;
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
   int* pair_in = reinterpret_cast<int*>(smem + C::OFF_PAIR_IN);
   unsigned char* pair_out = smem + C::OFF_PAIR_OUT;
-  int* cnt = reinterpret_cast<int*>(smem + C::OFF_CNT);   // [KMAX] counts, [KMAX] active list, [1] n_act
-  int* act = cnt + KMAX;
-  int* n_act_p = act + KMAX;
-  float* wt = reinterpret_cast<float*>(smem + C::OFF_W);
+  int* cnt = reinterpret_cast<int*>(smem + C::OFF_CNT);
+  int* n_items_p = cnt + KMAX;
+  unsigned short* items = reinterpret_cast<unsigned short*>(smem + C::OFF_ITEMS);
+  float* atile = reinterpret_cast<float*>(smem + C::OFF_A);
   float* acc = reinterpret_cast<float*>(smem + C::OFF_ACC);
   float* rnorm = reinterpret_cast<float*>(smem + C::OFF_NORM);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % C::NWN, wm = wave / C::NWN;
   const int row0 = blockIdx.x * BM;
   const int slice = blockIdx.y, n_slices = gridDim.y;
   const int ct0 = slice * CT;
@@ -105,137 +126,162 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_kernel(SpconvArgs a) {
   if (tid == 0) {
     int n = 0;
     for (int k = 0; k < a.K; ++k)
-      if (cnt[k] > 0) act[n++] = k;
-    *n_act_p = n;
+      for (int s0 = 0; s0 < cnt[k]; s0 += C::SUB) items[n++] = (unsigned short)(k | ((s0 / C::SUB) << 8));
+    *n_items_p = n;
   }
   __syncthreads();
-  const int n_iter = *n_act_p * ncc;
+  // Everything that steers control flow below is forced into SGPRs with readfirstlane: values read
+  // from LDS are "divergent" to the compiler, and a divergent branch around an MFMA makes it copy
+  // every accumulator at each region boundary (thousands of v_mov per item).
+  const int n_items = __builtin_amdgcn_readfirstlane(*n_items_p);
 
-  const float4* wbase = reinterpret_cast<const float4*>(a.w);
-  auto tile_ptr = [&](int it) {
-    const int k = act[it / ncc], cc = it % ncc;
-    return wbase + ((size_t)(k * n_slices + slice) * ncc + cc) * (C::TILE_FLOATS / 4);
-  };
+  if (n_items > 0) {  // block-uniform
+    const int r16 = lane & 15, g = lane >> 4;
+    const int grow = lane / C::P, gpiece = lane % C::P;   // gather role: row within an instruction, 16 B piece
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int wn_s = wave_s % C::NWN, wm_s = wave_s / C::NWN;
+    const float4* wbase = reinterpret_cast<const float4*>(a.w);
 
-  f32x4 accreg[C::MAXCH][C::NT];
-  const int r16 = lane & 15, g = lane >> 4;
+    float4 stage[C::GCH][C::NI];
+    float4 bnxt[C::NTW][C::JQ];
+    f32x4 accreg[C::MAXCW][C::NTW];
 
-  // A fragments of iteration `it`: lane (r16, g) holds channels [cc*CC + g*APL, +APL) of pair chunk*16 + r16
-  auto gather_a = [&](int it, float (&dst)[C::MAXCH][C::APL]) {
-    const int k = act[it / ncc], cc = it % ncc;
-    const int count = cnt[k];
-    const int nch = (count + 15) >> 4;
+    struct Item { int k, base, count, nch; };
+    auto decode = [&](int ii) {
+      const int item = __builtin_amdgcn_readfirstlane((int)items[ii]);
+      Item d;
+      d.k = item & 255;
+      d.base = (item >> 8) * C::SUB;
+      d.count = __builtin_amdgcn_readfirstlane(cnt[d.k]);
+      d.nch = (min(C::SUB, d.count - d.base) + 15) >> 4;
+      return d;
+    };
+    // issue the loads of (item, cc): gathered input rows -> stage, this wave's weight slice -> bnxt
+    auto prefetch = [&](const Item& d, int cc) {
+      const float4* wt = wbase + ((size_t)(d.k * n_slices + slice) * ncc + cc) * (C::TILE_FLOATS / 4) +
+                         (size_t)(wn_s * C::NTW) * C::JQ * 64 + lane;
 #pragma unroll
-    for (int c = 0; c < C::MAXCH; ++c) {
-      const int p = (wave + NW * c) * 16 + r16;
-      if (wave + NW * c < nch && p < count) {
-        const int in_row = pair_in[k * BM + p];
-        const float4* src = reinterpret_cast<const float4*>(a.in + (size_t)in_row * a.ld_in + cc * CC + g * C::APL);
+      for (int t = 0; t < C::NTW; ++t)
 #pragma unroll
-        for (int q = 0; q < C::APL / 4; ++q) {
-          const float4 v = src[q];
-          dst[c][4 * q] = v.x; dst[c][4 * q + 1] = v.y; dst[c][4 * q + 2] = v.z; dst[c][4 * q + 3] = v.w;
+        for (int q = 0; q < C::JQ; ++q) bnxt[t][q] = wt[(t * C::JQ + q) * 64];
+#pragma unroll
+      for (int j = 0; j < C::GCH; ++j) {
+        const int chunk = wave_s + NW * j;
+#pragma unroll
+        for (int i = 0; i < C::NI; ++i) {
+          const int p = d.base + chunk * 16 + i * C::RPI + grow;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (chunk < d.nch && p < d.count) {
+            const int in_row = pair_in[d.k * BM + p];
+            v = *reinterpret_cast<const float4*>(a.in + (size_t)in_row * a.ld_in + cc * CC + gpiece * 4);
+          }
+          stage[j][i] = v;
         }
-      } else {
-#pragma unroll
-        for (int e = 0; e < C::APL; ++e) dst[c][e] = 0.0f;
       }
-    }
-  };
-
-  if (n_iter > 0) {   // block-uniform; keeps every staging array's definition and uses in one region
-  // weight-tile staging registers: named scalars, not an array (an indexed array here sometimes
-  // stays an alloca -> scratch, which serialises the prefetch behind s_waitcnt + scratch_store)
-  float4 w0, w1, w2, w3, w4, w5, w6, w7;
-  auto load_w = [&](const float4* src) {
-    w0 = src[tid];
-    if constexpr (C::WPT > 1) w1 = src[tid + C::THREADS];
-    if constexpr (C::WPT > 2) w2 = src[tid + 2 * C::THREADS];
-    if constexpr (C::WPT > 3) w3 = src[tid + 3 * C::THREADS];
-    if constexpr (C::WPT > 4) {
-      w4 = src[tid + 4 * C::THREADS]; w5 = src[tid + 5 * C::THREADS];
-      w6 = src[tid + 6 * C::THREADS]; w7 = src[tid + 7 * C::THREADS];
-    }
-  };
-  auto store_w = [&](float4* dst) {
-    dst[tid] = w0;
-    if constexpr (C::WPT > 1) dst[tid + C::THREADS] = w1;
-    if constexpr (C::WPT > 2) dst[tid + 2 * C::THREADS] = w2;
-    if constexpr (C::WPT > 3) dst[tid + 3 * C::THREADS] = w3;
-    if constexpr (C::WPT > 4) {
-      dst[tid + 4 * C::THREADS] = w4; dst[tid + 5 * C::THREADS] = w5;
-      dst[tid + 6 * C::THREADS] = w6; dst[tid + 7 * C::THREADS] = w7;
-    }
-  };
-  load_w(tile_ptr(0));
-  store_w(reinterpret_cast<float4*>(wt));
-  float a_nxt[C::MAXCH][C::APL];
-  gather_a(0, a_nxt);
-  __syncthreads();
-
-  for (int it = 0; it < n_iter; ++it) {
-    const int k = act[it / ncc], cc = it % ncc, buf = C::DB ? (it & 1) : 0;
-    float av[C::MAXCH][C::APL];
+    };
+    // stage -> LDS tile; piece index XOR (row & 15) keeps the fragment reads conflict free
+    auto commit = [&]() {
 #pragma unroll
-    for (int c = 0; c < C::MAXCH; ++c)
+      for (int j = 0; j < C::GCH; ++j) {
+        const int chunk = wave_s + NW * j;
+        if (chunk < C::SCH) {
 #pragma unroll
-      for (int e = 0; e < C::APL; ++e) av[c][e] = a_nxt[c][e];
-    {  // software pipeline: next weight tile -> registers, next A fragments -> registers; both land
-       // while this iteration's MFMAs run (the last iteration re-reads its own operands: an
-       // unconditional load/store pair keeps the staging registers out of scratch)
-      const int nx = min(it + 1, n_iter - 1);
-      load_w(tile_ptr(nx));
-      gather_a(nx, a_nxt);
-    }
-    const int count = cnt[k];
-    const int nch = (count + 15) >> 4;
-    if (wave < nch) {  // this wave owns at least one chunk of this offset
+          for (int i = 0; i < C::NI; ++i) {
+            const int row = chunk * 16 + i * C::RPI + grow;
+            *reinterpret_cast<float4*>(atile + row * CC + ((gpiece ^ (row & 15)) % C::P) * 4) = stage[j][i];
+          }
+        }
+      }
+    };
+    // MFMAs of one item for a wave that owns NC chunks: straight-line code, no branches inside
+    auto compute = [&](auto nc_tag, const float4 (&bcur)[C::NTW][C::JQ]) {
+      constexpr int NC = decltype(nc_tag)::value;
+#pragma unroll
+      for (int q = 0; q < C::JQ; ++q) {
+        float4 af[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int row = (wm_s + C::NWM * c) * 16 + r16;
+          af[c] = *reinterpret_cast<const float4*>(atile + row * CC + (((q * 4 + g) ^ r16) % C::P) * 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const float av = e == 0 ? af[c].x : e == 1 ? af[c].y : e == 2 ? af[c].z : af[c].w;
+#pragma unroll
+            for (int t = 0; t < C::NTW; ++t) {
+              const float bv = e == 0 ? bcur[t][q].x : e == 1 ? bcur[t][q].y : e == 2 ? bcur[t][q].z : bcur[t][q].w;
+              accreg[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accreg[c][t], 0, 0, 0);
+            }
+          }
+        }
+      }
+    };
+    // D[row = 4*(lane>>4) + reg][col = lane&15] of each chunk -> accumulator rows of its outputs
+    auto flush = [&](auto nc_tag, const Item& d) {
+      constexpr int NC = decltype(nc_tag)::value;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int chunk = wm_s + C::NWM * c;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int p = d.base + chunk * 16 + g * 4 + reg;
+          if (p < d.count) {
+            float* dst = acc + (int)pair_out[d.k * BM + p] * C::ACC_LD + wn_s * C::NTW * 16 + r16;
+#pragma unroll
+            for (int t = 0; t < C::NTW; ++t) dst[t * 16] += accreg[c][t][reg];
+          }
+        }
+      }
+    };
+
+    int ii = 0, cc = 0;
+    Item cur = decode(0);
+    prefetch(cur, 0);
+    commit();
+    __syncthreads();
+
+    while (true) {
+      float4 bcur[C::NTW][C::JQ];
+#pragma unroll
+      for (int t = 0; t < C::NTW; ++t)
+#pragma unroll
+        for (int q = 0; q < C::JQ; ++q) bcur[t][q] = bnxt[t][q];
+      // next (item, cc); the last iteration re-reads its own operands (harmless, keeps staging in VGPRs)
+      int ii_n = ii, cc_n = cc + 1;
+      if (cc_n == ncc) { cc_n = 0; ii_n = ii + 1; }
+      const bool last = ii_n >= n_items;
+      if (last) { ii_n = ii; cc_n = cc; }
+      const Item nxt = decode(ii_n);
+      prefetch(nxt, cc_n);
+
       if (cc == 0) {
 #pragma unroll
-        for (int c = 0; c < C::MAXCH; ++c)
+        for (int c = 0; c < C::MAXCW; ++c)
 #pragma unroll
-          for (int nt = 0; nt < C::NT; ++nt) accreg[c][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int t = 0; t < C::NTW; ++t) accreg[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      const float4* wl = reinterpret_cast<const float4*>(wt + buf * C::TILE_FLOATS);
-#pragma unroll
-      for (int jq = 0; jq < C::JQ; ++jq) {
-#pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt) {
-          const float4 b = wl[(nt * C::JQ + jq) * 64 + lane];
-#pragma unroll
-          for (int c = 0; c < C::MAXCH; ++c) {
-            if (wave + NW * c < nch) {
-              accreg[c][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][jq * 4 + 0], b.x, accreg[c][nt], 0, 0, 0);
-              accreg[c][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][jq * 4 + 1], b.y, accreg[c][nt], 0, 0, 0);
-              accreg[c][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][jq * 4 + 2], b.z, accreg[c][nt], 0, 0, 0);
-              accreg[c][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][jq * 4 + 3], b.w, accreg[c][nt], 0, 0, 0);
-            }
-          }
-        }
+      // chunks of this item owned by this wave's row group (chunk = wm + NWM * c)
+      const int my_nc = (cur.nch - wm_s + C::NWM - 1) / C::NWM;
+      const bool do_flush = cc == ncc - 1;
+      if constexpr (C::MAXCW >= 4) {
+        if (my_nc >= 4) { compute(std::integral_constant<int, 4>{}, bcur); if (do_flush) flush(std::integral_constant<int, 4>{}, cur); }
+        else if (my_nc == 3) { compute(std::integral_constant<int, 3>{}, bcur); if (do_flush) flush(std::integral_constant<int, 3>{}, cur); }
       }
-      if (cc == ncc - 1) {  // D[row = 4*(lane>>4) + reg][col = lane&15] -> accumulator rows
-#pragma unroll
-        for (int c = 0; c < C::MAXCH; ++c) {
-          const int chunk = wave + NW * c;
-          if (chunk < nch) {
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-              const int p = chunk * 16 + g * 4 + reg;
-              if (p < count) {
-                float* dst = acc + (int)pair_out[k * BM + p] * C::ACC_LD + r16;
-#pragma unroll
-                for (int nt = 0; nt < C::NT; ++nt) dst[nt * 16] += accreg[c][nt][reg];
-              }
-            }
-          }
-        }
+      if constexpr (C::MAXCW >= 2) {
+        if (my_nc == 2) { compute(std::integral_constant<int, 2>{}, bcur); if (do_flush) flush(std::integral_constant<int, 2>{}, cur); }
       }
+      if (my_nc == 1) { compute(std::integral_constant<int, 1>{}, bcur); if (do_flush) flush(std::integral_constant<int, 1>{}, cur); }
+
+      __syncthreads();   // everyone is done reading the staged tile
+      if (last) break;
+      commit();
+      __syncthreads();
+      ii = ii_n; cc = cc_n; cur = nxt;
     }
-    if (!C::DB) __syncthreads();   // everyone is done reading the single weight buffer
-    store_w(reinterpret_cast<float4*>(wt + (C::DB ? (buf ^ 1) : 0) * C::TILE_FLOATS));
-    __syncthreads();
-  }
-  }  // n_iter > 0
+  }  // n_items > 0
+  __syncthreads();
 
   // ---- epilogue
   constexpr int C4 = CT / 4;
@@ -380,7 +426,7 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
   switch (spconv_ct(a.cout)) {
     case 32: wide ? launch_ct<32, 64>(a, st) : launch_ct<32, 32>(a, st); break;
     case 64: wide ? launch_ct<64, 64>(a, st) : launch_ct<64, 32>(a, st); break;
-    default: launch_ct<128, 32>(a, st); break;
+    default: wide ? launch_ct<128, 64>(a, st) : launch_ct<128, 32>(a, st); break;
   }
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
@@ -410,14 +456,15 @@ extern "C" {
 
 size_t eyoc_spconv_packed_floats(int K, int cin, int cout) { return (size_t)K * cin * cout; }
 
-// packed[k][slice][cc][nt][jq][lane][e] = W[k][cc*CC + (lane>>4)*(CC/4) + jq*4 + e][slice*CT + nt*16 + (lane&15)] * scale[col]
-// with CT = spconv_ct(cout), CC = spconv_cc(cin, cout): one [cc] entry is exactly the LDS image of a weight tile.
+// packed[k][slice][cc][nt][jq][lane][e] = W[k][cc*CC + (jq*4 + (lane>>4))*4 + e][slice*CT + nt*16 + (lane&15)] * scale[col]
+// with CT = spconv_ct(cout), CC = spconv_cc(cin, cout): for one (k, slice, cc) the [nt][jq][lane] float4s are
+// exactly the B fragments of v_mfma_f32_16x16x4_f32 (B[k = lane>>4][n = lane&15]) in the order a wave consumes them.
 int eyoc_spconv_pack_weights(const float* w, const float* scale, int K, int cin, int cout, float* packed) {
   EYOC_REQUIRE(w && packed, EYOC_ERR_INVALID, "pack_weights: NULL argument");
   EYOC_REQUIRE(cin > 0 && cin % 32 == 0 && (cout == 32 || cout == 64 || cout == 128 || cout == 256), EYOC_ERR_INVALID,
                "pack_weights: unsupported shape C_in %d C_out %d", cin, cout);
   const int CT = spconv_ct(cout), CC = spconv_cc(cin, cout);
-  const int n_slices = cout / CT, ncc = cin / CC, NT = CT / 16, JQ = CC / 16, APL = CC / 4;
+  const int n_slices = cout / CT, ncc = cin / CC, NT = CT / 16, JQ = CC / 16;
   size_t q = 0;
   for (int k = 0; k < K; ++k)
     for (int s = 0; s < n_slices; ++s)
@@ -426,7 +473,7 @@ int eyoc_spconv_pack_weights(const float* w, const float* scale, int K, int cin,
           for (int jq = 0; jq < JQ; ++jq)
             for (int lane = 0; lane < 64; ++lane)
               for (int e = 0; e < 4; ++e) {
-                const int ci = cc * CC + (lane >> 4) * APL + jq * 4 + e;
+                const int ci = cc * CC + (jq * 4 + (lane >> 4)) * 4 + e;
                 const int co = s * CT + nt * 16 + (lane & 15);
                 const float v = w[((size_t)k * cin + ci) * cout + co];
                 packed[q++] = scale ? v * scale[co] : v;

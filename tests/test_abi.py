@@ -43,8 +43,8 @@ def test_struct_sizes_match_header():
 
 
 def test_pack_weights_layout():
-    """packed[k][slice][cc][nt][jq][lane][e] = W[k][cc*CC + (lane>>4)*(CC/4) + jq*4 + e][slice*CT + nt*16 + (lane&15)] * s
-    with CT = min(cout, 128) and CC = 64 when cin % 64 == 0 and CT <= 64, else 32."""
+    """packed[k][slice][cc][nt][jq][lane][e] = W[k][cc*CC + (jq*4 + (lane>>4))*4 + e][slice*CT + nt*16 + (lane&15)] * s
+    with CT = min(cout, 128) and CC = 64 when cin % 64 == 0, else 32."""
     lib = _lib.load()
     rng = np.random.default_rng(0)
     for K, cin, cout in ((3, 64, 32), (2, 32, 256), (1, 96, 64), (2, 128, 64), (2, 128, 128)):
@@ -55,11 +55,11 @@ def test_pack_weights_layout():
         rc = lib.eyoc_spconv_pack_weights(W.ctypes.data, s.ctypes.data, K, cin, cout, out.ctypes.data)
         assert rc == 0
         CT = min(cout, 128)
-        CC = 64 if (cin % 64 == 0 and CT <= 64) else 32
+        CC = 64 if cin % 64 == 0 else 32
         P = out.reshape(K, cout // CT, cin // CC, CT // 16, CC // 16, 64, 4)
         lane = np.arange(64)
         for k, sl, cc, nt, jq, e in ((0, 0, 0, 0, 0, 0), (K - 1, cout // CT - 1, cin // CC - 1, CT // 16 - 1, CC // 16 - 1, 3)):
-            ci = cc * CC + (lane >> 4) * (CC // 4) + jq * 4 + e
+            ci = cc * CC + (jq * 4 + (lane >> 4)) * 4 + e
             co = sl * CT + nt * 16 + (lane & 15)
             np.testing.assert_array_equal(P[k, sl, cc, nt, jq, :, e], W[k, ci, co] * s[co])
         assert np.isclose(np.sort(out), np.sort((W * s).ravel())).all()     # a permutation, nothing lost
