@@ -53,8 +53,8 @@ struct Cfg {
   static constexpr int OFF_PAIR_IN = 0;                                      // int [KMAX][BM]
   static constexpr int OFF_PAIR_OUT = OFF_PAIR_IN + KMAX * BM * 4;           // u8  [KMAX][BM]
   static constexpr int OFF_CNT = OFF_PAIR_OUT + KMAX * BM;                   // int [KMAX] counts + [1] n_items
-  static constexpr int OFF_ITEMS = OFF_CNT + (KMAX + 1) * 4;                 // u16 [MAX_ITEMS]
-  static constexpr int OFF_A = (OFF_ITEMS + MAX_ITEMS * 2 + 15) / 16 * 16;   // float [SUB][CC] (XOR-swizzled pieces)
+  static constexpr int OFF_ITEMS = OFF_CNT + (KMAX + 1) * 4;                 // u32 [MAX_ITEMS + 2]: k | sub << 8 | pairs << 16
+  static constexpr int OFF_A = (OFF_ITEMS + (MAX_ITEMS + 2) * 4 + 15) / 16 * 16;  // float [SUB][CC] (XOR-swizzled pieces)
   static constexpr int OFF_ACC = OFF_A + SUB * CC * 4;                       // float [BM][ACC_LD]
   static constexpr int OFF_NORM = OFF_ACC + BM * ACC_LD * 4;                 // float [BM]
   static constexpr int LDS_BYTES = OFF_NORM + BM * 4;
@@ -82,13 +82,12 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_kernel(SpconvArgs a) {
   unsigned char* pair_out = smem + C::OFF_PAIR_OUT;
   int* cnt = reinterpret_cast<int*>(smem + C::OFF_CNT);
   int* n_items_p = cnt + KMAX;
-  unsigned short* items = reinterpret_cast<unsigned short*>(smem + C::OFF_ITEMS);
+  unsigned int* items = reinterpret_cast<unsigned int*>(smem + C::OFF_ITEMS);
   float* atile = reinterpret_cast<float*>(smem + C::OFF_A);
   float* acc = reinterpret_cast<float*>(smem + C::OFF_ACC);
   float* rnorm = reinterpret_cast<float*>(smem + C::OFF_NORM);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave % C::NWN, wm = wave / C::NWN;
   const int row0 = blockIdx.x * BM;
   const int slice = blockIdx.y, n_slices = gridDim.y;
   const int ct0 = slice * CT;
@@ -126,7 +125,9 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_kernel(SpconvArgs a) {
   if (tid == 0) {
     int n = 0;
     for (int k = 0; k < a.K; ++k)
-      for (int s0 = 0; s0 < cnt[k]; s0 += C::SUB) items[n++] = (unsigned short)(k | ((s0 / C::SUB) << 8));
+      for (int s0 = 0; s0 < cnt[k]; s0 += C::SUB)
+        items[n++] = (unsigned)k | ((unsigned)(s0 / C::SUB) << 8) | ((unsigned)min(C::SUB, cnt[k] - s0) << 16);
+    items[n] = items[n + 1] = n ? items[n - 1] : 0u;   // padding: the pipeline decodes two items ahead
     *n_items_p = n;
   }
   __syncthreads();
@@ -146,18 +147,29 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_kernel(SpconvArgs a) {
     float4 bnxt[C::NTW][C::JQ];
     f32x4 accreg[C::MAXCW][C::NTW];
 
-    struct Item { int k, base, count, nch; };
-    auto decode = [&](int ii) {
-      const int item = __builtin_amdgcn_readfirstlane((int)items[ii]);
+    struct Item { int k, base, n_here, nch; };
+    auto unpack = [&](unsigned rec) {   // rec must already be wave-uniform (readfirstlane'd)
       Item d;
-      d.k = item & 255;
-      d.base = (item >> 8) * C::SUB;
-      d.count = __builtin_amdgcn_readfirstlane(cnt[d.k]);
-      d.nch = (min(C::SUB, d.count - d.base) + 15) >> 4;
+      d.k = rec & 255u;
+      d.base = ((rec >> 8) & 255u) * C::SUB;
+      d.n_here = rec >> 16;
+      d.nch = (d.n_here + 15) >> 4;
       return d;
     };
-    // issue the loads of (item, cc): gathered input rows -> stage, this wave's weight slice -> bnxt
-    auto prefetch = [&](const Item& d, int cc) {
+    // ---- pipeline pieces, ordered by hand inside one iteration so that every LDS / global latency
+    // sits behind MFMAs instead of in front of them (only two waves share a SIMD)
+    // (1) LDS reads of the NEXT item's gather indices
+    auto read_gather_rows = [&](const Item& d, int (&rows)[C::GCH][C::NI]) {
+#pragma unroll
+      for (int j = 0; j < C::GCH; ++j)
+#pragma unroll
+        for (int i = 0; i < C::NI; ++i) {
+          const int pl = (wave_s + NW * j) * 16 + i * C::RPI + grow;      // pair index inside the item
+          rows[j][i] = pl < d.n_here ? pair_in[d.k * BM + d.base + pl] : -1;
+        }
+    };
+    // (2) global loads of the NEXT item: this wave's weight slice and its share of the gathered rows
+    auto issue_loads = [&](const Item& d, int cc, const int (&rows)[C::GCH][C::NI]) {
       const float4* wt = wbase + ((size_t)(d.k * n_slices + slice) * ncc + cc) * (C::TILE_FLOATS / 4) +
                          (size_t)(wn_s * C::NTW) * C::JQ * 64 + lane;
 #pragma unroll
@@ -165,21 +177,16 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_kernel(SpconvArgs a) {
 #pragma unroll
         for (int q = 0; q < C::JQ; ++q) bnxt[t][q] = wt[(t * C::JQ + q) * 64];
 #pragma unroll
-      for (int j = 0; j < C::GCH; ++j) {
-        const int chunk = wave_s + NW * j;
+      for (int j = 0; j < C::GCH; ++j)
 #pragma unroll
         for (int i = 0; i < C::NI; ++i) {
-          const int p = d.base + chunk * 16 + i * C::RPI + grow;
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (chunk < d.nch && p < d.count) {
-            const int in_row = pair_in[d.k * BM + p];
-            v = *reinterpret_cast<const float4*>(a.in + (size_t)in_row * a.ld_in + cc * CC + gpiece * 4);
-          }
+          if (rows[j][i] >= 0)
+            v = *reinterpret_cast<const float4*>(a.in + (size_t)rows[j][i] * a.ld_in + cc * CC + gpiece * 4);
           stage[j][i] = v;
         }
-      }
     };
-    // stage -> LDS tile; piece index XOR (row & 15) keeps the fragment reads conflict free
+    // (3) stage -> LDS tile; piece index XOR (row & 15) keeps the fragment reads conflict free
     auto commit = [&]() {
 #pragma unroll
       for (int j = 0; j < C::GCH; ++j) {
@@ -193,52 +200,86 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_kernel(SpconvArgs a) {
         }
       }
     };
-    // MFMAs of one item for a wave that owns NC chunks: straight-line code, no branches inside
-    auto compute = [&](auto nc_tag, const float4 (&bcur)[C::NTW][C::JQ]) {
+
+    // one iteration for a wave that owns NC chunks of the current item: straight-line code
+    auto body = [&](auto nc_tag, const Item& cur, int cc, const Item& nxt, int cc_n,
+                    const float4 (&bcur)[C::NTW][C::JQ]) {
       constexpr int NC = decltype(nc_tag)::value;
-#pragma unroll
-      for (int q = 0; q < C::JQ; ++q) {
-        float4 af[NC];
+      float4 af[NC > 0 ? NC : 1];
+      auto load_af = [&](int q) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           const int row = (wm_s + C::NWM * c) * 16 + r16;
           af[c] = *reinterpret_cast<const float4*>(atile + row * CC + (((q * 4 + g) ^ r16) % C::P) * 4);
         }
+      };
+      auto mfma_q = [&](int q) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int c = 0; c < NC; ++c) {
             const float av = e == 0 ? af[c].x : e == 1 ? af[c].y : e == 2 ? af[c].z : af[c].w;
 #pragma unroll
             for (int t = 0; t < C::NTW; ++t) {
               const float bv = e == 0 ? bcur[t][q].x : e == 1 ? bcur[t][q].y : e == 2 ? bcur[t][q].z : bcur[t][q].w;
-              accreg[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accreg[c][t], 0, 0, 0);
+              accreg[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, accreg[c][t], 0, 0, 0);
             }
           }
-        }
+      };
+      const bool do_flush = cc == ncc - 1;
+      if (cc == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+          for (int t = 0; t < C::NTW; ++t) accreg[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-    };
-    // D[row = 4*(lane>>4) + reg][col = lane&15] of each chunk -> accumulator rows of its outputs
-    auto flush = [&](auto nc_tag, const Item& d) {
-      constexpr int NC = decltype(nc_tag)::value;
+      load_af(0);
+      int rows[C::GCH][C::NI];
+      read_gather_rows(nxt, rows);
+      int orow[NC > 0 ? NC : 1];   // local output row of this lane's pair in each chunk (-1: padding)
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const int chunk = wm_s + C::NWM * c;
+        const int pl = (wm_s + C::NWM * c) * 16 + r16;
+        orow[c] = pl < cur.n_here ? (int)pair_out[cur.k * BM + cur.base + pl] : -1;
+      }
+      mfma_q(0);
+      issue_loads(nxt, cc_n, rows);
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int p = d.base + chunk * 16 + g * 4 + reg;
-          if (p < d.count) {
-            float* dst = acc + (int)pair_out[d.k * BM + p] * C::ACC_LD + wn_s * C::NTW * 16 + r16;
+      for (int q = 1; q < C::JQ; ++q) {
+        load_af(q);
+        mfma_q(q);
+      }
+      if (do_flush) {
+        // The weights are the MFMA A operand and the gathered rows the B operand, so
+        // D[i = 4*(lane>>4) + reg][j = lane&15] is (output channel i, pair j): every lane holds four
+        // CONSECUTIVE channels of one output row -> one 128-bit LDS read-add-write per chunk and tile.
+        // All reads are issued before any write (the rows of one item are distinct, no aliasing).
+        float4 old[NC > 0 ? NC : 1][C::NTW];
 #pragma unroll
-            for (int t = 0; t < C::NTW; ++t) dst[t * 16] += accreg[c][t][reg];
-          }
-        }
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+          for (int t = 0; t < C::NTW; ++t)
+            if (orow[c] >= 0)
+              old[c][t] = *reinterpret_cast<const float4*>(acc + orow[c] * C::ACC_LD + (wn_s * C::NTW + t) * 16 + g * 4);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+          for (int t = 0; t < C::NTW; ++t)
+            if (orow[c] >= 0) {
+              float4 v = old[c][t];
+              v.x += accreg[c][t][0]; v.y += accreg[c][t][1]; v.z += accreg[c][t][2]; v.w += accreg[c][t][3];
+              *reinterpret_cast<float4*>(acc + orow[c] * C::ACC_LD + (wn_s * C::NTW + t) * 16 + g * 4) = v;
+            }
       }
     };
 
     int ii = 0, cc = 0;
-    Item cur = decode(0);
-    prefetch(cur, 0);
+    Item cur = unpack(__builtin_amdgcn_readfirstlane((int)items[0]));
+    {
+      int rows[C::GCH][C::NI];
+      read_gather_rows(cur, rows);
+      issue_loads(cur, 0, rows);
+    }
     commit();
     __syncthreads();
 
@@ -253,26 +294,19 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_kernel(SpconvArgs a) {
       if (cc_n == ncc) { cc_n = 0; ii_n = ii + 1; }
       const bool last = ii_n >= n_items;
       if (last) { ii_n = ii; cc_n = cc; }
-      const Item nxt = decode(ii_n);
-      prefetch(nxt, cc_n);
+      const Item nxt = unpack(__builtin_amdgcn_readfirstlane((int)items[ii_n]));
 
-      if (cc == 0) {
-#pragma unroll
-        for (int c = 0; c < C::MAXCW; ++c)
-#pragma unroll
-          for (int t = 0; t < C::NTW; ++t) accreg[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
       // chunks of this item owned by this wave's row group (chunk = wm + NWM * c)
       const int my_nc = (cur.nch - wm_s + C::NWM - 1) / C::NWM;
-      const bool do_flush = cc == ncc - 1;
       if constexpr (C::MAXCW >= 4) {
-        if (my_nc >= 4) { compute(std::integral_constant<int, 4>{}, bcur); if (do_flush) flush(std::integral_constant<int, 4>{}, cur); }
-        else if (my_nc == 3) { compute(std::integral_constant<int, 3>{}, bcur); if (do_flush) flush(std::integral_constant<int, 3>{}, cur); }
+        if (my_nc >= 4) body(std::integral_constant<int, 4>{}, cur, cc, nxt, cc_n, bcur);
+        else if (my_nc == 3) body(std::integral_constant<int, 3>{}, cur, cc, nxt, cc_n, bcur);
       }
       if constexpr (C::MAXCW >= 2) {
-        if (my_nc == 2) { compute(std::integral_constant<int, 2>{}, bcur); if (do_flush) flush(std::integral_constant<int, 2>{}, cur); }
+        if (my_nc == 2) body(std::integral_constant<int, 2>{}, cur, cc, nxt, cc_n, bcur);
       }
-      if (my_nc == 1) { compute(std::integral_constant<int, 1>{}, bcur); if (do_flush) flush(std::integral_constant<int, 1>{}, cur); }
+      if (my_nc == 1) body(std::integral_constant<int, 1>{}, cur, cc, nxt, cc_n, bcur);
+      if (my_nc <= 0) body(std::integral_constant<int, 0>{}, cur, cc, nxt, cc_n, bcur);
 
       __syncthreads();   // everyone is done reading the staged tile
       if (last) break;
@@ -350,6 +384,8 @@ void launch_ct(const SpconvArgs& a, hipStream_t st) {
   }
   if ((long long)cdiv(a.n_out, 64) * slices >= 512) {
     launch_cfg<CT, 64, 4, CC>(a, st);
+  } else if constexpr (CT >= 128) {
+    launch_cfg<CT, 32, 4, CC>(a, st);   // 8 column tiles: keep 4 waves (2 tiles each), 2 chunks per item
   } else {
     launch_cfg<CT, 32, 2, CC>(a, st);
   }
