@@ -110,10 +110,13 @@ class RegistrationPipeline:
                 return res
             host = res.cpu()
             return [reg.decode_ransac_result(host[p], n) for p in range(batch.P)]
+        # SC2-PCR path (scripts/test_kitti.py:179-181): Matcher.estimator re-samples both clouds to
+        # num_node with replacement, matches them and registers the matched pairs
         results = []
+        rng = np.random.RandomState(seed)
         for p in range(batch.P):
-            idx = nn_idx[p * n:(p + 1) * n]
-            T, fit = self.matcher.SC2_PCR(batch.xyz0[p][None], batch.xyz1[p].index_select(0, idx)[None])
+            T, _, _, _, _ = self.matcher.estimator(batch.xyz0[p][None], batch.xyz1[p][None], F0[p * n:(p + 1) * n][None],
+                                                   F1[p * n:(p + 1) * n][None], rng=rng)
             results.append(T[0])
         T = torch.stack(results)
         return T if return_device else [reg.RegistrationResult(t.cpu().numpy().astype(np.float64), 0.0, 0.0) for t in T]

@@ -97,10 +97,13 @@ class Matcher:
         self.k2 = k2
         self.heatmap = heatmap
 
-    def _params(self):
-        return _lib.Sc2pcrParams(float(self.inlier_threshold), float(self.d_thre), float(self.ratio),
+    def _params(self, n):
+        # the library takes int(ratio * n) seeds; hand it a ratio that floors to exactly Python's
+        # int(num_corr * self.ratio) whatever fp32 does to the literal
+        n_seed = int(n * self.ratio)
+        return _lib.Sc2pcrParams(float(self.inlier_threshold), float(self.d_thre), (n_seed + 0.5) / n,
                                  float(self.nms_radius), int(self.num_iterations), int(self.max_points),
-                                 int(self.k1), int(self.k2))
+                                 int(self.k1), int(self.k2)), n_seed
 
     def match_pair(self, src_keypts, tgt_keypts, src_features, tgt_features, rng=None):
         """:280-305.  ``rng`` replaces the reference's global ``np.random`` for the resampling to
@@ -132,8 +135,7 @@ class Matcher:
         n = min(t.shape[0], int(self.max_points))
         s, t = s[:n].contiguous(), t[:n].contiguous()
         lib = _lib.load()
-        p = self._params()
-        n_seed = int(n * self.ratio)
+        p, n_seed = self._params(n)
         T = torch.empty((1, 4, 4), dtype=torch.float32, device=s.device)
         fit = torch.zeros((1, max(n_seed, 1)), dtype=torch.float32, device=s.device)
         with torch.cuda.device(s.device):

@@ -1,0 +1,72 @@
+"""GPU parity: SC2-PCR (Matcher) through the C ABI vs the reference's golden poses and vs the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import _inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+
+def _golden(name):
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+
+
+def test_sc2pcr_matches_reference_golden_poses():
+    import eyoc_amd
+    from oracle import sc2pcr as osc
+    g = _golden("g4_sc2pcr.npz")
+    cfg = json.loads(str(g["cfg"]))
+    m = eyoc_amd.Matcher(**cfg)
+    mo = osc.Matcher(**cfg)
+    for i, (seed, n, frac, tp) in enumerate(json.loads(str(g["cases"]))):
+        p0, p1, _ = gi.corr_case(seed, n, gi.rigid(*tp), frac, noise=0.03)
+        T, fit = m.SC2_PCR(torch.from_numpy(p0)[None].cuda(), torch.from_numpy(p1)[None].cuda())
+        assert T.shape == (1, 4, 4) and fit.shape == (1, int(n * cfg["ratio"]))
+        np.testing.assert_allclose(T[0].cpu().numpy(), g[f"T{i}"], rtol=0, atol=2e-4, err_msg=f"case {i}")
+        assert float(fit.max()) == pytest.approx(float(g[f"fitmax{i}"]), abs=2)
+        # seed-wise fitness: same multiset of hypotheses as the oracle up to tie-breaking noise
+        To, fo = mo.SC2_PCR(torch.from_numpy(p0)[None], torch.from_numpy(p1)[None])
+        assert abs(float(fit.sum()) - float(fo.sum())) <= 0.02 * float(fo.sum()) + 10
+
+
+def test_sc2pcr_small_inputs_and_estimator():
+    import eyoc_amd
+    from oracle import sc2pcr as osc
+    T = gi.rigid(0.01, 0.0, 0.08, 3.0, 0.2, 0.0)
+    p0, p1, _ = gi.corr_case(81, 20, T, 1.0, noise=0.01)          # k1 > n -> k1 = k2 = 4 branch
+    m = eyoc_amd.Matcher(**osc.KITTI_CFG)
+    Tg, fit = m.SC2_PCR(torch.from_numpy(p0)[None].cuda(), torch.from_numpy(p1)[None].cuda())
+    To, _ = osc.Matcher(**osc.KITTI_CFG).SC2_PCR(torch.from_numpy(p0)[None], torch.from_numpy(p1)[None])
+    np.testing.assert_allclose(Tg[0].cpu().numpy(), To[0].numpy(), atol=5e-4)
+    # estimator: descriptors that identify the correspondence exactly
+    n = 600
+    q0, q1, _ = gi.corr_case(82, n, T, 1.0, noise=0.01)
+    F = gi.unit_feats(83, n)
+    perm = np.random.default_rng(0).permutation(n)
+    mm = eyoc_amd.Matcher(**{**osc.KITTI_CFG, "num_node": "all"})
+    out = mm.estimator(torch.from_numpy(q0)[None].cuda(), torch.from_numpy(q1[perm])[None].cuda(),
+                       torch.from_numpy(F)[None].cuda(), torch.from_numpy(F[perm])[None].cuda())
+    Te, labels, sc, tc, fitness = out
+    np.testing.assert_allclose(Te[0].cpu().numpy(), T, atol=0.02)
+    assert labels.shape == (1, n) and labels.mean() > 0.95
+    np.testing.assert_allclose(tc[0].cpu().numpy(), q1, atol=1e-6)   # matching undid the permutation
+    with pytest.raises(NotImplementedError):
+        mm.SC2_PCR(torch.zeros(2, 10, 3).cuda(), torch.zeros(2, 10, 3).cuda())
+
+
+def test_sc2pcr_kitti_sized_problem_recovers_pose():
+    """N = 8000 correspondences as produced by match_pair's resampling (37 % duplicates), 25 % inliers."""
+    import eyoc_amd
+    from oracle import sc2pcr as osc
+    T = gi.rigid(0.0, 0.01, 0.1, 11.0, -0.3, 0.05)
+    p0, p1, inl = gi.corr_case(91, 5000, T, 0.25, noise=0.03)
+    sel = np.random.default_rng(1).choice(5000, 8000)
+    m = eyoc_amd.Matcher(**osc.KITTI_CFG)
+    Tg, fit = m.SC2_PCR(torch.from_numpy(p0[sel])[None].cuda(), torch.from_numpy(p1[sel])[None].cuda())
+    rte, rre, ok = eyoc_amd.registration_errors(Tg[0].cpu().numpy(), T)
+    assert ok and rte < 0.05 and rre < np.deg2rad(0.2)
+    assert fit.shape == (1, 1600)
