@@ -188,6 +188,15 @@ def main():
             "success_rate": float(np.mean([e["success"] for e in evals])),
         }
         log("timed region done; cpu baseline next")
+        # HBM traffic of the same kernels from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
+        # correction + WRITE_SIZE, separate passes; profiles/README.md) - only quoted for the profiled workload
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r1_spconv_traffic.json")))
+            if prof["workload"] == out["config"]["workload"]:
+                out["roofline"]["traffic"] = (prof["spconv_read_GB_per_forward_x2corr"] + prof["spconv_write_GB_per_forward"]) * 1e9
+                out["roofline"]["traffic_source"] = "profiles/r1_spconv_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+        except (OSError, KeyError, ValueError):
+            pass
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pairs[0], sd)
         else:

@@ -1,0 +1,50 @@
+"""Turn the rocprofv3 outputs merged under gpurun_out/ into the small summaries committed under
+profiles/ (the raw traces stay in scratch).  Usage: python scripts/summarize_profiles.py <tag>
+expects gpurun_out/<tag>_trace, <tag>_fetch, <tag>_write (see profiles/README.md for the commands)."""
+import json
+import os
+import re
+import shutil
+import sys
+
+import pandas as pd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+out = os.path.join(ROOT, "profiles")
+os.makedirs(out, exist_ok=True)
+g = os.path.join(ROOT, "gpurun_out")
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name).replace("void ", "")
+    return re.sub(r"\(.*", "", name)[:70]
+
+
+shutil.copy(os.path.join(g, f"{tag}_trace", f"{tag}_kernel_stats.csv"), os.path.join(out, f"{tag}_kernel_stats.csv"))
+bench = [l for l in open(os.path.join(g, f"{tag}_trace.log")) if l.startswith("{")][-1]
+open(os.path.join(out, f"{tag}_bench_under_rocprof.json"), "w").write(bench)
+steps = json.loads(bench)["steps"] + json.loads(bench)["warmup"]
+
+rows = {}
+for kind, col in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    df = pd.read_csv(os.path.join(g, f"{tag}_{kind}", f"{tag}_counter_collection.csv"))
+    df = df[df.Counter_Name == col]
+    df["kernel"] = df["Kernel_Name"].map(short)
+    for k, grp in df.groupby("kernel"):
+        r = rows.setdefault(k, {"kernel": k, "launches": len(grp)})
+        r[col + "_KB_total"] = float(grp.Counter_Value.sum())
+t = pd.DataFrame(rows.values()).fillna(0.0)
+# MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads
+t["hbm_read_GB_per_step_x2corr"] = t["FETCH_SIZE_KB_total"] * 1024 * 2 / steps / 1e9
+t["hbm_write_GB_per_step"] = t["WRITE_SIZE_KB_total"] * 1024 / steps / 1e9
+t = t.sort_values("hbm_read_GB_per_step_x2corr", ascending=False)
+t.to_csv(os.path.join(out, f"{tag}_hbm_traffic.csv"), index=False)
+sp = t[t.kernel.str.startswith("spconv_kernel")]
+summary = {"steps_profiled": steps,
+           "spconv_read_GB_per_forward_x2corr": float(sp.hbm_read_GB_per_step_x2corr.sum()),
+           "spconv_read_GB_per_forward_raw": float(sp.FETCH_SIZE_KB_total.sum() * 1024 / steps / 1e9),
+           "spconv_write_GB_per_forward": float(sp.hbm_write_GB_per_step.sum()),
+           "workload": json.loads(bench)["config"]["workload"]}
+json.dump(summary, open(os.path.join(out, f"{tag}_spconv_traffic.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))
