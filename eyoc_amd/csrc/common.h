@@ -114,4 +114,8 @@ struct eyoc_maps {
   int32_t* nbr_s1[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};    // [27][rows[l]]
   int32_t* nbr_down[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};  // [l]: [27][rows[l+1]]
   int32_t* nbr_up[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};    // [l]: [27][rows[l]]
+  // octree links between consecutive levels: parent[l][row of level l] = row of level l+1;
+  // children[l][row of level l+1][8] = rows of level l (slot = x-bit | y-bit << 1 | z-bit << 2) or -1
+  int32_t* parent[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
+  int32_t* children[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
 };

@@ -7,6 +7,12 @@
 //    smallest row index that mapped to it - this makes "first occurrence" deterministic.
 //  * level l+1 = unique floor(c / 2ts) * 2ts of level l: insert coarse keys, flag the rows that won
 //    their slot, exclusive-scan the flags, compact -> coarse rows ordered by first occurrence.
+//  * every fine row records its coarse parent and every coarse row its (up to 8) children, so the
+//    levels form an octree.  Only the COARSEST level's 27-neighbour table is found by hash probes;
+//    every finer table (stride-1, strided, transposed) is derived top-down from the table one level
+//    up: a neighbour of a voxel lives in one of 8 coarse blocks around its parent, and is that
+//    block's child in a known slot.  Per fine row that is 8 table reads + 8 child vectors instead of
+//    27 + 27 + 27 hash probes (3/4 of which would be misses that walk a probe chain).
 //  * rulebooks are output-stationary tables nbr[27][n_out] (k-major so that the 64 rows of a wave
 //    read/write one contiguous segment per offset).
 #include "common.h"
@@ -148,6 +154,84 @@ __global__ void k_neighbours(const int32_t* __restrict__ coords_out, int n_out, 
   }
 }
 
+// octree links for the rows of level l (tensor stride 1 << sh): slot[] / vals still describe where each
+// fine row landed in the coarse table, and k_compact has re-labelled vals with coarse row indices
+__global__ void k_children(const int* __restrict__ slot, const int* __restrict__ vals, const int32_t* __restrict__ coords,
+                           int n, int sh, int32_t* __restrict__ parent, int32_t* __restrict__ children) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = reinterpret_cast<const int4*>(coords)[i];
+  const int p = vals[slot[i]];
+  const int cs = ((c.y >> sh) & 1) | (((c.z >> sh) & 1) << 1) | (((c.w >> sh) & 1) << 2);
+  parent[i] = p;
+  children[(size_t)p * 8 + cs] = i;
+}
+
+// stride-1 table and transposed (2ts -> ts) table of level l from the stride-1 table of level l+1.
+// For fine row o with parity bits b and parent p, offset `off` on an axis reaches position b + off:
+//   -1 -> coarse block at -1, child bit 1;  0 / 1 -> own block, bit 0 / 1;  2 -> coarse block at +1, bit 0.
+__global__ void k_derive_fine(const int32_t* __restrict__ coords, int n, int sh, const int32_t* __restrict__ parent,
+                              const int32_t* __restrict__ children, const int32_t* __restrict__ s1c, int nc,
+                              int32_t* __restrict__ s1, int32_t* __restrict__ up) {
+  int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n) return;
+  const int4 c = reinterpret_cast<const int4*>(coords)[o];
+  const int b[3] = {(c.y >> sh) & 1, (c.z >> sh) & 1, (c.w >> sh) & 1};
+  const int p = parent[o];
+  int blk[8];   // a bit per axis: 0 = own coarse block, 1 = the neighbouring block on the side this voxel leans to
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const int ox = (a & 1) ? (b[0] ? 1 : -1) : 0, oy = (a & 2) ? (b[1] ? 1 : -1) : 0, oz = (a & 4) ? (b[2] ? 1 : -1) : 0;
+    const int kc = (ox + 1) + 3 * (oy + 1) + 9 * (oz + 1);
+    blk[a] = a == 0 ? p : s1c[(size_t)kc * nc + p];
+  }
+#pragma unroll 1
+  for (int k = 0; k < 27; ++k) {
+    const int off[3] = {k % 3 - 1, (k / 3) % 3 - 1, k / 9 - 1};
+    int a = 0, cs = 0, a_up = 0;
+    bool up_ok = true;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      const int t = b[ax] + off[ax];
+      a |= ((t < 0 || t > 1) ? 1 : 0) << ax;
+      cs |= (t & 1) << ax;
+      // transposed map: c_u - off*ts must be a coarse coordinate: even position needs off == 0,
+      // odd position needs off == +1 (the parent) or off == -1 (the next block)
+      up_ok = up_ok && (b[ax] ? off[ax] != 0 : off[ax] == 0);
+      a_up |= ((b[ax] && off[ax] < 0) ? 1 : 0) << ax;
+    }
+    const int B = blk[a];
+    s1[(size_t)k * n + o] = B >= 0 ? children[(size_t)B * 8 + cs] : -1;
+    if (up) up[(size_t)k * n + o] = up_ok ? blk[a_up] : -1;
+  }
+}
+
+// strided (ts -> 2ts) table: for coarse row v the fine row at c_v + off*ts:
+//   off -1 -> coarse block at -1, child bit 1;  off 0 / +1 -> own block, bit 0 / 1.
+__global__ void k_derive_down(int nc, const int32_t* __restrict__ children, const int32_t* __restrict__ s1c,
+                              int32_t* __restrict__ down) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nc) return;
+  int blk[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const int kc = (1 - (a & 1)) + 3 * (1 - ((a >> 1) & 1)) + 9 * (1 - ((a >> 2) & 1));
+    blk[a] = a == 0 ? v : s1c[(size_t)kc * nc + v];
+  }
+#pragma unroll 1
+  for (int k = 0; k < 27; ++k) {
+    const int off[3] = {k % 3 - 1, (k / 3) % 3 - 1, k / 9 - 1};
+    int a = 0, cs = 0;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      a |= (off[ax] < 0 ? 1 : 0) << ax;
+      cs |= (off[ax] != 0 ? 1 : 0) << ax;
+    }
+    const int B = blk[a];
+    down[(size_t)k * nc + v] = B >= 0 ? children[(size_t)B * 8 + cs] : -1;
+  }
+}
+
 __global__ void k_count_valid(const int32_t* __restrict__ t, long long n, unsigned long long* __restrict__ out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -193,6 +277,7 @@ size_t eyoc_maps_workspace_bytes(int n_rows) {
   b += EYOC_MAX_LEVELS * align_up(n * 16);                           // coordinates
   b += 10 * align_up(n * 27 * 4);                                    // 4 s1 + 3 down + 3 up tables
   b += 3 * align_up(n * 4) + align_up((n / SCAN_TILE + 2) * 4);      // slot, flag, partial sums
+  b += 3 * (align_up(n * 4) + align_up(n * 32));                     // parent / children links
   b += 4096;                                                         // counters
   return b + 64 * 256;
 }
@@ -267,25 +352,32 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
     m->coords[l] = cv.take<int32_t>((size_t)m->rows[l] * 4);
     hipLaunchKernelGGL(k_compact, dim3(nb), dim3(SCAN_BLOCK), 0, st, flag, partial, slot, src, n_src, ts2,
                        m->coords[l], t.vals);
+    // octree links fine (l-1) <-> coarse (l); same stream, so k_compact's re-labelling is visible
+    m->parent[l - 1] = cv.take<int32_t>((size_t)n_src);
+    m->children[l - 1] = cv.take<int32_t>((size_t)m->rows[l] * 8);
+    FAIL_HIP(hipMemsetAsync(m->children[l - 1], 0xFF, (size_t)m->rows[l] * 32, st));
+    hipLaunchKernelGGL(k_children, dim3(cdiv(n_src, 256)), dim3(256), 0, st, slot, t.vals, src, n_src, l - 1,
+                       m->parent[l - 1], m->children[l - 1]);
   }
-  // ---- rulebooks
+  // ---- rulebooks: hash probes at the coarsest level only, everything else derived top-down
   for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
-    const int nl = m->rows[l];
-    const int ts = 1 << l;
-    m->nbr_s1[l] = cv.take<int32_t>((size_t)27 * nl);
-    hipLaunchKernelGGL(k_neighbours, dim3(cdiv(nl, 256)), dim3(256), 0, st, m->coords[l], nl, m->table[l], ts, 1,
-                       m->nbr_s1[l]);
+    m->nbr_s1[l] = cv.take<int32_t>((size_t)27 * m->rows[l]);
     if (l + 1 < EYOC_MAX_LEVELS) {
-      const int nc = m->rows[l + 1];
-      // strided conv ts -> 2ts: for coarse row v the fine row at c_v + off * ts
-      m->nbr_down[l] = cv.take<int32_t>((size_t)27 * nc);
-      hipLaunchKernelGGL(k_neighbours, dim3(cdiv(nc, 256)), dim3(256), 0, st, m->coords[l + 1], nc, m->table[l], ts,
-                         1, m->nbr_down[l]);
-      // transposed conv 2ts -> ts: for fine row u the coarse row at c_u - off * ts
-      m->nbr_up[l] = cv.take<int32_t>((size_t)27 * nl);
-      hipLaunchKernelGGL(k_neighbours, dim3(cdiv(nl, 256)), dim3(256), 0, st, m->coords[l], nl, m->table[l + 1], ts,
-                         -1, m->nbr_up[l]);
+      m->nbr_down[l] = cv.take<int32_t>((size_t)27 * m->rows[l + 1]);
+      m->nbr_up[l] = cv.take<int32_t>((size_t)27 * m->rows[l]);
     }
+  }
+  {
+    const int top = EYOC_MAX_LEVELS - 1;
+    hipLaunchKernelGGL(k_neighbours, dim3(cdiv(m->rows[top], 256)), dim3(256), 0, st, m->coords[top], m->rows[top],
+                       m->table[top], 1 << top, 1, m->nbr_s1[top]);
+  }
+  for (int l = EYOC_MAX_LEVELS - 2; l >= 0; --l) {
+    const int nl = m->rows[l], nc = m->rows[l + 1];
+    hipLaunchKernelGGL(k_derive_fine, dim3(cdiv(nl, 256)), dim3(256), 0, st, m->coords[l], nl, l, m->parent[l],
+                       m->children[l], m->nbr_s1[l + 1], nc, m->nbr_s1[l], m->nbr_up[l]);
+    hipLaunchKernelGGL(k_derive_down, dim3(cdiv(nc, 256)), dim3(256), 0, st, nc, m->children[l], m->nbr_s1[l + 1],
+                       m->nbr_down[l]);
   }
   FAIL_HIP(hipGetLastError());
 #undef FAIL_HIP

@@ -260,6 +260,7 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
       a.coords = maps->coords[0]; a.n = n_out; a.table = maps->table[0]; a.ks = m->desc.conv1_kernel_size;
       a.in = buf[p.in_buf]; a.cin = p.cin; a.w = m->blob + p.w_off; a.bias = m->blob + p.b_off; a.cout = p.cout;
       a.out = buf[p.out_buf] + p.out_col; a.ld_out = m->bufs[p.out_buf].width;
+      a.parent = maps->parent[0]; a.children = maps->children[0]; a.s1c = maps->nbr_s1[1]; a.nc = maps->rows[1];
       rc = launch_conv1(a, st);
     } else {
       SpconvArgs a;

@@ -39,6 +39,12 @@ struct Conv1Args {
   int cout;               // 32 <= cout <= 128, multiple of 32
   float* out;             // rows of ld_out floats
   int ld_out;
+  // octree links (level 0 <-> 1) and the level-1 stride-1 table: with them a 3^3 / 5^3 window is read
+  // from the 27 coarse blocks around the parent without any hash probe; NULL -> probe the hash table
+  const int32_t* parent;    // [n]
+  const int32_t* children;  // [nc][8]
+  const int32_t* s1c;       // [27][nc]
+  int nc;
 };
 int launch_conv1(const Conv1Args& a, hipStream_t st);
 

@@ -443,6 +443,61 @@ __global__ __launch_bounds__(256) void conv1_kernel(Conv1Args a) {
   }
 }
 
+// Same convolution without hash probes: the ks^3 window (ks = 3 or 5) of a voxel lies inside the 27
+// level-1 blocks around its parent, whose rows come from the level-1 stride-1 table and whose
+// occupants come from the 8-entry child vectors (one 32-byte read per block).  ~1 KB of table reads
+// per output row instead of 125 probes of a 64-bit-key hash table.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv1_tree_kernel(Conv1Args a) {
+  constexpr int LDW = COUT + 4;   // padded weight rows: lanes hold different offsets k, keep them on different banks
+  extern __shared__ float wsm[];
+  const int K = a.ks * a.ks * a.ks, r = a.ks / 2;
+  for (int i = threadIdx.x; i < K * a.cin * COUT; i += 256) wsm[(i / COUT) * LDW + i % COUT] = a.w[i];
+  __syncthreads();
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= a.n) return;
+  const int4 c = reinterpret_cast<const int4*>(a.coords)[o];
+  const int bx = c.y & 1, by = c.z & 1, bz = c.w & 1;
+  const int p = a.parent[o];
+  float acc[COUT];
+#pragma unroll
+  for (int i = 0; i < COUT; ++i) acc[i] = 0.0f;
+#pragma unroll 1
+  for (int kc = 0; kc < 27; ++kc) {
+    const int ox = kc % 3 - 1, oy = (kc / 3) % 3 - 1, oz = kc / 9 - 1;
+    const int B = kc == 13 ? p : a.s1c[(size_t)kc * a.nc + p];
+    if (B < 0) continue;
+    const int4 lo = reinterpret_cast<const int4*>(a.children)[2 * (size_t)B];
+    const int4 hi = reinterpret_cast<const int4*>(a.children)[2 * (size_t)B + 1];
+    const int ch[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int cs = 0; cs < 8; ++cs) {
+      const int idx = ch[cs];
+      const int dx = 2 * ox + (cs & 1) - bx, dy = 2 * oy + ((cs >> 1) & 1) - by, dz = 2 * oz + (cs >> 2) - bz;
+      if (idx < 0 || dx < -r || dx > r || dy < -r || dy > r || dz < -r || dz > r) continue;
+      const int k = (dx + r) + a.ks * (dy + r) + a.ks * a.ks * (dz + r);
+      for (int ci = 0; ci < a.cin; ++ci) {
+        const float f = a.in[(size_t)idx * a.cin + ci];
+        const float4* wk = reinterpret_cast<const float4*>(wsm + (k * a.cin + ci) * LDW);
+#pragma unroll
+        for (int i = 0; i < COUT / 4; ++i) {
+          const float4 w4 = wk[i];
+          acc[4 * i] = fmaf(f, w4.x, acc[4 * i]); acc[4 * i + 1] = fmaf(f, w4.y, acc[4 * i + 1]);
+          acc[4 * i + 2] = fmaf(f, w4.z, acc[4 * i + 2]); acc[4 * i + 3] = fmaf(f, w4.w, acc[4 * i + 3]);
+        }
+      }
+    }
+  }
+  float* dst = a.out + (size_t)o * a.ld_out;
+#pragma unroll
+  for (int i = 0; i < COUT; i += 4) {
+    float4 v;
+    v.x = acc[i] + a.bias[i]; v.y = acc[i + 1] + a.bias[i + 1];
+    v.z = acc[i + 2] + a.bias[i + 2]; v.w = acc[i + 3] + a.bias[i + 3];
+    *reinterpret_cast<float4*>(dst + i) = v;
+  }
+}
+
 }  // namespace
 
 namespace eyoc {
@@ -477,6 +532,19 @@ int launch_conv1(const Conv1Args& a, hipStream_t st) {
   EYOC_REQUIRE(a.ld_out % 4 == 0, EYOC_ERR_INVALID, "conv1: ld_out must be a multiple of 4");
   if (a.n == 0) return EYOC_OK;
   dim3 grid(cdiv(a.n, 256));
+  const size_t tree_lds = (size_t)a.ks * a.ks * a.ks * a.cin * (a.cout + 4) * sizeof(float);
+  if (a.parent && a.children && a.s1c && (a.ks == 3 || a.ks == 5) && tree_lds <= 64 * 1024) {
+    switch (a.cout) {
+      case 32: hipLaunchKernelGGL(conv1_tree_kernel<32>, grid, dim3(256), tree_lds, st, a); break;
+      case 64: hipLaunchKernelGGL(conv1_tree_kernel<64>, grid, dim3(256), tree_lds, st, a); break;
+      case 128: hipLaunchKernelGGL(conv1_tree_kernel<128>, grid, dim3(256), tree_lds, st, a); break;
+      default:
+        set_error("conv1: C_out %d not in {32,64,128}", a.cout);
+        return EYOC_ERR_INVALID;
+    }
+    EYOC_CHECK_HIP(hipGetLastError());
+    return EYOC_OK;
+  }
   switch (a.cout) {
     case 32: hipLaunchKernelGGL(conv1_kernel<32>, grid, dim3(256), 0, st, a); break;
     case 64: hipLaunchKernelGGL(conv1_kernel<64>, grid, dim3(256), 0, st, a); break;
