@@ -32,6 +32,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int KMAX = 27;
 
+// Diagnostic build (-DEYOC_TRACE, scripts/trace_spconv.py): a few workgroups stamp s_memtime at their
+// phase boundaries.  Expands to nothing in the production build.
+#ifdef EYOC_TRACE
+constexpr int TRACE_STAMPS = 512, TRACE_WAVES = 8, TRACE_BLOCKS = 8;
+__device__ unsigned long long g_trace[TRACE_BLOCKS * TRACE_WAVES * TRACE_STAMPS];
+#define TR_DECL const int tr_blk = (blockIdx.x >= 300 && blockIdx.x < 300 + TRACE_BLOCKS && blockIdx.y == 0) ? (int)blockIdx.x - 300 : -1; int tr_n = 0
+#define TR() do { if (tr_blk >= 0 && (threadIdx.x & 63) == 0 && tr_n < TRACE_STAMPS) \
+    g_trace[(tr_blk * TRACE_WAVES + (threadIdx.x >> 6)) * TRACE_STAMPS + tr_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TR_DECL
+#define TR()
+#endif
+
 template <int CT, int BM, int NW, int CC>
 struct Cfg {
   static constexpr int THREADS = NW * 64;
@@ -39,7 +52,9 @@ struct Cfg {
   static constexpr int NWN = NW < NTILES ? NW : NTILES;        // waves along the output channels
   static constexpr int NWM = NW / NWN;                         // waves along the pair chunks
   static constexpr int NTW = NTILES / NWN;                     // column tiles per wave
-  static constexpr int SUB = BM < 64 ? BM : 64;                // pairs staged per item (<= 4 chunks)
+  // pairs staged per item (<= 4 chunks).  Staging the whole 128-row tile per offset (27 items instead of
+  // ~38) was measured 5 % SLOWER on MI355X: the time goes with the pairs, not with the item count.
+  static constexpr int SUB = BM < 64 ? BM : 64;
   static constexpr int SCH = SUB / 16;                         // chunks per item
   static constexpr int MAXCW = SCH / NWM;                      // chunks per wave per item
   static constexpr int GCH = (SCH + NW - 1) / NW;              // chunks each wave gathers per item
@@ -48,18 +63,19 @@ struct Cfg {
   static constexpr int RPI = 64 / P;                           // rows covered by one gather instruction
   static constexpr int NI = 16 / RPI;                          // gather instructions per chunk
   static constexpr int TILE_FLOATS = CC * CT;                  // one packed weight tile
-  static constexpr int ACC_LD = CT + 4;                        // padded accumulator row (keeps float4 alignment)
+  static constexpr int ACC_LD = CT;                            // accumulator row; float4 columns XOR-swizzled by the row
+  static constexpr int C4N = CT / 4;                           // float4 columns per accumulator row
   static constexpr int MAX_ITEMS = KMAX * (BM / SUB);
-  static constexpr int OFF_PAIR_IN = 0;                                      // int [KMAX][BM]
-  static constexpr int OFF_PAIR_OUT = OFF_PAIR_IN + KMAX * BM * 4;           // u8  [KMAX][BM]
-  static constexpr int OFF_CNT = OFF_PAIR_OUT + KMAX * BM;                   // int [KMAX] counts + [1] n_items
+  static constexpr int OFF_PAIR_IN = 0;                                      // u32 [KMAX][BM]: input row << 8 | local output row
+  static constexpr int OFF_CNT = OFF_PAIR_IN + KMAX * BM * 4;                // int [KMAX] counts + [1] n_items
   static constexpr int OFF_ITEMS = OFF_CNT + (KMAX + 1) * 4;                 // u32 [MAX_ITEMS + 2]: k | sub << 8 | pairs << 16
   static constexpr int OFF_A = (OFF_ITEMS + (MAX_ITEMS + 2) * 4 + 15) / 16 * 16;  // float [SUB][CC] (XOR-swizzled pieces)
   static constexpr int OFF_ACC = OFF_A + SUB * CC * 4;                       // float [BM][ACC_LD]
   static constexpr int OFF_NORM = OFF_ACC + BM * ACC_LD * 4;                 // float [BM]
   static constexpr int LDS_BYTES = OFF_NORM + BM * 4;
   static_assert(NWN * NWM == NW && NTW * NWN == NTILES && MAXCW >= 1 && MAXCW * NWM == SCH, "wave grid must tile the block");
-  static_assert(BM % SUB == 0 && BM <= 256, "BM must be a multiple of SUB and fit the u8 local row index");
+  static_assert(BM % SUB == 0 && BM <= 256, "BM must be a multiple of SUB; the local output row is packed in 8 bits");
+  static_assert(LDS_BYTES <= 80 * 1024, "two workgroups must fit one CU");
 };
 
 // One workgroup = BM output rows x CT output channels.  Waves split the OUTPUT CHANNELS (and, when
@@ -78,15 +94,19 @@ template <int CT, int BM, int NW, int CC>
 __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 4 : 2)) void spconv_kernel(SpconvArgs a) {
   using C = Cfg<CT, BM, NW, CC>;
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
-  int* pair_in = reinterpret_cast<int*>(smem + C::OFF_PAIR_IN);
-  unsigned char* pair_out = smem + C::OFF_PAIR_OUT;
+  unsigned int* pairs = reinterpret_cast<unsigned int*>(smem + C::OFF_PAIR_IN);
   int* cnt = reinterpret_cast<int*>(smem + C::OFF_CNT);
   int* n_items_p = cnt + KMAX;
   unsigned int* items = reinterpret_cast<unsigned int*>(smem + C::OFF_ITEMS);
   float* atile = reinterpret_cast<float*>(smem + C::OFF_A);
   float* acc = reinterpret_cast<float*>(smem + C::OFF_ACC);
   float* rnorm = reinterpret_cast<float*>(smem + C::OFF_NORM);
+  // accumulator element (row, float4 column): columns are XOR-swizzled by the row so that the 128-bit
+  // read-add-writes of lanes holding different rows spread over the banks without padding
+  auto acc_off = [](int row, int c4) { return row * C::ACC_LD + ((c4 ^ row) & (C::C4N - 1)) * 4; };
 
+  TR_DECL;
+  TR();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * BM;
   const int slice = blockIdx.y, n_slices = gridDim.y;
@@ -97,27 +117,40 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 4 : 2)) void spconv_kernel(Spco
   // ---- phase 0: zero the accumulator, compact the rulebook of this row tile
   for (int i = tid; i < BM * C::ACC_LD; i += C::THREADS) acc[i] = 0.0f;
   if (a.nbr) {
-    for (int k = wave; k < a.K; k += NW) {
-      const int32_t* col = a.nbr + (size_t)k * a.n_out + row0;
-      int base = 0;
-      for (int r0 = 0; r0 < BM; r0 += 64) {
-        const int r = r0 + lane;
-        const int idx = (r < rows_here) ? col[r] : -1;
-        const bool valid = idx >= 0;
-        const unsigned long long m = __ballot(valid);
-        if (valid) {
-          const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-          pair_in[k * BM + pos] = idx;
-          pair_out[k * BM + pos] = (unsigned char)r;
-        }
-        base += __popcll(m);
+    // all rulebook loads of this wave are issued back to back (one memory latency, not one per offset)
+    constexpr int KPW = (KMAX + NW - 1) / NW, RND = (BM + 63) / 64;
+    int idxv[KPW][RND];
+#pragma unroll
+    for (int kk = 0; kk < KPW; ++kk) {
+      const int k = wave + NW * kk;
+#pragma unroll
+      for (int r = 0; r < RND; ++r) {
+        const int row = r * 64 + lane;
+        idxv[kk][r] = (k < a.K && row < rows_here) ? a.nbr[(size_t)k * a.n_out + row0 + row] : -1;
       }
-      if (lane == 0) cnt[k] = base;
+    }
+#pragma unroll
+    for (int kk = 0; kk < KPW; ++kk) {
+      const int k = wave + NW * kk;
+      if (k < a.K) {
+        int base = 0;
+#pragma unroll
+        for (int r = 0; r < RND; ++r) {
+          const int idx = idxv[kk][r];
+          const bool valid = idx >= 0;
+          const unsigned long long m = __ballot(valid);
+          if (valid) {
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            pairs[k * BM + pos] = ((unsigned)idx << 8) | (unsigned)(r * 64 + lane);
+          }
+          base += __popcll(m);
+        }
+        if (lane == 0) cnt[k] = base;
+      }
     }
   } else {  // identity map (1x1 convolution)
     for (int r = tid; r < BM; r += C::THREADS) {
-      pair_in[r] = row0 + r;
-      pair_out[r] = (unsigned char)r;
+      pairs[r] = ((unsigned)(row0 + r) << 8) | (unsigned)r;
     }
     if (tid == 0) cnt[0] = rows_here;
   }
@@ -135,6 +168,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 4 : 2)) void spconv_kernel(Spco
   // from LDS are "divergent" to the compiler, and a divergent branch around an MFMA makes it copy
   // every accumulator at each region boundary (thousands of v_mov per item).
   const int n_items = __builtin_amdgcn_readfirstlane(*n_items_p);
+  TR();
 
   if (n_items > 0) {  // block-uniform
     const int r16 = lane & 15, g = lane >> 4;
@@ -165,7 +199,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 4 : 2)) void spconv_kernel(Spco
 #pragma unroll
         for (int i = 0; i < C::NI; ++i) {
           const int pl = (wave_s + NW * j) * 16 + i * C::RPI + grow;      // pair index inside the item
-          rows[j][i] = pl < d.n_here ? pair_in[d.k * BM + d.base + pl] : -1;
+          rows[j][i] = pl < d.n_here ? (int)(pairs[d.k * BM + d.base + pl] >> 8) : -1;
         }
     };
     // (2) global loads of the NEXT item: this wave's weight slice and its share of the gathered rows
@@ -187,11 +221,11 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 4 : 2)) void spconv_kernel(Spco
         }
     };
     // (3) stage -> LDS tile; piece index XOR (row & 15) keeps the fragment reads conflict free
-    auto commit = [&]() {
+    auto commit = [&](const Item& d) {   // only the chunks the item really has
 #pragma unroll
       for (int j = 0; j < C::GCH; ++j) {
         const int chunk = wave_s + NW * j;
-        if (chunk < C::SCH) {
+        if (chunk < d.nch) {
 #pragma unroll
           for (int i = 0; i < C::NI; ++i) {
             const int row = chunk * 16 + i * C::RPI + grow;
@@ -240,7 +274,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 4 : 2)) void spconv_kernel(Spco
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int pl = (wm_s + C::NWM * c) * 16 + r16;
-        orow[c] = pl < cur.n_here ? (int)pair_out[cur.k * BM + cur.base + pl] : -1;
+        orow[c] = pl < cur.n_here ? (int)(pairs[cur.k * BM + cur.base + pl] & 255u) : -1;
       }
       mfma_q(0);
       issue_loads(nxt, cc_n, rows);
@@ -260,7 +294,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 4 : 2)) void spconv_kernel(Spco
 #pragma unroll
           for (int t = 0; t < C::NTW; ++t)
             if (orow[c] >= 0)
-              old[c][t] = *reinterpret_cast<const float4*>(acc + orow[c] * C::ACC_LD + (wn_s * C::NTW + t) * 16 + g * 4);
+              old[c][t] = *reinterpret_cast<const float4*>(acc + acc_off(orow[c], (wn_s * C::NTW + t) * 4 + g));
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -268,7 +302,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 4 : 2)) void spconv_kernel(Spco
             if (orow[c] >= 0) {
               float4 v = old[c][t];
               v.x += accreg[c][t][0]; v.y += accreg[c][t][1]; v.z += accreg[c][t][2]; v.w += accreg[c][t][3];
-              *reinterpret_cast<float4*>(acc + orow[c] * C::ACC_LD + (wn_s * C::NTW + t) * 16 + g * 4) = v;
+              *reinterpret_cast<float4*>(acc + acc_off(orow[c], (wn_s * C::NTW + t) * 4 + g)) = v;
             }
       }
     };
@@ -280,10 +314,11 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 4 : 2)) void spconv_kernel(Spco
       read_gather_rows(cur, rows);
       issue_loads(cur, 0, rows);
     }
-    commit();
+    commit(cur);
     __syncthreads();
 
     while (true) {
+      TR();
       float4 bcur[C::NTW][C::JQ];
 #pragma unroll
       for (int t = 0; t < C::NTW; ++t)
@@ -308,21 +343,25 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 4 : 2)) void spconv_kernel(Spco
       if (my_nc == 1) body(std::integral_constant<int, 1>{}, cur, cc, nxt, cc_n, bcur);
       if (my_nc <= 0) body(std::integral_constant<int, 0>{}, cur, cc, nxt, cc_n, bcur);
 
+      TR();
       __syncthreads();   // everyone is done reading the staged tile
+      TR();
       if (last) break;
-      commit();
+      commit(nxt);
+      TR();
       __syncthreads();
       ii = ii_n; cc = cc_n; cur = nxt;
     }
   }  // n_items > 0
   __syncthreads();
+  TR();
 
   // ---- epilogue
   constexpr int C4 = CT / 4;
   if (a.l2norm) {
     for (int i = tid; i < BM * C4; i += C::THREADS) {
       const int r = i / C4, c4 = i % C4;
-      float4* p = reinterpret_cast<float4*>(acc + r * C::ACC_LD + c4 * 4);
+      float4* p = reinterpret_cast<float4*>(acc + acc_off(r, c4));
       float4 v = *p;
       if (a.bias) {
         const float4 b = *reinterpret_cast<const float4*>(a.bias + ct0 + c4 * 4);
@@ -334,7 +373,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 4 : 2)) void spconv_kernel(Spco
     for (int r = tid; r < BM; r += C::THREADS) {
       float s = 0.0f;
       for (int c = 0; c < CT; ++c) {
-        const float v = acc[r * C::ACC_LD + c];
+        const float v = acc[acc_off(r, c >> 2) + (c & 3)];
         s += v * v;
       }
       rnorm[r] = sqrtf(s);
@@ -345,7 +384,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 4 : 2)) void spconv_kernel(Spco
     const int r = i / C4, c4 = i % C4;
     if (r >= rows_here) continue;
     const size_t o = (size_t)(row0 + r);
-    float4 v = *reinterpret_cast<const float4*>(acc + r * C::ACC_LD + c4 * 4);
+    float4 v = *reinterpret_cast<const float4*>(acc + acc_off(r, c4));
     if (a.l2norm) {
       const float nrm = rnorm[r];
       v.x /= nrm; v.y /= nrm; v.z /= nrm; v.w /= nrm;
@@ -364,6 +403,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 4 : 2)) void spconv_kernel(Spco
     }
     *reinterpret_cast<float4*>(a.out + o * a.ld_out + ct0 + c4 * 4) = v;
   }
+  TR();
 }
 
 template <int CT, int BM, int NW, int CC>
@@ -558,6 +598,12 @@ int launch_conv1(const Conv1Args& a, hipStream_t st) {
 }
 
 }  // namespace eyoc
+
+#ifdef EYOC_TRACE
+extern "C" int eyoc_debug_trace(unsigned long long* out_host, size_t count) {
+  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_trace), count * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" {
 
