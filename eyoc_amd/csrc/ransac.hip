@@ -43,15 +43,17 @@ __device__ inline bool hypothesis(const float* __restrict__ src, const float* __
 #pragma unroll
     for (int d = 0; d < 3; ++d) { s[j][d] = src[3 * i + d]; q[j][d] = tc[3 * i + d]; }
   }
+  // edge-length checker on squared lengths (no square roots): ds < e*dt  <=>  ds^2 < e^2 dt^2
+  const double e2 = edge_sim * edge_sim;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = a + 1; b < 4; ++b) {
-      const double ds = sqrt((s[a][0] - s[b][0]) * (s[a][0] - s[b][0]) + (s[a][1] - s[b][1]) * (s[a][1] - s[b][1]) +
-                             (s[a][2] - s[b][2]) * (s[a][2] - s[b][2]));
-      const double dt = sqrt((q[a][0] - q[b][0]) * (q[a][0] - q[b][0]) + (q[a][1] - q[b][1]) * (q[a][1] - q[b][1]) +
-                             (q[a][2] - q[b][2]) * (q[a][2] - q[b][2]));
-      if (ds < dt * edge_sim || dt < ds * edge_sim) return false;
+      const double ds2 = (s[a][0] - s[b][0]) * (s[a][0] - s[b][0]) + (s[a][1] - s[b][1]) * (s[a][1] - s[b][1]) +
+                         (s[a][2] - s[b][2]) * (s[a][2] - s[b][2]);
+      const double dt2 = (q[a][0] - q[b][0]) * (q[a][0] - q[b][0]) + (q[a][1] - q[b][1]) * (q[a][1] - q[b][1]) +
+                         (q[a][2] - q[b][2]) * (q[a][2] - q[b][2]);
+      if (ds2 < dt2 * e2 || dt2 < ds2 * e2) return false;
     }
   double cs[3], cq[3];
 #pragma unroll

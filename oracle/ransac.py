@@ -12,7 +12,8 @@ counter-based sampler so that the HIP kernel can be checked hypothesis by hypoth
   1. correspondences: every source feature -> its nearest target feature (``mutual_filter=False``);
   2. per hypothesis h: draw 4 correspondence indices ``sample(seed, h, t) t=0..3``;
   3. edge-length checker on the 6 point pairs of the sample:
-     reject if ``|s_a - s_b| < 0.9 |t_a - t_b|`` or ``|t_a - t_b| < 0.9 |s_a - s_b|``;
+     reject if ``|s_a - s_b| < 0.9 |t_a - t_b|`` or ``|t_a - t_b| < 0.9 |s_a - s_b|`` (evaluated on the
+     squared lengths, which is the same predicate without square roots);
   4. rigid transform of the 4 pairs (Kabsch / ``Eigen::umeyama`` without scale);
   5. distance checker: reject unless all 4 residuals ``|T s - t| <= max_distance``;
   6. score on ALL correspondences: inliers = ``|T s - t| < max_distance``; fitness = inliers / n,
@@ -81,10 +82,11 @@ def ransac(src: np.ndarray, tgt: np.ndarray, corr_tgt: np.ndarray, max_distance:
         idx = sample_indices(seed, h0, cnt, n)
         s, t = S_all[idx], T_all[idx]                                    # [cnt,4,3]
         ok = np.ones(cnt, bool)
-        for a, b in pairs:
-            ds = np.linalg.norm(s[:, a] - s[:, b], axis=1)
-            dt = np.linalg.norm(t[:, a] - t[:, b], axis=1)
-            ok &= ~((ds < dt * edge_similarity) | (dt < ds * edge_similarity))
+        e2 = edge_similarity * edge_similarity
+        for a, b in pairs:   # squared form of the edge-length checker, as the kernel evaluates it
+            ds2 = ((s[:, a] - s[:, b]) ** 2).sum(1)
+            dt2 = ((t[:, a] - t[:, b]) ** 2).sum(1)
+            ok &= ~((ds2 < dt2 * e2) | (dt2 < ds2 * e2))
         cand = np.nonzero(ok)[0]
         if len(cand) == 0:
             continue

@@ -22,7 +22,7 @@ maps = cm.maps()
 lib = _lib.load()
 info = cm.info()
 print("rows", info["rows"], "pairs_s1", info["pairs_s1"], flush=True)
-cfgs = [("s1", 1, 64, 64), ("s1", 0, 64, 64), ("s1", 2, 128, 128), ("up", 0, 128, 64), ("s1", 0, 32, 32)]
+cfgs = [("s1", 1, 64, 64), ("s1", 0, 64, 64), ("s1", 2, 128, 128), ("up", 0, 128, 64), ("s1", 0, 32, 32), ("s1", 3, 256, 256), ("s1", 2, 64, 64)]
 if os.environ.get("ONE"):
     cfgs = cfgs[:1]
 for kind, lvl, cin, cout in cfgs:
