@@ -17,3 +17,4 @@ from .transform_estimation import (est_quad_linear_robust, estimate_transform, p
 from .registration import (Matcher, registration_ransac_based_on_feature_matching,  # noqa: F401
                            ransac_from_correspondences, RegistrationResult)
 from .metrics import registration_errors, apply_transform, evaluate_nn_dist  # noqa: F401
+from .voxelize import sparse_quantize, voxelize, extract_features  # noqa: F401

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_top(int* __restrict__ parti
 __global__ __launch_bounds__(SCAN_BLOCK) void k_compact(const int* __restrict__ flag, const int* __restrict__ partial,
                                                         const int* __restrict__ slot, const int32_t* __restrict__ coords,
                                                         int n, int ts2, int32_t* __restrict__ coords_out,
-                                                        int* __restrict__ vals) {
+                                                        int* __restrict__ vals, int32_t* __restrict__ sel_out) {
   const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
   int f[SCAN_ITEMS];
   int s = 0;
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_compact(const int* __restrict__ 
       int4 c = make_int4(b, x, y, z);
       reinterpret_cast<int4*>(coords_out)[pos] = c;
       vals[slot[i]] = pos;
+      if (sel_out) sel_out[pos] = i;
       ++pos;
     }
   }
@@ -152,6 +153,16 @@ __global__ void k_neighbours(const int32_t* __restrict__ coords_out, int n_out, 
     const int dx = (k % 3 - 1) * d, dy = ((k / 3) % 3 - 1) * d, dz = (k / 9 - 1) * d;
     nbr[(size_t)k * n_out + o] = hash_lookup(tin, pack_key(c.x, c.y + dx, c.z + dy, c.w + dz));
   }
+}
+
+// voxel coordinates of raw points: floor(x / voxel) in fp32 (IEEE division, like torch / numpy on fp32 input)
+__global__ void k_quantize(const float* __restrict__ xyz, int n, int stride, float voxel, int batch,
+                           int32_t* __restrict__ coords) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = xyz + (size_t)i * stride;
+  int4 c = make_int4(batch, (int)floorf(p[0] / voxel), (int)floorf(p[1] / voxel), (int)floorf(p[2] / voxel));
+  reinterpret_cast<int4*>(coords)[i] = c;
 }
 
 // octree links for the rows of level l (tensor stride 1 << sh): slot[] / vals still describe where each
@@ -351,7 +362,7 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
     m->rows[l] = host[0];
     m->coords[l] = cv.take<int32_t>((size_t)m->rows[l] * 4);
     hipLaunchKernelGGL(k_compact, dim3(nb), dim3(SCAN_BLOCK), 0, st, flag, partial, slot, src, n_src, ts2,
-                       m->coords[l], t.vals);
+                       m->coords[l], t.vals, (int32_t*)nullptr);
     // octree links fine (l-1) <-> coarse (l); same stream, so k_compact's re-labelling is visible
     m->parent[l - 1] = cv.take<int32_t>((size_t)n_src);
     m->children[l - 1] = cv.take<int32_t>((size_t)m->rows[l] * 8);
@@ -387,6 +398,54 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
     return EYOC_ERR_WORKSPACE;
   }
   *out = m;
+  return EYOC_OK;
+}
+
+// ---- voxeliser: first point of every occupied voxel, in input order
+size_t eyoc_voxelize_workspace_bytes(int n_points) {
+  if (n_points < 0) return 0;
+  const size_t n = (size_t)n_points, cap = table_capacity(n_points);
+  return align_up(cap * 8) + align_up(cap * 4) + align_up(n * 16) + 3 * align_up(n * 4) +
+         align_up((n / SCAN_TILE + 2) * 4) + 4096 + 16 * 256;
+}
+
+int eyoc_voxelize(eyoc_ctx* ctx, const float* xyz_dev, int n, int stride, float voxel_size, int batch_index,
+                  int32_t* sel_dev, int32_t* coords_dev, int* n_out, void* ws, size_t ws_bytes, void* stream) {
+  EYOC_REQUIRE(ctx && xyz_dev && sel_dev && coords_dev && n_out && ws, EYOC_ERR_INVALID, "eyoc_voxelize: NULL argument");
+  EYOC_REQUIRE(n > 0 && stride >= 3 && voxel_size > 0.0f, EYOC_ERR_INVALID, "eyoc_voxelize: n %d stride %d voxel %g", n,
+               stride, voxel_size);
+  EYOC_REQUIRE(batch_index >= 0 && batch_index < 1024, EYOC_ERR_RANGE, "eyoc_voxelize: batch index %d", batch_index);
+  EYOC_REQUIRE(((uintptr_t)ws & 255) == 0 && ws_bytes >= eyoc_voxelize_workspace_bytes(n), EYOC_ERR_WORKSPACE,
+               "eyoc_voxelize: workspace %zu < required %zu bytes (256-byte aligned)", ws_bytes,
+               eyoc_voxelize_workspace_bytes(n));
+  hipStream_t st = (hipStream_t)stream;
+  Carver cv(ws, ws_bytes);
+  int* counters = cv.take<int>(64);
+  int32_t* raw = cv.take<int32_t>((size_t)n * 4);
+  int* slot = cv.take<int>(n);
+  int* flag = cv.take<int>(n);
+  int* partial = cv.take<int>(n / SCAN_TILE + 2);
+  HashTable t;
+  const unsigned int cap = table_capacity(n);
+  t.keys = cv.take<unsigned long long>(cap);
+  t.vals = cv.take<int>(cap);
+  t.mask = cap - 1;
+  EYOC_CHECK_HIP(hipMemsetAsync(counters, 0, 64 * sizeof(int), st));
+  EYOC_CHECK_HIP(hipMemsetAsync(t.keys, 0xFF, (size_t)cap * 8, st));
+  EYOC_CHECK_HIP(hipMemsetAsync(t.vals, 0x7F, (size_t)cap * 4, st));
+  hipLaunchKernelGGL(k_quantize, dim3(cdiv(n, 256)), dim3(256), 0, st, xyz_dev, n, stride, voxel_size, batch_index, raw);
+  hipLaunchKernelGGL(k_insert, dim3(cdiv(n, 256)), dim3(256), 0, st, raw, n, 1, t, slot, counters);
+  hipLaunchKernelGGL(k_flag, dim3(cdiv(n, 256)), dim3(256), 0, st, slot, t.vals, n, flag, (int*)nullptr);
+  const int nb = cdiv(n, SCAN_TILE);
+  hipLaunchKernelGGL(k_scan_partials, dim3(nb), dim3(SCAN_BLOCK), 0, st, flag, n, partial);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, st, partial, nb, counters + 2);
+  hipLaunchKernelGGL(k_compact, dim3(nb), dim3(SCAN_BLOCK), 0, st, flag, partial, slot, raw, n, 1, coords_dev, t.vals,
+                     sel_dev);
+  int* host = (int*)ctx->pinned;
+  EYOC_CHECK_HIP(hipMemcpyAsync(host, counters, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  EYOC_CHECK_HIP(hipStreamSynchronize(st));
+  EYOC_REQUIRE(host[0] == 0, EYOC_ERR_RANGE, "eyoc_voxelize: %d points fall outside the key range (|c| < 2^17 - 16)", host[0]);
+  *n_out = host[2];
   return EYOC_OK;
 }
 

@@ -90,6 +90,19 @@ int eyoc_maps_info(eyoc_ctx* ctx, const eyoc_maps* maps, int conv1_kernel_size, 
                    eyoc_maps_info_t* info);
 
 /* ------------------------------------------------------------------------------------------------
+ * voxeliser (the step immediately before the path; SURVEY.md 8f "next" row 1)
+ *   replaces: ME.utils.sparse_quantize(xyz / voxel_size, return_index=True) followed by
+ *             floor(xyz[sel] / voxel_size).int()   (lib/data_loaders.py:940-943,969-979; util/misc.py:80-84)
+ *   xyz f32 rows of `stride` floats (3 = xyz, 4 = KITTI .bin xyzr) -> sel int32 [n_out] = index of the
+ *   first point of every occupied voxel, ascending; coords int32 [n_out,4] = (batch_index, floor(p / v)).
+ *   Outputs need room for n rows.  Synchronises `stream` once (to return n_out).
+ * --------------------------------------------------------------------------------------------- */
+size_t eyoc_voxelize_workspace_bytes(int n_points);
+int eyoc_voxelize(eyoc_ctx* ctx, const float* xyz_dev, int n_points, int stride, float voxel_size, int batch_index,
+                  int32_t* sel_dev, int32_t* coords_dev, int* n_out, void* workspace_dev, size_t workspace_bytes,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * one sparse convolution layer (unit tests, profiling)
  *   replaces: one MinkowskiConvolution / MinkowskiConvolutionTranspose forward with the batch norm
  *             that follows it folded in, plus the residual add / ReLU / concat write around it
