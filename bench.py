@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-One step = one pass of the hot path over a batch of ``--pairs`` (default 8) synthetic ~30k-voxel pairs
+One step = one pass of the hot path over a batch of ``--pairs`` (default 32) synthetic ~30k-voxel pairs
 already resident in HBM: coordinate maps + rulebooks for the 2P clouds, the batched ResUNetBN2C
 forward, the 5000x5000 feature nearest-neighbour search of every pair and 4-point RANSAC with the
 reference's 4,000,000 hypotheses per pair, and the device->host copy of the P poses.
@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=8, help="pairs per step per GPU")
+    ap.add_argument("--pairs", type=int, default=32, help="pairs per step per GPU (64 clouds of ~31k voxels in one batched forward)")
     ap.add_argument("--ransac-iters", type=int, default=4000000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
@@ -146,6 +146,17 @@ def main():
     elapsed = edist.max_over_ranks(elapsed, device)
     model.set_timing(False)
 
+    # latency of ONE pair through the same path (configs[1] of BASELINE.json read literally); not part of `value`
+    single = DeviceBatch(pairs[:1], seeds[:1], device, cfg.n_points)
+    for _ in range(3):
+        pipe.register(single)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(10):
+        pipe.register(single)
+    torch.cuda.synchronize()
+    single_ms = (time.perf_counter() - t1) / 10 * 1e3
+
     # algorithmic work of one forward on this batch geometry
     x = eyoc_amd.SparseTensor(batch.feats, coordinates=batch.coords)
     work = model.layer_work(x)
@@ -185,6 +196,7 @@ def main():
             "mfma": {"achieved": flops / (conv_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                      "frac": flops / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "flop_per_forward": flops},
             "forward_ms_per_step": fwd_ms,
+            "single_pair_latency_ms": single_ms,
             "success_rate": float(np.mean([e["success"] for e in evals])),
         }
         log("timed region done; cpu baseline next")
