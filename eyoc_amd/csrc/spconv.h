@@ -25,6 +25,7 @@ struct SpconvArgs {
 };
 
 int launch_spconv(const SpconvArgs& a, hipStream_t st);
+int launch_spconv_wave(const SpconvArgs& a, hipStream_t st);   // wave-private tiling (spconv_wave.hip)
 
 // first convolution: K = ks^3 offsets probed straight from the level-0 hash table (C_in is tiny)
 struct Conv1Args {

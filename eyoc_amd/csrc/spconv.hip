@@ -20,6 +20,7 @@
 //      once, so no atomics are needed and the summation order (k ascending) is deterministic.
 //   4. epilogue from LDS: + bias (folded BN shift) (+ residual) -> ReLU -> (row L2 normalisation)
 //      -> coalesced float4 row stores at the layer's column offset inside a concat buffer.
+#include <cstdlib>
 #include <type_traits>
 
 #include "spconv.h"
@@ -556,6 +557,8 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
                EYOC_ERR_INVALID, "spconv: pointers must be 16-byte aligned");
   EYOC_REQUIRE(!a.l2norm || a.cout <= 128, EYOC_ERR_INVALID, "spconv: l2norm needs C_out <= 128");
   if (a.n_out == 0) return EYOC_OK;
+  static const int use_wave = getenv("EYOC_SPCONV_WAVE") ? atoi(getenv("EYOC_SPCONV_WAVE")) : 0;
+  if (use_wave) return launch_spconv_wave(a, st);
   const bool wide = spconv_cc(a.cin, a.cout) == 64;
   switch (spconv_ct(a.cout)) {
     case 32: wide ? launch_ct<32, 64>(a, st) : launch_ct<32, 32>(a, st); break;
