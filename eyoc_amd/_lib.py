@@ -10,7 +10,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libeyoc_hip.so")
+LIB_PATH = os.environ.get("EYOC_HIP_LIB") or os.path.join(_HERE, "lib", "libeyoc_hip.so")   # override: diagnostics builds
 
 MAX_LEVELS = 4
 MAP_S1, MAP_DOWN, MAP_UP = 0, 1, 2
@@ -71,6 +71,7 @@ PROTOTYPES = {
     "eyoc_voxelize": (_i, [_vp, _vp, _i, _i, C.c_float, _i, _vp, _vp, C.POINTER(C.c_int), _vp, _sz, _vp]),
     "eyoc_spconv_packed_floats": (_sz, [_i, _i, _i]),
     "eyoc_spconv_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "eyoc_spconv_select_kernel": (_i, [_i]),
     "eyoc_spconv": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "eyoc_model_blob_floats": (_sz, [C.POINTER(ModelDesc)]),
     "eyoc_model_create": (_i, [_vp, C.POINTER(ModelDesc), C.POINTER(LayerParams), _i, _vp, _sz, C.POINTER(_vp)]),

@@ -543,6 +543,8 @@ __global__ __launch_bounds__(256) void conv1_tree_kernel(Conv1Args a) {
 
 namespace eyoc {
 
+static int g_kernel_mode = getenv("EYOC_SPCONV_WAVE") ? atoi(getenv("EYOC_SPCONV_WAVE")) : -1;
+
 int launch_spconv(const SpconvArgs& a, hipStream_t st) {
   EYOC_REQUIRE(a.in && a.w && a.out, EYOC_ERR_INVALID, "spconv: NULL tensor");
   EYOC_REQUIRE(a.n_out >= 0, EYOC_ERR_INVALID, "spconv: n_out %d", a.n_out);
@@ -557,8 +559,12 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
                EYOC_ERR_INVALID, "spconv: pointers must be 16-byte aligned");
   EYOC_REQUIRE(!a.l2norm || a.cout <= 128, EYOC_ERR_INVALID, "spconv: l2norm needs C_out <= 128");
   if (a.n_out == 0) return EYOC_OK;
-  static const int use_wave = getenv("EYOC_SPCONV_WAVE") ? atoi(getenv("EYOC_SPCONV_WAVE")) : 0;
-  if (use_wave) return launch_spconv_wave(a, st);
+  // Two decompositions: the wave-private kernel (spconv_wave.hip) wins once its 64-row tiles give every SIMD
+  // a few waves' worth of work (measured cross-over ~4000 tiles on MI355X); below that the workgroup-tiled
+  // kernel here balances better.  eyoc_spconv_select_kernel (or EYOC_SPCONV_WAVE=0 / 1 in the environment) forces one of them.
+  const int force = g_kernel_mode;
+  const long long wave_tiles = (long long)cdiv(a.n_out, 64) * (a.cout >= 64 ? a.cout / 64 : 1);
+  if (force > 0 || (force < 0 && wave_tiles >= 4096)) return launch_spconv_wave(a, st);
   const bool wide = spconv_cc(a.cin, a.cout) == 64;
   switch (spconv_ct(a.cout)) {
     case 32: wide ? launch_ct<32, 64>(a, st) : launch_ct<32, 32>(a, st); break;
@@ -611,6 +617,12 @@ extern "C" int eyoc_debug_trace(unsigned long long* out_host, size_t count) {
 extern "C" {
 
 size_t eyoc_spconv_packed_floats(int K, int cin, int cout) { return (size_t)K * cin * cout; }
+
+int eyoc_spconv_select_kernel(int mode) {
+  const int prev = eyoc::g_kernel_mode;
+  eyoc::g_kernel_mode = mode;
+  return prev;
+}
 
 // packed[k][slice][cc][nt][jq][lane][e] = W[k][cc*CC + (jq*4 + (lane>>4))*4 + e][slice*CT + nt*16 + (lane&15)] * scale[col]
 // with CT = spconv_ct(cout), CC = spconv_cc(cin, cout): for one (k, slice, cc) the [nt][jq][lane] float4s are

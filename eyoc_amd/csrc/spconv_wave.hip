@@ -19,7 +19,11 @@
 //   * epilogue from LDS: + bias (+ residual) -> ReLU -> (row L2 normalisation) -> coalesced float4 stores.
 // Summation order per output element is fixed (k ascending, channels ascending inside the MFMA chain), so
 // results are bit-reproducible from run to run.
+#include <cstdlib>
 #include <type_traits>
+#ifndef EYOC_ABL
+#define EYOC_ABL 0   // ablation builds (diagnostics only)
+#endif
 
 #include "spconv.h"
 
@@ -30,9 +34,19 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic build (-DEYOC_TRACE, scripts/trace_spconv.py): a few waves stamp the cycle counter at phase boundaries.
+#ifdef EYOC_TRACE
+constexpr int TRACE_STAMPS = 512, TRACE_WAVES = 16;
+__device__ unsigned long long g_wtrace[TRACE_WAVES * TRACE_STAMPS];
+#define TR_DECL const int tr_w = (tile >= 6000 && tile < 6000 + TRACE_WAVES) ? tile - 6000 : -1; int tr_n = 0
+#define TR() do { if (tr_w >= 0 && lane == 0 && tr_n < TRACE_STAMPS) g_wtrace[tr_w * TRACE_STAMPS + tr_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TR_DECL
+#define TR()
+#endif
+
 template <int CTW, int BMW, int CC, int NCMAX>
 struct WCfg {
-  static constexpr int WPB = 2;                 // waves per workgroup (independent of each other)
   static constexpr int NTW = CTW / 16;          // 16-channel tiles per wave
   static constexpr int JQ = CC / 16;            // 16-channel blocks per C_in slice
   static constexpr int C4N = CTW / 4;           // float4 columns per accumulator row
@@ -40,12 +54,13 @@ struct WCfg {
   static constexpr int LIST = BMW + 16 * NCMAX; // compacted pairs of one offset, padded to whole items
   static constexpr int ACC_BYTES = (BMW + 1) * CTW * 4;   // + 1: trash row for padding pairs
   static constexpr int WAVE_BYTES = ACC_BYTES + 2 * LIST * 4;
+  static constexpr int WPB = 2 * WAVE_BYTES <= 64 * 1024 ? 2 : 1;   // waves per workgroup (independent of each other)
   static_assert(BMW == 64 || BMW == 128, "rows per wave");
   static_assert(WAVE_BYTES % 16 == 0 && WPB * WAVE_BYTES <= 64 * 1024, "LDS budget");
 };
 
-template <int CTW, int BMW, int CC, int NCMAX>
-__global__ __launch_bounds__(128, 2) void spconv_wave_kernel(SpconvArgs a) {
+template <int CTW, int BMW, int CC, int NCMAX, int OCC>
+__global__ __launch_bounds__((WCfg<CTW, BMW, CC, NCMAX>::WPB * 64), OCC) void spconv_wave_kernel(SpconvArgs a) {
   using C = WCfg<CTW, BMW, CC, NCMAX>;
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::WPB * C::WAVE_BYTES];
   const int lane = threadIdx.x & 63;
@@ -56,6 +71,8 @@ __global__ __launch_bounds__(128, 2) void spconv_wave_kernel(SpconvArgs a) {
   const int row0 = rg * BMW;
   if (row0 >= a.n_out) return;   // wave-uniform; there is no barrier anywhere in this kernel
   const int rows_here = min(BMW, a.n_out - row0);
+  TR_DECL;
+  TR();
   float* acc = reinterpret_cast<float*>(smem + wave * C::WAVE_BYTES);
   unsigned int* list = reinterpret_cast<unsigned int*>(smem + wave * C::WAVE_BYTES + C::ACC_BYTES);
   auto acc_off = [](int row, int c4) { return row * CTW + ((c4 ^ row) & (C::C4N - 1)) * 4; };
@@ -71,6 +88,9 @@ __global__ __launch_bounds__(128, 2) void spconv_wave_kernel(SpconvArgs a) {
 
   auto load_idx = [&](int k, int r) -> int {
     const int row = r * 64 + lane;
+#if EYOC_ABL >= 6
+    return (k < K && row < rows_here) ? row0 + row : -1;   // dense synthetic rulebook, no memory
+#endif
     if (a.nbr) return (k < K && row < rows_here) ? a.nbr[(size_t)k * a.n_out + row0 + row] : -1;
     return (k == 0 && row < rows_here) ? row0 + row : -1;   // identity map (1x1 convolution)
   };
@@ -91,7 +111,6 @@ __global__ __launch_bounds__(128, 2) void spconv_wave_kernel(SpconvArgs a) {
     return P;
   };
 
-  const float4* wbase = reinterpret_cast<const float4*>(a.w);
   const int tile4 = CC * CT / 4;   // float4s of one packed (k, slice, cc) weight tile
 
   // ---- the unit stream.  A unit = (offset k, item of <= NCMAX chunks, C_in slice cc).  While unit u runs its
@@ -127,10 +146,14 @@ __global__ __launch_bounds__(128, 2) void spconv_wave_kernel(SpconvArgs a) {
   auto ldw = [&](int wt, int t, int q) -> float4 {
     constexpr int FPI = 4;   // fragments reachable through the 12-bit immediate
     const int f = t * C::JQ + q;
+#if EYOC_ABL == 2 || EYOC_ABL >= 5
+    return make_float4((float)lane, 1.f, (float)wt, 3.f);
+#endif
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off + (f % FPI) * 1024, wt + (f / FPI) * FPI * 1024, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
   };
 
+  TR();
   int k_c = K, k_n = K;
   const int P_first = produce(0, k_c);
   if (P_first > 0) {
@@ -156,7 +179,13 @@ __global__ __launch_bounds__(128, 2) void spconv_wave_kernel(SpconvArgs a) {
 #pragma unroll
       for (int q = 0; q < C::JQ; ++q)
 #pragma unroll
-        for (int c = 0; c < NCMAX; ++c) G[q][c] = *reinterpret_cast<const float4*>(gp[c] + cc_ * CC + q * 16);
+        for (int c = 0; c < NCMAX; ++c) {
+#if EYOC_ABL == 1 || EYOC_ABL >= 5
+          G[q][c] = make_float4((float)lane, 1.f, 2.f, (float)cc_);
+#else
+          G[q][c] = *reinterpret_cast<const float4*>(gp[c] + cc_ * CC + q * 16);
+#endif
+        }
     };
     auto load_w_head = [&](int wt, float4 (&W)[C::JQ][C::NTW]) {
 #pragma unroll
@@ -194,7 +223,8 @@ __global__ __launch_bounds__(128, 2) void spconv_wave_kernel(SpconvArgs a) {
               accr[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, accr[c][t], 0, 0, 0);
             }
           }
-      if (last_cc) {
+      TR();
+      if (last_cc && EYOC_ABL != 3) {
         // D[i = 4 g + reg][j] = (output channel i of the tile, pair j): one 128-bit read-add-write per chunk and tile
         float4 old[NC][C::NTW];
 #pragma unroll
@@ -215,6 +245,7 @@ __global__ __launch_bounds__(128, 2) void spconv_wave_kernel(SpconvArgs a) {
     // one unit: (cur) operand set is multiplied while the (nxt) set is filled; returns false after the last unit
     auto step = [&](const float* (&gp_c)[NCMAX], int (&orow_c)[NCMAX], float4 (&G_c)[C::JQ][NCMAX], float4 (&W_c)[C::JQ][C::NTW],
                     const float* (&gp_n)[NCMAX], int (&orow_n)[NCMAX], float4 (&G_n)[C::JQ][NCMAX], float4 (&W_n)[C::JQ][C::NTW]) -> bool {
+      TR();
       int cc_n = cc + 1, c0_n = c0, k_x = k_c, slot_x = slot_c, nch_x = nch_c;
       bool have = true;
       if (cc_n == ncc) {
@@ -233,6 +264,7 @@ __global__ __launch_bounds__(128, 2) void spconv_wave_kernel(SpconvArgs a) {
       read_records(slot_x, c0_n, gp_n, orow_n);        // (B) gather of the next unit
       load_gather(gp_n, cc_n, G_n);
       load_w_head(wptr(k_x, cc_n), W_n);               // (C) first weights of the next unit
+      TR();
       const int nc = min(NCMAX, nch_c - c0);
       const bool first_cc = cc == 0, last_cc = cc == ncc - 1;
       if constexpr (NCMAX >= 4) {
@@ -241,6 +273,7 @@ __global__ __launch_bounds__(128, 2) void spconv_wave_kernel(SpconvArgs a) {
       }
       if (nc == 2) compute(std::integral_constant<int, 2>{}, first_cc, last_cc, G_c, W_c, orow_c);
       if (nc == 1) compute(std::integral_constant<int, 1>{}, first_cc, last_cc, G_c, W_c, orow_c);
+      TR();
       k_c = k_x; slot_c = slot_x; nch_c = nch_x; c0 = c0_n; cc = cc_n;
       return have;
     };
@@ -254,6 +287,7 @@ __global__ __launch_bounds__(128, 2) void spconv_wave_kernel(SpconvArgs a) {
     }
   }
 
+  TR();
   // ---- epilogue
   constexpr int RPI = 64 / C::C4N;   // rows per store instruction
   const int er = lane / C::C4N, ec4 = lane % C::C4N;
@@ -280,13 +314,14 @@ __global__ __launch_bounds__(128, 2) void spconv_wave_kernel(SpconvArgs a) {
     }
     *reinterpret_cast<float4*>(a.out + o * a.ld_out + ct0 + ec4 * 4) = v;
   }
+  TR();
 }
 
-template <int CTW, int BMW, int CC, int NCMAX>
+template <int CTW, int BMW, int CC, int NCMAX, int OCC = 2>
 void launch_wave_cfg(const SpconvArgs& a, hipStream_t st) {
   using C = WCfg<CTW, BMW, CC, NCMAX>;
   const long long tiles = (long long)cdiv(a.n_out, BMW) * (a.cout / CTW);
-  hipLaunchKernelGGL((spconv_wave_kernel<CTW, BMW, CC, NCMAX>), dim3(cdiv(tiles, C::WPB)), dim3(C::WPB * 64), 0, st, a);
+  hipLaunchKernelGGL((spconv_wave_kernel<CTW, BMW, CC, NCMAX, OCC>), dim3(cdiv(tiles, C::WPB)), dim3(C::WPB * 64), 0, st, a);
 }
 
 }  // namespace
@@ -305,3 +340,9 @@ int launch_spconv_wave(const SpconvArgs& a, hipStream_t st) {
 }
 
 }  // namespace eyoc
+
+#ifdef EYOC_TRACE
+extern "C" int eyoc_debug_trace_wave(unsigned long long* out_host, size_t count) {
+  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_wtrace), count * sizeof(unsigned long long));
+}
+#endif

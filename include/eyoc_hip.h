@@ -117,6 +117,10 @@ int eyoc_spconv_pack_weights(const float* w_host /*[K,cin,cout]*/, const float* 
 int eyoc_spconv(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, const float* in_dev,
                 int ld_in, int cin, const float* wpacked_dev, int cout, const float* bias_dev,
                 const float* res_dev, int ld_res, int relu, float* out_dev, int ld_out, void* stream);
+/* Two decompositions implement the operator (workgroup-tiled: spconv.hip, wave-private: spconv_wave.hip);
+ * by default the launcher picks by problem size.  mode -1 = automatic (default), 0 = workgroup-tiled,
+ * 1 = wave-private.  Process-wide; meant for parity tests and profiling.  Returns the previous mode. */
+int eyoc_spconv_select_kernel(int mode);
 
 /* ------------------------------------------------------------------------------------------------
  * ResUNet2 family (ResUNetBN2C in production)

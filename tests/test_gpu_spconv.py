@@ -12,6 +12,17 @@ pytestmark = pytest.mark.gpu
 REL = 1e-4
 
 
+@pytest.fixture(params=[0, 1], ids=["tiled", "wave"], autouse=True)
+def spconv_kernel(request):
+    """Every test runs against both decompositions of the sparse convolution (spconv.hip / spconv_wave.hip);
+    production picks between them by problem size."""
+    from eyoc_amd import _lib
+    lib = _lib.load()
+    prev = lib.eyoc_spconv_select_kernel(request.param)
+    yield request.param
+    lib.eyoc_spconv_select_kernel(prev)
+
+
 def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
