@@ -183,7 +183,8 @@ __global__ void k_children(const int* __restrict__ slot, const int* __restrict__
 //   -1 -> coarse block at -1, child bit 1;  0 / 1 -> own block, bit 0 / 1;  2 -> coarse block at +1, bit 0.
 __global__ void k_derive_fine(const int32_t* __restrict__ coords, int n, int sh, const int32_t* __restrict__ parent,
                               const int32_t* __restrict__ children, const int32_t* __restrict__ s1c, int nc,
-                              int32_t* __restrict__ s1, int32_t* __restrict__ up) {
+                              int32_t* __restrict__ s1, int32_t* __restrict__ up, unsigned int* __restrict__ up_key,
+                              int* __restrict__ up_row) {
   int o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= n) return;
   const int4 c = reinterpret_cast<const int4*>(coords)[o];
@@ -214,6 +215,17 @@ __global__ void k_derive_fine(const int32_t* __restrict__ coords, int n, int sh,
     const int B = blk[a];
     s1[(size_t)k * n + o] = B >= 0 ? children[(size_t)B * 8 + cs] : -1;
     if (up) up[(size_t)k * n + o] = up_ok ? blk[a_up] : -1;
+  }
+  if (up_key) {
+    // pattern of the transposed map: parity class (which axes sit on an odd position) and which of the coarse
+    // blocks that class can reach exist -> 11-bit sort key (UP_KEY_BITS)
+    const int cls = b[0] | (b[1] << 1) | (b[2] << 2);
+    unsigned int present = 0;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+      if ((a & cls) == a && blk[a] >= 0) present |= 1u << a;
+    up_key[o] = ((unsigned)cls << 8) | present;
+    up_row[o] = o;
   }
 }
 
@@ -269,6 +281,8 @@ __global__ void k_count_region(const int32_t* __restrict__ coords, int n, HashTa
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
 }
 
+constexpr int UP_KEY_BITS = 11;
+
 unsigned int table_capacity(int n) {
   unsigned int cap = 1024;
   while (cap < 2u * (unsigned)n) cap <<= 1;
@@ -289,6 +303,7 @@ size_t eyoc_maps_workspace_bytes(int n_rows) {
   b += 10 * align_up(n * 27 * 4);                                    // 4 s1 + 3 down + 3 up tables
   b += 3 * align_up(n * 4) + align_up((n / SCAN_TILE + 2) * 4);      // slot, flag, partial sums
   b += 3 * (align_up(n * 4) + align_up(n * 32));                     // parent / children links
+  b += 6 * align_up(n * 4) + align_up(sort_rows_tmp_bytes(n_rows, UP_KEY_BITS));   // perm_up + sort keys / temporaries
   b += 4096;                                                         // counters
   return b + 64 * 256;
 }
@@ -383,10 +398,25 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
     hipLaunchKernelGGL(k_neighbours, dim3(cdiv(m->rows[top], 256)), dim3(256), 0, st, m->coords[top], m->rows[top],
                        m->table[top], 1 << top, 1, m->nbr_s1[top]);
   }
+  unsigned int* key_in = cv.take<unsigned int>(n);
+  unsigned int* key_out = cv.take<unsigned int>(n);
+  int* row_in = cv.take<int>(n);
+  const size_t sort_bytes = sort_rows_tmp_bytes(n, UP_KEY_BITS);
+  void* sort_tmp = cv.take<char>(sort_bytes);
   for (int l = EYOC_MAX_LEVELS - 2; l >= 0; --l) {
     const int nl = m->rows[l], nc = m->rows[l + 1];
+    m->perm_up[l] = cv.take<int32_t>((size_t)nl);
     hipLaunchKernelGGL(k_derive_fine, dim3(cdiv(nl, 256)), dim3(256), 0, st, m->coords[l], nl, l, m->parent[l],
-                       m->children[l], m->nbr_s1[l + 1], nc, m->nbr_s1[l], m->nbr_up[l]);
+                       m->children[l], m->nbr_s1[l + 1], nc, m->nbr_s1[l], m->nbr_up[l], key_in, row_in);
+    if (sort_rows_tmp_bytes(nl, UP_KEY_BITS) > sort_bytes) {
+      set_error("eyoc_maps_build: sort workspace too small for level %d", l);
+      delete m;
+      return EYOC_ERR_WORKSPACE;
+    }
+    if (int rc = sort_rows_by_key(sort_tmp, sort_bytes, key_in, key_out, row_in, m->perm_up[l], nl, UP_KEY_BITS, st)) {
+      delete m;
+      return rc;
+    }
     hipLaunchKernelGGL(k_derive_down, dim3(cdiv(nc, 256)), dim3(256), 0, st, nc, m->children[l], m->nbr_s1[l + 1],
                        m->nbr_down[l]);
   }
@@ -486,6 +516,14 @@ int eyoc_maps_copy_table(const eyoc_maps* maps, int kind, int level, int32_t* ou
   EYOC_REQUIRE(src && out_dev, EYOC_ERR_INVALID, "eyoc_maps_copy_table: bad kind %d / level %d or NULL output", kind, level);
   const int n_out = kind == EYOC_MAP_DOWN ? maps->rows[level + 1] : maps->rows[level];
   EYOC_CHECK_HIP(hipMemcpyAsync(out_dev, src, (size_t)n_out * 27 * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return EYOC_OK;
+}
+
+int eyoc_maps_copy_up_order(const eyoc_maps* maps, int level, int32_t* out_dev, void* stream) {
+  EYOC_REQUIRE(maps && out_dev && level >= 0 && level + 1 < maps->n_levels && maps->perm_up[level], EYOC_ERR_INVALID,
+               "eyoc_maps_copy_up_order: bad level %d or NULL argument", level);
+  EYOC_CHECK_HIP(hipMemcpyAsync(out_dev, maps->perm_up[level], (size_t)maps->rows[level] * 4, hipMemcpyDeviceToDevice,
+                                (hipStream_t)stream));
   return EYOC_OK;
 }
 

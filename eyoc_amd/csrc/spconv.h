@@ -22,6 +22,9 @@ struct SpconvArgs {
   int l2norm;           // divide every output row by its 2-norm (needs cout <= 128); no epsilon
   float* out;           // rows of ld_out floats; the layer writes columns [0, cout)
   int ld_out;
+  // optional: a permutation of the output rows; tiles take rows in this order (any order gives the same result,
+  // a good one makes the rows of a tile share their occupied offsets).  NULL = natural order.
+  const int32_t* perm = nullptr;
 };
 
 int launch_spconv(const SpconvArgs& a, hipStream_t st);

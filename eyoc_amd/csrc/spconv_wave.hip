@@ -86,13 +86,20 @@ __global__ __launch_bounds__((WCfg<CTW, BMW, CC, NCMAX>::WPB * 64), OCC) void sp
 
   for (int i = lane; i < (BMW + 1) * C::C4N; i += 64) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
+  // global output row of this lane's tile row(s): the tile takes rows in a.perm order when given
+  int grow0 = lane < rows_here ? row0 + lane : -1, grow1 = -1;
+  if constexpr (C::RND == 2) grow1 = 64 + lane < rows_here ? row0 + 64 + lane : -1;
+  if (a.perm) {
+    if (grow0 >= 0) grow0 = a.perm[grow0];
+    if (grow1 >= 0) grow1 = a.perm[grow1];
+  }
   auto load_idx = [&](int k, int r) -> int {
-    const int row = r * 64 + lane;
+    const int grow = r == 0 ? grow0 : grow1;
 #if EYOC_ABL >= 6
-    return (k < K && row < rows_here) ? row0 + row : -1;   // dense synthetic rulebook, no memory
+    return (k < K && grow >= 0) ? grow : -1;   // dense synthetic rulebook, no memory
 #endif
-    if (a.nbr) return (k < K && row < rows_here) ? a.nbr[(size_t)k * a.n_out + row0 + row] : -1;
-    return (k == 0 && row < rows_here) ? row0 + row : -1;   // identity map (1x1 convolution)
+    if (a.nbr) return (k < K && grow >= 0) ? a.nbr[(size_t)k * a.n_out + grow] : -1;
+    return (k == 0 && grow >= 0) ? grow : -1;   // identity map (1x1 convolution)
   };
   auto compact = [&](int i0, int i1, int slot) -> int {
     unsigned int* L = list + slot * C::LIST;
@@ -289,12 +296,14 @@ __global__ __launch_bounds__((WCfg<CTW, BMW, CC, NCMAX>::WPB * 64), OCC) void sp
 
   TR();
   // ---- epilogue
+  list[lane] = (unsigned)grow0;   // the pair lists are dead: park the global row of every tile row there
+  if constexpr (C::RND == 2) list[64 + lane] = (unsigned)grow1;
   constexpr int RPI = 64 / C::C4N;   // rows per store instruction
   const int er = lane / C::C4N, ec4 = lane % C::C4N;
   float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + ct0 + ec4 * 4);
   for (int r = er; r < rows_here; r += RPI) {
-    const size_t o = (size_t)(row0 + r);
+    const size_t o = (size_t)list[r];
     float4 v = *reinterpret_cast<const float4*>(acc + acc_off(r, ec4));
     v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
     if (a.l2norm) {

@@ -67,6 +67,14 @@ class CoordinateManager:
                        "eyoc_maps_copy_table")
         return out
 
+    def up_order(self, level: int) -> torch.Tensor:
+        """Copy of the row order ``int32 [rows(level)]`` the transposed convolutions tile their outputs in."""
+        out = torch.empty((self.rows(level),), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().eyoc_maps_copy_up_order(self.maps(), level, _lib.ptr(out), _lib.stream_ptr()),
+                       "eyoc_maps_copy_up_order")
+        return out
+
     def info(self, conv1_kernel_size: int = 0) -> dict:
         info = _lib.MapsInfo()
         with torch.cuda.device(self.device):

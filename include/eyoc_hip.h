@@ -78,6 +78,11 @@ size_t eyoc_maps_workspace_bytes(int n_rows);
 int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n_rows, void* workspace_dev,
                     size_t workspace_bytes, void* stream, eyoc_maps** out);
 int eyoc_maps_free(eyoc_maps* maps);
+/* Row order the transposed convolutions tile their outputs in: the rows of `level` (a fine level, 0 <= level <
+ * n_levels-1) sorted, stably, by the pattern of coarse blocks their transposed map reaches.  Purely a
+ * scheduling aid (tiles whose rows share their occupied kernel offsets) - results do not depend on it.
+ * out_dev: int32 [rows[level]]. */
+int eyoc_maps_copy_up_order(const eyoc_maps* maps, int level, int32_t* out_dev, void* stream);
 int eyoc_maps_rows(const eyoc_maps* maps, int level);
 /* device pointers into the workspace; valid while the maps object lives */
 const int32_t* eyoc_maps_coords(const eyoc_maps* maps, int level);             /* [rows,4]        */

@@ -18,6 +18,18 @@ def random_cloud(seed, n, extent=40, batch=1):
     return syn.batch_coords(out)
 
 
+def check_up_order(order, up):
+    """The tiling order of a transposed convolution: a permutation of the rows in which every pattern of
+    occupied offsets forms ONE run, rows ascending inside a run (stable)."""
+    n = up.shape[1]
+    np.testing.assert_array_equal(np.sort(order), np.arange(n))
+    pattern = ((up >= 0) * (1 << np.arange(27, dtype=np.int64))[:, None]).sum(0)[order]
+    starts = np.flatnonzero(np.r_[True, pattern[1:] != pattern[:-1]])
+    assert len(starts) == len(np.unique(pattern)), "a pattern is split over several runs"
+    same = pattern[1:] == pattern[:-1]
+    assert (np.diff(order)[same] > 0).all(), "rows of one pattern are not in ascending order"
+
+
 def check_against_oracle(coords):
     import eyoc_amd
     from eyoc_amd import _lib
@@ -35,6 +47,7 @@ def check_against_oracle(coords):
         if l < 3:
             np.testing.assert_array_equal(cm.table(_lib.MAP_DOWN, l).cpu().numpy(), maps["down"][l])
             np.testing.assert_array_equal(cm.table(_lib.MAP_UP, l).cpu().numpy(), maps["up"][l])
+            check_up_order(cm.up_order(l).cpu().numpy(), maps["up"][l])
     return info
 
 
