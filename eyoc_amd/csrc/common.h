@@ -122,6 +122,9 @@ struct eyoc_maps {
   // them), stable.  A transposed convolution that tiles its output rows in THIS order finds 2-3 occupied
   // offsets per tile instead of ~24 (spconv_wave.hip); the result does not depend on the order.
   int32_t* perm_up[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
+  // perm_s1[l]: same idea for the stride-1 convolutions of level l (rows grouped by a coarse key of their
+  // neighbour pattern); NULL = natural order
+  int32_t* perm_s1[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace eyoc {

@@ -15,6 +15,8 @@
 //    27 + 27 + 27 hash probes (3/4 of which would be misses that walk a probe chain).
 //  * rulebooks are output-stationary tables nbr[27][n_out] (k-major so that the 64 rows of a wave
 //    read/write one contiguous segment per offset).
+#include <cstdlib>
+
 #include "common.h"
 
 using namespace eyoc;
@@ -153,6 +155,25 @@ __global__ void k_neighbours(const int32_t* __restrict__ coords_out, int n_out, 
     const int dx = (k % 3 - 1) * d, dy = ((k / 3) % 3 - 1) * d, dz = (k / 9 - 1) * d;
     nbr[(size_t)k * n_out + o] = hash_lookup(tin, pack_key(c.x, c.y + dx, c.z + dy, c.w + dz));
   }
+}
+
+// sort key of a row's stride-1 neighbour pattern (see eyoc_maps::perm_s1); offsets enumerate x fastest, so
+// k / 9 is the z layer and (k / 3) % 3 the y row.  bits 0-1: does the z layer below / above hold any neighbour;
+// bits 2-3 (only when key_bits == 4): the y rows before / behind inside the own layer.  Coarse on purpose: finer
+// keys (up to the full 27-bit pattern) pack the chunks better but scatter a tile's rows over the cloud, and the
+// lost L2 locality of the gather costs more than the saved matrix work (measured on MI355X).
+__global__ void k_pattern_key(const int32_t* __restrict__ nbr, int n, int key_bits, unsigned int* __restrict__ key,
+                              int* __restrict__ row) {
+  int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n) return;
+  unsigned int mask = 0;
+#pragma unroll 1
+  for (int k = 0; k < 27; ++k) mask |= (nbr[(size_t)k * n + o] >= 0 ? 1u : 0u) << k;
+  const unsigned int lo = mask & 0x1FFu, mid = (mask >> 9) & 0x1FFu, hi = mask >> 18;
+  unsigned int kv = (lo ? 1u : 0u) | (hi ? 2u : 0u);
+  if (key_bits == 4) kv |= ((mid & 7u) ? 4u : 0u) | ((mid >> 6) ? 8u : 0u);
+  key[o] = kv;
+  row[o] = o;
 }
 
 // voxel coordinates of raw points: floor(x / voxel) in fp32 (IEEE division, like torch / numpy on fp32 input)
@@ -303,7 +324,7 @@ size_t eyoc_maps_workspace_bytes(int n_rows) {
   b += 10 * align_up(n * 27 * 4);                                    // 4 s1 + 3 down + 3 up tables
   b += 3 * align_up(n * 4) + align_up((n / SCAN_TILE + 2) * 4);      // slot, flag, partial sums
   b += 3 * (align_up(n * 4) + align_up(n * 32));                     // parent / children links
-  b += 6 * align_up(n * 4) + align_up(sort_rows_tmp_bytes(n_rows, UP_KEY_BITS));   // perm_up + sort keys / temporaries
+  b += 10 * align_up(n * 4) + align_up(sort_rows_tmp_bytes(n_rows, 27));   // perm_up, perm_s1, sort keys / temporaries
   b += 4096;                                                         // counters
   return b + 64 * 256;
 }
@@ -401,7 +422,7 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
   unsigned int* key_in = cv.take<unsigned int>(n);
   unsigned int* key_out = cv.take<unsigned int>(n);
   int* row_in = cv.take<int>(n);
-  const size_t sort_bytes = sort_rows_tmp_bytes(n, UP_KEY_BITS);
+  const size_t sort_bytes = sort_rows_tmp_bytes(n, 27);
   void* sort_tmp = cv.take<char>(sort_bytes);
   for (int l = EYOC_MAX_LEVELS - 2; l >= 0; --l) {
     const int nl = m->rows[l], nc = m->rows[l + 1];
@@ -419,6 +440,20 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
     }
     hipLaunchKernelGGL(k_derive_down, dim3(cdiv(nc, 256)), dim3(256), 0, st, nc, m->children[l], m->nbr_s1[l + 1],
                        m->nbr_down[l]);
+  }
+  // ---- tiling order of the stride-1 convolutions (EYOC_S1_ORDER=0 in the environment switches it off)
+  static const bool s1_order = !(getenv("EYOC_S1_ORDER") && atoi(getenv("EYOC_S1_ORDER")) == 0);
+  if (s1_order) {
+    for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
+      const int nl = m->rows[l];
+      const int bits = l == 0 ? 2 : 4;   // level 0 feeds the 32-channel, bandwidth-bound layers: keep more locality
+      m->perm_s1[l] = cv.take<int32_t>((size_t)nl);
+      hipLaunchKernelGGL(k_pattern_key, dim3(cdiv(nl, 256)), dim3(256), 0, st, m->nbr_s1[l], nl, bits, key_in, row_in);
+      if (int rc = sort_rows_by_key(sort_tmp, sort_bytes, key_in, key_out, row_in, m->perm_s1[l], nl, bits, st)) {
+        delete m;
+        return rc;
+      }
+    }
   }
   FAIL_HIP(hipGetLastError());
 #undef FAIL_HIP
