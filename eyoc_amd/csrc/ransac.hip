@@ -15,33 +15,43 @@ using namespace eyoc;
 
 namespace {
 
-__device__ inline unsigned int sample_index(unsigned long long base, unsigned long long ctr, unsigned int n) {
+// two sample indices per 64-bit word of the counter hash (low half, high half), each mapped to [0, n) by
+// (u * n) >> 32 - one v_mul_hi_u32 - so a hypothesis costs two splitmix64 finalisers, not four
+__device__ inline void sample_pair(unsigned long long base, unsigned long long ctr, unsigned int n, unsigned int& i0,
+                                   unsigned int& i1) {
   unsigned long long x = base + ctr;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
   x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
   x = x ^ (x >> 31);
-  const unsigned long long u = x >> 32;
-  return (unsigned int)((u * (unsigned long long)n) >> 32);
+  i0 = __umulhi((unsigned int)x, n);
+  i1 = __umulhi((unsigned int)(x >> 32), n);
 }
 
-__global__ void k_gather_targets(const float* __restrict__ tgt, const long long* __restrict__ corr, int n,
-                                 float* __restrict__ out) {
+// correspondence i as two 16-byte records (source point, its matched target point): the hypothesis generator
+// fetches a sampled point with ONE 128-bit load instead of three scattered dwords
+__global__ void k_gather_targets(const float* __restrict__ src, const float* __restrict__ tgt,
+                                 const long long* __restrict__ corr, int n, float4* __restrict__ src4,
+                                 float4* __restrict__ tc4) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const long long j = corr[i];
-  out[3 * i] = tgt[3 * j]; out[3 * i + 1] = tgt[3 * j + 1]; out[3 * i + 2] = tgt[3 * j + 2];
+  src4[i] = make_float4(src[3 * i], src[3 * i + 1], src[3 * i + 2], 0.f);
+  tc4[i] = make_float4(tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2], 0.f);
 }
 
 // transform of hypothesis h, or false if a checker rejects it
-__device__ inline bool hypothesis(const float* __restrict__ src, const float* __restrict__ tc, unsigned int n,
+__device__ inline bool hypothesis(const float4* __restrict__ src, const float4* __restrict__ tc, unsigned int n,
                                   unsigned long long base, unsigned int h, double edge_sim, double max_dist,
                                   double R[3][3], double t[3]) {
   double s[4][3], q[4][3];
+  unsigned int idx[4];
+  sample_pair(base, 2ull * h, n, idx[0], idx[1]);
+  sample_pair(base, 2ull * h + 1, n, idx[2], idx[3]);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const unsigned int i = sample_index(base, 4ull * h + j, n);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { s[j][d] = src[3 * i + d]; q[j][d] = tc[3 * i + d]; }
+    const float4 a = src[idx[j]], b = tc[idx[j]];
+    s[j][0] = a.x; s[j][1] = a.y; s[j][2] = a.z;
+    q[j][0] = b.x; q[j][1] = b.y; q[j][2] = b.z;
   }
   // edge-length checker on squared lengths (no square roots): ds < e*dt  <=>  ds^2 < e^2 dt^2
   const double e2 = edge_sim * edge_sim;
@@ -84,7 +94,7 @@ __device__ inline bool hypothesis(const float* __restrict__ src, const float* __
   return true;
 }
 
-__global__ __launch_bounds__(256) void k_generate(const float* __restrict__ src, const float* __restrict__ tc, int n,
+__global__ __launch_bounds__(256) void k_generate(const float4* __restrict__ src, const float4* __restrict__ tc, int n,
                                                   unsigned long long base, int H, float edge_sim, float max_dist,
                                                   int* __restrict__ n_surv, int* __restrict__ surv) {
   const int h = blockIdx.x * 256 + threadIdx.x;
@@ -95,7 +105,7 @@ __global__ __launch_bounds__(256) void k_generate(const float* __restrict__ src,
 }
 
 // key: (inliers << 32) | ~bits(rmse_f32): larger is better; ties on the key are broken by lower h
-__global__ __launch_bounds__(256) void k_score(const float* __restrict__ src, const float* __restrict__ tc, int n,
+__global__ __launch_bounds__(256) void k_score(const float4* __restrict__ src, const float4* __restrict__ tc, int n,
                                                unsigned long long base, float edge_sim, float max_dist,
                                                const int* __restrict__ n_surv, const int* __restrict__ surv,
                                                unsigned long long* __restrict__ keys) {
@@ -108,10 +118,11 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ src, co
     int cnt = 0;
     double err2 = 0;
     for (int i = lane; i < n; i += 64) {
-      const double x = src[3 * i], y = src[3 * i + 1], z = src[3 * i + 2];
-      const double dx = R[0][0] * x + R[0][1] * y + R[0][2] * z + t[0] - tc[3 * i];
-      const double dy = R[1][0] * x + R[1][1] * y + R[1][2] * z + t[1] - tc[3 * i + 1];
-      const double dz = R[2][0] * x + R[2][1] * y + R[2][2] * z + t[2] - tc[3 * i + 2];
+      const float4 a = src[i], b = tc[i];
+      const double x = a.x, y = a.y, z = a.z;
+      const double dx = R[0][0] * x + R[0][1] * y + R[0][2] * z + t[0] - b.x;
+      const double dy = R[1][0] * x + R[1][1] * y + R[1][2] * z + t[1] - b.y;
+      const double dz = R[2][0] * x + R[2][1] * y + R[2][2] * z + t[2] - b.z;
       const double d2 = dx * dx + dy * dy + dz * dz;
       if (sqrt(d2) < (double)max_dist) { ++cnt; err2 += d2; }
     }
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ src, co
   }
 }
 
-__global__ __launch_bounds__(1024) void k_select(const float* __restrict__ src, const float* __restrict__ tc, int n,
+__global__ __launch_bounds__(1024) void k_select(const float4* __restrict__ src, const float4* __restrict__ tc, int n,
                                                  unsigned long long base, float edge_sim, float max_dist,
                                                  const int* __restrict__ n_surv, const int* __restrict__ surv,
                                                  const unsigned long long* __restrict__ keys,
@@ -176,23 +187,26 @@ extern "C" int eyoc_ransac(eyoc_ctx* ctx, const float* src_dev, const float* tgt
   EYOC_REQUIRE(p->max_iteration >= 1, EYOC_ERR_INVALID, "eyoc_ransac: max_iteration %d", p->max_iteration);
   hipStream_t st = (hipStream_t)stream;
   const int H = p->max_iteration;
-  // scratch: [counter 256 B][tc n*3 f32][surv H i32][keys H u64]
-  const size_t off_tc = 256, off_surv = align_up(off_tc + (size_t)n * 12), off_keys = align_up(off_surv + (size_t)H * 4);
+  // scratch: [counter 256 B][src4 n float4][tc4 n float4][surv H i32][keys H u64]
+  const size_t off_src = 256, off_tc = align_up(off_src + (size_t)n * 16), off_surv = align_up(off_tc + (size_t)n * 16),
+               off_keys = align_up(off_surv + (size_t)H * 4);
   int rc = ctx->ensure_scratch(off_keys + (size_t)H * 8);
   if (rc) return rc;
   char* sc = (char*)ctx->scratch;
   int* n_surv = (int*)sc;
-  float* tc = (float*)(sc + off_tc);
+  float4* src4 = (float4*)(sc + off_src);
+  float4* tc = (float4*)(sc + off_tc);
   int* surv = (int*)(sc + off_surv);
   unsigned long long* keys = (unsigned long long*)(sc + off_keys);
   const unsigned long long base = (unsigned long long)p->seed * 0x9E3779B97F4A7C15ull;
   EYOC_CHECK_HIP(hipMemsetAsync(n_surv, 0, 256, st));
-  hipLaunchKernelGGL(k_gather_targets, dim3(cdiv(n, 256)), dim3(256), 0, st, tgt_dev, (const long long*)corr_tgt_dev, n, tc);
-  hipLaunchKernelGGL(k_generate, dim3(cdiv(H, 256)), dim3(256), 0, st, src_dev, tc, n, base, H, p->edge_similarity,
+  hipLaunchKernelGGL(k_gather_targets, dim3(cdiv(n, 256)), dim3(256), 0, st, src_dev, tgt_dev, (const long long*)corr_tgt_dev, n,
+                     src4, tc);
+  hipLaunchKernelGGL(k_generate, dim3(cdiv(H, 256)), dim3(256), 0, st, src4, tc, n, base, H, p->edge_similarity,
                      p->max_distance, n_surv, surv);
-  hipLaunchKernelGGL(k_score, dim3(2048), dim3(256), 0, st, src_dev, tc, n, base, p->edge_similarity, p->max_distance,
+  hipLaunchKernelGGL(k_score, dim3(2048), dim3(256), 0, st, src4, tc, n, base, p->edge_similarity, p->max_distance,
                      n_surv, surv, keys);
-  hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, st, src_dev, tc, n, base, p->edge_similarity, p->max_distance,
+  hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, st, src4, tc, n, base, p->edge_similarity, p->max_distance,
                      n_surv, surv, keys, result_dev);
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;

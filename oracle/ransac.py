@@ -21,8 +21,9 @@ counter-based sampler so that the HIP kernel can be checked hypothesis by hypoth
   7. ``RANSACConvergenceCriteria(4000000, 10000)``: the confidence argument is clamped to 1, which
      disables early termination - all ``max_iteration`` hypotheses are evaluated.
 
-Sampler (shared bit-for-bit with ``eyoc_amd/csrc/ransac.hip``): splitmix64 finaliser of the counter
-``seed * 0x9E3779B97F4A7C15 + 4 h + t``, upper 32 bits mapped to ``[0, n)`` by ``(u * n) >> 32``.
+Sampler (shared bit-for-bit with ``eyoc_amd/csrc/ransac.hip``): splitmix64 finaliser of the counters
+``seed * 0x9E3779B97F4A7C15 + 2 h + t`` (t = 0, 1); each 64-bit word yields two indices, its low and its high
+32 bits ``u`` mapped to ``[0, n)`` by ``(u * n) >> 32`` - samples 0, 1 from word 0 and 2, 3 from word 1.
 """
 from __future__ import annotations
 
@@ -35,13 +36,13 @@ def sample_indices(seed: int, h0: int, count: int, n: int) -> np.ndarray:
     """``[count, 4] int64`` correspondence indices for hypotheses ``h0 .. h0+count-1``."""
     with np.errstate(over="ignore"):
         base = np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15)
-        ctr = (np.arange(h0, h0 + count, dtype=np.uint64)[:, None] * np.uint64(4)
-               + np.arange(4, dtype=np.uint64)[None, :]) + base
+        ctr = (np.arange(h0, h0 + count, dtype=np.uint64)[:, None] * np.uint64(2)
+               + np.arange(2, dtype=np.uint64)[None, :]) + base
         x = ctr
         x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         x = x ^ (x >> np.uint64(31))
-        u = x >> np.uint64(32)
+        u = np.stack([x & np.uint64(0xFFFFFFFF), x >> np.uint64(32)], axis=2).reshape(count, 4)
         return ((u * np.uint64(n)) >> np.uint64(32)).astype(np.int64)
 
 
