@@ -15,6 +15,6 @@ from .eval import find_nn_gpu, pdist, find_corr, find_correspondences, random_sa
 from .transform_estimation import (est_quad_linear_robust, estimate_transform, pose_estimation,  # noqa: F401
                                    rigid_transform_3d, transform, integrate_trans)
 from .registration import (Matcher, registration_ransac_based_on_feature_matching,  # noqa: F401
-                           ransac_from_correspondences, RegistrationResult)
+                           ransac_from_correspondences, ransac_batched_from_correspondences, RegistrationResult)
 from .metrics import registration_errors, apply_transform, evaluate_nn_dist  # noqa: F401
 from .voxelize import sparse_quantize, voxelize, extract_features  # noqa: F401

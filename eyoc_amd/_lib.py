@@ -89,6 +89,8 @@ PROTOTYPES = {
     "eyoc_kabsch_batched": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "eyoc_irls_quad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "eyoc_ransac": (_i, [_vp, _vp, _vp, _vp, _i, C.POINTER(RansacParams), _vp, _vp]),
+    "eyoc_ransac_batched": (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i,
+                                 C.POINTER(RansacParams), _vp, _vp]),
     "eyoc_sc2pcr_workspace_bytes": (_sz, [_i, C.POINTER(Sc2pcrParams)]),
     "eyoc_sc2pcr": (_i, [_vp, _vp, _vp, _i, C.POINTER(Sc2pcrParams), _vp, _vp, _vp, _sz, _vp]),
 }

@@ -101,11 +101,10 @@ class RegistrationPipeline:
         n = batch.n_points
         out = []
         if self.cfg.use_RANSAC:
-            for p in range(batch.P):
-                out.append(reg.ransac_from_correspondences(
-                    batch.xyz0[p], batch.xyz1[p], nn_idx[p * n:(p + 1) * n], self.cfg.voxel_size * 1.0,
-                    self.cfg.ransac_max_iteration, seed=seed + p, as_device_result=True))
-            res = torch.stack(out)                                   # [P, 84] bytes on the device
+            # all pairs in one batched call (pair p samples with seed + p, exactly like a per-pair loop would)
+            res = reg.ransac_batched_from_correspondences(
+                batch.xyz0.reshape(-1, 3), batch.xyz1.reshape(-1, 3), nn_idx, batch.seg, batch.seg,
+                self.cfg.voxel_size * 1.0, self.cfg.ransac_max_iteration, seed=seed)   # [P, 84] bytes on the device
             if return_device:
                 return res
             host = res.cpu()

@@ -50,6 +50,26 @@ def ransac_from_correspondences(src, tgt, corr_tgt, max_correspondence_distance,
     return decode_ransac_result(res, n)
 
 
+def ransac_batched_from_correspondences(src, tgt, corr_tgt, seg_src, seg_tgt, max_correspondence_distance,
+                                        max_iteration=4000000, seed=0, edge_similarity=0.9):
+    """All pairs of a batch in a few launches: ``src [N,3]`` / ``corr_tgt int64 [N]`` hold the pairs back to back
+    (pair ``b`` = rows ``seg_src[b]:seg_src[b+1]``), ``tgt [M,3]`` likewise with ``seg_tgt``; ``corr_tgt`` indexes
+    INSIDE the pair's target segment.  Pair ``b`` uses ``seed + b``.  Returns the ``[P, 84]`` byte tensor of
+    ``eyoc_ransac_result`` records on the device (decode with ``decode_ransac_result``)."""
+    s = _cuda_f32(src)
+    t = _cuda_f32(tgt, s.device)
+    c = corr_tgt.to(s.device, torch.int64).contiguous()
+    P = len(seg_src) - 1
+    ss = (C.c_int32 * (P + 1))(*[int(v) for v in seg_src])
+    st = (C.c_int32 * (P + 1))(*[int(v) for v in seg_tgt])
+    p = _lib.RansacParams(float(max_correspondence_distance), float(edge_similarity), int(max_iteration), int(seed))
+    res = torch.empty((P, C.sizeof(_lib.RansacResult)), dtype=torch.uint8, device=s.device)
+    with torch.cuda.device(s.device):
+        _lib.check(_lib.load().eyoc_ransac_batched(_lib.ctx(s.device.index), _lib.ptr(s), _lib.ptr(t), _lib.ptr(c), ss, st, P,
+                                                   C.byref(p), _lib.ptr(res), _lib.stream_ptr()), "eyoc_ransac_batched")
+    return res
+
+
 def decode_ransac_result(res: torch.Tensor, n: int) -> RegistrationResult:
     r = _lib.RansacResult.from_buffer_copy(res.cpu().numpy().tobytes())
     T = np.array(list(r.T), np.float64).reshape(4, 4)

@@ -230,6 +230,14 @@ typedef struct {
  * result_dev points to one eyoc_ransac_result in device memory. */
 int eyoc_ransac(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int64_t* corr_tgt_dev,
                 int n, const eyoc_ransac_params* params, eyoc_ransac_result* result_dev, void* stream);
+/* The same for a batch of independent pairs in a few launches (the per-pair loop of scripts/test_kitti.py:130-225
+ * collapsed; SURVEY 8f "batched registration").  Pair b owns source rows / correspondences
+ * [seg_src[b], seg_src[b+1]) and target rows starting at seg_tgt[b]; corr_tgt holds target indices LOCAL to the
+ * pair's target segment; pair b samples with seed params->seed + b, so results[b] is bit-identical to
+ * eyoc_ransac on that pair with that seed.  seg_* are HOST arrays of n_pairs + 1 ints. */
+int eyoc_ransac_batched(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int64_t* corr_tgt_dev,
+                        const int32_t* seg_src_host, const int32_t* seg_tgt_host, int n_pairs,
+                        const eyoc_ransac_params* params, eyoc_ransac_result* results_dev, void* stream);
 
 /* replaces: Matcher.SC2_PCR (scripts/SC2_PCR/SC2_PCR.py:307-384) for bs == 1.
  * src,tgt f32 [n,3] matched correspondences -> T f32 [4,4], seedwise_fitness f32 [int(ratio*n)]. */

@@ -94,6 +94,39 @@ def test_ransac_no_survivor_and_permuted_correspondences():
         np.testing.assert_array_equal(res.transformation, np.eye(4))
 
 
+def test_ransac_batched_equals_per_pair_and_oracle():
+    """Ragged batch of 11 pairs (more than one launch chunk), one pair too large for the LDS-staged records:
+    every result is bit-identical to the single-pair call with seed + b, and the small ones to the oracle."""
+    import eyoc_amd
+    from eyoc_amd import registration as reg
+    from oracle import ransac as orn
+    T = gi.rigid(0.02, 0.01, -0.12, 5.0, -0.3, 0.2)
+    sizes = [400, 1500, 7000, 5, 900, 2048, 33, 640, 1200, 777, 3100]
+    H = 60000
+    src, tgt, corr, seg_s, seg_t, cases = [], [], [], [0], [0], []
+    for b, n in enumerate(sizes):
+        p0, p1, _ = gi.corr_case(200 + b, n, T, 0.25 if n > 100 else 1.0, noise=0.03)
+        perm = np.random.default_rng(b).permutation(n)
+        extra = np.random.default_rng(100 + b).uniform(-20, 20, (b * 3, 3)).astype(np.float32)   # unmatched target rows
+        t_rows = np.concatenate([p1[perm], extra])
+        c = np.argsort(perm)                                # source i matches target row c[i]
+        src.append(p0); tgt.append(t_rows); corr.append(c)
+        seg_s.append(seg_s[-1] + n); seg_t.append(seg_t[-1] + len(t_rows))
+        cases.append((p0, t_rows, c))
+    res = reg.ransac_batched_from_correspondences(torch.from_numpy(np.concatenate(src)), torch.from_numpy(np.concatenate(tgt)),
+                                                  torch.from_numpy(np.concatenate(corr)), seg_s, seg_t, 0.3, H, seed=40).cpu()
+    for b, (p0, t_rows, c) in enumerate(cases):
+        got = reg.decode_ransac_result(res[b], len(p0))
+        one = eyoc_amd.ransac_from_correspondences(torch.from_numpy(p0), torch.from_numpy(t_rows), torch.from_numpy(c), 0.3, H,
+                                                   seed=40 + b)
+        assert (got.survivors, got.best_hypothesis, got.inliers) == (one.survivors, one.best_hypothesis, one.inliers), b
+        np.testing.assert_array_equal(got.transformation, one.transformation)
+        if len(p0) <= 1500:
+            ref = orn.ransac(p0, t_rows, c, 0.3, H, seed=40 + b)
+            assert (got.survivors, got.best_hypothesis, got.inliers) == (ref["survivors"], ref["best_h"], ref["inliers"]), b
+            np.testing.assert_allclose(got.transformation, ref["T"], atol=1e-5)
+
+
 def test_feature_matching_ransac_end_to_end():
     import eyoc_amd
     T = gi.rigid(0.0, 0.01, -0.1, 6.0, -0.4, 0.05)
