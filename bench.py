@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=32, help="pairs per step per GPU (64 clouds of ~31k voxels in one batched forward)")
     ap.add_argument("--ransac-iters", type=int, default=4000000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency-probe", action="store_true",
+                    help="skip the single-pair latency runs (profiling passes: keeps the kernel statistics to the timed steps)")
     ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
     args = ap.parse_args()
 
@@ -147,15 +149,17 @@ def main():
     model.set_timing(False)
 
     # latency of ONE pair through the same path (configs[1] of BASELINE.json read literally); not part of `value`
-    single = DeviceBatch(pairs[:1], seeds[:1], device, cfg.n_points)
-    for _ in range(3):
-        pipe.register(single)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(10):
-        pipe.register(single)
-    torch.cuda.synchronize()
-    single_ms = (time.perf_counter() - t1) / 10 * 1e3
+    single_ms = None
+    if not args.no_latency_probe:
+        single = DeviceBatch(pairs[:1], seeds[:1], device, cfg.n_points)
+        for _ in range(3):
+            pipe.register(single)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            pipe.register(single)
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - t1) / 10 * 1e3
 
     # algorithmic work of one forward on this batch geometry
     x = eyoc_amd.SparseTensor(batch.feats, coordinates=batch.coords)
@@ -191,7 +195,7 @@ def main():
                        "voxels_per_level": rows},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "spconv_kernel<CT,BM,NW> (22 launches per forward, summed)",
+                         "kernel": "spconv_wave_kernel / spconv_kernel (the 22 sparse-conv launches of one forward, summed)",
                          "algorithmic_bytes_per_forward": gather, "ms_per_forward": conv_ms},
             "mfma": {"achieved": flops / (conv_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                      "frac": flops / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "flop_per_forward": flops},
