@@ -1,8 +1,8 @@
 // Brute-force 1-nearest-neighbour in feature space (lib/eval.py:18-48, lib/metrics.py:22-29 of the
-// reference).  One lane owns one query row (its C features live in VGPRs); target rows stream
-// through LDS in 256-row tiles and are read back as wave-wide broadcasts, so the kernel is pure
-// VALU work: 3 ops per (query, target, channel).  The four waves of a block walk different
-// quarters of each tile and grid.y splits the target range; partial minima are merged with one
+// reference).  One lane owns one query row (its C features live in VGPRs); the targets are transposed once
+// (channel-major) and read through the scalar cache as SGPR operands of packed-fp32 ops, so the kernel is pure
+// VALU work: 3 packed ops per (query, 2 targets, channel).  The four waves of a block walk interleaved
+// groups of targets and grid.y splits the target range; partial minima are merged with one
 // 64-bit atomicMin on (distance bits << 32 | index), which also implements "ties go to the lowest
 // index" independently of how the work was split.
 //
@@ -16,71 +16,121 @@ constexpr int MAX_SEG = 64;
 struct SegArgs {
   int a[MAX_SEG + 1];
   int b[MAX_SEG + 1];
+  int ld[MAX_SEG];              // targets of the segment rounded up to a whole group (row length of its transposed block)
+  long long bt_off[MAX_SEG];    // float offset of the segment's transposed block
 };
 
-template <int C> constexpr int tile_rows() { return C <= 32 ? 256 : 8192 / C; }  // 32 KB of LDS
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int TGROUP = 8;      // targets per inner iteration (four packed pairs)
+constexpr int SPLIT_ALIGN = 32;  // split boundaries: every wave of a block starts on a whole group
 
+// targets of segment s, channel-major and padded to a multiple of TGROUP: Bt[bt_off[s] + c * ld[s] + j].
+// Padding columns are zero and never compared.
+__global__ void knn_transpose_targets(const float* __restrict__ B, SegArgs seg, int C, float* __restrict__ Bt) {
+  const int s = blockIdx.z;
+  const int b0 = seg.b[s], nb = seg.b[s + 1] - b0, ld = seg.ld[s];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (c4, j): consecutive threads = consecutive targets
+  const int c4n = C / 4;
+  if (i >= ld * c4n) return;
+  const int j = i % ld, c4 = i / ld;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (j < nb) v = *reinterpret_cast<const float4*>(B + (size_t)(b0 + j) * C + 4 * c4);
+  float* dst = Bt + seg.bt_off[s] + (size_t)(4 * c4) * ld + j;
+  dst[0] = v.x; dst[ld] = v.y; dst[2 * (size_t)ld] = v.z; dst[3 * (size_t)ld] = v.w;
+}
+
+// Lane = query (C features in VGPRs); the targets are wave-uniform, so they come through the SCALAR cache
+// (s_load of eight consecutive targets of one channel) and feed the packed-fp32 ops as SGPR pairs: no LDS
+// traffic at all (the LDS-broadcast version of this kernel was bound by ds_read bandwidth, not by the VALU).
+// Two targets share one v_pk_* instruction; each (query, target) still sees the scalar contract.
 template <int C>
-__global__ __launch_bounds__(256) void knn1_kernel(const float* __restrict__ A, const float* __restrict__ B,
+__global__ __launch_bounds__(256) void knn1_kernel(const float* __restrict__ A, const float* __restrict__ Bt,
                                                    SegArgs seg, int split_len, int dist_type,
                                                    unsigned long long* __restrict__ best) {
 #pragma clang fp contract(off)
-  constexpr int TILE = tile_rows<C>();
-  __shared__ float tile[TILE * C];
   const int s = blockIdx.z;
   const int a0 = seg.a[s], na = seg.a[s + 1] - a0;
-  const int b0 = seg.b[s], nb = seg.b[s + 1] - b0;
+  const int nb = seg.b[s + 1] - seg.b[s], ld = seg.ld[s];
   const int q0 = blockIdx.x * 64;
   if (q0 >= na) return;
   const int t_begin = blockIdx.y * split_len;
   const int t_end = min(nb, t_begin + split_len);
   if (t_begin >= t_end) return;
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int q = q0 + lane;
   const bool q_ok = q < na;
-  float a[C];
+  f32x2 a[C];   // {a_c, a_c}: the query's feature in both halves of a packed operand
   {
     const float4* src = reinterpret_cast<const float4*>(A + (size_t)(a0 + (q_ok ? q : 0)) * C);
 #pragma unroll
     for (int i = 0; i < C / 4; ++i) {
-      float4 v = src[i];
-      a[4 * i] = v.x; a[4 * i + 1] = v.y; a[4 * i + 2] = v.z; a[4 * i + 3] = v.w;
+      const float4 v = src[i];
+      a[4 * i] = f32x2{v.x, v.x}; a[4 * i + 1] = f32x2{v.y, v.y}; a[4 * i + 2] = f32x2{v.z, v.z}; a[4 * i + 3] = f32x2{v.w, v.w};
     }
   }
   float best_d = __builtin_inff();
   int best_j = 0x7FFFFFFF;
   bool any = false;
-
-  for (int t0 = t_begin; t0 < t_end; t0 += TILE) {
-    const int cnt = min(TILE, t_end - t0);
-    __syncthreads();
-    {
-      const float4* src = reinterpret_cast<const float4*>(B + (size_t)(b0 + t0) * C);
-      float4* dst = reinterpret_cast<float4*>(tile);
-      for (int i = threadIdx.x; i < cnt * (C / 4); i += 256) dst[i] = src[i];
-    }
-    __syncthreads();
-    const int j_lo = wave * (TILE / 4);
-    const int j_hi = min(cnt, j_lo + TILE / 4);
-    for (int j = j_lo; j < j_hi; ++j) {
-      const float4* row = reinterpret_cast<const float4*>(tile + j * C);
-      float acc = 0.0f;
+  // the four waves of the block take interleaved groups of TGROUP targets
+  const float* bt = Bt + seg.bt_off[s];
+  for (int t = t_begin + wave * TGROUP; t < t_end; t += 4 * TGROUP) {
+    f32x2 acc[TGROUP / 2];
 #pragma unroll
-      for (int i = 0; i < C / 4; ++i) {
-        float4 b = row[i];
-        float d;
-        d = a[4 * i] - b.x;     acc = acc + d * d;
-        d = a[4 * i + 1] - b.y; acc = acc + d * d;
-        d = a[4 * i + 2] - b.z; acc = acc + d * d;
-        d = a[4 * i + 3] - b.w; acc = acc + d * d;
+    for (int k = 0; k < TGROUP / 2; ++k) acc[k] = f32x2{0.0f, 0.0f};
+    const float* col = bt + t;   // wave-uniform address
+    // Channels in batches of CB (eight SGPRs per channel).  Scalar loads return out of order, so a wait is always
+    // "all of them": the next batch is therefore issued right AFTER the wait for the current one (behind the first
+    // packed op that needs it) and its latency hides behind the rest of the current batch.
+    constexpr int CB = 4;
+    auto load_batch = [&](int cb, f32x2 (&b)[CB][TGROUP / 2]) {
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        const float4 lo = *reinterpret_cast<const float4*>(col + (size_t)(cb + c) * ld);
+        const float4 hi = *reinterpret_cast<const float4*>(col + (size_t)(cb + c) * ld + 4);
+        b[c][0] = f32x2{lo.x, lo.y}; b[c][1] = f32x2{lo.z, lo.w}; b[c][2] = f32x2{hi.x, hi.y}; b[c][3] = f32x2{hi.z, hi.w};
       }
-      if (dist_type == 1) acc = sqrtf(acc + 1e-7f);
-      if (acc < best_d) {
-        best_d = acc;
-        best_j = t0 + j;
-        any = true;
-      }
+    };
+    // the four target pairs side by side, so that dependent packed ops are never back to back (a wait state each)
+    auto channel = [&](int c, const f32x2 (&b)[TGROUP / 2]) {
+      f32x2 d[TGROUP / 2];
+#pragma unroll
+      for (int k = 0; k < TGROUP / 2; ++k) d[k] = a[c] - b[k];
+#pragma unroll
+      for (int k = 0; k < TGROUP / 2; ++k) d[k] = d[k] * d[k];
+#pragma unroll
+      for (int k = 0; k < TGROUP / 2; ++k) acc[k] = acc[k] + d[k];
+    };
+    f32x2 b0[CB][TGROUP / 2], b1[CB][TGROUP / 2];
+    load_batch(0, b0);
+#pragma unroll
+    for (int cb = 0; cb < C; cb += 2 * CB) {
+      __builtin_amdgcn_sched_barrier(0);
+      channel(cb, b0[0]);                               // forces the wait for batch b0
+      __builtin_amdgcn_sched_barrier(0);
+      load_batch(cb + CB, b1);                          // C is a multiple of 2 CB
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 1; c < CB; ++c) channel(cb + c, b0[c]);
+      __builtin_amdgcn_sched_barrier(0);
+      channel(cb + CB, b1[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (cb + 2 * CB < C) load_batch(cb + 2 * CB, b0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 1; c < CB; ++c) channel(cb + CB + c, b1[c]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < TGROUP; ++e) {
+      // branch-free on purpose: with branches here LLVM sinks the arithmetic of targets 2..7 below the first
+      // compare and keeps every scalar-loaded operand alive until then (SGPR spills)
+      float v = (e & 1) ? acc[e / 2].y : acc[e / 2].x;
+      v = dist_type == 1 ? sqrtf(v + 1e-7f) : v;
+      const bool better = (t + e < t_end) & (v < best_d);
+      best_d = better ? v : best_d;
+      best_j = better ? t + e : best_j;
+      any = any | better;
     }
   }
   if (q_ok && any) {
@@ -122,19 +172,18 @@ __global__ void pdist_kernel(const float* __restrict__ A, int n, const float* __
 }
 
 template <int C>
-void launch_knn(const float* A, const float* B, const SegArgs& seg, int nseg, int max_na, int max_nb, int dist_type,
+void launch_knn(const float* A, const float* Bt, const SegArgs& seg, int nseg, int max_na, int max_nb, int dist_type,
                 unsigned long long* best, hipStream_t st) {
-  constexpr int TILE = tile_rows<C>();
   int qtiles = eyoc::cdiv(max_na, 64);
   int total = qtiles * nseg;
-  int max_splits = eyoc::cdiv(max_nb, TILE);
-  int nsplit = 2048 / (total > 0 ? total : 1);
+  int max_splits = eyoc::cdiv(max_nb, SPLIT_ALIGN);
+  int nsplit = 4096 / (total > 0 ? total : 1);
   if (nsplit < 1) nsplit = 1;
   if (nsplit > max_splits) nsplit = max_splits;
-  int split_len = eyoc::cdiv(eyoc::cdiv(max_nb, nsplit), TILE) * TILE;
+  int split_len = eyoc::cdiv(eyoc::cdiv(max_nb, nsplit), SPLIT_ALIGN) * SPLIT_ALIGN;
   nsplit = eyoc::cdiv(max_nb, split_len);
   dim3 grid(qtiles, nsplit, nseg);
-  hipLaunchKernelGGL(knn1_kernel<C>, grid, dim3(256), 0, st, A, B, seg, split_len, dist_type, best);
+  hipLaunchKernelGGL(knn1_kernel<C>, grid, dim3(256), 0, st, A, Bt, seg, split_len, dist_type, best);
 }
 
 }  // namespace
@@ -160,16 +209,29 @@ extern "C" int eyoc_knn1(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, 
   const int n_total = seg_a[nseg] - seg_a[0];
   if (n_total == 0) return EYOC_OK;
   EYOC_REQUIRE(seg_a[0] == 0, EYOC_ERR_INVALID, "eyoc_knn1: seg_a[0] must be 0");
-  int rc = ctx->ensure_scratch((size_t)n_total * sizeof(unsigned long long));
+  long long bt_floats = 0;
+  int max_ld = 0;
+  for (int s = 0; s < nseg; ++s) {
+    const int nb = seg_b[s + 1] - seg_b[s];
+    seg.ld[s] = (nb + TGROUP - 1) / TGROUP * TGROUP;
+    seg.bt_off[s] = bt_floats;
+    bt_floats += (long long)seg.ld[s] * c;
+    max_ld = seg.ld[s] > max_ld ? seg.ld[s] : max_ld;
+  }
+  const size_t off_bt = eyoc::align_up((size_t)n_total * sizeof(unsigned long long));
+  int rc = ctx->ensure_scratch(off_bt + (size_t)bt_floats * sizeof(float) + 64);
   if (rc) return rc;
   unsigned long long* best = (unsigned long long*)ctx->scratch;
+  float* Bt = (float*)((char*)ctx->scratch + off_bt);
   EYOC_CHECK_HIP(hipMemsetAsync(best, 0xFF, (size_t)n_total * sizeof(unsigned long long), st));
   if (max_nb > 0) {
+    hipLaunchKernelGGL(knn_transpose_targets, dim3(eyoc::cdiv((long long)max_ld * (c / 4), 256), 1, nseg), dim3(256), 0, st, B_dev,
+                       seg, c, Bt);
     switch (c) {
-      case 16: launch_knn<16>(A_dev, B_dev, seg, nseg, max_na, max_nb, dist_type, best, st); break;
-      case 32: launch_knn<32>(A_dev, B_dev, seg, nseg, max_na, max_nb, dist_type, best, st); break;
-      case 64: launch_knn<64>(A_dev, B_dev, seg, nseg, max_na, max_nb, dist_type, best, st); break;
-      default: launch_knn<128>(A_dev, B_dev, seg, nseg, max_na, max_nb, dist_type, best, st); break;
+      case 16: launch_knn<16>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, st); break;
+      case 32: launch_knn<32>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, st); break;
+      case 64: launch_knn<64>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, st); break;
+      default: launch_knn<128>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, st); break;
     }
   }
   hipLaunchKernelGGL(knn1_unpack, dim3(eyoc::cdiv(n_total, 256)), dim3(256), 0, st, best, n_total,
