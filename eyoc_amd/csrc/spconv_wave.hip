@@ -173,13 +173,17 @@ __global__ __launch_bounds__((WCfg<CTW, BMW, CC, NCMAX>::WPB * 64), OCC) void sp
     float4 GA[C::JQ][NCMAX], GB[C::JQ][NCMAX], WA[C::JQ][C::NTW], WB[C::JQ][C::NTW];
     f32x4 accr[NCMAX][C::NTW];
 
+    // orow[] holds, per chunk, the BYTE offset of this lane's float4 column of tile 0 inside its accumulator row:
+    // row * CTW * 4 + ((g ^ row) & (C4N - 1)) * 16.  Tile t sits at that offset XOR t * 64 (the swizzle of acc_off,
+    // with the row-only part hoisted out of the per-tile work).
     auto read_records = [&](int slot, int cbase, const float* (&gp)[NCMAX], int (&orow)[NCMAX]) {
       const unsigned int* L = list + slot * C::LIST + cbase * 16 + j16;
 #pragma unroll
       for (int c = 0; c < NCMAX; ++c) {
         const unsigned rec = L[c * 16];
         gp[c] = a.in + (size_t)(rec >> 8) * a.ld_in + g * 4;
-        orow[c] = (int)(rec & 255u);
+        const int row = (int)(rec & 255u);
+        orow[c] = row * (CTW * 4) + (((g ^ row) & (C::C4N - 1)) << 4);
       }
     };
     auto load_gather = [&](const float* (&gp)[NCMAX], int cc_, float4 (&G)[C::JQ][NCMAX]) {
@@ -211,16 +215,27 @@ __global__ __launch_bounds__((WCfg<CTW, BMW, CC, NCMAX>::WPB * 64), OCC) void sp
     auto compute = [&](auto nc_tag, bool first_cc, bool last_cc, const float4 (&G)[C::JQ][NCMAX],
                        const float4 (&W)[C::JQ][C::NTW], const int (&orow)[NCMAX]) {
       constexpr int NC = decltype(nc_tag)::value;
-      if (first_cc) {
+      // the first MFMA of an item's first C_in slice takes a literal zero as its C operand: no accumulator clearing
+      {
+        if (first_cc) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
+          for (int c = 0; c < NC; ++c)
 #pragma unroll
-          for (int t = 0; t < C::NTW; ++t) accr[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < C::NTW; ++t)
+              accr[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[0][t].x, G[0][c].x, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int t = 0; t < C::NTW; ++t)
+              accr[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[0][t].x, G[0][c].x, accr[c][t], 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int q = 0; q < C::JQ; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; ++e) {
+          if (q == 0 && e == 0) continue;
 #pragma unroll
           for (int c = 0; c < NC; ++c) {
             const float av = e == 0 ? G[q][c].x : e == 1 ? G[q][c].y : e == 2 ? G[q][c].z : G[q][c].w;
@@ -230,21 +245,22 @@ __global__ __launch_bounds__((WCfg<CTW, BMW, CC, NCMAX>::WPB * 64), OCC) void sp
               accr[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, accr[c][t], 0, 0, 0);
             }
           }
-      TR();
+        }
       if (last_cc && EYOC_ABL != 3) {
         // D[i = 4 g + reg][j] = (output channel i of the tile, pair j): one 128-bit read-add-write per chunk and tile
         float4 old[NC][C::NTW];
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
-          for (int t = 0; t < C::NTW; ++t) old[c][t] = *reinterpret_cast<const float4*>(acc + acc_off(orow[c], t * 4 + g));
+          for (int t = 0; t < C::NTW; ++t)
+            old[c][t] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(acc) + (orow[c] ^ (t << 6)));
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
           for (int t = 0; t < C::NTW; ++t) {
             float4 v = old[c][t];
             v.x += accr[c][t][0]; v.y += accr[c][t][1]; v.z += accr[c][t][2]; v.w += accr[c][t][3];
-            *reinterpret_cast<float4*>(acc + acc_off(orow[c], t * 4 + g)) = v;
+            *reinterpret_cast<float4*>(reinterpret_cast<char*>(acc) + (orow[c] ^ (t << 6))) = v;
           }
       }
     };
