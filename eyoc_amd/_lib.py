@@ -67,6 +67,7 @@ PROTOTYPES = {
     "eyoc_maps_copy_coords": (_i, [_vp, _i, _vp, _vp]),
     "eyoc_maps_copy_table": (_i, [_vp, _i, _i, _vp, _vp]),
     "eyoc_maps_copy_up_order": (_i, [_vp, _i, _vp, _vp]),
+    "eyoc_maps_order_min_rows": (_i, [_i]),
     "eyoc_maps_info": (_i, [_vp, _vp, _i, _vp, C.POINTER(MapsInfo)]),
     "eyoc_voxelize_workspace_bytes": (_sz, [_i]),
     "eyoc_voxelize": (_i, [_vp, _vp, _i, _i, C.c_float, _i, _vp, _vp, C.POINTER(C.c_int), _vp, _sz, _vp]),

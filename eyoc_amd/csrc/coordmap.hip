@@ -176,6 +176,11 @@ __global__ void k_pattern_key(const int32_t* __restrict__ nbr, int n, int key_bi
   row[o] = o;
 }
 
+__global__ void k_iota(int32_t* __restrict__ out, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = i;
+}
+
 // voxel coordinates of raw points: floor(x / voxel) in fp32 (IEEE division, like torch / numpy on fp32 input)
 __global__ void k_quantize(const float* __restrict__ xyz, int n, int stride, float voxel, int batch,
                            int32_t* __restrict__ coords) {
@@ -303,6 +308,7 @@ __global__ void k_count_region(const int32_t* __restrict__ coords, int n, HashTa
 }
 
 constexpr int UP_KEY_BITS = 11;
+static int ORDER_MIN_ROWS = 65536;   // below this no convolution of the level reaches the wave-private kernel's tile count
 
 unsigned int table_capacity(int n) {
   unsigned int cap = 1024;
@@ -426,9 +432,18 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
   void* sort_tmp = cv.take<char>(sort_bytes);
   for (int l = EYOC_MAX_LEVELS - 2; l >= 0; --l) {
     const int nl = m->rows[l], nc = m->rows[l + 1];
-    m->perm_up[l] = cv.take<int32_t>((size_t)nl);
+    // the tiling orders only serve the wave-private convolution kernel, which takes over above ~4000 row tiles:
+    // small levels (single-pair latency path) skip the sorts
+    const bool ordered = nl >= ORDER_MIN_ROWS;
+    m->perm_up[l] = ordered ? cv.take<int32_t>((size_t)nl) : nullptr;
     hipLaunchKernelGGL(k_derive_fine, dim3(cdiv(nl, 256)), dim3(256), 0, st, m->coords[l], nl, l, m->parent[l],
-                       m->children[l], m->nbr_s1[l + 1], nc, m->nbr_s1[l], m->nbr_up[l], key_in, row_in);
+                       m->children[l], m->nbr_s1[l + 1], nc, m->nbr_s1[l], m->nbr_up[l], ordered ? key_in : (unsigned int*)nullptr,
+                       row_in);
+    if (!ordered) {
+      hipLaunchKernelGGL(k_derive_down, dim3(cdiv(nc, 256)), dim3(256), 0, st, nc, m->children[l], m->nbr_s1[l + 1],
+                         m->nbr_down[l]);
+      continue;
+    }
     if (sort_rows_tmp_bytes(nl, UP_KEY_BITS) > sort_bytes) {
       set_error("eyoc_maps_build: sort workspace too small for level %d", l);
       delete m;
@@ -446,6 +461,7 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
   if (s1_order) {
     for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
       const int nl = m->rows[l];
+      if (nl < ORDER_MIN_ROWS) continue;
       const int bits = l == 0 ? 2 : 4;   // level 0 feeds the 32-channel, bandwidth-bound layers: keep more locality
       m->perm_s1[l] = cv.take<int32_t>((size_t)nl);
       hipLaunchKernelGGL(k_pattern_key, dim3(cdiv(nl, 256)), dim3(256), 0, st, m->nbr_s1[l], nl, bits, key_in, row_in);
@@ -554,11 +570,22 @@ int eyoc_maps_copy_table(const eyoc_maps* maps, int kind, int level, int32_t* ou
   return EYOC_OK;
 }
 
+int eyoc_maps_order_min_rows(int min_rows) {
+  const int prev = ORDER_MIN_ROWS;
+  if (min_rows >= 0) ORDER_MIN_ROWS = min_rows;
+  return prev;
+}
+
 int eyoc_maps_copy_up_order(const eyoc_maps* maps, int level, int32_t* out_dev, void* stream) {
-  EYOC_REQUIRE(maps && out_dev && level >= 0 && level + 1 < maps->n_levels && maps->perm_up[level], EYOC_ERR_INVALID,
+  EYOC_REQUIRE(maps && out_dev && level >= 0 && level + 1 < maps->n_levels, EYOC_ERR_INVALID,
                "eyoc_maps_copy_up_order: bad level %d or NULL argument", level);
-  EYOC_CHECK_HIP(hipMemcpyAsync(out_dev, maps->perm_up[level], (size_t)maps->rows[level] * 4, hipMemcpyDeviceToDevice,
-                                (hipStream_t)stream));
+  const int n = maps->rows[level];
+  if (maps->perm_up[level]) {
+    EYOC_CHECK_HIP(hipMemcpyAsync(out_dev, maps->perm_up[level], (size_t)n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  } else {   // level too small to be ordered: the convolutions tile it in natural order
+    hipLaunchKernelGGL(k_iota, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, out_dev, n);
+    EYOC_CHECK_HIP(hipGetLastError());
+  }
   return EYOC_OK;
 }
 

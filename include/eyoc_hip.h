@@ -83,6 +83,9 @@ int eyoc_maps_free(eyoc_maps* maps);
  * scheduling aid (tiles whose rows share their occupied kernel offsets) - results do not depend on it.
  * out_dev: int32 [rows[level]]. */
 int eyoc_maps_copy_up_order(const eyoc_maps* maps, int level, int32_t* out_dev, void* stream);
+/* Levels with fewer rows than this keep the natural order (the sorts only pay off for the large-batch kernel;
+ * default 65536).  Process-wide; min_rows < 0 only queries.  Returns the previous value.  For tests / profiling. */
+int eyoc_maps_order_min_rows(int min_rows);
 int eyoc_maps_rows(const eyoc_maps* maps, int level);
 /* device pointers into the workspace; valid while the maps object lives */
 const int32_t* eyoc_maps_coords(const eyoc_maps* maps, int level);             /* [rows,4]        */

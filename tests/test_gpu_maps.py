@@ -18,6 +18,16 @@ def random_cloud(seed, n, extent=40, batch=1):
     return syn.batch_coords(out)
 
 
+@pytest.fixture(autouse=True)
+def order_small_levels():
+    """The tiling orders are only built for large levels in production; build them for the small test clouds too."""
+    from eyoc_amd import _lib
+    lib = _lib.load()
+    prev = lib.eyoc_maps_order_min_rows(0)
+    yield
+    lib.eyoc_maps_order_min_rows(prev)
+
+
 def check_up_order(order, up):
     """The tiling order of a transposed convolution: a permutation of the rows in which every pattern of
     occupied offsets forms ONE run, rows ascending inside a run (stable)."""
