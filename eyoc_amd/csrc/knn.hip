@@ -43,10 +43,13 @@ __global__ void knn_transpose_targets(const float* __restrict__ B, SegArgs seg, 
 // (s_load of eight consecutive targets of one channel) and feed the packed-fp32 ops as SGPR pairs: no LDS
 // traffic at all (the LDS-broadcast version of this kernel was bound by ds_read bandwidth, not by the VALU).
 // Two targets share one v_pk_* instruction; each (query, target) still sees the scalar contract.
-template <int C>
+// TOP2: also track the second smallest distance (Lowe's ratio test of the label generator,
+// lib/trainer.py:1060-1072); the target range is then NOT split over blocks (a 64-bit atomicMin cannot merge a
+// runner-up) and the four waves of the block merge their partial results through LDS.
+template <int C, bool TOP2>
 __global__ __launch_bounds__(256) void knn1_kernel(const float* __restrict__ A, const float* __restrict__ Bt,
                                                    SegArgs seg, int split_len, int dist_type,
-                                                   unsigned long long* __restrict__ best) {
+                                                   unsigned long long* __restrict__ best, float* __restrict__ second) {
 #pragma clang fp contract(off)
   const int s = blockIdx.z;
   const int a0 = seg.a[s], na = seg.a[s + 1] - a0;
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256) void knn1_kernel(const float* __restrict__ A, 
       a[4 * i] = f32x2{v.x, v.x}; a[4 * i + 1] = f32x2{v.y, v.y}; a[4 * i + 2] = f32x2{v.z, v.z}; a[4 * i + 3] = f32x2{v.w, v.w};
     }
   }
-  float best_d = __builtin_inff();
+  float best_d = __builtin_inff(), second_d = __builtin_inff();
   int best_j = 0x7FFFFFFF;
   bool any = false;
   // the four waves of the block take interleaved groups of TGROUP targets
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256) void knn1_kernel(const float* __restrict__ A, 
     // Channels in batches of CB (eight SGPRs per channel).  Scalar loads return out of order, so a wait is always
     // "all of them": the next batch is therefore issued right AFTER the wait for the current one (behind the first
     // packed op that needs it) and its latency hides behind the rest of the current batch.
-    constexpr int CB = 4;
+    constexpr int CB = C >= 8 ? 4 : C / 2;
     auto load_batch = [&](int cb, f32x2 (&b)[CB][TGROUP / 2]) {
 #pragma unroll
       for (int c = 0; c < CB; ++c) {
@@ -127,11 +130,40 @@ __global__ __launch_bounds__(256) void knn1_kernel(const float* __restrict__ A, 
       // compare and keeps every scalar-loaded operand alive until then (SGPR spills)
       float v = (e & 1) ? acc[e / 2].y : acc[e / 2].x;
       v = dist_type == 1 ? sqrtf(v + 1e-7f) : v;
-      const bool better = (t + e < t_end) & (v < best_d);
+      const bool valid = t + e < t_end;
+      const bool better = valid & (v < best_d);
+      if (TOP2) {   // the displaced best, or a value between the two, becomes the runner-up (NaNs never enter)
+        const float cand = better ? best_d : v;
+        second_d = (valid & (cand < second_d)) ? cand : second_d;
+      }
       best_d = better ? v : best_d;
       best_j = better ? t + e : best_j;
       any = any | better;
     }
+  }
+  if (TOP2) {
+    __shared__ float sd1[4][64], sd2[4][64];
+    __shared__ int sj[4][64];
+    sd1[wave][lane] = best_d; sd2[wave][lane] = second_d; sj[wave][lane] = any ? best_j : 0x7FFFFFFF;
+    __syncthreads();
+    if (wave == 0 && q_ok) {
+      float d1 = sd1[0][lane], d2 = sd2[0][lane];
+      int j1 = sj[0][lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float e1 = sd1[w][lane], e2 = sd2[w][lane];
+        const int k1 = sj[w][lane];
+        const bool take = (e1 < d1) | ((e1 == d1) & (k1 < j1));   // smaller distance, ties to the lower index
+        const float lose = take ? d1 : e1;                          // the loser of the two bests is a runner-up candidate
+        d1 = take ? e1 : d1;
+        j1 = take ? k1 : j1;
+        float r = d2 < e2 ? d2 : e2;
+        d2 = lose < r ? lose : r;
+      }
+      if (j1 != 0x7FFFFFFF) best[a0 + q] = ((unsigned long long)__float_as_uint(d1) << 32) | (unsigned)j1;
+      second[a0 + q] = d2;
+    }
+    return;
   }
   if (q_ok && any) {
     unsigned long long packed = ((unsigned long long)__float_as_uint(best_d) << 32) | (unsigned)best_j;
@@ -173,29 +205,30 @@ __global__ void pdist_kernel(const float* __restrict__ A, int n, const float* __
 
 template <int C>
 void launch_knn(const float* A, const float* Bt, const SegArgs& seg, int nseg, int max_na, int max_nb, int dist_type,
-                unsigned long long* best, hipStream_t st) {
+                unsigned long long* best, float* second, hipStream_t st) {
   int qtiles = eyoc::cdiv(max_na, 64);
   int total = qtiles * nseg;
   int max_splits = eyoc::cdiv(max_nb, SPLIT_ALIGN);
   int nsplit = 4096 / (total > 0 ? total : 1);
-  if (nsplit < 1) nsplit = 1;
+  if (nsplit < 1 || second) nsplit = 1;
   if (nsplit > max_splits) nsplit = max_splits;
   int split_len = eyoc::cdiv(eyoc::cdiv(max_nb, nsplit), SPLIT_ALIGN) * SPLIT_ALIGN;
   nsplit = eyoc::cdiv(max_nb, split_len);
   dim3 grid(qtiles, nsplit, nseg);
-  hipLaunchKernelGGL(knn1_kernel<C>, grid, dim3(256), 0, st, A, Bt, seg, split_len, dist_type, best);
+  if (second) hipLaunchKernelGGL((knn1_kernel<C, true>), grid, dim3(256), 0, st, A, Bt, seg, split_len, dist_type, best, second);
+  else hipLaunchKernelGGL((knn1_kernel<C, false>), grid, dim3(256), 0, st, A, Bt, seg, split_len, dist_type, best, second);
 }
 
 }  // namespace
 
-extern "C" int eyoc_knn1(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c, const int32_t* seg_a,
-                         const int32_t* seg_b, int nseg, int dist_type, int64_t* idx_dev, float* dist_dev,
-                         void* stream) {
+static int knn_run(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c, const int32_t* seg_a,
+                   const int32_t* seg_b, int nseg, int dist_type, int64_t* idx_dev, float* dist_dev, float* second_dev,
+                   void* stream) {
   EYOC_REQUIRE(ctx && A_dev && B_dev && seg_a && seg_b, EYOC_ERR_INVALID, "eyoc_knn1: NULL argument");
   EYOC_REQUIRE(nseg >= 1 && nseg <= MAX_SEG, EYOC_ERR_INVALID, "eyoc_knn1: nseg %d not in [1,%d]", nseg, MAX_SEG);
   EYOC_REQUIRE(dist_type == 0 || dist_type == 1, EYOC_ERR_INVALID, "eyoc_knn1: dist_type %d", dist_type);
-  EYOC_REQUIRE(c == 16 || c == 32 || c == 64 || c == 128, EYOC_ERR_INVALID,
-               "eyoc_knn1: feature dimension %d not supported (16/32/64/128)", c);
+  EYOC_REQUIRE(c == 4 || c == 16 || c == 32 || c == 64 || c == 128, EYOC_ERR_INVALID,
+               "eyoc_knn1: feature dimension %d not supported (4/16/32/64/128)", c);
   hipStream_t st = (hipStream_t)stream;
   SegArgs seg;
   int max_na = 0, max_nb = 0;
@@ -228,16 +261,29 @@ extern "C" int eyoc_knn1(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, 
     hipLaunchKernelGGL(knn_transpose_targets, dim3(eyoc::cdiv((long long)max_ld * (c / 4), 256), 1, nseg), dim3(256), 0, st, B_dev,
                        seg, c, Bt);
     switch (c) {
-      case 16: launch_knn<16>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, st); break;
-      case 32: launch_knn<32>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, st); break;
-      case 64: launch_knn<64>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, st); break;
-      default: launch_knn<128>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, st); break;
+      case 4: launch_knn<4>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, st); break;
+      case 16: launch_knn<16>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, st); break;
+      case 32: launch_knn<32>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, st); break;
+      case 64: launch_knn<64>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, st); break;
+      default: launch_knn<128>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, st); break;
     }
   }
   hipLaunchKernelGGL(knn1_unpack, dim3(eyoc::cdiv(n_total, 256)), dim3(256), 0, st, best, n_total,
                      (long long*)idx_dev, dist_dev);
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
+}
+
+extern "C" int eyoc_knn1(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c, const int32_t* seg_a,
+                         const int32_t* seg_b, int nseg, int dist_type, int64_t* idx_dev, float* dist_dev,
+                         void* stream) {
+  return knn_run(ctx, A_dev, B_dev, c, seg_a, seg_b, nseg, dist_type, idx_dev, dist_dev, nullptr, stream);
+}
+
+extern "C" int eyoc_knn2(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c, const int32_t* seg_a,
+                         const int32_t* seg_b, int nseg, int64_t* idx_dev, float* d1_dev, float* d2_dev, void* stream) {
+  EYOC_REQUIRE(d2_dev != nullptr, EYOC_ERR_INVALID, "eyoc_knn2: d2_dev is NULL");
+  return knn_run(ctx, A_dev, B_dev, c, seg_a, seg_b, nseg, 0, idx_dev, d1_dev, d2_dev, stream);
 }
 
 extern "C" int eyoc_pdist(eyoc_ctx* ctx, const float* A_dev, int n, const float* B_dev, int m, int c, int dist_type,

@@ -188,11 +188,36 @@ int eyoc_model_layer_ms(eyoc_model* model, float* ms /*[num_layers]*/);
  *   form, fp32, channels left to right, no FMA - bit-exact with oracle/matching.py); 1: L2 =
  *   sqrt(d2 + 1e-7); ties go to the lowest index.  Segmented form: nseg independent problems,
  *   rows [seg_a[s], seg_a[s+1]) of A against rows [seg_b[s], seg_b[s+1]) of B; indices are local to
- *   the B segment.  seg arrays are HOST arrays; nseg <= 64.  c <= 128.
+ *   the B segment.  seg arrays are HOST arrays; nseg <= 64.  c in {4, 16, 32, 64, 128}.
  * --------------------------------------------------------------------------------------------- */
 int eyoc_knn1(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c, const int32_t* seg_a,
               const int32_t* seg_b, int nseg, int dist_type, int64_t* idx_dev, float* dist_dev,
               void* stream);
+
+/* Two nearest neighbours for Lowe's ratio test (replaces pytorch3d.ops.knn_points(..., K=2) at
+ * lib/trainer.py:1060-1061, squared L2 like knn_points): idx int64 [n] (nearest, local to the B segment), d1 / d2
+ * f32 [n] smallest and second smallest squared distance (+inf when the segment has < 2 rows).  Same arithmetic
+ * and tie rule as eyoc_knn1; c may also be 4 (xyz padded with a zero column) for the 3-D nearest neighbour
+ * of lib/trainer.py:1195. */
+int eyoc_knn2(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c, const int32_t* seg_a,
+              const int32_t* seg_b, int nseg, int64_t* idx_dev, float* d1_dev, float* d2_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * label generation
+ *   replaces: calculate_ratio_test + get_topk_matches (lib/trainer.py:993-1017, 1066-1084): weight of every
+ *   query from its two nearest squared feature distances (cosine = 1 - d/2; x = clamp(1 - cosine, 1e-9);
+ *   weight = 1 - x0/x1, fp32 in that order) and the k queries of largest weight, largest first (torch.topk
+ *   order; ties in query order).  idx_out int64 [k], w_out f32 [k] or NULL; k <= n.
+ *   eyoc_pair_filter: order-preserving filter of index pairs (idx0[i], idx1[i]):
+ *     mode 0 (spherical filter, lib/trainer.py:1107-1110): keep iff |P0[idx0]| > radius and |P1[idx1]| > radius;
+ *     mode 1 (pose consistency, lib/trainer.py:1203-1206): keep iff |R P0[idx0] + t - P1[idx1]| < radius,
+ *            T_dev f32 [16] row-major.  pairs_out int64 [m,2] (first *n_out rows valid), n_out int32 on the device.
+ * --------------------------------------------------------------------------------------------- */
+int eyoc_lowe_topk(eyoc_ctx* ctx, const float* d1_dev, const float* d2_dev, int n, int k, int64_t* idx_out_dev,
+                   float* w_out_dev, void* stream);
+int eyoc_pair_filter(eyoc_ctx* ctx, int mode, const float* P0_dev, const float* P1_dev, const int64_t* idx0_dev,
+                     const int64_t* idx1_dev, int m, const float* T_dev, float radius, int64_t* pairs_out_dev,
+                     int32_t* n_out_dev, void* stream);
 
 /* replaces: lib.metrics.pdist (lib/metrics.py:22-29): dense out f32 [n,m]; same arithmetic as eyoc_knn1 */
 int eyoc_pdist(eyoc_ctx* ctx, const float* A_dev, int n, const float* B_dev, int m, int c, int dist_type,

@@ -13,4 +13,7 @@ Pinning status:
     installed here, and the reference holds no test or golden file for them.  They restate the
     published MinkowskiEngine 0.5.x / Open3D >= 0.12 algorithms and are pinned only by
     self-consistency checks (dense ``conv3d`` equivalence, hand-computed toy cases).
+  * ``voxelize.py`` (``ME.utils.sparse_quantize``) and ``labels.py`` (``lib/trainer.py:993-1218``, which imports
+    MinkowskiEngine / pytorch3d / open3d at module level): **parity unpinned** for the same reason; restated from
+    the source lines cited in each function, checked against independent numpy formulations.
 """

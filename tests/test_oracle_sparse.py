@@ -131,3 +131,38 @@ def test_ransac_recovers_planted_pose():
     assert res["survivors"] > 0 and res["inliers"] > 0.2 * len(p0)
     np.testing.assert_allclose(res["T"][:3, :3], T[:3, :3], atol=0.02)
     np.testing.assert_allclose(res["T"][:3, 3], T[:3, 3], atol=0.3)
+
+
+def test_label_oracle_properties():
+    """oracle/labels.py against independent numpy formulations (parity unpinned: lib/trainer.py cannot be imported)."""
+    from oracle import labels as ol
+    rng = np.random.default_rng(3)
+    A = rng.normal(size=(200, 32)).astype(np.float32)
+    B = rng.normal(size=(333, 32)).astype(np.float32)
+    idx, d1, d2 = ol.knn2(A, B)
+    D = ((A[:, None, :].astype(np.float64) - B[None].astype(np.float64)) ** 2).sum(2)
+    part = np.sort(D, axis=1)[:, :2]
+    np.testing.assert_array_equal(idx, D.argmin(1))
+    np.testing.assert_allclose(d1, part[:, 0], rtol=1e-5)
+    np.testing.assert_allclose(d2, part[:, 1], rtol=1e-5)
+    assert (d1 <= d2).all()
+    w = ol.lowe_weights(d1 / 40, d2 / 40)                       # unit-feature range: weight = 1 - d1/d2
+    np.testing.assert_allclose(w, 1 - d1 / d2, atol=2e-5)
+    src, tgt, ws = ol.topk_matches(w, idx, 50)
+    assert (np.diff(ws) <= 0).all() and len(src) == 50 and (tgt == idx[src]).all()
+    assert set(src) == set(np.argsort(-w, kind="stable")[:50])
+    # spherical filter keeps exactly the pairs with both ends outside the radius
+    C0 = rng.uniform(-40, 40, (200, 3)).astype(np.float32)
+    C1 = rng.uniform(-40, 40, (333, 3)).astype(np.float32)
+    F = lambda x: x / np.linalg.norm(x, axis=1, keepdims=True)
+    m, unc = ol.match_and_filter_corr([C0], [F(A)], [C1], [F(B)], radius=20, num_corres=60)
+    assert m.shape == (120, 2) and len(unc) == 1
+    keep = (np.linalg.norm(C0[m[:, 0]], axis=1) > 20) & (np.linalg.norm(C1[m[:, 1]], axis=1) > 20)
+    np.testing.assert_array_equal(unc[0], m[keep])
+    # pose-consistency filter
+    T = np.eye(4, dtype=np.float32); T[:3, 3] = [1, 2, 3]
+    P0 = rng.uniform(-10, 10, (300, 3)).astype(np.float32)
+    P1 = (P0 + T[:3, 3]).astype(np.float32)[::-1].copy()
+    out = ol.correspondences_under_pose(P0, P1, T, np.arange(0, 300, 3), 0.01)
+    np.testing.assert_array_equal(out[:, 1], 299 - out[:, 0])
+    assert len(out) == 100
