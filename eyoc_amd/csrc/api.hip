@@ -22,6 +22,17 @@ int eyoc_ctx::ensure_scratch(size_t bytes) {
   return EYOC_OK;
 }
 
+int eyoc_ctx::ensure_pool() {
+  if (pool_ready) return EYOC_OK;
+  EYOC_CHECK_HIP(hipEventCreateWithFlags(&pool_fork, hipEventDisableTiming));
+  for (int i = 0; i < POOL; ++i) {
+    EYOC_CHECK_HIP(hipStreamCreateWithFlags(&pool[i], hipStreamNonBlocking));
+    EYOC_CHECK_HIP(hipEventCreateWithFlags(&pool_done[i], hipEventDisableTiming));
+  }
+  pool_ready = true;
+  return EYOC_OK;
+}
+
 extern "C" {
 
 int eyoc_version(void) { return EYOC_VERSION; }
@@ -53,6 +64,13 @@ int eyoc_create(int device, eyoc_ctx** out) {
 
 int eyoc_destroy(eyoc_ctx* ctx) {
   if (!ctx) return EYOC_OK;
+  if (ctx->pool_ready) {
+    for (int i = 0; i < eyoc_ctx::POOL; ++i) {
+      (void)hipStreamDestroy(ctx->pool[i]);
+      (void)hipEventDestroy(ctx->pool_done[i]);
+    }
+    (void)hipEventDestroy(ctx->pool_fork);
+  }
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   delete ctx;

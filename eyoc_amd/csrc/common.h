@@ -61,6 +61,14 @@ struct eyoc_ctx {
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   int ensure_scratch(size_t bytes);
+  // side streams for batches of small independent problems (eyoc_sc2pcr_batched): forked from and joined to the
+  // caller's stream with events, created on first use
+  static constexpr int POOL = 8;
+  hipStream_t pool[POOL] = {};
+  hipEvent_t pool_done[POOL] = {};
+  hipEvent_t pool_fork = nullptr;
+  bool pool_ready = false;
+  int ensure_pool();
 };
 
 // ---------------------------------------------------------------------------------------------

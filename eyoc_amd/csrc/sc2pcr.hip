@@ -564,4 +564,53 @@ int eyoc_sc2pcr(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, int n
   return EYOC_OK;
 }
 
+// A batch of independent pairs (the loop of lib/trainer.py:1157-1166, which the reference leaves sequential with a
+// "ToDo: ... batched and parallelized").  One pair is ~50 small launches that fill a fraction of the GPU, so the
+// pairs run concurrently on the context's side streams (pair b on stream b % 8 with its own workspace slice),
+// forked from and joined back to `stream` with events.  Results are bit-identical to eyoc_sc2pcr per pair.
+//   src/tgt: pairs back to back, pair b = rows [seg[b], seg[b+1]) (HOST array of n_pairs + 1 ints);
+//   params[b]: per pair (the seed count int(ratio * n) depends on n);  T_dev f32 [n_pairs,16];
+//   fitness_dev f32 [n_pairs, fitness_stride] (row b holds the n_seed_b seedwise values).
+size_t eyoc_sc2pcr_batched_workspace_bytes(int max_n, const eyoc_sc2pcr_params* params) {
+  const size_t one = eyoc_sc2pcr_workspace_bytes(max_n, params);
+  return one ? align_up(one) * eyoc_ctx::POOL : 0;
+}
+
+int eyoc_sc2pcr_batched(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int32_t* seg_host, int n_pairs,
+                        const eyoc_sc2pcr_params* params, float* T_dev, float* fitness_dev, int fitness_stride, void* ws,
+                        size_t ws_bytes, void* stream) {
+  EYOC_REQUIRE(ctx && src_dev && tgt_dev && seg_host && params && T_dev && fitness_dev && ws, EYOC_ERR_INVALID,
+               "eyoc_sc2pcr_batched: NULL argument");
+  EYOC_REQUIRE(n_pairs >= 1, EYOC_ERR_INVALID, "eyoc_sc2pcr_batched: n_pairs %d", n_pairs);
+  size_t slice = 0;
+  for (int b = 0; b < n_pairs; ++b) {
+    const int n = seg_host[b + 1] - seg_host[b];
+    const size_t need = eyoc_sc2pcr_workspace_bytes(n, &params[b]);
+    EYOC_REQUIRE(need > 0, EYOC_ERR_INVALID, "eyoc_sc2pcr_batched: pair %d has an unsupported size %d", b, n);
+    EYOC_REQUIRE((int)(params[b].ratio * n) <= fitness_stride, EYOC_ERR_INVALID,
+                 "eyoc_sc2pcr_batched: fitness_stride %d too small for pair %d", fitness_stride, b);
+    slice = need > slice ? need : slice;
+  }
+  slice = align_up(slice);
+  EYOC_REQUIRE(ws_bytes >= slice * eyoc_ctx::POOL && ((uintptr_t)ws & 255) == 0, EYOC_ERR_WORKSPACE,
+               "eyoc_sc2pcr_batched: workspace %zu < required %zu bytes (256-byte aligned)", ws_bytes, slice * eyoc_ctx::POOL);
+  int rc = ctx->ensure_pool();
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  EYOC_CHECK_HIP(hipEventRecord(ctx->pool_fork, st));
+  const int used = n_pairs < eyoc_ctx::POOL ? n_pairs : eyoc_ctx::POOL;
+  for (int i = 0; i < used; ++i) EYOC_CHECK_HIP(hipStreamWaitEvent(ctx->pool[i], ctx->pool_fork, 0));
+  for (int b = 0; b < n_pairs; ++b) {
+    const int i = b % eyoc_ctx::POOL, s0 = seg_host[b], n = seg_host[b + 1] - s0;
+    rc = eyoc_sc2pcr(ctx, src_dev + 3 * (size_t)s0, tgt_dev + 3 * (size_t)s0, n, &params[b], T_dev + 16 * (size_t)b,
+                     fitness_dev + (size_t)b * fitness_stride, (char*)ws + slice * i, slice, ctx->pool[i]);
+    if (rc) break;
+  }
+  for (int i = 0; i < used; ++i) {   // always join, also on the error path
+    (void)hipEventRecord(ctx->pool_done[i], ctx->pool[i]);
+    (void)hipStreamWaitEvent(st, ctx->pool_done[i], 0);
+  }
+  return rc;
+}
+
 }  // extern "C"

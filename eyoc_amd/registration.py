@@ -164,6 +164,31 @@ class Matcher:
                                        _lib.ptr(fit), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "eyoc_sc2pcr")
         return T.to(dev_in), fit[:, :n_seed].to(dev_in)
 
+    def SC2_PCR_batch(self, src_list, tgt_list):
+        """The loop of lib/trainer.py:1157-1166 (``SC2_PCR`` once per pair, which the reference leaves sequential)
+        as one batched call: lists of ``[n_b,3]`` matched key points -> list of ``(T [4,4], seedwise_fitness)``,
+        each bit-identical to ``SC2_PCR(src[None], tgt[None])`` on that pair."""
+        ss = [_cuda_f32(s) for s in src_list]
+        dev = ss[0].device
+        ns = [min(s.shape[0], int(self.max_points)) for s in ss]
+        src = torch.cat([s[:n] for s, n in zip(ss, ns)]).contiguous()
+        tgt = torch.cat([_cuda_f32(t, dev)[:n] for t, n in zip(tgt_list, ns)]).contiguous()
+        B = len(ns)
+        seg = (C.c_int32 * (B + 1))(*np.concatenate([[0], np.cumsum(ns)]).astype(int).tolist())
+        pn = [self._params(n) for n in ns]
+        params = (_lib.Sc2pcrParams * B)(*[p for p, _ in pn])
+        stride = max(max(k for _, k in pn), 1)
+        T = torch.empty((B, 4, 4), dtype=torch.float32, device=dev)
+        fit = torch.zeros((B, stride), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        i_max = int(np.argmax(ns))
+        with torch.cuda.device(dev):
+            ws = _lib.workspace(lib.eyoc_sc2pcr_batched_workspace_bytes(ns[i_max], C.byref(params[i_max])), dev)
+            _lib.check(lib.eyoc_sc2pcr_batched(_lib.ctx(dev.index), _lib.ptr(src), _lib.ptr(tgt), seg, B, params, _lib.ptr(T),
+                                               _lib.ptr(fit), stride, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+                       "eyoc_sc2pcr_batched")
+        return [(T[b], fit[b, :pn[b][1]]) for b in range(B)]
+
     def estimator(self, src_keypts, tgt_keypts, src_features, tgt_features, rng=None):
         """:386-413 -> ``(T, labels, src_corr, tgt_corr, seedwise_fitness)``."""
         src_corr, tgt_corr = self.match_pair(src_keypts, tgt_keypts, src_features, tgt_features, rng)

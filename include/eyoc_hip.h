@@ -277,6 +277,14 @@ size_t eyoc_sc2pcr_workspace_bytes(int n, const eyoc_sc2pcr_params* params);
 int eyoc_sc2pcr(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, int n,
                 const eyoc_sc2pcr_params* params, float* T_dev, float* fitness_dev,
                 void* workspace_dev, size_t workspace_bytes, void* stream);
+/* A batch of independent pairs (the per-pair loop of lib/trainer.py:1157-1166; SURVEY 8f "batched registration"):
+ * pair b = rows [seg[b], seg[b+1]) of src / tgt (seg: HOST array of n_pairs + 1 ints), params[b] per pair,
+ * T_dev f32 [n_pairs,16], fitness_dev f32 [n_pairs, fitness_stride].  Pairs run concurrently on internal side
+ * streams, forked from / joined to `stream`; results are bit-identical to eyoc_sc2pcr on each pair. */
+size_t eyoc_sc2pcr_batched_workspace_bytes(int max_n, const eyoc_sc2pcr_params* params);
+int eyoc_sc2pcr_batched(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int32_t* seg_host,
+                        int n_pairs, const eyoc_sc2pcr_params* params, float* T_dev, float* fitness_dev,
+                        int fitness_stride, void* workspace_dev, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -70,3 +70,38 @@ def test_sc2pcr_kitti_sized_problem_recovers_pose():
     rte, rre, ok = eyoc_amd.registration_errors(Tg[0].cpu().numpy(), T)
     assert ok and rte < 0.05 and rre < np.deg2rad(0.2)
     assert fit.shape == (1, 1600)
+
+
+def test_sc2pcr_batched_equals_per_pair():
+    """11 ragged pairs (more than the 8 side streams): every pose and seedwise fitness is bit-identical to the
+    single-pair call, and the caller's stream sees the results without an explicit sync."""
+    import time
+    import eyoc_amd
+    m = eyoc_amd.Matcher(inlier_threshold=0.6, d_thre=0.1, ratio=0.2, nms_radius=0.6, max_points=8000, k1=30, k2=20,
+                         num_iterations=20)
+    T_gt = gi.rigid(0.02, -0.01, 0.1, 4.0, 0.3, -0.2)
+    sizes = [1200, 3000, 64, 800, 2500, 5000, 333, 1500, 2048, 900, 4100]
+    src, tgt = [], []
+    for b, n in enumerate(sizes):
+        p0, p1, _ = gi.corr_case(300 + b, n, T_gt, 0.3, noise=0.03)
+        src.append(torch.from_numpy(p0).cuda()); tgt.append(torch.from_numpy(p1).cuda())
+    out = m.SC2_PCR_batch(src, tgt)
+    got_T = torch.stack([t for t, _ in out]).cpu().numpy()          # ordered on the current stream after the join
+    for b, n in enumerate(sizes):
+        T1, f1 = m.SC2_PCR(src[b][None], tgt[b][None])
+        np.testing.assert_array_equal(got_T[b], T1[0].cpu().numpy())
+        np.testing.assert_array_equal(out[b][1].cpu().numpy(), f1[0].cpu().numpy())
+        if n >= 800:
+            np.testing.assert_allclose(got_T[b][:3, :3], T_gt[:3, :3], atol=0.02)
+    # throughput sanity: the batch must not be slower than the per-pair loop
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(3):
+        m.SC2_PCR_batch(src, tgt)
+    torch.cuda.synchronize(); tb = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(3):
+        for b in range(len(sizes)):
+            m.SC2_PCR(src[b][None], tgt[b][None])
+    torch.cuda.synchronize(); tl = time.perf_counter() - t0
+    print(f"SC2-PCR 11 pairs: batched {tb / 3 * 1e3:.2f} ms, loop {tl / 3 * 1e3:.2f} ms")
+    assert tb < tl * 1.1
