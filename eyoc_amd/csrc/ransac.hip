@@ -110,7 +110,8 @@ __device__ inline bool hypothesis(const float* __restrict__ rec, unsigned int n,
 }
 
 constexpr int CNT_STRIDE = 64;
-constexpr int GEN_THREADS = 1024, GEN_BLOCKS = 64;   // per pair
+constexpr int GEN_THREADS = 1024;
+constexpr int GEN_BLOCKS_MIN = 64, GEN_BLOCKS_TOTAL = 512;   // workgroups per pair: enough to fill the chip even for one pair
 constexpr int LDS_RECORDS = 6400;                    // 6400 * 24 B = 150 KB of the 160 KB LDS
 
 __device__ inline unsigned long long pair_base(unsigned int seed, int b) {
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(GEN_THREADS) void k_generate(PairArgs a) {
   const unsigned long long base = pair_base(a.seed, b);
   int* cnt = a.n_surv + c * CNT_STRIDE;
   int* surv = a.surv + (size_t)c * a.H;
-  for (int h = blockIdx.x * GEN_THREADS + threadIdx.x; h < a.H; h += GEN_BLOCKS * GEN_THREADS) {
+  for (int h = blockIdx.x * GEN_THREADS + threadIdx.x; h < a.H; h += gridDim.x * GEN_THREADS) {
     double R[3][3], t[3];
     if (hypothesis(rec, (unsigned)n, base, (unsigned)h, (double)a.edge_sim, (double)a.max_dist, R, t))
       surv[atomicAdd(cnt, 1)] = h;
@@ -272,8 +273,9 @@ extern "C" int eyoc_ransac_batched(eyoc_ctx* ctx, const float* src_dev, const fl
     EYOC_CHECK_HIP(hipMemsetAsync(a.n_surv, 0, (size_t)nc * CNT_STRIDE * 4, st));
     hipLaunchKernelGGL(k_gather_targets, dim3(cdiv(chunk_max, 256), nc), dim3(256), 0, st, src_dev, tgt_dev,
                        (const long long*)corr_tgt_dev, a);
-    if (in_lds) hipLaunchKernelGGL(k_generate<true>, dim3(GEN_BLOCKS, nc), dim3(GEN_THREADS), lds_bytes, st, a);
-    else hipLaunchKernelGGL(k_generate<false>, dim3(GEN_BLOCKS, nc), dim3(GEN_THREADS), 0, st, a);
+    const int gen_blocks = GEN_BLOCKS_TOTAL / nc > GEN_BLOCKS_MIN ? GEN_BLOCKS_TOTAL / nc : GEN_BLOCKS_MIN;
+    if (in_lds) hipLaunchKernelGGL(k_generate<true>, dim3(gen_blocks, nc), dim3(GEN_THREADS), lds_bytes, st, a);
+    else hipLaunchKernelGGL(k_generate<false>, dim3(gen_blocks, nc), dim3(GEN_THREADS), 0, st, a);
     hipLaunchKernelGGL(k_score, dim3(256, nc), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_select, dim3(nc), dim3(1024), 0, st, a, results_dev);
   }
