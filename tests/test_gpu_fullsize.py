@@ -1,0 +1,113 @@
+"""GPU checks at the benchmark's batch size (far beyond what the CPU oracle finishes in seconds) through
+size-independent properties: the two sparse-convolution decompositions agree, the tiling orders do not change a
+single bit, one cloud computed alone equals its rows inside the batch, and the layer operator is linear."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N_PAIRS = 8       # 16 clouds, ~490k voxels: level 0/1 run the wave-private kernel in automatic mode
+
+
+@pytest.fixture(scope="module")
+def big_batch():
+    from eyoc_amd import synthetic as syn
+    clouds = []
+    for s in range(N_PAIRS):
+        p = syn.make_pair(s)
+        clouds += [p["coords0"], p["coords1"]]
+    coords = syn.batch_coords(clouds)
+    return clouds, coords
+
+
+def _model():
+    import eyoc_amd
+    from eyoc_amd import synthetic as syn
+    m = eyoc_amd.load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, conv1_kernel_size=5, normalize_feature=True)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.make_weights().items()})
+    return m.cuda().eval()
+
+
+def _forward(model, coords):
+    import eyoc_amd
+    x = eyoc_amd.SparseTensor(torch.ones((len(coords), 1), device="cuda"), coordinates=torch.from_numpy(coords).cuda())
+    with torch.no_grad():
+        return model(x).F
+
+
+def test_forward_same_features_from_both_kernels_and_any_tiling_order(big_batch):
+    from eyoc_amd import _lib
+    lib = _lib.load()
+    clouds, coords = big_batch
+    assert len(coords) > 400000
+    model = _model()
+    auto = _forward(model, coords)                       # automatic choice: wave-private where it pays, sorted tiles
+    np.testing.assert_allclose(torch.linalg.norm(auto, dim=1).cpu().numpy(), 1.0, atol=1e-5)
+    prev = lib.eyoc_spconv_select_kernel(0)
+    try:
+        tiled = _forward(model, coords)                  # workgroup-tiled kernel everywhere
+    finally:
+        lib.eyoc_spconv_select_kernel(prev)
+    assert float((auto - tiled).abs().max()) < 2e-5      # different summation grouping inside the MFMA chains only
+    assert float((auto * tiled).sum(1).min()) > 1 - 1e-6
+    prev_rows = lib.eyoc_maps_order_min_rows(1 << 30)    # no tiling orders at all
+    try:
+        unordered = _forward(model, coords)
+    finally:
+        lib.eyoc_maps_order_min_rows(prev_rows)
+    assert torch.equal(auto, unordered), "the tiling order must not change any bit of the result"
+    assert torch.equal(auto, _forward(model, coords)), "run-to-run reproducibility"
+
+
+def test_cloud_alone_equals_its_rows_in_the_batch(big_batch):
+    """The batch column keeps neighbourhoods apart (scripts/test_kitti.py batches nothing, config 3 does): a cloud's
+    features do not depend on what else is in the batch - bit-exact when the same kernel computes both."""
+    from eyoc_amd import _lib, synthetic as syn
+    lib = _lib.load()
+    clouds, coords = big_batch
+    model = _model()
+    prev = lib.eyoc_spconv_select_kernel(0)
+    try:
+        full = _forward(model, coords)
+        n0 = len(clouds[0])
+        alone = _forward(model, syn.batch_coords([clouds[0]]))
+        last = _forward(model, syn.batch_coords([clouds[-1]]))
+    finally:
+        lib.eyoc_spconv_select_kernel(prev)
+    assert torch.equal(full[:n0], alone)
+    assert torch.equal(full[-len(clouds[-1]):], last)
+
+
+def test_layer_linearity_at_full_size(big_batch):
+    """conv(a x + b y) = a conv(x) + b conv(y) on a full-size stride-1 layer (wave-private kernel, sorted tiles)."""
+    import eyoc_amd
+    from eyoc_amd import _lib
+    lib = _lib.load()
+    _, coords = big_batch
+    cm = eyoc_amd.CoordinateManager(torch.from_numpy(coords).cuda())
+    maps = cm.maps()
+    n = cm.info()["rows"][1]
+    tab = lib.eyoc_maps_table(maps, _lib.MAP_S1, 1)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(n, 64, device="cuda", generator=g)
+    y = torch.randn(n, 64, device="cuda", generator=g)
+    W = (np.random.default_rng(2).normal(size=(27, 64, 64)) / 24).astype(np.float32)
+    packed = np.zeros(W.size, np.float32)
+    assert lib.eyoc_spconv_pack_weights(W.ctypes.data, None, 27, 64, 64, packed.ctypes.data) == 0
+    wd = torch.from_numpy(packed).cuda()
+
+    def conv(inp):
+        out = torch.empty(n, 64, device="cuda")
+        _lib.check(lib.eyoc_spconv(_lib.ctx(), tab, 27, n, _lib.ptr(inp), 64, 64, _lib.ptr(wd), 64, None, None, 0, 0,
+                                   _lib.ptr(out), 64, _lib.stream_ptr()), "eyoc_spconv")
+        return out
+
+    a, b = 0.75, -1.5
+    lhs = conv(a * x + b * y)
+    rhs = a * conv(x) + b * conv(y)
+    scale = float(rhs.abs().max())
+    assert float((lhs - rhs).abs().max()) < 2e-5 * scale
+    assert float(conv(torch.zeros_like(x)).abs().max()) == 0.0
