@@ -193,12 +193,15 @@ def main():
                                    f"5000-point NN, RANSAC {args.ransac_iters} hypotheses/pair)",
                        "pairs_per_step": args.pairs, "parallelism": f"pairs sharded over {world} GPU(s)",
                        "voxels_per_level": rows},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            # the sparse convolutions in fp32: ideal matrix time (flop / 157.3 TF) is ~1.8x their ideal HBM time
+            # (gather bytes / 8 TB/s), so the fp32 MFMA pipe is the binding roof; the HBM view of the same launches
+            # (the "gather GB/s" BASELINE.json asks for) follows in `hbm_gather`
+            "roofline": {"bound": "mfma", "achieved": flops / (conv_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF,
+                         "unit": "TFLOP/s", "frac": flops / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
                          "kernel": "spconv_wave_kernel / spconv_kernel (the 22 sparse-conv launches of one forward, summed)",
-                         "algorithmic_bytes_per_forward": gather, "ms_per_forward": conv_ms},
-            "mfma": {"achieved": flops / (conv_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": flops / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "flop_per_forward": flops},
+                         "algorithmic_flop_per_forward": flops, "ms_per_forward": conv_ms},
+            "hbm_gather": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "algorithmic_bytes_per_forward": gather},
             "forward_ms_per_step": fwd_ms,
             "single_pair_latency_ms": single_ms,
             "success_rate": float(np.mean([e["success"] for e in evals])),
