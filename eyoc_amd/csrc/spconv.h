@@ -25,6 +25,9 @@ struct SpconvArgs {
   // optional: a permutation of the output rows; tiles take rows in this order (any order gives the same result,
   // a good one makes the rows of a tile share their occupied offsets).  NULL = natural order.
   const int32_t* perm = nullptr;
+  // wave-private kernel only: the first `small_rows` rows (in tiling order; a multiple of 64) are cut into 32-row
+  // tiles.  They run last (heavy tiles first), so the kernel's tail is made of short-lived waves.  0 = none.
+  int small_rows = 0;
 };
 
 int launch_spconv(const SpconvArgs& a, hipStream_t st);
