@@ -104,12 +104,13 @@ __host__ __device__ inline unsigned int hash_key(unsigned long long k) {
 
 __device__ inline int hash_lookup(const HashTable& t, unsigned long long key) {
   unsigned int s = hash_key(key) & t.mask;
-  while (true) {
+  for (unsigned int probes = 0; probes <= t.mask; ++probes) {   // bounded: a table is never full (load <= 1/2)
     unsigned long long k = t.keys[s];
     if (k == key) return t.vals[s];
     if (k == KEY_EMPTY) return -1;
     s = (s + 1) & t.mask;
   }
+  return -1;
 }
 
 }  // namespace eyoc
@@ -133,9 +134,11 @@ struct eyoc_maps {
   // perm_s1[l]: same idea for the stride-1 convolutions of level l (rows grouped by a coarse key of their
   // neighbour pattern); NULL = natural order
   int32_t* perm_s1[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
+  bool table0_built = false;   // table[0] has its memory reserved but is only filled on demand (maps_build_table0)
 };
 
 namespace eyoc {
+int maps_build_table0(eyoc_maps* maps, hipStream_t st);
 size_t sort_rows_tmp_bytes(int n, int bits);
 int sort_rows_by_key(void* tmp, size_t tmp_bytes, const unsigned int* keys_in, unsigned int* keys_out, const int* vals_in,
                      int* vals_out, int n, int bits, hipStream_t st);

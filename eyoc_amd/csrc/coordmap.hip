@@ -41,7 +41,7 @@ __global__ void k_insert(const int32_t* __restrict__ coords, int n, int ts2, Has
   coarse_coord(coords + 4 * (size_t)i, ts2, b, x, y, z);
   constexpr int LIM = COORD_BIAS - 16;  // margin: neighbour probes reach +-8 voxels at tensor stride 8
   if (b < 0 || b >= 1024 || x < -LIM || x >= LIM || y < -LIM || y >= LIM || z < -LIM || z >= LIM) {
-    atomicAdd(&err[0], 1);
+    if (err) atomicAdd(&err[0], 1);
     if (slot_out) slot_out[i] = 0;
     return;
   }
@@ -193,15 +193,21 @@ __global__ void k_quantize(const float* __restrict__ xyz, int n, int stride, flo
 
 // octree links for the rows of level l (tensor stride 1 << sh): slot[] / vals still describe where each
 // fine row landed in the coarse table, and k_compact has re-labelled vals with coarse row indices
+// Two rows landing in the same child slot of the same block have identical coordinates: `dup` (level 0 only) counts
+// them - the duplicate check of the input needs no hash table of its own.
 __global__ void k_children(const int* __restrict__ slot, const int* __restrict__ vals, const int32_t* __restrict__ coords,
-                           int n, int sh, int32_t* __restrict__ parent, int32_t* __restrict__ children) {
+                           int n, int sh, int32_t* __restrict__ parent, int32_t* __restrict__ children, int* __restrict__ dup) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int4 c = reinterpret_cast<const int4*>(coords)[i];
   const int p = vals[slot[i]];
   const int cs = ((c.y >> sh) & 1) | (((c.z >> sh) & 1) << 1) | (((c.w >> sh) & 1) << 2);
   parent[i] = p;
-  children[(size_t)p * 8 + cs] = i;
+  if (dup) {
+    if (atomicCAS(&children[(size_t)p * 8 + cs], -1, i) != -1) atomicAdd(dup, 1);
+  } else {
+    children[(size_t)p * 8 + cs] = i;
+  }
 }
 
 // stride-1 table and transposed (2ts -> ts) table of level l from the stride-1 table of level l+1.
@@ -366,10 +372,20 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
   m->rows[0] = n;
   m->coords[0] = cv.take<int32_t>((size_t)n * 4);
   FAIL_HIP(hipMemcpyAsync(m->coords[0], coords_dev, (size_t)n * 16, hipMemcpyDeviceToDevice, st));
-  for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
-    // table of THIS level is built from the previous level's rows (or the input for l == 0)
-    const int n_src = l == 0 ? n : m->rows[l - 1];
-    const int32_t* src = l == 0 ? m->coords[0] : m->coords[l - 1];
+  // Level 0 needs no hash table: validation rides on the level-1 build (range check in its k_insert, duplicate
+  // rows = two rows in one child slot in k_children); the first convolution walks the octree (spconv.hip).  The
+  // table's memory stays reserved so that maps_build_table0 can build it for the hash-probing fallback.
+  {
+    const unsigned int cap = table_capacity(n);
+    m->table[0].keys = cv.take<unsigned long long>(cap);
+    m->table[0].vals = cv.take<int>(cap);
+    m->table[0].mask = cap - 1;
+    m->table0_built = false;
+  }
+  for (int l = 1; l < EYOC_MAX_LEVELS; ++l) {
+    // table of THIS level is built from the previous level's rows
+    const int n_src = m->rows[l - 1];
+    const int32_t* src = m->coords[l - 1];
     const int ts2 = 1 << l;
     const unsigned int cap = table_capacity(n_src);
     HashTable& t = m->table[l];
@@ -379,28 +395,18 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
     FAIL_HIP(hipMemsetAsync(t.keys, 0xFF, (size_t)cap * 8, st));
     FAIL_HIP(hipMemsetAsync(t.vals, 0x7F, (size_t)cap * 4, st));
     hipLaunchKernelGGL(k_insert, dim3(cdiv(n_src, 256)), dim3(256), 0, st, src, n_src, ts2, t, slot, counters);
-    hipLaunchKernelGGL(k_flag, dim3(cdiv(n_src, 256)), dim3(256), 0, st, slot, t.vals, n_src, flag,
-                       l == 0 ? counters + 1 : (int*)nullptr);
-    if (l == 0) {
-      FAIL_HIP(hipMemcpyAsync(host, counters, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-      FAIL_HIP(hipStreamSynchronize(st));
-      if (host[0] != 0) {
-        set_error("eyoc_maps_build: %d coordinate rows outside the supported key range (|c| < 2^17 - 16, 0 <= batch < 1024)", host[0]);
-        delete m;
-        return EYOC_ERR_RANGE;
-      }
-      if (host[1] != 0) {
-        set_error("eyoc_maps_build: %d duplicate coordinate rows (a sparse tensor needs unique coordinates)", host[1]);
-        delete m;
-        return EYOC_ERR_DUPLICATE;
-      }
-      continue;  // level-0 values already are the row indices
-    }
+    hipLaunchKernelGGL(k_flag, dim3(cdiv(n_src, 256)), dim3(256), 0, st, slot, t.vals, n_src, flag, (int*)nullptr);
     const int nb = cdiv(n_src, SCAN_TILE);
     hipLaunchKernelGGL(k_scan_partials, dim3(nb), dim3(SCAN_BLOCK), 0, st, flag, n_src, partial);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, st, partial, nb, counters + 2 + l);
     FAIL_HIP(hipMemcpyAsync(host, counters + 2 + l, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (l == 1) FAIL_HIP(hipMemcpyAsync(host + 1, counters, sizeof(int), hipMemcpyDeviceToHost, st));
     FAIL_HIP(hipStreamSynchronize(st));
+    if (l == 1 && host[1] != 0) {
+      set_error("eyoc_maps_build: %d coordinate rows outside the supported key range (|c| < 2^17 - 16, 0 <= batch < 1024)", host[1]);
+      delete m;
+      return EYOC_ERR_RANGE;
+    }
     m->rows[l] = host[0];
     m->coords[l] = cv.take<int32_t>((size_t)m->rows[l] * 4);
     hipLaunchKernelGGL(k_compact, dim3(nb), dim3(SCAN_BLOCK), 0, st, flag, partial, slot, src, n_src, ts2,
@@ -410,7 +416,16 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
     m->children[l - 1] = cv.take<int32_t>((size_t)m->rows[l] * 8);
     FAIL_HIP(hipMemsetAsync(m->children[l - 1], 0xFF, (size_t)m->rows[l] * 32, st));
     hipLaunchKernelGGL(k_children, dim3(cdiv(n_src, 256)), dim3(256), 0, st, slot, t.vals, src, n_src, l - 1,
-                       m->parent[l - 1], m->children[l - 1]);
+                       m->parent[l - 1], m->children[l - 1], l == 1 ? counters + 1 : (int*)nullptr);
+    if (l == 1) {
+      FAIL_HIP(hipMemcpyAsync(host, counters + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+      FAIL_HIP(hipStreamSynchronize(st));
+      if (host[0] != 0) {
+        set_error("eyoc_maps_build: %d duplicate coordinate rows (a sparse tensor needs unique coordinates)", host[0]);
+        delete m;
+        return EYOC_ERR_DUPLICATE;
+      }
+    }
   }
   // ---- rulebooks: hash probes at the coarsest level only, everything else derived top-down
   for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
@@ -570,6 +585,24 @@ int eyoc_maps_copy_table(const eyoc_maps* maps, int kind, int level, int32_t* ou
   return EYOC_OK;
 }
 
+}  // extern "C"
+
+// level-0 hash table on demand (only the hash-probing first-convolution fallback reads it)
+int eyoc::maps_build_table0(eyoc_maps* m, hipStream_t st) {
+  if (m->table0_built) return EYOC_OK;
+  HashTable& t = m->table[0];
+  const size_t cap = (size_t)t.mask + 1;
+  EYOC_CHECK_HIP(hipMemsetAsync(t.keys, 0xFF, cap * 8, st));
+  EYOC_CHECK_HIP(hipMemsetAsync(t.vals, 0x7F, cap * 4, st));
+  hipLaunchKernelGGL(k_insert, dim3(cdiv(m->rows[0], 256)), dim3(256), 0, st, m->coords[0], m->rows[0], 1, t, (int*)nullptr,
+                     (int*)nullptr /* no range errors: the rows passed eyoc_maps_build */);
+  EYOC_CHECK_HIP(hipGetLastError());
+  m->table0_built = true;
+  return EYOC_OK;
+}
+
+extern "C" {
+
 int eyoc_maps_order_min_rows(int min_rows) {
   const int prev = ORDER_MIN_ROWS;
   if (min_rows >= 0) ORDER_MIN_ROWS = min_rows;
@@ -612,9 +645,12 @@ int eyoc_maps_info(eyoc_ctx* ctx, const eyoc_maps* m, int conv1_ks, void* stream
       count(m->nbr_up[l], 27ll * m->rows[l], 16 + l);
     }
   }
-  if (conv1_ks > 0)
+  if (conv1_ks > 0) {   // the one statistic that probes the level-0 hash table: build it now if nobody has
+    rc = maps_build_table0(const_cast<eyoc_maps*>(m), st);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_count_region, dim3(cdiv(m->rows[0], 256)), dim3(256), 0, st, m->coords[0], m->rows[0],
                        m->table[0], conv1_ks, cnt + 24);
+  }
   unsigned long long* host = (unsigned long long*)ctx->pinned;
   EYOC_CHECK_HIP(hipMemcpyAsync(host, cnt, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   EYOC_CHECK_HIP(hipStreamSynchronize(st));

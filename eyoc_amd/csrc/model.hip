@@ -261,7 +261,8 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
       a.in = buf[p.in_buf]; a.cin = p.cin; a.w = m->blob + p.w_off; a.bias = m->blob + p.b_off; a.cout = p.cout;
       a.out = buf[p.out_buf] + p.out_col; a.ld_out = m->bufs[p.out_buf].width;
       a.parent = maps->parent[0]; a.children = maps->children[0]; a.s1c = maps->nbr_s1[1]; a.nc = maps->rows[1];
-      rc = launch_conv1(a, st);
+      rc = conv1_walks_octree(a) ? EYOC_OK : maps_build_table0(const_cast<eyoc_maps*>(maps), st);
+      if (!rc) rc = launch_conv1(a, st);
     } else {
       SpconvArgs a;
       a.nbr = p.map == M_S1 ? maps->nbr_s1[p.level] : p.map == M_DOWN ? maps->nbr_down[p.level]

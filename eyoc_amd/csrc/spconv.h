@@ -54,5 +54,6 @@ struct Conv1Args {
   int nc;
 };
 int launch_conv1(const Conv1Args& a, hipStream_t st);
+bool conv1_walks_octree(const Conv1Args& a);   // false: launch_conv1 will probe a.table (it must be built)
 
 }  // namespace eyoc

@@ -575,6 +575,11 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
   return EYOC_OK;
 }
 
+bool conv1_walks_octree(const Conv1Args& a) {
+  const size_t tree_lds = (size_t)a.ks * a.ks * a.ks * a.cin * (a.cout + 4) * sizeof(float);
+  return a.parent && a.children && a.s1c && (a.ks == 3 || a.ks == 5) && tree_lds <= 64 * 1024;
+}
+
 int launch_conv1(const Conv1Args& a, hipStream_t st) {
   EYOC_REQUIRE(a.ks == 1 || a.ks == 3 || a.ks == 5 || a.ks == 7, EYOC_ERR_INVALID, "conv1: kernel size %d", a.ks);
   EYOC_REQUIRE(a.cin >= 1 && a.cin * a.cout <= 8192, EYOC_ERR_INVALID, "conv1: C_in %d x C_out %d too large", a.cin, a.cout);
@@ -582,7 +587,7 @@ int launch_conv1(const Conv1Args& a, hipStream_t st) {
   if (a.n == 0) return EYOC_OK;
   dim3 grid(cdiv(a.n, 256));
   const size_t tree_lds = (size_t)a.ks * a.ks * a.ks * a.cin * (a.cout + 4) * sizeof(float);
-  if (a.parent && a.children && a.s1c && (a.ks == 3 || a.ks == 5) && tree_lds <= 64 * 1024) {
+  if (conv1_walks_octree(a)) {
     switch (a.cout) {
       case 32: hipLaunchKernelGGL(conv1_tree_kernel<32>, grid, dim3(256), tree_lds, st, a); break;
       case 64: hipLaunchKernelGGL(conv1_tree_kernel<64>, grid, dim3(256), tree_lds, st, a); break;

@@ -254,3 +254,14 @@ def test_model_api_surface():
     assert out.F.shape == (4, 32) and len(out) == 4 and out.C.shape == (4, 4)
     cs, fs = out.decomposed_coordinates_and_features
     assert len(cs) == 1 and fs[0].shape == (4, 32)
+
+
+def test_first_conv_kernel_size_7_hash_probing_fallback():
+    """7^3 does not fit the octree walk (3^3 / 5^3 only): the first convolution probes the level-0 hash table, which
+    the maps build on demand (FCGF's 3DMatch setting uses conv1_kernel_size = 7)."""
+    from eyoc_amd import synthetic as syn
+    rng = np.random.default_rng(13)
+    c = np.unique(rng.integers(-9, 9, size=(1200, 3)), axis=0).astype(np.int32)
+    coords = syn.batch_coords([c[:500], c[500:]])
+    sd = syn.make_weights(seed=7, conv1_kernel_size=7)
+    check_forward(coords, np.ones((len(coords), 1), np.float32), sd, conv1_kernel_size=7)
