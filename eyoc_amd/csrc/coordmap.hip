@@ -163,7 +163,7 @@ __global__ void k_neighbours(const int32_t* __restrict__ coords_out, int n_out, 
 // keys (up to the full 27-bit pattern) pack the chunks better but scatter a tile's rows over the cloud, and the
 // lost L2 locality of the gather costs more than the saved matrix work (measured on MI355X).
 __global__ void k_pattern_key(const int32_t* __restrict__ nbr, int n, int key_bits, unsigned int* __restrict__ key,
-                              int* __restrict__ row) {
+                              int* __restrict__ row, unsigned int key_tag) {
   int o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= n) return;
   unsigned int mask = 0;
@@ -172,7 +172,7 @@ __global__ void k_pattern_key(const int32_t* __restrict__ nbr, int n, int key_bi
   const unsigned int lo = mask & 0x1FFu, mid = (mask >> 9) & 0x1FFu, hi = mask >> 18;
   unsigned int kv = (lo ? 1u : 0u) | (hi ? 2u : 0u);
   if (key_bits == 4) kv |= ((mid & 7u) ? 4u : 0u) | ((mid >> 6) ? 8u : 0u);
-  key[o] = kv;
+  key[o] = key_tag | kv;
   row[o] = o;
 }
 
@@ -216,7 +216,7 @@ __global__ void k_children(const int* __restrict__ slot, const int* __restrict__
 __global__ void k_derive_fine(const int32_t* __restrict__ coords, int n, int sh, const int32_t* __restrict__ parent,
                               const int32_t* __restrict__ children, const int32_t* __restrict__ s1c, int nc,
                               int32_t* __restrict__ s1, int32_t* __restrict__ up, unsigned int* __restrict__ up_key,
-                              int* __restrict__ up_row) {
+                              int* __restrict__ up_row, unsigned int key_tag) {
   int o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= n) return;
   const int4 c = reinterpret_cast<const int4*>(coords)[o];
@@ -256,7 +256,7 @@ __global__ void k_derive_fine(const int32_t* __restrict__ coords, int n, int sh,
 #pragma unroll
     for (int a = 0; a < 8; ++a)
       if ((a & cls) == a && blk[a] >= 0) present |= 1u << a;
-    up_key[o] = ((unsigned)cls << 8) | present;
+    up_key[o] = key_tag | ((unsigned)cls << 8) | present;
     up_row[o] = o;
   }
 }
@@ -336,7 +336,7 @@ size_t eyoc_maps_workspace_bytes(int n_rows) {
   b += 10 * align_up(n * 27 * 4);                                    // 4 s1 + 3 down + 3 up tables
   b += 3 * align_up(n * 4) + align_up((n / SCAN_TILE + 2) * 4);      // slot, flag, partial sums
   b += 3 * (align_up(n * 4) + align_up(n * 32));                     // parent / children links
-  b += 10 * align_up(n * 4) + align_up(sort_rows_tmp_bytes(n_rows, 27));   // perm_up, perm_s1, sort keys / temporaries
+  b += 4 * align_up(4 * n * 4) + align_up(sort_rows_tmp_bytes(4 * n_rows, UP_KEY_BITS + 3));   // tiling orders: keys, rows, result (<= 2 segments per level, levels sum to < 2 n)
   b += 4096;                                                         // counters
   return b + 64 * 256;
 }
@@ -440,50 +440,51 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
     hipLaunchKernelGGL(k_neighbours, dim3(cdiv(m->rows[top], 256)), dim3(256), 0, st, m->coords[top], m->rows[top],
                        m->table[top], 1 << top, 1, m->nbr_s1[top]);
   }
-  unsigned int* key_in = cv.take<unsigned int>(n);
-  unsigned int* key_out = cv.take<unsigned int>(n);
-  int* row_in = cv.take<int>(n);
-  const size_t sort_bytes = sort_rows_tmp_bytes(n, 27);
+  // ---- tiling orders (perm_up / perm_s1): every ordered table contributes a segment of (key, row) pairs tagged with
+  // its segment number in the high key bits, and ONE stable radix sort orders all segments at once (seven separate
+  // rocPRIM sorts cost 38 small launches, 0.7 ms per 64-cloud batch).  The orders only serve the wave-private
+  // convolution kernel, which takes over above ~4000 row tiles: small levels (single-pair latency path) skip them.
+  static const bool s1_order = !(getenv("EYOC_S1_ORDER") && atoi(getenv("EYOC_S1_ORDER")) == 0);
+  int seg_up[EYOC_MAX_LEVELS], seg_s1[EYOC_MAX_LEVELS], seg_base[2 * EYOC_MAX_LEVELS], n_seg = 0;
+  size_t total = 0;
+  for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
+    seg_up[l] = seg_s1[l] = -1;
+    if (m->rows[l] < ORDER_MIN_ROWS) continue;
+    if (l + 1 < EYOC_MAX_LEVELS) { seg_up[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l]; }
+    if (s1_order) { seg_s1[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l]; }
+  }
+  constexpr int TAG_SHIFT = UP_KEY_BITS;                 // keys < 2^11, segment tag above (at most 7 segments: 3 bits)
+  unsigned int* key_in = cv.take<unsigned int>(total);
+  unsigned int* key_out = cv.take<unsigned int>(total);
+  int* row_in = cv.take<int>(total);
+  int32_t* perm_all = cv.take<int32_t>(total);
+  const size_t sort_bytes = sort_rows_tmp_bytes((int)total, TAG_SHIFT + 3);
   void* sort_tmp = cv.take<char>(sort_bytes);
   for (int l = EYOC_MAX_LEVELS - 2; l >= 0; --l) {
     const int nl = m->rows[l], nc = m->rows[l + 1];
-    // the tiling orders only serve the wave-private convolution kernel, which takes over above ~4000 row tiles:
-    // small levels (single-pair latency path) skip the sorts
-    const bool ordered = nl >= ORDER_MIN_ROWS;
-    m->perm_up[l] = ordered ? cv.take<int32_t>((size_t)nl) : nullptr;
+    const int su = seg_up[l];
     hipLaunchKernelGGL(k_derive_fine, dim3(cdiv(nl, 256)), dim3(256), 0, st, m->coords[l], nl, l, m->parent[l],
-                       m->children[l], m->nbr_s1[l + 1], nc, m->nbr_s1[l], m->nbr_up[l], ordered ? key_in : (unsigned int*)nullptr,
-                       row_in);
-    if (!ordered) {
-      hipLaunchKernelGGL(k_derive_down, dim3(cdiv(nc, 256)), dim3(256), 0, st, nc, m->children[l], m->nbr_s1[l + 1],
-                         m->nbr_down[l]);
-      continue;
-    }
-    if (sort_rows_tmp_bytes(nl, UP_KEY_BITS) > sort_bytes) {
-      set_error("eyoc_maps_build: sort workspace too small for level %d", l);
-      delete m;
-      return EYOC_ERR_WORKSPACE;
-    }
-    if (int rc = sort_rows_by_key(sort_tmp, sort_bytes, key_in, key_out, row_in, m->perm_up[l], nl, UP_KEY_BITS, st)) {
-      delete m;
-      return rc;
-    }
+                       m->children[l], m->nbr_s1[l + 1], nc, m->nbr_s1[l], m->nbr_up[l],
+                       su >= 0 ? key_in + seg_base[su] : (unsigned int*)nullptr, su >= 0 ? row_in + seg_base[su] : (int*)nullptr,
+                       (unsigned int)(su >= 0 ? su : 0) << TAG_SHIFT);
     hipLaunchKernelGGL(k_derive_down, dim3(cdiv(nc, 256)), dim3(256), 0, st, nc, m->children[l], m->nbr_s1[l + 1],
                        m->nbr_down[l]);
   }
-  // ---- tiling order of the stride-1 convolutions (EYOC_S1_ORDER=0 in the environment switches it off)
-  static const bool s1_order = !(getenv("EYOC_S1_ORDER") && atoi(getenv("EYOC_S1_ORDER")) == 0);
-  if (s1_order) {
+  for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
+    const int ss = seg_s1[l];
+    if (ss < 0) continue;
+    const int bits = l == 0 ? 2 : 4;   // level 0 feeds the 32-channel, bandwidth-bound layers: keep more locality
+    hipLaunchKernelGGL(k_pattern_key, dim3(cdiv(m->rows[l], 256)), dim3(256), 0, st, m->nbr_s1[l], m->rows[l], bits,
+                       key_in + seg_base[ss], row_in + seg_base[ss], (unsigned int)ss << TAG_SHIFT);
+  }
+  if (total > 0) {
+    if (int rc = sort_rows_by_key(sort_tmp, sort_bytes, key_in, key_out, row_in, perm_all, (int)total, TAG_SHIFT + 3, st)) {
+      delete m;
+      return rc;
+    }
     for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
-      const int nl = m->rows[l];
-      if (nl < ORDER_MIN_ROWS) continue;
-      const int bits = l == 0 ? 2 : 4;   // level 0 feeds the 32-channel, bandwidth-bound layers: keep more locality
-      m->perm_s1[l] = cv.take<int32_t>((size_t)nl);
-      hipLaunchKernelGGL(k_pattern_key, dim3(cdiv(nl, 256)), dim3(256), 0, st, m->nbr_s1[l], nl, bits, key_in, row_in);
-      if (int rc = sort_rows_by_key(sort_tmp, sort_bytes, key_in, key_out, row_in, m->perm_s1[l], nl, bits, st)) {
-        delete m;
-        return rc;
-      }
+      if (seg_up[l] >= 0) m->perm_up[l] = perm_all + seg_base[seg_up[l]];
+      if (seg_s1[l] >= 0) m->perm_s1[l] = perm_all + seg_base[seg_s1[l]];
     }
   }
   FAIL_HIP(hipGetLastError());
