@@ -160,6 +160,18 @@ def main():
             pipe.register(single)
         torch.cuda.synchronize()
         single_ms = (time.perf_counter() - t1) / 10 * 1e3
+    # the SC2-PCR back-end instead of RANSAC (scripts/test_kitti.py:179-181, configs[4] of BASELINE.json) on the same
+    # batch: secondary figure, not part of `value`
+    sc2_rate = None
+    if not args.no_latency_probe:
+        pipe2 = RegistrationPipeline(model, RegistrationConfig(use_RANSAC=False))
+        pipe2.register(batch, return_device=True)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(3):
+            pipe2.register(batch, return_device=True)
+        torch.cuda.synchronize()
+        sc2_rate = 3 * args.pairs / (time.perf_counter() - t2)
 
     # algorithmic work of one forward on this batch geometry
     x = eyoc_amd.SparseTensor(batch.feats, coordinates=batch.coords)
@@ -204,6 +216,7 @@ def main():
                            "algorithmic_bytes_per_forward": gather},
             "forward_ms_per_step": fwd_ms,
             "single_pair_latency_ms": single_ms,
+            "sc2pcr_path_pairs_per_s": sc2_rate,
             "success_rate": float(np.mean([e["success"] for e in evals])),
         }
         log("timed region done; cpu baseline next")

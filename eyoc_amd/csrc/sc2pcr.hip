@@ -38,10 +38,12 @@ __device__ inline float cross_len(float sx, float sy, float sz, float tx, float 
   return fabsf(sqrtf(dx * dx + dy * dy + dz * dz) - sqrtf(ex * ex + ey * ey + ez * ez));
 }
 
-// ---- y = SC x (one sweep).  256 threads = 256 rows; columns stream through LDS in tiles of 1024.
+// ---- y = SC x (one sweep).  256 threads = 256 rows; grid.y splits the COLUMNS (a lane-per-row kernel over all
+// columns is 32 workgroups at n = 8000, an eighth of the chip): block (bx, by) writes the partial sums of its
+// column range to part[by][row] and k_sc_normalize adds the ranges in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void k_sc_matvec(const float* __restrict__ src, const float* __restrict__ tgt, int n,
-                                                   float inv_d2, const float* __restrict__ x, float* __restrict__ y,
-                                                   const Sc2Ctl* __restrict__ ctl) {
+                                                   float inv_d2, const float* __restrict__ x, float* __restrict__ part,
+                                                   int col_chunk, const Sc2Ctl* __restrict__ ctl) {
   if (ctl->converged) return;
   __shared__ float ls[1024 * 3], lt[1024 * 3], lx[1024];
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -50,8 +52,9 @@ __global__ __launch_bounds__(256) void k_sc_matvec(const float* __restrict__ src
   const float sx = src[3 * ii], sy = src[3 * ii + 1], sz = src[3 * ii + 2];
   const float tx = tgt[3 * ii], ty = tgt[3 * ii + 1], tz = tgt[3 * ii + 2];
   float acc = 0.0f;
-  for (int j0 = 0; j0 < n; j0 += 1024) {
-    const int cnt = min(1024, n - j0);
+  const int c_begin = blockIdx.y * col_chunk, c_end = min(n, c_begin + col_chunk);
+  for (int j0 = c_begin; j0 < c_end; j0 += 1024) {
+    const int cnt = min(1024, c_end - j0);
     __syncthreads();
     for (int t = threadIdx.x; t < cnt * 3; t += 256) { ls[t] = src[3 * j0 + t]; lt[t] = tgt[3 * j0 + t]; }
     for (int t = threadIdx.x; t < cnt; t += 256) lx[t] = x[j0 + t];
@@ -63,17 +66,22 @@ __global__ __launch_bounds__(256) void k_sc_matvec(const float* __restrict__ src
       acc += sc * lx[j];
     }
   }
-  if (ok) y[i] = acc;
+  if (ok) part[(size_t)blockIdx.y * n + i] = acc;
 }
 
 // ---- v_new = y / (||y|| + 1e-6); converged = allclose(v_new, v_old); one workgroup
-__global__ __launch_bounds__(1024) void k_sc_normalize(const float* __restrict__ y, float* __restrict__ v, int n,
-                                                       Sc2Ctl* __restrict__ ctl) {
+__global__ __launch_bounds__(1024) void k_sc_normalize(const float* __restrict__ part, int n_part, float* __restrict__ y,
+                                                       float* __restrict__ v, int n, Sc2Ctl* __restrict__ ctl) {
   if (ctl->converged) return;
   __shared__ double red[16];
   __shared__ int bad[16];
   double s = 0;
-  for (int i = threadIdx.x; i < n; i += 1024) s += (double)y[i] * (double)y[i];
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    float t = part[i];
+    for (int c = 1; c < n_part; ++c) t += part[(size_t)c * n + i];   // column ranges in ascending order
+    y[i] = t;
+    s += (double)t * (double)t;
+  }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -119,16 +127,18 @@ __global__ __launch_bounds__(256) void k_masks(const float* __restrict__ src, co
 }
 
 // ---- non-maximum suppression in source space: score = conf if no j within R has a larger conf, else 0
+// grid.y splits the columns; `dom` (zero-initialised) collects "some column dominates row i" with atomicOr.
 __global__ __launch_bounds__(256) void k_nms(const float* __restrict__ src, const float* __restrict__ conf, int n, float R,
-                                             float* __restrict__ score) {
+                                             int col_chunk, int* __restrict__ dom) {
   __shared__ float ls[1024 * 3], lc[1024];
   const int i = blockIdx.x * 256 + threadIdx.x;
   const bool ok = i < n;
   const int ii = ok ? i : 0;
   const float sx = src[3 * ii], sy = src[3 * ii + 1], sz = src[3 * ii + 2], ci = conf[ii];
   bool dominated = false;
-  for (int j0 = 0; j0 < n; j0 += 1024) {
-    const int cnt = min(1024, n - j0);
+  const int c_begin = blockIdx.y * col_chunk, c_end = min(n, c_begin + col_chunk);
+  for (int j0 = c_begin; j0 < c_end; j0 += 1024) {
+    const int cnt = min(1024, c_end - j0);
     __syncthreads();
     for (int t = threadIdx.x; t < cnt * 3; t += 256) ls[t] = src[3 * j0 + t];
     for (int t = threadIdx.x; t < cnt; t += 256) lc[t] = conf[j0 + t];
@@ -138,24 +148,36 @@ __global__ __launch_bounds__(256) void k_nms(const float* __restrict__ src, cons
       dominated |= (lc[j] > ci) && (sqrtf(dx * dx + dy * dy + dz * dz) < R);
     }
   }
-  if (ok) score[i] = dominated ? 0.0f : ci;
+  if (ok && dominated) atomicOr(&dom[i], 1);
+}
+
+__global__ void k_nms_score(const float* __restrict__ conf, const int* __restrict__ dom, int n, float* __restrict__ score) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) score[i] = dom[i] ? 0.0f : conf[i];
 }
 
 // ---- stable descending rank of score; the first n_seed ranks are the seeds
-__global__ __launch_bounds__(256) void k_rank(const float* __restrict__ score, int n, int n_seed, int* __restrict__ seeds) {
+// (grid.y splits the columns; the partial ranks are integers, so atomicAdd keeps the result exact)
+__global__ __launch_bounds__(256) void k_rank(const float* __restrict__ score, int n, int col_chunk, int* __restrict__ rank_out) {
   __shared__ float lc[1024];
   const int i = blockIdx.x * 256 + threadIdx.x;
   const bool ok = i < n;
   const float si = score[ok ? i : 0];
   int rank = 0;
-  for (int j0 = 0; j0 < n; j0 += 1024) {
-    const int cnt = min(1024, n - j0);
+  const int c_begin = blockIdx.y * col_chunk, c_end = min(n, c_begin + col_chunk);
+  for (int j0 = c_begin; j0 < c_end; j0 += 1024) {
+    const int cnt = min(1024, c_end - j0);
     __syncthreads();
     for (int t = threadIdx.x; t < cnt; t += 256) lc[t] = score[j0 + t];
     __syncthreads();
     for (int j = 0; j < cnt; ++j) rank += (lc[j] > si) || (lc[j] == si && (j0 + j) < i);
   }
-  if (ok && rank < n_seed) seeds[rank] = i;
+  if (ok && rank) atomicAdd(&rank_out[i], rank);
+}
+
+__global__ void k_seeds(const int* __restrict__ rank, int n, int n_seed, int* __restrict__ seeds) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && rank[i] < n_seed) seeds[rank[i]] = i;
 }
 
 // ---- per seed: SC2 row = popcount(tight[seed] & tight[j]) * hard[seed][j]; stable top-k1 of it
@@ -481,7 +503,8 @@ __global__ void k_fill(float* p, int n, float v) {
 
 struct Plan {
   int n, words, n_seed, k1, k2;
-  size_t off_ctl, off_v, off_y, off_score, off_seeds, off_hard, off_tight, off_knn, off_Ts, total;
+  int n_part, col_chunk;   // column ranges of the lane-per-row sweeps (matvec, NMS, rank)
+  size_t off_ctl, off_v, off_y, off_score, off_seeds, off_hard, off_tight, off_knn, off_Ts, off_part, off_int, total;
 };
 
 Plan make_plan(int n, const eyoc_sc2pcr_params* p) {
@@ -503,6 +526,15 @@ Plan make_plan(int n, const eyoc_sc2pcr_params* p) {
   pl.off_tight = take((size_t)n * pl.words * 8);
   pl.off_knn = take((size_t)(pl.n_seed + 1) * K1_MAX * 4);
   pl.off_Ts = take((size_t)(pl.n_seed + 1) * 16 * 4);
+  // enough workgroups for the whole chip: rows / 256 x column ranges >= ~1024, ranges of at least 64 columns
+  const int row_blocks = (n + 255) / 256;
+  int parts = (1024 + row_blocks - 1) / row_blocks;
+  if (parts > (n + 63) / 64) parts = (n + 63) / 64;
+  if (parts < 1) parts = 1;
+  pl.col_chunk = (n + parts - 1) / parts;
+  pl.n_part = (n + pl.col_chunk - 1) / pl.col_chunk;
+  pl.off_part = take((size_t)pl.n_part * n * 4);
+  pl.off_int = take((size_t)2 * n * 4);          // NMS domination flags, ranks
   pl.total = o + 256;
   return pl;
 }
@@ -538,17 +570,24 @@ int eyoc_sc2pcr(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, int n
   unsigned long long* tight = (unsigned long long*)(b + pl.off_tight);
   int* knn = (int*)(b + pl.off_knn);
   float* Ts = (float*)(b + pl.off_Ts);
+  float* part = (float*)(b + pl.off_part);
+  int* dom = (int*)(b + pl.off_int);
+  int* rank = dom + n;
   const float d = p->d_thre;
   EYOC_CHECK_HIP(hipMemsetAsync(ctl, 0, sizeof(Sc2Ctl), st));
   // leading eigenvector of the first-order compatibility matrix (power iteration from all-ones)
   hipLaunchKernelGGL(k_fill, dim3(cdiv(n, 256)), dim3(256), 0, st, v, n, 1.0f);
   for (int it = 0; it < p->num_iterations; ++it) {
-    hipLaunchKernelGGL(k_sc_matvec, dim3(cdiv(n, 256)), dim3(256), 0, st, src_dev, tgt_dev, n, 1.0f / (d * d), v, y, ctl);
-    hipLaunchKernelGGL(k_sc_normalize, dim3(1), dim3(1024), 0, st, y, v, n, ctl);
+    hipLaunchKernelGGL(k_sc_matvec, dim3(cdiv(n, 256), pl.n_part), dim3(256), 0, st, src_dev, tgt_dev, n, 1.0f / (d * d), v, part,
+                       pl.col_chunk, ctl);
+    hipLaunchKernelGGL(k_sc_normalize, dim3(1), dim3(1024), 0, st, part, pl.n_part, y, v, n, ctl);
   }
   // seeds: NMS on the eigenvector in source space, stable top-n_seed
-  hipLaunchKernelGGL(k_nms, dim3(cdiv(n, 256)), dim3(256), 0, st, src_dev, v, n, p->nms_radius, score);
-  hipLaunchKernelGGL(k_rank, dim3(cdiv(n, 256)), dim3(256), 0, st, score, n, pl.n_seed, seeds);
+  EYOC_CHECK_HIP(hipMemsetAsync(dom, 0, (size_t)2 * n * 4, st));
+  hipLaunchKernelGGL(k_nms, dim3(cdiv(n, 256), pl.n_part), dim3(256), 0, st, src_dev, v, n, p->nms_radius, pl.col_chunk, dom);
+  hipLaunchKernelGGL(k_nms_score, dim3(cdiv(n, 256)), dim3(256), 0, st, v, dom, n, score);
+  hipLaunchKernelGGL(k_rank, dim3(cdiv(n, 256), pl.n_part), dim3(256), 0, st, score, n, pl.col_chunk, rank);
+  hipLaunchKernelGGL(k_seeds, dim3(cdiv(n, 256)), dim3(256), 0, st, rank, n, pl.n_seed, seeds);
   // hard masks, second-order measure per seed, two-stage consensus, hypotheses
   hipLaunchKernelGGL(k_masks, dim3(cdiv((long long)n * pl.words, 4)), dim3(256), 0, st, src_dev, tgt_dev, n, pl.words, d,
                      hard, tight);

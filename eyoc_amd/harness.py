@@ -109,15 +109,26 @@ class RegistrationPipeline:
                 return res
             host = res.cpu()
             return [reg.decode_ransac_result(host[p], n) for p in range(batch.P)]
-        # SC2-PCR path (scripts/test_kitti.py:179-181): Matcher.estimator re-samples both clouds to
-        # num_node with replacement, matches them and registers the matched pairs
-        results = []
+        # SC2-PCR path (scripts/test_kitti.py:179-181): Matcher.estimator re-samples both clouds to num_node with
+        # replacement, matches them and registers the matched pairs.  Same draws and the same arithmetic as a
+        # per-pair loop over ``matcher.estimator``, but ONE segmented nearest-neighbour launch and ONE batched
+        # SC2-PCR call for all pairs.
         rng = np.random.RandomState(seed)
+        m = self.matcher
+        src_k, tgt_k, src_d, tgt_d = [], [], [], []
         for p in range(batch.P):
-            T, _, _, _, _ = self.matcher.estimator(batch.xyz0[p][None], batch.xyz1[p][None], F0[p * n:(p + 1) * n][None],
-                                                   F1[p * n:(p + 1) * n][None], rng=rng)
-            results.append(T[0])
-        T = torch.stack(results)
+            if m.num_node == 'all':
+                si, ti = np.arange(n), np.arange(n)
+            else:
+                si, ti = rng.choice(n, m.num_node), rng.choice(n, m.num_node)
+            si = torch.from_numpy(si).to(F.device); ti = torch.from_numpy(ti).to(F.device)
+            src_k.append(batch.xyz0[p][si]); tgt_k.append(batch.xyz1[p][ti])
+            src_d.append(F0[p * n:(p + 1) * n][si]); tgt_d.append(F1[p * n:(p + 1) * n][ti])
+        seg = np.concatenate([[0], np.cumsum([len(x) for x in src_d])])
+        nn = knn1_segmented(torch.cat(src_d), torch.cat(tgt_d), seg, seg, "SquareL2", return_distance=False)
+        tgt_m = [tgt_k[p][nn[int(seg[p]):int(seg[p + 1])]] for p in range(batch.P)]
+        out = m.SC2_PCR_batch(src_k, tgt_m)
+        T = torch.stack([t for t, _ in out])
         return T if return_device else [reg.RegistrationResult(t.cpu().numpy().astype(np.float64), 0.0, 0.0) for t in T]
 
     def evaluate(self, batch: DeviceBatch, results):

@@ -105,3 +105,28 @@ def test_sc2pcr_batched_equals_per_pair():
     torch.cuda.synchronize(); tl = time.perf_counter() - t0
     print(f"SC2-PCR 11 pairs: batched {tb / 3 * 1e3:.2f} ms, loop {tl / 3 * 1e3:.2f} ms")
     assert tb < tl * 1.1
+
+
+def test_harness_sc2pcr_path_equals_per_pair_estimator():
+    """RegistrationPipeline with use_RANSAC=False (scripts/test_kitti.py:179-181) batches the matching and the
+    SC2-PCR of all pairs; the poses are bit-identical to looping ``Matcher.estimator`` with the same draws."""
+    import eyoc_amd
+    from eyoc_amd import synthetic as syn
+    from eyoc_amd.harness import DeviceBatch, RegistrationConfig, RegistrationPipeline
+    model = eyoc_amd.load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, conv1_kernel_size=5, normalize_feature=True)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.make_weights().items()})
+    model = model.cuda().eval()
+    cfg = RegistrationConfig(use_RANSAC=False)
+    pipe = RegistrationPipeline(model, cfg)
+    pairs, seeds = [syn.make_pair(s) for s in range(3)], [0, 1, 2]
+    batch = DeviceBatch(pairs, seeds, torch.device("cuda"), cfg.n_points)
+    T = pipe.register(batch, seed=5, return_device=True).cpu().numpy()
+    # the same thing pair by pair
+    F = pipe.features(batch).F
+    F0, F1 = F.index_select(0, batch.sel0), F.index_select(0, batch.sel1)
+    n = batch.n_points
+    rng = np.random.RandomState(5)
+    for p in range(3):
+        Tp, _, _, _, _ = pipe.matcher.estimator(batch.xyz0[p][None], batch.xyz1[p][None], F0[p * n:(p + 1) * n][None],
+                                                F1[p * n:(p + 1) * n][None], rng=rng)
+        np.testing.assert_array_equal(T[p], Tp[0].cpu().numpy())
