@@ -69,24 +69,32 @@ __global__ __launch_bounds__(256) void k_sc_matvec(const float* __restrict__ src
   if (ok) part[(size_t)blockIdx.y * n + i] = acc;
 }
 
-// ---- v_new = y / (||y|| + 1e-6); converged = allclose(v_new, v_old); one workgroup
-__global__ __launch_bounds__(1024) void k_sc_normalize(const float* __restrict__ part, int n_part, float* __restrict__ y,
-                                                       float* __restrict__ v, int n, Sc2Ctl* __restrict__ ctl) {
+// ---- y = sum of the column ranges (ascending), per-block sum of squares (fp64) for the norm
+__global__ __launch_bounds__(256) void k_sc_reduce(const float* __restrict__ part, int n_part, int n, float* __restrict__ y,
+                                                  double* __restrict__ block_sq, const Sc2Ctl* __restrict__ ctl) {
   if (ctl->converged) return;
-  __shared__ double red[16];
-  __shared__ int bad[16];
+  __shared__ double red[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
   double s = 0;
-  for (int i = threadIdx.x; i < n; i += 1024) {
+  if (i < n) {
     float t = part[i];
-    for (int c = 1; c < n_part; ++c) t += part[(size_t)c * n + i];   // column ranges in ascending order
+    for (int c = 1; c < n_part; ++c) t += part[(size_t)c * n + i];
     y[i] = t;
-    s += (double)t * (double)t;
+    s = (double)t * (double)t;
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
+  if (threadIdx.x == 0) block_sq[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// ---- v_new = y / (||y|| + 1e-6); converged = allclose(v_new, v_old); one workgroup
+__global__ __launch_bounds__(1024) void k_sc_normalize(const double* __restrict__ block_sq, int n_blocks, const float* __restrict__ y,
+                                                       float* __restrict__ v, int n, Sc2Ctl* __restrict__ ctl) {
+  if (ctl->converged) return;
+  __shared__ int bad[16];
   double tot = 0;
-  for (int w = 0; w < 16; ++w) tot += red[w];
+  for (int b = 0; b < n_blocks; ++b) tot += block_sq[b];   // every thread the same order: deterministic, no broadcast needed
   const float nrm = (float)sqrt(tot) + 1e-6f;
   int nb = 0;
   for (int i = threadIdx.x; i < n; i += 1024) {
@@ -504,7 +512,7 @@ __global__ void k_fill(float* p, int n, float v) {
 struct Plan {
   int n, words, n_seed, k1, k2;
   int n_part, col_chunk;   // column ranges of the lane-per-row sweeps (matvec, NMS, rank)
-  size_t off_ctl, off_v, off_y, off_score, off_seeds, off_hard, off_tight, off_knn, off_Ts, off_part, off_int, total;
+  size_t off_ctl, off_v, off_y, off_score, off_seeds, off_hard, off_tight, off_knn, off_Ts, off_part, off_int, off_sq, total;
 };
 
 Plan make_plan(int n, const eyoc_sc2pcr_params* p) {
@@ -535,6 +543,7 @@ Plan make_plan(int n, const eyoc_sc2pcr_params* p) {
   pl.n_part = (n + pl.col_chunk - 1) / pl.col_chunk;
   pl.off_part = take((size_t)pl.n_part * n * 4);
   pl.off_int = take((size_t)2 * n * 4);          // NMS domination flags, ranks
+  pl.off_sq = take((size_t)row_blocks * 8);      // per-block sums of squares of a sweep
   pl.total = o + 256;
   return pl;
 }
@@ -573,6 +582,7 @@ int eyoc_sc2pcr(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, int n
   float* part = (float*)(b + pl.off_part);
   int* dom = (int*)(b + pl.off_int);
   int* rank = dom + n;
+  double* block_sq = (double*)(b + pl.off_sq);
   const float d = p->d_thre;
   EYOC_CHECK_HIP(hipMemsetAsync(ctl, 0, sizeof(Sc2Ctl), st));
   // leading eigenvector of the first-order compatibility matrix (power iteration from all-ones)
@@ -580,7 +590,8 @@ int eyoc_sc2pcr(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, int n
   for (int it = 0; it < p->num_iterations; ++it) {
     hipLaunchKernelGGL(k_sc_matvec, dim3(cdiv(n, 256), pl.n_part), dim3(256), 0, st, src_dev, tgt_dev, n, 1.0f / (d * d), v, part,
                        pl.col_chunk, ctl);
-    hipLaunchKernelGGL(k_sc_normalize, dim3(1), dim3(1024), 0, st, part, pl.n_part, y, v, n, ctl);
+    hipLaunchKernelGGL(k_sc_reduce, dim3(cdiv(n, 256)), dim3(256), 0, st, part, pl.n_part, n, y, block_sq, ctl);
+    hipLaunchKernelGGL(k_sc_normalize, dim3(1), dim3(1024), 0, st, block_sq, cdiv(n, 256), y, v, n, ctl);
   }
   // seeds: NMS on the eigenvector in source space, stable top-n_seed
   EYOC_CHECK_HIP(hipMemsetAsync(dom, 0, (size_t)2 * n * 4, st));
