@@ -43,10 +43,12 @@ __global__ void knn_transpose_targets(const float* __restrict__ B, SegArgs seg, 
 // (s_load of eight consecutive targets of one channel) and feed the packed-fp32 ops as SGPR pairs: no LDS
 // traffic at all (the LDS-broadcast version of this kernel was bound by ds_read bandwidth, not by the VALU).
 // Two targets share one v_pk_* instruction; each (query, target) still sees the scalar contract.
+// DOT: the value minimised is -<a, b> (one packed FMA per channel and target pair) instead of the squared distance:
+// the arg-max of the inner product of util/transform_estimation.py:131-133 without its [N0, N1] matrix.
 // TOP2: also track the second smallest distance (Lowe's ratio test of the label generator,
 // lib/trainer.py:1060-1072); the target range is then NOT split over blocks (a 64-bit atomicMin cannot merge a
 // runner-up) and the four waves of the block merge their partial results through LDS.
-template <int C, bool TOP2>
+template <int C, bool TOP2, bool DOT>
 __global__ __launch_bounds__(256) void knn1_kernel(const float* __restrict__ A, const float* __restrict__ Bt,
                                                    SegArgs seg, int split_len, int dist_type,
                                                    unsigned long long* __restrict__ best, float* __restrict__ second) {
@@ -96,6 +98,11 @@ __global__ __launch_bounds__(256) void knn1_kernel(const float* __restrict__ A, 
     };
     // the four target pairs side by side, so that dependent packed ops are never back to back (a wait state each)
     auto channel = [&](int c, const f32x2 (&b)[TGROUP / 2]) {
+      if (DOT) {
+#pragma unroll
+        for (int k = 0; k < TGROUP / 2; ++k) acc[k] = __builtin_elementwise_fma(a[c], -b[k], acc[k]);
+        return;
+      }
       f32x2 d[TGROUP / 2];
 #pragma unroll
       for (int k = 0; k < TGROUP / 2; ++k) d[k] = a[c] - b[k];
@@ -166,13 +173,15 @@ __global__ __launch_bounds__(256) void knn1_kernel(const float* __restrict__ A, 
     return;
   }
   if (q_ok && any) {
-    unsigned long long packed = ((unsigned long long)__float_as_uint(best_d) << 32) | (unsigned)best_j;
+    unsigned int bits = __float_as_uint(best_d);
+    if (DOT) bits = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);   // negative values too: order-preserving key
+    unsigned long long packed = ((unsigned long long)bits << 32) | (unsigned)best_j;
     atomicMin(&best[a0 + q], packed);
   }
 }
 
 __global__ void knn1_unpack(const unsigned long long* __restrict__ best, int n, long long* __restrict__ idx,
-                            float* __restrict__ dist) {
+                            float* __restrict__ dist, int dot) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   unsigned long long p = best[i];
@@ -182,7 +191,9 @@ __global__ void knn1_unpack(const unsigned long long* __restrict__ best, int n, 
     return;
   }
   if (idx) idx[i] = (long long)(unsigned)(p & 0xFFFFFFFFull);
-  if (dist) dist[i] = __uint_as_float((unsigned)(p >> 32));
+  unsigned int bits = (unsigned)(p >> 32);
+  if (dot) bits = (bits & 0x80000000u) ? (bits & 0x7FFFFFFFu) : ~bits;   // undo the key, then negate: the inner product
+  if (dist) dist[i] = dot ? -__uint_as_float(bits) : __uint_as_float(bits);
 }
 
 // dense distance matrix (lib/metrics.py:22-29) with the same arithmetic contract as knn1_kernel
@@ -205,7 +216,7 @@ __global__ void pdist_kernel(const float* __restrict__ A, int n, const float* __
 
 template <int C>
 void launch_knn(const float* A, const float* Bt, const SegArgs& seg, int nseg, int max_na, int max_nb, int dist_type,
-                unsigned long long* best, float* second, hipStream_t st) {
+                unsigned long long* best, float* second, bool dot, hipStream_t st) {
   int qtiles = eyoc::cdiv(max_na, 64);
   int total = qtiles * nseg;
   int max_splits = eyoc::cdiv(max_nb, SPLIT_ALIGN);
@@ -215,15 +226,16 @@ void launch_knn(const float* A, const float* Bt, const SegArgs& seg, int nseg, i
   int split_len = eyoc::cdiv(eyoc::cdiv(max_nb, nsplit), SPLIT_ALIGN) * SPLIT_ALIGN;
   nsplit = eyoc::cdiv(max_nb, split_len);
   dim3 grid(qtiles, nsplit, nseg);
-  if (second) hipLaunchKernelGGL((knn1_kernel<C, true>), grid, dim3(256), 0, st, A, Bt, seg, split_len, dist_type, best, second);
-  else hipLaunchKernelGGL((knn1_kernel<C, false>), grid, dim3(256), 0, st, A, Bt, seg, split_len, dist_type, best, second);
+  if (second) hipLaunchKernelGGL((knn1_kernel<C, true, false>), grid, dim3(256), 0, st, A, Bt, seg, split_len, dist_type, best, second);
+  else if (dot) hipLaunchKernelGGL((knn1_kernel<C, false, true>), grid, dim3(256), 0, st, A, Bt, seg, split_len, 0, best, second);
+  else hipLaunchKernelGGL((knn1_kernel<C, false, false>), grid, dim3(256), 0, st, A, Bt, seg, split_len, dist_type, best, second);
 }
 
 }  // namespace
 
 static int knn_run(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c, const int32_t* seg_a,
                    const int32_t* seg_b, int nseg, int dist_type, int64_t* idx_dev, float* dist_dev, float* second_dev,
-                   void* stream) {
+                   void* stream, bool dot = false) {
   EYOC_REQUIRE(ctx && A_dev && B_dev && seg_a && seg_b, EYOC_ERR_INVALID, "eyoc_knn1: NULL argument");
   EYOC_REQUIRE(nseg >= 1 && nseg <= MAX_SEG, EYOC_ERR_INVALID, "eyoc_knn1: nseg %d not in [1,%d]", nseg, MAX_SEG);
   EYOC_REQUIRE(dist_type == 0 || dist_type == 1, EYOC_ERR_INVALID, "eyoc_knn1: dist_type %d", dist_type);
@@ -261,15 +273,15 @@ static int knn_run(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c,
     hipLaunchKernelGGL(knn_transpose_targets, dim3(eyoc::cdiv((long long)max_ld * (c / 4), 256), 1, nseg), dim3(256), 0, st, B_dev,
                        seg, c, Bt);
     switch (c) {
-      case 4: launch_knn<4>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, st); break;
-      case 16: launch_knn<16>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, st); break;
-      case 32: launch_knn<32>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, st); break;
-      case 64: launch_knn<64>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, st); break;
-      default: launch_knn<128>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, st); break;
+      case 4: launch_knn<4>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, dot, st); break;
+      case 16: launch_knn<16>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, dot, st); break;
+      case 32: launch_knn<32>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, dot, st); break;
+      case 64: launch_knn<64>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, dot, st); break;
+      default: launch_knn<128>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, dot, st); break;
     }
   }
   hipLaunchKernelGGL(knn1_unpack, dim3(eyoc::cdiv(n_total, 256)), dim3(256), 0, st, best, n_total,
-                     (long long*)idx_dev, dist_dev);
+                     (long long*)idx_dev, dist_dev, dot ? 1 : 0);
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
 }
@@ -278,6 +290,11 @@ extern "C" int eyoc_knn1(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, 
                          const int32_t* seg_b, int nseg, int dist_type, int64_t* idx_dev, float* dist_dev,
                          void* stream) {
   return knn_run(ctx, A_dev, B_dev, c, seg_a, seg_b, nseg, dist_type, idx_dev, dist_dev, nullptr, stream);
+}
+
+extern "C" int eyoc_dotmax(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c, const int32_t* seg_a,
+                           const int32_t* seg_b, int nseg, int64_t* idx_dev, float* weight_dev, void* stream) {
+  return knn_run(ctx, A_dev, B_dev, c, seg_a, seg_b, nseg, 0, idx_dev, weight_dev, nullptr, stream, true);
 }
 
 extern "C" int eyoc_knn2(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c, const int32_t* seg_a,

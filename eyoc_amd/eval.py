@@ -54,6 +54,24 @@ def knn1_segmented(A: torch.Tensor, B: torch.Tensor, seg_a, seg_b, dist_type="Sq
     return (idx, dist) if return_distance else idx
 
 
+def dotmax_segmented(A, B, seg_a, seg_b):
+    """``(A @ B.T).max(dim=1)`` per segment without the matrix: ``(weight f32 [len(A)], idx int64 [len(A)])`` on the
+    device (util/transform_estimation.py:131-133)."""
+    A, B = _cuda_f32(A), _cuda_f32(B, A.device if A.is_cuda else None)
+    if A.shape[1] != B.shape[1]:
+        raise ValueError("feature dimensions differ")
+    nseg = len(seg_a) - 1
+    sa = (C.c_int32 * (nseg + 1))(*[int(v) for v in seg_a])
+    sb = (C.c_int32 * (nseg + 1))(*[int(v) for v in seg_b])
+    idx = torch.zeros(A.shape[0], dtype=torch.int64, device=A.device)
+    w = torch.full((A.shape[0],), float("nan"), dtype=torch.float32, device=A.device)
+    if A.shape[0]:
+        with torch.cuda.device(A.device):
+            _lib.check(_lib.load().eyoc_dotmax(_lib.ctx(A.device.index), _lib.ptr(A), _lib.ptr(B), A.shape[1], sa, sb, nseg,
+                                               _lib.ptr(idx), _lib.ptr(w), _lib.stream_ptr()), "eyoc_dotmax")
+    return w, idx
+
+
 def find_nn_gpu(F0, F1, nn_max_n=-1, return_distance=False, dist_type='SquareL2'):
     """lib/eval.py:18-48.  Returns CPU tensors like the reference: ``inds int64 [N0]`` and, on request,
     ``dists f32 [N0,1]``."""

@@ -81,8 +81,12 @@ def pose_estimation(model, device, xyz0, xyz1, coord0, coord1, feats0, feats1, r
     from .sparse_tensor import SparseTensor
     F0 = model(SparseTensor(feats0.to(device), coordinates=coord0.to(device))).F
     F1 = model(SparseTensor(feats1.to(device), coordinates=coord1.to(device))).F
-    corr = F0.mm(F1.t())
-    weight, inds = corr.max(dim=1)
+    if return_corr:                              # the reference's dense form, only on request
+        corr = F0.mm(F1.t())
+        weight, inds = corr.max(dim=1)
+    else:                                        # streaming arg-max of the same inner products (eyoc_dotmax)
+        from .eval import dotmax_segmented
+        weight, inds = dotmax_segmented(F0, F1, [0, F0.shape[0]], [0, F1.shape[0]])
     weight = weight.unsqueeze(1).cpu()
     xyz1_corr = xyz1[inds.cpu(), :]
     trans = est_quad_linear_robust(xyz0, xyz1_corr, weight)

@@ -194,6 +194,13 @@ int eyoc_knn1(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c, cons
               const int32_t* seg_b, int nseg, int dist_type, int64_t* idx_dev, float* dist_dev,
               void* stream);
 
+/* Arg-max of the inner product (replaces ``corr = F0.mm(F1.t()); weight, inds = corr.max(dim=1)`` of
+ * util/transform_estimation.py:131-133 without materialising the [N0,N1] matrix - 3.6 GB at 30k voxels):
+ * idx int64 [n] (local to the B segment, ties to the lowest index), weight f32 [n] = max_j <A_i, B_j> accumulated
+ * with fp32 FMAs over the channels in order. */
+int eyoc_dotmax(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c, const int32_t* seg_a,
+                const int32_t* seg_b, int nseg, int64_t* idx_dev, float* weight_dev, void* stream);
+
 /* Two nearest neighbours for Lowe's ratio test (replaces pytorch3d.ops.knn_points(..., K=2) at
  * lib/trainer.py:1060-1061, squared L2 like knn_points): idx int64 [n] (nearest, local to the B segment), d1 / d2
  * f32 [n] smallest and second smallest squared distance (+inf when the segment has < 2 rows).  Same arithmetic

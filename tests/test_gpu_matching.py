@@ -112,3 +112,32 @@ def test_find_corr_and_random_sample_glue():
     assert p.shape == (1200, 3) and f.shape == (1200, 32)
     p, f = eyoc_amd.random_sample(xyz0.numpy(), torch.from_numpy(F0), 900)
     assert p.shape == (900, 3)
+
+
+def test_dotmax_streaming_argmax_vs_dense_matmul():
+    """eyoc_dotmax = ``(F0 @ F1.T).max(dim=1)`` of util/transform_estimation.py:131-133 without the matrix: weights to
+    fp32 rounding, indices equal wherever the dense maximum is unambiguous; also a negative-only row and segments."""
+    from eyoc_amd.eval import dotmax_segmented
+    rng = np.random.default_rng(17)
+
+    def unit(n, c):
+        f = rng.normal(size=(n, c)).astype(np.float32)
+        return f / np.linalg.norm(f, axis=1, keepdims=True).astype(np.float32)
+
+    for na, nb, c in ((3000, 3500, 32), (70, 9, 16), (500, 1200, 64)):
+        A, B = unit(na, c), unit(nb, c)
+        A[5] = -B.mean(0) * 50                                  # every inner product of this row is negative
+        w, idx = dotmax_segmented(torch.from_numpy(A), torch.from_numpy(B), [0, na], [0, nb])
+        D = A.astype(np.float64) @ B.T.astype(np.float64)
+        ref_i, ref_w = D.argmax(1), D.max(1)
+        np.testing.assert_allclose(w.cpu().numpy(), ref_w, rtol=0, atol=3e-6 * max(1.0, np.abs(ref_w).max()))
+        top2 = np.sort(D, axis=1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 1e-5 * np.abs(top2[:, 1]).clip(1e-3)
+        np.testing.assert_array_equal(idx.cpu().numpy()[clear], ref_i[clear])
+        assert clear.mean() > 0.9
+    A, B = unit(600, 32), unit(700, 32)
+    w, idx = dotmax_segmented(torch.from_numpy(A), torch.from_numpy(B), [0, 100, 600], [0, 300, 700])
+    D0, D1 = A[:100] @ B[:300].T, A[100:] @ B[300:].T
+    got = idx.cpu().numpy()
+    assert (got[:100] == D0.argmax(1)).mean() > 0.98 and (got[100:] == D1.argmax(1)).mean() > 0.98
+    assert got[:100].max() < 300 and got[100:].max() < 400
