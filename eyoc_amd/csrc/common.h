@@ -134,6 +134,9 @@ struct eyoc_maps {
   // perm_s1[l]: same idea for the stride-1 convolutions of level l (rows grouped by a coarse key of their
   // neighbour pattern); NULL = natural order
   int32_t* perm_s1[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
+  // perm_down[l]: rows of level l+1 (outputs of the strided convolution l -> l+1) grouped by which of their own 8
+  // children exist (those are 8 of the 27 offsets of the strided map)
+  int32_t* perm_down[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
   bool table0_built = false;   // table[0] has its memory reserved but is only filled on demand (maps_build_table0)
 };
 

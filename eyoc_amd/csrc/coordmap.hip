@@ -176,6 +176,18 @@ __global__ void k_pattern_key(const int32_t* __restrict__ nbr, int n, int key_bi
   row[o] = o;
 }
 
+// sort key of a coarse row for the strided convolution: which of its own 8 children exist
+__global__ void k_children_key(const int32_t* __restrict__ children, int nc, unsigned int* __restrict__ key,
+                               int* __restrict__ row, unsigned int key_tag) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nc) return;
+  const int4 lo = reinterpret_cast<const int4*>(children)[2 * (size_t)v], hi = reinterpret_cast<const int4*>(children)[2 * (size_t)v + 1];
+  const unsigned int m = (lo.x >= 0 ? 1u : 0u) | (lo.y >= 0 ? 2u : 0u) | (lo.z >= 0 ? 4u : 0u) | (lo.w >= 0 ? 8u : 0u) |
+                         (hi.x >= 0 ? 16u : 0u) | (hi.y >= 0 ? 32u : 0u) | (hi.z >= 0 ? 64u : 0u) | (hi.w >= 0 ? 128u : 0u);
+  key[v] = key_tag | m;
+  row[v] = v;
+}
+
 __global__ void k_iota(int32_t* __restrict__ out, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = i;
@@ -336,7 +348,7 @@ size_t eyoc_maps_workspace_bytes(int n_rows) {
   b += 10 * align_up(n * 27 * 4);                                    // 4 s1 + 3 down + 3 up tables
   b += 3 * align_up(n * 4) + align_up((n / SCAN_TILE + 2) * 4);      // slot, flag, partial sums
   b += 3 * (align_up(n * 4) + align_up(n * 32));                     // parent / children links
-  b += 4 * align_up(4 * n * 4) + align_up(sort_rows_tmp_bytes(4 * n_rows, UP_KEY_BITS + 3));   // tiling orders: keys, rows, result (<= 2 segments per level, levels sum to < 2 n)
+  b += 4 * align_up(4 * n * 4) + align_up(sort_rows_tmp_bytes(4 * n_rows, UP_KEY_BITS + 4));   // tiling orders: keys, rows, result (<= 2 segments per level, levels sum to < 2 n)
   b += 4096;                                                         // counters
   return b + 64 * 256;
 }
@@ -445,20 +457,23 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
   // rocPRIM sorts cost 38 small launches, 0.7 ms per 64-cloud batch).  The orders only serve the wave-private
   // convolution kernel, which takes over above ~4000 row tiles: small levels (single-pair latency path) skip them.
   static const bool s1_order = !(getenv("EYOC_S1_ORDER") && atoi(getenv("EYOC_S1_ORDER")) == 0);
-  int seg_up[EYOC_MAX_LEVELS], seg_s1[EYOC_MAX_LEVELS], seg_base[2 * EYOC_MAX_LEVELS], n_seg = 0;
+  int seg_up[EYOC_MAX_LEVELS], seg_s1[EYOC_MAX_LEVELS], seg_dn[EYOC_MAX_LEVELS], seg_base[3 * EYOC_MAX_LEVELS], n_seg = 0;
   size_t total = 0;
   for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
-    seg_up[l] = seg_s1[l] = -1;
+    seg_up[l] = seg_s1[l] = seg_dn[l] = -1;
+    if (l + 1 < EYOC_MAX_LEVELS && m->rows[l + 1] >= ORDER_MIN_ROWS) {   // outputs of the strided conv l -> l+1
+      seg_dn[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l + 1];
+    }
     if (m->rows[l] < ORDER_MIN_ROWS) continue;
     if (l + 1 < EYOC_MAX_LEVELS) { seg_up[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l]; }
     if (s1_order) { seg_s1[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l]; }
   }
-  constexpr int TAG_SHIFT = UP_KEY_BITS;                 // keys < 2^11, segment tag above (at most 7 segments: 3 bits)
+  constexpr int TAG_SHIFT = UP_KEY_BITS, TAG_BITS = 4;   // keys < 2^11, segment tag above (at most 10 segments)
   unsigned int* key_in = cv.take<unsigned int>(total);
   unsigned int* key_out = cv.take<unsigned int>(total);
   int* row_in = cv.take<int>(total);
   int32_t* perm_all = cv.take<int32_t>(total);
-  const size_t sort_bytes = sort_rows_tmp_bytes((int)total, TAG_SHIFT + 3);
+  const size_t sort_bytes = sort_rows_tmp_bytes((int)total, TAG_SHIFT + TAG_BITS);
   void* sort_tmp = cv.take<char>(sort_bytes);
   for (int l = EYOC_MAX_LEVELS - 2; l >= 0; --l) {
     const int nl = m->rows[l], nc = m->rows[l + 1];
@@ -470,6 +485,12 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
     hipLaunchKernelGGL(k_derive_down, dim3(cdiv(nc, 256)), dim3(256), 0, st, nc, m->children[l], m->nbr_s1[l + 1],
                        m->nbr_down[l]);
   }
+  for (int l = 0; l + 1 < EYOC_MAX_LEVELS; ++l) {
+    const int sd = seg_dn[l];
+    if (sd < 0) continue;
+    hipLaunchKernelGGL(k_children_key, dim3(cdiv(m->rows[l + 1], 256)), dim3(256), 0, st, m->children[l], m->rows[l + 1],
+                       key_in + seg_base[sd], row_in + seg_base[sd], (unsigned int)sd << TAG_SHIFT);
+  }
   for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
     const int ss = seg_s1[l];
     if (ss < 0) continue;
@@ -478,13 +499,14 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
                        key_in + seg_base[ss], row_in + seg_base[ss], (unsigned int)ss << TAG_SHIFT);
   }
   if (total > 0) {
-    if (int rc = sort_rows_by_key(sort_tmp, sort_bytes, key_in, key_out, row_in, perm_all, (int)total, TAG_SHIFT + 3, st)) {
+    if (int rc = sort_rows_by_key(sort_tmp, sort_bytes, key_in, key_out, row_in, perm_all, (int)total, TAG_SHIFT + TAG_BITS, st)) {
       delete m;
       return rc;
     }
     for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
       if (seg_up[l] >= 0) m->perm_up[l] = perm_all + seg_base[seg_up[l]];
       if (seg_s1[l] >= 0) m->perm_s1[l] = perm_all + seg_base[seg_s1[l]];
+      if (seg_dn[l] >= 0) m->perm_down[l] = perm_all + seg_base[seg_dn[l]];
     }
   }
   FAIL_HIP(hipGetLastError());

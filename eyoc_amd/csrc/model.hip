@@ -273,7 +273,8 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
       a.res = p.res_buf >= 0 ? buf[p.res_buf] : nullptr; a.ld_res = p.res_buf >= 0 ? m->bufs[p.res_buf].width : 0;
       a.relu = p.relu; a.l2norm = p.l2norm;
       a.out = buf[p.out_buf] + p.out_col; a.ld_out = m->bufs[p.out_buf].width;
-      a.perm = p.map == M_UP ? maps->perm_up[p.level] : p.map == M_S1 ? maps->perm_s1[p.level] : nullptr;
+      a.perm = p.map == M_UP ? maps->perm_up[p.level] : p.map == M_S1 ? maps->perm_s1[p.level]
+               : p.map == M_DOWN ? maps->perm_down[p.level] : nullptr;
       rc = launch_spconv(a, st);
     }
     if (rc) return rc;
