@@ -199,6 +199,8 @@ __global__ __launch_bounds__(256) void k_seed_topk(const unsigned long long* __r
   extern __shared__ unsigned char dyn[];
   unsigned short* row = reinterpret_cast<unsigned short*>(dyn);                                            // [n]
   unsigned long long* srow = reinterpret_cast<unsigned long long*>(dyn + ((size_t)n * 2 + 15) / 16 * 16);  // [words]
+  unsigned short* cand = reinterpret_cast<unsigned short*>(dyn + ((size_t)n * 2 + 15) / 16 * 16 + (size_t)words * 8);  // [<= n]
+  __shared__ int cand_n;
   __shared__ int hist[1024];
   __shared__ int fine[16];
   __shared__ int thr_bucket, thr_value, n_above, need_eq;
@@ -214,14 +216,50 @@ __global__ __launch_bounds__(256) void k_seed_topk(const unsigned long long* __r
   if (threadIdx.x < 16) fine[threadIdx.x] = 0;
   if (threadIdx.x == 0) above_n = 0;
   __syncthreads();
-  for (int j = threadIdx.x; j < n; j += 256) {
-    int c = 0;
-    if ((hs[j >> 6] >> (j & 63)) & 1ull) {
-      const unsigned long long* tj = tight + (size_t)j * words;
-      for (int w = 0; w < words; ++w) c += __popcll(srow[w] & tj[w]);
+  // The hard row is sparse (a few percent): compact its set bits into an LDS list, then ONE WAVE per candidate j
+  // ANDs the two 1 KB tight rows with coalesced loads (a lane-per-j loop read them 8 bytes at a time, every lane a
+  // different row, and idled on the unset bits).
+  for (int j = threadIdx.x; j < n; j += 256) row[j] = 0;
+  if (threadIdx.x == 0) cand_n = 0;
+  __syncthreads();
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int w = wave; w < words; w += 4) {
+      const unsigned long long bits = hs[w];
+      const bool set = (bits >> lane) & 1ull;          // columns >= n are never set (k_masks)
+      int base = 0;
+      if (lane == 0 && bits) base = atomicAdd(&cand_n, __popcll(bits));
+      base = __shfl(base, 0, 64);
+      if (set) cand[base + __popcll(bits & ((1ull << lane) - 1ull))] = (unsigned short)(w * 64 + lane);
     }
-    row[j] = (unsigned short)c;
-    atomicAdd(&hist[c >> 4], 1);
+    __syncthreads();
+    const int nc = cand_n;
+    // four candidates per wave in flight: the loop is bound by the latency of the row loads, not by the popcounts
+    for (int ci = wave * 4; ci < nc; ci += 16) {
+      int c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = cand[min(ci + u, nc - 1)];
+        const unsigned long long* tj = tight + (size_t)j * words;
+        int acc = 0;
+        for (int w = lane; w < words; w += 64) acc += __popcll(srow[w] & tj[w]);
+        c[u] = acc;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c[u] += __shfl_down(c[u], d, 64);
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (ci + u < nc) {
+            row[cand[ci + u]] = (unsigned short)c[u];
+            atomicAdd(&hist[c[u] >> 4], 1);
+          }
+      }
+    }
+    if (threadIdx.x == 0) atomicAdd(&hist[0], n - nc);   // every other column counts 0
   }
   __syncthreads();
   if (threadIdx.x == 0) {   // bucket of the k1-th largest value
@@ -602,7 +640,14 @@ int eyoc_sc2pcr(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, int n
   // hard masks, second-order measure per seed, two-stage consensus, hypotheses
   hipLaunchKernelGGL(k_masks, dim3(cdiv((long long)n * pl.words, 4)), dim3(256), 0, st, src_dev, tgt_dev, n, pl.words, d,
                      hard, tight);
-  const size_t dyn = ((size_t)n * 2 + 15) / 16 * 16 + (size_t)pl.words * 8;
+  const size_t dyn = ((size_t)n * 2 + 15) / 16 * 16 + (size_t)pl.words * 8 + (size_t)pl.words * 64 * 2;   // row, seed row, candidates
+  if (dyn > 48 * 1024) {   // beyond the default dynamic-LDS allowance (n > ~12000)
+    static bool attr_set = false;
+    if (!attr_set) {
+      EYOC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seed_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      attr_set = true;
+    }
+  }
   hipLaunchKernelGGL(k_seed_topk, dim3(pl.n_seed), dim3(256), dyn, st, hard, tight, n, pl.words, seeds, pl.k1, knn);
   hipLaunchKernelGGL(k_seed_solve, dim3(cdiv(pl.n_seed, 4)), dim3(256), 0, st, src_dev, tgt_dev, n, pl.n_seed, knn, pl.k1,
                      pl.k2, d, p->num_iterations, p->inlier_threshold, Ts, fitness_dev);
