@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=32, help="pairs per step per GPU (64 clouds of ~31k voxels in one batched forward)")
+    ap.add_argument("--pairs", type=int, default=64, help="pairs per step per GPU (128 clouds of ~31k voxels in one batched forward)")
     ap.add_argument("--ransac-iters", type=int, default=4000000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency-probe", action="store_true",

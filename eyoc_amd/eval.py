@@ -31,6 +31,9 @@ def _cuda_f32(t, device=None) -> torch.Tensor:
     return t.to(torch.float32).contiguous()
 
 
+MAX_SEGMENTS = 64
+
+
 def knn1_segmented(A: torch.Tensor, B: torch.Tensor, seg_a, seg_b, dist_type="SquareL2", return_distance=True):
     """Independent 1-NN problems packed in one launch: rows ``seg_a[s]:seg_a[s+1]`` of ``A`` against rows
     ``seg_b[s]:seg_b[s+1]`` of ``B``.  Returns device tensors ``idx int64 [len(A)]`` (local to the B
@@ -48,9 +51,16 @@ def knn1_segmented(A: torch.Tensor, B: torch.Tensor, seg_a, seg_b, dist_type="Sq
     if A.shape[1] != B.shape[1]:
         raise ValueError("feature dimensions differ")
     with torch.cuda.device(A.device):
-        _lib.check(_lib.load().eyoc_knn1(_lib.ctx(A.device.index), _lib.ptr(A), _lib.ptr(B), A.shape[1], sa, sb, nseg,
-                                         _DIST[dist_type], _lib.ptr(idx), _lib.ptr(dist), _lib.stream_ptr()),
-                   "eyoc_knn1")
+        for s0 in range(0, nseg, MAX_SEGMENTS):     # the library takes at most 64 segments per launch
+            ns = min(MAX_SEGMENTS, nseg - s0)
+            a0 = int(seg_a[s0])
+            sa_c = (C.c_int32 * (ns + 1))(*[int(v) - a0 for v in seg_a[s0:s0 + ns + 1]])
+            sb_c = (C.c_int32 * (ns + 1))(*[int(v) for v in seg_b[s0:s0 + ns + 1]])
+            if int(seg_a[s0 + ns]) == a0:
+                continue
+            _lib.check(_lib.load().eyoc_knn1(_lib.ctx(A.device.index), _lib.ptr(A[a0:]), _lib.ptr(B), A.shape[1], sa_c, sb_c, ns,
+                                             _DIST[dist_type], _lib.ptr(idx[a0:]), _lib.ptr(dist[a0:]), _lib.stream_ptr()),
+                       "eyoc_knn1")
     return (idx, dist) if return_distance else idx
 
 
