@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int MAX_SEG = 64;
+constexpr int MAX_SEG = 128;
 struct SegArgs {
   int a[MAX_SEG + 1];
   int b[MAX_SEG + 1];

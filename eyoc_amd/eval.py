@@ -31,7 +31,7 @@ def _cuda_f32(t, device=None) -> torch.Tensor:
     return t.to(torch.float32).contiguous()
 
 
-MAX_SEGMENTS = 64
+MAX_SEGMENTS = 128
 
 
 def knn1_segmented(A: torch.Tensor, B: torch.Tensor, seg_a, seg_b, dist_type="SquareL2", return_distance=True):
@@ -51,7 +51,7 @@ def knn1_segmented(A: torch.Tensor, B: torch.Tensor, seg_a, seg_b, dist_type="Sq
     if A.shape[1] != B.shape[1]:
         raise ValueError("feature dimensions differ")
     with torch.cuda.device(A.device):
-        for s0 in range(0, nseg, MAX_SEGMENTS):     # the library takes at most 64 segments per launch
+        for s0 in range(0, nseg, MAX_SEGMENTS):     # the library takes at most 128 segments per launch
             ns = min(MAX_SEGMENTS, nseg - s0)
             a0 = int(seg_a[s0])
             sa_c = (C.c_int32 * (ns + 1))(*[int(v) - a0 for v in seg_a[s0:s0 + ns + 1]])

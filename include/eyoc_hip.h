@@ -188,7 +188,7 @@ int eyoc_model_layer_ms(eyoc_model* model, float* ms /*[num_layers]*/);
  *   form, fp32, channels left to right, no FMA - bit-exact with oracle/matching.py); 1: L2 =
  *   sqrt(d2 + 1e-7); ties go to the lowest index.  Segmented form: nseg independent problems,
  *   rows [seg_a[s], seg_a[s+1]) of A against rows [seg_b[s], seg_b[s+1]) of B; indices are local to
- *   the B segment.  seg arrays are HOST arrays; nseg <= 64.  c in {4, 16, 32, 64, 128}.
+ *   the B segment.  seg arrays are HOST arrays; nseg <= 128.  c in {4, 16, 32, 64, 128}.
  * --------------------------------------------------------------------------------------------- */
 int eyoc_knn1(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c, const int32_t* seg_a,
               const int32_t* seg_b, int nseg, int dist_type, int64_t* idx_dev, float* dist_dev,

@@ -141,3 +141,21 @@ def test_dotmax_streaming_argmax_vs_dense_matmul():
     got = idx.cpu().numpy()
     assert (got[:100] == D0.argmax(1)).mean() > 0.98 and (got[100:] == D1.argmax(1)).mean() > 0.98
     assert got[:100].max() < 300 and got[100:].max() < 400
+
+
+def test_many_segments_in_one_call():
+    """100 segments in one launch and 150 through the wrapper's chunking (the library takes 128 per launch)."""
+    from eyoc_amd.eval import knn1_segmented
+    from oracle import matching as om
+    rng = np.random.default_rng(23)
+    for nseg in (100, 150):
+        na = rng.integers(1, 40, nseg); nb = rng.integers(1, 50, nseg)
+        A = rng.normal(size=(int(na.sum()), 32)).astype(np.float32)
+        B = rng.normal(size=(int(nb.sum()), 32)).astype(np.float32)
+        sa, sb = np.r_[0, np.cumsum(na)], np.r_[0, np.cumsum(nb)]
+        idx, d = knn1_segmented(torch.from_numpy(A), torch.from_numpy(B), sa, sb)
+        idx, d = idx.cpu().numpy(), d.cpu().numpy()
+        for s in range(nseg):
+            ri, rd = om.find_nn(A[sa[s]:sa[s + 1]], B[sb[s]:sb[s + 1]], return_distance=True)
+            np.testing.assert_array_equal(idx[sa[s]:sa[s + 1]], ri)
+            np.testing.assert_array_equal(d[sa[s]:sa[s + 1]], rd[:, 0])
