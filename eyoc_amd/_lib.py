@@ -71,6 +71,7 @@ PROTOTYPES = {
     "eyoc_maps_info": (_i, [_vp, _vp, _i, _vp, C.POINTER(MapsInfo)]),
     "eyoc_voxelize_workspace_bytes": (_sz, [_i]),
     "eyoc_voxelize": (_i, [_vp, _vp, _i, _i, C.c_float, _i, _vp, _vp, C.POINTER(C.c_int), _vp, _sz, _vp]),
+    "eyoc_gather_rows": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, C.c_float, _vp, _vp]),
     "eyoc_dotmax": (_i, [_vp, _vp, _vp, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i, _vp, _vp, _vp]),
     "eyoc_knn2": (_i, [_vp, _vp, _vp, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i, _vp, _vp, _vp, _vp]),
     "eyoc_lowe_topk": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),

@@ -69,6 +69,8 @@ struct eyoc_ctx {
   hipEvent_t pool_fork = nullptr;
   bool pool_ready = false;
   int ensure_pool();
+  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remembered per ctx, not per process
+  bool ransac_attr_set = false, sc2_attr_set = false;
 };
 
 // ---------------------------------------------------------------------------------------------

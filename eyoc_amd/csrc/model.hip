@@ -268,6 +268,7 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
       a.nbr = p.map == M_S1 ? maps->nbr_s1[p.level] : p.map == M_DOWN ? maps->nbr_down[p.level]
               : p.map == M_UP ? maps->nbr_up[p.level] : nullptr;
       a.K = p.K; a.n_out = n_out;
+      a.n_in = maps->rows[m->bufs[p.in_buf].level];
       a.in = buf[p.in_buf] + p.in_col; a.ld_in = m->bufs[p.in_buf].width; a.cin = p.cin;
       a.w = m->blob + p.w_off; a.cout = p.cout; a.bias = m->blob + p.b_off;
       a.res = p.res_buf >= 0 ? buf[p.res_buf] : nullptr; a.ld_res = p.res_buf >= 0 ? m->bufs[p.res_buf].width : 0;

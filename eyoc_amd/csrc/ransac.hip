@@ -5,10 +5,16 @@
 //   1. generate: one lane per hypothesis h - counter-hash sampler (bit-identical to
 //      oracle/ransac.py), edge-length checker, 4-point Kabsch in fp64, distance checker.  Survivors
 //      (typically well under a few percent) append h to a compact list with one atomic.
-//   2. score: one WAVE per survivor re-derives its transform and sweeps all correspondences with
-//      coalesced loads (a lane-per-hypothesis loop over 5000 points would idle 63 lanes whenever one
-//      hypothesis survives) - inlier count and squared error are wave-reduced.
-//   3. select: single workgroup arg-max with the total order (more inliers, lower RMSE, lower h).
+//      The survivor's transform (12 doubles) is stored next to its index.
+//   2. count: a wave takes 16 survivors at a time and sweeps all correspondences, 4 per lane held in registers
+//      as doubles; the 16 transforms are wave-uniform and come through the scalar cache as SGPR operands of
+//      v_fma_f64 (17 VALU instructions per (hypothesis, correspondence), no loads or conversions in the
+//      inner loop).  With a trained network's inlier ratio p about p^4 of the 4M hypotheses survive (32 000 per
+//      pair at p = 0.3) and this sweep IS the cost of RANSAC: the first version (one wave per survivor,
+//      transform re-derived per wave, sqrt per residual) spent 8.2 ms per 16 pairs there.
+//      The largest count of each pair is kept with an atomicMax.
+//   3. rmse: only the survivors that reach the largest count (almost always one) get their inlier RMSE.
+//   4. select: single workgroup arg-max with the total order (more inliers, lower RMSE, lower h).
 #include "pose_math.h"
 
 using namespace eyoc;
@@ -36,9 +42,12 @@ struct PairArgs {          // a chunk of pairs; segment bounds travel as kernel 
   unsigned int seed;       // pair b uses seed + b
   int H;
   float edge_sim, max_dist;
-  int* n_surv;             // [chunk] survivor counters (CNT_STRIDE ints apart)
+  int* n_surv;             // [chunk] survivor counters (CNT_STRIDE ints apart); [+1] = largest inlier count
   int* surv;               // [chunk][H]
-  unsigned long long* keys;  // [chunk][H]
+  int* cnts;               // [chunk][H] inlier count of every survivor
+  unsigned int* rmse;      // [chunk][H] fp32 bits of the inlier RMSE (only written for survivors at the largest count)
+  double* xf;              // [chunk][cap_t][12] transforms (R row-major, t) of the first cap_t survivors of a pair
+  int cap_t;
 };
 
 __global__ void k_gather_targets(const float* __restrict__ src, const float* __restrict__ tgt,
@@ -137,13 +146,111 @@ __global__ __launch_bounds__(GEN_THREADS) void k_generate(PairArgs a) {
   int* surv = a.surv + (size_t)c * a.H;
   for (int h = blockIdx.x * GEN_THREADS + threadIdx.x; h < a.H; h += gridDim.x * GEN_THREADS) {
     double R[3][3], t[3];
-    if (hypothesis(rec, (unsigned)n, base, (unsigned)h, (double)a.edge_sim, (double)a.max_dist, R, t))
-      surv[atomicAdd(cnt, 1)] = h;
+    if (hypothesis(rec, (unsigned)n, base, (unsigned)h, (double)a.edge_sim, (double)a.max_dist, R, t)) {
+      const int slot = atomicAdd(cnt, 1);
+      surv[slot] = h;
+      if (slot < a.cap_t) {
+        double* x = a.xf + ((size_t)c * a.cap_t + slot) * 12;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          x[3 * i] = R[i][0]; x[3 * i + 1] = R[i][1]; x[3 * i + 2] = R[i][2];
+          x[9 + i] = t[i];
+        }
+      }
+    }
   }
 }
 
-// key: (inliers << 32) | ~bits(rmse_f32): larger is better; ties on the key are broken by lower h
-__global__ __launch_bounds__(256) void k_score(PairArgs a) {
+// squared form of Open3D's `dist < max_correspondence_distance` (no fp64 square root per residual)
+__device__ inline double thr2_of(float max_dist) { return (double)max_dist * (double)max_dist; }
+
+// ---- count.  A wave takes a group of G <= 64 survivors and sweeps the correspondences in blocks of 64 * PPL held
+// in registers as doubles.  For one survivor of the group its transform arrives in SGPRs (scalar loads: the address
+// is wave-uniform), the residual test of the block is 16 VALU instructions per correspondence, and the inlier count
+// of the block is s_bcnt1 of the compare masks - scalar work.  Lane s of one VGPR accumulates survivor s's count, so
+// the group's counts are written with one coalesced store and nothing is ever reduced across lanes.
+constexpr int PPL = 4;
+
+__global__ __launch_bounds__(256) void k_count(PairArgs a, const double* __restrict__ xf_all) {
+  const int c = blockIdx.y;
+  const int s0 = a.s0[c], n = a.n[c];
+  const float* __restrict__ rec = a.rec + (size_t)s0 * 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int ns_all = a.n_surv[c * CNT_STRIDE];
+  const int ns = ns_all < a.cap_t ? ns_all : a.cap_t;
+  const double thr2 = thr2_of(a.max_dist);
+  const double* __restrict__ xf = xf_all + (size_t)c * a.cap_t * 12;
+  int* cnts = a.cnts + (size_t)c * a.H;
+  int G = 64;   // few survivors: smaller groups, so that a pair still spreads over >= 256 waves
+  while (G > 8 && (ns + G - 1) / G < 256) G >>= 1;
+  const int n_groups = (ns + G - 1) / G;
+  int best = 0;
+  for (int grp = blockIdx.x * 4 + wave; grp < n_groups; grp += gridDim.x * 4) {
+    const int sbase = grp * G;
+    const int gs = min(G, ns - sbase);
+    int mycnt = 0;
+    for (int i0 = 0; i0 < n; i0 += 64 * PPL) {
+      double x[PPL], y[PPL], z[PPL], qx[PPL], qy[PPL], qz[PPL];
+#pragma unroll
+      for (int u = 0; u < PPL; ++u) {
+        const int i = i0 + u * 64 + lane;
+        if (i < n) {
+          const float2* r = reinterpret_cast<const float2*>(rec + (size_t)i * 6);
+          const float2 p0 = r[0], p1 = r[1], p2 = r[2];
+          x[u] = p0.x; y[u] = p0.y; z[u] = p1.x; qx[u] = p1.y; qy[u] = p2.x; qz[u] = p2.y;
+        } else {   // past the end: a correspondence no transform brings within reach
+          x[u] = y[u] = z[u] = 0.0; qx[u] = qy[u] = qz[u] = 1e18;
+        }
+      }
+#pragma unroll 1
+      for (int s = 0; s < gs; ++s) {
+        const double* __restrict__ T = xf + (size_t)(sbase + s) * 12;   // wave-uniform
+        const double r00 = T[0], r01 = T[1], r02 = T[2], r10 = T[3], r11 = T[4], r12 = T[5], r20 = T[6], r21 = T[7], r22 = T[8];
+        const double t0 = T[9], t1 = T[10], t2 = T[11];
+        int csum = 0;
+#pragma unroll
+        for (int u = 0; u < PPL; ++u) {
+          const double dx = fma(r00, x[u], fma(r01, y[u], fma(r02, z[u], t0 - qx[u])));
+          const double dy = fma(r10, x[u], fma(r11, y[u], fma(r12, z[u], t1 - qy[u])));
+          const double dz = fma(r20, x[u], fma(r21, y[u], fma(r22, z[u], t2 - qz[u])));
+          const double d2 = fma(dx, dx, fma(dy, dy, dz * dz));
+          csum += __popcll(__ballot(d2 < thr2));
+        }
+        mycnt += lane == s ? csum : 0;
+      }
+    }
+    if (lane < gs) cnts[sbase + lane] = mycnt;
+    best = mycnt > best ? mycnt : best;   // lanes >= gs hold 0
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) best = max(best, __shfl_xor(best, d, 64));
+  if (lane == 0 && best > 0) atomicMax(a.n_surv + c * CNT_STRIDE + 1, best);
+}
+
+// residual sweep of one hypothesis by one wave: inlier count and sum of squared inlier residuals (lane 0)
+__device__ inline void sweep(const float* __restrict__ rec, int n, const double R[3][3], const double t[3], double thr2,
+                             int lane, int& cnt_out, double& err2_out) {
+  int cnt = 0;
+  double err2 = 0;
+  for (int i = lane; i < n; i += 64) {
+    const float2* r = reinterpret_cast<const float2*>(rec + (size_t)i * 6);
+    const float2 p0 = r[0], p1 = r[1], p2 = r[2];
+    const double x = p0.x, y = p0.y, z = p1.x;
+    const double dx = fma(R[0][0], x, fma(R[0][1], y, fma(R[0][2], z, t[0] - (double)p1.y)));
+    const double dy = fma(R[1][0], x, fma(R[1][1], y, fma(R[1][2], z, t[1] - (double)p2.x)));
+    const double dz = fma(R[2][0], x, fma(R[2][1], y, fma(R[2][2], z, t[2] - (double)p2.y)));
+    const double d2 = fma(dx, dx, fma(dy, dy, dz * dz));   // the same expression as k_count: the counts must agree
+    if (d2 < thr2) { ++cnt; err2 += d2; }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_down(cnt, d, 64);
+  cnt_out = cnt;
+  err2_out = wave_sum(err2);
+}
+
+// survivors beyond the transform store (more than cap_t per pair): one wave per survivor re-derives the transform
+__global__ __launch_bounds__(256) void k_count_overflow(PairArgs a) {
   const int c = blockIdx.y, b = a.pair0 + c;
   const int s0 = a.s0[c], n = a.n[c];
   const float* rec = a.rec + (size_t)s0 * 6;
@@ -151,47 +258,66 @@ __global__ __launch_bounds__(256) void k_score(PairArgs a) {
   const int lane = threadIdx.x & 63;
   const int ns = a.n_surv[c * CNT_STRIDE];
   const int* surv = a.surv + (size_t)c * a.H;
-  unsigned long long* keys = a.keys + (size_t)c * a.H;
+  int* cnts = a.cnts + (size_t)c * a.H;
+  const double thr2 = thr2_of(a.max_dist);
+  int best = 0;
+  for (int sidx = a.cap_t + blockIdx.x * 4 + (threadIdx.x >> 6); sidx < ns; sidx += gridDim.x * 4) {
+    double R[3][3], t[3], err2;
+    int cnt;
+    hypothesis(rec, (unsigned)n, base, (unsigned)surv[sidx], (double)a.edge_sim, (double)a.max_dist, R, t);
+    sweep(rec, n, R, t, thr2, lane, cnt, err2);
+    cnt = __shfl(cnt, 0, 64);
+    if (lane == 0) cnts[sidx] = cnt;
+    best = cnt > best ? cnt : best;
+  }
+  if (lane == 0 && best > 0) atomicMax(a.n_surv + c * CNT_STRIDE + 1, best);
+}
+
+// inlier RMSE (fp32 bits) of the survivors that reach the largest count
+__global__ __launch_bounds__(256) void k_rmse(PairArgs a) {
+  const int c = blockIdx.y, b = a.pair0 + c;
+  const int s0 = a.s0[c], n = a.n[c];
+  const float* rec = a.rec + (size_t)s0 * 6;
+  const unsigned long long base = pair_base(a.seed, b);
+  const int lane = threadIdx.x & 63;
+  const int ns = a.n_surv[c * CNT_STRIDE], best = a.n_surv[c * CNT_STRIDE + 1];
+  const int* surv = a.surv + (size_t)c * a.H;
+  const int* cnts = a.cnts + (size_t)c * a.H;
+  unsigned int* rmse = a.rmse + (size_t)c * a.H;
+  const double thr2 = thr2_of(a.max_dist);
   for (int sidx = blockIdx.x * 4 + (threadIdx.x >> 6); sidx < ns; sidx += gridDim.x * 4) {
-    const int h = surv[sidx];
-    double R[3][3], t[3];
-    hypothesis(rec, (unsigned)n, base, (unsigned)h, (double)a.edge_sim, (double)a.max_dist, R, t);
-    int cnt = 0;
-    double err2 = 0;
-    for (int i = lane; i < n; i += 64) {
-      const float2* r = reinterpret_cast<const float2*>(rec + (size_t)i * 6);
-      const float2 p0 = r[0], p1 = r[1], p2 = r[2];
-      const double x = p0.x, y = p0.y, z = p1.x;
-      const double dx = R[0][0] * x + R[0][1] * y + R[0][2] * z + t[0] - p1.y;
-      const double dy = R[1][0] * x + R[1][1] * y + R[1][2] * z + t[1] - p2.x;
-      const double dz = R[2][0] * x + R[2][1] * y + R[2][2] * z + t[2] - p2.y;
-      const double d2 = dx * dx + dy * dy + dz * dz;
-      if (sqrt(d2) < (double)a.max_dist) { ++cnt; err2 += d2; }
-    }
+    if (cnts[sidx] != best) continue;   // wave-uniform
+    double R[3][3], t[3], err2;
+    int cnt;
+    if (sidx < a.cap_t) {               // the stored transform, so that this sweep sees what k_count saw
+      const double* x = a.xf + ((size_t)c * a.cap_t + sidx) * 12;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_down(cnt, d, 64);
-    err2 = wave_sum(err2);
-    if (lane == 0) {
-      const float rmse = cnt > 0 ? (float)sqrt(err2 / cnt) : __builtin_inff();
-      keys[sidx] = ((unsigned long long)(unsigned)cnt << 32) | (unsigned long long)(~__float_as_uint(rmse));
+      for (int i = 0; i < 3; ++i) { R[i][0] = x[3 * i]; R[i][1] = x[3 * i + 1]; R[i][2] = x[3 * i + 2]; t[i] = x[9 + i]; }
+    } else {
+      hypothesis(rec, (unsigned)n, base, (unsigned)surv[sidx], (double)a.edge_sim, (double)a.max_dist, R, t);
     }
+    sweep(rec, n, R, t, thr2, lane, cnt, err2);
+    if (lane == 0) rmse[sidx] = __float_as_uint(cnt > 0 ? (float)sqrt(err2 / cnt) : __builtin_inff());
   }
 }
 
+// key: (inliers << 32) | ~bits(rmse_f32): larger is better; ties on the key are broken by lower h
 __global__ __launch_bounds__(1024) void k_select(PairArgs a, eyoc_ransac_result* __restrict__ results) {
   __shared__ unsigned long long bk[16];
   __shared__ int bh[16];
   const int c = blockIdx.x, b = a.pair0 + c;
   const int s0 = a.s0[c], n = a.n[c];
   const float* rec = a.rec + (size_t)s0 * 6;
-  const int ns = a.n_surv[c * CNT_STRIDE];
+  const int ns = a.n_surv[c * CNT_STRIDE], best = a.n_surv[c * CNT_STRIDE + 1];
   const int* surv = a.surv + (size_t)c * a.H;
-  const unsigned long long* keys = a.keys + (size_t)c * a.H;
+  const int* cnts = a.cnts + (size_t)c * a.H;
+  const unsigned int* rmse = a.rmse + (size_t)c * a.H;
   eyoc_ransac_result* out = results + b;
   unsigned long long best_k = 0;
   int best_h = 0x7FFFFFFF;
   for (int i = threadIdx.x; i < ns; i += 1024) {
-    const unsigned long long k = keys[i];
+    if (cnts[i] != best) continue;
+    const unsigned long long k = ((unsigned long long)(unsigned)best << 32) | (unsigned long long)(~rmse[i]);
     const int h = surv[i];
     if (k > best_k || (k == best_k && h < best_h)) { best_k = k; best_h = h; }
   }
@@ -243,22 +369,26 @@ extern "C" int eyoc_ransac_batched(eyoc_ctx* ctx, const float* src_dev, const fl
   // survivor lists are sized for the worst case (every hypothesis survives): run the pairs in chunks so the
   // scratch stays bounded (12 bytes per hypothesis and pair of the chunk)
   const int chunk = n_pairs < CHUNK ? n_pairs : CHUNK;
+  // transforms are stored for the first cap_t survivors of a pair (96 B each; 1M = the survivors of an inlier ratio
+  // of 0.7); the rest - only ever reached by degenerate inputs - are re-derived by k_count_overflow
+  const int cap_t = H < (1 << 20) ? H : (1 << 20);
   const size_t off_cnt = 0, off_rec = align_up((size_t)chunk * CNT_STRIDE * 4), off_surv = align_up(off_rec + (size_t)total * 24);
-  const size_t off_keys = align_up(off_surv + (size_t)chunk * H * 4);
-  int rc = ctx->ensure_scratch(off_keys + (size_t)chunk * H * 8);
+  const size_t off_cnts = align_up(off_surv + (size_t)chunk * H * 4), off_rmse = align_up(off_cnts + (size_t)chunk * H * 4);
+  const size_t off_xf = align_up(off_rmse + (size_t)chunk * H * 4);
+  int rc = ctx->ensure_scratch(off_xf + (size_t)chunk * cap_t * 96);
   if (rc) return rc;
   char* sc = (char*)ctx->scratch;
   PairArgs a;
   a.rec = (float*)(sc + off_rec); a.seed = p->seed; a.H = H; a.edge_sim = p->edge_similarity; a.max_dist = p->max_distance;
-  a.n_surv = (int*)(sc + off_cnt); a.surv = (int*)(sc + off_surv); a.keys = (unsigned long long*)(sc + off_keys);
+  a.n_surv = (int*)(sc + off_cnt); a.surv = (int*)(sc + off_surv); a.cnts = (int*)(sc + off_cnts);
+  a.rmse = (unsigned int*)(sc + off_rmse); a.xf = (double*)(sc + off_xf); a.cap_t = cap_t;
   const bool in_lds = max_n <= LDS_RECORDS;
   const size_t lds_bytes = in_lds ? (size_t)max_n * 24 : 0;
   if (in_lds) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!ctx->ransac_attr_set) {
       EYOC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_generate<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          LDS_RECORDS * 24));
-      attr_set = true;
+      ctx->ransac_attr_set = true;
     }
   }
   for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
@@ -276,7 +406,9 @@ extern "C" int eyoc_ransac_batched(eyoc_ctx* ctx, const float* src_dev, const fl
     const int gen_blocks = GEN_BLOCKS_TOTAL / nc > GEN_BLOCKS_MIN ? GEN_BLOCKS_TOTAL / nc : GEN_BLOCKS_MIN;
     if (in_lds) hipLaunchKernelGGL(k_generate<true>, dim3(gen_blocks, nc), dim3(GEN_THREADS), lds_bytes, st, a);
     else hipLaunchKernelGGL(k_generate<false>, dim3(gen_blocks, nc), dim3(GEN_THREADS), 0, st, a);
-    hipLaunchKernelGGL(k_score, dim3(256, nc), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_count, dim3(2048 / nc, nc), dim3(256), 0, st, a, (const double*)a.xf);
+    if (H > cap_t) hipLaunchKernelGGL(k_count_overflow, dim3(256, nc), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_rmse, dim3(64, nc), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_select, dim3(nc), dim3(1024), 0, st, a, results_dev);
   }
   EYOC_CHECK_HIP(hipGetLastError());

@@ -642,10 +642,9 @@ int eyoc_sc2pcr(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, int n
                      hard, tight);
   const size_t dyn = ((size_t)n * 2 + 15) / 16 * 16 + (size_t)pl.words * 8 + (size_t)pl.words * 64 * 2;   // row, seed row, candidates
   if (dyn > 48 * 1024) {   // beyond the default dynamic-LDS allowance (n > ~12000)
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!ctx->sc2_attr_set) {
       EYOC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seed_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-      attr_set = true;
+      ctx->sc2_attr_set = true;
     }
   }
   hipLaunchKernelGGL(k_seed_topk, dim3(pl.n_seed), dim3(256), dyn, st, hard, tight, n, pl.words, seeds, pl.k1, knn);

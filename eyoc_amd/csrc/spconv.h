@@ -11,6 +11,7 @@ inline int spconv_cc(int cin, int /*cout*/) { return cin % 64 == 0 ? 64 : 32; }
 struct SpconvArgs {
   const int32_t* nbr;   // [K][n_out] or NULL (identity, K == 1)
   int K, n_out;
+  int n_in = 0;         // rows of the input tensor when known (every entry of nbr is < n_in); must be < 2^24
   const float* in;      // rows of ld_in floats; the layer reads columns [0, cin)
   int ld_in, cin;
   const float* w;       // packed weights (eyoc_spconv_pack_weights)

@@ -558,13 +558,19 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
   EYOC_REQUIRE((((uintptr_t)a.in | (uintptr_t)a.out | (uintptr_t)a.w | (uintptr_t)a.res | (uintptr_t)a.bias) & 15) == 0,
                EYOC_ERR_INVALID, "spconv: pointers must be 16-byte aligned");
   EYOC_REQUIRE(!a.l2norm || a.cout <= 128, EYOC_ERR_INVALID, "spconv: l2norm needs C_out <= 128");
+  // the compacted pair records carry the input row in 24 bits (spconv.hip / spconv_wave.hip: row << 8 | local row)
+  EYOC_REQUIRE((a.nbr ? a.n_in : a.n_out) < (1 << 24), EYOC_ERR_INVALID,
+               "spconv: %d input rows exceed the 2^24 rows one launch can address", a.nbr ? a.n_in : a.n_out);
   if (a.n_out == 0) return EYOC_OK;
   // Two decompositions: the wave-private kernel (spconv_wave.hip) wins once its 64-row tiles give every SIMD
   // a few waves' worth of work (measured cross-over ~4000 tiles on MI355X); below that the workgroup-tiled
   // kernel here balances better.  eyoc_spconv_select_kernel (or EYOC_SPCONV_WAVE=0 / 1 in the environment) forces one of them.
   const int force = g_kernel_mode;
   const long long wave_tiles = (long long)cdiv(a.n_out, 64) * (a.cout >= 64 ? a.cout / 64 : 1);
-  if (force > 0 || (force < 0 && wave_tiles >= 4096)) return launch_spconv_wave(a, st);
+  // row normalisation needs the whole output row in one tile: the wave-private kernel's tiles are at most 64
+  // channels wide, so a normalised 128-channel layer always takes the workgroup-tiled kernel (CT = 128)
+  const bool wave_ok = !(a.l2norm && a.cout > 64);
+  if (wave_ok && (force > 0 || (force < 0 && wave_tiles >= 4096))) return launch_spconv_wave(a, st);
   const bool wide = spconv_cc(a.cin, a.cout) == 64;
   switch (spconv_ct(a.cout)) {
     case 32: wide ? launch_ct<32, 64>(a, st) : launch_ct<32, 32>(a, st); break;

@@ -34,6 +34,20 @@ def _cuda_f32(t, device=None) -> torch.Tensor:
 MAX_SEGMENTS = 128
 
 
+def _segment_chunks(seg_a, seg_b):
+    """The library takes at most ``MAX_SEGMENTS`` segments per launch: yield ``(a0, sa, sb, ns)`` per launch, with
+    ``sa`` re-based to the chunk's first A row ``a0`` (outputs are per A row) and ``sb`` absolute."""
+    nseg = len(seg_a) - 1
+    for s0 in range(0, nseg, MAX_SEGMENTS):
+        ns = min(MAX_SEGMENTS, nseg - s0)
+        a0 = int(seg_a[s0])
+        if int(seg_a[s0 + ns]) == a0:
+            continue
+        sa = (C.c_int32 * (ns + 1))(*[int(v) - a0 for v in seg_a[s0:s0 + ns + 1]])
+        sb = (C.c_int32 * (ns + 1))(*[int(v) for v in seg_b[s0:s0 + ns + 1]])
+        yield a0, sa, sb, ns
+
+
 def knn1_segmented(A: torch.Tensor, B: torch.Tensor, seg_a, seg_b, dist_type="SquareL2", return_distance=True):
     """Independent 1-NN problems packed in one launch: rows ``seg_a[s]:seg_a[s+1]`` of ``A`` against rows
     ``seg_b[s]:seg_b[s+1]`` of ``B``.  Returns device tensors ``idx int64 [len(A)]`` (local to the B
@@ -41,9 +55,6 @@ def knn1_segmented(A: torch.Tensor, B: torch.Tensor, seg_a, seg_b, dist_type="Sq
     if dist_type not in _DIST:
         raise NotImplementedError('Not implemented')
     A, B = _cuda_f32(A), _cuda_f32(B, A.device if A.is_cuda else None)
-    nseg = len(seg_a) - 1
-    sa = (C.c_int32 * (nseg + 1))(*[int(v) for v in seg_a])
-    sb = (C.c_int32 * (nseg + 1))(*[int(v) for v in seg_b])
     idx = torch.empty(A.shape[0], dtype=torch.int64, device=A.device)
     dist = torch.empty(A.shape[0], dtype=torch.float32, device=A.device)
     if A.shape[0] == 0:
@@ -51,17 +62,29 @@ def knn1_segmented(A: torch.Tensor, B: torch.Tensor, seg_a, seg_b, dist_type="Sq
     if A.shape[1] != B.shape[1]:
         raise ValueError("feature dimensions differ")
     with torch.cuda.device(A.device):
-        for s0 in range(0, nseg, MAX_SEGMENTS):     # the library takes at most 128 segments per launch
-            ns = min(MAX_SEGMENTS, nseg - s0)
-            a0 = int(seg_a[s0])
-            sa_c = (C.c_int32 * (ns + 1))(*[int(v) - a0 for v in seg_a[s0:s0 + ns + 1]])
-            sb_c = (C.c_int32 * (ns + 1))(*[int(v) for v in seg_b[s0:s0 + ns + 1]])
-            if int(seg_a[s0 + ns]) == a0:
-                continue
-            _lib.check(_lib.load().eyoc_knn1(_lib.ctx(A.device.index), _lib.ptr(A[a0:]), _lib.ptr(B), A.shape[1], sa_c, sb_c, ns,
+        for a0, sa, sb, ns in _segment_chunks(seg_a, seg_b):
+            _lib.check(_lib.load().eyoc_knn1(_lib.ctx(A.device.index), _lib.ptr(A[a0:]), _lib.ptr(B), A.shape[1], sa, sb, ns,
                                              _DIST[dist_type], _lib.ptr(idx[a0:]), _lib.ptr(dist[a0:]), _lib.stream_ptr()),
                        "eyoc_knn1")
     return (idx, dist) if return_distance else idx
+
+
+def gather_rows(F: torch.Tensor, sel: torch.Tensor, G: torch.Tensor | None = None, beta: float = 0.0) -> torch.Tensor:
+    """``F[sel]`` in one launch (``eyoc_gather_rows``); with ``G`` ``[len(sel), C]`` the gathered rows are blended
+    and re-normalised, ``(F[sel] + beta * G) / |.|`` - the descriptor mode of the synthetic benchmark."""
+    F = _cuda_f32(F)
+    sel = sel.to(F.device, torch.int64).contiguous()
+    c = F.shape[1]
+    out = torch.empty((sel.shape[0], c), dtype=torch.float32, device=F.device)
+    if G is not None:
+        G = _cuda_f32(G, F.device)
+        if tuple(G.shape) != (sel.shape[0], c):
+            raise ValueError("G must be [len(sel), C]")
+    with torch.cuda.device(F.device):
+        _lib.check(_lib.load().eyoc_gather_rows(_lib.ctx(F.device.index), _lib.ptr(F), F.stride(0), c, _lib.ptr(sel),
+                                                sel.shape[0], _lib.ptr(G), C.c_float(beta), _lib.ptr(out),
+                                                _lib.stream_ptr()), "eyoc_gather_rows")
+    return out
 
 
 def dotmax_segmented(A, B, seg_a, seg_b):
@@ -70,15 +93,13 @@ def dotmax_segmented(A, B, seg_a, seg_b):
     A, B = _cuda_f32(A), _cuda_f32(B, A.device if A.is_cuda else None)
     if A.shape[1] != B.shape[1]:
         raise ValueError("feature dimensions differ")
-    nseg = len(seg_a) - 1
-    sa = (C.c_int32 * (nseg + 1))(*[int(v) for v in seg_a])
-    sb = (C.c_int32 * (nseg + 1))(*[int(v) for v in seg_b])
     idx = torch.zeros(A.shape[0], dtype=torch.int64, device=A.device)
     w = torch.full((A.shape[0],), float("nan"), dtype=torch.float32, device=A.device)
     if A.shape[0]:
         with torch.cuda.device(A.device):
-            _lib.check(_lib.load().eyoc_dotmax(_lib.ctx(A.device.index), _lib.ptr(A), _lib.ptr(B), A.shape[1], sa, sb, nseg,
-                                               _lib.ptr(idx), _lib.ptr(w), _lib.stream_ptr()), "eyoc_dotmax")
+            for a0, sa, sb, ns in _segment_chunks(seg_a, seg_b):
+                _lib.check(_lib.load().eyoc_dotmax(_lib.ctx(A.device.index), _lib.ptr(A[a0:]), _lib.ptr(B), A.shape[1], sa, sb,
+                                                   ns, _lib.ptr(idx[a0:]), _lib.ptr(w[a0:]), _lib.stream_ptr()), "eyoc_dotmax")
     return w, idx
 
 

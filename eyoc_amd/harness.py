@@ -16,10 +16,10 @@ import numpy as np
 import torch
 
 from . import registration as reg
-from .eval import knn1_segmented
+from .eval import gather_rows, knn1_segmented
 from .metrics import registration_errors
 from .sparse_tensor import SparseTensor
-from .synthetic import batch_coords, subsample_indices
+from .synthetic import batch_coords, plant_correspondences, subsample_indices
 
 
 @dataclass
@@ -43,10 +43,18 @@ class RegistrationConfig:
 
 class DeviceBatch:
     """``P`` pairs resident in HBM: batched coordinates/features for the 2P clouds, the voxel centres'
-    points, and the (seeded) sample indices of ``random_sample`` (scripts/test_kitti.py:159-160)."""
+    points, and the (seeded) sample indices of ``random_sample`` (scripts/test_kitti.py:159-160).
 
-    def __init__(self, pairs, seeds, device, n_points=5000):
+    ``descriptor=dict(inlier_ratio=p, beta=8.0, plant_radius=0.2)`` switches on the benchmark's descriptor mode
+    (``synthetic.plant_correspondences``): the sample sets contain ``p * n_points`` ground-truth partners and the
+    per-sample descriptors ``G0 / G1`` are blended into the network's features inside the timed path
+    (``eyoc_gather_rows``), so that the matcher sees a stated inlier ratio instead of the zero signal of
+    random-init weights."""
+
+    def __init__(self, pairs, seeds, device, n_points=5000, descriptor=None):
         self.P = len(pairs)
+        self.descriptor = dict(descriptor) if descriptor else None
+        self.beta = float(self.descriptor.get("beta", 8.0)) if self.descriptor else 0.0
         clouds, feats, self.sizes = [], [], []
         for p in pairs:
             for i in (0, 1):
@@ -58,16 +66,26 @@ class DeviceBatch:
         self.feats = torch.from_numpy(np.concatenate(feats, 0)).to(device)
         self.T_gt = [np.asarray(p["T_gt"], np.float32) for p in pairs]
         sel0, sel1, xyz0, xyz1, self.counts = [], [], [], [], []
+        G0, G1, self.planted = [], [], []
         for j, (p, seed) in enumerate(zip(pairs, seeds)):
+            planted = None
+            if self.descriptor:
+                planted = plant_correspondences(p, seed, n_points, self.descriptor.get("inlier_ratio", 0.3),
+                                                self.descriptor.get("plant_radius", 0.2), self.descriptor.get("feat_dim", 32))
+                G0.append(planted["G0"]); G1.append(planted["G1"]); self.planted.append(planted["planted"])
             for i, (sel, xyz) in enumerate(((sel0, xyz0), (sel1, xyz1))):
                 n = self.sizes[2 * j + i]
-                if n >= n_points:
+                if planted is not None:
+                    idx = planted[f"sel{i}"]
+                elif n >= n_points:
                     idx = subsample_indices(seed * 2 + i, n, n_points)
                 else:                        # random_sample with replacement when the cloud is small
                     idx = np.random.default_rng(seed * 2 + i + 10**6).choice(n, n_points)
                 sel.append(idx + self.offsets[2 * j + i])
                 xyz.append(p[f"xyz{i}"][idx])
             self.counts.append(n_points)
+        self.G0 = torch.from_numpy(np.concatenate(G0)).to(device) if G0 else None
+        self.G1 = torch.from_numpy(np.concatenate(G1)).to(device) if G1 else None
         self.sel0 = torch.from_numpy(np.concatenate(sel0)).to(device)
         self.sel1 = torch.from_numpy(np.concatenate(sel1)).to(device)
         self.xyz0 = torch.from_numpy(np.stack(xyz0)).to(device)      # [P, n_points, 3]
@@ -96,11 +114,13 @@ class RegistrationPipeline:
     def register(self, batch: DeviceBatch, seed: int = 0, return_device=False):
         """One pass of the hot path over ``P`` pairs -> ``T f32 [P,4,4]`` (host) and per-pair stats."""
         F = self.features(batch).F
-        F0, F1 = F.index_select(0, batch.sel0), F.index_select(0, batch.sel1)
-        nn_idx = knn1_segmented(F0, F1, batch.seg, batch.seg, "SquareL2", return_distance=False)
+        F0 = gather_rows(F, batch.sel0, batch.G0, batch.beta)     # the sampled rows (+ descriptor blend, if any)
+        F1 = gather_rows(F, batch.sel1, batch.G1, batch.beta)
         n = batch.n_points
         out = []
         if self.cfg.use_RANSAC:
+            nn_idx = knn1_segmented(F0, F1, batch.seg, batch.seg, "SquareL2", return_distance=False)
+            self.last_nn_idx = nn_idx
             # all pairs in one batched call (pair p samples with seed + p, exactly like a per-pair loop would)
             res = reg.ransac_batched_from_correspondences(
                 batch.xyz0.reshape(-1, 3), batch.xyz1.reshape(-1, 3), nn_idx, batch.seg, batch.seg,
@@ -130,6 +150,22 @@ class RegistrationPipeline:
         out = m.SC2_PCR_batch(src_k, tgt_m)
         T = torch.stack([t for t, _ in out])
         return T if return_device else [reg.RegistrationResult(t.cpu().numpy().astype(np.float64), 0.0, 0.0) for t in T]
+
+    def correspondence_inlier_ratio(self, batch: DeviceBatch, nn_idx=None, thresh=None):
+        """Diagnostic (outside the timed path): per pair, the fraction of the feature correspondences of the last
+        RANSAC-path ``register`` whose ground-truth residual ``|T_gt x0 - x1|`` is below ``thresh`` (default: the
+        RANSAC distance threshold)."""
+        nn_idx = self.last_nn_idx if nn_idx is None else nn_idx
+        thresh = self.cfg.voxel_size if thresh is None else thresh
+        n = batch.n_points
+        nn = nn_idx.cpu().numpy().reshape(batch.P, n)
+        x0, x1 = batch.xyz0.cpu().numpy(), batch.xyz1.cpu().numpy()
+        out = []
+        for p in range(batch.P):
+            T = batch.T_gt[p].astype(np.float64)
+            r = x0[p].astype(np.float64) @ T[:3, :3].T + T[:3, 3] - x1[p][nn[p]]
+            out.append(float((np.linalg.norm(r, axis=1) < thresh).mean()))
+        return out
 
     def evaluate(self, batch: DeviceBatch, results):
         """RTE / RRE / success per pair (scripts/test_kitti.py:187-211)."""

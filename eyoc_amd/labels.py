@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .eval import _cuda_f32
+from .eval import _cuda_f32, _segment_chunks
 
 
 def knn2_segmented(A, B, seg_a, seg_b):
@@ -20,17 +20,16 @@ def knn2_segmented(A, B, seg_a, seg_b):
     B = _cuda_f32(B, A.device)
     if A.shape[1] != B.shape[1]:
         raise ValueError("feature dimensions differ")
-    nseg = len(seg_a) - 1
-    sa = (C.c_int32 * (nseg + 1))(*[int(v) for v in seg_a])
-    sb = (C.c_int32 * (nseg + 1))(*[int(v) for v in seg_b])
     idx = torch.zeros(A.shape[0], dtype=torch.int64, device=A.device)
     d1 = torch.full((A.shape[0],), float("inf"), dtype=torch.float32, device=A.device)
     d2 = torch.full((A.shape[0],), float("inf"), dtype=torch.float32, device=A.device)
     if A.shape[0] == 0:
         return idx, d1, d2
     with torch.cuda.device(A.device):
-        _lib.check(_lib.load().eyoc_knn2(_lib.ctx(A.device.index), _lib.ptr(A), _lib.ptr(B), A.shape[1], sa, sb, nseg,
-                                         _lib.ptr(idx), _lib.ptr(d1), _lib.ptr(d2), _lib.stream_ptr()), "eyoc_knn2")
+        for a0, sa, sb, ns in _segment_chunks(seg_a, seg_b):      # at most 128 segments per launch
+            _lib.check(_lib.load().eyoc_knn2(_lib.ctx(A.device.index), _lib.ptr(A[a0:]), _lib.ptr(B), A.shape[1], sa, sb, ns,
+                                             _lib.ptr(idx[a0:]), _lib.ptr(d1[a0:]), _lib.ptr(d2[a0:]), _lib.stream_ptr()),
+                       "eyoc_knn2")
     return idx, d1, d2
 
 

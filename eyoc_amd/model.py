@@ -88,6 +88,7 @@ class ResUNet2(nn.Module):
         self._handle = None      # eyoc_model*
         self._blob = None        # packed weights (device tensor, float32)
         self._packed_device = None
+        self._packed_version = None
         self._timing = False
 
     # ------------------------------------------------------------------ packing
@@ -100,6 +101,16 @@ class ResUNet2(nn.Module):
             d.channels[i], d.tr_channels[i] = self.CHANNELS[i], self.TR_CHANNELS[i]
         d.bn_eps = 1e-5
         return d
+
+    def _weights_version(self):
+        """Changes whenever a parameter / buffer is rebound or modified in place (``copy_``, ``.data`` edits bump
+        ``_version``): the EMA labeler sync of lib/trainer.py:1509-1513 updates weights exactly that way."""
+        v = 0
+        for t in self.parameters():
+            v += t._version + (t.data_ptr() & 0xFFFFFFFF)
+        for t in self.buffers():
+            v += t._version + (t.data_ptr() & 0xFFFFFFFF)
+        return v
 
     def _invalidate(self):
         if self._handle is not None:
@@ -148,6 +159,11 @@ class ResUNet2(nn.Module):
                 items.append(lp)
         return (_lib.LayerParams * len(items))(*items), len(items), keep
 
+    def repack(self):
+        """Fold and upload the current parameters again (explicit form of what ``forward`` does on its own when it
+        sees that a parameter changed in place)."""
+        return self.pack(self._packed_device)
+
     def pack(self, device=None, blob: torch.Tensor | None = None, from_blob=False):
         """(Re)create the device-side model.  ``from_blob=True`` adopts an already packed blob (the
         receiving side of the weight broadcast) instead of packing this module's parameters."""
@@ -173,6 +189,7 @@ class ResUNet2(nn.Module):
                                            blob.numel(), C.byref(h))
         _lib.check(rc, "eyoc_model_create")
         self._handle, self._blob, self._packed_device = h, blob, device
+        self._packed_version = None if from_blob else self._weights_version()
         if self._timing:
             _lib.check(lib.eyoc_model_set_timing(h, 1), "eyoc_model_set_timing")
         return blob
@@ -195,6 +212,8 @@ class ResUNet2(nn.Module):
         dev = x.device
         if self._handle is None or self._packed_device != dev:
             self.pack(dev)
+        elif self._packed_version is not None and self._packed_version != self._weights_version():
+            self.pack(dev)       # parameters changed in place since the blob was packed (adopted blobs are exempt)
         lib = _lib.load()
         cm = x.coordinate_manager
         maps = cm.maps()

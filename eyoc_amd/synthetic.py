@@ -18,7 +18,7 @@ import numpy as np
 
 __all__ = [
     "make_scene", "raycast", "voxelize", "make_pair", "make_weights", "subsample_indices",
-    "batch_coords", "RESUNET_BN2C_LAYOUT",
+    "batch_coords", "RESUNET_BN2C_LAYOUT", "plant_correspondences",
 ]
 
 GROUND_Z = 0.0
@@ -322,6 +322,55 @@ def subsample_indices(seed, n, k=5000):
     if n <= k:
         return np.arange(n)
     return rng.permutation(n)[:k]
+
+
+def plant_correspondences(pair, seed, n_points=5000, inlier_ratio=0.3, plant_radius=0.2, feat_dim=32):
+    """Sample sets and descriptors that give the matcher a STATED inlier ratio (benchmark "descriptor mode").
+
+    The reference samples ``n_points`` voxels of each cloud uniformly (scripts/test_kitti.py:159-160) and a trained
+    FCGF network then matches a fraction of them correctly.  Random-init weights carry no geometric signal, so the
+    synthetic benchmark plants it: ``m = round(inlier_ratio * n_points)`` source voxels whose ground-truth image
+    has a cloud-1 voxel within ``plant_radius`` metres are sampled together with that voxel (each target used
+    once); the remaining ``n_points - m`` rows of both sample sets are uniform draws from the rest of the clouds.
+    Planted partners share one random unit descriptor, every other row gets its own, so after the blend
+    ``normalise(F_net + beta * G)`` the feature nearest neighbour of a planted source is its partner and every
+    other source matches at random.  The residuals of the planted pairs are the real ones of the two voxelised
+    scans (0 .. ``plant_radius``), so RANSAC sees realistic inlier noise.
+
+    Returns ``dict(sel0, sel1 int64 [n_points], G0, G1 f32 [n_points, feat_dim], planted int)``; ``planted`` can be
+    below the request when the overlap is too small.
+    """
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng([int(seed), 77])
+    x0 = pair["xyz0"].astype(np.float64)
+    x1 = pair["xyz1"].astype(np.float64)
+    T = np.asarray(pair["T_gt"], np.float64)
+    d, j = cKDTree(x1).query(x0 @ T[:3, :3].T + T[:3, 3], k=1)
+    cand = np.nonzero(d < plant_radius)[0]
+    cand = cand[rng.permutation(len(cand))]
+    _, first = np.unique(j[cand], return_index=True)          # every target at most once
+    cand = cand[np.sort(first)]
+    n0, n1 = len(x0), len(x1)
+    m = int(min(round(inlier_ratio * n_points), len(cand), n_points))
+    src_pl, tgt_pl = cand[:m], j[cand[:m]]
+
+    def fill(n, taken, count):
+        rest = np.setdiff1d(np.arange(n), taken, assume_unique=False)
+        if len(rest) >= count:
+            return rest[rng.permutation(len(rest))[:count]]
+        return rng.choice(n, count)                           # tiny clouds: with replacement, like random_sample
+    sel0 = np.concatenate([src_pl, fill(n0, src_pl, n_points - m)])
+    sel1 = np.concatenate([tgt_pl, fill(n1, tgt_pl, n_points - m)])
+
+    def unit(k):
+        g = rng.normal(size=(k, feat_dim))
+        return (g / np.linalg.norm(g, axis=1, keepdims=True)).astype(np.float32)
+    shared = unit(m)
+    G0 = np.concatenate([shared, unit(n_points - m)])
+    G1 = np.concatenate([shared, unit(n_points - m)])
+    o0, o1 = rng.permutation(n_points), rng.permutation(n_points)   # planted rows anywhere in the sample sets
+    return {"sel0": sel0[o0].astype(np.int64), "sel1": sel1[o1].astype(np.int64), "G0": G0[o0], "G1": G1[o1],
+            "planted": m}
 
 
 # (name, kernel volume, C_in, C_out) in the order ResUNet2.__init__ creates them

@@ -116,7 +116,8 @@ int eyoc_voxelize(eyoc_ctx* ctx, const float* xyz_dev, int n_points, int stride,
  *             that follows it folded in, plus the residual add / ReLU / concat write around it
  *             (model/residual_block.py:37-53, model/resunet.py:142-186).
  *   out[o, :] = act( sum_k in[nbr[k][o], :] @ W[k] + bias (+ res[o, :]) ),  nbr == NULL: K must be
- *   1 and the map is the identity (1x1 convolution).  cin % 32 == 0, cout in {32,64,128,256}.
+ *   1 and the map is the identity (1x1 convolution).  cin % 32 == 0, cout in {32,64,128,256}; every entry of
+ *   nbr must be < 2^24 (the model forward checks its level sizes; ~550 clouds of 30k voxels in one batch).
  *   Weights must be in the packed layout produced by eyoc_spconv_pack_weights (host side).
  * --------------------------------------------------------------------------------------------- */
 size_t eyoc_spconv_packed_floats(int K, int cin, int cout);
@@ -193,6 +194,14 @@ int eyoc_model_layer_ms(eyoc_model* model, float* ms /*[num_layers]*/);
 int eyoc_knn1(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c, const int32_t* seg_a,
               const int32_t* seg_b, int nseg, int dist_type, int64_t* idx_dev, float* dist_dev,
               void* stream);
+
+/* Row gather: out[i,:] = F[sel[i], 0:c] (F rows are `ld` floats apart) - the `F[inds]` of
+ * scripts/test_kitti.py:30-35,159-160 and of Matcher.match_pair (scripts/SC2_PCR/SC2_PCR.py:291-294).
+ * With G_dev != NULL (f32 [n,c]) the gathered row is blended and re-normalised,
+ * out[i,:] = (F[sel[i],:] + beta * G[i,:]) / |.|_2 : the synthetic benchmark's descriptor mode (random-init
+ * weights carry no geometric signal; G plants it at a stated inlier ratio).  c: power of two in [4,256]. */
+int eyoc_gather_rows(eyoc_ctx* ctx, const float* F_dev, int ld, int c, const int64_t* sel_dev, int n,
+                     const float* G_dev, float beta, float* out_dev, void* stream);
 
 /* Arg-max of the inner product (replaces ``corr = F0.mm(F1.t()); weight, inds = corr.max(dim=1)`` of
  * util/transform_estimation.py:131-133 without materialising the [N0,N1] matrix - 3.6 GB at 30k voxels):

@@ -67,6 +67,22 @@ def est_quad_linear_robust(pts0, pts1, weight=None, iters=20):
     return T
 
 
+def pose_estimation(F0, F1, xyz0, xyz1, inds=None):
+    """util/transform_estimation.py:131-136 given the two feature matrices (the forwards of :127-130 are
+    ``oracle.resunet.resunet_forward``): ``corr = F0 F1^T`` (dense), ``weight, inds = corr.max(1)``,
+    ``est_quad_linear_robust(xyz0, xyz1[inds], weight)``.  ``inds`` overrides the arg-max (tests: compare the
+    solver on identical correspondences when a near-tie flips an index).  Returns ``(T [4,4], weight [n,1], inds)``."""
+    F0, F1 = torch.as_tensor(F0).float(), torch.as_tensor(F1).float()
+    corr = F0.mm(F1.t())
+    weight, arg = corr.max(dim=1)
+    if inds is not None:
+        arg = torch.as_tensor(inds).long()
+        weight = corr[torch.arange(len(F0)), arg]
+    weight = weight.unsqueeze(1)
+    T = est_quad_linear_robust(torch.as_tensor(xyz0).float(), torch.as_tensor(xyz1).float()[arg, :], weight)
+    return T, weight, arg
+
+
 # ----------------------------------------------------------------------------- weighted Kabsch
 def integrate_trans(R, t):
     """scripts/SC2_PCR/utils/SE3.py:75-96 (batched form)."""

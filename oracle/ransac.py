@@ -16,7 +16,8 @@ counter-based sampler so that the HIP kernel can be checked hypothesis by hypoth
      squared lengths, which is the same predicate without square roots);
   4. rigid transform of the 4 pairs (Kabsch / ``Eigen::umeyama`` without scale);
   5. distance checker: reject unless all 4 residuals ``|T s - t| <= max_distance``;
-  6. score on ALL correspondences: inliers = ``|T s - t| < max_distance``; fitness = inliers / n,
+  6. score on ALL correspondences: inliers = ``|T s - t| < max_distance`` (evaluated as
+     ``|T s - t|^2 < max_distance^2`` - the same predicate without a square root per residual); fitness = inliers / n,
      inlier RMSE; keep the hypothesis with higher fitness, then lower RMSE, then lower h;
   7. ``RANSACConvergenceCriteria(4000000, 10000)``: the confidence argument is clamped to 1, which
      disables early termination - all ``max_iteration`` hypotheses are evaluated.
@@ -99,11 +100,11 @@ def ransac(src: np.ndarray, tgt: np.ndarray, corr_tgt: np.ndarray, max_distance:
         survivors += len(cand)
         for c0 in range(0, len(cand), 256):
             Tc = Ts[c0:c0 + 256]
-            d = np.linalg.norm(np.einsum("bij,nj->bni", Tc[:, :3, :3], S_all) + Tc[:, None, :3, 3]
-                               - T_all[None], axis=2)
-            inl = d < max_distance
+            r = np.einsum("bij,nj->bni", Tc[:, :3, :3], S_all) + Tc[:, None, :3, 3] - T_all[None]
+            d2 = (r * r).sum(2)
+            inl = d2 < max_distance * max_distance     # squared form of `dist < max_distance`, as the kernel evaluates it
             cntc = inl.sum(1)
-            err2 = np.where(inl, d * d, 0.0).sum(1)
+            err2 = np.where(inl, d2, 0.0).sum(1)
             with np.errstate(invalid="ignore", divide="ignore"):
                 rmse = np.where(cntc > 0, np.sqrt(err2 / np.maximum(cntc, 1)), np.inf)
             rmse = rmse.astype(np.float32).astype(np.float64)   # the device ranks by the fp32 RMSE

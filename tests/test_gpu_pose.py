@@ -28,6 +28,7 @@ def test_rigid_transform_3d_vs_golden():
         assert T.is_cuda and T.shape == (A.shape[0], 4, 4)
         T = T.cpu().numpy()
         ok = well_conditioned(A, B, w)
+        print(f"kabsch golden case {i} {case}: max |T - T_ref| = {np.abs(T[ok] - g[f'T{i}'][ok]).max():.2e} over {int(ok.sum())} problems")
         np.testing.assert_allclose(T[ok], g[f"T{i}"][ok], rtol=0, atol=5e-4, err_msg=f"case {i} {case}")
         np.testing.assert_allclose(np.linalg.det(T[:, :3, :3]), 1.0, atol=1e-5)
         np.testing.assert_array_equal(T[:, 3], np.tile([0, 0, 0, 1], (len(T), 1)))

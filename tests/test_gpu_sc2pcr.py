@@ -26,6 +26,7 @@ def test_sc2pcr_matches_reference_golden_poses():
         p0, p1, _ = gi.corr_case(seed, n, gi.rigid(*tp), frac, noise=0.03)
         T, fit = m.SC2_PCR(torch.from_numpy(p0)[None].cuda(), torch.from_numpy(p1)[None].cuda())
         assert T.shape == (1, 4, 4) and fit.shape == (1, int(n * cfg["ratio"]))
+        print(f"sc2pcr golden case {i}: max |T - T_ref| = {np.abs(T[0].cpu().numpy() - g[f'T{i}']).max():.2e}")
         np.testing.assert_allclose(T[0].cpu().numpy(), g[f"T{i}"], rtol=0, atol=2e-4, err_msg=f"case {i}")
         assert float(fit.max()) == pytest.approx(float(g[f"fitmax{i}"]), abs=2)
         # seed-wise fitness: same multiset of hypotheses as the oracle up to tie-breaking noise
@@ -41,6 +42,7 @@ def test_sc2pcr_small_inputs_and_estimator():
     m = eyoc_amd.Matcher(**osc.KITTI_CFG)
     Tg, fit = m.SC2_PCR(torch.from_numpy(p0)[None].cuda(), torch.from_numpy(p1)[None].cuda())
     To, _ = osc.Matcher(**osc.KITTI_CFG).SC2_PCR(torch.from_numpy(p0)[None], torch.from_numpy(p1)[None])
+    print(f"sc2pcr n=20 vs oracle: max |T - T_oracle| = {np.abs(Tg[0].cpu().numpy() - To[0].numpy()).max():.2e}")
     np.testing.assert_allclose(Tg[0].cpu().numpy(), To[0].numpy(), atol=5e-4)
     # estimator: descriptors that identify the correspondence exactly
     n = 600

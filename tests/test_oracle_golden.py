@@ -133,7 +133,16 @@ def test_se3_helpers_match_reference(golden_dir):
 
 
 # ----------------------------------------------------------------------------- G6 (hand-computed)
-def test_metrics_hand_cases():
+def _product_metrics():
+    import eyoc_amd.metrics as pm      # numpy only: importable (and checked) without a GPU
+    return pm
+
+
+@pytest.mark.parametrize("which", ["oracle", "product"])
+def test_metrics_hand_cases(which):
+    """scripts/test_kitti.py:187-211 on hand-computed cases - the oracle's twin AND eyoc_amd.metrics (the copy the
+    harness and bench report with)."""
+    op = globals()["op"] if which == "oracle" else _product_metrics()
     T = np.eye(4, dtype=np.float32)
     assert op.registration_errors(T, T) == (0.0, 0.0, True)
     a = np.deg2rad(3.0)
