@@ -63,10 +63,9 @@ __global__ void k_gather_targets(const float* __restrict__ src, const float* __r
   r[3] = tgt[3 * j]; r[4] = tgt[3 * j + 1]; r[5] = tgt[3 * j + 2];
 }
 
-// transform of hypothesis h, or false if a checker rejects it.  `rec` may point to LDS or global memory.
-__device__ inline bool hypothesis(const float* __restrict__ rec, unsigned int n, unsigned long long base, unsigned int h,
-                                  double edge_sim, double max_dist, double R[3][3], double t[3]) {
-  double s[4][3], q[4][3];
+// the four sampled correspondences of hypothesis h and the edge-length checker on them
+__device__ inline bool sample_and_check_edges(const float* __restrict__ rec, unsigned int n, unsigned long long base,
+                                              unsigned int h, double edge_sim, double s[4][3], double q[4][3]) {
   unsigned int idx[4];
   sample_pair(base, 2ull * h, n, idx[0], idx[1]);
   sample_pair(base, 2ull * h + 1, n, idx[2], idx[3]);
@@ -89,6 +88,12 @@ __device__ inline bool hypothesis(const float* __restrict__ rec, unsigned int n,
                          (q[a][2] - q[b][2]) * (q[a][2] - q[b][2]);
       if (ds2 < dt2 * e2 || dt2 < ds2 * e2) return false;
     }
+  return true;
+}
+
+// 4-point Kabsch and the distance checker
+__device__ inline bool fit_and_check_distance(const double s[4][3], const double q[4][3], double max_dist, double R[3][3],
+                                              double t[3]) {
   double cs[3], cq[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
@@ -118,6 +123,14 @@ __device__ inline bool hypothesis(const float* __restrict__ rec, unsigned int n,
   return true;
 }
 
+// transform of hypothesis h, or false if a checker rejects it.  `rec` may point to LDS or global memory.
+__device__ inline bool hypothesis(const float* __restrict__ rec, unsigned int n, unsigned long long base, unsigned int h,
+                                  double edge_sim, double max_dist, double R[3][3], double t[3]) {
+  double s[4][3], q[4][3];
+  if (!sample_and_check_edges(rec, n, base, h, edge_sim, s, q)) return false;
+  return fit_and_check_distance(s, q, max_dist, R, t);
+}
+
 constexpr int CNT_STRIDE = 64;
 constexpr int GEN_THREADS = 1024;
 constexpr int GEN_BLOCKS_MIN = 64, GEN_BLOCKS_TOTAL = 512;   // workgroups per pair: enough to fill the chip even for one pair
@@ -129,9 +142,14 @@ __device__ inline unsigned long long pair_base(unsigned int seed, int b) {
 
 // One workgroup stages its pair's records in LDS (sampling is 8 random reads per hypothesis: L2 round trips
 // dominated the first version of this kernel) and walks a strided slice of the hypotheses.
+// The edge-length checker rejects ~99 % of the hypotheses even at a 30 % inlier ratio, but in lock step a wave pays
+// for the 4-point Kabsch (a Jacobi eigen-solver) whenever ONE of its 64 lanes gets through - about half of all waves
+// at that ratio (k_generate 0.2 -> 1.0 ms per 8 pairs).  So the wave queues the hypotheses that pass the edge check
+// in LDS and only fits them 64 at a time, all lanes busy.
 template <bool IN_LDS>
 __global__ __launch_bounds__(GEN_THREADS) void k_generate(PairArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lrec[];
+  __shared__ int queue[GEN_THREADS / 64][128];
   const int c = blockIdx.y, b = a.pair0 + c;
   const int s0 = a.s0[c], n = a.n[c];
   const float* rec = a.rec + (size_t)s0 * 6;
@@ -144,21 +162,44 @@ __global__ __launch_bounds__(GEN_THREADS) void k_generate(PairArgs a) {
   const unsigned long long base = pair_base(a.seed, b);
   int* cnt = a.n_surv + c * CNT_STRIDE;
   int* surv = a.surv + (size_t)c * a.H;
-  for (int h = blockIdx.x * GEN_THREADS + threadIdx.x; h < a.H; h += gridDim.x * GEN_THREADS) {
-    double R[3][3], t[3];
-    if (hypothesis(rec, (unsigned)n, base, (unsigned)h, (double)a.edge_sim, (double)a.max_dist, R, t)) {
-      const int slot = atomicAdd(cnt, 1);
-      surv[slot] = h;
-      if (slot < a.cap_t) {
-        double* x = a.xf + ((size_t)c * a.cap_t + slot) * 12;
+  const int lane = threadIdx.x & 63;
+  int* wq = queue[threadIdx.x >> 6];
+  int queued = 0;   // wave-uniform
+  const double edge_sim = (double)a.edge_sim, max_dist = (double)a.max_dist;
+  auto fit = [&](int h) {   // h < 0: idle lane
+    double s[4][3], q[4][3], R[3][3], t[3];
+    if (h < 0) return;
+    sample_and_check_edges(rec, (unsigned)n, base, (unsigned)h, edge_sim, s, q);   // re-draws the sample (cheaper than queueing 24 doubles)
+    if (!fit_and_check_distance(s, q, max_dist, R, t)) return;
+    const int slot = atomicAdd(cnt, 1);
+    surv[slot] = h;
+    if (slot < a.cap_t) {
+      double* x = a.xf + ((size_t)c * a.cap_t + slot) * 12;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          x[3 * i] = R[i][0]; x[3 * i + 1] = R[i][1]; x[3 * i + 2] = R[i][2];
-          x[9 + i] = t[i];
-        }
+      for (int i = 0; i < 3; ++i) {
+        x[3 * i] = R[i][0]; x[3 * i + 1] = R[i][1]; x[3 * i + 2] = R[i][2];
+        x[9 + i] = t[i];
       }
     }
+  };
+  const int stride = gridDim.x * GEN_THREADS;
+  const int rounds = (a.H + stride - 1) / stride;
+  for (int r = 0; r < rounds; ++r) {
+    const int h = r * stride + blockIdx.x * GEN_THREADS + threadIdx.x;
+    bool pass = false;
+    if (h < a.H) {
+      double s[4][3], q[4][3];
+      pass = sample_and_check_edges(rec, (unsigned)n, base, (unsigned)h, edge_sim, s, q);
+    }
+    const unsigned long long m = __ballot(pass);
+    if (pass) wq[queued + __popcll(m & ((1ull << lane) - 1ull))] = h;
+    queued += __popcll(m);
+    if (queued >= 64) {   // wave-uniform
+      queued -= 64;
+      fit(wq[queued + lane]);
+    }
   }
+  fit(lane < queued ? wq[lane] : -1);
 }
 
 // squared form of Open3D's `dist < max_correspondence_distance` (no fp64 square root per residual)
@@ -182,8 +223,8 @@ __global__ __launch_bounds__(256) void k_count(PairArgs a, const double* __restr
   const double thr2 = thr2_of(a.max_dist);
   const double* __restrict__ xf = xf_all + (size_t)c * a.cap_t * 12;
   int* cnts = a.cnts + (size_t)c * a.H;
-  int G = 64;   // few survivors: smaller groups, so that a pair still spreads over >= 256 waves
-  while (G > 8 && (ns + G - 1) / G < 256) G >>= 1;
+  int G = 64;   // fewer survivors: smaller groups, so that a pair still gives every wave of its grid slice a group
+  while (G > 8 && (ns + G - 1) / G < (int)gridDim.x * 4) G >>= 1;
   const int n_groups = (ns + G - 1) / G;
   int best = 0;
   for (int grp = blockIdx.x * 4 + wave; grp < n_groups; grp += gridDim.x * 4) {
@@ -285,19 +326,24 @@ __global__ __launch_bounds__(256) void k_rmse(PairArgs a) {
   const int* cnts = a.cnts + (size_t)c * a.H;
   unsigned int* rmse = a.rmse + (size_t)c * a.H;
   const double thr2 = thr2_of(a.max_dist);
-  for (int sidx = blockIdx.x * 4 + (threadIdx.x >> 6); sidx < ns; sidx += gridDim.x * 4) {
-    if (cnts[sidx] != best) continue;   // wave-uniform
-    double R[3][3], t[3], err2;
-    int cnt;
-    if (sidx < a.cap_t) {               // the stored transform, so that this sweep sees what k_count saw
-      const double* x = a.xf + ((size_t)c * a.cap_t + sidx) * 12;
+  // every wave scans 64 counts at a time (coalesced) and sweeps only the survivors at the largest count
+  for (int s64 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; s64 < ns; s64 += gridDim.x * 4 * 64) {
+    unsigned long long cand = __ballot(s64 + lane < ns && cnts[s64 + lane] == best);
+    while (cand) {   // wave-uniform
+      const int sidx = s64 + __builtin_ctzll(cand);
+      cand &= cand - 1;
+      double R[3][3], t[3], err2;
+      int cnt;
+      if (sidx < a.cap_t) {               // the stored transform, so that this sweep sees what k_count saw
+        const double* x = a.xf + ((size_t)c * a.cap_t + sidx) * 12;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) { R[i][0] = x[3 * i]; R[i][1] = x[3 * i + 1]; R[i][2] = x[3 * i + 2]; t[i] = x[9 + i]; }
-    } else {
-      hypothesis(rec, (unsigned)n, base, (unsigned)surv[sidx], (double)a.edge_sim, (double)a.max_dist, R, t);
+        for (int i = 0; i < 3; ++i) { R[i][0] = x[3 * i]; R[i][1] = x[3 * i + 1]; R[i][2] = x[3 * i + 2]; t[i] = x[9 + i]; }
+      } else {
+        hypothesis(rec, (unsigned)n, base, (unsigned)surv[sidx], (double)a.edge_sim, (double)a.max_dist, R, t);
+      }
+      sweep(rec, n, R, t, thr2, lane, cnt, err2);
+      if (lane == 0) rmse[sidx] = __float_as_uint(cnt > 0 ? (float)sqrt(err2 / cnt) : __builtin_inff());
     }
-    sweep(rec, n, R, t, thr2, lane, cnt, err2);
-    if (lane == 0) rmse[sidx] = __float_as_uint(cnt > 0 ? (float)sqrt(err2 / cnt) : __builtin_inff());
   }
 }
 

@@ -22,7 +22,8 @@ pipe = RegistrationPipeline(model, RegistrationConfig())
 def ev():
     e = torch.cuda.Event(enable_timing=True); e.record(); return e
 
-for ratio in (None, 0.05, 0.15, 0.3, 0.6):
+RATIOS = [None if r == "none" else float(r) for r in os.environ.get("RATIOS", "none,0.05,0.15,0.3,0.6").split(",")]
+for ratio in RATIOS:
     batch = DeviceBatch(pairs, seeds, dev, 5000, descriptor=None if ratio is None else dict(inlier_ratio=ratio))
     for _ in range(2): res = pipe.register(batch)
     torch.cuda.synchronize()
@@ -42,6 +43,8 @@ for ratio in (None, 0.05, 0.15, 0.3, 0.6):
           f"survivors/pair {np.mean([x.survivors for x in res]):.0f} inliers {np.mean([x.inliers for x in res]):.0f} "
           f"success {np.mean([e['success'] for e in evals]):.3f} rte {np.median([e['rte'] for e in evals]):.3f} rre {np.median([e['rre_deg'] for e in evals]):.3f}", flush=True)
 
+if os.environ.get("NO_MORTON"):
+    sys.exit(0)
 # (b) Morton order of the input rows
 def morton_perm(coords):
     c = coords.astype(np.int64)
