@@ -1,23 +1,38 @@
 #!/usr/bin/env python
 """Benchmark of the registration hot path on synthetic KITTI-shaped pairs.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the hot path over a batch of ``--pairs`` (default 32) synthetic ~30k-voxel pairs
-already resident in HBM: coordinate maps + rulebooks for the 2P clouds, the batched ResUNetBN2C
-forward, the 5000x5000 feature nearest-neighbour search of every pair and 4-point RANSAC with the
-reference's 4,000,000 hypotheses per pair, and the device->host copy of the P poses.
-Pairs are independent, so ranks take disjoint pairs (weak scaling: per-GPU work is fixed); the only
-collective is the one-off broadcast of the packed weights.
+N > 1 runs one rank per GPU: under ``torch.distributed.run`` the ranks come from the launcher's environment, and a
+plain ``python bench.py --gpus N`` spawns them itself (RCCL group over 127.0.0.1).  Pairs are independent, so ranks
+take disjoint pairs (weak scaling: per-GPU work is fixed); the only collectives are the one-off broadcast of the
+packed weights and the final gather of the per-pair result records onto every rank.
+
+One step = one pass of the hot path over a batch of ``--pairs`` synthetic ~30k-voxel pairs already resident in HBM:
+coordinate maps + rulebooks for the 2P clouds, the batched ResUNetBN2C forward, the row gather of the 5000-point
+samples, the 5000x5000 feature nearest-neighbour search of every pair, 4-point RANSAC with the reference's 4,000,000
+hypotheses per pair, and the device->host copy of the P poses.
+
+Descriptor mode (default ``--inlier-ratio 0.3``).  There is no checkpoint offline and random-init features carry no
+geometric signal, so a run on them "registers" nothing and RANSAC is timed with no hypothesis surviving its
+checkers.  The bench therefore plants signal at a STATED inlier ratio (``eyoc_amd.synthetic.plant_correspondences``):
+the sample sets contain that fraction of ground-truth partners, whose shared descriptors are blended into the
+network's output rows inside the timed path.  Nothing is skipped: the full forward runs, and RANSAC scores every
+surviving hypothesis (~p^4 * 4M per pair) on all 5000 correspondences like Open3D does.  ``--inlier-ratio 0``
+switches the planting off (the round-1 workload).
+
+``--total-pairs T`` switches to a fixed split (configs[3] of BASELINE.json: the 545 LoKITTI_50 pairs): pair i goes
+to rank i % N, every rank walks its pairs in batches of ``--pairs`` (ragged last batch), ``--steps`` counts passes
+over the split, scaling is "strong".  Scenes repeat with period ``--pool`` (generating 545 distinct scenes would
+take minutes of host time; the device work does not depend on which scene it is).
 
 The JSON line carries, besides the driver's contract fields,
-  roofline      the sparse-convolution kernels (spconv_kernel<...>, 22 launches per forward) summed:
-                algorithmic gather bytes (SURVEY.md 8d formula, from the realised rulebook sizes)
-                over their hipEvent-measured durations inside the timed steps, against 8 TB/s HBM;
-                `mfma` gives the same kernels' fp32 FLOP/s against the 157.3 TFLOP/s matrix peak;
-  cpu_baseline  the CPU oracle (a port of the reference algorithms; the reference's own sparse conv
-                and RANSAC live in MinkowskiEngine / Open3D, which cannot run here) timed on the
-                host cores on a bounded sample.
+  roofline      the sparse-convolution kernels (22 launches per forward) summed: algorithmic FLOP (SURVEY.md 8d,
+                from the realised rulebooks) over their hipEvent durations inside the timed steps;
+  hbm_gather    the same launches as algorithmic gather bytes / time against 8 TB/s, with the compulsory bytes
+                and, when profiles/ holds a PMC pass of this workload, traffic / compulsory;
+  cpu_baseline  the CPU oracle (a port of the reference algorithms; the reference's own sparse conv and RANSAC
+                live in MinkowskiEngine / Open3D, which cannot run here): median over 5 pairs after a warm-up.
 """
 import argparse
 import json
@@ -35,20 +50,31 @@ import eyoc_amd  # noqa: E402
 from eyoc_amd import dist as edist  # noqa: E402
 from eyoc_amd import synthetic as syn  # noqa: E402
 from eyoc_amd.harness import DeviceBatch, RegistrationConfig, RegistrationPipeline  # noqa: E402
+from eyoc_amd.metrics import registration_errors  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_16x16x4_f32 dense peak
+REC = 20                   # floats per result record: 16 pose + RTE + RRE + success + rank
 
 
-def build_model(device, rank):
-    sd = syn.make_weights()
-    Model = eyoc_amd.load_model("ResUNetBN2C")
-    model = Model(1, 32, bn_momentum=0.05, conv1_kernel_size=5, normalize_feature=True)
-    if rank == 0:
-        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
-    model = model.to(device).eval()
-    edist.broadcast_model(model, device, src=0)
-    return model, sd
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=64, help="pairs per step per GPU (128 clouds of ~31k voxels in one batched forward)")
+    ap.add_argument("--ransac-iters", type=int, default=4000000)
+    ap.add_argument("--inlier-ratio", type=float, default=0.3, help="planted inlier ratio of the descriptor mode (0 = off)")
+    ap.add_argument("--total-pairs", type=int, default=0, help="fixed split of this many pairs over all ranks (strong scaling)")
+    ap.add_argument("--pool", type=int, default=0, help="distinct scenes per rank in --total-pairs mode (default: --pairs)")
+    ap.add_argument("--nuscenes", action="store_true", help="nuScenes-shaped pairs: 32 beams, d in [5,50] m (configs[4])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", "--no-latency-probe", dest="no_extras", action="store_true",
+                    help="only the timed steps (profiling passes: keeps the kernel statistics to the timed region)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="(tests) no GPU work: a stub step exercises launch / sharding / timing / gather on CPU over gloo")
+    ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
+    return ap.parse_args(argv)
 
 
 def usable_cores():
@@ -64,176 +90,338 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(pair, sd, sample_hyp=200000, full_hyp=4000000):
-    """Oracle timed on the host: 2 forwards + 5000x5000 NN + a slice of the RANSAC hypotheses."""
+def _make_pair(job):
+    seed, nuscenes = job
+    if nuscenes:   # 32-beam sensor, wider baseline (BASELINE.json configs[4]); the voxel band follows the sparser sweep
+        return syn.make_pair(seed, dist_range=(5.0, 50.0), beams=32, band=None)
+    return syn.make_pair(seed)
+
+
+def make_pairs(seeds, nuscenes=False, workers=None):
+    """Synthetic pairs, generated in parallel (numpy ray casting, ~1.3 s each).  Must run BEFORE this process touches
+    the GPU: the workers are forked."""
+    import multiprocessing as mp
+    workers = workers or max(1, min(8, usable_cores(), len(seeds)))
+    jobs = [(s, nuscenes) for s in seeds]
+    if workers == 1:
+        return [_make_pair(j) for j in jobs]
+    with mp.get_context("fork").Pool(workers) as pool:
+        return pool.map(_make_pair, jobs)
+
+
+def build_model(device, rank):
+    sd = syn.make_weights()
+    Model = eyoc_amd.load_model("ResUNetBN2C")
+    model = Model(1, 32, bn_momentum=0.05, conv1_kernel_size=5, normalize_feature=True)
+    if rank == 0:
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model = model.to(device).eval()
+    edist.broadcast_model(model, device, src=0)
+    return model, sd
+
+
+def cpu_baseline(pairs, seeds, sd, descriptor, sample_hyp=200000, full_hyp=4000000, n_pairs=5):
+    """The oracle timed on the host, per pair: 2 forwards + descriptor blend + 5000x5000 NN + a slice of the RANSAC
+    hypotheses (time scaled to the full count).  One warm-up pair, then the median of ``n_pairs`` pairs."""
     from oracle import matching as om
     from oracle import ransac as orn
     from oracle import resunet as orr
     torch.set_num_threads(usable_cores())
-    t0 = time.perf_counter()
-    F = []
-    for i in (0, 1):
-        F.append(orr.resunet_forward(sd, syn.batch_coords([pair[f"coords{i}"]]), pair[f"feats{i}"]).numpy())
-    t_feat = time.perf_counter() - t0
-    i0 = syn.subsample_indices(0, len(F[0]))
-    i1 = syn.subsample_indices(1, len(F[1]))
-    t0 = time.perf_counter()
-    nn = om.find_nn(F[0][i0], F[1][i1])
-    t_nn = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    orn.ransac(pair["xyz0"][i0], pair["xyz1"][i1], nn, 0.3, sample_hyp, seed=0)
-    t_ransac = (time.perf_counter() - t0) * (full_hyp / sample_hyp)
-    total = t_feat + t_nn + t_ransac
-    return {"value": 1.0 / total, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": (f"1 pair: 2 oracle forwards ({t_feat:.2f} s) + 5000x5000 NN ({t_nn:.2f} s) + "
-                       f"{sample_hyp} of {full_hyp} RANSAC hypotheses (time x{full_hyp // sample_hyp} = {t_ransac:.1f} s)")}
+    times = []
+    for k in range(min(n_pairs + 1, len(pairs))):
+        pair, seed = pairs[k], seeds[k]
+        t0 = time.perf_counter()
+        F = [orr.resunet_forward(sd, syn.batch_coords([pair[f"coords{i}"]]), pair[f"feats{i}"]).numpy() for i in (0, 1)]
+        t_feat = time.perf_counter() - t0
+        if descriptor:
+            pl = syn.plant_correspondences(pair, seed, 5000, descriptor["inlier_ratio"])
+            i0, i1 = pl["sel0"], pl["sel1"]
+        else:
+            i0, i1 = syn.subsample_indices(seed * 2, len(F[0])), syn.subsample_indices(seed * 2 + 1, len(F[1]))
+        t0 = time.perf_counter()
+        F0, F1 = F[0][i0], F[1][i1]
+        if descriptor:
+            F0 = F0 + np.float32(8.0) * pl["G0"]; F0 /= np.linalg.norm(F0, axis=1, keepdims=True)
+            F1 = F1 + np.float32(8.0) * pl["G1"]; F1 /= np.linalg.norm(F1, axis=1, keepdims=True)
+        nn = om.find_nn(F0, F1)
+        t_nn = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        orn.ransac(pair["xyz0"][i0], pair["xyz1"][i1], nn, 0.3, sample_hyp, seed=0)
+        t_ransac = (time.perf_counter() - t0) * (full_hyp / sample_hyp)
+        times.append((t_feat + t_nn + t_ransac, t_feat, t_nn, t_ransac))
+    timed = times[1:] if len(times) > 1 else times
+    med = sorted(timed)[len(timed) // 2]
+    return {"value": 1.0 / med[0], "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": (f"median of {len(timed)} pairs after 1 warm-up pair; per pair: 2 oracle forwards ({med[1]:.2f} s) + "
+                       f"5000x5000 NN ({med[2]:.2f} s) + {sample_hyp} of {full_hyp} RANSAC hypotheses "
+                       f"(time x{full_hyp // sample_hyp} = {med[3]:.1f} s)")}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=64, help="pairs per step per GPU (128 clouds of ~31k voxels in one batched forward)")
-    ap.add_argument("--ransac-iters", type=int, default=4000000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-latency-probe", action="store_true",
-                    help="skip the single-pair latency runs (profiling passes: keeps the kernel statistics to the timed steps)")
-    ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
-    args = ap.parse_args()
+class StubPipeline:
+    """--dry-run: stands in for the GPU step so that the launch / shard / barrier / timing / gather logic of this file
+    can run on CPU over gloo (tests/test_bench_dist.py).  A 'registration' returns the ground truth."""
 
+    class _R:
+        def __init__(self, T):
+            self.transformation, self.inliers, self.survivors = T.astype(np.float64), 0, 0
+
+    def register(self, batch, seed=0):
+        return [self._R(T) for T in batch.T_gt]
+
+
+class StubBatch:
+    def __init__(self, pairs, seeds, *a, **k):
+        self.P, self.T_gt, self.voxels = len(pairs), [np.asarray(p["T_gt"], np.float32) for p in pairs], 0
+
+
+def records_of(results, batch, rank, cfg):
+    rec = np.zeros((len(results), REC), np.float32)
+    for p, r in enumerate(results):
+        rte, rre, ok = registration_errors(r.transformation.astype(np.float32), batch.T_gt[p], cfg.rte_thresh, cfg.rre_thresh)
+        rec[p, :16] = r.transformation.astype(np.float32).reshape(16)
+        rec[p, 16:] = (rte, np.rad2deg(rre), float(ok), float(rank))
+    return rec
+
+
+def timed_rate(pipe, batch, reps, warm=1):
+    for _ in range(warm):
+        pipe.register(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pipe.register(batch)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def worker(args):
     t_start = time.perf_counter()
 
     def log(msg):
         if args.verbose:
-            print(f"[bench +{time.perf_counter() - t_start:7.2f}s] {msg}", file=sys.stderr, flush=True)
+            print(f"[bench r{os.environ.get('RANK', '0')} +{time.perf_counter() - t_start:7.2f}s] {msg}", file=sys.stderr, flush=True)
 
-    rank, local_rank, world = edist.init()
+    rank, local_rank, world = edist.env_rank()
     assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+    dry = args.dry_run
+    descriptor = dict(inlier_ratio=args.inlier_ratio) if args.inlier_ratio > 0 else None
 
-    model, sd = build_model(device, rank)
-    log("model packed")
-    cfg = RegistrationConfig(ransac_max_iteration=args.ransac_iters)
-    pipe = RegistrationPipeline(model, cfg)
+    # ---- which pairs are mine (SURVEY 8e: pair i -> rank i % world)
+    total_mode = args.total_pairs > 0
+    if total_mode:
+        mine = edist.shard(args.total_pairs, rank, world)
+        pool = args.pool or args.pairs
+        scene_of = lambda i: rank + world * ((i // world) % pool)          # scenes repeat with period `pool` per rank
+    else:
+        mine = [rank + world * j for j in range(args.pairs)]
+        scene_of = lambda i: i
+    scenes = sorted({scene_of(i) for i in mine})
+    if dry:
+        gen = {}
+        for s_ in scenes:              # stub scenes: the "pose" of scene s is a translation of s metres along x
+            T = np.eye(4, dtype=np.float32)
+            T[0, 3] = s_
+            gen[s_] = {"T_gt": T}
+    else:
+        made = make_pairs(scenes, args.nuscenes)      # before any GPU call: forks
+        gen = dict(zip(scenes, made))
+    log(f"{len(scenes)} scenes generated for {len(mine)} pairs")
 
-    # synthetic inputs: rank r owns pairs r, r + world, ... (round-robin over a virtual split)
-    seeds = [rank + world * j for j in range(args.pairs)]
-    pairs = [syn.make_pair(s) for s in seeds]
-    batch = DeviceBatch(pairs, seeds, device, cfg.n_points)
-    torch.cuda.synchronize()
-    log(f"inputs resident: {batch.voxels} voxels in {2 * args.pairs} clouds")
+    edist.init(backend="gloo" if dry else None)
+    if dry:
+        device = torch.device("cpu")
+        cfg = RegistrationConfig(ransac_max_iteration=args.ransac_iters)
+        pipe, Batch, model, sd = StubPipeline(), StubBatch, None, None
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(device)
+        model, sd = build_model(device, rank)
+        log("model packed")
+        cfg = RegistrationConfig(ransac_max_iteration=args.ransac_iters)
+        pipe, Batch = RegistrationPipeline(model, cfg), DeviceBatch
+
+    batches = []
+    for b0 in range(0, len(mine), args.pairs):
+        ids = mine[b0:b0 + args.pairs]
+        batches.append((ids, Batch([gen[scene_of(i)] for i in ids], [scene_of(i) for i in ids], device, cfg.n_points,
+                                   descriptor=descriptor)))
+    if not dry:
+        torch.cuda.synchronize()
+    log(f"inputs resident: {sum(b.voxels for _, b in batches)} voxels in {len(batches)} batch(es)")
 
     for i in range(args.warmup):
-        pipe.register(batch)
+        pipe.register(batches[i % len(batches)][1])
         log(f"warmup {i} done")
-    model.set_timing(True)
-    n_layers = None
-    layer_ms = None
+    if model is not None:
+        model.set_timing(True)
+        pipe.timing = True
+    layer_ms, stage_ms, n_fwd = None, {"feat": 0.0, "match": 0.0, "reg": 0.0}, 0
+    passes = args.steps
+    steps_timed = passes * len(batches) if total_mode else passes
     edist.barrier()
-    torch.cuda.synchronize()
+    if not dry:
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
-    results = None
-    for _ in range(args.steps):
+    last = {}
+    for s in range(steps_timed):
+        ids, batch = batches[s % len(batches)]
         results = pipe.register(batch)
-        ms = np.array(model.layer_ms())         # events were recorded on the launch stream; read after the step's sync
-        layer_ms = ms if layer_ms is None else layer_ms + ms
-        log(f"step done ({ms.sum():.2f} ms in forward kernels)")
+        last[s % len(batches)] = results
+        if model is not None:
+            ms = np.array(model.layer_ms())         # events were recorded on the launch stream; read after the step's sync
+            layer_ms = ms if layer_ms is None else layer_ms + ms
+            for k, v in pipe.stage_ms().items():
+                stage_ms[k] += v
+            n_fwd += 1
     edist.barrier()
-    torch.cuda.synchronize()
+    if not dry:
+        torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     elapsed = edist.max_over_ranks(elapsed, device)
-    model.set_timing(False)
+    if model is not None:
+        model.set_timing(False)
+        pipe.timing = False
+    log(f"timed region: {elapsed:.3f} s")
 
-    # latency of ONE pair through the same path (configs[1] of BASELINE.json read literally); not part of `value`
-    single_ms = None
-    if not args.no_latency_probe:
-        single = DeviceBatch(pairs[:1], seeds[:1], device, cfg.n_points)
-        for _ in range(3):
-            pipe.register(single)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(10):
-            pipe.register(single)
-        torch.cuda.synchronize()
-        single_ms = (time.perf_counter() - t1) / 10 * 1e3
-    # the SC2-PCR back-end instead of RANSAC (scripts/test_kitti.py:179-181, configs[4] of BASELINE.json) on the same
-    # batch: secondary figure, not part of `value`
-    sc2_rate = None
-    if not args.no_latency_probe:
-        pipe2 = RegistrationPipeline(model, RegistrationConfig(use_RANSAC=False))
-        pipe2.register(batch, return_device=True)
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        for _ in range(3):
-            pipe2.register(batch, return_device=True)
-        torch.cuda.synchronize()
-        sc2_rate = 3 * args.pairs / (time.perf_counter() - t2)
+    # ---- per-pair records of the last pass, gathered so that every rank holds all of them in global pair order
+    rec = np.concatenate([records_of(last[b], batches[b][1], rank, cfg) for b in sorted(last)]) if last else np.zeros((0, REC), np.float32)
+    rec_t = torch.from_numpy(rec).to(device)
+    n_global = args.total_pairs if total_mode else args.pairs * world
+    allrec = (edist.gather_records_ragged(rec_t, n_global) if total_mode else edist.gather_records(rec_t)).cpu().numpy()
+    ranks_seen = sorted({int(r) for r in allrec[:, 19] if not np.isnan(r)})
 
-    # algorithmic work of one forward on this batch geometry
-    x = eyoc_amd.SparseTensor(batch.feats, coordinates=batch.coords)
+    if rank != 0:
+        return
+    pairs_done = (args.total_pairs * passes) if total_mode else args.pairs * passes * world
+    b0 = batches[0][1]
+    out = {
+        "metric": "registered pairs/sec (30k-voxel KITTI pairs)",
+        "value": pairs_done / elapsed, "unit": "pairs/s",
+        "n_gpus": world, "steps": steps_timed, "warmup": args.warmup,
+        "ms_per_step": elapsed / steps_timed * 1e3,
+        "higher_is_better": True, "scaling": "strong" if total_mode else "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "ranks_seen": ranks_seen,
+        "per_rank_pairs_per_s": pairs_done / elapsed / world,
+        "success_rate": float(np.nanmean(allrec[:, 18])),
+        "median_rte_m": float(np.nanmedian(allrec[:, 16])), "median_rre_deg": float(np.nanmedian(allrec[:, 17])),
+        "records_gathered": int(allrec.shape[0]),
+    }
+    shape = "nuScenes-shaped (32 beams, d in [5,50] m)" if args.nuscenes else "30 cm KITTI-shaped"
+    plant = (f"planted inlier ratio {args.inlier_ratio:g}" if descriptor else "no planted signal (random-init features)")
+    if dry:
+        out["config"] = {"workload": "dry run (stub step)", "pairs_per_step": args.pairs}
+        out["pose_tx"] = allrec[:, 3].tolist()          # lets the test check the global pair order of the gather
+        out["record_rank"] = allrec[:, 19].tolist()
+        print(json.dumps(out))
+        return
+    out["config"] = {"workload": f"{args.pairs} synthetic {shape} pairs per step per GPU "
+                                 f"(mean {b0.voxels // (2 * b0.P)} voxels/cloud, ResUNetBN2C random-init, "
+                                 f"5000-point NN, RANSAC {args.ransac_iters} hypotheses/pair, {plant})",
+                     "pairs_per_step": args.pairs, "parallelism": f"pairs sharded over {world} GPU(s)",
+                     "inlier_ratio": args.inlier_ratio if descriptor else None}
+    if total_mode:
+        out["config"]["total_pairs"] = args.total_pairs
+        out["config"]["batches_per_rank"] = [len(ids) for ids, _ in batches]
+    # ---- algorithmic work of one forward on the first batch's geometry
+    x = eyoc_amd.SparseTensor(b0.feats, coordinates=b0.coords)
     work = model.layer_work(x)
-    conv = [i for i, w in enumerate(work) if w["name"] != "conv1"]      # the spconv_kernel launches
+    conv = [i for i, w in enumerate(work) if w["name"] != "conv1"]      # the sparse-conv launches
     gather = sum(work[i]["gather_bytes"] for i in conv)
+    compulsory = sum(work[i]["compulsory_bytes"] for i in conv)
     flops = sum(work[i]["flop"] for i in conv)
-    conv_ms = float(sum(layer_ms[i] for i in conv)) / args.steps
-    fwd_ms = float(layer_ms.sum()) / args.steps
-    rows = x.coordinate_manager.info()["rows"]
-    evals = pipe.evaluate(batch, results)
-
-    if rank == 0 and args.verbose:
+    conv_ms = float(sum(layer_ms[i] for i in conv)) / n_fwd
+    out["config"]["voxels_per_level"] = x.coordinate_manager.info()["rows"]
+    if args.verbose:
         print(f"{'layer':18s} {'ms':>8s} {'GFLOP':>8s} {'TFLOP/s':>8s} {'gatherGB/s':>10s} {'pairs':>10s}", file=sys.stderr)
         for i, w in enumerate(work):
-            ms_i = layer_ms[i] / args.steps
+            ms_i = layer_ms[i] / n_fwd
             print(f"{w['name']:18s} {ms_i:8.3f} {w['flop'] / 1e9:8.2f} {w['flop'] / ms_i / 1e9:8.2f} "
                   f"{w['gather_bytes'] / ms_i / 1e6:10.1f} {w['pairs']:10d}", file=sys.stderr)
-    if rank == 0:
-        total_pairs = args.pairs * args.steps * world
-        achieved = gather / (conv_ms * 1e-3) / 1e9
-        out = {
-            "metric": "registered pairs/sec (30k-voxel KITTI pairs)",
-            "value": total_pairs / elapsed, "unit": "pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.pairs} synthetic 30 cm KITTI-shaped pairs per step per GPU "
-                                   f"(mean {batch.voxels // (2 * args.pairs)} voxels/cloud, ResUNetBN2C random-init, "
-                                   f"5000-point NN, RANSAC {args.ransac_iters} hypotheses/pair)",
-                       "pairs_per_step": args.pairs, "parallelism": f"pairs sharded over {world} GPU(s)",
-                       "voxels_per_level": rows},
-            # the sparse convolutions in fp32: ideal matrix time (flop / 157.3 TF) is ~1.8x their ideal HBM time
-            # (gather bytes / 8 TB/s), so the fp32 MFMA pipe is the binding roof; the HBM view of the same launches
-            # (the "gather GB/s" BASELINE.json asks for) follows in `hbm_gather`
-            "roofline": {"bound": "mfma", "achieved": flops / (conv_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF,
-                         "unit": "TFLOP/s", "frac": flops / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
-                         "kernel": "spconv_wave_kernel / spconv_kernel (the 22 sparse-conv launches of one forward, summed)",
-                         "algorithmic_flop_per_forward": flops, "ms_per_forward": conv_ms},
-            "hbm_gather": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "algorithmic_bytes_per_forward": gather},
-            "forward_ms_per_step": fwd_ms,
-            "single_pair_latency_ms": single_ms,
-            "sc2pcr_path_pairs_per_s": sc2_rate,
-            "success_rate": float(np.mean([e["success"] for e in evals])),
-        }
-        log("timed region done; cpu baseline next")
-        # HBM traffic of the same kernels from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
-        # correction + WRITE_SIZE, separate passes; profiles/README.md) - only quoted for the profiled workload
+    achieved_tf = flops / (conv_ms * 1e-3) / 1e12
+    achieved_gbs = gather / (conv_ms * 1e-3) / 1e9
+    math_mode = getattr(model, "spconv_math", "fp32")
+    # fp32 MFMA: ideal matrix time (flop / 157.3 TF) is ~1.8x the ideal HBM time (gather bytes / 8 TB/s), so the fp32
+    # matrix pipe is the binding roof of these kernels; `hbm_gather` is the HBM view of the same launches
+    out["roofline"] = {"bound": "mfma", "achieved": achieved_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                       "frac": achieved_tf / MFMA_F32_PEAK_TF, "traffic": None,
+                       "kernel": "spconv_wave_kernel<...> (the 22 sparse-conv launches of one forward, summed)",
+                       "algorithmic_flop_per_forward": flops, "ms_per_forward": conv_ms, "math": math_mode}
+    out["hbm_gather"] = {"achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_forward": gather, "compulsory_bytes_per_forward": compulsory,
+                         "traffic_over_compulsory": None}
+    out["forward_ms_per_step"] = float(layer_ms.sum()) / n_fwd
+    out["stage_ms_per_step"] = {k: v / n_fwd for k, v in stage_ms.items()}
+    out["survivors_per_pair"] = float(np.mean([r.survivors for b in last.values() for r in b]))
+    # HBM traffic of the same kernels from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
+    # WRITE_SIZE, separate passes; profiles/README.md) - quoted only when they were taken on this workload
+    for tag in ("r2", "r1"):
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r1_spconv_traffic.json")))
+            prof = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_spconv_traffic.json")))
             if prof["workload"] == out["config"]["workload"]:
-                out["roofline"]["traffic"] = (prof["spconv_read_GB_per_forward_x2corr"] + prof["spconv_write_GB_per_forward"]) * 1e9
-                out["roofline"]["traffic_source"] = "profiles/r1_spconv_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                traffic = (prof["spconv_read_GB_per_forward_x2corr"] + prof["spconv_write_GB_per_forward"]) * 1e9
+                out["roofline"]["traffic"] = traffic
+                out["roofline"]["traffic_source"] = f"profiles/{tag}_spconv_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                out["hbm_gather"]["traffic_over_compulsory"] = traffic / compulsory
+                break
         except (OSError, KeyError, ValueError):
             pass
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pairs[0], sd)
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out))
+
+    extras = world == 1 and not total_mode and not args.no_extras
+    if extras:
+        pairs0 = [gen[scene_of(i)] for i in mine]
+        seeds0 = [scene_of(i) for i in mine]
+        # configs[1] read literally: ONE pair through the same path (latency); configs[2]: batch = 8 pairs
+        single = DeviceBatch(pairs0[:1], seeds0[:1], device, cfg.n_points, descriptor=descriptor)
+        out["single_pair_latency_ms"] = timed_rate(pipe, single, 10, 3) * 1e3
+        if len(pairs0) >= 8:
+            b8 = DeviceBatch(pairs0[:8], seeds0[:8], device, cfg.n_points, descriptor=descriptor)
+            out["batch8_pairs_per_s"] = 8 / timed_rate(pipe, b8, 10, 2)
+        log("latency probes done")
+        # RANSAC cost against the inlier ratio (the number of surviving hypotheses grows like p^4)
+        sweep = []
+        for ratio in (0.0, 0.15, 0.3, 0.6):
+            bs = DeviceBatch(pairs0, seeds0, device, cfg.n_points, descriptor=dict(inlier_ratio=ratio) if ratio > 0 else None)
+            pipe.timing = True
+            for _ in range(2):
+                res = pipe.register(bs)
+            st = pipe.stage_ms()
+            pipe.timing = False
+            dt = timed_rate(pipe, bs, 3, 0)
+            ev = pipe.evaluate(bs, res)
+            sweep.append({"inlier_ratio": ratio, "realised_inlier_ratio": float(np.mean(pipe.correspondence_inlier_ratio(bs))),
+                          "survivors_per_pair": float(np.mean([r.survivors for r in res])), "ransac_ms_per_step": st["reg"],
+                          "pairs_per_s": len(pairs0) / dt, "success_rate": float(np.mean([e["success"] for e in ev]))})
+            del bs
+        out["ransac_sweep"] = sweep
+        log("ransac sweep done")
+        # the SC2-PCR back-end instead of RANSAC (scripts/test_kitti.py:179-181, configs[4]) on the same batch
+        pipe2 = RegistrationPipeline(model, RegistrationConfig(use_RANSAC=False))
+        t_sc2 = timed_rate(pipe2, b0, 3, 1)
+        ev2 = pipe2.evaluate(b0, pipe2.register(b0))
+        out["sc2pcr_path"] = {"pairs_per_s": b0.P / t_sc2, "success_rate": float(np.mean([e["success"] for e in ev2]))}
+        log("sc2pcr path done")
+    if world == 1 and not total_mode and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline([gen[scene_of(i)] for i in mine[:6]], [scene_of(i) for i in mine[:6]], sd, descriptor)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+
+
+def _spawned(rank, world, argv):
+    worker(parse_args(argv))
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: start the ranks ourselves (one per GPU, RCCL over 127.0.0.1)
+        edist.spawn_ranks(_spawned, args.gpus, (list(argv),))
+        return
+    worker(args)
 
 
 if __name__ == "__main__":

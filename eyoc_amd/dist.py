@@ -73,6 +73,44 @@ def gather_records(records: torch.Tensor) -> torch.Tensor:
     return stacked.reshape(-1, records.shape[1])
 
 
+def gather_records_ragged(records: torch.Tensor, n_total: int) -> torch.Tensor:
+    """The same for a split that does not divide evenly (LoKITTI_50: 545 pairs over 8 ranks = 69 / 68 per rank):
+    rank r holds the rows of pairs ``r, r + W, ...`` (``ceil`` or ``floor`` of ``n_total / W`` of them); shorter
+    ranks are padded with NaN rows for the collective and the padding is cut off again -> ``[n_total, R]`` in
+    global pair order on every rank."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return records[:n_total]
+    world = dist.get_world_size()
+    per = (n_total + world - 1) // world
+    pad = per - records.shape[0]
+    if pad < 0:
+        raise ValueError("a rank holds more rows than ceil(n_total / world)")
+    if pad:
+        records = torch.cat([records, torch.full((pad, records.shape[1]), float("nan"), dtype=records.dtype,
+                                                 device=records.device)])
+    return gather_records(records)[:n_total]
+
+
+def spawn_ranks(fn, world: int, args=()):
+    """Launch ``world`` ranks of ``fn(rank, world, *args)`` on this node when no launcher did
+    (``python bench.py --gpus N`` without torchrun): each child gets the RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* environment torchrun would have set, then ``init()`` forms the RCCL (or gloo) group as usual."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_spawn_entry, args=(world, port, fn, args), nprocs=world, join=True)
+
+
+def _spawn_entry(rank, world, port, fn, args):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    fn(rank, world, *args)
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -103,6 +103,24 @@ class RegistrationPipeline:
         self.model = model
         self.cfg = config or RegistrationConfig()
         self.matcher = None if self.cfg.use_RANSAC else reg.Matcher(**self.cfg.sc2pcr)
+        # per-stage timers like the reference's feat / reg timers (scripts/test_kitti.py:109,217-222): with
+        # ``timing = True`` every ``register`` brackets its stages with events on the launch stream and
+        # ``stage_ms()`` returns the durations of the last call (synchronises)
+        self.timing = False
+        self._ev = None
+
+    def _mark(self, i):
+        if self.timing:
+            if self._ev is None:
+                self._ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            self._ev[i].record()
+
+    def stage_ms(self):
+        """``dict(feat=, match=, reg=)`` of the last timed ``register``: maps + forward; row gather + feature NN;
+        RANSAC / SC2-PCR."""
+        e = self._ev
+        e[3].synchronize()
+        return {"feat": e[0].elapsed_time(e[1]), "match": e[1].elapsed_time(e[2]), "reg": e[2].elapsed_time(e[3])}
 
     @torch.no_grad()
     def features(self, batch: DeviceBatch) -> SparseTensor:
@@ -113,7 +131,9 @@ class RegistrationPipeline:
     @torch.no_grad()
     def register(self, batch: DeviceBatch, seed: int = 0, return_device=False):
         """One pass of the hot path over ``P`` pairs -> ``T f32 [P,4,4]`` (host) and per-pair stats."""
+        self._mark(0)
         F = self.features(batch).F
+        self._mark(1)
         F0 = gather_rows(F, batch.sel0, batch.G0, batch.beta)     # the sampled rows (+ descriptor blend, if any)
         F1 = gather_rows(F, batch.sel1, batch.G1, batch.beta)
         n = batch.n_points
@@ -121,10 +141,12 @@ class RegistrationPipeline:
         if self.cfg.use_RANSAC:
             nn_idx = knn1_segmented(F0, F1, batch.seg, batch.seg, "SquareL2", return_distance=False)
             self.last_nn_idx = nn_idx
+            self._mark(2)
             # all pairs in one batched call (pair p samples with seed + p, exactly like a per-pair loop would)
             res = reg.ransac_batched_from_correspondences(
                 batch.xyz0.reshape(-1, 3), batch.xyz1.reshape(-1, 3), nn_idx, batch.seg, batch.seg,
                 self.cfg.voxel_size * 1.0, self.cfg.ransac_max_iteration, seed=seed)   # [P, 84] bytes on the device
+            self._mark(3)
             if return_device:
                 return res
             host = res.cpu()
