@@ -79,6 +79,12 @@ PROTOTYPES = {
     "eyoc_spconv_packed_floats": (_sz, [_i, _i, _i]),
     "eyoc_spconv_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "eyoc_spconv_select_kernel": (_i, [_i]),
+    "eyoc_spconv_pack_weights_split16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "eyoc_spconv_ex": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "eyoc_split16_encode": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "eyoc_split16_decode": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "eyoc_model_set_math": (_i, [_vp, _i]),
+    "eyoc_model_last_math": (_i, [_vp]),
     "eyoc_spconv": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "eyoc_model_blob_floats": (_sz, [C.POINTER(ModelDesc)]),
     "eyoc_model_create": (_i, [_vp, C.POINTER(ModelDesc), C.POINTER(LayerParams), _i, _vp, _sz, C.POINTER(_vp)]),

@@ -2,7 +2,9 @@
 // Mirrors ResUNet2.__init__/forward (model/resunet.py:18-193) and BasicBlockBase.forward
 // (model/residual_block.py:37-53) with every batch norm folded into the convolution before it
 // (eval mode, model/common.py:4-6) and every ReLU / residual add / concat fused into a conv epilogue.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "spconv.h"
 
@@ -22,6 +24,7 @@ struct LayerPlan {
   int in_buf, in_col, out_buf, out_col, res_buf;  // buffer ids (-1 none)
   int relu, l2norm, has_bias;
   size_t w_off = 0, b_off = 0;  // float offsets into the blob
+  size_t w16_off = 0, s_off = 0;  // SPLIT16 copy of the weights (same size) and the layer's out_scale scalar (spconv layers only)
 };
 
 // activation buffers
@@ -40,6 +43,8 @@ struct eyoc_model {
   BufPlan bufs[B_COUNT];
   float* blob = nullptr;
   size_t blob_floats = 0;
+  int math = -1;           // -1 automatic, 0 fp32 MFMA, 1 SPLIT16 (eyoc_model_set_math)
+  int last_math = 0;       // what the last forward used
   int timing = 0;
   std::vector<hipEvent_t> events;
   int events_valid = 0;
@@ -102,9 +107,24 @@ void build_plan(const eyoc_model_desc& d, std::vector<LayerPlan>& L, BufPlan* bu
     p.b_off = off;
     off += pad64((size_t)p.cout);
   }
+  // second half of the blob: the SPLIT16 packing of every sparse-conv layer (spconv_wave.hip, MATH = 1)
+  for (auto& p : L) {
+    if (p.map == M_CONV1) continue;
+    p.w16_off = off;
+    off += pad64((size_t)p.K * p.cin * p.cout);
+    p.s_off = off;
+    off += 64;
+  }
 }
 
-size_t plan_blob_floats(const std::vector<LayerPlan>& L) { return L.empty() ? 0 : L.back().b_off + pad64(L.back().cout); }
+size_t plan_blob_floats(const std::vector<LayerPlan>& L) {
+  size_t end = 0;
+  for (auto& p : L) {
+    end = std::max(end, p.b_off + pad64(p.cout));
+    if (p.map != M_CONV1) end = std::max(end, p.s_off + 64);
+  }
+  return end;
+}
 
 const eyoc_layer_params* find_layer(const eyoc_layer_params* layers, int n, const std::string& name) {
   for (int i = 0; i < n; ++i)
@@ -187,6 +207,8 @@ int eyoc_model_create(eyoc_ctx* ctx, const eyoc_model_desc* desc, const eyoc_lay
         for (size_t i = 0; i < (size_t)p.K * p.cin * p.cout; ++i) w[i] = cv->kernel[i] * scale[i % p.cout];
       } else {
         rc = eyoc_spconv_pack_weights(cv->kernel, scale.data(), p.K, p.cin, p.cout, w);
+        if (!rc) rc = eyoc_spconv_pack_weights_split16(cv->kernel, scale.data(), p.K, p.cin, p.cout, host.data() + p.w16_off,
+                                                       host.data() + p.s_off);
         if (rc) { delete m; return rc; }
       }
       memcpy(host.data() + p.b_off, shift.data(), p.cout * sizeof(float));
@@ -217,6 +239,15 @@ size_t eyoc_model_workspace_bytes(const eyoc_model* m, const eyoc_maps* maps) {
 }
 
 int eyoc_model_num_layers(const eyoc_model* m) { return m ? (int)m->layers.size() : 0; }
+
+int eyoc_model_set_math(eyoc_model* m, int mode) {
+  EYOC_REQUIRE(m && mode >= -1 && mode <= 1, EYOC_ERR_INVALID, "eyoc_model_set_math: mode %d not in {-1, 0, 1}", mode);
+  const int prev = m->math;
+  m->math = mode;
+  return prev + 1 ? prev + 2 : 1;   // previous mode + 2 (so that every valid answer is positive): 1 = auto, 2 = fp32, 3 = split16
+}
+
+int eyoc_model_last_math(const eyoc_model* m) { return m ? m->last_math : -1; }
 
 int eyoc_model_set_timing(eyoc_model* m, int on) {
   EYOC_REQUIRE(m, EYOC_ERR_INVALID, "eyoc_model_set_timing: NULL model");
@@ -250,6 +281,17 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
   buf[B_IN] = const_cast<float*>(feats_dev);
   buf[B_OUT] = out_dev;
   for (int i = B_X1; i < B_OUT; ++i) buf[i] = cv.take<float>((size_t)maps->rows[m->bufs[i].level] * m->bufs[i].width);
+  // arithmetic of the sparse convolutions: SPLIT16 needs the wave-private kernel for EVERY layer (only it reads and
+  // writes the format), which pays off once the finest level alone fills the chip (>= 4096 wave tiles ~ 4 KITTI
+  // pairs); small batches stay on fp32, where the launcher picks the workgroup-tiled kernel per layer
+  static const int env_math = getenv("EYOC_SPCONV_MATH") ? atoi(getenv("EYOC_SPCONV_MATH")) : -1;
+  const int want = m->math >= 0 ? m->math : env_math;
+  const bool split_ok = spconv_forced_kernel() != 0 && !(m->desc.normalize_feature && m->desc.out_channels > 64) &&
+                        m->desc.channels[1] % 8 == 0;
+  const bool split = split_ok && (want == 1 || (want < 0 && cdiv(maps->rows[0], 64) >= 4096));
+  EYOC_REQUIRE(want != 1 || split, EYOC_ERR_INVALID,
+               "eyoc_model_forward: split16 arithmetic is not available for this model / kernel selection");
+  m->last_math = split ? 1 : 0;
   if (m->timing) EYOC_CHECK_HIP(hipEventRecord(m->events[0], st));
   for (size_t li = 0; li < m->layers.size(); ++li) {
     const LayerPlan& p = m->layers[li];
@@ -260,6 +302,7 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
       a.coords = maps->coords[0]; a.n = n_out; a.table = maps->table[0]; a.ks = m->desc.conv1_kernel_size;
       a.in = buf[p.in_buf]; a.cin = p.cin; a.w = m->blob + p.w_off; a.bias = m->blob + p.b_off; a.cout = p.cout;
       a.out = buf[p.out_buf] + p.out_col; a.ld_out = m->bufs[p.out_buf].width;
+      a.out_split = split ? 1 : 0;
       a.parent = maps->parent[0]; a.children = maps->children[0]; a.s1c = maps->nbr_s1[1]; a.nc = maps->rows[1];
       rc = conv1_walks_octree(a) ? EYOC_OK : maps_build_table0(const_cast<eyoc_maps*>(maps), st);
       if (!rc) rc = launch_conv1(a, st);
@@ -274,6 +317,12 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
       a.res = p.res_buf >= 0 ? buf[p.res_buf] : nullptr; a.ld_res = p.res_buf >= 0 ? m->bufs[p.res_buf].width : 0;
       a.relu = p.relu; a.l2norm = p.l2norm;
       a.out = buf[p.out_buf] + p.out_col; a.ld_out = m->bufs[p.out_buf].width;
+      if (split) {
+        a.math = 1;
+        a.w = m->blob + p.w16_off;
+        a.out_scale = m->blob + p.s_off;
+        a.out_split = p.out_buf != B_OUT;
+      }
       a.perm = p.map == M_UP ? maps->perm_up[p.level] : p.map == M_S1 ? maps->perm_s1[p.level]
                : p.map == M_DOWN ? maps->perm_down[p.level] : nullptr;
       rc = launch_spconv(a, st);

@@ -23,6 +23,12 @@ struct SpconvArgs {
   int l2norm;           // divide every output row by its 2-norm (needs cout <= 128); no epsilon
   float* out;           // rows of ld_out floats; the layer writes columns [0, cout)
   int ld_out;
+  // ---- arithmetic / storage format (wave-private kernel only; SPLIT16 is documented in spconv_wave.hip)
+  // math 0: fp32 rows, v_mfma_f32_16x16x4_f32.  math 1: `in` (and `res`) are SPLIT16 rows, `w` is packed by
+  // eyoc_spconv_pack_weights_split16, three v_mfma_f32_16x16x32_f16 per product block (hi*hi + hi*lo + lo*hi).
+  int math = 0;
+  int out_split = 0;               // write SPLIT16 rows (internal activations) instead of fp32 rows
+  const float* out_scale = nullptr;  // device scalar multiplied into the accumulated sums (undoes the weight pre-scale); NULL = 1
   // optional: a permutation of the output rows; tiles take rows in this order (any order gives the same result,
   // a good one makes the rows of a tile share their occupied offsets).  NULL = natural order.
   const int32_t* perm = nullptr;
@@ -31,7 +37,44 @@ struct SpconvArgs {
   int small_rows = 0;
 };
 
+// ---- SPLIT16 row format: every group of 8 channels takes 32 bytes, the 8 fp16 "hi" halves (x rounded to fp16)
+// followed by the 8 fp16 "lo" halves (x - hi rounded to fp16): the same 4 bytes per channel as fp32, 22 significant
+// bits (hi + lo reproduces x to 2^-22 relative, or 2^-25 absolute below 2^-3: fp16 subnormals are honoured by the
+// fp16 MFMA on gfx950, scripts/micro/mfma_f16_denorm.hip).  Channel c of a row lives at byte (c / 8) * 32 + (c % 8) * 2
+// (hi) and + 16 (lo), so leading dimensions and column offsets stay what they are for fp32 rows as long as they
+// are multiples of 8 channels.
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+
+__device__ inline void split16_encode4(const float4 v, uint2& hi, uint2& lo) {
+  half4_t h, l;
+  h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+  l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
+  l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
+  hi = __builtin_bit_cast(uint2, h);
+  lo = __builtin_bit_cast(uint2, l);
+}
+__device__ inline float4 split16_decode4(const uint2 hi, const uint2 lo) {
+  const half4_t h = __builtin_bit_cast(half4_t, hi), l = __builtin_bit_cast(half4_t, lo);
+  return make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
+}
+// byte offset of the hi halves of channels [c, c + 4) (c % 4 == 0) inside a SPLIT16 row; the lo halves sit 16 bytes on
+__host__ __device__ inline int split16_off4(int c) { return (c >> 3) * 32 + (c & 7) * 2; }
+// store / load 4 consecutive channels of a SPLIT16 row that starts at `row` (fp32-typed pointer, 4 bytes per channel)
+__device__ inline void split16_store4(float* row, int c, const float4 v) {
+  uint2 hi, lo;
+  split16_encode4(v, hi, lo);
+  char* p = reinterpret_cast<char*>(row) + split16_off4(c);
+  *reinterpret_cast<uint2*>(p) = hi;
+  *reinterpret_cast<uint2*>(p + 16) = lo;
+}
+__device__ inline float4 split16_load4(const float* row, int c) {
+  const char* p = reinterpret_cast<const char*>(row) + split16_off4(c);
+  return split16_decode4(*reinterpret_cast<const uint2*>(p), *reinterpret_cast<const uint2*>(p + 16));
+}
+
 int launch_spconv(const SpconvArgs& a, hipStream_t st);
+int spconv_forced_kernel();   // eyoc_spconv_select_kernel state: -1 automatic, 0 workgroup-tiled, 1 wave-private
 int launch_spconv_wave(const SpconvArgs& a, hipStream_t st);   // wave-private tiling (spconv_wave.hip)
 
 // first convolution: K = ks^3 offsets probed straight from the level-0 hash table (C_in is tiny)
@@ -47,6 +90,7 @@ struct Conv1Args {
   int cout;               // 32 <= cout <= 128, multiple of 32
   float* out;             // rows of ld_out floats
   int ld_out;
+  int out_split = 0;      // write SPLIT16 rows (see above) instead of fp32 rows
   // octree links (level 0 <-> 1) and the level-1 stride-1 table: with them a 3^3 / 5^3 window is read
   // from the 27 coarse blocks around the parent without any hash probe; NULL -> probe the hash table
   const int32_t* parent;    // [n]

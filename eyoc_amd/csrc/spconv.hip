@@ -20,6 +20,7 @@
 //      once, so no atomics are needed and the summation order (k ascending) is deterministic.
 //   4. epilogue from LDS: + bias (folded BN shift) (+ residual) -> ReLU -> (row L2 normalisation)
 //      -> coalesced float4 row stores at the layer's column offset inside a concat buffer.
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -479,7 +480,8 @@ __global__ __launch_bounds__(256) void conv1_kernel(Conv1Args a) {
       float4 v;
       v.x = acc[i] + a.bias[i]; v.y = acc[i + 1] + a.bias[i + 1];
       v.z = acc[i + 2] + a.bias[i + 2]; v.w = acc[i + 3] + a.bias[i + 3];
-      *reinterpret_cast<float4*>(dst + i) = v;
+      if (a.out_split) split16_store4(dst, i, v);
+      else *reinterpret_cast<float4*>(dst + i) = v;
     }
   }
 }
@@ -535,8 +537,23 @@ __global__ __launch_bounds__(256) void conv1_tree_kernel(Conv1Args a) {
     float4 v;
     v.x = acc[i] + a.bias[i]; v.y = acc[i + 1] + a.bias[i + 1];
     v.z = acc[i + 2] + a.bias[i + 2]; v.w = acc[i + 3] + a.bias[i + 3];
-    *reinterpret_cast<float4*>(dst + i) = v;
+    if (a.out_split) split16_store4(dst, i, v);
+    else *reinterpret_cast<float4*>(dst + i) = v;
   }
+}
+
+// fp32 rows <-> SPLIT16 rows (tests, and callers that feed eyoc_spconv_ex directly)
+__global__ void k_split16_encode(const float* __restrict__ in, int n, int c, int ld_in, float* __restrict__ out, int ld_out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = t / (c / 4), q = t % (c / 4);
+  if (r >= n) return;
+  split16_store4(out + (size_t)r * ld_out, q * 4, *reinterpret_cast<const float4*>(in + (size_t)r * ld_in + q * 4));
+}
+__global__ void k_split16_decode(const float* __restrict__ in, int n, int c, int ld_in, float* __restrict__ out, int ld_out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = t / (c / 4), q = t % (c / 4);
+  if (r >= n) return;
+  *reinterpret_cast<float4*>(out + (size_t)r * ld_out + q * 4) = split16_load4(in + (size_t)r * ld_in, q * 4);
 }
 
 }  // namespace
@@ -544,6 +561,8 @@ __global__ __launch_bounds__(256) void conv1_tree_kernel(Conv1Args a) {
 namespace eyoc {
 
 static int g_kernel_mode = getenv("EYOC_SPCONV_WAVE") ? atoi(getenv("EYOC_SPCONV_WAVE")) : -1;
+
+int spconv_forced_kernel() { return g_kernel_mode; }
 
 int launch_spconv(const SpconvArgs& a, hipStream_t st) {
   EYOC_REQUIRE(a.in && a.w && a.out, EYOC_ERR_INVALID, "spconv: NULL tensor");
@@ -570,6 +589,11 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
   // row normalisation needs the whole output row in one tile: the wave-private kernel's tiles are at most 64
   // channels wide, so a normalised 128-channel layer always takes the workgroup-tiled kernel (CT = 128)
   const bool wave_ok = !(a.l2norm && a.cout > 64);
+  if (a.math != 0 || a.out_split) {   // SPLIT16 rows exist in the wave-private kernel only
+    EYOC_REQUIRE(wave_ok, EYOC_ERR_INVALID, "spconv: a normalised %d-channel layer has no split16 kernel", a.cout);
+    EYOC_REQUIRE(a.math == 0 || a.cin % 8 == 0, EYOC_ERR_INVALID, "spconv: split16 needs C_in %% 8 == 0");
+    return launch_spconv_wave(a, st);
+  }
   if (wave_ok && (force > 0 || (force < 0 && wave_tiles >= 4096))) return launch_spconv_wave(a, st);
   const bool wide = spconv_cc(a.cin, a.cout) == 64;
   switch (spconv_ct(a.cout)) {
@@ -657,6 +681,82 @@ int eyoc_spconv_pack_weights(const float* w, const float* scale, int K, int cin,
                 const float v = w[((size_t)k * cin + ci) * cout + co];
                 packed[q++] = scale ? v * scale[co] : v;
               }
+  return EYOC_OK;
+}
+
+// SPLIT16 packing: the same [k][slice][cc][nt][jq][lane] grid of 16-byte fragments as the fp32 layout, but fragment
+// jq = 2 q + p holds 8 fp16 values: the hi (p = 0) or lo (p = 1) halves of
+//   W[k][cc*CC + q*32 + (lane>>4)*8 + e][slice*CT + nt*16 + (lane&15)] * scale[col] * 2^sh,   e = 0..7
+// i.e. the A operand of v_mfma_f32_16x16x32_f16 (A[i = lane&15][k-slot (lane>>4)*8 + e]).  2^sh lifts the largest
+// |weight| of the layer into [256, 512) so that the lo halves stay clear of the fp16 subnormals; the kernel multiplies
+// its sums by *out_scale = 2^-sh.
+int eyoc_spconv_pack_weights_split16(const float* w, const float* scale, int K, int cin, int cout, float* packed,
+                                     float* out_scale) {
+  EYOC_REQUIRE(w && packed && out_scale, EYOC_ERR_INVALID, "pack_weights_split16: NULL argument");
+  EYOC_REQUIRE(cin > 0 && cin % 32 == 0 && (cout == 32 || cout == 64 || cout == 128 || cout == 256), EYOC_ERR_INVALID,
+               "pack_weights_split16: unsupported shape C_in %d C_out %d", cin, cout);
+  const int CT = spconv_ct(cout), CC = spconv_cc(cin, cout);
+  const int n_slices = cout / CT, ncc = cin / CC, NT = CT / 16, JQ = CC / 16;
+  float wmax = 0.f;
+  for (size_t i = 0; i < (size_t)K * cin * cout; ++i) {
+    const float v = fabsf(scale ? w[i] * scale[i % cout] : w[i]);
+    if (v > wmax) wmax = v;
+  }
+  int sh = 0;
+  if (wmax > 0.f && std::isfinite(wmax)) {
+    int e;
+    frexpf(wmax, &e);        // wmax = m * 2^e, m in [0.5, 1)
+    sh = 9 - e;              // wmax * 2^sh in [256, 512)
+    if (sh > 24) sh = 24;
+    if (sh < -6) sh = -6;
+  }
+  const float up = ldexpf(1.0f, sh);
+  *out_scale = ldexpf(1.0f, -sh);
+  _Float16* out = reinterpret_cast<_Float16*>(packed);
+  size_t q8 = 0;
+  for (int k = 0; k < K; ++k)
+    for (int s = 0; s < n_slices; ++s)
+      for (int cc = 0; cc < ncc; ++cc)
+        for (int nt = 0; nt < NT; ++nt)
+          for (int jq = 0; jq < JQ; ++jq)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int e = 0; e < 8; ++e) {
+                const int ci = cc * CC + (jq >> 1) * 32 + (lane >> 4) * 8 + e;
+                const int co = s * CT + nt * 16 + (lane & 15);
+                float v = w[((size_t)k * cin + ci) * cout + co];
+                if (scale) v *= scale[co];
+                v *= up;
+                const _Float16 h = (_Float16)v;
+                out[q8++] = (jq & 1) ? (_Float16)(v - (float)h) : h;
+              }
+  return EYOC_OK;
+}
+
+int eyoc_spconv_ex(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, const float* in_dev, int ld_in, int cin,
+                   const float* wpacked_dev, int cout, const float* bias_dev, const float* res_dev, int ld_res, int relu,
+                   float* out_dev, int ld_out, int math, int out_split, const float* out_scale_dev, void* stream) {
+  EYOC_REQUIRE(ctx, EYOC_ERR_INVALID, "eyoc_spconv_ex: NULL ctx");
+  EYOC_REQUIRE(math == 0 || math == 1, EYOC_ERR_INVALID, "eyoc_spconv_ex: math %d", math);
+  SpconvArgs a;
+  a.nbr = nbr_dev; a.K = K; a.n_out = n_out; a.in = in_dev; a.ld_in = ld_in; a.cin = cin; a.w = wpacked_dev;
+  a.cout = cout; a.bias = bias_dev; a.res = res_dev; a.ld_res = ld_res; a.relu = relu; a.l2norm = 0;
+  a.out = out_dev; a.ld_out = ld_out; a.math = math; a.out_split = out_split; a.out_scale = out_scale_dev;
+  return launch_spconv(a, (hipStream_t)stream);
+}
+
+int eyoc_split16_encode(eyoc_ctx* ctx, const float* in_dev, int n, int c, int ld_in, float* out_dev, int ld_out, void* stream) {
+  EYOC_REQUIRE(ctx && in_dev && out_dev && n >= 0 && c > 0 && c % 8 == 0 && ld_in % 4 == 0 && ld_out % 8 == 0, EYOC_ERR_INVALID,
+               "eyoc_split16_encode: bad argument (c %d must be a multiple of 8)", c);
+  if (n) hipLaunchKernelGGL(k_split16_encode, dim3(cdiv((long long)n * (c / 4), 256)), dim3(256), 0, (hipStream_t)stream, in_dev, n, c, ld_in, out_dev, ld_out);
+  EYOC_CHECK_HIP(hipGetLastError());
+  return EYOC_OK;
+}
+
+int eyoc_split16_decode(eyoc_ctx* ctx, const float* in_dev, int n, int c, int ld_in, float* out_dev, int ld_out, void* stream) {
+  EYOC_REQUIRE(ctx && in_dev && out_dev && n >= 0 && c > 0 && c % 8 == 0 && ld_in % 8 == 0 && ld_out % 4 == 0, EYOC_ERR_INVALID,
+               "eyoc_split16_decode: bad argument (c %d must be a multiple of 8)", c);
+  if (n) hipLaunchKernelGGL(k_split16_decode, dim3(cdiv((long long)n * (c / 4), 256)), dim3(256), 0, (hipStream_t)stream, in_dev, n, c, ld_in, out_dev, ld_out);
+  EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
 }
 

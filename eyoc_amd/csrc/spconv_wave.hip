@@ -19,6 +19,16 @@
 //   * epilogue from LDS: + bias (+ residual) -> ReLU -> (row L2 normalisation) -> coalesced float4 stores.
 // Summation order per output element is fixed (k ascending, channels ascending inside the MFMA chain), so
 // results are bit-reproducible from run to run.
+//
+// MATH = 1 (SPLIT16): the same decomposition on the fp16 matrix pipe.  fp32 MFMA runs at the VALU rate (157 TFLOP/s),
+// fp16 MFMA 8x (16x16x32) to 16x faster, and 1e-4 parity rules out plain fp16 / bf16 operands - but not exact
+// splitting: every operand is kept as hi + lo with hi = fp16(x), lo = fp16(x - hi) (22 significant bits, spconv.h),
+// and a product block is three MFMAs, W_hi X_hi + W_hi X_lo + W_lo X_hi, accumulated in fp32 (the dropped lo*lo term
+// is 2^-22 relative).  Activations are STORED in that format by the producing layer's epilogue (4 bytes per channel
+// like fp32, so gather bytes are unchanged) and weights are split on the host, so the hot loop has no conversions:
+// lane (g, j) reads the 32 bytes of pair j's row that hold channels 32q + 8g .. +7 (16 B hi, 16 B lo) = operand
+// element [k-slots 8g .. 8g+7][column j] of v_mfma_f32_16x16x32_f16.  48 MFMAs of 32 cycles per unit instead of 128.
+// Errors against an fp64 oracle are those of the fp32 path (tests/test_gpu_split16.py).
 #include <cstdlib>
 #include <type_traits>
 #ifndef EYOC_WPB
@@ -70,7 +80,7 @@ struct WCfg {
   static_assert(WAVE_BYTES % 16 == 0 && WPB * WAVE_BYTES <= 64 * 1024, "LDS budget");
 };
 
-template <int CTW, int BMW, int CC, int NCMAX, int OCC>
+template <int CTW, int BMW, int CC, int NCMAX, int OCC, int MATH>
 __global__ __launch_bounds__((WCfg<CTW, BMW, CC, NCMAX>::WPB * 64), OCC) void spconv_wave_kernel(SpconvArgs a) {
   using C = WCfg<CTW, BMW, CC, NCMAX>;
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::WPB * C::WAVE_BYTES];
@@ -204,7 +214,7 @@ __global__ __launch_bounds__((WCfg<CTW, BMW, CC, NCMAX>::WPB * 64), OCC) void sp
 #pragma unroll
       for (int c = 0; c < NCMAX; ++c) {
         const unsigned rec = L[c * 16];
-        gp[c] = a.in + (size_t)(rec >> 8) * a.ld_in + g * 4;
+        gp[c] = a.in + (size_t)(rec >> 8) * a.ld_in + g * (MATH ? 8 : 4);
         const int row = (int)(rec & 255u);
         orow[c] = row * (CTW * 4) + (((g ^ row) & (C::C4N - 1)) << 4);
       }
@@ -217,7 +227,9 @@ __global__ __launch_bounds__((WCfg<CTW, BMW, CC, NCMAX>::WPB * 64), OCC) void sp
 #if EYOC_ABL == 1 || EYOC_ABL >= 5
           G[q][c] = make_float4((float)lane, 1.f, 2.f, (float)cc_);
 #else
-          G[q][c] = *reinterpret_cast<const float4*>(gp[c] + cc_ * CC + q * 16);
+          // fp32: channels 16 q + 4 g .. +3.  SPLIT16: fragment q = 2 q' + p is the hi (p = 0) / lo (p = 1) half of the
+          // 32-byte group holding channels 32 q' + 8 g .. +7
+          G[q][c] = *reinterpret_cast<const float4*>(gp[c] + cc_ * CC + (MATH ? (q >> 1) * 32 + (q & 1) * 4 : q * 16));
 #endif
         }
     };
@@ -238,6 +250,25 @@ __global__ __launch_bounds__((WCfg<CTW, BMW, CC, NCMAX>::WPB * 64), OCC) void sp
     auto compute = [&](auto nc_tag, bool first_cc, bool last_cc, const float4 (&G)[C::JQ][NCMAX],
                        const float4 (&W)[C::JQ][C::NTW], const int (&orow)[NCMAX]) {
       constexpr int NC = decltype(nc_tag)::value;
+      if constexpr (MATH == 1) {
+        // three fp16 MFMAs per (chunk, tile, 32-channel block): W_hi X_hi, W_hi X_lo, W_lo X_hi
+#pragma unroll
+        for (int qq = 0; qq < C::JQ / 2; ++qq)
+#pragma unroll
+          for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              const half8_t xv = __builtin_bit_cast(half8_t, G[2 * qq + (term == 1 ? 1 : 0)][c]);
+#pragma unroll
+              for (int t = 0; t < C::NTW; ++t) {
+                const half8_t wv = __builtin_bit_cast(half8_t, W[2 * qq + (term == 2 ? 1 : 0)][t]);
+                if (first_cc && qq == 0 && term == 0)
+                  accr[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                else
+                  accr[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, accr[c][t], 0, 0, 0);
+              }
+            }
+      } else {
       // the first MFMA of an item's first C_in slice takes a literal zero as its C operand: no accumulator clearing
       {
         if (first_cc) {
@@ -269,6 +300,7 @@ __global__ __launch_bounds__((WCfg<CTW, BMW, CC, NCMAX>::WPB * 64), OCC) void sp
             }
           }
         }
+      }
       if (last_cc && EYOC_ABL != 3) {
         // D[i = 4 g + reg][j] = (output channel i of the tile, pair j): one 128-bit read-add-write per chunk and tile
         float4 old[NC][C::NTW];
@@ -341,10 +373,11 @@ __global__ __launch_bounds__((WCfg<CTW, BMW, CC, NCMAX>::WPB * 64), OCC) void sp
   const int er = lane / C::C4N, ec4 = lane % C::C4N;
   float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + ct0 + ec4 * 4);
+  const float os = a.out_scale ? *a.out_scale : 1.0f;   // undoes the weight pre-scale of the SPLIT16 packing (a power of two)
   for (int r = er; r < rows_here; r += RPI) {
     const size_t o = (size_t)list[r];
     float4 v = *reinterpret_cast<const float4*>(acc + acc_off(r, ec4));
-    v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+    v.x = v.x * os + b4.x; v.y = v.y * os + b4.y; v.z = v.z * os + b4.z; v.w = v.w * os + b4.w;
     if (a.l2norm) {
       float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
 #pragma unroll
@@ -353,14 +386,16 @@ __global__ __launch_bounds__((WCfg<CTW, BMW, CC, NCMAX>::WPB * 64), OCC) void sp
       v.x /= nrm; v.y /= nrm; v.z /= nrm; v.w /= nrm;
     } else {
       if (a.res) {
-        const float4 q = *reinterpret_cast<const float4*>(a.res + o * a.ld_res + ct0 + ec4 * 4);
+        const float4 q = MATH ? split16_load4(a.res + o * a.ld_res, ct0 + ec4 * 4)
+                              : *reinterpret_cast<const float4*>(a.res + o * a.ld_res + ct0 + ec4 * 4);
         v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
       }
       if (a.relu) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }
     }
-    *reinterpret_cast<float4*>(a.out + o * a.ld_out + ct0 + ec4 * 4) = v;
+    if (a.out_split) split16_store4(a.out + o * a.ld_out, ct0 + ec4 * 4, v);
+    else *reinterpret_cast<float4*>(a.out + o * a.ld_out + ct0 + ec4 * 4) = v;
   }
   TR();
 }
@@ -370,7 +405,8 @@ void launch_wave_cfg(const SpconvArgs& a, hipStream_t st) {
   using C = WCfg<CTW, BMW, CC, NCMAX>;
   const long long tiles = (long long)(a.small_rows / (BMW / 2) + cdiv(a.n_out - a.small_rows, BMW)) * (a.cout / CTW);
   const int blocks = (cdiv(tiles, C::WPB) + 8 * EYOC_XG - 1) / (8 * EYOC_XG) * (8 * EYOC_XG);   // whole runs (surplus waves exit at once)
-  hipLaunchKernelGGL((spconv_wave_kernel<CTW, BMW, CC, NCMAX, OCC>), dim3(blocks), dim3(C::WPB * 64), 0, st, a);
+  if (a.math == 1) hipLaunchKernelGGL((spconv_wave_kernel<CTW, BMW, CC, NCMAX, OCC, 1>), dim3(blocks), dim3(C::WPB * 64), 0, st, a);
+  else hipLaunchKernelGGL((spconv_wave_kernel<CTW, BMW, CC, NCMAX, OCC, 0>), dim3(blocks), dim3(C::WPB * 64), 0, st, a);
 }
 
 }  // namespace

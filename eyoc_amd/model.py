@@ -90,6 +90,7 @@ class ResUNet2(nn.Module):
         self._packed_device = None
         self._packed_version = None
         self._timing = False
+        self._math = -1          # sparse-conv arithmetic: -1 automatic, 0 fp32 MFMA, 1 split16 (see spconv_math)
 
     # ------------------------------------------------------------------ packing
     def _desc(self):
@@ -192,6 +193,8 @@ class ResUNet2(nn.Module):
         self._packed_version = None if from_blob else self._weights_version()
         if self._timing:
             _lib.check(lib.eyoc_model_set_timing(h, 1), "eyoc_model_set_timing")
+        if self._math != -1:
+            lib.eyoc_model_set_math(h, self._math)
         return blob
 
     @property
@@ -223,6 +226,33 @@ class ResUNet2(nn.Module):
             _lib.check(lib.eyoc_model_forward(_lib.ctx(dev.index), self._handle, maps, _lib.ptr(x.F), _lib.ptr(out),
                                               _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "eyoc_model_forward")
         return SparseTensor(out, coordinate_map_key=x.coordinate_map_key, coordinate_manager=cm)
+
+    # ------------------------------------------------------------------ arithmetic of the sparse convolutions
+    _MATH = {"auto": -1, "fp32": 0, "split16": 1}
+
+    @property
+    def spconv_math(self) -> str:
+        """"auto" (default: split16 for batches that fill the chip, else fp32), "fp32" (v_mfma_f32_16x16x4_f32) or
+        "split16" (three fp16 MFMAs per product on hi/lo-split fp16 operands - 22-bit significands, fp32
+        accumulation; activations must stay below 65504)."""
+        return {v: k for k, v in self._MATH.items()}[self._math]
+
+    @spconv_math.setter
+    def spconv_math(self, mode: str):
+        if mode not in self._MATH:
+            raise ValueError(f"spconv_math must be one of {sorted(self._MATH)}")
+        self._math = self._MATH[mode]
+        if self._handle is not None:
+            rc = _lib.load().eyoc_model_set_math(self._handle, self._math)
+            if rc < 0:
+                _lib.check(rc, "eyoc_model_set_math")
+
+    @property
+    def last_spconv_math(self) -> str:
+        """What the last forward ran in ("fp32" / "split16")."""
+        if self._handle is None:
+            return "fp32"
+        return "split16" if _lib.load().eyoc_model_last_math(self._handle) == 1 else "fp32"
 
     # ------------------------------------------------------------------ measurement hooks
     def set_timing(self, on: bool):

@@ -126,6 +126,19 @@ int eyoc_spconv_pack_weights(const float* w_host /*[K,cin,cout]*/, const float* 
 int eyoc_spconv(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, const float* in_dev,
                 int ld_in, int cin, const float* wpacked_dev, int cout, const float* bias_dev,
                 const float* res_dev, int ld_res, int relu, float* out_dev, int ld_out, void* stream);
+/* The same layer on the fp16 matrix pipe at fp32 accuracy ("split16", eyoc_amd/csrc/spconv_wave.hip): math = 1 expects
+ * `in_dev` / `res_dev` rows in the SPLIT16 format (eyoc_split16_encode: per 8 channels 16 B of fp16 hi halves + 16 B
+ * of fp16 lo halves, x = hi + lo to 2^-22 - the same 4 bytes per channel, so leading dimensions are unchanged) and
+ * weights packed by eyoc_spconv_pack_weights_split16, which also returns the scalar the kernel multiplies its sums
+ * with (upload it and pass it as out_scale_dev).  out_split = 1 writes SPLIT16 rows, 0 fp32 rows.  math = 0 is
+ * eyoc_spconv.  Always runs the wave-private kernel. */
+int eyoc_spconv_pack_weights_split16(const float* w_host, const float* scale_host, int K, int cin, int cout,
+                                     float* packed_host, float* out_scale_host);
+int eyoc_spconv_ex(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, const float* in_dev, int ld_in, int cin,
+                   const float* wpacked_dev, int cout, const float* bias_dev, const float* res_dev, int ld_res, int relu,
+                   float* out_dev, int ld_out, int math, int out_split, const float* out_scale_dev, void* stream);
+int eyoc_split16_encode(eyoc_ctx* ctx, const float* in_dev, int n, int c, int ld_in, float* out_dev, int ld_out, void* stream);
+int eyoc_split16_decode(eyoc_ctx* ctx, const float* in_dev, int n, int c, int ld_in, float* out_dev, int ld_out, void* stream);
 /* Two decompositions implement the operator (workgroup-tiled: spconv.hip, wave-private: spconv_wave.hip);
  * by default the launcher picks by problem size.  mode -1 = automatic (default), 0 = workgroup-tiled,
  * 1 = wave-private.  Process-wide; meant for parity tests and profiling.  Returns the previous mode. */
@@ -176,6 +189,12 @@ int eyoc_model_num_layers(const eyoc_model* model);
 int eyoc_model_layer_work(eyoc_ctx* ctx, const eyoc_model* model, const eyoc_maps* maps, void* stream,
                           const char** names, int64_t* pairs, double* flops, double* gather_bytes,
                           double* compulsory_bytes);
+/* Arithmetic of the sparse convolutions inside eyoc_model_forward: -1 automatic (default: split16 once the batch
+ * fills the chip - >= 262144 level-0 rows - else fp32), 0 fp32 MFMA, 1 split16 (three fp16 MFMAs per product on
+ * hi/lo-split operands: 22-bit significands, fp32 accumulation; activations must stay below 65504).  Returns the
+ * previous mode + 2, or a negative status.  eyoc_model_last_math: what the last forward used (0 / 1). */
+int eyoc_model_set_math(eyoc_model* model, int mode);
+int eyoc_model_last_math(const eyoc_model* model);
 /* when `on`, eyoc_model_forward brackets every layer with hipEvents on `stream` and
  * eyoc_model_layer_ms returns the per-layer durations of the last forward (synchronises) */
 int eyoc_model_set_timing(eyoc_model* model, int on);

@@ -1,0 +1,211 @@
+"""GPU parity of the split16 sparse convolution (three fp16 MFMAs per product on hi/lo-split operands,
+eyoc_amd/csrc/spconv_wave.hip MATH = 1): the SPLIT16 row format, single layers against an fp64 restatement next to the
+fp32-MFMA path, and the whole network against the oracle at the same 1e-4 bar as the fp32 path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _lib():
+    from eyoc_amd import _lib as L
+    return L, L.load()
+
+
+def encode(x):
+    L, lib = _lib()
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    L.check(lib.eyoc_split16_encode(L.ctx(), L.ptr(x), x.shape[0], x.shape[1], x.stride(0), L.ptr(out), out.stride(0), L.stream_ptr()))
+    return out
+
+
+def decode(x):
+    L, lib = _lib()
+    out = torch.empty_like(x)
+    L.check(lib.eyoc_split16_decode(L.ctx(), L.ptr(x), x.shape[0], x.shape[1], x.stride(0), L.ptr(out), out.stride(0), L.stream_ptr()))
+    return out
+
+
+def test_split16_row_format_round_trip():
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.normal(size=(500, 64)), rng.normal(size=(500, 64)) * 1e-3, rng.uniform(-6e4, 6e4, (24, 64)),
+                        np.zeros((8, 64))]).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    enc = encode(xd)
+    back = decode(enc).cpu().numpy()
+    err = np.abs(back - x)
+    bound = np.maximum(np.abs(x) * 2.0 ** -21, 2.0 ** -24)      # 22-bit significand, fp16 subnormal floor of the lo half
+    assert (err <= bound).all(), float((err / bound).max())
+    print(f"split16 round trip: max rel err {float((err / np.maximum(np.abs(x), 1e-30))[np.abs(x) > 0.125].max()):.2e}")
+    # layout: per 8 channels 8 fp16 hi then 8 fp16 lo
+    raw = enc.cpu().numpy().view(np.float16).reshape(len(x), 8, 2, 8)
+    np.testing.assert_array_equal(raw[:, :, 0, :].reshape(len(x), 64), x.astype(np.float16))
+    hi = raw[:, :, 0, :].reshape(len(x), 64).astype(np.float32)
+    np.testing.assert_array_equal(raw[:, :, 1, :].reshape(len(x), 64), (x - hi).astype(np.float16))
+
+
+def run_layer_split(nbr, x, W, bias=None, scale=None, res=None, relu=False, out_split=False):
+    L, lib = _lib()
+    K, cin, cout = W.shape
+    packed = np.zeros(K * cin * cout, np.float32)
+    os_ = np.zeros(1, np.float32)
+    sc = None if scale is None else np.ascontiguousarray(scale, np.float32)
+    assert lib.eyoc_spconv_pack_weights_split16(np.ascontiguousarray(W).ctypes.data, None if sc is None else sc.ctypes.data, K, cin,
+                                                cout, packed.ctypes.data, os_.ctypes.data) == 0
+    dev = torch.device("cuda")
+    n_out = nbr.shape[1] if nbr is not None else x.shape[0]
+    xin = encode(torch.from_numpy(x).to(dev))
+    rin = None if res is None else encode(torch.from_numpy(res).to(dev))
+    out = torch.full((n_out, cout), -555.0, device=dev)
+    wd, osd = torch.from_numpy(packed).to(dev), torch.from_numpy(os_).to(dev)
+    bd = None if bias is None else torch.from_numpy(np.ascontiguousarray(bias, np.float32)).to(dev)
+    nd = None if nbr is None else torch.from_numpy(np.ascontiguousarray(nbr, np.int32)).to(dev)
+    L.check(lib.eyoc_spconv_ex(L.ctx(), L.ptr(nd), K, n_out, L.ptr(xin), xin.stride(0), cin, L.ptr(wd), cout, L.ptr(bd), L.ptr(rin),
+                               0 if rin is None else rin.stride(0), 1 if relu else 0, L.ptr(out), out.stride(0), 1,
+                               1 if out_split else 0, L.ptr(osd), L.stream_ptr()), "eyoc_spconv_ex")
+    if out_split:
+        out = decode(out)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def layer_f64(nbr, x, W, bias=None, scale=None, res=None, relu=False):
+    """fp64 restatement of one layer (independent of both GPU paths' rounding)."""
+    if nbr is None:
+        nbr = np.arange(x.shape[0], dtype=np.int32)[None]
+    Wd = W.astype(np.float64) * (1.0 if scale is None else scale.astype(np.float64)[None, None, :])
+    out = np.zeros((nbr.shape[1], W.shape[2]))
+    xd = x.astype(np.float64)
+    for k in range(nbr.shape[0]):
+        v = nbr[k] >= 0
+        out[v] += xd[nbr[k][v]] @ Wd[k]
+    if bias is not None:
+        out += bias[None]
+    if res is not None:
+        out += res
+    return np.maximum(out, 0) if relu else out
+
+
+@pytest.fixture(scope="module")
+def maps():
+    from test_gpu_spconv import small_maps
+    return small_maps(0, 4000)
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (32, 64), (128, 128), (256, 64), (128, 256), (96, 64), (64, 32)])
+def test_split16_layer_is_as_accurate_as_fp32_mfma(maps, cin, cout):
+    """Against an fp64 restatement: the split16 layer's error must be of the order of the fp32-MFMA layer's own
+    (both ~1e-7 relative to the largest output), three orders of magnitude inside the 1e-4 bar."""
+    from eyoc_amd import _lib as L
+    from test_gpu_spconv import run_layer
+    nbr = maps["s1"][0]
+    rng = np.random.default_rng(cin * 7 + cout)
+    x = np.abs(rng.normal(size=(nbr.shape[1], cin))).astype(np.float32)         # post-ReLU-like activations
+    x[rng.random(x.shape) < 0.3] = 0
+    W = (rng.normal(size=(27, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    s = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    b = rng.normal(size=cout).astype(np.float32)
+    r = rng.normal(size=(nbr.shape[1], cout)).astype(np.float32)
+    want = layer_f64(nbr, x, W, bias=b, scale=s, res=r, relu=True)
+    lib = L.load()
+    prev = lib.eyoc_spconv_select_kernel(1)
+    try:
+        got32 = run_layer(nbr, x, W, bias=b, scale=s, res=r, relu=True)
+    finally:
+        lib.eyoc_spconv_select_kernel(prev)
+    got16 = run_layer_split(nbr, x, W, bias=b, scale=s, res=r, relu=True)
+    got16s = run_layer_split(nbr, x, W, bias=b, scale=s, res=r, relu=True, out_split=True)
+    e32, e16, e16s = rel_err(got32, want), rel_err(got16, want), rel_err(got16s, want)
+    print(f"{cin}->{cout}: vs fp64  fp32-mfma {e32:.2e}  split16 {e16:.2e}  split16 + split store {e16s:.2e}")
+    assert e16 < 2e-6 and e16s < 2e-6 and e16 < 8 * e32 + 2e-7
+
+
+def test_split16_identity_strided_transposed_and_ragged(maps):
+    rng = np.random.default_rng(3)
+    n1, n2 = len(maps["cm"][0]), len(maps["cm"][1])
+    x1 = rng.normal(size=(n1, 32)).astype(np.float32)
+    Wd = (rng.normal(size=(27, 32, 64)) / 16).astype(np.float32)
+    down = run_layer_split(maps["down"][0], x1, Wd)
+    assert down.shape == (n2, 64) and rel_err(down, layer_f64(maps["down"][0], x1, Wd)) < 2e-6
+    Wu = (rng.normal(size=(27, 64, 32)) / 16).astype(np.float32)
+    assert rel_err(run_layer_split(maps["up"][0], down, Wu), layer_f64(maps["up"][0], down, Wu)) < 2e-6
+    W1 = (rng.normal(size=(1, 96, 64)) / 10).astype(np.float32)
+    x96 = rng.normal(size=(n1, 96)).astype(np.float32)
+    assert rel_err(run_layer_split(None, x96, W1, relu=True), layer_f64(None, x96, W1, relu=True)) < 2e-6
+    for n in (1, 17, 65, 200):
+        from oracle import coords as oc
+        c = np.unique(rng.integers(-6, 6, size=(4 * n + 8, 3)), axis=0)[:n]
+        cm = oc.CoordMap(np.concatenate([np.zeros((len(c), 1), np.int64), c], 1), 1)
+        nbr = oc.kernel_map(cm, cm, 3)
+        x = rng.normal(size=(len(c), 32)).astype(np.float32)
+        W = (rng.normal(size=(27, 32, 32)) / 10).astype(np.float32)
+        assert rel_err(run_layer_split(nbr, x, W), layer_f64(nbr, x, W)) < 2e-6
+
+
+def _forward(model, coords, feats):
+    import eyoc_amd
+    return model(eyoc_amd.SparseTensor(torch.from_numpy(feats).cuda(), coordinates=torch.from_numpy(coords).cuda())).F.cpu().numpy()
+
+
+def test_split16_forward_matches_oracle_like_fp32(request):
+    """Whole ResUNetBN2C forward on a 31k-voxel cloud in both arithmetics against the CPU oracle, same bar (1e-4 of the
+    largest feature, cosine 1 - 1e-6 per row); split16 is selected explicitly and must really have run."""
+    from eyoc_amd import synthetic as syn
+    from oracle import resunet as orr
+    from test_gpu_round2 import _model
+    p = syn.make_pair(1)
+    coords = syn.batch_coords([p["coords0"]])
+    model, sd = _model()
+    want = orr.resunet_forward(sd, coords, p["feats0"]).numpy()
+    errs = {}
+    for mode in ("fp32", "split16"):
+        model.spconv_math = mode
+        got = _forward(model, coords, p["feats0"])
+        assert model.last_spconv_math == mode
+        errs[mode] = rel_err(got, want)
+        cos = (got * want).sum(1)
+        assert errs[mode] < REL and cos.min() > 1 - 1e-6, (mode, errs[mode], float(cos.min()))
+        np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+    print(f"forward vs oracle: fp32-mfma {errs['fp32']:.2e}  split16 {errs['split16']:.2e}")
+    # batched small clouds + permuted rows: the row-order contract holds in split16 too
+    rng = np.random.default_rng(11)
+    c = np.unique(rng.integers(-12, 12, size=(3000, 3)) // np.array([1, 1, 2]), axis=0)
+    rng.shuffle(c)
+    cb = syn.batch_coords([c[:900].astype(np.int32), c[900:].astype(np.int32)])
+    ones = np.ones((len(cb), 1), np.float32)
+    a = _forward(model, cb, ones)
+    assert rel_err(a, orr.resunet_forward(sd, cb, ones).numpy()) < REL
+    perm = rng.permutation(len(cb))
+    assert rel_err(_forward(model, cb[perm], ones), a[perm]) < 1e-5
+    # automatic mode: small batches stay on fp32
+    model.spconv_math = "auto"
+    _forward(model, cb, ones)
+    assert model.last_spconv_math == "fp32"
+
+
+def test_split16_other_channel_tables():
+    from eyoc_amd import synthetic as syn
+    from oracle import resunet as orr
+    import eyoc_amd
+    rng = np.random.default_rng(12)
+    c = np.unique(rng.integers(-10, 10, size=(1500, 3)), axis=0).astype(np.int32)
+    coords = syn.batch_coords([c])
+    sd = syn.make_weights(seed=5, in_channels=3, conv1_kernel_size=3, tr_channels=(None, 64, 64, 64, 64))
+    m = eyoc_amd.load_model("ResUNetBN2B")(3, 32, bn_momentum=0.05, conv1_kernel_size=3, normalize_feature=False)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m = m.cuda().eval()
+    m.spconv_math = "split16"
+    f3 = rng.normal(size=(len(coords), 3)).astype(np.float32)
+    got = _forward(m, coords, f3)
+    want = orr.resunet_forward(sd, coords, f3, normalize_feature=False, conv1_kernel_size=3).numpy()
+    assert m.last_spconv_math == "split16" and rel_err(got, want) < REL
