@@ -68,6 +68,8 @@ def parse_args(argv=None):
     ap.add_argument("--total-pairs", type=int, default=0, help="fixed split of this many pairs over all ranks (strong scaling)")
     ap.add_argument("--pool", type=int, default=0, help="distinct scenes per rank in --total-pairs mode (default: --pairs)")
     ap.add_argument("--nuscenes", action="store_true", help="nuScenes-shaped pairs: 32 beams, d in [5,50] m (configs[4])")
+    ap.add_argument("--math", choices=["auto", "fp32", "split16"], default="auto",
+                    help="arithmetic of the sparse convolutions (auto: split16 for batches that fill the chip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", "--no-latency-probe", dest="no_extras", action="store_true",
                     help="only the timed steps (profiling passes: keeps the kernel statistics to the timed region)")
@@ -238,6 +240,7 @@ def worker(args):
         device = torch.device("cuda", local_rank)
         torch.cuda.set_device(device)
         model, sd = build_model(device, rank)
+        model.spconv_math = args.math
         log("model packed")
         cfg = RegistrationConfig(ransac_max_iteration=args.ransac_iters)
         pipe, Batch = RegistrationPipeline(model, cfg), DeviceBatch
@@ -319,7 +322,7 @@ def worker(args):
         return
     out["config"] = {"workload": f"{args.pairs} synthetic {shape} pairs per step per GPU "
                                  f"(mean {b0.voxels // (2 * b0.P)} voxels/cloud, ResUNetBN2C random-init, "
-                                 f"5000-point NN, RANSAC {args.ransac_iters} hypotheses/pair, {plant})",
+                                 f"5000-point NN, RANSAC {args.ransac_iters} hypotheses/pair, {plant}, spconv math {model.last_spconv_math})",
                      "pairs_per_step": args.pairs, "parallelism": f"pairs sharded over {world} GPU(s)",
                      "inlier_ratio": args.inlier_ratio if descriptor else None}
     if total_mode:
@@ -342,13 +345,27 @@ def worker(args):
                   f"{w['gather_bytes'] / ms_i / 1e6:10.1f} {w['pairs']:10d}", file=sys.stderr)
     achieved_tf = flops / (conv_ms * 1e-3) / 1e12
     achieved_gbs = gather / (conv_ms * 1e-3) / 1e9
-    math_mode = getattr(model, "spconv_math", "fp32")
-    # fp32 MFMA: ideal matrix time (flop / 157.3 TF) is ~1.8x the ideal HBM time (gather bytes / 8 TB/s), so the fp32
-    # matrix pipe is the binding roof of these kernels; `hbm_gather` is the HBM view of the same launches
-    out["roofline"] = {"bound": "mfma", "achieved": achieved_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                       "frac": achieved_tf / MFMA_F32_PEAK_TF, "traffic": None,
-                       "kernel": "spconv_wave_kernel<...> (the 22 sparse-conv launches of one forward, summed)",
-                       "algorithmic_flop_per_forward": flops, "ms_per_forward": conv_ms, "math": math_mode}
+    math_mode = model.last_spconv_math
+    kernel = "spconv_wave_kernel<...> (the 22 sparse-conv launches of one forward, summed)"
+    if math_mode == "split16":
+        # split16: every algorithmic fp32 multiply-add is three fp16 MFMA multiply-adds at ~1.25 PFLOP/s
+        # (v_mfma_f32_16x16x32_f16, measured by scripts/micro/mfma_f16_rates.hip), i.e. an ideal matrix time of
+        # 3 * flop / 1250 TF ~ 8 ms against gather bytes / 8 TB/s ~ 12 ms: the HBM-side gather is the binding roof
+        out["roofline"] = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None, "kernel": kernel,
+                           "algorithmic_bytes_per_forward": gather, "ms_per_forward": conv_ms, "math": math_mode}
+        out["dtype_note"] = ("fp32 storage and accumulation; sparse-conv products as three fp16 MFMAs on hi/lo-split operands "
+                             "(22-bit significands): error against fp64 equals the fp32-MFMA path's (tests/test_gpu_split16.py); "
+                             "--math fp32 runs v_mfma_f32_16x16x4_f32 instead")
+        out["mfma"] = {"fp32_equivalent_TFLOPs": achieved_tf, "fp16_mfma_issued_TFLOPs": 3 * achieved_tf,
+                       "fp16_mfma_peak_TFLOPs": 2500.0, "frac_of_fp16_peak": 3 * achieved_tf / 2500.0,
+                       "vs_fp32_mfma_peak": achieved_tf / MFMA_F32_PEAK_TF, "algorithmic_flop_per_forward": flops}
+    else:
+        # fp32 MFMA: ideal matrix time (flop / 157.3 TF) is ~1.8x the ideal HBM time (gather bytes / 8 TB/s), so the
+        # fp32 matrix pipe is the binding roof of these kernels
+        out["roofline"] = {"bound": "mfma", "achieved": achieved_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                           "frac": achieved_tf / MFMA_F32_PEAK_TF, "traffic": None, "kernel": kernel,
+                           "algorithmic_flop_per_forward": flops, "ms_per_forward": conv_ms, "math": math_mode}
     out["hbm_gather"] = {"achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_forward": gather, "compulsory_bytes_per_forward": compulsory,
                          "traffic_over_compulsory": None}

@@ -22,6 +22,7 @@ maps = cm.maps()
 lib = _lib.load()
 info = cm.info()
 print("rows", info["rows"], "pairs_s1", info["pairs_s1"], flush=True)
+MATH = int(os.environ.get("MATH", "1"))
 cfgs = [("s1", 1, 64, 64), ("s1", 0, 64, 64), ("s1", 2, 128, 128), ("up", 0, 128, 64), ("s1", 0, 32, 32), ("s1", 3, 256, 256), ("s1", 2, 64, 64)]
 if os.environ.get("ONE"):
     cfgs = cfgs[:1]
@@ -33,13 +34,23 @@ for kind, lvl, cin, cout in cfgs:
     x = torch.randn(n_in, cin, device="cuda")
     W = np.random.default_rng(0).normal(size=(27, cin, cout)).astype(np.float32)
     packed = np.zeros(W.size, np.float32)
-    lib.eyoc_spconv_pack_weights(W.ctypes.data, None, 27, cin, cout, packed.ctypes.data)
+    osc = np.ones(1, np.float32)
+    if MATH:
+        lib.eyoc_spconv_pack_weights_split16(W.ctypes.data, None, 27, cin, cout, packed.ctypes.data, osc.ctypes.data)
+        xs = torch.empty_like(x)
+        lib.eyoc_split16_encode(_lib.ctx(), _lib.ptr(x), n_in, cin, cin, _lib.ptr(xs), cin, _lib.stream_ptr())
+        x = xs
+    else:
+        lib.eyoc_spconv_pack_weights(W.ctypes.data, None, 27, cin, cout, packed.ctypes.data)
     wd = torch.from_numpy(packed).cuda()
+    osd = torch.from_numpy(osc).cuda()
     out = torch.empty(n_out, cout, device="cuda")
+    # the tiling order the model forward would use for this table
+    perm = torch.empty(n_out, dtype=torch.int32, device="cuda")
 
     def run():
-        _lib.check(lib.eyoc_spconv(_lib.ctx(), tab, 27, n_out, _lib.ptr(x), cin, cin, _lib.ptr(wd), cout, None, None, 0, 0,
-                                   _lib.ptr(out), cout, _lib.stream_ptr()))
+        _lib.check(lib.eyoc_spconv_ex(_lib.ctx(), tab, 27, n_out, _lib.ptr(x), cin, cin, _lib.ptr(wd), cout, None, None, 0, 0,
+                                      _lib.ptr(out), cout, MATH, MATH, _lib.ptr(osd), _lib.stream_ptr()))
     for _ in range(3):
         run()
     torch.cuda.synchronize()

@@ -48,3 +48,18 @@ summary = {"steps_profiled": steps,
            "workload": json.loads(bench)["config"]["workload"]}
 json.dump(summary, open(os.path.join(out, f"{tag}_spconv_traffic.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
+
+# optional 4th pass: matrix-pipe counters per kernel (gpurun_out/<tag>_mfma)
+mf = os.path.join(g, f"{tag}_mfma", f"{tag}_counter_collection.csv")
+if os.path.exists(mf):
+    df = pd.read_csv(mf)
+    df["kernel"] = df["Kernel_Name"].map(short)
+    piv = df.pivot_table(index="kernel", columns="Counter_Name", values="Counter_Value", aggfunc="sum").fillna(0.0)
+    piv["launches"] = df[df.Counter_Name == df.Counter_Name.iloc[0]].groupby("kernel").size()
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in piv and "SQ_BUSY_CYCLES" in piv:
+        # MfmaUtil as rocprof-compute defines it: MFMA-busy cycles over (busy cycles x 4 SIMDs... per-SE counters are
+        # already summed); reported as a plain ratio of the two counters
+        piv["mfma_busy_over_sq_busy"] = piv["SQ_VALU_MFMA_BUSY_CYCLES"] / piv["SQ_BUSY_CYCLES"].clip(lower=1)
+    piv = piv.sort_values(piv.columns[0], ascending=False)
+    piv.to_csv(os.path.join(out, f"{tag}_mfma_counters.csv"))
+    print(piv.head(12).to_string())
