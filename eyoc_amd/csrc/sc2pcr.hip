@@ -41,7 +41,7 @@ __device__ inline float cross_len(float sx, float sy, float sz, float tx, float 
 // ---- y = SC x (one sweep).  256 threads = 256 rows; grid.y splits the COLUMNS (a lane-per-row kernel over all
 // columns is 32 workgroups at n = 8000, an eighth of the chip): block (bx, by) writes the partial sums of its
 // column range to part[by][row] and k_sc_normalize adds the ranges in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void k_sc_matvec(const float* __restrict__ src, const float* __restrict__ tgt, int n,
+__device__ __forceinline__ void d_sc_matvec(const float* __restrict__ src, const float* __restrict__ tgt, int n,
                                                    float inv_d2, const float* __restrict__ x, float* __restrict__ part,
                                                    int col_chunk, const Sc2Ctl* __restrict__ ctl) {
   if (ctl->converged) return;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_sc_matvec(const float* __restrict__ src
 }
 
 // ---- y = sum of the column ranges (ascending), per-block sum of squares (fp64) for the norm
-__global__ __launch_bounds__(256) void k_sc_reduce(const float* __restrict__ part, int n_part, int n, float* __restrict__ y,
+__device__ __forceinline__ void d_sc_reduce(const float* __restrict__ part, int n_part, int n, float* __restrict__ y,
                                                   double* __restrict__ block_sq, const Sc2Ctl* __restrict__ ctl) {
   if (ctl->converged) return;
   __shared__ double red[4];
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void k_sc_reduce(const float* __restrict__ par
 }
 
 // ---- v_new = y / (||y|| + 1e-6); converged = allclose(v_new, v_old); one workgroup
-__global__ __launch_bounds__(1024) void k_sc_normalize(const double* __restrict__ block_sq, int n_blocks, const float* __restrict__ y,
+__device__ __forceinline__ void d_sc_normalize(const double* __restrict__ block_sq, int n_blocks, const float* __restrict__ y,
                                                        float* __restrict__ v, int n, Sc2Ctl* __restrict__ ctl) {
   if (ctl->converged) return;
   __shared__ int bad[16];
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(1024) void k_sc_normalize(const double* __restrict_
 }
 
 // ---- bit matrices: hard[i][w] bit b = cross(i, 64 w + b) < d ; tight = < d/2.   One wave per (row, 64 columns).
-__global__ __launch_bounds__(256) void k_masks(const float* __restrict__ src, const float* __restrict__ tgt, int n,
+__device__ __forceinline__ void d_masks(const float* __restrict__ src, const float* __restrict__ tgt, int n,
                                                int words, float d, unsigned long long* __restrict__ hard,
                                                unsigned long long* __restrict__ tight) {
   const int lane = threadIdx.x & 63;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_masks(const float* __restrict__ src, co
 
 // ---- non-maximum suppression in source space: score = conf if no j within R has a larger conf, else 0
 // grid.y splits the columns; `dom` (zero-initialised) collects "some column dominates row i" with atomicOr.
-__global__ __launch_bounds__(256) void k_nms(const float* __restrict__ src, const float* __restrict__ conf, int n, float R,
+__device__ __forceinline__ void d_nms(const float* __restrict__ src, const float* __restrict__ conf, int n, float R,
                                              int col_chunk, int* __restrict__ dom) {
   __shared__ float ls[1024 * 3], lc[1024];
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -159,14 +159,14 @@ __global__ __launch_bounds__(256) void k_nms(const float* __restrict__ src, cons
   if (ok && dominated) atomicOr(&dom[i], 1);
 }
 
-__global__ void k_nms_score(const float* __restrict__ conf, const int* __restrict__ dom, int n, float* __restrict__ score) {
+__device__ __forceinline__ void d_nms_score(const float* __restrict__ conf, const int* __restrict__ dom, int n, float* __restrict__ score) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) score[i] = dom[i] ? 0.0f : conf[i];
 }
 
 // ---- stable descending rank of score; the first n_seed ranks are the seeds
 // (grid.y splits the columns; the partial ranks are integers, so atomicAdd keeps the result exact)
-__global__ __launch_bounds__(256) void k_rank(const float* __restrict__ score, int n, int col_chunk, int* __restrict__ rank_out) {
+__device__ __forceinline__ void d_rank(const float* __restrict__ score, int n, int col_chunk, int* __restrict__ rank_out) {
   __shared__ float lc[1024];
   const int i = blockIdx.x * 256 + threadIdx.x;
   const bool ok = i < n;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void k_rank(const float* __restrict__ score, i
   if (ok && rank) atomicAdd(&rank_out[i], rank);
 }
 
-__global__ void k_seeds(const int* __restrict__ rank, int n, int n_seed, int* __restrict__ seeds) {
+__device__ __forceinline__ void d_seeds(const int* __restrict__ rank, int n, int n_seed, int* __restrict__ seeds) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && rank[i] < n_seed) seeds[rank[i]] = i;
 }
@@ -193,7 +193,7 @@ __global__ void k_seeds(const int* __restrict__ rank, int n, int n_seed, int* __
 // counts) lives in LDS.  Selection is exact and deterministic: coarse then fine histogram give the
 // k1-th largest value v*; everything above v* is taken, and of the values equal to v* the lowest
 // indices are taken through an ordered block scan.
-__global__ __launch_bounds__(256) void k_seed_topk(const unsigned long long* __restrict__ hard,
+__device__ __forceinline__ void d_seed_topk(const unsigned long long* __restrict__ hard,
                                                    const unsigned long long* __restrict__ tight, int n, int words,
                                                    const int* __restrict__ seeds, int k1, int* __restrict__ knn1) {
   extern __shared__ unsigned char dyn[];
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_seed_topk(const unsigned long long* __r
 }
 
 // ---- per seed (one wave): local consensus, power iteration, weighted Kabsch, inlier count
-__global__ __launch_bounds__(256) void k_seed_solve(const float* __restrict__ src, const float* __restrict__ tgt, int n,
+__device__ __forceinline__ void d_seed_solve(const float* __restrict__ src, const float* __restrict__ tgt, int n,
                                                     int n_seed, const int* __restrict__ knn1, int k1, int k2, float d,
                                                     int max_iter, float inlier_thr, float* __restrict__ Ts,
                                                     float* __restrict__ fitness) {
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void k_seed_solve(const float* __restrict__ sr
 }
 
 // ---- first arg-max of the seed-wise fitness, then <= it_num refinement rounds (post_refinement)
-__global__ __launch_bounds__(1024) void k_refine(const float* __restrict__ src, const float* __restrict__ tgt, int n,
+__device__ __forceinline__ void d_refine(const float* __restrict__ src, const float* __restrict__ tgt, int n,
                                                  const float* __restrict__ Ts, const float* __restrict__ fitness,
                                                  int n_seed, float refine_thr, int it_num, float* __restrict__ Tout,
                                                  Sc2Ctl* __restrict__ ctl) {
@@ -542,9 +542,84 @@ __global__ __launch_bounds__(1024) void k_refine(const float* __restrict__ src, 
   }
 }
 
-__global__ void k_fill(float* p, int n, float v) {
+__device__ __forceinline__ void d_fill(float* p, int n, float v) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
+}
+
+// ---- batching: a launch handles up to SC2_CHUNK independent pairs, pair = blockIdx.z.  Every per-pair argument of
+// the kernels above travels in the kernel-argument block (no descriptor upload, nothing to keep alive); grids are
+// sized for the largest pair of the chunk and the surplus blocks of smaller pairs leave at once.  A pair's arithmetic
+// is untouched, so batched results are bit-identical to single-pair calls.
+constexpr int SC2_CHUNK = 16;
+struct Sc2Pair {
+  const float* src; const float* tgt;
+  float* T_out; float* fitness;
+  Sc2Ctl* ctl; float* v; float* y; float* score; int* seeds;
+  unsigned long long* hard; unsigned long long* tight;
+  int* knn; float* Ts; float* part; int* dom; int* rank; double* block_sq;
+  int n, words, n_seed, k1, k2, n_part, col_chunk, num_iterations;
+  float d, inlier_thr, nms_radius, refine_thr;
+};
+struct Sc2Batch { Sc2Pair p[SC2_CHUNK]; };
+
+__global__ __launch_bounds__(256) void k_init(Sc2Batch B) {
+  const Sc2Pair& q = B.p[blockIdx.z];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < q.n) { q.v[i] = 1.0f; q.dom[i] = 0; q.rank[i] = 0; }
+  if (i < (int)(sizeof(Sc2Ctl) / 4)) reinterpret_cast<int*>(q.ctl)[i] = 0;
+}
+__global__ __launch_bounds__(256) void k_sc_matvec(Sc2Batch B, int it) {
+  const Sc2Pair& q = B.p[blockIdx.z];
+  if (it >= q.num_iterations) return;
+  if ((int)blockIdx.x * 256 >= q.n || (int)blockIdx.y >= q.n_part) return;
+  d_sc_matvec(q.src, q.tgt, q.n, 1.0f / (q.d * q.d), q.v, q.part, q.col_chunk, q.ctl);
+}
+__global__ __launch_bounds__(256) void k_sc_reduce(Sc2Batch B, int it) {
+  const Sc2Pair& q = B.p[blockIdx.z];
+  if (it >= q.num_iterations) return;
+  if ((int)blockIdx.x * 256 >= q.n) return;
+  d_sc_reduce(q.part, q.n_part, q.n, q.y, q.block_sq, q.ctl);
+}
+__global__ __launch_bounds__(1024) void k_sc_normalize(Sc2Batch B, int it) {
+  const Sc2Pair& q = B.p[blockIdx.z];
+  if (it >= q.num_iterations) return;
+  d_sc_normalize(q.block_sq, (q.n + 255) / 256, q.y, q.v, q.n, q.ctl);
+}
+__global__ __launch_bounds__(256) void k_nms(Sc2Batch B) {
+  const Sc2Pair& q = B.p[blockIdx.z];
+  if ((int)blockIdx.x * 256 >= q.n || (int)blockIdx.y >= q.n_part) return;
+  d_nms(q.src, q.v, q.n, q.nms_radius, q.col_chunk, q.dom);
+}
+__global__ __launch_bounds__(256) void k_nms_score(Sc2Batch B) {
+  const Sc2Pair& q = B.p[blockIdx.z];
+  d_nms_score(q.v, q.dom, q.n, q.score);
+}
+__global__ __launch_bounds__(256) void k_rank(Sc2Batch B) {
+  const Sc2Pair& q = B.p[blockIdx.z];
+  if ((int)blockIdx.x * 256 >= q.n || (int)blockIdx.y >= q.n_part) return;
+  d_rank(q.score, q.n, q.col_chunk, q.rank);
+}
+__global__ __launch_bounds__(256) void k_seeds(Sc2Batch B) {
+  const Sc2Pair& q = B.p[blockIdx.z];
+  d_seeds(q.rank, q.n, q.n_seed, q.seeds);
+}
+__global__ __launch_bounds__(256) void k_masks(Sc2Batch B) {
+  const Sc2Pair& q = B.p[blockIdx.z];
+  d_masks(q.src, q.tgt, q.n, q.words, q.d, q.hard, q.tight);
+}
+__global__ __launch_bounds__(256) void k_seed_topk(Sc2Batch B) {
+  const Sc2Pair& q = B.p[blockIdx.z];
+  if ((int)blockIdx.x >= q.n_seed) return;
+  d_seed_topk(q.hard, q.tight, q.n, q.words, q.seeds, q.k1, q.knn);
+}
+__global__ __launch_bounds__(256) void k_seed_solve(Sc2Batch B) {
+  const Sc2Pair& q = B.p[blockIdx.z];
+  d_seed_solve(q.src, q.tgt, q.n, q.n_seed, q.knn, q.k1, q.k2, q.d, q.num_iterations, q.inlier_thr, q.Ts, q.fitness);
+}
+__global__ __launch_bounds__(1024) void k_refine(Sc2Batch B) {
+  const Sc2Pair& q = B.p[blockIdx.z];
+  d_refine(q.src, q.tgt, q.n, q.Ts, q.fitness, q.n_seed, q.refine_thr, 20, q.T_out, q.ctl);
 }
 
 struct Plan {
@@ -595,79 +670,97 @@ size_t eyoc_sc2pcr_workspace_bytes(int n, const eyoc_sc2pcr_params* params) {
   return make_plan(n, params).total;
 }
 
-int eyoc_sc2pcr(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, int n, const eyoc_sc2pcr_params* p, float* T_dev,
-                float* fitness_dev, void* ws, size_t ws_bytes, void* stream) {
-  EYOC_REQUIRE(ctx && src_dev && tgt_dev && p && T_dev && ws, EYOC_ERR_INVALID, "eyoc_sc2pcr: NULL argument");
+// one chunk of <= SC2_CHUNK pairs: ~70 launches whatever the number of pairs
+static int sc2pcr_chunk(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int32_t* seg_host, int n_pairs,
+                        const eyoc_sc2pcr_params* params, float* T_dev, float* fitness_dev, int fitness_stride, char* ws,
+                        size_t slice, hipStream_t st) {
+  Sc2Batch B;
+  int n_max = 0, part_max = 0, seed_max = 0, words_max = 0, it_max = 0;
+  for (int c = 0; c < SC2_CHUNK; ++c) {
+    const int b = c < n_pairs ? c : 0;   // unused slots repeat pair 0 (never launched: grid.z = n_pairs)
+    const int s0 = seg_host[b], n = seg_host[b + 1] - s0;
+    const eyoc_sc2pcr_params* p = &params[b];
+    const Plan pl = make_plan(n, p);
+    char* w = ws + slice * (size_t)b;
+    Sc2Pair& q = B.p[c];
+    q.src = src_dev + 3 * (size_t)s0; q.tgt = tgt_dev + 3 * (size_t)s0;
+    q.T_out = T_dev + 16 * (size_t)b; q.fitness = fitness_dev + (size_t)b * fitness_stride;
+    q.ctl = (Sc2Ctl*)(w + pl.off_ctl); q.v = (float*)(w + pl.off_v); q.y = (float*)(w + pl.off_y);
+    q.score = (float*)(w + pl.off_score); q.seeds = (int*)(w + pl.off_seeds);
+    q.hard = (unsigned long long*)(w + pl.off_hard); q.tight = (unsigned long long*)(w + pl.off_tight);
+    q.knn = (int*)(w + pl.off_knn); q.Ts = (float*)(w + pl.off_Ts); q.part = (float*)(w + pl.off_part);
+    q.dom = (int*)(w + pl.off_int); q.rank = q.dom + n; q.block_sq = (double*)(w + pl.off_sq);
+    q.n = n; q.words = pl.words; q.n_seed = pl.n_seed; q.k1 = pl.k1; q.k2 = pl.k2; q.n_part = pl.n_part;
+    q.col_chunk = pl.col_chunk; q.num_iterations = p->num_iterations;
+    q.d = p->d_thre; q.inlier_thr = p->inlier_threshold; q.nms_radius = p->nms_radius;
+    // the reference refines with 0.10 m for its 3DMatch setting and 1.2 m otherwise (SC2_PCR.py:254-257)
+    q.refine_thr = p->inlier_threshold == 0.10f ? 0.10f : 1.2f;
+    if (c < n_pairs) {
+      n_max = n > n_max ? n : n_max; part_max = pl.n_part > part_max ? pl.n_part : part_max;
+      seed_max = pl.n_seed > seed_max ? pl.n_seed : seed_max; words_max = pl.words > words_max ? pl.words : words_max;
+      it_max = p->num_iterations > it_max ? p->num_iterations : it_max;
+    }
+  }
+  const unsigned Z = (unsigned)n_pairs;
+  const int rb = cdiv(n_max, 256);
+  // leading eigenvector of the first-order compatibility matrix (power iteration from all-ones); a pair whose own
+  // num_iterations is below the chunk's maximum sits the surplus sweeps out
+  hipLaunchKernelGGL(k_init, dim3(rb, 1, Z), dim3(256), 0, st, B);
+  for (int it = 0; it < it_max; ++it) {
+    hipLaunchKernelGGL(k_sc_matvec, dim3(rb, part_max, Z), dim3(256), 0, st, B, it);
+    hipLaunchKernelGGL(k_sc_reduce, dim3(rb, 1, Z), dim3(256), 0, st, B, it);
+    hipLaunchKernelGGL(k_sc_normalize, dim3(1, 1, Z), dim3(1024), 0, st, B, it);
+  }
+  // seeds: NMS on the eigenvector in source space, stable top-n_seed
+  hipLaunchKernelGGL(k_nms, dim3(rb, part_max, Z), dim3(256), 0, st, B);
+  hipLaunchKernelGGL(k_nms_score, dim3(rb, 1, Z), dim3(256), 0, st, B);
+  hipLaunchKernelGGL(k_rank, dim3(rb, part_max, Z), dim3(256), 0, st, B);
+  hipLaunchKernelGGL(k_seeds, dim3(rb, 1, Z), dim3(256), 0, st, B);
+  // hard masks, second-order measure per seed, two-stage consensus, hypotheses
+  hipLaunchKernelGGL(k_masks, dim3(cdiv((long long)n_max * words_max, 4), 1, Z), dim3(256), 0, st, B);
+  const size_t dyn = ((size_t)n_max * 2 + 15) / 16 * 16 + (size_t)words_max * 8 + (size_t)words_max * 64 * 2;   // row, seed row, candidates
+  if (dyn > 48 * 1024 && !ctx->sc2_attr_set) {   // beyond the default dynamic-LDS allowance (n > ~12000)
+    EYOC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seed_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    ctx->sc2_attr_set = true;
+  }
+  hipLaunchKernelGGL(k_seed_topk, dim3(seed_max, 1, Z), dim3(256), dyn, st, B);
+  hipLaunchKernelGGL(k_seed_solve, dim3(cdiv(seed_max, 4), 1, Z), dim3(256), 0, st, B);
+  hipLaunchKernelGGL(k_refine, dim3(1, 1, Z), dim3(1024), 0, st, B);
+  EYOC_CHECK_HIP(hipGetLastError());
+  return EYOC_OK;
+}
+
+static int sc2pcr_check(int n, const eyoc_sc2pcr_params* p, const float* fitness_dev) {
   EYOC_REQUIRE(n >= 8 && n <= MAX_N, EYOC_ERR_INVALID, "eyoc_sc2pcr: n %d not in [8, %d]", n, MAX_N);
   EYOC_REQUIRE(n <= p->max_points, EYOC_ERR_INVALID, "eyoc_sc2pcr: n %d exceeds max_points %d (truncate first)", n, p->max_points);
   const Plan pl = make_plan(n, p);
   EYOC_REQUIRE(pl.k1 >= 1 && pl.k1 <= K1_MAX && pl.k2 >= 1 && pl.k2 <= pl.k1 && pl.k2 <= K2_MAX, EYOC_ERR_INVALID,
                "eyoc_sc2pcr: need 1 <= k2 <= k1 <= %d (got k1 %d k2 %d)", K1_MAX, pl.k1, pl.k2);
   EYOC_REQUIRE(pl.n_seed >= 1 && fitness_dev, EYOC_ERR_INVALID, "eyoc_sc2pcr: ratio %g gives no seeds for n %d", p->ratio, n);
-  EYOC_REQUIRE(ws_bytes >= pl.total && ((uintptr_t)ws & 255) == 0, EYOC_ERR_WORKSPACE,
-               "eyoc_sc2pcr: workspace %zu < required %zu bytes (256-byte aligned)", ws_bytes, pl.total);
-  hipStream_t st = (hipStream_t)stream;
-  char* b = (char*)ws;
-  Sc2Ctl* ctl = (Sc2Ctl*)(b + pl.off_ctl);
-  float* v = (float*)(b + pl.off_v);
-  float* y = (float*)(b + pl.off_y);
-  float* score = (float*)(b + pl.off_score);
-  int* seeds = (int*)(b + pl.off_seeds);
-  unsigned long long* hard = (unsigned long long*)(b + pl.off_hard);
-  unsigned long long* tight = (unsigned long long*)(b + pl.off_tight);
-  int* knn = (int*)(b + pl.off_knn);
-  float* Ts = (float*)(b + pl.off_Ts);
-  float* part = (float*)(b + pl.off_part);
-  int* dom = (int*)(b + pl.off_int);
-  int* rank = dom + n;
-  double* block_sq = (double*)(b + pl.off_sq);
-  const float d = p->d_thre;
-  EYOC_CHECK_HIP(hipMemsetAsync(ctl, 0, sizeof(Sc2Ctl), st));
-  // leading eigenvector of the first-order compatibility matrix (power iteration from all-ones)
-  hipLaunchKernelGGL(k_fill, dim3(cdiv(n, 256)), dim3(256), 0, st, v, n, 1.0f);
-  for (int it = 0; it < p->num_iterations; ++it) {
-    hipLaunchKernelGGL(k_sc_matvec, dim3(cdiv(n, 256), pl.n_part), dim3(256), 0, st, src_dev, tgt_dev, n, 1.0f / (d * d), v, part,
-                       pl.col_chunk, ctl);
-    hipLaunchKernelGGL(k_sc_reduce, dim3(cdiv(n, 256)), dim3(256), 0, st, part, pl.n_part, n, y, block_sq, ctl);
-    hipLaunchKernelGGL(k_sc_normalize, dim3(1), dim3(1024), 0, st, block_sq, cdiv(n, 256), y, v, n, ctl);
-  }
-  // seeds: NMS on the eigenvector in source space, stable top-n_seed
-  EYOC_CHECK_HIP(hipMemsetAsync(dom, 0, (size_t)2 * n * 4, st));
-  hipLaunchKernelGGL(k_nms, dim3(cdiv(n, 256), pl.n_part), dim3(256), 0, st, src_dev, v, n, p->nms_radius, pl.col_chunk, dom);
-  hipLaunchKernelGGL(k_nms_score, dim3(cdiv(n, 256)), dim3(256), 0, st, v, dom, n, score);
-  hipLaunchKernelGGL(k_rank, dim3(cdiv(n, 256), pl.n_part), dim3(256), 0, st, score, n, pl.col_chunk, rank);
-  hipLaunchKernelGGL(k_seeds, dim3(cdiv(n, 256)), dim3(256), 0, st, rank, n, pl.n_seed, seeds);
-  // hard masks, second-order measure per seed, two-stage consensus, hypotheses
-  hipLaunchKernelGGL(k_masks, dim3(cdiv((long long)n * pl.words, 4)), dim3(256), 0, st, src_dev, tgt_dev, n, pl.words, d,
-                     hard, tight);
-  const size_t dyn = ((size_t)n * 2 + 15) / 16 * 16 + (size_t)pl.words * 8 + (size_t)pl.words * 64 * 2;   // row, seed row, candidates
-  if (dyn > 48 * 1024) {   // beyond the default dynamic-LDS allowance (n > ~12000)
-    if (!ctx->sc2_attr_set) {
-      EYOC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seed_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-      ctx->sc2_attr_set = true;
-    }
-  }
-  hipLaunchKernelGGL(k_seed_topk, dim3(pl.n_seed), dim3(256), dyn, st, hard, tight, n, pl.words, seeds, pl.k1, knn);
-  hipLaunchKernelGGL(k_seed_solve, dim3(cdiv(pl.n_seed, 4)), dim3(256), 0, st, src_dev, tgt_dev, n, pl.n_seed, knn, pl.k1,
-                     pl.k2, d, p->num_iterations, p->inlier_threshold, Ts, fitness_dev);
-  // the reference refines with 0.10 m for its 3DMatch setting and 1.2 m otherwise (SC2_PCR.py:254-257)
-  const float refine_thr = p->inlier_threshold == 0.10f ? 0.10f : 1.2f;
-  hipLaunchKernelGGL(k_refine, dim3(1), dim3(1024), 0, st, src_dev, tgt_dev, n, Ts, fitness_dev, pl.n_seed, refine_thr, 20,
-                     T_dev, ctl);
-  EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
 }
 
+int eyoc_sc2pcr(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, int n, const eyoc_sc2pcr_params* p, float* T_dev,
+                float* fitness_dev, void* ws, size_t ws_bytes, void* stream) {
+  EYOC_REQUIRE(ctx && src_dev && tgt_dev && p && T_dev && ws, EYOC_ERR_INVALID, "eyoc_sc2pcr: NULL argument");
+  int rc = sc2pcr_check(n, p, fitness_dev);
+  if (rc) return rc;
+  const Plan pl = make_plan(n, p);
+  EYOC_REQUIRE(ws_bytes >= pl.total && ((uintptr_t)ws & 255) == 0, EYOC_ERR_WORKSPACE,
+               "eyoc_sc2pcr: workspace %zu < required %zu bytes (256-byte aligned)", ws_bytes, pl.total);
+  const int32_t seg[2] = {0, n};
+  return sc2pcr_chunk(ctx, src_dev, tgt_dev, seg, 1, p, T_dev, fitness_dev, pl.n_seed, (char*)ws, 0, (hipStream_t)stream);
+}
+
 // A batch of independent pairs (the loop of lib/trainer.py:1157-1166, which the reference leaves sequential with a
-// "ToDo: ... batched and parallelized").  One pair is ~50 small launches that fill a fraction of the GPU, so the
-// pairs run concurrently on the context's side streams (pair b on stream b % 8 with its own workspace slice),
-// forked from and joined back to `stream` with events.  Results are bit-identical to eyoc_sc2pcr per pair.
+// "ToDo: ... batched and parallelized"): SC2_CHUNK pairs per launch (blockIdx.z = pair), ~70 launches per chunk instead
+// of ~70 per pair.  Results are bit-identical to eyoc_sc2pcr per pair.
 //   src/tgt: pairs back to back, pair b = rows [seg[b], seg[b+1]) (HOST array of n_pairs + 1 ints);
 //   params[b]: per pair (the seed count int(ratio * n) depends on n);  T_dev f32 [n_pairs,16];
 //   fitness_dev f32 [n_pairs, fitness_stride] (row b holds the n_seed_b seedwise values).
 size_t eyoc_sc2pcr_batched_workspace_bytes(int max_n, const eyoc_sc2pcr_params* params) {
   const size_t one = eyoc_sc2pcr_workspace_bytes(max_n, params);
-  return one ? align_up(one) * eyoc_ctx::POOL : 0;
+  return one ? align_up(one) * SC2_CHUNK : 0;
 }
 
 int eyoc_sc2pcr_batched(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int32_t* seg_host, int n_pairs,
@@ -679,32 +772,23 @@ int eyoc_sc2pcr_batched(eyoc_ctx* ctx, const float* src_dev, const float* tgt_de
   size_t slice = 0;
   for (int b = 0; b < n_pairs; ++b) {
     const int n = seg_host[b + 1] - seg_host[b];
-    const size_t need = eyoc_sc2pcr_workspace_bytes(n, &params[b]);
-    EYOC_REQUIRE(need > 0, EYOC_ERR_INVALID, "eyoc_sc2pcr_batched: pair %d has an unsupported size %d", b, n);
+    int rc = sc2pcr_check(n, &params[b], fitness_dev);
+    if (rc) return rc;
+    const size_t need = make_plan(n, &params[b]).total;
     EYOC_REQUIRE((int)(params[b].ratio * n) <= fitness_stride, EYOC_ERR_INVALID,
                  "eyoc_sc2pcr_batched: fitness_stride %d too small for pair %d", fitness_stride, b);
     slice = need > slice ? need : slice;
   }
   slice = align_up(slice);
-  EYOC_REQUIRE(ws_bytes >= slice * eyoc_ctx::POOL && ((uintptr_t)ws & 255) == 0, EYOC_ERR_WORKSPACE,
-               "eyoc_sc2pcr_batched: workspace %zu < required %zu bytes (256-byte aligned)", ws_bytes, slice * eyoc_ctx::POOL);
-  int rc = ctx->ensure_pool();
-  if (rc) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  EYOC_CHECK_HIP(hipEventRecord(ctx->pool_fork, st));
-  const int used = n_pairs < eyoc_ctx::POOL ? n_pairs : eyoc_ctx::POOL;
-  for (int i = 0; i < used; ++i) EYOC_CHECK_HIP(hipStreamWaitEvent(ctx->pool[i], ctx->pool_fork, 0));
-  for (int b = 0; b < n_pairs; ++b) {
-    const int i = b % eyoc_ctx::POOL, s0 = seg_host[b], n = seg_host[b + 1] - s0;
-    rc = eyoc_sc2pcr(ctx, src_dev + 3 * (size_t)s0, tgt_dev + 3 * (size_t)s0, n, &params[b], T_dev + 16 * (size_t)b,
-                     fitness_dev + (size_t)b * fitness_stride, (char*)ws + slice * i, slice, ctx->pool[i]);
-    if (rc) break;
+  EYOC_REQUIRE(ws_bytes >= slice * SC2_CHUNK && ((uintptr_t)ws & 255) == 0, EYOC_ERR_WORKSPACE,
+               "eyoc_sc2pcr_batched: workspace %zu < required %zu bytes (256-byte aligned)", ws_bytes, slice * SC2_CHUNK);
+  for (int b0 = 0; b0 < n_pairs; b0 += SC2_CHUNK) {   // chunks run back to back on `stream` and reuse the workspace slices
+    const int nc = n_pairs - b0 < SC2_CHUNK ? n_pairs - b0 : SC2_CHUNK;
+    int rc = sc2pcr_chunk(ctx, src_dev, tgt_dev, seg_host + b0, nc, params + b0, T_dev + 16 * (size_t)b0,
+                          fitness_dev + (size_t)b0 * fitness_stride, fitness_stride, (char*)ws, slice, (hipStream_t)stream);
+    if (rc) return rc;
   }
-  for (int i = 0; i < used; ++i) {   // always join, also on the error path
-    (void)hipEventRecord(ctx->pool_done[i], ctx->pool[i]);
-    (void)hipStreamWaitEvent(st, ctx->pool_done[i], 0);
-  }
-  return rc;
+  return EYOC_OK;
 }
 
 }  // extern "C"

@@ -152,26 +152,43 @@ class RegistrationPipeline:
             host = res.cpu()
             return [reg.decode_ransac_result(host[p], n) for p in range(batch.P)]
         # SC2-PCR path (scripts/test_kitti.py:179-181): Matcher.estimator re-samples both clouds to num_node with
-        # replacement, matches them and registers the matched pairs.  Same draws and the same arithmetic as a
-        # per-pair loop over ``matcher.estimator``, but ONE segmented nearest-neighbour launch and ONE batched
-        # SC2-PCR call for all pairs.
+        # replacement, matches them and registers the matched pairs.  Same draws (pair by pair from one seeded
+        # RandomState, source before target) and the same arithmetic as a per-pair loop over ``matcher.estimator``,
+        # but no per-pair device work: ONE index upload, two row gathers, one segmented nearest-neighbour launch and
+        # one batched SC2-PCR call for all pairs.  The host draws overlap the forward, which is still running.
         rng = np.random.RandomState(seed)
         m = self.matcher
-        src_k, tgt_k, src_d, tgt_d = [], [], [], []
-        for p in range(batch.P):
-            if m.num_node == 'all':
-                si, ti = np.arange(n), np.arange(n)
-            else:
-                si, ti = rng.choice(n, m.num_node), rng.choice(n, m.num_node)
-            si = torch.from_numpy(si).to(F.device); ti = torch.from_numpy(ti).to(F.device)
-            src_k.append(batch.xyz0[p][si]); tgt_k.append(batch.xyz1[p][ti])
-            src_d.append(F0[p * n:(p + 1) * n][si]); tgt_d.append(F1[p * n:(p + 1) * n][ti])
-        seg = np.concatenate([[0], np.cumsum([len(x) for x in src_d])])
-        nn = knn1_segmented(torch.cat(src_d), torch.cat(tgt_d), seg, seg, "SquareL2", return_distance=False)
-        tgt_m = [tgt_k[p][nn[int(seg[p]):int(seg[p + 1])]] for p in range(batch.P)]
-        out = m.SC2_PCR_batch(src_k, tgt_m)
-        T = torch.stack([t for t, _ in out])
-        return T if return_device else [reg.RegistrationResult(t.cpu().numpy().astype(np.float64), 0.0, 0.0) for t in T]
+        P = batch.P
+        if m.num_node == 'all':
+            nn_pts = n
+            gsi = gti = np.arange(P * n, dtype=np.int64)
+        else:
+            nn_pts = int(m.num_node)
+            draws = np.empty((P, 2, nn_pts), np.int64)
+            for p in range(P):
+                draws[p, 0] = rng.choice(n, nn_pts)
+                draws[p, 1] = rng.choice(n, nn_pts)
+            draws += (np.arange(P, dtype=np.int64) * n)[:, None, None]
+            gsi, gti = draws[:, 0].reshape(-1), draws[:, 1].reshape(-1)
+        idx = torch.from_numpy(np.stack([gsi, gti])).to(F.device, non_blocking=True)
+        src_d, tgt_d = gather_rows(F0, idx[0]), gather_rows(F1, idx[1])
+        src_k = batch.xyz0.reshape(-1, 3).index_select(0, idx[0])
+        tgt_k = batch.xyz1.reshape(-1, 3).index_select(0, idx[1])
+        seg = np.arange(P + 1) * nn_pts
+        nn = knn1_segmented(src_d, tgt_d, seg, seg, "SquareL2", return_distance=False)
+        self._mark(2)
+        base = torch.arange(P, device=F.device).repeat_interleave(nn_pts) * nn_pts     # local -> packed target row
+        keep = min(nn_pts, int(m.max_points))                                            # SC2_PCR.py:318-319 truncation
+        tgt_m = tgt_k.index_select(0, nn + base)
+        if keep < nn_pts:
+            src_k = src_k.reshape(P, nn_pts, 3)[:, :keep].reshape(-1, 3)
+            tgt_m = tgt_m.reshape(P, nn_pts, 3)[:, :keep].reshape(-1, 3)
+        T, _, _ = m.SC2_PCR_packed(src_k.contiguous(), tgt_m.contiguous(), np.arange(P + 1) * keep)
+        self._mark(3)
+        if return_device:
+            return T
+        Th = T.cpu().numpy().astype(np.float64)
+        return [reg.RegistrationResult(Th[p], 0.0, 0.0) for p in range(P)]
 
     def correspondence_inlier_ratio(self, batch: DeviceBatch, nn_idx=None, thresh=None):
         """Diagnostic (outside the timed path): per pair, the fraction of the feature correspondences of the last

@@ -164,17 +164,20 @@ class Matcher:
                                        _lib.ptr(fit), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "eyoc_sc2pcr")
         return T.to(dev_in), fit[:, :n_seed].to(dev_in)
 
-    def SC2_PCR_batch(self, src_list, tgt_list):
-        """The loop of lib/trainer.py:1157-1166 (``SC2_PCR`` once per pair, which the reference leaves sequential)
-        as one batched call: lists of ``[n_b,3]`` matched key points -> list of ``(T [4,4], seedwise_fitness)``,
-        each bit-identical to ``SC2_PCR(src[None], tgt[None])`` on that pair."""
-        ss = [_cuda_f32(s) for s in src_list]
-        dev = ss[0].device
-        ns = [min(s.shape[0], int(self.max_points)) for s in ss]
-        src = torch.cat([s[:n] for s, n in zip(ss, ns)]).contiguous()
-        tgt = torch.cat([_cuda_f32(t, dev)[:n] for t, n in zip(tgt_list, ns)]).contiguous()
+    def SC2_PCR_packed(self, src, tgt, seg):
+        """Batched ``SC2_PCR`` on packed inputs: ``src / tgt f32 [N,3]`` hold the matched key points of all pairs back
+        to back, pair ``b`` = rows ``seg[b]:seg[b+1]`` (each at most ``max_points`` rows: truncate before packing).
+        Returns ``(T [B,4,4], fitness [B, stride], n_seed list)`` on the device; every pair is bit-identical to
+        ``SC2_PCR`` on it alone.  16 pairs share a launch (``eyoc_sc2pcr_batched``)."""
+        src = _cuda_f32(src)
+        tgt = _cuda_f32(tgt, src.device)
+        dev = src.device
+        seg = [int(v) for v in seg]
+        ns = [b - a for a, b in zip(seg[:-1], seg[1:])]
+        if max(ns) > int(self.max_points):
+            raise ValueError("a pair exceeds max_points: truncate before packing")
         B = len(ns)
-        seg = (C.c_int32 * (B + 1))(*np.concatenate([[0], np.cumsum(ns)]).astype(int).tolist())
+        segc = (C.c_int32 * (B + 1))(*seg)
         pn = [self._params(n) for n in ns]
         params = (_lib.Sc2pcrParams * B)(*[p for p, _ in pn])
         stride = max(max(k for _, k in pn), 1)
@@ -184,10 +187,22 @@ class Matcher:
         i_max = int(np.argmax(ns))
         with torch.cuda.device(dev):
             ws = _lib.workspace(lib.eyoc_sc2pcr_batched_workspace_bytes(ns[i_max], C.byref(params[i_max])), dev)
-            _lib.check(lib.eyoc_sc2pcr_batched(_lib.ctx(dev.index), _lib.ptr(src), _lib.ptr(tgt), seg, B, params, _lib.ptr(T),
+            _lib.check(lib.eyoc_sc2pcr_batched(_lib.ctx(dev.index), _lib.ptr(src), _lib.ptr(tgt), segc, B, params, _lib.ptr(T),
                                                _lib.ptr(fit), stride, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
                        "eyoc_sc2pcr_batched")
-        return [(T[b], fit[b, :pn[b][1]]) for b in range(B)]
+        return T, fit, [k for _, k in pn]
+
+    def SC2_PCR_batch(self, src_list, tgt_list):
+        """The loop of lib/trainer.py:1157-1166 (``SC2_PCR`` once per pair, which the reference leaves sequential)
+        as one batched call: lists of ``[n_b,3]`` matched key points -> list of ``(T [4,4], seedwise_fitness)``,
+        each bit-identical to ``SC2_PCR(src[None], tgt[None])`` on that pair."""
+        ss = [_cuda_f32(s) for s in src_list]
+        dev = ss[0].device
+        ns = [min(s.shape[0], int(self.max_points)) for s in ss]
+        src = torch.cat([s[:n] for s, n in zip(ss, ns)]).contiguous()
+        tgt = torch.cat([_cuda_f32(t, dev)[:n] for t, n in zip(tgt_list, ns)]).contiguous()
+        T, fit, n_seed = self.SC2_PCR_packed(src, tgt, np.concatenate([[0], np.cumsum(ns)]))
+        return [(T[b], fit[b, :n_seed[b]]) for b in range(len(ns))]
 
     def estimator(self, src_keypts, tgt_keypts, src_features, tgt_features, rng=None):
         """:386-413 -> ``(T, labels, src_corr, tgt_corr, seedwise_fitness)``."""

@@ -256,3 +256,32 @@ def test_random_sample_contract():
     want = np.random.RandomState(4).choice(10, 25)
     np.testing.assert_array_equal(a.numpy(), xyz.numpy()[want])
     np.testing.assert_array_equal(fa.cpu().numpy()[:, 0], want.astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------------ configs[4]
+def test_nuscenes_shaped_pairs_through_the_sc2pcr_path():
+    """BASELINE.json configs[4]: nuScenes-shaped input (32 beams, d in [5, 50] m) through the SC2-PCR back-end
+    (scripts/test_kitti.py:179-181 with config_KITTI.json's constants).  With planted descriptors every pair whose
+    overlap supports the requested inlier ratio must register; the batched call must equal the per-pair estimator
+    path on the same draws (covered bit for bit by test_harness_sc2pcr_path_equals_per_pair_estimator on KITTI-shaped
+    pairs; here: success on the other sensor geometry)."""
+    from eyoc_amd import synthetic as syn
+    from eyoc_amd.harness import DeviceBatch, RegistrationConfig, RegistrationPipeline
+    model, _ = _model()
+    pairs = [syn.make_pair(200 + s, dist_range=(5.0, 50.0), beams=32, band=None) for s in range(4)]
+    seeds = list(range(200, 204))
+    print("nuScenes-shaped voxel counts", [(p["stats"]["n0"], p["stats"]["n1"], round(p["stats"]["dist"], 1)) for p in pairs])
+    cfg = RegistrationConfig(use_RANSAC=False)
+    pipe = RegistrationPipeline(model, cfg)
+    batch = DeviceBatch(pairs, seeds, torch.device("cuda"), cfg.n_points, descriptor=dict(inlier_ratio=0.3))
+    res = pipe.register(batch, seed=1)
+    evals = pipe.evaluate(batch, res)
+    print("planted", batch.planted, "rte", [round(e["rte"], 3) for e in evals], "rre", [round(e["rre_deg"], 3) for e in evals])
+    for e, planted in zip(evals, batch.planted):
+        if planted >= 250:          # >= 5 % true correspondences: SC2-PCR must find the pose
+            assert e["success"], e
+    assert sum(e["success"] for e in evals) >= 3
+    # and the RANSAC back-end on the same batch
+    pipe_r = RegistrationPipeline(model, RegistrationConfig(ransac_max_iteration=1000000))
+    ev_r = pipe_r.evaluate(batch, pipe_r.register(batch))
+    assert sum(e["success"] for e in ev_r) >= 3

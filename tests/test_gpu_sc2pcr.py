@@ -75,14 +75,14 @@ def test_sc2pcr_kitti_sized_problem_recovers_pose():
 
 
 def test_sc2pcr_batched_equals_per_pair():
-    """11 ragged pairs (more than the 8 side streams): every pose and seedwise fitness is bit-identical to the
+    """19 ragged pairs (more than one 16-pair launch chunk): every pose and seedwise fitness is bit-identical to the
     single-pair call, and the caller's stream sees the results without an explicit sync."""
     import time
     import eyoc_amd
     m = eyoc_amd.Matcher(inlier_threshold=0.6, d_thre=0.1, ratio=0.2, nms_radius=0.6, max_points=8000, k1=30, k2=20,
                          num_iterations=20)
     T_gt = gi.rigid(0.02, -0.01, 0.1, 4.0, 0.3, -0.2)
-    sizes = [1200, 3000, 64, 800, 2500, 5000, 333, 1500, 2048, 900, 4100]
+    sizes = [1200, 3000, 64, 800, 2500, 5000, 333, 1500, 2048, 900, 4100, 700, 1999, 256, 3100, 1000, 40, 2222, 650]
     src, tgt = [], []
     for b, n in enumerate(sizes):
         p0, p1, _ = gi.corr_case(300 + b, n, T_gt, 0.3, noise=0.03)
@@ -105,7 +105,7 @@ def test_sc2pcr_batched_equals_per_pair():
         for b in range(len(sizes)):
             m.SC2_PCR(src[b][None], tgt[b][None])
     torch.cuda.synchronize(); tl = time.perf_counter() - t0
-    print(f"SC2-PCR 11 pairs: batched {tb / 3 * 1e3:.2f} ms, loop {tl / 3 * 1e3:.2f} ms")
+    print(f"SC2-PCR {len(sizes)} pairs: batched {tb / 3 * 1e3:.2f} ms, loop {tl / 3 * 1e3:.2f} ms")
     assert tb < tl * 1.1
 
 
