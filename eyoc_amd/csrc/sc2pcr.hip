@@ -28,7 +28,8 @@ struct Sc2Ctl {          // device-side control block
   int best_seed;
   float best_fitness;
   float norm;            // ||M v|| of the current sweep
-  int pad[3];
+  int dense;             // the compatibility graph has more edges than the CSR arrays hold: dense sweeps instead
+  int pad[2];
 };
 
 __device__ inline float cross_len(float sx, float sy, float sz, float tx, float ty, float tz, float sjx, float sjy,
@@ -93,8 +94,14 @@ __device__ __forceinline__ void d_sc_normalize(const double* __restrict__ block_
                                                        float* __restrict__ v, int n, Sc2Ctl* __restrict__ ctl) {
   if (ctl->converged) return;
   __shared__ int bad[16];
+  __shared__ double wsq[16];
+  double sq = 0;   // ||y||^2 in fp64, fixed order (thread-strided partial sums, wave trees, waves ascending)
+  for (int i = threadIdx.x; i < n; i += 1024) sq += (double)y[i] * (double)y[i];
+  sq = wave_sum(sq);
+  if ((threadIdx.x & 63) == 0) wsq[threadIdx.x >> 6] = sq;
+  __syncthreads();
   double tot = 0;
-  for (int b = 0; b < n_blocks; ++b) tot += block_sq[b];   // every thread the same order: deterministic, no broadcast needed
+  for (int w = 0; w < 16; ++w) tot += wsq[w];
   const float nrm = (float)sqrt(tot) + 1e-6f;
   int nb = 0;
   for (int i = threadIdx.x; i < n; i += 1024) {
@@ -131,7 +138,98 @@ __device__ __forceinline__ void d_masks(const float* __restrict__ src, const flo
     t = c < 0.5f * d;
   }
   const unsigned long long hm = __ballot(h), tm = __ballot(t);
-  if (lane == 0) { hard[wid] = hm; tight[wid] = tm; }
+  if (lane == 0) {
+    hard[wid] = hm; tight[wid] = tm;
+  }
+}
+
+// ---- CSR form of the two compatibility graphs.  The hard graph (c < d) is exactly the support of the first-order
+// matrix SC = max(0, 1 - c^2/d^2): a few percent of the N^2 entries on real correspondences, so the 20 power sweeps
+// run as sparse mat-vecs over (column, value) lists instead of recomputing N^2 cross lengths each (k_sc_matvec was
+// 45 % of SC2-PCR).  The tight graph's column lists serve the second-order counts of k_seed_topk.
+// One workgroup per pair: exclusive scan of the row lengths; more edges than the arrays hold -> ctl->dense.
+// row lengths: one wave per row pops the row's words (coalesced)
+__device__ __forceinline__ void d_csr_count(const unsigned long long* __restrict__ hard, int n, int words, int* __restrict__ cnt_h) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  int c = 0;
+  for (int w = lane; w < words; w += 64) c += __popcll(hard[(size_t)i * words + w]);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
+  if (lane == 0) cnt_h[i] = c;
+}
+__device__ __forceinline__ void d_csr_scan(int* __restrict__ cnt_h, int n, long long cap, Sc2Ctl* __restrict__ ctl) {
+  __shared__ long long tot[16];
+  __shared__ long long carry;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 <= n; i0 += 1024) {      // position n receives the total
+    const int i = i0 + threadIdx.x;
+    const int vh = i < n ? cnt_h[i] : 0;
+    long long ih = vh;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const long long oh = __shfl_up(ih, d, 64);
+      if (lane >= d) ih += oh;
+    }
+    if (lane == 63) tot[wave] = ih;
+    __syncthreads();
+    long long bh = carry;
+    for (int w = 0; w < wave; ++w) bh += tot[w];
+    if (i <= n) {
+      const long long eh = bh + ih - vh;
+      cnt_h[i] = (int)(eh < 0x7FFFFFFF ? eh : 0x7FFFFFFF);
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = bh + ih;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && carry > cap) ctl->dense = 1;
+}
+
+// one wave per row: the set bits of the two mask rows become ascending column lists (+ the SC value for the hard one)
+__device__ __forceinline__ void d_csr_fill(const float* __restrict__ src, const float* __restrict__ tgt, int n, int words,
+                                           float inv_d2, const unsigned long long* __restrict__ hard,
+                                           const int* __restrict__ ptr_h, unsigned short* __restrict__ col_h,
+                                           float* __restrict__ val_h, const Sc2Ctl* __restrict__ ctl) {
+  if (ctl->dense) return;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const float sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
+  const float tx = tgt[3 * i], ty = tgt[3 * i + 1], tz = tgt[3 * i + 2];
+  int oh = ptr_h[i];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int w = 0; w < words; ++w) {
+    const unsigned long long hm = hard[(size_t)i * words + w];
+    const int j = w * 64 + lane;
+    if ((hm >> lane) & 1ull) {
+      const float c = cross_len(sx, sy, sz, tx, ty, tz, src[3 * j], src[3 * j + 1], src[3 * j + 2], tgt[3 * j], tgt[3 * j + 1],
+                                tgt[3 * j + 2]);
+      const int pos = oh + __popcll(hm & lt);
+      col_h[pos] = (unsigned short)j;
+      val_h[pos] = fmaxf(1.0f - c * c * inv_d2, 0.0f);   // the expression of the dense sweep
+    }
+    oh += __popcll(hm);
+  }
+}
+
+// y = SC x over the CSR lists: one wave per row, lanes stride the row's entries, fixed-order wave reduction
+__device__ __forceinline__ void d_sc_spmv(const int* __restrict__ ptr_h, const unsigned short* __restrict__ col_h,
+                                          const float* __restrict__ val_h, int n, const float* __restrict__ x,
+                                          float* __restrict__ y, const Sc2Ctl* __restrict__ ctl) {
+  if (ctl->converged || ctl->dense) return;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int b = ptr_h[i], e = ptr_h[i + 1];
+  float acc = 0.0f;
+  for (int k = b + lane; k < e; k += 64) acc += val_h[k] * x[col_h[k]];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_down(acc, d, 64);
+  if (lane == 0) y[i] = acc;
 }
 
 // ---- non-maximum suppression in source space: score = conf if no j within R has a larger conf, else 0
@@ -558,10 +656,13 @@ struct Sc2Pair {
   Sc2Ctl* ctl; float* v; float* y; float* score; int* seeds;
   unsigned long long* hard; unsigned long long* tight;
   int* knn; float* Ts; float* part; int* dom; int* rank; double* block_sq;
+  int* ptr_h; unsigned short* col_h; float* val_h;   // CSR of the hard graph (support of the first-order matrix)
+  long long csr_cap;
   int n, words, n_seed, k1, k2, n_part, col_chunk, num_iterations;
   float d, inlier_thr, nms_radius, refine_thr;
 };
 struct Sc2Batch { Sc2Pair p[SC2_CHUNK]; };
+static_assert(sizeof(Sc2Batch) <= 4000, "the batch descriptor travels as a kernel argument (4 KB limit)");
 
 __global__ __launch_bounds__(256) void k_init(Sc2Batch B) {
   const Sc2Pair& q = B.p[blockIdx.z];
@@ -571,15 +672,32 @@ __global__ __launch_bounds__(256) void k_init(Sc2Batch B) {
 }
 __global__ __launch_bounds__(256) void k_sc_matvec(Sc2Batch B, int it) {
   const Sc2Pair& q = B.p[blockIdx.z];
-  if (it >= q.num_iterations) return;
+  if (it >= q.num_iterations || !q.ctl->dense) return;   // dense fallback only (graph too large for the CSR arrays)
   if ((int)blockIdx.x * 256 >= q.n || (int)blockIdx.y >= q.n_part) return;
   d_sc_matvec(q.src, q.tgt, q.n, 1.0f / (q.d * q.d), q.v, q.part, q.col_chunk, q.ctl);
 }
 __global__ __launch_bounds__(256) void k_sc_reduce(Sc2Batch B, int it) {
   const Sc2Pair& q = B.p[blockIdx.z];
-  if (it >= q.num_iterations) return;
+  if (it >= q.num_iterations || !q.ctl->dense) return;
   if ((int)blockIdx.x * 256 >= q.n) return;
   d_sc_reduce(q.part, q.n_part, q.n, q.y, q.block_sq, q.ctl);
+}
+__global__ __launch_bounds__(256) void k_sc_spmv(Sc2Batch B, int it) {
+  const Sc2Pair& q = B.p[blockIdx.z];
+  if (it >= q.num_iterations) return;
+  d_sc_spmv(q.ptr_h, q.col_h, q.val_h, q.n, q.v, q.y, q.ctl);
+}
+__global__ __launch_bounds__(1024) void k_csr_scan(Sc2Batch B) {
+  const Sc2Pair& q = B.p[blockIdx.z];
+  d_csr_scan(q.ptr_h, q.n, q.csr_cap, q.ctl);
+}
+__global__ __launch_bounds__(256) void k_csr_count(Sc2Batch B) {
+  const Sc2Pair& q = B.p[blockIdx.z];
+  d_csr_count(q.hard, q.n, q.words, q.ptr_h);
+}
+__global__ __launch_bounds__(256) void k_csr_fill(Sc2Batch B) {
+  const Sc2Pair& q = B.p[blockIdx.z];
+  d_csr_fill(q.src, q.tgt, q.n, q.words, 1.0f / (q.d * q.d), q.hard, q.ptr_h, q.col_h, q.val_h, q.ctl);
 }
 __global__ __launch_bounds__(1024) void k_sc_normalize(Sc2Batch B, int it) {
   const Sc2Pair& q = B.p[blockIdx.z];
@@ -626,6 +744,8 @@ struct Plan {
   int n, words, n_seed, k1, k2;
   int n_part, col_chunk;   // column ranges of the lane-per-row sweeps (matvec, NMS, rank)
   size_t off_ctl, off_v, off_y, off_score, off_seeds, off_hard, off_tight, off_knn, off_Ts, off_part, off_int, off_sq, total;
+  size_t off_ptr_h, off_col_h, off_val_h;
+  long long csr_cap;   // entries each CSR list can hold: a quarter of the N^2 pairs (denser graphs sweep densely)
 };
 
 Plan make_plan(int n, const eyoc_sc2pcr_params* p) {
@@ -657,6 +777,10 @@ Plan make_plan(int n, const eyoc_sc2pcr_params* p) {
   pl.off_part = take((size_t)pl.n_part * n * 4);
   pl.off_int = take((size_t)2 * n * 4);          // NMS domination flags, ranks
   pl.off_sq = take((size_t)row_blocks * 8);      // per-block sums of squares of a sweep
+  pl.csr_cap = (long long)n * n / 4 + 64;
+  pl.off_ptr_h = take((size_t)(n + 1) * 4);
+  pl.off_col_h = take((size_t)pl.csr_cap * 2);
+  pl.off_val_h = take((size_t)pl.csr_cap * 4);
   pl.total = o + 256;
   return pl;
 }
@@ -690,6 +814,8 @@ static int sc2pcr_chunk(eyoc_ctx* ctx, const float* src_dev, const float* tgt_de
     q.hard = (unsigned long long*)(w + pl.off_hard); q.tight = (unsigned long long*)(w + pl.off_tight);
     q.knn = (int*)(w + pl.off_knn); q.Ts = (float*)(w + pl.off_Ts); q.part = (float*)(w + pl.off_part);
     q.dom = (int*)(w + pl.off_int); q.rank = q.dom + n; q.block_sq = (double*)(w + pl.off_sq);
+    q.ptr_h = (int*)(w + pl.off_ptr_h); q.col_h = (unsigned short*)(w + pl.off_col_h);
+    q.val_h = (float*)(w + pl.off_val_h); q.csr_cap = pl.csr_cap;
     q.n = n; q.words = pl.words; q.n_seed = pl.n_seed; q.k1 = pl.k1; q.k2 = pl.k2; q.n_part = pl.n_part;
     q.col_chunk = pl.col_chunk; q.num_iterations = p->num_iterations;
     q.d = p->d_thre; q.inlier_thr = p->inlier_threshold; q.nms_radius = p->nms_radius;
@@ -706,7 +832,16 @@ static int sc2pcr_chunk(eyoc_ctx* ctx, const float* src_dev, const float* tgt_de
   // leading eigenvector of the first-order compatibility matrix (power iteration from all-ones); a pair whose own
   // num_iterations is below the chunk's maximum sits the surplus sweeps out
   hipLaunchKernelGGL(k_init, dim3(rb, 1, Z), dim3(256), 0, st, B);
+  // the two compatibility graphs as bit matrices, then as CSR lists (or ctl->dense when they do not fit)
+  hipLaunchKernelGGL(k_masks, dim3(cdiv((long long)n_max * words_max, 4), 1, Z), dim3(256), 0, st, B);
+  hipLaunchKernelGGL(k_csr_count, dim3(cdiv(n_max, 4), 1, Z), dim3(256), 0, st, B);
+  hipLaunchKernelGGL(k_csr_scan, dim3(1, 1, Z), dim3(1024), 0, st, B);
+  hipLaunchKernelGGL(k_csr_fill, dim3(cdiv(n_max, 4), 1, Z), dim3(256), 0, st, B);
+  // leading eigenvector of the first-order compatibility matrix (power iteration from all-ones); a pair whose own
+  // num_iterations is below the chunk's maximum sits the surplus sweeps out.  Sparse sweep; the dense kernels only
+  // do anything for a pair whose graph overflowed the CSR arrays
   for (int it = 0; it < it_max; ++it) {
+    hipLaunchKernelGGL(k_sc_spmv, dim3(cdiv(n_max, 4), 1, Z), dim3(256), 0, st, B, it);
     hipLaunchKernelGGL(k_sc_matvec, dim3(rb, part_max, Z), dim3(256), 0, st, B, it);
     hipLaunchKernelGGL(k_sc_reduce, dim3(rb, 1, Z), dim3(256), 0, st, B, it);
     hipLaunchKernelGGL(k_sc_normalize, dim3(1, 1, Z), dim3(1024), 0, st, B, it);
@@ -716,8 +851,7 @@ static int sc2pcr_chunk(eyoc_ctx* ctx, const float* src_dev, const float* tgt_de
   hipLaunchKernelGGL(k_nms_score, dim3(rb, 1, Z), dim3(256), 0, st, B);
   hipLaunchKernelGGL(k_rank, dim3(rb, part_max, Z), dim3(256), 0, st, B);
   hipLaunchKernelGGL(k_seeds, dim3(rb, 1, Z), dim3(256), 0, st, B);
-  // hard masks, second-order measure per seed, two-stage consensus, hypotheses
-  hipLaunchKernelGGL(k_masks, dim3(cdiv((long long)n_max * words_max, 4), 1, Z), dim3(256), 0, st, B);
+  // second-order measure per seed, two-stage consensus, hypotheses
   const size_t dyn = ((size_t)n_max * 2 + 15) / 16 * 16 + (size_t)words_max * 8 + (size_t)words_max * 64 * 2;   // row, seed row, candidates
   if (dyn > 48 * 1024 && !ctx->sc2_attr_set) {   // beyond the default dynamic-LDS allowance (n > ~12000)
     EYOC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seed_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
