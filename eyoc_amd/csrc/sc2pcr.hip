@@ -125,21 +125,35 @@ __device__ __forceinline__ void d_sc_normalize(const double* __restrict__ block_
 __device__ __forceinline__ void d_masks(const float* __restrict__ src, const float* __restrict__ tgt, int n,
                                                int words, float d, unsigned long long* __restrict__ hard,
                                                unsigned long long* __restrict__ tight) {
-  const int lane = threadIdx.x & 63;
-  const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wid >= (long long)n * words) return;
-  const int i = (int)(wid / words), w = (int)(wid % words);
-  const int j = w * 64 + lane;
-  bool h = false, t = false;
-  if (j < n) {
-    const float c = cross_len(src[3 * i], src[3 * i + 1], src[3 * i + 2], tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2],
-                              src[3 * j], src[3 * j + 1], src[3 * j + 2], tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2]);
-    h = c < d;
-    t = c < 0.5f * d;
+  // one wave per 64 x 64 tile: the lane's column stays in registers, the 64 rows come through LDS broadcasts, and
+  // lane r keeps the two ballots of row r, so a tile costs 12 loads per lane instead of 12 per cross length
+  __shared__ float rows[4][64 * 6];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long tile = (long long)blockIdx.x * 4 + wave;
+  const long long n_tiles = (long long)words * words;
+  if (tile >= n_tiles) return;   // wave-uniform; no barrier below
+  const int ti = (int)(tile / words), w = (int)(tile % words);
+  const int j = w * 64 + lane, i_mine = ti * 64 + lane;
+  float* R = rows[wave];
+  {
+    const int ii = i_mine < n ? i_mine : 0;
+    R[lane * 6 + 0] = src[3 * ii]; R[lane * 6 + 1] = src[3 * ii + 1]; R[lane * 6 + 2] = src[3 * ii + 2];
+    R[lane * 6 + 3] = tgt[3 * ii]; R[lane * 6 + 4] = tgt[3 * ii + 1]; R[lane * 6 + 5] = tgt[3 * ii + 2];
   }
-  const unsigned long long hm = __ballot(h), tm = __ballot(t);
-  if (lane == 0) {
-    hard[wid] = hm; tight[wid] = tm;
+  const int jj = j < n ? j : 0;
+  const float sjx = src[3 * jj], sjy = src[3 * jj + 1], sjz = src[3 * jj + 2];
+  const float tjx = tgt[3 * jj], tjy = tgt[3 * jj + 1], tjz = tgt[3 * jj + 2];
+  unsigned long long my_h = 0, my_t = 0;
+  const int rows_here = min(64, n - ti * 64);
+  for (int r = 0; r < rows_here; ++r) {
+    const float c = cross_len(R[r * 6], R[r * 6 + 1], R[r * 6 + 2], R[r * 6 + 3], R[r * 6 + 4], R[r * 6 + 5], sjx, sjy, sjz, tjx,
+                              tjy, tjz);
+    const unsigned long long hm = __ballot(j < n && c < d), tm = __ballot(j < n && c < 0.5f * d);
+    if (lane == r) { my_h = hm; my_t = tm; }
+  }
+  if (lane < rows_here) {
+    hard[(size_t)i_mine * words + w] = my_h;
+    tight[(size_t)i_mine * words + w] = my_t;
   }
 }
 
@@ -833,7 +847,7 @@ static int sc2pcr_chunk(eyoc_ctx* ctx, const float* src_dev, const float* tgt_de
   // num_iterations is below the chunk's maximum sits the surplus sweeps out
   hipLaunchKernelGGL(k_init, dim3(rb, 1, Z), dim3(256), 0, st, B);
   // the two compatibility graphs as bit matrices, then as CSR lists (or ctl->dense when they do not fit)
-  hipLaunchKernelGGL(k_masks, dim3(cdiv((long long)n_max * words_max, 4), 1, Z), dim3(256), 0, st, B);
+  hipLaunchKernelGGL(k_masks, dim3(cdiv((long long)words_max * words_max, 4), 1, Z), dim3(256), 0, st, B);
   hipLaunchKernelGGL(k_csr_count, dim3(cdiv(n_max, 4), 1, Z), dim3(256), 0, st, B);
   hipLaunchKernelGGL(k_csr_scan, dim3(1, 1, Z), dim3(1024), 0, st, B);
   hipLaunchKernelGGL(k_csr_fill, dim3(cdiv(n_max, 4), 1, Z), dim3(256), 0, st, B);
