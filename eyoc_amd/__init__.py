@@ -18,5 +18,5 @@ from .registration import (Matcher, registration_ransac_based_on_feature_matchin
                            ransac_from_correspondences, ransac_batched_from_correspondences, RegistrationResult)
 from .metrics import registration_errors, apply_transform, evaluate_nn_dist  # noqa: F401
 from .voxelize import sparse_quantize, voxelize, extract_features  # noqa: F401
-from .labels import (knn2_segmented, lowe_topk, spherical_filter, match_and_filter_corr,  # noqa: F401
-                     correspondences_under_pose)
+from .labels import (knn2_segmented, lowe_topk, spherical_filter, similarity_filter, load_dist_sim_map,  # noqa: F401
+                     match_and_filter_corr, correspondences_under_pose)

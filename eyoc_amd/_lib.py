@@ -76,6 +76,8 @@ PROTOTYPES = {
     "eyoc_knn2": (_i, [_vp, _vp, _vp, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i, _vp, _vp, _vp, _vp]),
     "eyoc_lowe_topk": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "eyoc_pair_filter": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, C.c_float, _vp, _vp, _vp]),
+    "eyoc_pair_filter_similarity": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, C.c_float, C.c_float, C.c_double, _vp, _vp,
+                                         _vp]),
     "eyoc_spconv_packed_floats": (_sz, [_i, _i, _i]),
     "eyoc_spconv_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "eyoc_spconv_select_kernel": (_i, [_i]),

@@ -42,11 +42,16 @@ __device__ inline float norm3(float x, float y, float z) {
 
 // mode 0 (lib/trainer.py:1107-1110): keep pair i iff |P0[i0]| > radius and |P1[i1]| > radius.
 // mode 1 (lib/trainer.py:1203-1206): keep iff |R P0[i0] + t - P1[i1]| < radius, T row-major 4x4.
+// mode 2 (lib/trainer.py:1118-1149, "Similarity"): d0 = |P0[i0]|, d1 = |P1[i1]|; look the pair up in the
+//         distance-similarity table at [min(int(|d0 - d1| / g1), xlim - 1)][min(int(min(d0, d1) / g0), ylim - 1)] and keep it
+//         iff the entry exceeds the threshold (fp64 table and compare, like the reference's float64 tensor).
 // One workgroup, order-preserving compaction (m is a few thousand).
+struct SimTable { const double* t; int xlim, ylim; float g0, g1; double thresh; };
+
 __global__ __launch_bounds__(1024) void k_pair_filter(int mode, const float* __restrict__ P0, const float* __restrict__ P1,
                                                      const long long* __restrict__ i0, const long long* __restrict__ i1, int m,
                                                      const float* __restrict__ T, float radius, long long* __restrict__ out,
-                                                     int* __restrict__ n_out) {
+                                                     int* __restrict__ n_out, SimTable sim) {
 #pragma clang fp contract(off)
   __shared__ int wave_cnt[16];
   __shared__ int base_s;
@@ -63,6 +68,12 @@ __global__ __launch_bounds__(1024) void k_pair_filter(int mode, const float* __r
       const float* q = P1 + 3 * b;
       if (mode == 0) {
         keep = norm3(p[0], p[1], p[2]) > radius && norm3(q[0], q[1], q[2]) > radius;
+      } else if (mode == 2) {
+        const float d0 = norm3(p[0], p[1], p[2]), d1 = norm3(q[0], q[1], q[2]);
+        long long c0 = (long long)(fminf(d0, d1) / sim.g0), c1 = (long long)(fabsf(d0 - d1) / sim.g1);   // .long(): towards zero
+        c0 = c0 < 0 ? 0 : (c0 >= sim.ylim ? sim.ylim - 1 : c0);
+        c1 = c1 < 0 ? 0 : (c1 >= sim.xlim ? sim.xlim - 1 : c1);
+        keep = sim.t[c1 * sim.ylim + c0] > sim.thresh;
       } else {
         const float x = ((T[0] * p[0] + T[1] * p[1]) + T[2] * p[2]) + T[3];
         const float y = ((T[4] * p[0] + T[5] * p[1]) + T[6] * p[2]) + T[7];
@@ -130,7 +141,21 @@ int eyoc_pair_filter(eyoc_ctx* ctx, int mode, const float* P0_dev, const float* 
   EYOC_REQUIRE(mode == 0 || (mode == 1 && T_dev), EYOC_ERR_INVALID, "eyoc_pair_filter: mode %d (1 needs a pose)", mode);
   EYOC_REQUIRE(m >= 0, EYOC_ERR_INVALID, "eyoc_pair_filter: m %d", m);
   hipLaunchKernelGGL(k_pair_filter, dim3(1), dim3(1024), 0, (hipStream_t)stream, mode, P0_dev, P1_dev, (const long long*)idx0_dev,
-                     (const long long*)idx1_dev, m, T_dev, radius, (long long*)pairs_out_dev, n_out_dev);
+                     (const long long*)idx1_dev, m, T_dev, radius, (long long*)pairs_out_dev, n_out_dev, SimTable{});
+  EYOC_CHECK_HIP(hipGetLastError());
+  return EYOC_OK;
+}
+
+int eyoc_pair_filter_similarity(eyoc_ctx* ctx, const float* P0_dev, const float* P1_dev, const int64_t* idx0_dev,
+                                const int64_t* idx1_dev, int m, const double* table_dev, int xlim, int ylim, float grid0,
+                                float grid1, double thresh, int64_t* pairs_out_dev, int32_t* n_out_dev, void* stream) {
+  EYOC_REQUIRE(ctx && P0_dev && P1_dev && idx0_dev && idx1_dev && table_dev && pairs_out_dev && n_out_dev, EYOC_ERR_INVALID,
+               "eyoc_pair_filter_similarity: NULL argument");
+  EYOC_REQUIRE(m >= 0 && xlim >= 1 && ylim >= 1 && grid0 > 0.f && grid1 > 0.f, EYOC_ERR_INVALID,
+               "eyoc_pair_filter_similarity: m %d table %d x %d grid %g %g", m, xlim, ylim, grid0, grid1);
+  SimTable sim{table_dev, xlim, ylim, grid0, grid1, thresh};
+  hipLaunchKernelGGL(k_pair_filter, dim3(1), dim3(1024), 0, (hipStream_t)stream, 2, P0_dev, P1_dev, (const long long*)idx0_dev,
+                     (const long long*)idx1_dev, m, (const float*)nullptr, 0.0f, (long long*)pairs_out_dev, n_out_dev, sim);
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
 }

@@ -68,16 +68,53 @@ def spherical_filter(C0, C1, idx0, idx1, radius):
     return _pair_filter(0, C0, C1, idx0, idx1, None, float(radius))
 
 
+FRAME_TO_YGRID = {0: 1, 1: 1.5, 2: 2, 3: 2.5, 4: 2.5, 5: 2.5}      # lib/trainer.py:1136
+
+
+def load_dist_sim_map(path):
+    """``config/dist_sim_plot/<dataset>_distSimPlot.npz`` as the reference reads it (lib/trainer.py:1128-1132):
+    ``{frame_index 0..5: float64 [xlim, ylim]}``."""
+    maps = np.load(path, allow_pickle=True)["res"].tolist()
+    return {i: np.asarray(maps[i], np.float64) for i in range(6)}
+
+
+def similarity_filter(C0, C1, idx0, idx1, dist_sim_map, frame_distance, similarity_thresh=0.4):
+    """lib/trainer.py:1118-1149 for one pair: keep the index pairs whose (min centre distance, centre-distance gap)
+    cell of the distance-similarity table exceeds ``similarity_thresh``.  ``dist_sim_map``: ``{0..5: [xlim, ylim]}``
+    (``load_dist_sim_map``); ``frame_distance``: the pair's frame gap (the table slice is ``clamp(gap // 5, 0, 5)``)."""
+    frame_index = min(max(0, int(frame_distance) // 5), 5)
+    table = np.ascontiguousarray(np.asarray(dist_sim_map[frame_index], np.float64))
+    xlim, ylim = table.shape
+    P0 = _cuda_f32(C0)
+    P1 = _cuda_f32(C1, P0.device)
+    i0 = idx0.to(P0.device, torch.int64).contiguous()
+    i1 = idx1.to(P0.device, torch.int64).contiguous()
+    m = i0.shape[0]
+    out = torch.empty((m, 2), dtype=torch.int64, device=P0.device)
+    n_out = torch.zeros(1, dtype=torch.int32, device=P0.device)
+    td = torch.from_numpy(table).to(P0.device)
+    with torch.cuda.device(P0.device):
+        _lib.check(_lib.load().eyoc_pair_filter_similarity(
+            _lib.ctx(P0.device.index), _lib.ptr(P0), _lib.ptr(P1), _lib.ptr(i0), _lib.ptr(i1), m, _lib.ptr(td), xlim, ylim,
+            C.c_float(5.0), C.c_float(FRAME_TO_YGRID[frame_index]), C.c_double(similarity_thresh), _lib.ptr(out), _lib.ptr(n_out),
+            _lib.stream_ptr()), "eyoc_pair_filter_similarity")
+    return out[:int(n_out.item())]
+
+
 def match_and_filter_corr(C_batch_0, F_batch_0, C_batch_1, F_batch_1, radius=20, feature_filter="Lowe",
-                          spatial_filter="Spherical", frame_distance=None, num_corres=5000):
+                          spatial_filter="Spherical", frame_distance=None, num_corres=5000, dist_sim_map=None,
+                          similarity_thresh=0.4):
     """lib/trainer.py:1025-1151.  Lists of per-cloud ``[n_i,3]`` coordinates and ``[n_i,d]`` features ->
-    ``(matches int64 [N,2] on the CPU, with the collate biases; list of per-pair [M_i,2] device tensors)``."""
+    ``(matches int64 [N,2] on the CPU, with the collate biases; list of per-pair [M_i,2] device tensors)``.
+    ``spatial_filter="Similarity"`` needs ``frame_distance`` (one gap per pair) and ``dist_sim_map`` (the reference
+    reads it from ``config/dist_sim_plot/<pretraining_dataset>_distSimPlot.npz``: ``load_dist_sim_map``) with
+    ``similarity_thresh`` = ``config.similarity_thresh``."""
     if feature_filter not in ("None", "Lowe"):
         raise AssertionError(feature_filter)
-    if spatial_filter == "Similarity":
-        raise NotImplementedError("the similarity filter needs the reference's config/dist_sim_plot tables")
-    if spatial_filter not in ("Spherical", "None"):
+    if spatial_filter not in ("Spherical", "None", "Similarity"):
         raise AssertionError(spatial_filter)
+    if spatial_filter == "Similarity" and (dist_sim_map is None or frame_distance is None):
+        raise ValueError('spatial_filter="Similarity" needs dist_sim_map and frame_distance')
     F0s = [_cuda_f32(f) for f in F_batch_0]
     dev = F0s[0].device
     F1s = [_cuda_f32(f, dev) for f in F_batch_1]
@@ -106,6 +143,9 @@ def match_and_filter_corr(C_batch_0, F_batch_0, C_batch_1, F_batch_1, radius=20,
     for p in range(len(F0s)):
         if spatial_filter == "None":
             uncollated.append(torch.stack([idx1[p], idx2[p]], 1))
+        elif spatial_filter == "Similarity":
+            uncollated.append(similarity_filter(C_batch_0[p], C_batch_1[p], idx1[p], idx2[p], dist_sim_map, frame_distance[p],
+                                                similarity_thresh))
         else:
             uncollated.append(spherical_filter(C_batch_0[p], C_batch_1[p], idx1[p], idx2[p], radius))
     return matches.cpu(), uncollated

@@ -254,6 +254,14 @@ int eyoc_pair_filter(eyoc_ctx* ctx, int mode, const float* P0_dev, const float* 
                      const int64_t* idx1_dev, int m, const float* T_dev, float radius, int64_t* pairs_out_dev,
                      int32_t* n_out_dev, void* stream);
 
+/* The "Similarity" spatial filter of match_and_filter_corr (lib/trainer.py:1118-1149): with d0 = |P0[idx0]|, d1 = |P1[idx1]|
+ * a pair is kept iff table[min(int(|d0 - d1| / grid1), xlim - 1)][min(int(min(d0, d1) / grid0), ylim - 1)] > thresh.
+ * table_dev: fp64 [xlim, ylim] row-major (one frame-distance slice of config/dist_sim_plot/<dataset>_distSimPlot.npz;
+ * the reference uses grid0 = 5 and grid1 in {1, 1.5, 2, 2.5} by frame index).  Output like eyoc_pair_filter. */
+int eyoc_pair_filter_similarity(eyoc_ctx* ctx, const float* P0_dev, const float* P1_dev, const int64_t* idx0_dev,
+                                const int64_t* idx1_dev, int m, const double* table_dev, int xlim, int ylim, float grid0,
+                                float grid1, double thresh, int64_t* pairs_out_dev, int32_t* n_out_dev, void* stream);
+
 /* replaces: lib.metrics.pdist (lib/metrics.py:22-29): dense out f32 [n,m]; same arithmetic as eyoc_knn1 */
 int eyoc_pdist(eyoc_ctx* ctx, const float* A_dev, int n, const float* B_dev, int m, int c, int dist_type,
                float* out_dev, void* stream);

@@ -80,10 +80,32 @@ def apply_pose(T, P):
     return out
 
 
+FRAME_TO_YGRID = {0: 1, 1: 1.5, 2: 2, 3: 2.5, 4: 2.5, 5: 2.5}
+
+
+def similarity_mask(C0, C1, a, b, dist_sim_map, frame_distance, similarity_thresh=0.4):
+    """lib/trainer.py:1118-1149: the "Similarity" spatial filter of one pair.  ``d0, d1`` = centre distances of the
+    two endpoints (fp32); table coordinates ``(min(d0, d1) / 5).long()`` and ``(|d0 - d1| / ygrid).long()`` clamped
+    into the table, which is indexed ``[gap cell, min-distance cell]`` and compared in float64."""
+    d0 = norm3(np.asarray(C0)[a])
+    d1 = norm3(np.asarray(C1)[b])
+    gap = np.abs(d0 - d1)
+    dmin = np.minimum(d0, d1)
+    frame_index = min(max(0, int(frame_distance) // 5), 5)
+    table = np.asarray(dist_sim_map[frame_index], np.float64)
+    xlim, ylim = table.shape
+    c0 = (dmin / F32(5)).astype(np.int64)                               # fp32 division, truncation like .long()
+    c1 = (gap / F32(FRAME_TO_YGRID[frame_index])).astype(np.int64)
+    c0 = np.clip(c0, 0, ylim - 1)
+    c1 = np.clip(c1, 0, xlim - 1)
+    return table[c1, c0] > similarity_thresh
+
+
 def match_and_filter_corr(C_batch_0, F_batch_0, C_batch_1, F_batch_1, radius=20, feature_filter="Lowe",
-                          spatial_filter="Spherical", num_corres=5000):
+                          spatial_filter="Spherical", num_corres=5000, frame_distance=None, dist_sim_map=None,
+                          similarity_thresh=0.4):
     """lib/trainer.py:1025-1151 -> (matches int64 [N,2] with the collate biases, list of per-pair [M_i,2])."""
-    assert feature_filter in ("None", "Lowe") and spatial_filter in ("Spherical", "None")
+    assert feature_filter in ("None", "Lowe") and spatial_filter in ("Spherical", "None", "Similarity")
     n1 = min(num_corres, min(len(f) for f in F_batch_0))
     n2 = min(num_corres, min(len(f) for f in F_batch_1))
     m1, m2 = [], []
@@ -100,9 +122,11 @@ def match_and_filter_corr(C_batch_0, F_batch_0, C_batch_1, F_batch_1, radius=20,
     bias2 = np.cumsum([0] + [len(f) for f in F_batch_1][:-1])
     matches = np.concatenate([np.stack([a + b1, b + b2], 1) for a, b, b1, b2 in zip(m1, m2, bias1, bias2)])
     uncollated = []
-    for C0, C1, a, b in zip(C_batch_0, C_batch_1, m1, m2):
+    for p, (C0, C1, a, b) in enumerate(zip(C_batch_0, C_batch_1, m1, m2)):
         if spatial_filter == "None":
             mask = np.ones(len(a), bool)
+        elif spatial_filter == "Similarity":
+            mask = similarity_mask(C0, C1, a, b, dist_sim_map, frame_distance[p], similarity_thresh)
         else:
             mask = (norm3(np.asarray(C0)[a]) > F32(radius)) & (norm3(np.asarray(C1)[b]) > F32(radius))
         uncollated.append(np.stack([a[mask], b[mask]], 1))

@@ -94,6 +94,50 @@ def test_match_and_filter_corr_vs_oracle(feature_filter, spatial_filter):
         assert 0 < sum(len(u) for u in ru) < len(rm)
 
 
+def synthetic_dist_sim_map(seed=0):
+    """A table of the reference's shape family (config/dist_sim_plot/*.npz: six float64 slices [gap cells, distance cells],
+    similarity decaying with both coordinates) - data, like a checkpoint; the real tables stay with the reference."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for i, shape in enumerate([(12, 16), (18, 16), (20, 18), (20, 18), (20, 18), (20, 18)]):
+        gy, gx = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), indexing="ij")
+        out[i] = np.clip(0.85 * np.exp(-0.12 * gy - 0.05 * gx) + 0.05 * rng.normal(size=shape), 0.0, 1.0)
+    return out
+
+
+def test_similarity_filter_vs_oracle():
+    """The "Similarity" spatial filter (lib/trainer.py:1118-1149): table lookup at (centre-distance gap, smaller centre
+    distance) + threshold; kept pairs and their order bit-exact against oracle/labels.similarity_mask, including the
+    clamped cells (distances beyond the table) and every frame-distance slice."""
+    import eyoc_amd
+    from oracle import labels as ol
+    rng = np.random.default_rng(44)
+    table = synthetic_dist_sim_map()
+    C0 = (rng.uniform(-1, 1, (3000, 3)) * rng.choice([5, 40, 150], (3000, 1))).astype(np.float32)
+    C1 = (rng.uniform(-1, 1, (2500, 3)) * rng.choice([5, 40, 150], (2500, 1))).astype(np.float32)
+    a = rng.integers(0, 3000, 4000)
+    b = rng.integers(0, 2500, 4000)
+    for frame_distance in (0, 4, 7, 12, 19, 26, 100):
+        for thresh in (0.4, 0.1):
+            got = eyoc_amd.similarity_filter(torch.from_numpy(C0), torch.from_numpy(C1), torch.from_numpy(a), torch.from_numpy(b),
+                                             table, frame_distance, thresh).cpu().numpy()
+            mask = ol.similarity_mask(C0, C1, a, b, table, frame_distance, thresh)
+            np.testing.assert_array_equal(got, np.stack([a[mask], b[mask]], 1))
+            assert 0 < mask.sum() < len(mask)
+    # through match_and_filter_corr
+    pairs = [make_pair(rng, 1500, 1300), make_pair(rng, 800, 2000)]
+    args = lambda f: ([f(p[0]) for p in pairs], [f(p[1]) for p in pairs], [f(p[2]) for p in pairs], [f(p[3]) for p in pairs])
+    matches, unc = eyoc_amd.match_and_filter_corr(*args(torch.from_numpy), feature_filter="Lowe", spatial_filter="Similarity",
+                                                  frame_distance=[3, 17], num_corres=600, dist_sim_map=table, similarity_thresh=0.3)
+    rm, ru = ol.match_and_filter_corr(*args(lambda x: x), 20, "Lowe", "Similarity", num_corres=600, frame_distance=[3, 17],
+                                      dist_sim_map=table, similarity_thresh=0.3)
+    np.testing.assert_array_equal(matches.numpy(), rm)
+    for x, y in zip(unc, ru):
+        np.testing.assert_array_equal(x.cpu().numpy(), y)
+    with pytest.raises(ValueError):
+        eyoc_amd.match_and_filter_corr(*args(torch.from_numpy), spatial_filter="Similarity")
+
+
 def test_correspondences_under_pose_vs_oracle():
     import eyoc_amd
     from oracle import labels as ol

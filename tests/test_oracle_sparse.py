@@ -166,3 +166,38 @@ def test_label_oracle_properties():
     out = ol.correspondences_under_pose(P0, P1, T, np.arange(0, 300, 3), 0.01)
     np.testing.assert_array_equal(out[:, 1], 299 - out[:, 0])
     assert len(out) == 100
+
+
+def test_similarity_mask_against_an_independent_torch_formulation():
+    """oracle.labels.similarity_mask (numpy) against the same rule written with torch tensor ops (norm, integer cast,
+    clamping by masked assignment, 2-D indexing) on the reference's real KITTI table when the reference tree is around
+    (this container), else on a synthetic table of the same shapes.  lib/trainer.py itself cannot be imported
+    (MinkowskiEngine / pytorch3d / open3d at module scope), so this is as close to a pin as the filter gets."""
+    import os
+    import torch
+    from oracle import labels as ol
+    path = "/root/reference/config/dist_sim_plot/kitti_distSimPlot.npz"
+    rng = np.random.default_rng(3)
+    if os.path.exists(path):
+        maps = np.load(path, allow_pickle=True)["res"].tolist()
+        table = {i: np.asarray(maps[i], np.float64) for i in range(6)}
+    else:
+        table = {i: rng.uniform(0, 1, sh) for i, sh in enumerate([(12, 16), (18, 16), (20, 18), (20, 18), (20, 18), (20, 18)])}
+    C0 = (rng.uniform(-1, 1, (2000, 3)) * rng.choice([5, 40, 150], (2000, 1))).astype(np.float32)
+    C1 = (rng.uniform(-1, 1, (2000, 3)) * rng.choice([5, 40, 150], (2000, 1))).astype(np.float32)
+    a, b = rng.integers(0, 2000, 3000), rng.integers(0, 2000, 3000)
+    for frame_distance in (0, 6, 11, 16, 23, 40):
+        fi = min(max(0, frame_distance // 5), 5)
+        t = torch.tensor(table[fi])
+        d0 = torch.norm(torch.from_numpy(C0)[a], dim=1)
+        d1 = torch.norm(torch.from_numpy(C1)[b], dim=1)
+        gap = (d0 - d1).abs()
+        dmin = torch.minimum(d0, d1)
+        c0 = (dmin / 5).long()
+        c1 = (gap / {0: 1, 1: 1.5, 2: 2, 3: 2.5, 4: 2.5, 5: 2.5}[fi]).long()
+        c0[c0 >= t.shape[1]] = t.shape[1] - 1
+        c1[c1 >= t.shape[0]] = t.shape[0] - 1
+        want = (t[c1, c0] > 0.4).numpy()
+        got = ol.similarity_mask(C0, C1, a, b, table, frame_distance, 0.4)
+        # torch.norm and the oracle's fixed-order fp32 norm can differ in the last bit: allow the cells on a boundary
+        assert (got != want).sum() <= 3, int((got != want).sum())
