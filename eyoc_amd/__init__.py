@@ -20,3 +20,4 @@ from .metrics import registration_errors, apply_transform, evaluate_nn_dist  # n
 from .voxelize import sparse_quantize, voxelize, extract_features  # noqa: F401
 from .labels import (knn2_segmented, lowe_topk, spherical_filter, similarity_filter, load_dist_sim_map,  # noqa: F401
                      match_and_filter_corr, correspondences_under_pose)
+from .autograd import sparse_conv, contrastive_hardest_negative_loss  # noqa: F401,E402

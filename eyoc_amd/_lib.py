@@ -81,6 +81,9 @@ PROTOTYPES = {
     "eyoc_spconv_packed_floats": (_sz, [_i, _i, _i]),
     "eyoc_spconv_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "eyoc_spconv_select_kernel": (_i, [_i]),
+    "eyoc_spconv_pack_weights_transposed": (_i, [_vp, _i, _i, _i, _i, _vp]),
+    "eyoc_spconv_grad_weight_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "eyoc_spconv_grad_weight": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "eyoc_spconv_pack_weights_split16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "eyoc_spconv_ex": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "eyoc_split16_encode": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),

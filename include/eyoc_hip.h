@@ -139,6 +139,19 @@ int eyoc_spconv_ex(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, cons
                    float* out_dev, int ld_out, int math, int out_split, const float* out_scale_dev, void* stream);
 int eyoc_split16_encode(eyoc_ctx* ctx, const float* in_dev, int n, int c, int ld_in, float* out_dev, int ld_out, void* stream);
 int eyoc_split16_decode(eyoc_ctx* ctx, const float* in_dev, int n, int c, int ld_in, float* out_dev, int ld_out, void* stream);
+/* Backward of one layer (the reference back-propagates through MinkowskiEngine, lib/trainer.py:1667).
+ *   grad-input: dIn[i] = sum_k dOut[o] W[k]^T over the pairs (i -> o, k) is a sparse convolution over the TRANSPOSED
+ *     rulebook - for a stride-1 table the same table with mirrored offsets (mirror = 1), for the strided (EYOC_MAP_DOWN)
+ *     table the EYOC_MAP_UP table of the same level and vice versa (mirror = 0) - so it runs eyoc_spconv on weights
+ *     packed by eyoc_spconv_pack_weights_transposed (C_in and C_out swap roles: the call has cin = C_out, cout = C_in).
+ *   grad-weight: dW[k][ci][co] = sum over o with nbr[k][o] >= 0 of in[nbr[k][o]][ci] * dout[o][co], plain [K, cin, cout]
+ *     layout, fp32 MFMA, deterministic (fixed reduction order).  C_in, C_out: multiples of 16; nbr == NULL: identity map. */
+int eyoc_spconv_pack_weights_transposed(const float* w_host /*[K,cin,cout]*/, int K, int cin, int cout, int mirror,
+                                        float* packed_host);
+size_t eyoc_spconv_grad_weight_workspace_bytes(int K, int n_out, int cin, int cout);
+int eyoc_spconv_grad_weight(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, const float* in_dev, int ld_in, int cin,
+                            const float* dout_dev, int ld_dout, int cout, float* dw_dev, void* workspace_dev,
+                            size_t workspace_bytes, void* stream);
 /* Two decompositions implement the operator (workgroup-tiled: spconv.hip, wave-private: spconv_wave.hip);
  * by default the launcher picks by problem size.  mode -1 = automatic (default), 0 = workgroup-tiled,
  * 1 = wave-private.  Process-wide; meant for parity tests and profiling.  Returns the previous mode. */
