@@ -227,6 +227,9 @@ def worker(args):
     else:
         made = make_pairs(scenes, args.nuscenes)      # before any GPU call: forks
         gen = dict(zip(scenes, made))
+        nus_pairs = None
+        if world == 1 and not total_mode and not args.no_extras and not args.nuscenes:
+            nus_pairs = make_pairs(list(range(5000, 5016)), True)   # configs[4] leg of the extras (needs the fork too)
     log(f"{len(scenes)} scenes generated for {len(mine)} pairs")
 
     edist.init(backend="gloo" if dry else None)
@@ -419,6 +422,15 @@ def worker(args):
         t_sc2 = timed_rate(pipe2, b0, 3, 1)
         ev2 = pipe2.evaluate(b0, pipe2.register(b0))
         out["sc2pcr_path"] = {"pairs_per_s": b0.P / t_sc2, "success_rate": float(np.mean([e["success"] for e in ev2]))}
+        # configs[4]: nuScenes-shaped input (32 beams, d in [5, 50] m) through the SC2-PCR back-end, 16 pairs per step
+        if nus_pairs is not None:
+            nseeds = list(range(5000, 5016))
+            bn = DeviceBatch(nus_pairs, nseeds, device, cfg.n_points, descriptor=descriptor)
+            t_n = timed_rate(pipe2, bn, 3, 1)
+            evn = pipe2.evaluate(bn, pipe2.register(bn))
+            out["nuscenes_sc2pcr_path"] = {"pairs_per_s": bn.P / t_n, "success_rate": float(np.mean([e["success"] for e in evn])),
+                                           "pairs_per_step": bn.P, "mean_voxels_per_cloud": bn.voxels // (2 * bn.P),
+                                           "planted_min": int(min(bn.planted)) if bn.planted else None}
         log("sc2pcr path done")
     if world == 1 and not total_mode and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline([gen[scene_of(i)] for i in mine[:6]], [scene_of(i) for i in mine[:6]], sd, descriptor)

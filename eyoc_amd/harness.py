@@ -41,6 +41,31 @@ class RegistrationConfig:
         nms_radius=0.6, max_points=8000, k1=30, k2=20))   # scripts/SC2_PCR/config_json/config_KITTI.json
 
 
+_SC2_KEYS = ("inlier_threshold", "num_node", "use_mutual", "d_thre", "num_iterations", "ratio", "nms_radius", "max_points",
+             "k1", "k2")
+
+
+def load_config(config, sc2pcr_config=None, use_RANSAC=True, rte_thresh=2.0, rre_thresh=5.0) -> RegistrationConfig:
+    """The reference's run configuration -> ``RegistrationConfig`` (scripts/test_kitti.py:258-292).
+
+    ``config``: the ``config.json`` a training run leaves in its ``save_dir`` (a path or the loaded dict) - the keys
+    ``model``, ``model_n_out``, ``conv1_kernel_size``, ``normalize_feature``, ``bn_momentum``, ``voxel_size`` are read,
+    everything else (trainer / loader settings) is ignored.  With ``use_RANSAC=False`` the SC2-PCR constants are merged
+    in from ``sc2pcr_config`` (path or dict; the reference reads scripts/SC2_PCR/config_json/config_KITTI.json) exactly
+    like test_kitti.py does; ``rte_thresh`` / ``rre_thresh`` are its command-line flags."""
+    import json
+
+    def as_dict(c):
+        return json.load(open(c)) if isinstance(c, (str, bytes)) or hasattr(c, "__fspath__") else dict(c)
+    c = as_dict(config)
+    kw = {k: c[k] for k in ("model", "model_n_out", "conv1_kernel_size", "normalize_feature", "bn_momentum", "voxel_size") if k in c}
+    out = RegistrationConfig(use_RANSAC=bool(use_RANSAC), rte_thresh=float(rte_thresh), rre_thresh=float(rre_thresh), **kw)
+    if not use_RANSAC and sc2pcr_config is not None:
+        sc = as_dict(sc2pcr_config)
+        out.sc2pcr = {**out.sc2pcr, **{k: sc[k] for k in _SC2_KEYS if k in sc}}
+    return out
+
+
 class DeviceBatch:
     """``P`` pairs resident in HBM: batched coordinates/features for the 2P clouds, the voxel centres'
     points, and the (seeded) sample indices of ``random_sample`` (scripts/test_kitti.py:159-160).

@@ -29,7 +29,7 @@ def test_rigid_transform_3d_vs_golden():
         T = T.cpu().numpy()
         ok = well_conditioned(A, B, w)
         print(f"kabsch golden case {i} {case}: max |T - T_ref| = {np.abs(T[ok] - g[f'T{i}'][ok]).max():.2e} over {int(ok.sum())} problems")
-        np.testing.assert_allclose(T[ok], g[f"T{i}"][ok], rtol=0, atol=5e-4, err_msg=f"case {i} {case}")
+        np.testing.assert_allclose(T[ok], g[f"T{i}"][ok], rtol=0, atol=1e-4, err_msg=f"case {i} {case}")   # realised: <= 1.6e-5
         np.testing.assert_allclose(np.linalg.det(T[:, :3, :3]), 1.0, atol=1e-5)
         np.testing.assert_array_equal(T[:, 3], np.tile([0, 0, 0, 1], (len(T), 1)))
     # CPU inputs are uploaded and the result comes back on the CPU

@@ -27,7 +27,7 @@ def test_sc2pcr_matches_reference_golden_poses():
         T, fit = m.SC2_PCR(torch.from_numpy(p0)[None].cuda(), torch.from_numpy(p1)[None].cuda())
         assert T.shape == (1, 4, 4) and fit.shape == (1, int(n * cfg["ratio"]))
         print(f"sc2pcr golden case {i}: max |T - T_ref| = {np.abs(T[0].cpu().numpy() - g[f'T{i}']).max():.2e}")
-        np.testing.assert_allclose(T[0].cpu().numpy(), g[f"T{i}"], rtol=0, atol=2e-4, err_msg=f"case {i}")
+        np.testing.assert_allclose(T[0].cpu().numpy(), g[f"T{i}"], rtol=0, atol=1e-4, err_msg=f"case {i}")   # realised: <= 3e-5
         assert float(fit.max()) == pytest.approx(float(g[f"fitmax{i}"]), abs=2)
         # seed-wise fitness: same multiset of hypotheses as the oracle up to tie-breaking noise
         To, fo = mo.SC2_PCR(torch.from_numpy(p0)[None], torch.from_numpy(p1)[None])
@@ -43,7 +43,7 @@ def test_sc2pcr_small_inputs_and_estimator():
     Tg, fit = m.SC2_PCR(torch.from_numpy(p0)[None].cuda(), torch.from_numpy(p1)[None].cuda())
     To, _ = osc.Matcher(**osc.KITTI_CFG).SC2_PCR(torch.from_numpy(p0)[None], torch.from_numpy(p1)[None])
     print(f"sc2pcr n=20 vs oracle: max |T - T_oracle| = {np.abs(Tg[0].cpu().numpy() - To[0].numpy()).max():.2e}")
-    np.testing.assert_allclose(Tg[0].cpu().numpy(), To[0].numpy(), atol=5e-4)
+    np.testing.assert_allclose(Tg[0].cpu().numpy(), To[0].numpy(), atol=1e-4)   # realised: 1.4e-6
     # estimator: descriptors that identify the correspondence exactly
     n = 600
     q0, q1, _ = gi.corr_case(82, n, T, 1.0, noise=0.01)

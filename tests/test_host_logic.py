@@ -1,0 +1,55 @@
+"""CPU tests of host-side logic of the product package that needs no GPU: the reference-config loader, the planted
+correspondences of the benchmark's descriptor mode, the split of pairs over ranks."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+
+def test_load_config_reads_the_reference_run_configuration(tmp_path):
+    from eyoc_amd.harness import load_config, RegistrationConfig
+    cfg = {"model": "ResUNetBN2C", "model_n_out": 32, "conv1_kernel_size": 5, "normalize_feature": True, "bn_momentum": 0.05,
+           "voxel_size": 0.3, "batch_size": 4, "lr": 0.1, "dataset": "KITTINMPairDataset", "optimizer": "SGD"}
+    p = tmp_path / "config.json"
+    p.write_text(json.dumps(cfg))
+    c = load_config(str(p))
+    assert isinstance(c, RegistrationConfig) and c.use_RANSAC and c.model == "ResUNetBN2C" and c.voxel_size == 0.3
+    assert c.ransac_max_iteration == 4000000 and c.n_points == 5000
+    sc = {"num_iterations": 20, "ratio": 0.2, "k1": 30, "k2": 20, "inlier_threshold": 0.6, "d_thre": 0.1, "downsample": 0.3,
+          "re_thre": 5, "te_thre": 60, "num_node": 8000, "use_mutual": False, "max_points": 8000, "nms_radius": 0.6}
+    c2 = load_config(cfg, sc, use_RANSAC=False, rte_thresh=1.0, rre_thresh=2.5)
+    assert not c2.use_RANSAC and c2.rte_thresh == 1.0 and c2.rre_thresh == 2.5
+    assert c2.sc2pcr["num_node"] == 8000 and c2.sc2pcr["nms_radius"] == 0.6 and "downsample" not in c2.sc2pcr
+    # the reference's own SC2-PCR constants, when its tree is around
+    ref = "/root/reference/scripts/SC2_PCR/config_json/config_KITTI.json"
+    if os.path.exists(ref):
+        c3 = load_config(cfg, ref, use_RANSAC=False)
+        assert c3.sc2pcr == RegistrationConfig().sc2pcr          # the defaults ARE config_KITTI.json
+
+
+def test_planted_correspondences_have_the_stated_inlier_ratio():
+    from eyoc_amd import synthetic as syn
+    p = syn.make_pair(5, beams=32, azimuths=1000, band=None)
+    for ratio in (0.1, 0.3):
+        d = syn.plant_correspondences(p, 5, 2000, ratio)
+        assert d["sel0"].shape == d["sel1"].shape == (2000,) and d["G0"].shape == (2000, 32)
+        np.testing.assert_allclose(np.linalg.norm(d["G0"], axis=1), 1.0, atol=1e-5)
+        nn = np.argmax(d["G0"] @ d["G1"].T, 1)                   # the match a descriptor-only nearest neighbour finds
+        T = p["T_gt"].astype(np.float64)
+        r = p["xyz0"][d["sel0"]] @ T[:3, :3].T + T[:3, 3] - p["xyz1"][d["sel1"]][nn]
+        realised = float((np.linalg.norm(r, axis=1) < 0.3).mean())
+        assert d["planted"] == round(ratio * 2000) and abs(realised - ratio) < 0.02
+        assert len(set(d["sel1"][:]) ) == 2000 and len(set(d["sel0"])) == 2000     # no sample drawn twice
+    # deterministic in (pair, seed)
+    a, b = syn.plant_correspondences(p, 5, 500, 0.3), syn.plant_correspondences(p, 5, 500, 0.3)
+    np.testing.assert_array_equal(a["sel0"], b["sel0"]); np.testing.assert_array_equal(a["G1"], b["G1"])
+
+
+def test_round_robin_shard_covers_every_pair_once():
+    from eyoc_amd import dist as edist
+    for total, world in ((545, 8), (994, 8), (7, 2), (3, 4)):
+        seen = sorted(i for r in range(world) for i in edist.shard(total, r, world))
+        assert seen == list(range(total))
+        sizes = [len(edist.shard(total, r, world)) for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1
