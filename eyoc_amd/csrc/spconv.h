@@ -74,6 +74,8 @@ __device__ inline float4 split16_load4(const float* row, int c) {
 }
 
 int launch_spconv(const SpconvArgs& a, hipStream_t st);
+int launch_spconv_rs(const SpconvArgs& a, hipStream_t st);     // row-stationary, SPLIT16 only (spconv_rs.hip)
+bool spconv_rs_fits(const SpconvArgs& a);
 int spconv_forced_kernel();   // eyoc_spconv_select_kernel state: -1 automatic, 0 workgroup-tiled, 1 wave-private
 int launch_spconv_wave(const SpconvArgs& a, hipStream_t st);   // wave-private tiling (spconv_wave.hip)
 

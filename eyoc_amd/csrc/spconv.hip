@@ -592,6 +592,9 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
   if (a.math != 0 || a.out_split) {   // SPLIT16 rows exist in the wave-private kernel only
     EYOC_REQUIRE(wave_ok, EYOC_ERR_INVALID, "spconv: a normalised %d-channel layer has no split16 kernel", a.cout);
     EYOC_REQUIRE(a.math == 0 || a.cin % 8 == 0, EYOC_ERR_INVALID, "spconv: split16 needs C_in %% 8 == 0");
+    // split16 layers: the row-stationary kernel (spconv_rs.hip) unless EYOC_SPCONV_RS=0 asks for the wave-private one
+    static const int use_rs = getenv("EYOC_SPCONV_RS") ? atoi(getenv("EYOC_SPCONV_RS")) : 1;
+    if (a.math == 1 && use_rs && spconv_rs_fits(a)) return launch_spconv_rs(a, st);
     return launch_spconv_wave(a, st);
   }
   if (wave_ok && (force > 0 || (force < 0 && wave_tiles >= 4096))) return launch_spconv_wave(a, st);

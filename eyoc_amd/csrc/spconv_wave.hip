@@ -251,23 +251,39 @@ __global__ __launch_bounds__((WCfg<CTW, BMW, CC, NCMAX>::WPB * 64), OCC) void sp
                        const float4 (&W)[C::JQ][C::NTW], const int (&orow)[NCMAX]) {
       constexpr int NC = decltype(nc_tag)::value;
       if constexpr (MATH == 1) {
-        // three fp16 MFMAs per (chunk, tile, 32-channel block): W_hi X_hi, W_hi X_lo, W_lo X_hi
+        // three fp16 MFMAs per (chunk, tile, 32-channel block): W_hi X_hi, W_hi X_lo, W_lo X_hi.  The first one of an
+        // item's first C_in slice takes a literal zero as its C operand (no accumulator clearing); that choice is made
+        // ONCE per unit - a test inside the loops costs a scalar branch per MFMA and fences the schedule
+        if (first_cc) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int t = 0; t < C::NTW; ++t)
+              accr[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, W[0][t]), __builtin_bit_cast(half8_t, G[0][c]),
+                                                                  f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int t = 0; t < C::NTW; ++t)
+              accr[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, W[0][t]), __builtin_bit_cast(half8_t, G[0][c]),
+                                                                  accr[c][t], 0, 0, 0);
+        }
 #pragma unroll
         for (int qq = 0; qq < C::JQ / 2; ++qq)
 #pragma unroll
-          for (int term = 0; term < 3; ++term)
+          for (int term = 0; term < 3; ++term) {
+            if (qq == 0 && term == 0) continue;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
               const half8_t xv = __builtin_bit_cast(half8_t, G[2 * qq + (term == 1 ? 1 : 0)][c]);
 #pragma unroll
               for (int t = 0; t < C::NTW; ++t) {
                 const half8_t wv = __builtin_bit_cast(half8_t, W[2 * qq + (term == 2 ? 1 : 0)][t]);
-                if (first_cc && qq == 0 && term == 0)
-                  accr[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                else
-                  accr[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, accr[c][t], 0, 0, 0);
+                accr[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, accr[c][t], 0, 0, 0);
               }
             }
+          }
       } else {
       // the first MFMA of an item's first C_in slice takes a literal zero as its C operand: no accumulator clearing
       {
