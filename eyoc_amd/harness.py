@@ -70,7 +70,7 @@ class DeviceBatch:
     """``P`` pairs resident in HBM: batched coordinates/features for the 2P clouds, the voxel centres'
     points, and the (seeded) sample indices of ``random_sample`` (scripts/test_kitti.py:159-160).
 
-    ``descriptor=dict(inlier_ratio=p, beta=8.0, plant_radius=0.2)`` switches on the benchmark's descriptor mode
+    ``descriptor=dict(inlier_ratio=p, beta=8.0, plant_radius=0.3)`` switches on the benchmark's descriptor mode
     (``synthetic.plant_correspondences``): the sample sets contain ``p * n_points`` ground-truth partners and the
     per-sample descriptors ``G0 / G1`` are blended into the network's features inside the timed path
     (``eyoc_gather_rows``), so that the matcher sees a stated inlier ratio instead of the zero signal of
@@ -96,7 +96,7 @@ class DeviceBatch:
             planted = None
             if self.descriptor:
                 planted = plant_correspondences(p, seed, n_points, self.descriptor.get("inlier_ratio", 0.3),
-                                                self.descriptor.get("plant_radius", 0.2), self.descriptor.get("feat_dim", 32))
+                                                self.descriptor.get("plant_radius", 0.3), self.descriptor.get("feat_dim", 32))
                 G0.append(planted["G0"]); G1.append(planted["G1"]); self.planted.append(planted["planted"])
             for i, (sel, xyz) in enumerate(((sel0, xyz0), (sel1, xyz1))):
                 n = self.sizes[2 * j + i]
