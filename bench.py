@@ -349,7 +349,7 @@ def worker(args):
     achieved_tf = flops / (conv_ms * 1e-3) / 1e12
     achieved_gbs = gather / (conv_ms * 1e-3) / 1e9
     math_mode = model.last_spconv_math
-    kernel = "spconv_wave_kernel<...> (the 22 sparse-conv launches of one forward, summed)"
+    kernel = ("spconv_rs_kernel<...>" if math_mode == "split16" else "spconv_wave_kernel<...>") + " (the 22 sparse-conv launches of one forward, summed)"
     if math_mode == "split16":
         # split16: every algorithmic fp32 multiply-add is three fp16 MFMA multiply-adds at ~1.25 PFLOP/s
         # (v_mfma_f32_16x16x32_f16, measured by scripts/micro/mfma_f16_rates.hip), i.e. an ideal matrix time of

@@ -287,7 +287,7 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
   static const int env_math = getenv("EYOC_SPCONV_MATH") ? atoi(getenv("EYOC_SPCONV_MATH")) : -1;
   const int want = m->math >= 0 ? m->math : env_math;
   const bool split_ok = spconv_forced_kernel() != 0 && !(m->desc.normalize_feature && m->desc.out_channels > 64) &&
-                        m->desc.channels[1] % 8 == 0;
+                        m->desc.channels[1] % 32 == 0;
   const bool split = split_ok && (want == 1 || (want < 0 && cdiv(maps->rows[0], 64) >= 4096));
   EYOC_REQUIRE(want != 1 || split, EYOC_ERR_INVALID,
                "eyoc_model_forward: split16 arithmetic is not available for this model / kernel selection");

@@ -37,12 +37,16 @@ struct SpconvArgs {
   int small_rows = 0;
 };
 
-// ---- SPLIT16 row format: every group of 8 channels takes 32 bytes, the 8 fp16 "hi" halves (x rounded to fp16)
-// followed by the 8 fp16 "lo" halves (x - hi rounded to fp16): the same 4 bytes per channel as fp32, 22 significant
-// bits (hi + lo reproduces x to 2^-22 relative, or 2^-25 absolute below 2^-3: fp16 subnormals are honoured by the
-// fp16 MFMA on gfx950, scripts/micro/mfma_f16_denorm.hip).  Channel c of a row lives at byte (c / 8) * 32 + (c % 8) * 2
-// (hi) and + 16 (lo), so leading dimensions and column offsets stay what they are for fp32 rows as long as they
-// are multiples of 8 channels.
+// ---- SPLIT16 row format: every block of 32 channels takes 128 bytes (one cache line), the 32 fp16 "hi" halves (x rounded
+// to fp16) followed by the 32 fp16 "lo" halves (x - hi rounded to fp16): the same 4 bytes per channel as fp32, 22
+// significant bits (hi + lo reproduces x to 2^-22 relative, or 2^-25 absolute below 2^-3: fp16 subnormals are honoured by
+// the fp16 MFMA on gfx950, scripts/micro/mfma_f16_denorm.hip).  Channel c of a row lives at byte (c / 32) * 128 +
+// (c % 32) * 2 (hi) and + 64 (lo), so leading dimensions and column offsets stay what they are for fp32 rows as long as
+// they are multiples of 32 channels.  The 64-byte halves matter: the four lanes that gather one row's MFMA operand read
+// 64 CONTIGUOUS bytes per instruction (hi halves of 32 channels, then the lo halves).  An earlier layout interleaved hi
+// and lo per 8 channels; each gather instruction then touched both 64-byte sectors of the line, and the HBM-side read
+// traffic of the row-stationary kernel was 1.5x the algorithmic gather bytes (FETCH_SIZE, calibrated with
+// scripts/micro/fetch_calib.hip).
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 
@@ -58,19 +62,20 @@ __device__ inline float4 split16_decode4(const uint2 hi, const uint2 lo) {
   const half4_t h = __builtin_bit_cast(half4_t, hi), l = __builtin_bit_cast(half4_t, lo);
   return make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
 }
-// byte offset of the hi halves of channels [c, c + 4) (c % 4 == 0) inside a SPLIT16 row; the lo halves sit 16 bytes on
-__host__ __device__ inline int split16_off4(int c) { return (c >> 3) * 32 + (c & 7) * 2; }
+// byte offset of the hi halves of channels [c, c + 4) (c % 4 == 0) inside a SPLIT16 row; the lo halves sit 64 bytes on
+__host__ __device__ inline int split16_off4(int c) { return (c >> 5) * 128 + (c & 31) * 2; }
+constexpr int SPLIT16_LO = 64;   // byte distance from a channel's hi half to its lo half
 // store / load 4 consecutive channels of a SPLIT16 row that starts at `row` (fp32-typed pointer, 4 bytes per channel)
 __device__ inline void split16_store4(float* row, int c, const float4 v) {
   uint2 hi, lo;
   split16_encode4(v, hi, lo);
   char* p = reinterpret_cast<char*>(row) + split16_off4(c);
   *reinterpret_cast<uint2*>(p) = hi;
-  *reinterpret_cast<uint2*>(p + 16) = lo;
+  *reinterpret_cast<uint2*>(p + SPLIT16_LO) = lo;
 }
 __device__ inline float4 split16_load4(const float* row, int c) {
   const char* p = reinterpret_cast<const char*>(row) + split16_off4(c);
-  return split16_decode4(*reinterpret_cast<const uint2*>(p), *reinterpret_cast<const uint2*>(p + 16));
+  return split16_decode4(*reinterpret_cast<const uint2*>(p), *reinterpret_cast<const uint2*>(p + SPLIT16_LO));
 }
 
 int launch_spconv(const SpconvArgs& a, hipStream_t st);

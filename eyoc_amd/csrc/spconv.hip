@@ -562,6 +562,9 @@ namespace eyoc {
 
 static int g_kernel_mode = getenv("EYOC_SPCONV_WAVE") ? atoi(getenv("EYOC_SPCONV_WAVE")) : -1;
 
+// split16 layers: 1 = choose per layer (default), 0 = always the wave-private kernel, 2 = always the row-stationary one
+static int g_split16_kernel = getenv("EYOC_SPCONV_RS") ? atoi(getenv("EYOC_SPCONV_RS")) : 1;
+
 int spconv_forced_kernel() { return g_kernel_mode; }
 
 int launch_spconv(const SpconvArgs& a, hipStream_t st) {
@@ -591,10 +594,15 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
   const bool wave_ok = !(a.l2norm && a.cout > 64);
   if (a.math != 0 || a.out_split) {   // SPLIT16 rows exist in the wave-private kernel only
     EYOC_REQUIRE(wave_ok, EYOC_ERR_INVALID, "spconv: a normalised %d-channel layer has no split16 kernel", a.cout);
-    EYOC_REQUIRE(a.math == 0 || a.cin % 8 == 0, EYOC_ERR_INVALID, "spconv: split16 needs C_in %% 8 == 0");
+    EYOC_REQUIRE(a.math == 0 || (a.cin % 32 == 0 && a.ld_in % 32 == 0), EYOC_ERR_INVALID, "spconv: split16 rows come in blocks of 32 channels");
+    EYOC_REQUIRE(!a.out_split || a.ld_out % 32 == 0, EYOC_ERR_INVALID, "spconv: split16 output rows come in blocks of 32 channels");
     // split16 layers: the row-stationary kernel (spconv_rs.hip) unless EYOC_SPCONV_RS=0 asks for the wave-private one
-    static const int use_rs = getenv("EYOC_SPCONV_RS") ? atoi(getenv("EYOC_SPCONV_RS")) : 1;
-    if (a.math == 1 && use_rs && spconv_rs_fits(a)) return launch_spconv_rs(a, st);
+    const int use_rs = g_split16_kernel;
+    // measured per layer of the 64-pair bench: the row-stationary kernel wins on the stride-1, transposed and 1x1 layers
+    // with C_in >= 64 (-5 .. -15 %); the 32-channel layers and the strided convolutions (few, scattered pairs per
+    // output row: 2.9x more zero MFMAs buy nothing there) stay on the wave-private kernel
+    const bool rs_layer = a.cin >= 64 && !(a.n_in > a.n_out);
+    if (a.math == 1 && spconv_rs_fits(a) && (use_rs == 2 || (use_rs == 1 && rs_layer))) return launch_spconv_rs(a, st);
     return launch_spconv_wave(a, st);
   }
   if (wave_ok && (force > 0 || (force < 0 && wave_tiles >= 4096))) return launch_spconv_wave(a, st);
@@ -735,29 +743,35 @@ int eyoc_spconv_pack_weights_split16(const float* w, const float* scale, int K, 
   return EYOC_OK;
 }
 
-int eyoc_spconv_ex(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, const float* in_dev, int ld_in, int cin,
+int eyoc_spconv_select_split16_kernel(int mode) {
+  const int prev = eyoc::g_split16_kernel;
+  if (mode >= 0 && mode <= 2) eyoc::g_split16_kernel = mode;
+  return prev;
+}
+
+int eyoc_spconv_ex(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, int n_in, const float* in_dev, int ld_in, int cin,
                    const float* wpacked_dev, int cout, const float* bias_dev, const float* res_dev, int ld_res, int relu,
                    float* out_dev, int ld_out, int math, int out_split, const float* out_scale_dev, void* stream) {
   EYOC_REQUIRE(ctx, EYOC_ERR_INVALID, "eyoc_spconv_ex: NULL ctx");
   EYOC_REQUIRE(math == 0 || math == 1, EYOC_ERR_INVALID, "eyoc_spconv_ex: math %d", math);
   SpconvArgs a;
-  a.nbr = nbr_dev; a.K = K; a.n_out = n_out; a.in = in_dev; a.ld_in = ld_in; a.cin = cin; a.w = wpacked_dev;
+  a.nbr = nbr_dev; a.K = K; a.n_out = n_out; a.n_in = n_in; a.in = in_dev; a.ld_in = ld_in; a.cin = cin; a.w = wpacked_dev;
   a.cout = cout; a.bias = bias_dev; a.res = res_dev; a.ld_res = ld_res; a.relu = relu; a.l2norm = 0;
   a.out = out_dev; a.ld_out = ld_out; a.math = math; a.out_split = out_split; a.out_scale = out_scale_dev;
   return launch_spconv(a, (hipStream_t)stream);
 }
 
 int eyoc_split16_encode(eyoc_ctx* ctx, const float* in_dev, int n, int c, int ld_in, float* out_dev, int ld_out, void* stream) {
-  EYOC_REQUIRE(ctx && in_dev && out_dev && n >= 0 && c > 0 && c % 8 == 0 && ld_in % 4 == 0 && ld_out % 8 == 0, EYOC_ERR_INVALID,
-               "eyoc_split16_encode: bad argument (c %d must be a multiple of 8)", c);
+  EYOC_REQUIRE(ctx && in_dev && out_dev && n >= 0 && c > 0 && c % 32 == 0 && ld_in % 4 == 0 && ld_out % 32 == 0, EYOC_ERR_INVALID,
+               "eyoc_split16_encode: bad argument (c %d must be a multiple of 32)", c);
   if (n) hipLaunchKernelGGL(k_split16_encode, dim3(cdiv((long long)n * (c / 4), 256)), dim3(256), 0, (hipStream_t)stream, in_dev, n, c, ld_in, out_dev, ld_out);
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
 }
 
 int eyoc_split16_decode(eyoc_ctx* ctx, const float* in_dev, int n, int c, int ld_in, float* out_dev, int ld_out, void* stream) {
-  EYOC_REQUIRE(ctx && in_dev && out_dev && n >= 0 && c > 0 && c % 8 == 0 && ld_in % 8 == 0 && ld_out % 4 == 0, EYOC_ERR_INVALID,
-               "eyoc_split16_decode: bad argument (c %d must be a multiple of 8)", c);
+  EYOC_REQUIRE(ctx && in_dev && out_dev && n >= 0 && c > 0 && c % 32 == 0 && ld_in % 32 == 0 && ld_out % 4 == 0, EYOC_ERR_INVALID,
+               "eyoc_split16_decode: bad argument (c %d must be a multiple of 32)", c);
   if (n) hipLaunchKernelGGL(k_split16_decode, dim3(cdiv((long long)n * (c / 4), 256)), dim3(256), 0, (hipStream_t)stream, in_dev, n, c, ld_in, out_dev, ld_out);
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;

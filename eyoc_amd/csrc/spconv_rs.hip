@@ -123,11 +123,12 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_rs_kernel(SpconvArgs a) {
   auto gather = [&](int qb, const int (&idx)[NC], float4 (&X)[NC][2]) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      // the 32 bytes of the row that hold channels 32 qb + 8 g .. +7: 16 B of hi halves, 16 B of lo halves
-      const unsigned int off = idx[c] >= 0 ? (unsigned)idx[c] * ld_bytes + (unsigned)(qb * 32 + g * 8) * 4u : OOB;
+      // channels 32 qb + 8 g .. +7 of the row: 16 B of hi halves in the first 64 bytes of the block's line, 16 B of lo
+      // halves in the second - the four lanes of a row read 64 contiguous bytes per instruction
+      const unsigned int off = idx[c] >= 0 ? (unsigned)idx[c] * ld_bytes + (unsigned)(qb * 128 + g * 16) : OOB;
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, idx[c] >= 0 ? off + 16u * p : OOB, 0, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, idx[c] >= 0 ? off + 64u * p : OOB, 0, 0);
         X[c][p] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
       }
     }

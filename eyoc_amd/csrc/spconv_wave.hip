@@ -26,7 +26,7 @@
 // and a product block is three MFMAs, W_hi X_hi + W_hi X_lo + W_lo X_hi, accumulated in fp32 (the dropped lo*lo term
 // is 2^-22 relative).  Activations are STORED in that format by the producing layer's epilogue (4 bytes per channel
 // like fp32, so gather bytes are unchanged) and weights are split on the host, so the hot loop has no conversions:
-// lane (g, j) reads the 32 bytes of pair j's row that hold channels 32q + 8g .. +7 (16 B hi, 16 B lo) = operand
+// lane (g, j) reads the two 16-byte pieces of pair j's row that hold channels 32q + 8g .. +7 (hi, lo) = operand
 // element [k-slots 8g .. 8g+7][column j] of v_mfma_f32_16x16x32_f16.  48 MFMAs of 32 cycles per unit instead of 128.
 // Errors against an fp64 oracle are those of the fp32 path (tests/test_gpu_split16.py).
 #include <cstdlib>
@@ -214,7 +214,7 @@ __global__ __launch_bounds__((WCfg<CTW, BMW, CC, NCMAX>::WPB * 64), OCC) void sp
 #pragma unroll
       for (int c = 0; c < NCMAX; ++c) {
         const unsigned rec = L[c * 16];
-        gp[c] = a.in + (size_t)(rec >> 8) * a.ld_in + g * (MATH ? 8 : 4);
+        gp[c] = a.in + (size_t)(rec >> 8) * a.ld_in + g * 4;
         const int row = (int)(rec & 255u);
         orow[c] = row * (CTW * 4) + (((g ^ row) & (C::C4N - 1)) << 4);
       }
@@ -227,9 +227,9 @@ __global__ __launch_bounds__((WCfg<CTW, BMW, CC, NCMAX>::WPB * 64), OCC) void sp
 #if EYOC_ABL == 1 || EYOC_ABL >= 5
           G[q][c] = make_float4((float)lane, 1.f, 2.f, (float)cc_);
 #else
-          // fp32: channels 16 q + 4 g .. +3.  SPLIT16: fragment q = 2 q' + p is the hi (p = 0) / lo (p = 1) half of the
-          // 32-byte group holding channels 32 q' + 8 g .. +7
-          G[q][c] = *reinterpret_cast<const float4*>(gp[c] + cc_ * CC + (MATH ? (q >> 1) * 32 + (q & 1) * 4 : q * 16));
+          // fp32: channels 16 q + 4 g .. +3.  SPLIT16: fragment q = 2 q' + p holds the hi (p = 0) / lo (p = 1) halves of
+          // channels 32 q' + 8 g .. +7: 16 bytes at g * 16 inside the first / second 64 bytes of block q' (spconv.h)
+          G[q][c] = *reinterpret_cast<const float4*>(gp[c] + cc_ * CC + (MATH ? (q >> 1) * 32 + (q & 1) * 16 : q * 16));
 #endif
         }
     };

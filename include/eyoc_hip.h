@@ -127,14 +127,20 @@ int eyoc_spconv(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, const f
                 int ld_in, int cin, const float* wpacked_dev, int cout, const float* bias_dev,
                 const float* res_dev, int ld_res, int relu, float* out_dev, int ld_out, void* stream);
 /* The same layer on the fp16 matrix pipe at fp32 accuracy ("split16", eyoc_amd/csrc/spconv_wave.hip): math = 1 expects
- * `in_dev` / `res_dev` rows in the SPLIT16 format (eyoc_split16_encode: per 8 channels 16 B of fp16 hi halves + 16 B
- * of fp16 lo halves, x = hi + lo to 2^-22 - the same 4 bytes per channel, so leading dimensions are unchanged) and
+ * `in_dev` / `res_dev` rows in the SPLIT16 format (eyoc_split16_encode: per 32 channels 64 B of fp16 hi halves + 64 B
+ * of fp16 lo halves, x = hi + lo to 2^-22 - the same 4 bytes per channel, so leading dimensions are unchanged; column
+ * offsets and widths must be multiples of 32 channels) and
  * weights packed by eyoc_spconv_pack_weights_split16, which also returns the scalar the kernel multiplies its sums
  * with (upload it and pass it as out_scale_dev).  out_split = 1 writes SPLIT16 rows, 0 fp32 rows.  math = 0 is
- * eyoc_spconv.  Always runs the wave-private kernel. */
+ * eyoc_spconv.  n_in = rows of the input tensor (0 = unknown: every entry of nbr is assumed < 2^24).  Two kernels
+ * implement split16 layers - wave-private (spconv_wave.hip, pair compaction + LDS accumulators) and row-stationary
+ * (spconv_rs.hip, register accumulators + zero operands, weights shared through LDS); the launcher picks per layer,
+ * eyoc_spconv_select_split16_kernel forces one (0 wave-private, 2 row-stationary, 1 automatic; returns the previous
+ * mode; process-wide, for tests and profiling). */
+int eyoc_spconv_select_split16_kernel(int mode);
 int eyoc_spconv_pack_weights_split16(const float* w_host, const float* scale_host, int K, int cin, int cout,
                                      float* packed_host, float* out_scale_host);
-int eyoc_spconv_ex(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, const float* in_dev, int ld_in, int cin,
+int eyoc_spconv_ex(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, int n_in, const float* in_dev, int ld_in, int cin,
                    const float* wpacked_dev, int cout, const float* bias_dev, const float* res_dev, int ld_res, int relu,
                    float* out_dev, int ld_out, int math, int out_split, const float* out_scale_dev, void* stream);
 int eyoc_split16_encode(eyoc_ctx* ctx, const float* in_dev, int n, int c, int ld_in, float* out_dev, int ld_out, void* stream);

@@ -49,7 +49,7 @@ for kind, lvl, cin, cout in cfgs:
     perm = torch.empty(n_out, dtype=torch.int32, device="cuda")
 
     def run():
-        _lib.check(lib.eyoc_spconv_ex(_lib.ctx(), tab, 27, n_out, _lib.ptr(x), cin, cin, _lib.ptr(wd), cout, None, None, 0, 0,
+        _lib.check(lib.eyoc_spconv_ex(_lib.ctx(), tab, 27, n_out, n_in, _lib.ptr(x), cin, cin, _lib.ptr(wd), cout, None, None, 0, 0,
                                       _lib.ptr(out), cout, MATH, MATH, _lib.ptr(osd), _lib.stream_ptr()))
     for _ in range(3):
         run()

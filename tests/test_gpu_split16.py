@@ -21,6 +21,15 @@ def _lib():
     return L, L.load()
 
 
+@pytest.fixture(params=[0, 2], ids=["wave-private", "row-stationary"], autouse=True)
+def split16_kernel(request):
+    """Every test runs on both split16 kernels (spconv_wave.hip MATH = 1 / spconv_rs.hip); production picks per layer."""
+    L, lib = _lib()
+    prev = lib.eyoc_spconv_select_split16_kernel(request.param)
+    yield request.param
+    lib.eyoc_spconv_select_split16_kernel(prev)
+
+
 def encode(x):
     L, lib = _lib()
     x = x.contiguous()
@@ -47,8 +56,8 @@ def test_split16_row_format_round_trip():
     bound = np.maximum(np.abs(x) * 2.0 ** -21, 2.0 ** -24)      # 22-bit significand, fp16 subnormal floor of the lo half
     assert (err <= bound).all(), float((err / bound).max())
     print(f"split16 round trip: max rel err {float((err / np.maximum(np.abs(x), 1e-30))[np.abs(x) > 0.125].max()):.2e}")
-    # layout: per 8 channels 8 fp16 hi then 8 fp16 lo
-    raw = enc.cpu().numpy().view(np.float16).reshape(len(x), 8, 2, 8)
+    # layout: per 32 channels 32 fp16 hi (64 bytes) then 32 fp16 lo (64 bytes)
+    raw = enc.cpu().numpy().view(np.float16).reshape(len(x), 2, 2, 32)
     np.testing.assert_array_equal(raw[:, :, 0, :].reshape(len(x), 64), x.astype(np.float16))
     hi = raw[:, :, 0, :].reshape(len(x), 64).astype(np.float32)
     np.testing.assert_array_equal(raw[:, :, 1, :].reshape(len(x), 64), (x - hi).astype(np.float16))
@@ -70,7 +79,7 @@ def run_layer_split(nbr, x, W, bias=None, scale=None, res=None, relu=False, out_
     wd, osd = torch.from_numpy(packed).to(dev), torch.from_numpy(os_).to(dev)
     bd = None if bias is None else torch.from_numpy(np.ascontiguousarray(bias, np.float32)).to(dev)
     nd = None if nbr is None else torch.from_numpy(np.ascontiguousarray(nbr, np.int32)).to(dev)
-    L.check(lib.eyoc_spconv_ex(L.ctx(), L.ptr(nd), K, n_out, L.ptr(xin), xin.stride(0), cin, L.ptr(wd), cout, L.ptr(bd), L.ptr(rin),
+    L.check(lib.eyoc_spconv_ex(L.ctx(), L.ptr(nd), K, n_out, x.shape[0], L.ptr(xin), xin.stride(0), cin, L.ptr(wd), cout, L.ptr(bd), L.ptr(rin),
                                0 if rin is None else rin.stride(0), 1 if relu else 0, L.ptr(out), out.stride(0), 1,
                                1 if out_split else 0, L.ptr(osd), L.stream_ptr()), "eyoc_spconv_ex")
     if out_split:
