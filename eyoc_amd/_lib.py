@@ -87,6 +87,9 @@ PROTOTYPES = {
     "eyoc_spconv_pack_weights_split16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "eyoc_spconv_ex": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "eyoc_spconv_select_split16_kernel": (_i, [_i]),
+    "eyoc_spconv_local_rulebook_bytes": (_sz, [_i]),
+    "eyoc_spconv_build_local_rulebook": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "eyoc_spconv_staged": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "eyoc_split16_encode": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "eyoc_split16_decode": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "eyoc_model_set_math": (_i, [_vp, _i]),

@@ -28,6 +28,7 @@ struct SpconvArgs {
   // eyoc_spconv_pack_weights_split16, three v_mfma_f32_16x16x32_f16 per product block (hi*hi + hi*lo + lo*hi).
   int math = 0;
   int out_split = 0;               // write SPLIT16 rows (internal activations) instead of fp32 rows
+  const unsigned char* local = nullptr;   // per-tile local rulebooks of `nbr` (build_local_rulebook) or NULL: enables the staged kernel
   const float* out_scale = nullptr;  // device scalar multiplied into the accumulated sums (undoes the weight pre-scale); NULL = 1
   // optional: a permutation of the output rows; tiles take rows in this order (any order gives the same result,
   // a good one makes the rows of a tile share their occupied offsets).  NULL = natural order.
@@ -78,7 +79,15 @@ __device__ inline float4 split16_load4(const float* row, int c) {
   return split16_decode4(*reinterpret_cast<const uint2*>(p), *reinterpret_cast<const uint2*>(p + SPLIT16_LO));
 }
 
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits for
+// every global load the wave has in flight - which turns a software pipeline whose loads are meant to land a stage
+// later (gathers, weight pieces) into a blocking one: each stage then pays a full memory latency at its barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 int launch_spconv(const SpconvArgs& a, hipStream_t st);
+int launch_spconv_st(const SpconvArgs& a, const unsigned char* local_dev, hipStream_t st);   // tile-local input stage (spconv_st.hip)
+size_t local_rulebook_bytes(int n_out);
+int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st);
 int launch_spconv_rs(const SpconvArgs& a, hipStream_t st);     // row-stationary, SPLIT16 only (spconv_rs.hip)
 bool spconv_rs_fits(const SpconvArgs& a);
 int spconv_forced_kernel();   // eyoc_spconv_select_kernel state: -1 automatic, 0 workgroup-tiled, 1 wave-private

@@ -601,6 +601,11 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
     // measured per layer of the 64-pair bench: the row-stationary kernel wins on the stride-1, transposed and 1x1 layers
     // with C_in >= 64 (-5 .. -15 %); the 32-channel layers and the strided convolutions (few, scattered pairs per
     // output row: 2.9x more zero MFMAs buy nothing there) stay on the wave-private kernel
+    if (a.math == 1 && a.local && use_rs != 0 && a.K == 27 && !a.l2norm) {   // stride-1 table with local rulebooks: staged kernel
+      SpconvArgs b = a;
+      b.perm = nullptr;
+      return launch_spconv_st(b, a.local, st);
+    }
     const bool rs_layer = a.cin >= 64 && !(a.n_in > a.n_out);
     if (a.math == 1 && spconv_rs_fits(a) && (use_rs == 2 || (use_rs == 1 && rs_layer))) return launch_spconv_rs(a, st);
     return launch_spconv_wave(a, st);
@@ -741,6 +746,28 @@ int eyoc_spconv_pack_weights_split16(const float* w, const float* scale, int K, 
                 out[q8++] = (jq & 1) ? (_Float16)(v - (float)h) : h;
               }
   return EYOC_OK;
+}
+
+size_t eyoc_spconv_local_rulebook_bytes(int n_out) { return n_out < 0 ? 0 : local_rulebook_bytes(n_out) + 256; }
+
+int eyoc_spconv_build_local_rulebook(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, void* out_dev, int32_t* overflow_dev,
+                                     void* stream) {
+  EYOC_REQUIRE(ctx && nbr_dev && out_dev && overflow_dev && K >= 1 && K <= 27 && n_out >= 0, EYOC_ERR_INVALID,
+               "eyoc_spconv_build_local_rulebook: bad argument");
+  EYOC_CHECK_HIP(hipMemsetAsync(overflow_dev, 0, 4, (hipStream_t)stream));
+  return build_local_rulebook(nbr_dev, K, n_out, (unsigned char*)out_dev, overflow_dev, (hipStream_t)stream);
+}
+
+int eyoc_spconv_staged(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* local_dev, int n_out, int n_in, const float* in_dev, int ld_in,
+                       int cin, const float* wpacked_dev, int cout, const float* bias_dev, const float* res_dev, int ld_res, int relu,
+                       float* out_dev, int ld_out, int out_split, const float* out_scale_dev, void* stream) {
+  EYOC_REQUIRE(ctx && nbr_dev && local_dev, EYOC_ERR_INVALID, "eyoc_spconv_staged: NULL argument");
+  SpconvArgs a;
+  a.nbr = nbr_dev; a.K = 27; a.n_out = n_out; a.n_in = n_in; a.in = in_dev; a.ld_in = ld_in; a.cin = cin; a.w = wpacked_dev;
+  a.cout = cout; a.bias = bias_dev; a.res = res_dev; a.ld_res = ld_res; a.relu = relu; a.l2norm = 0;
+  a.out = out_dev; a.ld_out = ld_out; a.math = 1; a.out_split = out_split; a.out_scale = out_scale_dev;
+  a.local = (const unsigned char*)local_dev;
+  return launch_spconv(a, (hipStream_t)stream);
 }
 
 int eyoc_spconv_select_split16_kernel(int mode) {

@@ -218,7 +218,9 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_rs_kernel(SpconvArgs a) {
         store_w((s + 1) % RING, P_s1);                                                 // registers -> LDS, one stage ahead
       }
       multiply(s % RING, X_c);
-      __syncthreads();   // ring[(s + 1) % 3] complete for everyone; ring[s % 3] free again from stage s + 2's store on
+      lds_barrier();     // ring[(s + 1) % 3] complete for everyone; ring[s % 3] free again from stage s + 2's store on.
+                         // NOT __syncthreads(): that drains vmcnt and would wait for the gather and the weight pieces
+                         // issued above, which are meant to land during the NEXT stage
     };
     for (int s = 0; s < n_stages; s += 2) {
       step(s, XA, XB, PB, PA);

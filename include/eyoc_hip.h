@@ -138,6 +138,17 @@ int eyoc_spconv(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, const f
  * eyoc_spconv_select_split16_kernel forces one (0 wave-private, 2 row-stationary, 1 automatic; returns the previous
  * mode; process-wide, for tests and profiling). */
 int eyoc_spconv_select_split16_kernel(int mode);
+/* Stride-1 (3^3) split16 layers with a tile-local input stage (spconv_st.hip): per 64-row tile the distinct input rows are
+ * copied to LDS once per 32-channel block and all 27 offsets run from there.  Needs the table's per-tile "local
+ * rulebooks" (built once per table; *overflow_dev counts tiles with more than 255 distinct input rows - the staged
+ * kernel must not be used when it is non-zero; rows in Morton order never overflow).  eyoc_model_forward builds and
+ * uses them itself; these entry points exist for tests and profiling. */
+size_t eyoc_spconv_local_rulebook_bytes(int n_out);
+int eyoc_spconv_build_local_rulebook(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, void* out_dev,
+                                     int32_t* overflow_dev, void* stream);
+int eyoc_spconv_staged(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* local_dev, int n_out, int n_in, const float* in_dev,
+                       int ld_in, int cin, const float* wpacked_dev, int cout, const float* bias_dev, const float* res_dev,
+                       int ld_res, int relu, float* out_dev, int ld_out, int out_split, const float* out_scale_dev, void* stream);
 int eyoc_spconv_pack_weights_split16(const float* w_host, const float* scale_host, int K, int cin, int cout,
                                      float* packed_host, float* out_scale_host);
 int eyoc_spconv_ex(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, int n_in, const float* in_dev, int ld_in, int cin,
