@@ -61,6 +61,9 @@ PROTOTYPES = {
     "eyoc_maps_workspace_bytes": (_sz, [_i]),
     "eyoc_maps_build": (_i, [_vp, _vp, _i, _vp, _sz, _vp, C.POINTER(_vp)]),
     "eyoc_maps_free": (_i, [_vp]),
+    "eyoc_maps_internal_order": (_i, [_i]),
+    "eyoc_maps_row_order": (_vp, [_vp]),
+    "eyoc_maps_copy_row_order": (_i, [_vp, _vp, _vp]),
     "eyoc_maps_rows": (_i, [_vp, _i]),
     "eyoc_maps_coords": (_vp, [_vp, _i]),
     "eyoc_maps_table": (_vp, [_vp, _i, _i]),

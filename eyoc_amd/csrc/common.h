@@ -139,11 +139,22 @@ struct eyoc_maps {
   // perm_down[l]: rows of level l+1 (outputs of the strided convolution l -> l+1) grouped by which of their own 8
   // children exist (those are 8 of the 27 offsets of the strided map)
   int32_t* perm_down[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
+  // Internal row order.  For large batches level 0 is stored in Z-order (Morton order of (batch, x, y, z)) instead of
+  // the caller's order: 64 consecutive rows are then a compact blob of voxels, which is what the tile-local input stage
+  // of the sparse convolution needs (spconv_st.hip).  row_perm[i] = caller's row of internal row i (NULL: identity).
+  // Only the network input (read through row_perm by the first convolution) and output (scattered through it by the
+  // last) are in the caller's order; coarser levels follow from level 0 as before (first occurrence = Z-order too).
+  int32_t* row_perm = nullptr;
+  // per-tile local rulebooks of the stride-1 tables (spconv_st.hip), built when the rows are in Z-order; NULL otherwise
+  unsigned char* local_s1[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
   bool table0_built = false;   // table[0] has its memory reserved but is only filled on demand (maps_build_table0)
 };
 
 namespace eyoc {
 int maps_build_table0(eyoc_maps* maps, hipStream_t st);
+size_t sort_rows64_tmp_bytes(int n);
+int sort_rows_by_key64(void* tmp, size_t tmp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out, const int* vals_in,
+                       int* vals_out, int n, hipStream_t st);
 size_t sort_rows_tmp_bytes(int n, int bits);
 int sort_rows_by_key(void* tmp, size_t tmp_bytes, const unsigned int* keys_in, unsigned int* keys_out, const int* vals_in,
                      int* vals_out, int n, int bits, hipStream_t st);

@@ -17,7 +17,7 @@
 //    read/write one contiguous segment per offset).
 #include <cstdlib>
 
-#include "common.h"
+#include "spconv.h"
 
 using namespace eyoc;
 
@@ -188,6 +188,29 @@ __global__ void k_children_key(const int32_t* __restrict__ children, int nc, uns
   row[v] = v;
 }
 
+// Z-order key of a row: batch outermost, then the bits of x, y, z (biased to be non-negative) interleaved
+__device__ inline unsigned long long spread18(unsigned int v) {
+  unsigned long long x = v & 0x3FFFFu;
+  x = (x | (x << 32)) & 0x001F00000000FFFFull;
+  x = (x | (x << 16)) & 0x001F0000FF0000FFull;
+  x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+  x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+  x = (x | (x << 2)) & 0x1249249249249249ull;
+  return x;
+}
+__global__ void k_morton_key(const int32_t* __restrict__ coords, int n, unsigned long long* __restrict__ key, int* __restrict__ row) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = reinterpret_cast<const int4*>(coords)[i];
+  key[i] = ((unsigned long long)(unsigned)c.x << 54) | spread18((unsigned)(c.y + COORD_BIAS)) | (spread18((unsigned)(c.z + COORD_BIAS)) << 1) |
+           (spread18((unsigned)(c.w + COORD_BIAS)) << 2);
+  row[i] = i;
+}
+__global__ void k_gather_coords(const int32_t* __restrict__ coords, const int* __restrict__ perm, int n, int32_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) reinterpret_cast<int4*>(out)[i] = reinterpret_cast<const int4*>(coords)[perm[i]];
+}
+
 __global__ void k_iota(int32_t* __restrict__ out, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = i;
@@ -326,7 +349,9 @@ __global__ void k_count_region(const int32_t* __restrict__ coords, int n, HashTa
 }
 
 constexpr int UP_KEY_BITS = 11;
-static int ORDER_MIN_ROWS = 65536;   // below this no convolution of the level reaches the wave-private kernel's tile count
+static int ORDER_MIN_ROWS = 65536;
+static int INTERNAL_ORDER = -1;          // eyoc_maps_internal_order: -1 automatic (Z-order from 262144 rows), 0 caller's order, 1 Z-order
+constexpr int ZORDER_MIN_ROWS = 262144;  // the batch size from which the model runs split16 (model.hip)   // below this no convolution of the level reaches the wave-private kernel's tile count
 
 unsigned int table_capacity(int n) {
   unsigned int cap = 1024;
@@ -349,8 +374,10 @@ size_t eyoc_maps_workspace_bytes(int n_rows) {
   b += 3 * align_up(n * 4) + align_up((n / SCAN_TILE + 2) * 4);      // slot, flag, partial sums
   b += 3 * (align_up(n * 4) + align_up(n * 32));                     // parent / children links
   b += 4 * align_up(4 * n * 4) + align_up(sort_rows_tmp_bytes(4 * n_rows, UP_KEY_BITS + 4));   // tiling orders: keys, rows, result (<= 2 segments per level, levels sum to < 2 n)
+  b += align_up(n * 8) * 2 + align_up(n * 4) * 2 + align_up(sort_rows64_tmp_bytes(n_rows));   // Z-order: keys in / out, rows in, permutation
+  b += 2 * (align_up(local_rulebook_bytes(n_rows)) + 256);           // local rulebooks of the stride-1 tables (levels sum to < 2 n rows)
   b += 4096;                                                         // counters
-  return b + 64 * 256;
+  return b + 96 * 256;
 }
 
 int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, size_t ws_bytes, void* stream,
@@ -383,7 +410,20 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
   // ---- level 0: the caller's rows, in the caller's order
   m->rows[0] = n;
   m->coords[0] = cv.take<int32_t>((size_t)n * 4);
-  FAIL_HIP(hipMemcpyAsync(m->coords[0], coords_dev, (size_t)n * 16, hipMemcpyDeviceToDevice, st));
+  const bool zorder = INTERNAL_ORDER > 0 || (INTERNAL_ORDER < 0 && n >= ZORDER_MIN_ROWS);
+  if (zorder) {
+    unsigned long long* zk_in = cv.take<unsigned long long>(n);
+    unsigned long long* zk_out = cv.take<unsigned long long>(n);
+    int* zr_in = cv.take<int>(n);
+    m->row_perm = cv.take<int32_t>(n);
+    const size_t zb = sort_rows64_tmp_bytes(n);
+    void* ztmp = cv.take<char>(zb);
+    hipLaunchKernelGGL(k_morton_key, dim3(cdiv(n, 256)), dim3(256), 0, st, coords_dev, n, zk_in, zr_in);
+    if (int rc = sort_rows_by_key64(ztmp, zb, zk_in, zk_out, zr_in, m->row_perm, n, st)) { delete m; return rc; }
+    hipLaunchKernelGGL(k_gather_coords, dim3(cdiv(n, 256)), dim3(256), 0, st, coords_dev, m->row_perm, n, m->coords[0]);
+  } else {
+    FAIL_HIP(hipMemcpyAsync(m->coords[0], coords_dev, (size_t)n * 16, hipMemcpyDeviceToDevice, st));
+  }
   // Level 0 needs no hash table: validation rides on the level-1 build (range check in its k_insert, duplicate
   // rows = two rows in one child slot in k_children); the first convolution walks the octree (spconv.hip).  The
   // table's memory stays reserved so that maps_build_table0 can build it for the hash-probing fallback.
@@ -509,6 +549,18 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
       if (seg_dn[l] >= 0) m->perm_down[l] = perm_all + seg_base[seg_dn[l]];
     }
   }
+  // ---- local rulebooks of the stride-1 tables (tile-local input stage of the sparse convolution): only for Z-ordered rows
+  if (zorder) {
+    FAIL_HIP(hipMemsetAsync(counters + 8, 0, sizeof(int), st));
+    for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
+      m->local_s1[l] = cv.take<unsigned char>(local_rulebook_bytes(m->rows[l]));
+      if (int rc = build_local_rulebook(m->nbr_s1[l], 27, m->rows[l], m->local_s1[l], counters + 8, st)) { delete m; return rc; }
+    }
+    FAIL_HIP(hipMemcpyAsync(host, counters + 8, sizeof(int), hipMemcpyDeviceToHost, st));
+    FAIL_HIP(hipStreamSynchronize(st));
+    if (host[0] != 0)   // a tile with more than 510 distinct input rows (cannot happen for Z-ordered rows): no staged kernel
+      for (int l = 0; l < EYOC_MAX_LEVELS; ++l) m->local_s1[l] = nullptr;
+  }
   FAIL_HIP(hipGetLastError());
 #undef FAIL_HIP
   if (!cv.ok()) {
@@ -626,6 +678,14 @@ int eyoc::maps_build_table0(eyoc_maps* m, hipStream_t st) {
 
 extern "C" {
 
+int eyoc_maps_internal_order(int mode) {
+  const int prev = INTERNAL_ORDER;
+  if (mode >= -1 && mode <= 1) INTERNAL_ORDER = mode;
+  return prev + 2;
+}
+
+const int32_t* eyoc_maps_row_order(const eyoc_maps* maps) { return maps ? maps->row_perm : nullptr; }
+
 int eyoc_maps_order_min_rows(int min_rows) {
   const int prev = ORDER_MIN_ROWS;
   if (min_rows >= 0) ORDER_MIN_ROWS = min_rows;
@@ -639,6 +699,18 @@ int eyoc_maps_copy_up_order(const eyoc_maps* maps, int level, int32_t* out_dev, 
   if (maps->perm_up[level]) {
     EYOC_CHECK_HIP(hipMemcpyAsync(out_dev, maps->perm_up[level], (size_t)n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   } else {   // level too small to be ordered: the convolutions tile it in natural order
+    hipLaunchKernelGGL(k_iota, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, out_dev, n);
+    EYOC_CHECK_HIP(hipGetLastError());
+  }
+  return EYOC_OK;
+}
+
+int eyoc_maps_copy_row_order(const eyoc_maps* maps, int32_t* out_dev, void* stream) {
+  EYOC_REQUIRE(maps && out_dev, EYOC_ERR_INVALID, "eyoc_maps_copy_row_order: NULL argument");
+  const int n = maps->rows[0];
+  if (maps->row_perm) {
+    EYOC_CHECK_HIP(hipMemcpyAsync(out_dev, maps->row_perm, (size_t)n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  } else {   // the caller's order was kept
     hipLaunchKernelGGL(k_iota, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, out_dev, n);
     EYOC_CHECK_HIP(hipGetLastError());
   }

@@ -24,4 +24,19 @@ int sort_rows_by_key(void* tmp, size_t tmp_bytes, const unsigned int* keys_in, u
   return EYOC_OK;
 }
 
+size_t sort_rows64_tmp_bytes(int n) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr,
+                                  (int*)nullptr, (size_t)(n > 0 ? n : 1), 0u, 64u, (hipStream_t)0);
+  return bytes;
+}
+
+// the same with 64-bit keys (Z-order of the coordinates)
+int sort_rows_by_key64(void* tmp, size_t tmp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out, const int* vals_in,
+                       int* vals_out, int n, hipStream_t st) {
+  size_t need = tmp_bytes;
+  EYOC_CHECK_HIP(rocprim::radix_sort_pairs(tmp, need, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, 64u, st));
+  return EYOC_OK;
+}
+
 }  // namespace eyoc

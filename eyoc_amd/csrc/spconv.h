@@ -28,6 +28,7 @@ struct SpconvArgs {
   // eyoc_spconv_pack_weights_split16, three v_mfma_f32_16x16x32_f16 per product block (hi*hi + hi*lo + lo*hi).
   int math = 0;
   int out_split = 0;               // write SPLIT16 rows (internal activations) instead of fp32 rows
+  const int32_t* out_perm = nullptr;      // output row o is written to row out_perm[o] of `out` (the network output in the caller's order); res is not permuted
   const unsigned char* local = nullptr;   // per-tile local rulebooks of `nbr` (build_local_rulebook) or NULL: enables the staged kernel
   const float* out_scale = nullptr;  // device scalar multiplied into the accumulated sums (undoes the weight pre-scale); NULL = 1
   // optional: a permutation of the output rows; tiles take rows in this order (any order gives the same result,
@@ -107,6 +108,7 @@ struct Conv1Args {
   float* out;             // rows of ld_out floats
   int ld_out;
   int out_split = 0;      // write SPLIT16 rows (see above) instead of fp32 rows
+  const int32_t* in_perm = nullptr;   // input row i is read from row in_perm[i] of `in` (the network input in the caller's order)
   // octree links (level 0 <-> 1) and the level-1 stride-1 table: with them a 3^3 / 5^3 window is read
   // from the 27 coarse blocks around the parent without any hash probe; NULL -> probe the hash table
   const int32_t* parent;    // [n]

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 4 : 2)) void spconv_kernel(Spco
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }
     }
-    *reinterpret_cast<float4*>(a.out + o * a.ld_out + ct0 + c4 * 4) = v;
+    *reinterpret_cast<float4*>(a.out + (a.out_perm ? (size_t)a.out_perm[o] : o) * a.ld_out + ct0 + c4 * 4) = v;
   }
   TR();
 }
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(Conv1Args a) {
       if (ok) idx = hash_lookup(a.table, pack_key(c.x, c.y + dx, c.z + dy, c.w + dz));
       if (__ballot(idx >= 0) == 0ull) continue;
       for (int ci = 0; ci < a.cin; ++ci) {
-        const float f = idx >= 0 ? a.in[(size_t)idx * a.cin + ci] : 0.0f;
+        const float f = idx >= 0 ? a.in[(size_t)(a.in_perm ? a.in_perm[idx] : idx) * a.cin + ci] : 0.0f;
         const float* wk = ws + (kk * a.cin + ci) * COUT;
 #pragma unroll
         for (int i = 0; i < COUT; ++i) acc[i] = fmaf(f, wk[i], acc[i]);
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void conv1_tree_kernel(Conv1Args a) {
       if (idx < 0 || dx < -r || dx > r || dy < -r || dy > r || dz < -r || dz > r) continue;
       const int k = (dx + r) + a.ks * (dy + r) + a.ks * a.ks * (dz + r);
       for (int ci = 0; ci < a.cin; ++ci) {
-        const float f = a.in[(size_t)idx * a.cin + ci];
+        const float f = a.in[(size_t)(a.in_perm ? a.in_perm[idx] : idx) * a.cin + ci];
         const float4* wk = reinterpret_cast<const float4*>(wsm + (k * a.cin + ci) * LDW);
 #pragma unroll
         for (int i = 0; i < COUT / 4; ++i) {

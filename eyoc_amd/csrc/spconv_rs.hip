@@ -265,8 +265,9 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_rs_kernel(SpconvArgs a) {
           v[t].x = fmaxf(v[t].x, 0.f); v[t].y = fmaxf(v[t].y, 0.f); v[t].z = fmaxf(v[t].z, 0.f); v[t].w = fmaxf(v[t].w, 0.f);
         }
       }
-      if (a.out_split) split16_store4(a.out + (size_t)o * a.ld_out, ch, v[t]);
-      else *reinterpret_cast<float4*>(a.out + (size_t)o * a.ld_out + ch) = v[t];
+      const size_t oo = a.out_perm ? (size_t)a.out_perm[o] : (size_t)o;
+      if (a.out_split) split16_store4(a.out + oo * a.ld_out, ch, v[t]);
+      else *reinterpret_cast<float4*>(a.out + oo * a.ld_out + ch) = v[t];
     }
   }
 }

@@ -154,6 +154,10 @@ __global__ __launch_bounds__(NW * 64, 1) void spconv_st_kernel(SpconvArgs a, con
   auto load_w = [&](int k, int qb, float4 (&W)[NTW][2]) {
     const int cc = (qb * 32) / CC, qp = ((qb * 32) % CC) / 32;
     const int wbase = __builtin_amdgcn_readfirstlane((((k * n_slices + slice) * ncc + cc) * tile4 + (nt0 * JQ + 2 * qp) * 64) * 16);
+#if defined(EYOC_ST_ABL) && (EYOC_ST_ABL & 4)
+    for (int t = 0; t < NTW; ++t) { asm volatile("" : "+v"(W[t][0].x), "+v"(W[t][1].x)); }
+    return;
+#endif
 #pragma unroll
     for (int t = 0; t < NTW; ++t)
 #pragma unroll
@@ -195,6 +199,10 @@ __global__ __launch_bounds__(NW * 64, 1) void spconv_st_kernel(SpconvArgs a, con
     // the LDS addresses only depend on the local indices, which do not change from block to block: left alone, the
     // compiler hoists all 27 x 8 address computations out of the block loop and spills (512 VGPRs); this keeps them here
     asm volatile("" : "+v"(w));
+#if defined(EYOC_ST_ABL) && (EYOC_ST_ABL & 8)
+    for (int c = 0; c < NC; ++c) { X[c][0].x = __uint_as_float(w); asm volatile("" : "+v"(X[c][0].y), "+v"(X[c][1].x)); }
+    return;
+#endif
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
 #if defined(EYOC_ST_ABL) && (EYOC_ST_ABL & 1)

@@ -410,8 +410,9 @@ __global__ __launch_bounds__((WCfg<CTW, BMW, CC, NCMAX>::WPB * 64), OCC) void sp
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }
     }
-    if (a.out_split) split16_store4(a.out + o * a.ld_out, ct0 + ec4 * 4, v);
-    else *reinterpret_cast<float4*>(a.out + o * a.ld_out + ct0 + ec4 * 4) = v;
+    const size_t oo = a.out_perm ? (size_t)a.out_perm[o] : o;
+    if (a.out_split) split16_store4(a.out + oo * a.ld_out, ct0 + ec4 * 4, v);
+    else *reinterpret_cast<float4*>(a.out + oo * a.ld_out + ct0 + ec4 * 4) = v;
   }
   TR();
 }

@@ -67,6 +67,18 @@ class CoordinateManager:
                        "eyoc_maps_copy_table")
         return out
 
+    def row_order(self) -> torch.Tensor | None:
+        """``int32 [rows(0)]``: caller's row of every internal row when the maps keep their rows in Z-order (large
+        batches), ``None`` when the caller's order was kept.  Level coordinates and tables are in internal rows; the
+        network's input and output stay in the caller's order either way."""
+        lib = _lib.load()
+        if not lib.eyoc_maps_row_order(self.maps()):
+            return None
+        out = torch.empty((self.rows(0),), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(lib.eyoc_maps_copy_row_order(self.maps(), _lib.ptr(out), _lib.stream_ptr()), "eyoc_maps_copy_row_order")
+        return out
+
     def up_order(self, level: int) -> torch.Tensor:
         """Copy of the row order ``int32 [rows(level)]`` the transposed convolutions tile their outputs in."""
         out = torch.empty((self.rows(level),), dtype=torch.int32, device=self.device)

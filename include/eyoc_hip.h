@@ -86,6 +86,17 @@ int eyoc_maps_copy_up_order(const eyoc_maps* maps, int level, int32_t* out_dev, 
 /* Levels with fewer rows than this keep the natural order (the sorts only pay off for the large-batch kernel;
  * default 65536).  Process-wide; min_rows < 0 only queries.  Returns the previous value.  For tests / profiling. */
 int eyoc_maps_order_min_rows(int min_rows);
+/* Internal row order.  From 262144 rows on (mode -1, the default) the maps store level 0 in Z-order (Morton order of
+ * (batch, x, y, z)) instead of the caller's order, so that 64 consecutive rows are a compact blob of voxels - what
+ * the tile-local input stage of the sparse convolution needs.  eyoc_maps_coords / _table then describe the INTERNAL
+ * rows; eyoc_maps_row_order returns the device array perm[i] = caller's row of internal row i (NULL: the caller's order
+ * was kept).  eyoc_model_forward reads its input and writes its output in the caller's order either way.
+ * eyoc_maps_internal_order(mode): -1 automatic, 0 always the caller's order, 1 always Z-order; returns the previous
+ * mode + 2; process-wide, for tests. */
+int eyoc_maps_internal_order(int mode);
+const int32_t* eyoc_maps_row_order(const eyoc_maps* maps);
+/* stream-ordered copy of the same array (the identity when the caller's order was kept); out_dev: int32 [rows[0]] */
+int eyoc_maps_copy_row_order(const eyoc_maps* maps, int32_t* out_dev, void* stream);
 int eyoc_maps_rows(const eyoc_maps* maps, int level);
 /* device pointers into the workspace; valid while the maps object lives */
 const int32_t* eyoc_maps_coords(const eyoc_maps* maps, int level);             /* [rows,4]        */

@@ -14,7 +14,8 @@ if os.environ.get("MORTON", "1") == "1": coords = coords[morton_order(coords)]
 cm = eyoc_amd.CoordinateManager(torch.from_numpy(coords).cuda())
 maps = cm.maps(); lib = _lib.load(); info = cm.info()
 print("rows", info["rows"], flush=True)
-for lvl, cin, cout in ((0, 64, 64), (0, 32, 32), (1, 64, 64), (2, 128, 128), (3, 256, 256)):
+LAYERS = ((0, 64, 64), (2, 128, 128)) if os.environ.get("ONLY_ST") else ((0, 64, 64), (0, 32, 32), (1, 64, 64), (2, 128, 128), (3, 256, 256))
+for lvl, cin, cout in LAYERS:
     n = info["rows"][lvl]; prs = info["pairs_s1"][lvl]
     tab = lib.eyoc_maps_table(maps, 0, lvl)
     x = torch.randn(n, cin, device="cuda"); xs = torch.empty_like(x)
@@ -34,7 +35,7 @@ for lvl, cin, cout in ((0, 64, 64), (0, 32, 32), (1, 64, 64), (2, 128, 128), (3,
         e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / reps
     t_lr = timeit(lambda: lib.eyoc_spconv_build_local_rulebook(_lib.ctx(), tab, 27, n, _lib.ptr(local), _lib.ptr(ovf), _lib.stream_ptr()))
     res = {}
-    for name, mode in (("wave", 0), ("rs", 2)):
+    for name, mode in (() if os.environ.get("ONLY_ST") else (("wave", 0), ("rs", 2))):
         lib.eyoc_spconv_select_split16_kernel(mode)
         res[name] = timeit(lambda: _lib.check(lib.eyoc_spconv_ex(_lib.ctx(), tab, 27, n, n, _lib.ptr(xs), cin, cin, _lib.ptr(wd), cout, None, None, 0, 0, _lib.ptr(out), cout, 1, 1, _lib.ptr(osd), _lib.stream_ptr())))
     lib.eyoc_spconv_select_split16_kernel(1)

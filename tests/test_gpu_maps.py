@@ -83,6 +83,54 @@ def test_maps_synthetic_kitti_cloud():
     assert 57000 <= info["rows"][0] <= 66000
 
 
+@pytest.fixture
+def zorder_rows():
+    from eyoc_amd import _lib
+    lib = _lib.load()
+    prev = lib.eyoc_maps_internal_order(1) - 2
+    yield
+    lib.eyoc_maps_internal_order(prev)
+
+
+@pytest.mark.parametrize("case", ["random3", "kitti", "tiny"])
+def test_maps_in_z_order_equal_the_oracle_maps_of_the_z_ordered_cloud(zorder_rows, case):
+    """Large batches keep their rows in Z-order internally (eyoc_maps_row_order); forced here for small clouds.  The
+    permutation is the stable Morton order of (batch, x, y, z) and every level, table and tiling order is bit-exactly
+    what the oracle builds for the cloud permuted that way."""
+    import eyoc_amd
+    from eyoc_amd import synthetic as syn
+    from test_gpu_split16 import morton_order
+    if case == "random3":
+        coords = random_cloud(5, 2500, batch=3)
+    elif case == "kitti":
+        p = syn.make_pair(3)
+        coords = syn.batch_coords([p["coords0"], p["coords1"]])
+    else:
+        coords = np.array([[0, -1, -1, -1], [0, -2, 0, 1], [0, 0, 0, 0], [1, 0, 0, 0], [1, 1, 0, 0], [0, -9, 7, -8]], np.int32)
+    cm = eyoc_amd.CoordinateManager(torch.from_numpy(coords).cuda())
+    perm = cm.row_order().cpu().numpy()
+    np.testing.assert_array_equal(perm, morton_order(coords))
+    np.testing.assert_array_equal(cm.level_coordinates(0).cpu().numpy(), coords[perm])
+    from oracle import coords as oc
+    from eyoc_amd import _lib
+    maps = oc.build_maps(coords[perm], conv1_kernel_size=5)
+    info = cm.info(conv1_kernel_size=5)
+    assert info["rows"] == oc.map_stats(maps)["rows"] and info["pairs_conv1"] == oc.map_stats(maps)["pairs_k5"]
+    for l in range(4):
+        np.testing.assert_array_equal(cm.level_coordinates(l).cpu().numpy(), maps["cm"][l].coords)
+        np.testing.assert_array_equal(cm.table(_lib.MAP_S1, l).cpu().numpy(), maps["s1"][l])
+        if l < 3:
+            np.testing.assert_array_equal(cm.table(_lib.MAP_DOWN, l).cpu().numpy(), maps["down"][l])
+            np.testing.assert_array_equal(cm.table(_lib.MAP_UP, l).cpu().numpy(), maps["up"][l])
+            check_up_order(cm.up_order(l).cpu().numpy(), maps["up"][l])
+
+
+def test_maps_keep_the_callers_order_for_small_clouds():
+    import eyoc_amd
+    cm = eyoc_amd.CoordinateManager(torch.from_numpy(random_cloud(6, 500)).cuda())
+    assert cm.row_order() is None
+
+
 def test_maps_reject_duplicates_and_out_of_range():
     import eyoc_amd
     dup = torch.tensor([[0, 1, 2, 3], [0, 4, 5, 6], [0, 1, 2, 3]], dtype=torch.int32).cuda()

@@ -202,6 +202,40 @@ def test_split16_forward_matches_oracle_like_fp32(request):
     assert model.last_spconv_math == "fp32"
 
 
+def test_forward_on_z_ordered_rows_with_the_staged_kernel(request):
+    """Production path of the large batches, forced onto a 2 x 31k-voxel batch: rows kept in Z-order inside the maps,
+    conv1 reading and the last layer writing through the permutation, the 64+-channel stride-1 layers on the tile-local
+    input stage.  The caller sees its own row order; same bar as every other forward."""
+    from eyoc_amd import _lib as L, synthetic as syn
+    from oracle import resunet as orr
+    from test_gpu_round2 import _model
+    lib = L.load()
+    p = syn.make_pair(4)
+    coords = syn.batch_coords([p["coords0"], p["coords1"]])
+    feats = np.concatenate([p["feats0"], p["feats1"]])
+    model, sd = _model()
+    want = orr.resunet_forward(sd, coords, feats).numpy()
+    prev = lib.eyoc_maps_internal_order(1) - 2
+    try:
+        for mode in ("split16", "fp32"):
+            model.spconv_math = mode
+            got = _forward(model, coords, feats)
+            assert model.last_spconv_math == mode
+            e = rel_err(got, want)
+            cos = (got * want).sum(1)
+            print(f"z-ordered forward, {mode}: err {e:.2e}")
+            assert e < REL and cos.min() > 1 - 1e-6, (mode, e, float(cos.min()))
+        # the permutation is invisible: permuting the caller's rows permutes the output
+        rng = np.random.default_rng(3)
+        perm = rng.permutation(len(coords))
+        model.spconv_math = "split16"
+        a = _forward(model, coords, feats)
+        assert rel_err(_forward(model, coords[perm], feats[perm]), a[perm]) < 1e-5
+    finally:
+        lib.eyoc_maps_internal_order(prev)
+        model.spconv_math = "auto"
+
+
 def test_split16_other_channel_tables():
     from eyoc_amd import synthetic as syn
     from oracle import resunet as orr
