@@ -375,7 +375,8 @@ size_t eyoc_maps_workspace_bytes(int n_rows) {
   b += 3 * (align_up(n * 4) + align_up(n * 32));                     // parent / children links
   b += 4 * align_up(4 * n * 4) + align_up(sort_rows_tmp_bytes(4 * n_rows, UP_KEY_BITS + 4));   // tiling orders: keys, rows, result (<= 2 segments per level, levels sum to < 2 n)
   b += align_up(n * 8) * 2 + align_up(n * 4) * 2 + align_up(sort_rows64_tmp_bytes(n_rows));   // Z-order: keys in / out, rows in, permutation
-  b += 2 * (align_up(local_rulebook_bytes(n_rows)) + 256);           // local rulebooks of the stride-1 tables (levels sum to < 2 n rows)
+  // local rulebooks of the stride-1 tables (levels sum to < 2 n rows; every level rounds up to a whole tile)
+  b += 2 * align_up(local_rulebook_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_bytes(1)) + 256);
   b += 4096;                                                         // counters
   return b + 96 * 256;
 }
@@ -558,7 +559,7 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
     }
     FAIL_HIP(hipMemcpyAsync(host, counters + 8, sizeof(int), hipMemcpyDeviceToHost, st));
     FAIL_HIP(hipStreamSynchronize(st));
-    if (host[0] != 0)   // a tile with more than 510 distinct input rows (cannot happen for Z-ordered rows): no staged kernel
+    if (host[0] != 0)   // a tile with more than 1278 distinct input rows (does not happen for Z-ordered rows): no staged kernel
       for (int l = 0; l < EYOC_MAX_LEVELS; ++l) m->local_s1[l] = nullptr;
   }
   FAIL_HIP(hipGetLastError());

@@ -323,9 +323,8 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
         a.w = m->blob + p.w16_off;
         a.out_scale = m->blob + p.s_off;
         a.out_split = p.out_buf != B_OUT;
-        // stride-1 layers on Z-ordered rows: tile-local input stage (spconv_st.hip); the 32-channel layers stay on the
-        // wave-private kernel (measured: 0.54 vs 0.62 ms on the level-0 32 -> 32 layers)
-        if (p.map == M_S1 && p.cin >= 64) a.local = maps->local_s1[p.level];
+        // stride-1 layers on Z-ordered rows: tile-local input stage (spconv_st.hip)
+        if (p.map == M_S1 && p.cin >= 32 && p.cin % 32 == 0) a.local = maps->local_s1[p.level];
       }
       if (p.out_buf == B_OUT) a.out_perm = maps->row_perm;   // the network output goes back to the caller's row order
       a.perm = p.map == M_UP ? maps->perm_up[p.level] : p.map == M_S1 ? maps->perm_s1[p.level]

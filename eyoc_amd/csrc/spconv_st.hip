@@ -1,23 +1,25 @@
 // Sparse convolution with a tile-local input stage (gfx950, SPLIT16 arithmetic, stride-1 rulebooks).
 //
-// The split16 kernels are bound by their gather: a stride-1 layer reads every input row ~9 times (once per occupied
-// offset of each output row it neighbours), the re-reads are 10^4..10^5 cycles apart, and nothing survives that long
-// in a 32 KB L1 through which the CU streams its other waves' gathers - HBM-side traffic equals the algorithmic gather
-// bytes, 3.9x the compulsory bytes.  This kernel gathers every input row a tile needs ONCE:
+// A stride-1 layer reads every input row ~10 times (once per occupied offset of each output row it neighbours); the
+// gathering kernels (spconv_wave.hip, spconv_rs.hip) fetch each of those reads from L2 / HBM.  This kernel fetches every
+// input row a tile needs ONCE per 32-channel block:
 //
-//   * the rows of a level are stored in Morton order (eyoc_maps_build sorts them), so 64 consecutive output rows are
-//     a compact blob of voxels whose 27-neighbourhoods overlap: ~680 (row, offset) pairs but only ~140 distinct
-//     input rows (5x re-use; at most ~250);
-//   * a "local rulebook" per tile, built once per stride-1 table (k_local_rulebook, shared by every layer and every
-//     32-channel block that uses the table): the list U of distinct input rows (<= 255) and, per (offset, output row),
-//     the index into U (255 = no neighbour);
-//   * per (tile, 32-channel block) the wave copies its U rows' 128-byte lines global -> LDS (32 KB per wave, 16-byte
-//     pieces XOR-swizzled by the row so that 16 random rows spread over the banks), then runs all 27 offsets from LDS:
-//     register accumulators, zero operands for missing neighbours (LDS row 255 is zero) and weights shared through an
-//     LDS ring by the 4 waves of the workgroup, exactly like the row-stationary kernel (spconv_rs.hip).
+//   * the rows of a level are stored in Morton order (eyoc_maps_build sorts them), so 256 consecutive output rows are a
+//     compact blob of voxels whose 27-neighbourhoods overlap: ~2500 (row, offset) pairs but only ~380..500 distinct
+//     input rows (at most ~720);
+//   * a "local rulebook" per 256-row tile, built once per stride-1 table (k_local_rulebook, shared by every layer and
+//     every channel block that uses the table): the list U of distinct input rows and, per (offset, output row), the
+//     LDS slot of that row (slot 639 = a row of zeros = no neighbour);
+//   * per (tile, 32-channel block) the workgroup's 4 waves copy the U rows' 128-byte lines global -> LDS (80 KB, 16-byte
+//     pieces XOR-swizzled by the row so that random rows spread over the banks), then every wave runs all 27 offsets of
+//     its 64 output rows from LDS: register accumulators, zero operands for missing neighbours, weight fragments
+//     straight from L2 one stage ahead.
 //
-// One workgroup (4 waves, 152 KB of LDS) per CU, one wave per SIMD: the inner loop has no global loads at all (operands
-// and weights from LDS, local indices in 27 registers), so it does not need co-resident waves to hide memory latency.
+// Two workgroups (2 x 80 KB of LDS, 8 waves) per CU, two waves per SIMD: while one workgroup waits for its stage (or
+// loads its rulebook, or stores its outputs) the other one owns the matrix pipe, and inside the offset loop the two
+// waves of a SIMD fill each other's LDS / L2 latencies.  (The first version of this kernel staged per WAVE, 32 KB each,
+// one wave per SIMD: every stage, prologue and epilogue was exposed - 2.3 ms on the 3.8M-row 64 -> 64 layer, MFMA
+// pipe 43% busy; scripts/bench_staged.py + the EYOC_ST_ABL builds have the breakdown.)
 #include <cstdlib>
 
 #include "spconv.h"
@@ -29,34 +31,37 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int NW = 4;
-constexpr int UMAX = 255;                                  // distinct input rows staged per pass (row 255 = zeros)
-constexpr int NPASS = 2;                                   // a tile with more distinct rows (<= 510) takes a second pass
-constexpr int X_BYTES = 256 * 128;                         // per-wave stage: 256 rows x one 32-channel block
+constexpr int NW = 4;                                      // waves per workgroup, 64 output rows each
+constexpr int TILE = NW * 64;                              // output rows per workgroup
+constexpr int XROWS = 640;                                 // LDS stage: rows of one 32-channel block (128 bytes each)
+constexpr int UMAX = XROWS - 1;                            // distinct input rows staged per pass; slot UMAX holds zeros
+constexpr int NPASS = 2;                                   // a tile with more distinct rows (<= 1278) takes a second pass
+constexpr int UCAP = 1280;
+constexpr int X_BYTES = XROWS * 128;                       // 80 KB: two workgroups per CU
+constexpr int NIT = XROWS / (8 * NW);                      // staging instructions per wave and block (8 rows each)
 
-// ---- local rulebook of one 64-row tile (LR_BYTES bytes): int n_unique (-1: more than NPASS * UMAX), pad[3]; int U[512];
-// unsigned loc[NPASS][27][16] = per pass the four chunk rows' local indices of (offset k, column j) packed as bytes
-// (chunk c in bits 8c..; 255 = no neighbour, or a neighbour staged in the other pass)
-constexpr int LR_BYTES = 16 + 512 * 4 + NPASS * 27 * 16 * 4;   // 5520
-constexpr int HSLOTS = 2048;                               // > 64 * 27 possible distinct rows: probing always terminates
+// ---- local rulebook of one 256-row tile (LR_BYTES bytes): int n_unique (-1: more than NPASS * UMAX), pad[3];
+// int U[UCAP]; uint2 loc[NPASS][27][64]: entry (pass, k, 16 w + j) packs, as four 16-bit values v = 8 l + (l & 7), the
+// LDS slots l of the neighbours at offset k of output rows 64 w + 16 c + j, c = 0..3 (slot UMAX = no neighbour, or a
+// neighbour staged in the other pass).  v << 4 is the LDS address of the row's first piece with the swizzle applied.
+constexpr int LR_BYTES = 16 + UCAP * 4 + NPASS * 27 * 64 * 8;   // 32784
+constexpr int HSLOTS = 8192;                               // > 256 * 27 possible distinct rows: probing always terminates
 
 __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restrict__ nbr, int K, int n_out, unsigned char* __restrict__ out,
                                                         int* __restrict__ overflow) {
-  __shared__ int keys[4][HSLOTS];
-  __shared__ unsigned short ids[4][HSLOTS];
+  __shared__ int hk[HSLOTS];
+  __shared__ unsigned short hid[HSLOTS];
+  __shared__ int wave_cnt[NW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.x * 4 + wave;
-  const int row0 = tile * 64;
-  if (row0 >= n_out) return;   // wave-uniform; no barrier in this kernel
-  int* hk = keys[wave];
-  unsigned short* hid = ids[wave];
-  for (int i = lane; i < HSLOTS; i += 64) hk[i] = -1;
-  const int row = row0 + lane;
+  const int tile = blockIdx.x;
+  const int row = tile * TILE + (int)threadIdx.x;
+  for (int i = threadIdx.x; i < HSLOTS; i += 256) hk[i] = -1;
+  __syncthreads();
   // 1. insert every valid entry (linear probing; duplicates meet their own key)
   for (int k = 0; k < K; ++k) {
     const int idx = row < n_out ? nbr[(size_t)k * n_out + row] : -1;
     if (idx >= 0) {
-      unsigned int s = ((unsigned)idx * 2654435761u) >> 21;
+      unsigned int s = ((unsigned)idx * 2654435761u) >> 19;
       while (true) {
         const int prev = atomicCAS(&hk[s], -1, idx);
         if (prev == -1 || prev == idx) break;
@@ -64,64 +69,73 @@ __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restric
       }
     }
   }
-  // 2. number the occupied slots in slot order (deterministic)
-  int base = 0;
+  __syncthreads();
+  // 2. number the occupied slots in slot order (deterministic): every wave owns a quarter of the table
+  constexpr int PER_WAVE = HSLOTS / NW;
+  int cnt = 0;
+  for (int i0 = 0; i0 < PER_WAVE; i0 += 64) cnt += __popcll(__ballot(hk[wave * PER_WAVE + i0 + lane] >= 0));
+  if (lane == 0) wave_cnt[wave] = cnt;
+  __syncthreads();
+  int base = 0, total = 0;
+  for (int w = 0; w < NW; ++w) { if (w < wave) base += wave_cnt[w]; total += wave_cnt[w]; }
   unsigned char* lr = out + (size_t)tile * LR_BYTES;
   int* U = reinterpret_cast<int*>(lr + 16);
-  for (int i0 = 0; i0 < HSLOTS; i0 += 64) {
-    const int key = hk[i0 + lane];
+  for (int i0 = 0; i0 < PER_WAVE; i0 += 64) {
+    const int s = wave * PER_WAVE + i0 + lane;
+    const int key = hk[s];
     const unsigned long long m = __ballot(key >= 0);
     const int id = base + __popcll(m & ((1ull << lane) - 1ull));
     if (key >= 0) {
-      hid[i0 + lane] = (unsigned short)id;
+      hid[s] = (unsigned short)id;
       if (id < NPASS * UMAX) U[id] = key;
     }
     base += __popcll(m);
   }
-  if (lane == 0) {
-    reinterpret_cast<int*>(lr)[0] = base <= NPASS * UMAX ? base : -1;
-    if (base > NPASS * UMAX) atomicAdd(overflow, 1);
+  if (threadIdx.x == 0) {
+    reinterpret_cast<int*>(lr)[0] = total <= NPASS * UMAX ? total : -1;
+    if (total > NPASS * UMAX) atomicAdd(overflow, 1);
   }
-  // 3. local index of every (offset, row); lanes j = lane & 15 of chunk c = lane >> 4 pack into one word per (k, j)
-  unsigned int* loc = reinterpret_cast<unsigned int*>(lr + 16 + 512 * 4);
+  __syncthreads();
+  // 3. LDS slot of every (offset, row): row r = 64 w + 16 c + j goes to 16-bit lane c of entry (k, 16 w + j)
+  unsigned short* loc = reinterpret_cast<unsigned short*>(lr + 16 + UCAP * 4);
+  const int r = (int)threadIdx.x, w = r >> 6, c = (r >> 4) & 3, j = r & 15;
   for (int k = 0; k < 27; ++k) {
     const int idx = (k < K && row < n_out) ? nbr[(size_t)k * n_out + row] : -1;
     int id = -1;
     if (idx >= 0) {
-      unsigned int s = ((unsigned)idx * 2654435761u) >> 21;
+      unsigned int s = ((unsigned)idx * 2654435761u) >> 19;
       while (hk[s] != idx) s = (s + 1) & (HSLOTS - 1);
       id = hid[s];
     }
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
-      const unsigned int l = (id >= p * UMAX && id < (p + 1) * UMAX) ? (unsigned)(id - p * UMAX) : 255u;
-      // gather the four chunks' bytes of column j into lane j: lane (c, j) holds byte c
-      unsigned int w = l << (8 * (lane >> 4));
-      w |= __shfl_xor(w, 16, 64);
-      w |= __shfl_xor(w, 32, 64);
-      if (lane < 16) loc[(p * 27 + k) * 16 + lane] = w;
+      const int l = (id >= p * UMAX && id < (p + 1) * UMAX) ? id - p * UMAX : UMAX;
+      loc[(((size_t)(p * 27 + k) * 64) + w * 16 + j) * 4 + c] = (unsigned short)(l * 8 + (l & 7));
     }
   }
 }
 
-// byte offset of 16-byte piece p (0..3 hi halves of channels 8p.., 4..7 lo halves) of staged row l
-__device__ __forceinline__ int xs_off(int l, int p) { return l * 128 + ((p ^ (l & 7)) << 4); }
-
-template <int NTW, int CC>
-__global__ __launch_bounds__(NW * 64, 1) void spconv_st_kernel(SpconvArgs a, const unsigned char* __restrict__ local) {
+// The workgroup's 256 rows x CTG output channels are split over its 4 waves as 4 row quarters x CTG channels (NH = 1:
+// 64 rows x NTW * 16 channels per wave) or as 2 row halves x 2 channel halves (NH = 2: 128 rows x 32 channels per wave -
+// half the weight bytes through the L1, twice the operand reads from LDS).
+template <int NTW, int CC, int NH>
+__global__ __launch_bounds__(NW * 64, 2) void spconv_st_kernel(SpconvArgs a, const unsigned char* __restrict__ local, int n_tiles) {
   constexpr int CTW = NTW * 16, NC = 4;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int CTG = CTW * NH;                                        // output channels per workgroup
+  extern __shared__ __attribute__((aligned(16))) unsigned char xs[];   // the workgroup's stage: XROWS x 128 bytes
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  unsigned char* xs = smem + wave * X_BYTES;                          // this wave's stage
   const int g = lane >> 4, j = lane & 15;
-  const int n_cg = a.cout / CTW;
-  const int wg = (int)blockIdx.x;
-  const int rgw = wg / n_cg, cg = wg - rgw * n_cg;
-  const int tile = rgw * NW + wave;
-  const int row0 = tile * 64;
-  const bool live = row0 < a.n_out;                                    // wave-uniform; dead waves keep the barriers company
-  const int ct0 = cg * CTW;
+  // workgroup -> (tile, channel group): consecutive workgroups go to consecutive XCDs, so the channel group is taken
+  // from the XCD number - each XCD's L2 then holds the weights of one channel group only (a 256 -> 256 layer has 7 MB of
+  // split weights, an L2 has 4 MB)
+  const int n_cg = a.cout / CTG;                                       // 1, 2, 4 or 8
+  const int xcd = (int)blockIdx.x & 7, per = 8 / n_cg;
+  const int cg = xcd % n_cg, tile = ((int)blockIdx.x >> 3) * per + xcd / n_cg;
+  if (tile >= n_tiles) return;
+  const int w0 = NH == 1 ? wave : 2 * (wave >> 1);                     // first 64-row quarter of this wave
+  const int row0 = tile * TILE + w0 * 64;                              // past n_out: the wave stages and multiplies zeros, stores nothing
+  const int ct0 = cg * CTG + (NH == 2 ? (wave & 1) * CTW : 0);
   const int CT = a.cout >= 128 ? 128 : a.cout;
   const int n_slices = a.cout / CT, slice = ct0 / CT, nt0 = (ct0 - slice * CT) / 16;
   constexpr int JQ = CC / 16;
@@ -129,27 +143,26 @@ __global__ __launch_bounds__(NW * 64, 1) void spconv_st_kernel(SpconvArgs a, con
   const int nqb = a.cin / 32;
   constexpr int K = 27;
 
-  const unsigned char* lr = local + (size_t)(live ? tile : 0) * LR_BYTES;
-  const int n_u = live ? __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(lr)[0]) : 0;
+  const unsigned char* lr = local + (size_t)tile * LR_BYTES;
+  const int n_u = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(lr)[0]);
   const int* __restrict__ U = reinterpret_cast<const int*>(lr + 16);
-  const unsigned int* __restrict__ locp = reinterpret_cast<const unsigned int*>(lr + 16 + 512 * 4);
-  const int n_pass = n_u > UMAX ? 2 : 1;                               // wave-uniform; the second pass is rare (a tile across a Z-curve jump)
-  unsigned int loc4[27];
-  // zero row (local index 255), written once: no stage ever touches it
-  if (lane < 8) *reinterpret_cast<float4*>(xs + 255 * 128 + lane * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+  const uint2* __restrict__ locp = reinterpret_cast<const uint2*>(lr + 16 + UCAP * 4) + w0 * 16 + j;
+  const int n_pass = n_u > UMAX ? 2 : 1;                               // workgroup-uniform; the second pass is rare
+  // zero row (slot UMAX), written once: no stage ever touches it
+  if (threadIdx.x < 8) *reinterpret_cast<float4*>(xs + UMAX * 128 + threadIdx.x * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
 
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, K * a.cin * a.cout * 4, 0x00020000);
   const int tile4 = CC * CT / 4;
 
-  f32x4 acc[NC][NTW];
+  f32x4 acc[NH][NC][NTW];
 #pragma unroll
-  for (int c = 0; c < NC; ++c)
+  for (int h = 0; h < NH; ++h)
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) acc[h][c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // this wave's MFMA weight fragments of stage (k, qb), straight from L2 / L1 into operand registers, one stage ahead.
-  // (No LDS ring and no barrier here, unlike spconv_rs.hip: with one wave per SIMD a barrier per stage leaves the
-  // matrix pipe idle while the slowest wave arrives, and 4 waves per CU ask the L1 for 8 KB per ~800-cycle stage.)
+  // this wave's MFMA weight fragments of stage (k, qb), straight from L2 / L1 into operand registers, one stage ahead
   const int lane_off = lane * 16;
   auto load_w = [&](int k, int qb, float4 (&W)[NTW][2]) {
     const int cc = (qb * 32) / CC, qp = ((qb * 32) % CC) / 32;
@@ -166,55 +179,53 @@ __global__ __launch_bounds__(NW * 64, 1) void spconv_st_kernel(SpconvArgs a, con
         W[t][p] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
       }
   };
-  // stage block qb of this tile's distinct input rows: 8 lanes per row (one 128-byte line), 8 rows per instruction,
-  // global -> LDS directly (global_load_lds_dwordx4: lane i lands at base + 16 i, so the XOR swizzle of the pieces is
-  // applied on the SOURCE side), all loads of a stage in flight at once - one memory latency per (tile, block)
-  int Ureg[32];                                                      // this lane's rows of the pass: U[pass * 255 + 8 it + lane / 8]
+  // stage block qb of the tile's distinct input rows: 8 lanes per row (one 128-byte line), 8 rows per instruction, wave w
+  // takes the 8-row groups 4 it + w; global -> LDS directly (global_load_lds_dwordx4: lane i lands at base + 16 i, so the
+  // XOR swizzle of the pieces is applied on the SOURCE side), all loads of a stage in flight at once
+  int Ureg[NIT];                                                     // this lane's rows of the pass
   int n_up = 0;                                                      // distinct rows of the current pass
   auto begin_pass = [&](int pass) {
     n_up = min(n_u - pass * UMAX, UMAX);
 #pragma unroll
-    for (int it = 0; it < 32; ++it) {
-      const int l = it * 8 + (lane >> 3);
+    for (int it = 0; it < NIT; ++it) {
+      const int l = (it * NW + wave) * 8 + (lane >> 3);
       Ureg[it] = l < n_up ? U[pass * UMAX + l] : 0;
     }
-#pragma unroll
-    for (int k = 0; k < 27; ++k) loc4[k] = live ? locp[(pass * 27 + k) * 16 + j] : 0xFFFFFFFFu;
   };
   auto stage = [&](int qb) {
 #if defined(EYOC_ST_ABL) && (EYOC_ST_ABL & 2)
     return;
 #endif
 #pragma unroll
-    for (int it = 0; it < 32; ++it) {
-      if (it * 8 < n_up) {                                           // wave-uniform
-        const int l = it * 8 + (lane >> 3);
-        const float* src = a.in + (size_t)Ureg[it] * a.ld_in + qb * 32 + (((lane & 7) ^ (l & 7)) << 2);
+    for (int it = 0; it < NIT; ++it) {
+      const int l0 = (it * NW + wave) * 8;
+      if (l0 < n_up) {                                               // wave-uniform
+        const int l = l0 + (lane >> 3);
+        int u = Ureg[it];
+        asm volatile("" : "+v"(u));                                    // keep the 20 source addresses out of the registers between blocks
+        const float* src = a.in + (size_t)u * a.ld_in + qb * 32 + (((lane & 7) ^ (l & 7)) << 2);
         if (l < n_up)
-          __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(xs + it * 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(xs + l0 * 128), 16, 0, 0);
       }
     }
   };
-  auto read_x = [&](unsigned int w, float4 (&X)[NC][2]) {
-    // the LDS addresses only depend on the local indices, which do not change from block to block: left alone, the
-    // compiler hoists all 27 x 8 address computations out of the block loop and spills (512 VGPRs); this keeps them here
-    asm volatile("" : "+v"(w));
+  // operands of one offset: lane (g, j) reads pieces g (hi halves of channels 8 g ..) and 4 + g (lo halves) of the four
+  // rows its entry names
+  const unsigned int gh = (unsigned)g << 4, gl = (unsigned)(g ^ 4) << 4;
+  auto read_x = [&](const uint2 L, float4 (&X)[NC][2]) {
 #if defined(EYOC_ST_ABL) && (EYOC_ST_ABL & 8)
-    for (int c = 0; c < NC; ++c) { X[c][0].x = __uint_as_float(w); asm volatile("" : "+v"(X[c][0].y), "+v"(X[c][1].x)); }
+    for (int c = 0; c < NC; ++c) { X[c][0].x = __uint_as_float(L.x); asm volatile("" : "+v"(X[c][0].y), "+v"(X[c][1].x)); }
     return;
 #endif
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-#if defined(EYOC_ST_ABL) && (EYOC_ST_ABL & 1)
-      const int l = 255 + 0 * (int)w;
-#else
-      const int l = (int)((w >> (8 * c)) & 255u);
-#endif
-      X[c][0] = *reinterpret_cast<const float4*>(xs + xs_off(l, g));
-      X[c][1] = *reinterpret_cast<const float4*>(xs + xs_off(l, 4 + g));
+      const unsigned int v = ((c < 2 ? L.x : L.y) >> (16 * (c & 1))) & 0xFFFFu;
+      const unsigned int ad = v << 4;
+      X[c][0] = *reinterpret_cast<const float4*>(xs + (ad ^ gh));
+      X[c][1] = *reinterpret_cast<const float4*>(xs + (ad ^ gl));
     }
   };
-  auto multiply = [&](const float4 (&X)[NC][2], const float4 (&W)[NTW][2]) {
+  auto multiply = [&](int h, const float4 (&X)[NC][2], const float4 (&W)[NTW][2]) {
 #pragma unroll
     for (int term = 0; term < 3; ++term)
 #pragma unroll
@@ -222,62 +233,68 @@ __global__ __launch_bounds__(NW * 64, 1) void spconv_st_kernel(SpconvArgs a, con
         const half8_t xv = __builtin_bit_cast(half8_t, X[c][term == 1 ? 1 : 0]);
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
-          acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, W[t][term == 2 ? 1 : 0]), xv, acc[c][t], 0, 0, 0);
+          acc[h][c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, W[t][term == 2 ? 1 : 0]), xv, acc[h][c][t], 0, 0, 0);
       }
   };
 
-  // ---- stage stream: s = 27 qb + k (this kernel serves 3^3 stride-1 tables only, K == 27; the offset loop is unrolled so
-  // that the local indices stay in registers).  While stage s multiplies, the inputs of stage s + 1 are read from the
-  // LDS stage and its weight fragments from L2 into the other operand set.  The waves of a workgroup never wait for
-  // each other.
+  // ---- per (pass, block): stage, then 27 offsets of NH half-steps (64 rows each).  While a half-step multiplies, the
+  // operands of the next one are read from LDS into the other X set; the weight fragments of offset k + 1 arrive from L2
+  // in the other W set while offset k multiplies; the rulebook entries run two offsets ahead.
   float4 XA[NC][2], XB[NC][2], WA[NTW][2], WB[NTW][2];
+  uint2 L[3][NH];
+  bool first = true;
   for (int pass = 0; pass < n_pass; ++pass) {
     begin_pass(pass);
-    load_w(0, 0, WA);
-    stage(0);
-    __builtin_amdgcn_s_waitcnt(0x0070);                              // vmcnt(0): the stage has landed
+    const uint2* lp = locp + pass * 27 * 64;
     for (int qb = 0; qb < nqb; ++qb) {
-      read_x(loc4[0], XA);
+      if (!first) __syncthreads();                                     // every wave is done with the previous block's rows
+      first = false;
+      stage(qb);
+      load_w(0, qb, WA);
 #pragma unroll
-      for (int k = 0; k < 27; ++k) {
-        const int kn = k < 26 ? k + 1 : 0, qn = k < 26 ? qb : qb + 1;
-        if (k & 1) {
-          if (qn < nqb) load_w(kn, qn, WA);
-          if (k < 26) read_x(loc4[kn], XA);
-          multiply(XB, WB);
-        } else {
-          if (qn < nqb) load_w(kn, qn, WB);
-          if (k < 26) read_x(loc4[kn], XB);
-          multiply(XA, WA);
+      for (int h = 0; h < NH; ++h) { L[0][h] = lp[h * 16]; L[1][h] = lp[64 + h * 16]; }
+      __builtin_amdgcn_s_waitcnt(0x0070);                              // vmcnt(0): this wave's part of the stage has landed
+      __syncthreads();
+      read_x(L[0][0], XA);
+#pragma unroll
+      for (int hs = 0; hs < 27 * NH; ++hs) {
+        const int k = hs / NH, h = hs % NH;                            // compile-time after unrolling
+        if (h == 0) {
+          if (k + 2 < 27) {
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh) L[(k + 2) % 3][hh] = lp[(k + 2) * 64 + hh * 16];
+          }
+          if (k < 26) { if (k & 1) load_w(k + 1, qb, WA); else load_w(k + 1, qb, WB); }
         }
-        __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting later stages' loads up here (it spills at 512 VGPRs)
-      }
-      // offset 26 multiplied set A and fetched the next block's first weights into set B: hand them over, refill the stage
-      if (qb + 1 < nqb) {
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) { WA[t][0] = WB[t][0]; WA[t][1] = WB[t][1]; }
-        stage(qb + 1);
-        __builtin_amdgcn_s_waitcnt(0x0070);
+        const int hn = hs + 1, kn = hn / NH, hhn = hn % NH;
+        if (hs & 1) {
+          if (hn < 27 * NH) read_x(L[kn % 3][hhn], XA);
+          if (k & 1) multiply(h, XB, WB); else multiply(h, XB, WA);
+        } else {
+          if (hn < 27 * NH) read_x(L[kn % 3][hhn], XB);
+          if (k & 1) multiply(h, XA, WB); else multiply(h, XA, WA);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting later offsets' loads up here (register budget: 256)
       }
     }
   }
 
   // ---- epilogue straight from the registers: lane (g, j) holds channels 16 t + 4 g .. +3 of row 16 c + j
-  if (!live) return;
   const float os = a.out_scale ? *a.out_scale : 1.0f;
   float4 b4[NTW];
 #pragma unroll
   for (int t = 0; t < NTW; ++t)
     b4[t] = a.bias ? *reinterpret_cast<const float4*>(a.bias + ct0 + 16 * t + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const int o = row0 + 16 * c + j;
+  for (int hc = 0; hc < NH * NC; ++hc) {
+    const int h = hc / NC, c = hc % NC;
+    const int o = row0 + 64 * h + 16 * c + j;
     if (o >= a.n_out) continue;
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
       const int ch = ct0 + 16 * t + 4 * g;
-      float4 v = make_float4(acc[c][t][0] * os + b4[t].x, acc[c][t][1] * os + b4[t].y, acc[c][t][2] * os + b4[t].z,
-                             acc[c][t][3] * os + b4[t].w);
+      float4 v = make_float4(acc[h][c][t][0] * os + b4[t].x, acc[h][c][t][1] * os + b4[t].y, acc[h][c][t][2] * os + b4[t].z,
+                             acc[h][c][t][3] * os + b4[t].w);
       if (a.res) {
         const float4 q = split16_load4(a.res + (size_t)o * a.ld_res, ch);
         v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
@@ -293,13 +310,13 @@ __global__ __launch_bounds__(NW * 64, 1) void spconv_st_kernel(SpconvArgs a, con
 
 namespace eyoc {
 
-size_t local_rulebook_bytes(int n_out) { return (size_t)cdiv(n_out, 64) * LR_BYTES; }
+size_t local_rulebook_bytes(int n_out) { return (size_t)cdiv(n_out, TILE) * LR_BYTES; }
 
 // builds the per-tile local rulebooks of a stride-1 table; *overflow_dev (zeroed by the caller) counts tiles with more
-// than 255 distinct input rows (the staged kernel must not be used for the table then)
+// than NPASS * UMAX distinct input rows (the staged kernel must not be used for the table then)
 int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st) {
   if (n_out <= 0) return EYOC_OK;
-  hipLaunchKernelGGL(k_local_rulebook, dim3(cdiv(cdiv(n_out, 64), 4)), dim3(256), 0, st, nbr_dev, K, n_out, out_dev, overflow_dev);
+  hipLaunchKernelGGL(k_local_rulebook, dim3(cdiv(n_out, TILE)), dim3(256), 0, st, nbr_dev, K, n_out, out_dev, overflow_dev);
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
 }
@@ -307,23 +324,30 @@ int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char
 // stride-1 SPLIT16 layers whose table has a local rulebook (rows in natural = Morton order, no tiling permutation)
 int launch_spconv_st(const SpconvArgs& a, const unsigned char* local_dev, hipStream_t st) {
   EYOC_REQUIRE(a.math == 1 && local_dev && !a.l2norm && a.K == 27 && !a.perm, EYOC_ERR_INVALID, "spconv_st: unsupported layer");
-  const int ctw = a.cout >= 64 ? 64 : 32;
+  static const int shape = [] { const char* e = getenv("EYOC_ST_SHAPE"); return e ? atoi(e) : 1; }();   // 0: 64 x 64 per wave, 1: 128 x 32
+  const int ctg = a.cout >= 64 ? 64 : 32;                            // output channels per workgroup
   const bool wide = spconv_cc(a.cin, a.cout) == 64;
-  const long long wgs = (long long)cdiv(a.n_out, 64 * NW) * (a.cout / ctw);
-  const dim3 grid((unsigned)wgs), block(NW * 64);
-  const size_t lds = (size_t)NW * X_BYTES;
-  static bool attr_done[4] = {false, false, false, false};
-#define EYOC_ST(NTW_, CC_, I_)                                                                                              \
+  const int n_cg = a.cout / ctg;
+  EYOC_REQUIRE(n_cg >= 1 && n_cg <= 8 && 8 % n_cg == 0, EYOC_ERR_INVALID, "spconv_st: %d output channels", a.cout);
+  const int n_tiles = cdiv(a.n_out, TILE);
+  const dim3 grid((unsigned)(cdiv(n_tiles, 8 / n_cg) * 8)), block(NW * 64);
+  const size_t lds = (size_t)X_BYTES;
+  int dev = 0;
+  EYOC_CHECK_HIP(hipGetDevice(&dev));
+  static bool attr_done[64][6] = {};
+#define EYOC_ST(NTW_, CC_, NH_, I_)                                                                                         \
   do {                                                                                                                      \
-    if (!attr_done[I_]) {                                                                                                   \
-      EYOC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spconv_st_kernel<NTW_, CC_>),                        \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                          \
-      attr_done[I_] = true;                                                                                                 \
+    if (dev >= 64 || !attr_done[dev][I_]) {                                                                                 \
+      EYOC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spconv_st_kernel<NTW_, CC_, NH_>),                   \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, X_BYTES));                             \
+      if (dev < 64) attr_done[dev][I_] = true;                                                                              \
     }                                                                                                                       \
-    hipLaunchKernelGGL((spconv_st_kernel<NTW_, CC_>), grid, block, lds, st, a, local_dev);                                  \
+    hipLaunchKernelGGL((spconv_st_kernel<NTW_, CC_, NH_>), grid, block, lds, st, a, local_dev, n_tiles);                    \
   } while (0)
-  if (ctw == 64) { if (wide) EYOC_ST(4, 64, 0); else EYOC_ST(4, 32, 1); }
-  else { if (wide) EYOC_ST(2, 64, 2); else EYOC_ST(2, 32, 3); }
+  if (ctg == 64) {
+    if (shape == 1) { if (wide) EYOC_ST(2, 64, 2, 4); else EYOC_ST(2, 32, 2, 5); }
+    else { if (wide) EYOC_ST(4, 64, 1, 0); else EYOC_ST(4, 32, 1, 1); }
+  } else { if (wide) EYOC_ST(2, 64, 1, 2); else EYOC_ST(2, 32, 1, 3); }
 #undef EYOC_ST
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;

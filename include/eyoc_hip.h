@@ -149,9 +149,9 @@ int eyoc_spconv(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, const f
  * eyoc_spconv_select_split16_kernel forces one (0 wave-private, 2 row-stationary, 1 automatic; returns the previous
  * mode; process-wide, for tests and profiling). */
 int eyoc_spconv_select_split16_kernel(int mode);
-/* Stride-1 (3^3) split16 layers with a tile-local input stage (spconv_st.hip): per 64-row tile the distinct input rows are
+/* Stride-1 (3^3) split16 layers with a tile-local input stage (spconv_st.hip): per 256-row tile the distinct input rows are
  * copied to LDS once per 32-channel block and all 27 offsets run from there.  Needs the table's per-tile "local
- * rulebooks" (built once per table; *overflow_dev counts tiles with more than 255 distinct input rows - the staged
+ * rulebooks" (built once per table; *overflow_dev counts 256-row tiles with more than 1278 distinct input rows - the staged
  * kernel must not be used when it is non-zero; rows in Morton order never overflow).  eyoc_model_forward builds and
  * uses them itself; these entry points exist for tests and profiling. */
 size_t eyoc_spconv_local_rulebook_bytes(int n_out);

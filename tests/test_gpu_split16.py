@@ -283,7 +283,7 @@ def run_layer_staged(nbr, x, W, bias=None, scale=None, res=None, relu=False, out
     local = torch.zeros(int(lib.eyoc_spconv_local_rulebook_bytes(n_out)), dtype=torch.uint8, device=dev)
     ovf = torch.zeros(1, dtype=torch.int32, device=dev)
     L.check(lib.eyoc_spconv_build_local_rulebook(L.ctx(), L.ptr(nd), K, n_out, L.ptr(local), L.ptr(ovf), L.stream_ptr()))
-    assert int(ovf.item()) == 0, "a tile has more than 510 distinct input rows"
+    assert int(ovf.item()) == 0, "a tile has more than 1278 distinct input rows"
     xin = encode(torch.from_numpy(x).to(dev))
     rin = None if res is None else encode(torch.from_numpy(res).to(dev))
     out = torch.full((n_out, cout), -555.0, device=dev)
@@ -324,9 +324,9 @@ def test_staged_kernel_vs_fp64(morton_maps, cin, cout, level):
     got32, _ = run_layer_staged(nbr, x, W, bias=b, scale=s, res=r, relu=True, out_split=False)
     e, e32 = rel_err(got, want), rel_err(got32, want)
     # the local rulebook: distinct rows per tile and their re-use
-    lr = local.cpu().numpy()[:((n + 63) // 64) * 5520].reshape(-1, 5520)
+    lr = local.cpu().numpy()[:((n + 255) // 256) * 32784].reshape(-1, 32784)   # one record per 256-row tile, n_unique first
     n_u = lr[:, :4].copy().view(np.int32)[:, 0]
     pairs = int((nbr >= 0).sum())
     print(f"staged {cin}->{cout} level {level}: n {n} err {e:.2e} / {e32:.2e}  distinct rows per tile mean {n_u.mean():.0f} max {n_u.max()}"
           f"  re-use {pairs / n_u.sum():.2f}x")
-    assert e < 2e-6 and e32 < 2e-6 and n_u.max() <= 510 and n_u.min() >= 1
+    assert e < 2e-6 and e32 < 2e-6 and n_u.max() <= 1278 and n_u.min() >= 1
