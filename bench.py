@@ -349,11 +349,14 @@ def worker(args):
     achieved_tf = flops / (conv_ms * 1e-3) / 1e12
     achieved_gbs = gather / (conv_ms * 1e-3) / 1e9
     math_mode = model.last_spconv_math
-    kernel = ("spconv_rs_kernel<...>" if math_mode == "split16" else "spconv_wave_kernel<...>") + " (the 22 sparse-conv launches of one forward, summed)"
+    kernel = ("spconv_st_kernel<2, 64, 2> (12 of the launches; + spconv_st_kernel<2, 32, 1>, spconv_rs_kernel, spconv_wave_kernel)"
+              if math_mode == "split16" else "spconv_wave_kernel<...>") + " - the 22 sparse-conv launches of one forward, summed"
     if math_mode == "split16":
-        # split16: every algorithmic fp32 multiply-add is three fp16 MFMA multiply-adds at ~1.25 PFLOP/s
-        # (v_mfma_f32_16x16x32_f16, measured by scripts/micro/mfma_f16_rates.hip), i.e. an ideal matrix time of
-        # 3 * flop / 1250 TF ~ 8 ms against gather bytes / 8 TB/s ~ 12 ms: the HBM-side gather is the binding roof
+        # split16: every algorithmic fp32 multiply-add is three fp16 MFMA multiply-adds (2.5 PFLOP/s dense peak), i.e. an
+        # ideal matrix time of 3 * flop / 2500 TF ~ 4 ms against SURVEY 8(d)'s gather bytes / 8 TB/s ~ 12 ms: by the
+        # survey's per-unit figures the HBM-side gather is the binding roof.  (The staged kernel re-uses gathered rows in
+        # LDS, so the measured traffic is BELOW the algorithmic gather bytes; what limits it in practice is MFMA issue
+        # over all 27 offsets of a tile, zero blocks included - DESIGN.md 3.2c.)
         out["roofline"] = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None, "kernel": kernel,
                            "algorithmic_bytes_per_forward": gather, "ms_per_forward": conv_ms, "math": math_mode}

@@ -26,11 +26,15 @@ MATH = int(os.environ.get("MATH", "1"))
 cfgs = [("s1", 1, 64, 64), ("s1", 0, 64, 64), ("s1", 2, 128, 128), ("up", 0, 128, 64), ("s1", 0, 32, 32), ("s1", 3, 256, 256), ("s1", 2, 64, 64)]
 if os.environ.get("ONE"):
     cfgs = cfgs[:1]
+if os.environ.get("K8"):
+    cfgs = [("up", 0, 128, 64), ("down", 0, 32, 64), ("up", 1, 256, 64), ("down", 1, 64, 128)]
 for kind, lvl, cin, cout in cfgs:
     n_out = info["rows"][lvl]
-    n_in = info["rows"][lvl + 1] if kind == "up" else n_out
+    if kind == "down":
+        n_out = info["rows"][lvl + 1]
+    n_in = info["rows"][lvl + 1] if kind == "up" else info["rows"][lvl]
     tab = lib.eyoc_maps_table(maps, {"s1": 0, "down": 1, "up": 2}[kind], lvl)
-    prs = info["pairs_s1"][lvl] if kind == "s1" else info["pairs_up"][lvl]
+    prs = info["pairs_s1"][lvl] if kind == "s1" else info["pairs_up"][lvl] if kind == "up" else info["pairs_down"][lvl]
     x = torch.randn(n_in, cin, device="cuda")
     W = np.random.default_rng(0).normal(size=(27, cin, cout)).astype(np.float32)
     packed = np.zeros(W.size, np.float32)
