@@ -62,6 +62,7 @@ PROTOTYPES = {
     "eyoc_maps_build": (_i, [_vp, _vp, _i, _vp, _sz, _vp, C.POINTER(_vp)]),
     "eyoc_maps_free": (_i, [_vp]),
     "eyoc_maps_internal_order": (_i, [_i]),
+    "eyoc_maps_order_window_shift": (_i, [_i]),
     "eyoc_maps_row_order": (_vp, [_vp]),
     "eyoc_maps_copy_row_order": (_i, [_vp, _vp, _vp]),
     "eyoc_maps_rows": (_i, [_vp, _i]),

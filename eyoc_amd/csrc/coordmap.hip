@@ -162,8 +162,15 @@ __global__ void k_neighbours(const int32_t* __restrict__ coords_out, int n_out, 
 // bits 2-3 (only when key_bits == 4): the y rows before / behind inside the own layer.  Coarse on purpose: finer
 // keys (up to the full 27-bit pattern) pack the chunks better but scatter a tile's rows over the cloud, and the
 // lost L2 locality of the gather costs more than the saved matrix work (measured on MI355X).
+// Z-ordered levels sort their tiling orders inside WINDOWS of 2^wshift consecutive rows (window number above the
+// pattern key): a window's rows and their neighbours stay L2-resident while its pattern runs are walked, instead of
+// every run sweeping the whole level (the transposed convolution 1 -> 0 read 11 GB that way, 2.2x its gather bytes).
+constexpr int KEY_PATTERN_BITS = 11, KEY_WINDOW_BITS = 8;
+__device__ inline unsigned int window_bits(int row, int wshift) {
+  return wshift < 0 ? 0u : (unsigned)min(row >> wshift, (1 << KEY_WINDOW_BITS) - 1) << KEY_PATTERN_BITS;
+}
 __global__ void k_pattern_key(const int32_t* __restrict__ nbr, int n, int key_bits, unsigned int* __restrict__ key,
-                              int* __restrict__ row, unsigned int key_tag) {
+                              int* __restrict__ row, unsigned int key_tag, int wshift) {
   int o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= n) return;
   unsigned int mask = 0;
@@ -172,19 +179,19 @@ __global__ void k_pattern_key(const int32_t* __restrict__ nbr, int n, int key_bi
   const unsigned int lo = mask & 0x1FFu, mid = (mask >> 9) & 0x1FFu, hi = mask >> 18;
   unsigned int kv = (lo ? 1u : 0u) | (hi ? 2u : 0u);
   if (key_bits == 4) kv |= ((mid & 7u) ? 4u : 0u) | ((mid >> 6) ? 8u : 0u);
-  key[o] = key_tag | kv;
+  key[o] = key_tag | window_bits(o, wshift) | kv;
   row[o] = o;
 }
 
 // sort key of a coarse row for the strided convolution: which of its own 8 children exist
 __global__ void k_children_key(const int32_t* __restrict__ children, int nc, unsigned int* __restrict__ key,
-                               int* __restrict__ row, unsigned int key_tag) {
+                               int* __restrict__ row, unsigned int key_tag, int wshift) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nc) return;
   const int4 lo = reinterpret_cast<const int4*>(children)[2 * (size_t)v], hi = reinterpret_cast<const int4*>(children)[2 * (size_t)v + 1];
   const unsigned int m = (lo.x >= 0 ? 1u : 0u) | (lo.y >= 0 ? 2u : 0u) | (lo.z >= 0 ? 4u : 0u) | (lo.w >= 0 ? 8u : 0u) |
                          (hi.x >= 0 ? 16u : 0u) | (hi.y >= 0 ? 32u : 0u) | (hi.z >= 0 ? 64u : 0u) | (hi.w >= 0 ? 128u : 0u);
-  key[v] = key_tag | m;
+  key[v] = key_tag | window_bits(v, wshift) | m;
   row[v] = v;
 }
 
@@ -251,7 +258,7 @@ __global__ void k_children(const int* __restrict__ slot, const int* __restrict__
 __global__ void k_derive_fine(const int32_t* __restrict__ coords, int n, int sh, const int32_t* __restrict__ parent,
                               const int32_t* __restrict__ children, const int32_t* __restrict__ s1c, int nc,
                               int32_t* __restrict__ s1, int32_t* __restrict__ up, unsigned int* __restrict__ up_key,
-                              int* __restrict__ up_row, unsigned int key_tag) {
+                              int* __restrict__ up_row, unsigned int key_tag, int wshift) {
   int o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= n) return;
   const int4 c = reinterpret_cast<const int4*>(coords)[o];
@@ -291,7 +298,7 @@ __global__ void k_derive_fine(const int32_t* __restrict__ coords, int n, int sh,
 #pragma unroll
     for (int a = 0; a < 8; ++a)
       if ((a & cls) == a && blk[a] >= 0) present |= 1u << a;
-    up_key[o] = key_tag | ((unsigned)cls << 8) | present;
+    up_key[o] = key_tag | window_bits(o, wshift) | ((unsigned)cls << 8) | present;
     up_row[o] = o;
   }
 }
@@ -348,8 +355,11 @@ __global__ void k_count_region(const int32_t* __restrict__ coords, int n, HashTa
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
 }
 
-constexpr int UP_KEY_BITS = 11;
+constexpr int UP_KEY_BITS = KEY_PATTERN_BITS + KEY_WINDOW_BITS;
 static int ORDER_MIN_ROWS = 65536;
+// Z-ordered levels: window of the tiling orders, log2 rows.  Measured on the 64-pair bench: 2^17-2^18 rows (2^12, 2^14
+// lose - too many short pattern runs; no windows: +23 % on the 1 -> 0 transposed convolution)
+static int ORDER_WINDOW_SHIFT = getenv("EYOC_ORDER_WINDOW_SHIFT") ? atoi(getenv("EYOC_ORDER_WINDOW_SHIFT")) : 18;
 static int INTERNAL_ORDER = -1;          // eyoc_maps_internal_order: -1 automatic (Z-order from 262144 rows), 0 caller's order, 1 Z-order
 constexpr int ZORDER_MIN_ROWS = 262144;  // the batch size from which the model runs split16 (model.hip)   // below this no convolution of the level reaches the wave-private kernel's tile count
 
@@ -507,9 +517,10 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
     }
     if (m->rows[l] < ORDER_MIN_ROWS) continue;
     if (l + 1 < EYOC_MAX_LEVELS) { seg_up[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l]; }
-    if (s1_order) { seg_s1[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l]; }
+    if (s1_order && !zorder) { seg_s1[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l]; }
   }
-  constexpr int TAG_SHIFT = UP_KEY_BITS, TAG_BITS = 4;   // keys < 2^11, segment tag above (at most 10 segments)
+  constexpr int TAG_SHIFT = UP_KEY_BITS, TAG_BITS = 4;   // pattern keys < 2^11, window number, segment tag above (at most 10 segments)
+  const int wshift = zorder ? ORDER_WINDOW_SHIFT : -1;
   unsigned int* key_in = cv.take<unsigned int>(total);
   unsigned int* key_out = cv.take<unsigned int>(total);
   int* row_in = cv.take<int>(total);
@@ -522,7 +533,7 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
     hipLaunchKernelGGL(k_derive_fine, dim3(cdiv(nl, 256)), dim3(256), 0, st, m->coords[l], nl, l, m->parent[l],
                        m->children[l], m->nbr_s1[l + 1], nc, m->nbr_s1[l], m->nbr_up[l],
                        su >= 0 ? key_in + seg_base[su] : (unsigned int*)nullptr, su >= 0 ? row_in + seg_base[su] : (int*)nullptr,
-                       (unsigned int)(su >= 0 ? su : 0) << TAG_SHIFT);
+                       (unsigned int)(su >= 0 ? su : 0) << TAG_SHIFT, wshift);
     hipLaunchKernelGGL(k_derive_down, dim3(cdiv(nc, 256)), dim3(256), 0, st, nc, m->children[l], m->nbr_s1[l + 1],
                        m->nbr_down[l]);
   }
@@ -530,14 +541,14 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
     const int sd = seg_dn[l];
     if (sd < 0) continue;
     hipLaunchKernelGGL(k_children_key, dim3(cdiv(m->rows[l + 1], 256)), dim3(256), 0, st, m->children[l], m->rows[l + 1],
-                       key_in + seg_base[sd], row_in + seg_base[sd], (unsigned int)sd << TAG_SHIFT);
+                       key_in + seg_base[sd], row_in + seg_base[sd], (unsigned int)sd << TAG_SHIFT, wshift);
   }
   for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
     const int ss = seg_s1[l];
     if (ss < 0) continue;
     const int bits = l == 0 ? 2 : 4;   // level 0 feeds the 32-channel, bandwidth-bound layers: keep more locality
     hipLaunchKernelGGL(k_pattern_key, dim3(cdiv(m->rows[l], 256)), dim3(256), 0, st, m->nbr_s1[l], m->rows[l], bits,
-                       key_in + seg_base[ss], row_in + seg_base[ss], (unsigned int)ss << TAG_SHIFT);
+                       key_in + seg_base[ss], row_in + seg_base[ss], (unsigned int)ss << TAG_SHIFT, wshift);
   }
   if (total > 0) {
     if (int rc = sort_rows_by_key(sort_tmp, sort_bytes, key_in, key_out, row_in, perm_all, (int)total, TAG_SHIFT + TAG_BITS, st)) {
@@ -686,6 +697,12 @@ int eyoc_maps_internal_order(int mode) {
 }
 
 const int32_t* eyoc_maps_row_order(const eyoc_maps* maps) { return maps ? maps->row_perm : nullptr; }
+
+int eyoc_maps_order_window_shift(int shift) {
+  const int prev = ORDER_WINDOW_SHIFT;
+  if (shift >= 0) ORDER_WINDOW_SHIFT = shift;
+  return prev;
+}
 
 int eyoc_maps_order_min_rows(int min_rows) {
   const int prev = ORDER_MIN_ROWS;

@@ -57,17 +57,21 @@ __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restric
   const int row = tile * TILE + (int)threadIdx.x;
   for (int i = threadIdx.x; i < HSLOTS; i += 256) hk[i] = -1;
   __syncthreads();
-  // 1. insert every valid entry (linear probing; duplicates meet their own key)
-  for (int k = 0; k < K; ++k) {
-    const int idx = row < n_out ? nbr[(size_t)k * n_out + row] : -1;
+  // 1. insert every valid entry (linear probing; duplicates meet their own key); the slot found stays in a register
+  unsigned short slot[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const int idx = (k < K && row < n_out) ? nbr[(size_t)k * n_out + row] : -1;
+    unsigned int s = 0xFFFFu;
     if (idx >= 0) {
-      unsigned int s = ((unsigned)idx * 2654435761u) >> 19;
+      s = ((unsigned)idx * 2654435761u) >> 19;
       while (true) {
         const int prev = atomicCAS(&hk[s], -1, idx);
         if (prev == -1 || prev == idx) break;
         s = (s + 1) & (HSLOTS - 1);
       }
     }
+    slot[k] = (unsigned short)s;
   }
   __syncthreads();
   // 2. number the occupied slots in slot order (deterministic): every wave owns a quarter of the table
@@ -99,16 +103,12 @@ __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restric
   // 3. LDS slot of every (offset, row): row r = 64 w + 16 c + j goes to 16-bit lane c of entry (k, 16 w + j)
   unsigned short* loc = reinterpret_cast<unsigned short*>(lr + 16 + UCAP * 4);
   const int r = (int)threadIdx.x, w = r >> 6, c = (r >> 4) & 3, j = r & 15;
+#pragma unroll
   for (int k = 0; k < 27; ++k) {
-    const int idx = (k < K && row < n_out) ? nbr[(size_t)k * n_out + row] : -1;
-    int id = -1;
-    if (idx >= 0) {
-      unsigned int s = ((unsigned)idx * 2654435761u) >> 19;
-      while (hk[s] != idx) s = (s + 1) & (HSLOTS - 1);
-      id = hid[s];
-    }
+    const int id = slot[k] != 0xFFFFu ? (int)hid[slot[k]] : -1;
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
+      if (p > 0 && total <= p * UMAX) continue;                         // nobody reads the entries of a pass that does not happen
       const int l = (id >= p * UMAX && id < (p + 1) * UMAX) ? id - p * UMAX : UMAX;
       loc[(((size_t)(p * 27 + k) * 64) + w * 16 + j) * 4 + c] = (unsigned short)(l * 8 + (l & 7));
     }

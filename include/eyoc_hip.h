@@ -86,6 +86,10 @@ int eyoc_maps_copy_up_order(const eyoc_maps* maps, int level, int32_t* out_dev, 
 /* Levels with fewer rows than this keep the natural order (the sorts only pay off for the large-batch kernel;
  * default 65536).  Process-wide; min_rows < 0 only queries.  Returns the previous value.  For tests / profiling. */
 int eyoc_maps_order_min_rows(int min_rows);
+/* Z-ordered maps sort their tiling orders inside windows of 2^shift consecutive rows (default 18; the window's rows and
+ * their neighbours stay cache-resident while its pattern runs are walked).  Process-wide; shift < 0 only queries.
+ * Returns the previous value.  For tests / profiling. */
+int eyoc_maps_order_window_shift(int shift);
 /* Internal row order.  From 262144 rows on (mode -1, the default) the maps store level 0 in Z-order (Morton order of
  * (batch, x, y, z)) instead of the caller's order, so that 64 consecutive rows are a compact blob of voxels - what
  * the tile-local input stage of the sparse convolution needs.  eyoc_maps_coords / _table then describe the INTERNAL

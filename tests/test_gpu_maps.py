@@ -28,12 +28,15 @@ def order_small_levels():
     lib.eyoc_maps_order_min_rows(prev)
 
 
-def check_up_order(order, up):
+def check_up_order(order, up, window_shift=None):
     """The tiling order of a transposed convolution: a permutation of the rows in which every pattern of
-    occupied offsets forms ONE run, rows ascending inside a run (stable)."""
+    occupied offsets forms ONE run, rows ascending inside a run (stable).  Z-ordered maps order inside windows of
+    2^window_shift consecutive rows (windows ascending, one run per pattern and window)."""
     n = up.shape[1]
     np.testing.assert_array_equal(np.sort(order), np.arange(n))
-    pattern = ((up >= 0) * (1 << np.arange(27, dtype=np.int64))[:, None]).sum(0)[order]
+    window = np.zeros(n, np.int64) if window_shift is None else (order >> window_shift).astype(np.int64)
+    assert (np.diff(window) >= 0).all(), "windows are not in ascending order"
+    pattern = ((up >= 0) * (1 << np.arange(27, dtype=np.int64))[:, None]).sum(0)[order] + (window << 27)
     starts = np.flatnonzero(np.r_[True, pattern[1:] != pattern[:-1]])
     assert len(starts) == len(np.unique(pattern)), "a pattern is split over several runs"
     same = pattern[1:] == pattern[:-1]
@@ -88,8 +91,10 @@ def zorder_rows():
     from eyoc_amd import _lib
     lib = _lib.load()
     prev = lib.eyoc_maps_internal_order(1) - 2
+    prev_w = lib.eyoc_maps_order_window_shift(12)   # several windows in a 62k-row cloud
     yield
     lib.eyoc_maps_internal_order(prev)
+    lib.eyoc_maps_order_window_shift(prev_w)
 
 
 @pytest.mark.parametrize("case", ["random3", "kitti", "tiny"])
@@ -122,7 +127,7 @@ def test_maps_in_z_order_equal_the_oracle_maps_of_the_z_ordered_cloud(zorder_row
         if l < 3:
             np.testing.assert_array_equal(cm.table(_lib.MAP_DOWN, l).cpu().numpy(), maps["down"][l])
             np.testing.assert_array_equal(cm.table(_lib.MAP_UP, l).cpu().numpy(), maps["up"][l])
-            check_up_order(cm.up_order(l).cpu().numpy(), maps["up"][l])
+            check_up_order(cm.up_order(l).cpu().numpy(), maps["up"][l], window_shift=12)
 
 
 def test_maps_keep_the_callers_order_for_small_clouds():
