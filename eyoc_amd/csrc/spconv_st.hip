@@ -122,6 +122,9 @@ template <int NTW, int CC, int NH>
 __global__ __launch_bounds__(NW * 64, 2) void spconv_st_kernel(SpconvArgs a, const unsigned char* __restrict__ local, int n_tiles) {
   constexpr int CTW = NTW * 16, NC = 4;
   constexpr int CTG = CTW * NH;                                        // output channels per workgroup
+  // offsets the weight fragments run ahead (measured: the 32-channel layers' short offsets want two - 0.43 -> 0.39 ms on
+  // the 1.95 M-row 32 -> 32 layer - the others lose 8 % to the third register set)
+  constexpr int WD = (NTW * NH <= 2) ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char xs[];   // the workgroup's stage: XROWS x 128 bytes
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -182,28 +185,26 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_kernel(SpconvArgs a, con
   // stage block qb of the tile's distinct input rows: 8 lanes per row (one 128-byte line), 8 rows per instruction, wave w
   // takes the 8-row groups 4 it + w; global -> LDS directly (global_load_lds_dwordx4: lane i lands at base + 16 i, so the
   // XOR swizzle of the pieces is applied on the SOURCE side), all loads of a stage in flight at once
-  int Ureg[NIT];                                                     // this lane's rows of the pass
+  // (the row numbers are re-read from the rulebook for every block: 20 registers held across the offset loop cost more
+  // than one L2 round trip per block, which the other workgroup of the CU covers)
   int n_up = 0;                                                      // distinct rows of the current pass
-  auto begin_pass = [&](int pass) {
-    n_up = min(n_u - pass * UMAX, UMAX);
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int l = (it * NW + wave) * 8 + (lane >> 3);
-      Ureg[it] = l < n_up ? U[pass * UMAX + l] : 0;
-    }
-  };
-  auto stage = [&](int qb) {
+  auto stage = [&](int pass, int qb) {
 #if defined(EYOC_ST_ABL) && (EYOC_ST_ABL & 2)
     return;
 #endif
+    int Ureg[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int l = (it * NW + wave) * 8 + (lane >> 3);
+      asm volatile("" : "+v"(l));                                      // opaque: or the loads are hoisted out of the block loop (and spill)
+      Ureg[it] = l < n_up ? U[pass * UMAX + l] : 0;
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int l0 = (it * NW + wave) * 8;
       if (l0 < n_up) {                                               // wave-uniform
         const int l = l0 + (lane >> 3);
-        int u = Ureg[it];
-        asm volatile("" : "+v"(u));                                    // keep the 20 source addresses out of the registers between blocks
-        const float* src = a.in + (size_t)u * a.ld_in + qb * 32 + (((lane & 7) ^ (l & 7)) << 2);
+        const float* src = a.in + (size_t)Ureg[it] * a.ld_in + qb * 32 + (((lane & 7) ^ (l & 7)) << 2);
         if (l < n_up)
           __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(xs + l0 * 128), 16, 0, 0);
       }
@@ -238,19 +239,20 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_kernel(SpconvArgs a, con
   };
 
   // ---- per (pass, block): stage, then 27 offsets of NH half-steps (64 rows each).  While a half-step multiplies, the
-  // operands of the next one are read from LDS into the other X set; the weight fragments of offset k + 1 arrive from L2
-  // in the other W set while offset k multiplies; the rulebook entries run two offsets ahead.
-  float4 XA[NC][2], XB[NC][2], WA[NTW][2], WB[NTW][2];
+  // operands of the next one are read from LDS into the other X set; weight fragments and rulebook entries run two
+  // offsets ahead (three register sets each).
+  float4 XA[NC][2], XB[NC][2], W[3][NTW][2];
   uint2 L[3][NH];
   bool first = true;
   for (int pass = 0; pass < n_pass; ++pass) {
-    begin_pass(pass);
+    n_up = min(n_u - pass * UMAX, UMAX);
     const uint2* lp = locp + pass * 27 * 64;
     for (int qb = 0; qb < nqb; ++qb) {
       if (!first) __syncthreads();                                     // every wave is done with the previous block's rows
       first = false;
-      stage(qb);
-      load_w(0, qb, WA);
+      stage(pass, qb);
+      load_w(0, qb, W[0]);
+      if (WD == 2) load_w(1, qb, W[1]);
 #pragma unroll
       for (int h = 0; h < NH; ++h) { L[0][h] = lp[h * 16]; L[1][h] = lp[64 + h * 16]; }
       __builtin_amdgcn_s_waitcnt(0x0070);                              // vmcnt(0): this wave's part of the stage has landed
@@ -259,20 +261,18 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_kernel(SpconvArgs a, con
 #pragma unroll
       for (int hs = 0; hs < 27 * NH; ++hs) {
         const int k = hs / NH, h = hs % NH;                            // compile-time after unrolling
-        if (h == 0) {
-          if (k + 2 < 27) {
+        if (h == 0 && k + 2 < 27) {
 #pragma unroll
-            for (int hh = 0; hh < NH; ++hh) L[(k + 2) % 3][hh] = lp[(k + 2) * 64 + hh * 16];
-          }
-          if (k < 26) { if (k & 1) load_w(k + 1, qb, WA); else load_w(k + 1, qb, WB); }
+          for (int hh = 0; hh < NH; ++hh) L[(k + 2) % 3][hh] = lp[(k + 2) * 64 + hh * 16];
         }
+        if (h == 0 && k + WD < 27) load_w(k + WD, qb, W[(k + WD) % 3]);   // weights run WD offsets ahead
         const int hn = hs + 1, kn = hn / NH, hhn = hn % NH;
         if (hs & 1) {
           if (hn < 27 * NH) read_x(L[kn % 3][hhn], XA);
-          if (k & 1) multiply(h, XB, WB); else multiply(h, XB, WA);
+          multiply(h, XB, W[k % 3]);
         } else {
           if (hn < 27 * NH) read_x(L[kn % 3][hhn], XB);
-          if (k & 1) multiply(h, XA, WB); else multiply(h, XA, WA);
+          multiply(h, XA, W[k % 3]);
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting later offsets' loads up here (register budget: 256)
       }
