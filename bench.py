@@ -271,16 +271,46 @@ def worker(args):
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     last = {}
-    for s in range(steps_timed):
-        ids, batch = batches[s % len(batches)]
-        results = pipe.register(batch)
-        last[s % len(batches)] = results
+    # Software-pipelined over the steps: step s is ENQUEUED before the host reads step s-1's results and timers (two
+    # event sets, results left on the device until then), so the GPU never waits for the host's decode between steps.
+    # Everything - the last step's read-back included - is inside the timed bracket.
+    pending = None           # (step, device result, event slot) of the step whose read-back is still due
+
+    def collect(item):
+        nonlocal layer_ms, n_fwd
+        s_, res_, slot_ = item
+        batch_ = batches[s_ % len(batches)][1]
+        host = res_.cpu()
+        last[s_ % len(batches)] = [eyoc_amd.registration.decode_ransac_result(host[p], batch_.n_points) for p in range(batch_.P)] \
+            if cfg.use_RANSAC else res_
         if model is not None:
-            ms = np.array(model.layer_ms())         # events were recorded on the launch stream; read after the step's sync
+            model.timing_slot(slot_)
+            ms = np.array(model.layer_ms())
             layer_ms = ms if layer_ms is None else layer_ms + ms
-            for k, v in pipe.stage_ms().items():
+            for k, v in pipe.stage_ms(slot_).items():
                 stage_ms[k] += v
             n_fwd += 1
+
+    for s in range(steps_timed):
+        ids, batch = batches[s % len(batches)]
+        if dry or not cfg.use_RANSAC:
+            last[s % len(batches)] = pipe.register(batch)
+            if model is not None and not dry:
+                ms = np.array(model.layer_ms())
+                layer_ms = ms if layer_ms is None else layer_ms + ms
+                for k, v in pipe.stage_ms().items():
+                    stage_ms[k] += v
+                n_fwd += 1
+            continue
+        slot = s & 1
+        model.timing_slot(slot)
+        pipe.slot = slot
+        res = pipe.register(batch, return_device=True)
+        if pending is not None:
+            collect(pending)
+        pending = (s, res, slot)
+    if pending is not None:
+        collect(pending)
     edist.barrier()
     if not dry:
         torch.cuda.synchronize()

@@ -46,8 +46,9 @@ struct eyoc_model {
   int math = -1;           // -1 automatic, 0 fp32 MFMA, 1 SPLIT16 (eyoc_model_set_math)
   int last_math = 0;       // what the last forward used
   int timing = 0;
-  std::vector<hipEvent_t> events;
-  int events_valid = 0;
+  std::vector<hipEvent_t> events;     // two sets of layers + 1 events (eyoc_model_timing_slot)
+  int slot = 0;
+  int events_valid[2] = {0, 0};
 };
 
 namespace {
@@ -252,19 +253,26 @@ int eyoc_model_last_math(const eyoc_model* m) { return m ? m->last_math : -1; }
 int eyoc_model_set_timing(eyoc_model* m, int on) {
   EYOC_REQUIRE(m, EYOC_ERR_INVALID, "eyoc_model_set_timing: NULL model");
   m->timing = on ? 1 : 0;
-  m->events_valid = 0;
+  m->events_valid[0] = m->events_valid[1] = 0;
   if (on && m->events.empty()) {
-    m->events.resize(m->layers.size() + 1);
+    m->events.resize(2 * (m->layers.size() + 1));
     for (auto& e : m->events) EYOC_CHECK_HIP(hipEventCreate(&e));
   }
   return EYOC_OK;
 }
 
+int eyoc_model_timing_slot(eyoc_model* m, int slot) {
+  EYOC_REQUIRE(m && (slot == 0 || slot == 1), EYOC_ERR_INVALID, "eyoc_model_timing_slot: slot %d", slot);
+  m->slot = slot;
+  return EYOC_OK;
+}
+
 int eyoc_model_layer_ms(eyoc_model* m, float* ms) {
   EYOC_REQUIRE(m && ms, EYOC_ERR_INVALID, "eyoc_model_layer_ms: NULL argument");
-  EYOC_REQUIRE(m->timing && m->events_valid, EYOC_ERR_INVALID, "eyoc_model_layer_ms: no timed forward recorded");
-  EYOC_CHECK_HIP(hipEventSynchronize(m->events.back()));
-  for (size_t i = 0; i < m->layers.size(); ++i) EYOC_CHECK_HIP(hipEventElapsedTime(&ms[i], m->events[i], m->events[i + 1]));
+  EYOC_REQUIRE(m->timing && m->events_valid[m->slot], EYOC_ERR_INVALID, "eyoc_model_layer_ms: no timed forward recorded in slot %d", m->slot);
+  const hipEvent_t* ev = m->events.data() + (size_t)m->slot * (m->layers.size() + 1);
+  EYOC_CHECK_HIP(hipEventSynchronize(ev[m->layers.size()]));
+  for (size_t i = 0; i < m->layers.size(); ++i) EYOC_CHECK_HIP(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
   return EYOC_OK;
 }
 
@@ -292,7 +300,8 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
   EYOC_REQUIRE(want != 1 || split, EYOC_ERR_INVALID,
                "eyoc_model_forward: split16 arithmetic is not available for this model / kernel selection");
   m->last_math = split ? 1 : 0;
-  if (m->timing) EYOC_CHECK_HIP(hipEventRecord(m->events[0], st));
+  hipEvent_t* ev = m->timing ? m->events.data() + (size_t)m->slot * (m->layers.size() + 1) : nullptr;
+  if (m->timing) EYOC_CHECK_HIP(hipEventRecord(ev[0], st));
   for (size_t li = 0; li < m->layers.size(); ++li) {
     const LayerPlan& p = m->layers[li];
     const int n_out = maps->rows[p.out_level];
@@ -304,6 +313,22 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
       a.out = buf[p.out_buf] + p.out_col; a.ld_out = m->bufs[p.out_buf].width;
       a.out_split = split ? 1 : 0;
       a.in_perm = maps->row_perm;                        // Z-ordered maps: the caller's features are read through the permutation
+      if (a.in_perm) {
+        // ... once: a copy in internal order in a buffer nothing uses yet (an indirection per probed neighbour cost the
+        // 5^3 first convolution 0.4 of its 2.0 ms on the 64-pair batch)
+        int best = -1;
+        size_t best_sz = 0;
+        for (int i = B_X1; i < B_OUT; ++i) {
+          const size_t sz = (size_t)maps->rows[m->bufs[i].level] * m->bufs[i].width;
+          if (i != p.out_buf && sz > best_sz) { best = i; best_sz = sz; }
+        }
+        if (best >= 0 && best_sz >= (size_t)n_out * p.cin) {
+          rc = launch_permute_rows(a.in, a.in_perm, n_out, p.cin, buf[best], st);
+          if (rc) return rc;
+          a.in = buf[best];
+          a.in_perm = nullptr;
+        }
+      }
       a.parent = maps->parent[0]; a.children = maps->children[0]; a.s1c = maps->nbr_s1[1]; a.nc = maps->rows[1];
       rc = conv1_walks_octree(a) ? EYOC_OK : maps_build_table0(const_cast<eyoc_maps*>(maps), st);
       if (!rc) rc = launch_conv1(a, st);
@@ -332,9 +357,9 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
       rc = launch_spconv(a, st);
     }
     if (rc) return rc;
-    if (m->timing) EYOC_CHECK_HIP(hipEventRecord(m->events[li + 1], st));
+    if (m->timing) EYOC_CHECK_HIP(hipEventRecord(ev[li + 1], st));
   }
-  if (m->timing) m->events_valid = 1;
+  if (m->timing) m->events_valid[m->slot] = 1;
   return EYOC_OK;
 }
 

@@ -86,6 +86,7 @@ __device__ inline float4 split16_load4(const float* row, int c) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 int launch_spconv(const SpconvArgs& a, hipStream_t st);
+int launch_permute_rows(const float* in, const int32_t* perm, int n, int c, float* out, hipStream_t st);
 int launch_spconv_st(const SpconvArgs& a, const unsigned char* local_dev, hipStream_t st);   // tile-local input stage (spconv_st.hip)
 size_t local_rulebook_bytes(int n_out);
 int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st);

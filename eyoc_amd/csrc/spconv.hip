@@ -626,6 +626,20 @@ bool conv1_walks_octree(const Conv1Args& a) {
   return a.parent && a.children && a.s1c && (a.ks == 3 || a.ks == 5) && tree_lds <= 64 * 1024;
 }
 
+// out[i, :] = in[perm[i], :] for narrow rows (the network input, C_in = 1 in production)
+__global__ void k_permute_rows(const float* __restrict__ in, const int32_t* __restrict__ perm, int n, int c, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)n * c) return;
+  const int r = (int)(i / c), j = (int)(i - (long long)r * c);
+  out[i] = in[(size_t)perm[r] * c + j];
+}
+int launch_permute_rows(const float* in, const int32_t* perm, int n, int c, float* out, hipStream_t st) {
+  if (n <= 0) return EYOC_OK;
+  hipLaunchKernelGGL(k_permute_rows, dim3((unsigned)cdiv((long long)n * c, 256)), dim3(256), 0, st, in, perm, n, c, out);
+  EYOC_CHECK_HIP(hipGetLastError());
+  return EYOC_OK;
+}
+
 int launch_conv1(const Conv1Args& a, hipStream_t st) {
   EYOC_REQUIRE(a.ks == 1 || a.ks == 3 || a.ks == 5 || a.ks == 7, EYOC_ERR_INVALID, "conv1: kernel size %d", a.ks);
   EYOC_REQUIRE(a.cin >= 1 && a.cin * a.cout <= 8192, EYOC_ERR_INVALID, "conv1: C_in %d x C_out %d too large", a.cin, a.cout);

@@ -132,18 +132,20 @@ class RegistrationPipeline:
         # ``timing = True`` every ``register`` brackets its stages with events on the launch stream and
         # ``stage_ms()`` returns the durations of the last call (synchronises)
         self.timing = False
+        self.slot = 0          # which of two event sets the next ``register`` records into (see ``stage_ms``)
         self._ev = None
 
     def _mark(self, i):
         if self.timing:
             if self._ev is None:
-                self._ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            self._ev[i].record()
+                self._ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(2)]
+            self._ev[self.slot][i].record()
 
-    def stage_ms(self):
-        """``dict(feat=, match=, reg=)`` of the last timed ``register``: maps + forward; row gather + feature NN;
-        RANSAC / SC2-PCR."""
-        e = self._ev
+    def stage_ms(self, slot=None):
+        """``dict(feat=, match=, reg=)`` of the last timed ``register`` of event set ``slot`` (default: the current
+        one): maps + forward; row gather + feature NN; RANSAC / SC2-PCR.  Two sets, so that step k's timers can be read
+        after step k+1 was enqueued."""
+        e = self._ev[self.slot if slot is None else slot]
         e[3].synchronize()
         return {"feat": e[0].elapsed_time(e[1]), "match": e[1].elapsed_time(e[2]), "reg": e[2].elapsed_time(e[3])}
 

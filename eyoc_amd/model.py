@@ -260,6 +260,11 @@ class ResUNet2(nn.Module):
         if self._handle is not None:
             _lib.check(_lib.load().eyoc_model_set_timing(self._handle, 1 if on else 0), "eyoc_model_set_timing")
 
+    def timing_slot(self, slot: int):
+        """Select one of the two event sets the timed forwards record into / ``layer_ms`` reads from: a caller that
+        alternates them can enqueue step k+1 before it reads step k's durations (no host wait between steps)."""
+        _lib.check(_lib.load().eyoc_model_timing_slot(self._handle, int(slot)), "eyoc_model_timing_slot")
+
     def layer_ms(self):
         lib = _lib.load()
         n = lib.eyoc_model_num_layers(self._handle)

@@ -244,6 +244,9 @@ int eyoc_model_last_math(const eyoc_model* model);
  * eyoc_model_layer_ms returns the per-layer durations of the last forward (synchronises) */
 int eyoc_model_set_timing(eyoc_model* model, int on);
 int eyoc_model_layer_ms(eyoc_model* model, float* ms /*[num_layers]*/);
+/* Two event sets: forwards record into, and eyoc_model_layer_ms reads from, the selected one (0 or 1) - so that a caller
+ * can enqueue step k + 1 before it reads step k's durations, and the GPU never waits for the host between steps. */
+int eyoc_model_timing_slot(eyoc_model* model, int slot);
 
 /* ------------------------------------------------------------------------------------------------
  * feature matching
