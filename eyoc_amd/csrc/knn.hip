@@ -51,7 +51,8 @@ __global__ void knn_transpose_targets(const float* __restrict__ B, SegArgs seg, 
 template <int C, bool TOP2, bool DOT>
 __global__ __launch_bounds__(256) void knn1_kernel(const float* __restrict__ A, const float* __restrict__ Bt,
                                                    SegArgs seg, int split_len, int dist_type,
-                                                   unsigned long long* __restrict__ best, float* __restrict__ second) {
+                                                   unsigned long long* __restrict__ best, float* __restrict__ second,
+                                                   const int* __restrict__ only = nullptr) {
 #pragma clang fp contract(off)
   const int s = blockIdx.z;
   const int a0 = seg.a[s], na = seg.a[s + 1] - a0;
@@ -64,7 +65,11 @@ __global__ __launch_bounds__(256) void knn1_kernel(const float* __restrict__ A, 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int q = q0 + lane;
-  const bool q_ok = q < na;
+  bool q_ok = q < na;
+  if (only) {   // second pass of the MFMA pre-filter: only the rows it could not decide; most waves have none
+    q_ok = q_ok && only[a0 + q] != 0;
+    if (__ballot(q_ok) == 0ull) return;                              // the whole block: its four waves share the queries
+  }
   f32x2 a[C];   // {a_c, a_c}: the query's feature in both halves of a packed operand
   {
     const float4* src = reinterpret_cast<const float4*>(A + (size_t)(a0 + (q_ok ? q : 0)) * C);
@@ -196,6 +201,152 @@ __global__ void knn1_unpack(const unsigned long long* __restrict__ best, int n, 
   if (dist) dist[i] = dot ? -__uint_as_float(bits) : __uint_as_float(bits);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// MFMA pre-filter for the plain index query (SquareL2, no distances asked for, enough rows to fill the chip).
+//
+// The contract above costs 3 VALU ops per (query, target, channel) - 3.3 ms for the bench's 64 x 5000 x 5000 x 32.  The
+// arg-min, however, is almost always decided by a far cheaper score: s(i, j) = |b_j|^2 - 2 <a_i, b_j> on the fp32
+// matrix pipe (v_mfma_f32_16x16x4_f32; the norm rides along as a 33rd "channel" against a constant 1).  With
+// |s(i, j) - (d(i, j) - |a_i|^2)| <= e for every j - d the contract's fp32 value - the contract's arg-min j* satisfies
+// s(j*) <= min_j s + 2 e.  So every wave tracks, per query, the smallest score with its index AND the second smallest
+// score: if the runner-up is farther than 2 e, the index is final (exact ties included: they would both be within
+// 2 e); otherwise the row is flagged and the exact kernel above recomputes it (waves without a flagged row exit at
+// once).  e = 128 u (|a_i| + max_j |b_j|)^2, u = 2^-24, covers the rounding of both evaluations with a wide margin
+// (K = 36 products and sums of magnitude <= (|a| + |b|)^2 on either side).  Rows with non-finite scores are flagged too.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+struct SegMfma { long long bm_off[MAX_SEG]; };
+constexpr int MF_ROWS = 64;                    // query rows per wave (4 MFMA row tiles)
+
+// B operand fragments: tile t (16 targets), slice q (4 channels; slice C/4 = the norm): 64 floats, lane l = element
+// (k = 4 q + l / 16, j = 16 t + l % 16): -2 b[j][k], or |b_j|^2 against the constant 1 of the queries (padding: +inf)
+template <int C>
+__global__ void knn_pack_targets_mfma(const float* __restrict__ B, SegArgs seg, SegMfma sm, float* __restrict__ Bm,
+                                      int* __restrict__ bmax_bits) {
+  constexpr int NQ = C / 4 + 1;
+  const int s = blockIdx.z;
+  const int b0 = seg.b[s], nb = seg.b[s + 1] - b0;
+  const int n16 = (nb + 15) / 16;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;        // (tile, lane)
+  if (idx >= n16 * 64) return;
+  const int t = idx >> 6, l = idx & 63, j = 16 * t + (l & 15), kq = l >> 4;
+  float* dst = Bm + sm.bm_off[s] + (size_t)t * NQ * 64 + l;
+  const bool ok = j < nb;
+  const float* row = B + (size_t)(b0 + (ok ? j : 0)) * C;
+  float n2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < C / 4; ++q) {
+    const float4 v = *reinterpret_cast<const float4*>(row + 4 * q);
+    n2 += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    const float mine = kq == 0 ? v.x : kq == 1 ? v.y : kq == 2 ? v.z : v.w;
+    dst[q * 64] = ok ? -2.0f * mine : 0.0f;
+  }
+  dst[(C / 4) * 64] = kq == 0 ? (ok ? n2 : __builtin_inff()) : 0.0f;
+  if (ok && kq == 0 && n2 == n2) atomicMax(bmax_bits + s, __float_as_int(n2));   // non-negative floats order like ints
+}
+
+__global__ void knn_row_norms(const float* __restrict__ A, int n, int C, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float n2 = 0.f;
+  for (int c = 0; c < C; ++c) n2 += A[(size_t)i * C + c] * A[(size_t)i * C + c];
+  out[i] = n2;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void knn_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Bm, SegArgs seg,
+                                                       SegMfma sm, const float* __restrict__ anorm,
+                                                       const int* __restrict__ bmax_bits,
+                                                       unsigned long long* __restrict__ best, int* __restrict__ flags) {
+  constexpr int NQ = C / 4 + 1, RT = MF_ROWS / 16;
+  const int s = blockIdx.z;
+  const int a0 = seg.a[s], na = seg.a[s + 1] - a0;
+  const int nb = seg.b[s + 1] - seg.b[s];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int q0 = (blockIdx.x * 4 + wave) * MF_ROWS;
+  if (q0 >= na || nb <= 0) return;                                  // wave-uniform; no barrier in this kernel
+  const int jl = lane & 15, g = lane >> 4;
+  // A fragments: row tile r, slice q: element (i = q0 + 16 r + jl, k = 4 q + g); the last slice is the constant 1
+  float af[RT][NQ];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const int i = q0 + 16 * r + jl;
+    const float* row = A + (size_t)(a0 + (i < na ? i : na - 1)) * C;
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) af[r][q] = row[4 * q + g];
+    af[r][C / 4] = g == 0 ? 1.0f : 0.0f;
+  }
+  // per lane: queries 16 r + 4 g + e (e = 0..3) against the targets j = jl (mod 16)
+  float m1[RT][4], m2[RT][4];
+  int j1[RT][4];
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { m1[r][e] = __builtin_inff(); m2[r][e] = __builtin_inff(); j1[r][e] = 0x7FFFFFFF; }
+  const float* bm = Bm + sm.bm_off[s] + lane;
+  const int n16 = (nb + 15) / 16;
+  float bf[2][NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) bf[0][q] = bm[q * 64];
+  for (int t = 0; t < n16; t += 2) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int tt = t + half;
+      if (tt >= n16) break;                                          // wave-uniform
+      if (tt + 1 < n16) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) bf[half ^ 1][q] = bm[((size_t)(tt + 1) * NQ + q) * 64];
+      }
+      const int jt = 16 * tt + jl;
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][q], bf[half][q], acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = acc[e];
+          const bool better = v < m1[r][e];
+          const float lose = better ? m1[r][e] : v;                  // NaN scores never enter
+          m2[r][e] = lose < m2[r][e] ? lose : m2[r][e];
+          m1[r][e] = better ? v : m1[r][e];
+          j1[r][e] = better ? jt : j1[r][e];
+        }
+      }
+    }
+  }
+  // merge the 16 lanes of a group (same queries, interleaved targets): smaller score, ties to the lower index; the
+  // loser's best and both runner-ups compete for the runner-up
+  const float bmax = sqrtf(__int_as_float(bmax_bits[s]));
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a1 = m1[r][e], a2 = m2[r][e];
+      int k1 = j1[r][e];
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) {
+        const float o1 = __shfl_xor(a1, d, 64), o2 = __shfl_xor(a2, d, 64);
+        const int ok1 = __shfl_xor(k1, d, 64);
+        const bool take = (o1 < a1) | ((o1 == a1) & (ok1 < k1));
+        const float lose = take ? a1 : o1;
+        a1 = take ? o1 : a1;
+        k1 = take ? ok1 : k1;
+        const float rr = a2 < o2 ? a2 : o2;
+        a2 = lose < rr ? lose : rr;
+      }
+      const int i = q0 + 16 * r + 4 * g + e;
+      if (jl == 0 && i < na) {
+        const float an = sqrtf(anorm[a0 + i]);
+        const float err = 128.0f * 5.9604645e-8f * (an + bmax) * (an + bmax);
+        // decided: a finite best whose runner-up is out of reach.  (a2 - a1 <= 2 err, NaN / inf anywhere: not decided)
+        const bool decided = (a1 < __builtin_inff()) & (a1 > -__builtin_inff()) & (a2 - a1 > 2.0f * err) & (k1 != 0x7FFFFFFF);
+        best[a0 + i] = decided ? (unsigned long long)(unsigned)k1 : ~0ull;
+        flags[a0 + i] = decided ? 0 : 1;
+      }
+    }
+}
+
 // dense distance matrix (lib/metrics.py:22-29) with the same arithmetic contract as knn1_kernel
 __global__ void pdist_kernel(const float* __restrict__ A, int n, const float* __restrict__ B, int m, int c,
                              int dist_type, float* __restrict__ out) {
@@ -216,7 +367,7 @@ __global__ void pdist_kernel(const float* __restrict__ A, int n, const float* __
 
 template <int C>
 void launch_knn(const float* A, const float* Bt, const SegArgs& seg, int nseg, int max_na, int max_nb, int dist_type,
-                unsigned long long* best, float* second, bool dot, hipStream_t st) {
+                unsigned long long* best, float* second, bool dot, hipStream_t st, const int* only = nullptr) {
   int qtiles = eyoc::cdiv(max_na, 64);
   int total = qtiles * nseg;
   int max_splits = eyoc::cdiv(max_nb, SPLIT_ALIGN);
@@ -226,12 +377,19 @@ void launch_knn(const float* A, const float* Bt, const SegArgs& seg, int nseg, i
   int split_len = eyoc::cdiv(eyoc::cdiv(max_nb, nsplit), SPLIT_ALIGN) * SPLIT_ALIGN;
   nsplit = eyoc::cdiv(max_nb, split_len);
   dim3 grid(qtiles, nsplit, nseg);
-  if (second) hipLaunchKernelGGL((knn1_kernel<C, true, false>), grid, dim3(256), 0, st, A, Bt, seg, split_len, dist_type, best, second);
-  else if (dot) hipLaunchKernelGGL((knn1_kernel<C, false, true>), grid, dim3(256), 0, st, A, Bt, seg, split_len, 0, best, second);
-  else hipLaunchKernelGGL((knn1_kernel<C, false, false>), grid, dim3(256), 0, st, A, Bt, seg, split_len, dist_type, best, second);
+  if (second) hipLaunchKernelGGL((knn1_kernel<C, true, false>), grid, dim3(256), 0, st, A, Bt, seg, split_len, dist_type, best, second, (const int*)nullptr);
+  else if (dot) hipLaunchKernelGGL((knn1_kernel<C, false, true>), grid, dim3(256), 0, st, A, Bt, seg, split_len, 0, best, second, (const int*)nullptr);
+  else hipLaunchKernelGGL((knn1_kernel<C, false, false>), grid, dim3(256), 0, st, A, Bt, seg, split_len, dist_type, best, second, only);
 }
 
 }  // namespace
+
+static int g_knn_prefilter = getenv("EYOC_KNN_PREFILTER") ? atoi(getenv("EYOC_KNN_PREFILTER")) : 1;
+extern "C" int eyoc_knn_prefilter(int mode) {
+  const int prev = g_knn_prefilter;
+  if (mode >= 0 && mode <= 2) g_knn_prefilter = mode;
+  return prev;
+}
 
 static int knn_run(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c, const int32_t* seg_a,
                    const int32_t* seg_b, int nseg, int dist_type, int64_t* idx_dev, float* dist_dev, float* second_dev,
@@ -263,19 +421,48 @@ static int knn_run(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c,
     bt_floats += (long long)seg.ld[s] * c;
     max_ld = seg.ld[s] > max_ld ? seg.ld[s] : max_ld;
   }
+  // MFMA pre-filter (see knn_mfma_kernel): plain index queries that fill the chip
+  const int prefilter_env = g_knn_prefilter;
+  long long waves = 0, bm_floats = 0;
+  SegMfma sm;
+  for (int s = 0; s < nseg; ++s) {
+    waves += eyoc::cdiv(seg_a[s + 1] - seg_a[s], MF_ROWS);
+    sm.bm_off[s] = bm_floats;
+    bm_floats += (long long)eyoc::cdiv(seg_b[s + 1] - seg_b[s], 16) * (c / 4 + 1) * 64;
+  }
+  const bool prefilter = prefilter_env != 0 && !dot && !second_dev && !dist_dev && dist_type == 0 && c == 32 && max_nb > 0 &&
+                         (waves >= 1024 || prefilter_env == 2);
   const size_t off_bt = eyoc::align_up((size_t)n_total * sizeof(unsigned long long));
-  int rc = ctx->ensure_scratch(off_bt + (size_t)bt_floats * sizeof(float) + 64);
+  const size_t off_bm = eyoc::align_up(off_bt + (size_t)bt_floats * sizeof(float) + 64);
+  const size_t off_an = eyoc::align_up(off_bm + (prefilter ? (size_t)bm_floats * sizeof(float) : 0));
+  const size_t off_fl = eyoc::align_up(off_an + (prefilter ? (size_t)n_total * sizeof(float) : 0));
+  const size_t off_bx = eyoc::align_up(off_fl + (prefilter ? (size_t)n_total * sizeof(int) : 0));
+  int rc = ctx->ensure_scratch(off_bx + MAX_SEG * sizeof(int) + 64);
   if (rc) return rc;
   unsigned long long* best = (unsigned long long*)ctx->scratch;
   float* Bt = (float*)((char*)ctx->scratch + off_bt);
   EYOC_CHECK_HIP(hipMemsetAsync(best, 0xFF, (size_t)n_total * sizeof(unsigned long long), st));
+  const int* only = nullptr;
+  if (prefilter) {
+    float* Bm = (float*)((char*)ctx->scratch + off_bm);
+    float* anorm = (float*)((char*)ctx->scratch + off_an);
+    int* flags = (int*)((char*)ctx->scratch + off_fl);
+    int* bmax = (int*)((char*)ctx->scratch + off_bx);
+    EYOC_CHECK_HIP(hipMemsetAsync(bmax, 0, MAX_SEG * sizeof(int), st));
+    hipLaunchKernelGGL(knn_pack_targets_mfma<32>, dim3(eyoc::cdiv((long long)eyoc::cdiv(max_nb, 16) * 64, 256), 1, nseg), dim3(256), 0, st,
+                       B_dev, seg, sm, Bm, bmax);
+    hipLaunchKernelGGL(knn_row_norms, dim3(eyoc::cdiv(n_total, 256)), dim3(256), 0, st, A_dev, n_total, c, anorm);
+    hipLaunchKernelGGL(knn_mfma_kernel<32>, dim3(eyoc::cdiv(max_na, 4 * MF_ROWS), 1, nseg), dim3(256), 0, st, A_dev, Bm, seg, sm,
+                       anorm, bmax, best, flags);
+    only = flags;
+  }
   if (max_nb > 0) {
     hipLaunchKernelGGL(knn_transpose_targets, dim3(eyoc::cdiv((long long)max_ld * (c / 4), 256), 1, nseg), dim3(256), 0, st, B_dev,
                        seg, c, Bt);
     switch (c) {
       case 4: launch_knn<4>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, dot, st); break;
       case 16: launch_knn<16>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, dot, st); break;
-      case 32: launch_knn<32>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, dot, st); break;
+      case 32: launch_knn<32>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, dot, st, only); break;
       case 64: launch_knn<64>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, dot, st); break;
       default: launch_knn<128>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, dot, st); break;
     }

@@ -56,7 +56,8 @@ def knn1_segmented(A: torch.Tensor, B: torch.Tensor, seg_a, seg_b, dist_type="Sq
         raise NotImplementedError('Not implemented')
     A, B = _cuda_f32(A), _cuda_f32(B, A.device if A.is_cuda else None)
     idx = torch.empty(A.shape[0], dtype=torch.int64, device=A.device)
-    dist = torch.empty(A.shape[0], dtype=torch.float32, device=A.device)
+    # no distances asked for: the library is told so (NULL) - it may then decide most rows by an MFMA score (knn.hip)
+    dist = torch.empty(A.shape[0] if return_distance else 0, dtype=torch.float32, device=A.device)
     if A.shape[0] == 0:
         return (idx, dist) if return_distance else idx
     if A.shape[1] != B.shape[1]:
@@ -64,7 +65,8 @@ def knn1_segmented(A: torch.Tensor, B: torch.Tensor, seg_a, seg_b, dist_type="Sq
     with torch.cuda.device(A.device):
         for a0, sa, sb, ns in _segment_chunks(seg_a, seg_b):
             _lib.check(_lib.load().eyoc_knn1(_lib.ctx(A.device.index), _lib.ptr(A[a0:]), _lib.ptr(B), A.shape[1], sa, sb, ns,
-                                             _DIST[dist_type], _lib.ptr(idx[a0:]), _lib.ptr(dist[a0:]), _lib.stream_ptr()),
+                                             _DIST[dist_type], _lib.ptr(idx[a0:]), _lib.ptr(dist[a0:]) if return_distance else None,
+                                             _lib.stream_ptr()),
                        "eyoc_knn1")
     return (idx, dist) if return_distance else idx
 

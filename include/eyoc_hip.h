@@ -248,6 +248,11 @@ int eyoc_model_layer_ms(eyoc_model* model, float* ms /*[num_layers]*/);
  * can enqueue step k + 1 before it reads step k's durations, and the GPU never waits for the host between steps. */
 int eyoc_model_timing_slot(eyoc_model* model, int slot);
 
+/* MFMA pre-filter of eyoc_knn1's plain index query (SquareL2, idx only, C = 32): an fp32-MFMA score decides every row
+ * whose runner-up is out of rounding reach, the exact kernel recomputes the rest - the indices are identical either way.
+ * mode 0: never, 1 (default): when the query fills the chip (>= 1024 waves of 64 rows), 2: always; < 0 only queries.
+ * Returns the previous mode.  Process-wide; for tests and profiling. */
+int eyoc_knn_prefilter(int mode);
 /* ------------------------------------------------------------------------------------------------
  * feature matching
  *   replaces: lib.eval.find_nn_gpu + lib.metrics.pdist (lib/eval.py:18-48, lib/metrics.py:22-29)

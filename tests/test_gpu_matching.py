@@ -159,3 +159,76 @@ def test_many_segments_in_one_call():
             ri, rd = om.find_nn(A[sa[s]:sa[s + 1]], B[sb[s]:sb[s + 1]], return_distance=True)
             np.testing.assert_array_equal(idx[sa[s]:sa[s + 1]], ri)
             np.testing.assert_array_equal(d[sa[s]:sa[s + 1]], rd[:, 0])
+
+
+@pytest.fixture
+def prefilter_always():
+    from eyoc_amd import _lib
+    lib = _lib.load()
+    prev = lib.eyoc_knn_prefilter(2)
+    yield lib
+    lib.eyoc_knn_prefilter(prev)
+
+
+def test_mfma_prefilter_gives_the_contract_indices(prefilter_always):
+    """The fp32-MFMA score pre-filter (knn.hip) only ever decides rows whose runner-up is out of rounding reach and
+    hands the rest to the exact kernel: indices identical to the oracle on ordinary features, on segments of odd sizes,
+    on exact ties (duplicated targets, lowest index wins), on near-ties one ulp apart, with NaN rows and with
+    features of very different norms."""
+    import eyoc_amd
+    from oracle import matching as om
+    lib = prefilter_always
+    rng = np.random.default_rng(5)
+
+    def check(A, B, seg_a=None, seg_b=None, oracle=True):
+        seg_a = np.array([0, len(A)]) if seg_a is None else seg_a
+        seg_b = np.array([0, len(B)]) if seg_b is None else seg_b
+        got = eyoc_amd.knn1_segmented(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(), seg_a, seg_b,
+                                      return_distance=False).cpu().numpy()
+        for s in range(len(seg_a) - 1 if oracle else 0):
+            np.testing.assert_array_equal(got[seg_a[s]:seg_a[s + 1]], om.find_nn(A[seg_a[s]:seg_a[s + 1]], B[seg_b[s]:seg_b[s + 1]]))
+        lib.eyoc_knn_prefilter(0)
+        ref = eyoc_amd.knn1_segmented(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(), seg_a, seg_b,
+                                      return_distance=False).cpu().numpy()
+        lib.eyoc_knn_prefilter(2)
+        np.testing.assert_array_equal(got, ref)
+
+    # ordinary unit features, ragged segments (tiles of 16 targets / 64 queries with tails)
+    sizes_a, sizes_b = [100, 1, 257, 64, 1000], [300, 50, 129, 1000, 17]
+    A = np.concatenate([gi.unit_feats(190 + i, n) for i, n in enumerate(sizes_a)])
+    B = np.concatenate([gi.unit_feats(195 + i, n) for i, n in enumerate(sizes_b)])
+    check(A, B, np.cumsum([0] + sizes_a), np.cumsum([0] + sizes_b))
+    # exact ties: every target appears three times (shuffled), queries ARE targets
+    base = gi.unit_feats(7, 400)
+    B = np.concatenate([base, base, base])[rng.permutation(1200)]
+    check(base[:300].copy(), B)
+    # near-ties: targets that differ from each other in the last bits of one channel
+    B = np.repeat(gi.unit_feats(8, 50), 20, axis=0)
+    B[:, 3] = np.nextafter(B[:, 3], np.float32(2.0) * np.sign(rng.normal(size=len(B))).astype(np.float32))
+    check(gi.unit_feats(9, 500), B)
+    # clustered features: many candidates within 1e-5 of the best
+    centre = gi.unit_feats(10, 1)
+    B = (centre + 1e-6 * rng.normal(size=(2000, 32))).astype(np.float32)
+    check((centre + 1e-6 * rng.normal(size=(200, 32))).astype(np.float32), B)
+    # very different norms
+    A = (gi.unit_feats(11, 300) * rng.uniform(1e-3, 1e3, size=(300, 1))).astype(np.float32)
+    B = (gi.unit_feats(12, 900) * rng.uniform(1e-3, 1e3, size=(900, 1))).astype(np.float32)
+    check(A, B)
+    # ... and a NaN / an inf row on either side: whatever the exact kernel answers (a NaN distance never wins there;
+    # numpy's argmin, i.e. the oracle, lets it win), the pre-filter must answer the same
+    A[7, 5] = np.nan
+    A[9, 0] = np.inf
+    B[100, 2] = np.nan
+    B[200, 1] = np.inf
+    check(A, B, oracle=False)
+
+
+def test_mfma_prefilter_decides_almost_every_row_of_the_bench_query(prefilter_always):
+    """5000 x 5000 unit features per pair (the bench's query): the exact second pass sees a handful of rows."""
+    import eyoc_amd
+    from eyoc_amd import _lib
+    from oracle import matching as om
+    F0, F1 = gi.unit_feats(300, 5000), gi.unit_feats(301, 5000)
+    got = eyoc_amd.knn1_segmented(torch.from_numpy(F0).cuda(), torch.from_numpy(F1).cuda(), np.array([0, 5000]), np.array([0, 5000]),
+                                  return_distance=False).cpu().numpy()
+    np.testing.assert_array_equal(got, om.find_nn(F0, F1))
