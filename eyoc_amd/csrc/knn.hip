@@ -52,23 +52,28 @@ template <int C, bool TOP2, bool DOT>
 __global__ __launch_bounds__(256) void knn1_kernel(const float* __restrict__ A, const float* __restrict__ Bt,
                                                    SegArgs seg, int split_len, int dist_type,
                                                    unsigned long long* __restrict__ best, float* __restrict__ second,
-                                                   const int* __restrict__ only = nullptr) {
+                                                   const int* __restrict__ only = nullptr, const int* __restrict__ only_cnt = nullptr) {
 #pragma clang fp contract(off)
   const int s = blockIdx.z;
   const int a0 = seg.a[s], na = seg.a[s + 1] - a0;
   const int nb = seg.b[s + 1] - seg.b[s], ld = seg.ld[s];
-  const int q0 = blockIdx.x * 64;
-  if (q0 >= na) return;
   const int t_begin = blockIdx.y * split_len;
   const int t_end = min(nb, t_begin + split_len);
   if (t_begin >= t_end) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int q = q0 + lane;
+  // query tiles: one per block - or, in the second pass of the MFMA pre-filter, a few blocks per segment that walk the
+  // dense list of the rows it could not decide (any number of them, usually a handful)
+  for (int q0 = blockIdx.x * 64;; q0 += gridDim.x * 64) {
+  int q = q0 + lane;
   bool q_ok = q < na;
-  if (only) {   // second pass of the MFMA pre-filter: only the rows it could not decide; most waves have none
-    q_ok = q_ok && only[a0 + q] != 0;
-    if (__ballot(q_ok) == 0ull) return;                              // the whole block: its four waves share the queries
+  if (only) {
+    const int cnt = only_cnt[s];
+    if (q0 >= cnt) return;                                           // the whole block: its four waves share the queries
+    q_ok = q0 + lane < cnt;
+    q = q_ok ? only[a0 + q0 + lane] : 0;
+  } else if (q0 >= na) {
+    return;
   }
   f32x2 a[C];   // {a_c, a_c}: the query's feature in both halves of a packed operand
   {
@@ -183,6 +188,8 @@ __global__ __launch_bounds__(256) void knn1_kernel(const float* __restrict__ A, 
     unsigned long long packed = ((unsigned long long)bits << 32) | (unsigned)best_j;
     atomicMin(&best[a0 + q], packed);
   }
+  if (!only) return;
+  }
 }
 
 __global__ void knn1_unpack(const unsigned long long* __restrict__ best, int n, long long* __restrict__ idx,
@@ -256,7 +263,8 @@ template <int C>
 __global__ __launch_bounds__(256) void knn_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Bm, SegArgs seg,
                                                        SegMfma sm, const float* __restrict__ anorm,
                                                        const int* __restrict__ bmax_bits,
-                                                       unsigned long long* __restrict__ best, int* __restrict__ flags) {
+                                                       unsigned long long* __restrict__ best, int* __restrict__ flist,
+                                                       int* __restrict__ fcnt) {
   constexpr int NQ = C / 4 + 1, RT = MF_ROWS / 16;
   const int s = blockIdx.z;
   const int a0 = seg.a[s], na = seg.a[s + 1] - a0;
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(256) void knn_mfma_kernel(const float* __restrict__
         // decided: a finite best whose runner-up is out of reach.  (a2 - a1 <= 2 err, NaN / inf anywhere: not decided)
         const bool decided = (a1 < __builtin_inff()) & (a1 > -__builtin_inff()) & (a2 - a1 > 2.0f * err) & (k1 != 0x7FFFFFFF);
         best[a0 + i] = decided ? (unsigned long long)(unsigned)k1 : ~0ull;
-        flags[a0 + i] = decided ? 0 : 1;
+        if (!decided) flist[a0 + atomicAdd(fcnt + s, 1)] = i;            // the segment's undecided rows, densely (any order)
       }
     }
 }
@@ -367,8 +375,9 @@ __global__ void pdist_kernel(const float* __restrict__ A, int n, const float* __
 
 template <int C>
 void launch_knn(const float* A, const float* Bt, const SegArgs& seg, int nseg, int max_na, int max_nb, int dist_type,
-                unsigned long long* best, float* second, bool dot, hipStream_t st, const int* only = nullptr) {
-  int qtiles = eyoc::cdiv(max_na, 64);
+                unsigned long long* best, float* second, bool dot, hipStream_t st, const int* only = nullptr,
+                const int* only_cnt = nullptr) {
+  int qtiles = only ? 2 : eyoc::cdiv(max_na, 64);   // second pass of the pre-filter: two blocks per (segment, split) walk the list
   int total = qtiles * nseg;
   int max_splits = eyoc::cdiv(max_nb, SPLIT_ALIGN);
   int nsplit = 4096 / (total > 0 ? total : 1);
@@ -377,9 +386,9 @@ void launch_knn(const float* A, const float* Bt, const SegArgs& seg, int nseg, i
   int split_len = eyoc::cdiv(eyoc::cdiv(max_nb, nsplit), SPLIT_ALIGN) * SPLIT_ALIGN;
   nsplit = eyoc::cdiv(max_nb, split_len);
   dim3 grid(qtiles, nsplit, nseg);
-  if (second) hipLaunchKernelGGL((knn1_kernel<C, true, false>), grid, dim3(256), 0, st, A, Bt, seg, split_len, dist_type, best, second, (const int*)nullptr);
-  else if (dot) hipLaunchKernelGGL((knn1_kernel<C, false, true>), grid, dim3(256), 0, st, A, Bt, seg, split_len, 0, best, second, (const int*)nullptr);
-  else hipLaunchKernelGGL((knn1_kernel<C, false, false>), grid, dim3(256), 0, st, A, Bt, seg, split_len, dist_type, best, second, only);
+  if (second) hipLaunchKernelGGL((knn1_kernel<C, true, false>), grid, dim3(256), 0, st, A, Bt, seg, split_len, dist_type, best, second, (const int*)nullptr, (const int*)nullptr);
+  else if (dot) hipLaunchKernelGGL((knn1_kernel<C, false, true>), grid, dim3(256), 0, st, A, Bt, seg, split_len, 0, best, second, (const int*)nullptr, (const int*)nullptr);
+  else hipLaunchKernelGGL((knn1_kernel<C, false, false>), grid, dim3(256), 0, st, A, Bt, seg, split_len, dist_type, best, second, only, only_cnt);
 }
 
 }  // namespace
@@ -437,24 +446,26 @@ static int knn_run(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c,
   const size_t off_an = eyoc::align_up(off_bm + (prefilter ? (size_t)bm_floats * sizeof(float) : 0));
   const size_t off_fl = eyoc::align_up(off_an + (prefilter ? (size_t)n_total * sizeof(float) : 0));
   const size_t off_bx = eyoc::align_up(off_fl + (prefilter ? (size_t)n_total * sizeof(int) : 0));
-  int rc = ctx->ensure_scratch(off_bx + MAX_SEG * sizeof(int) + 64);
+  int rc = ctx->ensure_scratch(off_bx + 2 * MAX_SEG * sizeof(int) + 64);
   if (rc) return rc;
   unsigned long long* best = (unsigned long long*)ctx->scratch;
   float* Bt = (float*)((char*)ctx->scratch + off_bt);
   EYOC_CHECK_HIP(hipMemsetAsync(best, 0xFF, (size_t)n_total * sizeof(unsigned long long), st));
-  const int* only = nullptr;
+  const int *only = nullptr, *only_cnt = nullptr;
   if (prefilter) {
     float* Bm = (float*)((char*)ctx->scratch + off_bm);
     float* anorm = (float*)((char*)ctx->scratch + off_an);
     int* flags = (int*)((char*)ctx->scratch + off_fl);
     int* bmax = (int*)((char*)ctx->scratch + off_bx);
-    EYOC_CHECK_HIP(hipMemsetAsync(bmax, 0, MAX_SEG * sizeof(int), st));
+    int* fcnt = bmax + MAX_SEG;
+    EYOC_CHECK_HIP(hipMemsetAsync(bmax, 0, 2 * MAX_SEG * sizeof(int), st));
     hipLaunchKernelGGL(knn_pack_targets_mfma<32>, dim3(eyoc::cdiv((long long)eyoc::cdiv(max_nb, 16) * 64, 256), 1, nseg), dim3(256), 0, st,
                        B_dev, seg, sm, Bm, bmax);
     hipLaunchKernelGGL(knn_row_norms, dim3(eyoc::cdiv(n_total, 256)), dim3(256), 0, st, A_dev, n_total, c, anorm);
     hipLaunchKernelGGL(knn_mfma_kernel<32>, dim3(eyoc::cdiv(max_na, 4 * MF_ROWS), 1, nseg), dim3(256), 0, st, A_dev, Bm, seg, sm,
-                       anorm, bmax, best, flags);
+                       anorm, bmax, best, flags, fcnt);
     only = flags;
+    only_cnt = fcnt;
   }
   if (max_nb > 0) {
     hipLaunchKernelGGL(knn_transpose_targets, dim3(eyoc::cdiv((long long)max_ld * (c / 4), 256), 1, nseg), dim3(256), 0, st, B_dev,
@@ -462,7 +473,7 @@ static int knn_run(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c,
     switch (c) {
       case 4: launch_knn<4>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, dot, st); break;
       case 16: launch_knn<16>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, dot, st); break;
-      case 32: launch_knn<32>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, dot, st, only); break;
+      case 32: launch_knn<32>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, dot, st, only, only_cnt); break;
       case 64: launch_knn<64>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, dot, st); break;
       default: launch_knn<128>(A_dev, Bt, seg, nseg, max_na, max_nb, dist_type, best, second_dev, dot, st); break;
     }
