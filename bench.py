@@ -75,6 +75,9 @@ def parse_args(argv=None):
                     help="only the timed steps (profiling passes: keeps the kernel statistics to the timed region)")
     ap.add_argument("--dry-run", action="store_true",
                     help="(tests) no GPU work: a stub step exercises launch / sharding / timing / gather on CPU over gloo")
+    ap.add_argument("--overlap-maps", action="store_true",
+                    help="build the next step's coordinate maps on a side stream while the current step runs (measured: "
+                         "+0.5 % - the conv and RANSAC kernels fill the register files, the side stream only runs in their tails)")
     ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
     return ap.parse_args(argv)
 
@@ -274,11 +277,13 @@ def worker(args):
     # Software-pipelined over the steps: step s is ENQUEUED before the host reads step s-1's results and timers (two
     # event sets, results left on the device until then), so the GPU never waits for the host's decode between steps.
     # Everything - the last step's read-back included - is inside the timed bracket.
-    pending = None           # (step, device result, event slot) of the step whose read-back is still due
+    pending = None           # (step, device result, event slot, maps) of the step whose read-back is still due
+    next_maps = None
+    overlap_maps = args.overlap_maps
 
     def collect(item):
         nonlocal layer_ms, n_fwd
-        s_, res_, slot_ = item
+        s_, res_, slot_ = item[:3]
         batch_ = batches[s_ % len(batches)][1]
         host = res_.cpu()
         last[s_ % len(batches)] = [eyoc_amd.registration.decode_ransac_result(host[p], batch_.n_points) for p in range(batch_.P)] \
@@ -305,10 +310,16 @@ def worker(args):
         slot = s & 1
         model.timing_slot(slot)
         pipe.slot = slot
-        res = pipe.register(batch, return_device=True)
+        if next_maps is None and overlap_maps:
+            next_maps = pipe.prepare_maps(batch)                    # first step: nothing to hide behind
+        res = pipe.register(batch, return_device=True, maps=next_maps)
+        held, next_maps = next_maps, None
+        if overlap_maps and s + 1 < steps_timed:
+            # the next step's maps, on the side stream, while this step's matching / RANSAC runs on the main stream
+            next_maps = pipe.prepare_maps(batches[(s + 1) % len(batches)][1])
         if pending is not None:
             collect(pending)
-        pending = (s, res, slot)
+        pending = (s, res, slot, held)
     if pending is not None:
         collect(pending)
     edist.barrier()

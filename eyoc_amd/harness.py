@@ -150,16 +150,36 @@ class RegistrationPipeline:
         return {"feat": e[0].elapsed_time(e[1]), "match": e[1].elapsed_time(e[2]), "reg": e[2].elapsed_time(e[3])}
 
     @torch.no_grad()
-    def features(self, batch: DeviceBatch) -> SparseTensor:
+    def features(self, batch: DeviceBatch, maps=None) -> SparseTensor:
         """scripts/test_kitti.py:141-150 for all 2P clouds at once (the maps are rebuilt per call, like
-        the reference rebuilds its coordinate manager for every SparseTensor)."""
+        the reference rebuilds its coordinate manager for every SparseTensor - or taken from ``prepare_maps``)."""
+        if maps is not None:
+            cm, ready = maps
+            torch.cuda.current_stream().wait_event(ready)
+            return self.model(SparseTensor(batch.feats, coordinate_manager=cm))
         return self.model(SparseTensor(batch.feats, coordinates=batch.coords))
 
     @torch.no_grad()
-    def register(self, batch: DeviceBatch, seed: int = 0, return_device=False):
+    def prepare_maps(self, batch: DeviceBatch):
+        """Build the coordinate maps of ``batch`` NOW, on a side stream: they only depend on the coordinates, so a
+        serving loop builds the next batch's maps (hash / sort / rulebook kernels, latency- and atomics-bound) while the
+        previous batch is still in its RANSAC (VALU-bound) on the main stream.  Returns the handle ``register(...,
+        maps=)`` takes; keep it alive until that step's results were read."""
+        from .sparse_tensor import CoordinateManager
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=batch.coords.device)
+        with torch.cuda.stream(self._side):
+            cm = CoordinateManager(batch.coords)
+            cm.maps()
+            ready = torch.cuda.Event()
+            ready.record(self._side)
+        return cm, ready
+
+    @torch.no_grad()
+    def register(self, batch: DeviceBatch, seed: int = 0, return_device=False, maps=None):
         """One pass of the hot path over ``P`` pairs -> ``T f32 [P,4,4]`` (host) and per-pair stats."""
         self._mark(0)
-        F = self.features(batch).F
+        F = self.features(batch, maps).F
         self._mark(1)
         F0 = gather_rows(F, batch.sel0, batch.G0, batch.beta)     # the sampled rows (+ descriptor blend, if any)
         F1 = gather_rows(F, batch.sel1, batch.G1, batch.beta)
