@@ -147,6 +147,7 @@ struct eyoc_maps {
   int32_t* row_perm = nullptr;
   // per-tile local rulebooks of the stride-1 tables (spconv_st.hip), built when the rows are in Z-order; NULL otherwise
   unsigned char* local_s1[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned char* local_up[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};   // transposed tables (outputs at level l)
   bool table0_built = false;   // table[0] has its memory reserved but is only filled on demand (maps_build_table0)
 };
 

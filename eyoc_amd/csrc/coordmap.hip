@@ -387,6 +387,7 @@ size_t eyoc_maps_workspace_bytes(int n_rows) {
   b += align_up(n * 8) * 2 + align_up(n * 4) * 2 + align_up(sort_rows64_tmp_bytes(n_rows));   // Z-order: keys in / out, rows in, permutation
   // local rulebooks of the stride-1 tables (levels sum to < 2 n rows; every level rounds up to a whole tile)
   b += 2 * align_up(local_rulebook_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_bytes(1)) + 256);
+  b += 2 * align_up(local_rulebook_up_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_up_bytes(1)) + 256);
   b += 4096;                                                         // counters
   return b + 96 * 256;
 }
@@ -564,14 +565,21 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
   // ---- local rulebooks of the stride-1 tables (tile-local input stage of the sparse convolution): only for Z-ordered rows
   if (zorder) {
     FAIL_HIP(hipMemsetAsync(counters + 8, 0, sizeof(int), st));
+    FAIL_HIP(hipMemsetAsync(counters + 9, 0, sizeof(int), st));
     for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
       m->local_s1[l] = cv.take<unsigned char>(local_rulebook_bytes(m->rows[l]));
       if (int rc = build_local_rulebook(m->nbr_s1[l], 27, m->rows[l], m->local_s1[l], counters + 8, st)) { delete m; return rc; }
+      if (l + 1 < EYOC_MAX_LEVELS && spconv_up_enabled()) {   // the transposed table whose outputs are this level's rows
+        m->local_up[l] = cv.take<unsigned char>(local_rulebook_up_bytes(m->rows[l]));
+        if (int rc = build_local_rulebook_up(m->nbr_up[l], 27, m->rows[l], m->local_up[l], counters + 9, st)) { delete m; return rc; }
+      }
     }
-    FAIL_HIP(hipMemcpyAsync(host, counters + 8, sizeof(int), hipMemcpyDeviceToHost, st));
+    FAIL_HIP(hipMemcpyAsync(host, counters + 8, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     FAIL_HIP(hipStreamSynchronize(st));
     if (host[0] != 0)   // a tile with more than 1278 distinct input rows (does not happen for Z-ordered rows): no staged kernel
       for (int l = 0; l < EYOC_MAX_LEVELS; ++l) m->local_s1[l] = nullptr;
+    if (host[1] != 0)   // ... more than 639 distinct coarse rows under a 256-row tile
+      for (int l = 0; l < EYOC_MAX_LEVELS; ++l) m->local_up[l] = nullptr;
   }
   FAIL_HIP(hipGetLastError());
 #undef FAIL_HIP

@@ -30,6 +30,7 @@ struct SpconvArgs {
   int out_split = 0;               // write SPLIT16 rows (internal activations) instead of fp32 rows
   const int32_t* out_perm = nullptr;      // output row o is written to row out_perm[o] of `out` (the network output in the caller's order); res is not permuted
   const unsigned char* local = nullptr;   // per-tile local rulebooks of `nbr` (build_local_rulebook) or NULL: enables the staged kernel
+  const unsigned char* local_up = nullptr;   // ... of a transposed table (build_local_rulebook_up): enables spconv_up.hip
   const float* out_scale = nullptr;  // device scalar multiplied into the accumulated sums (undoes the weight pre-scale); NULL = 1
   // optional: a permutation of the output rows; tiles take rows in this order (any order gives the same result,
   // a good one makes the rows of a tile share their occupied offsets).  NULL = natural order.
@@ -88,10 +89,14 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 int launch_spconv(const SpconvArgs& a, hipStream_t st);
 int launch_permute_rows(const float* in, const int32_t* perm, int n, int c, float* out, hipStream_t st);
 int launch_spconv_st(const SpconvArgs& a, const unsigned char* local_dev, hipStream_t st);   // tile-local input stage (spconv_st.hip)
+int launch_spconv_up(const SpconvArgs& a, const unsigned char* local_dev, hipStream_t st);   // transposed 3^3 / stride 2 (spconv_up.hip)
+size_t local_rulebook_up_bytes(int n_out);
+int build_local_rulebook_up(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st);
 size_t local_rulebook_bytes(int n_out);
 int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st);
 int launch_spconv_rs(const SpconvArgs& a, hipStream_t st);     // row-stationary, SPLIT16 only (spconv_rs.hip)
 bool spconv_rs_fits(const SpconvArgs& a);
+bool spconv_up_enabled();    // eyoc_spconv_select_up_kernel state
 int spconv_forced_kernel();   // eyoc_spconv_select_kernel state: -1 automatic, 0 workgroup-tiled, 1 wave-private
 int launch_spconv_wave(const SpconvArgs& a, hipStream_t st);   // wave-private tiling (spconv_wave.hip)
 

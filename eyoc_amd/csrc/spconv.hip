@@ -566,6 +566,11 @@ static int g_kernel_mode = getenv("EYOC_SPCONV_WAVE") ? atoi(getenv("EYOC_SPCONV
 static int g_split16_kernel = getenv("EYOC_SPCONV_RS") ? atoi(getenv("EYOC_SPCONV_RS")) : 1;
 
 int spconv_forced_kernel() { return g_kernel_mode; }
+// staged kernel for the transposed convolutions (spconv_up.hip): off by default - measured level with the row-stationary
+// kernel in windowed pattern order (0.75 / 1.16 / 1.50 vs 0.63 / 1.02 / 1.57 ms on the bench's three layers) while its
+// rulebooks add 0.7 ms to the map build; it reads 20 GB less from HBM per forward
+int g_up_kernel = getenv("EYOC_SPCONV_UP") ? atoi(getenv("EYOC_SPCONV_UP")) : 0;
+bool spconv_up_enabled() { return g_up_kernel != 0; }
 
 int launch_spconv(const SpconvArgs& a, hipStream_t st) {
   EYOC_REQUIRE(a.in && a.w && a.out, EYOC_ERR_INVALID, "spconv: NULL tensor");
@@ -605,6 +610,11 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
       SpconvArgs b = a;
       b.perm = nullptr;
       return launch_spconv_st(b, a.local, st);
+    }
+    if (a.math == 1 && a.local_up && use_rs != 0 && a.K == 27 && !a.l2norm && a.cout % 64 == 0) {   // transposed table with tile rulebooks
+      SpconvArgs b = a;
+      b.perm = nullptr;
+      return launch_spconv_up(b, a.local_up, st);
     }
     const bool rs_layer = a.cin >= 64 && !(a.n_in > a.n_out);
     if (a.math == 1 && spconv_rs_fits(a) && (use_rs == 2 || (use_rs == 1 && rs_layer))) return launch_spconv_rs(a, st);
@@ -782,6 +792,12 @@ int eyoc_spconv_staged(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* local_
   a.out = out_dev; a.ld_out = ld_out; a.math = 1; a.out_split = out_split; a.out_scale = out_scale_dev;
   a.local = (const unsigned char*)local_dev;
   return launch_spconv(a, (hipStream_t)stream);
+}
+
+int eyoc_spconv_select_up_kernel(int on) {
+  const int prev = eyoc::g_up_kernel;
+  if (on == 0 || on == 1) eyoc::g_up_kernel = on;
+  return prev;
 }
 
 int eyoc_spconv_select_split16_kernel(int mode) {

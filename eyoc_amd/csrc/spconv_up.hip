@@ -1,0 +1,329 @@
+// Transposed 3^3 / stride-2 sparse convolution with a tile-local input stage (gfx950, SPLIT16 arithmetic, Z-ordered rows).
+//
+// A fine output row of the transposed convolution has 1, 2, 4 or 8 coarse neighbours - which of the 27 offsets can be
+// occupied is decided by its parity class (on which axes it sits between two coarse voxels): 2.5 pairs per row on the
+// bench geometry.  Walking all 27 offsets densely like the stride-1 staged kernel (spconv_st.hip) would multiply ten
+// zeros for every product; the gathering kernels in pattern-sorted order (spconv_rs.hip) avoid that but fetch every
+// (row, offset) pair from L2 / HBM - 10 GB for the 3.8 M-row 1 -> 0 layer whose distinct inputs are 0.8 GB, 1.6 ms at
+// the HBM limit.  This kernel does both things right:
+//
+//   * tile = 256 consecutive (Z-ordered) output rows; their ~100-200 distinct coarse input rows are staged in LDS once
+//     per 32-channel block, exactly like spconv_st.hip;
+//   * INSIDE the tile the rows are sorted by their occupancy mask (k_local_rulebook_up: a 256-key bitonic sort), so a
+//     16-row MFMA group holds rows of one or two patterns; the rulebook carries the union mask of every group and the
+//     wave only multiplies the (group, offset) blocks whose mask bit is set (~5 of 27 instead of 27);
+//     (the 27 offsets split into 8 disjoint sets by parity class, so class-sorted slots give every wave - 64 slots, 32
+//     output channels - about 7 offsets to walk);
+//   * the offset loop is dynamic (scalar find-first-bit over the wave's union mask), weights and rulebook entries of
+//     the next occupied offset are prefetched while the current one multiplies; outputs go back to their rows through
+//     the tile's slot -> row list.
+#include <cstdlib>
+
+#include "spconv.h"
+
+using namespace eyoc;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NW = 4, TILE = 256;                            // builder: one thread per row
+constexpr int NWK = 8;                                      // kernel: 8 waves = 4 slot quarters x 2 output-channel halves
+constexpr int XROWS = 640, UMAX = XROWS - 1, X_BYTES = XROWS * 128, NIT = XROWS / (8 * NWK);   // 80 KB: 2 workgroups = 16 waves per CU
+// rulebook of one tile: int n_unique (-1: more than UMAX), pad[3]; int U[640]; int row[256] (output row of slot s, -1:
+// none); unsigned gmask[16] (union of the occupancy masks of slots 16 g ..); uint2 loc[27][4][16]: entry (k, w, j) packs
+// the LDS slots v = 8 l + (l & 7) of the neighbours at offset k of tile slots 64 w + 16 c + j, c = 0..3 (UMAX: none)
+constexpr int OFF_U = 16, OFF_ROW = OFF_U + XROWS * 4, OFF_GM = OFF_ROW + TILE * 4, OFF_LOC = OFF_GM + 16 * 4;
+constexpr int UP_LR_BYTES = OFF_LOC + 27 * 4 * 16 * 8;      // 17488
+constexpr int HSLOTS = 4096;                                // >= 2 x (256 rows x 8 neighbours)
+
+__global__ __launch_bounds__(256) void k_local_rulebook_up(const int32_t* __restrict__ nbr, int K, int n_out,
+                                                           unsigned char* __restrict__ out, int* __restrict__ overflow) {
+  __shared__ int hk[HSLOTS];
+  __shared__ unsigned short hid[HSLOTS];
+  __shared__ unsigned short ids_row[27][TILE];               // LDS slot of (offset, local row), UMAX = none
+  __shared__ unsigned long long key[TILE];
+  __shared__ int wave_cnt[NW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x;
+  const int r = (int)threadIdx.x;
+  const int row = tile * TILE + r;
+  for (int i = threadIdx.x; i < HSLOTS; i += 256) hk[i] = -1;
+  __syncthreads();
+  unsigned short slot[27];
+  unsigned int mask = 0;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const int idx = (k < K && row < n_out) ? nbr[(size_t)k * n_out + row] : -1;
+    unsigned int s = 0xFFFFu;
+    if (idx >= 0) {
+      mask |= 1u << k;
+      s = ((unsigned)idx * 2654435761u) >> 20;
+      while (true) {
+        const int prev = atomicCAS(&hk[s], -1, idx);
+        if (prev == -1 || prev == idx) break;
+        s = (s + 1) & (HSLOTS - 1);
+      }
+    }
+    slot[k] = (unsigned short)s;
+  }
+  __syncthreads();
+  // number the occupied hash slots in slot order (deterministic)
+  constexpr int PER_WAVE = HSLOTS / NW;
+  int cnt = 0;
+  for (int i0 = 0; i0 < PER_WAVE; i0 += 64) cnt += __popcll(__ballot(hk[wave * PER_WAVE + i0 + lane] >= 0));
+  if (lane == 0) wave_cnt[wave] = cnt;
+  __syncthreads();
+  int base = 0, total = 0;
+  for (int w = 0; w < NW; ++w) { if (w < wave) base += wave_cnt[w]; total += wave_cnt[w]; }
+  unsigned char* lr = out + (size_t)tile * UP_LR_BYTES;
+  int* U = reinterpret_cast<int*>(lr + OFF_U);
+  for (int i0 = 0; i0 < PER_WAVE; i0 += 64) {
+    const int s = wave * PER_WAVE + i0 + lane;
+    const int k_ = hk[s];
+    const unsigned long long m = __ballot(k_ >= 0);
+    const int id = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (k_ >= 0) {
+      hid[s] = (unsigned short)id;
+      if (id < UMAX) U[id] = k_;
+    }
+    base += __popcll(m);
+  }
+  if (threadIdx.x == 0) {
+    reinterpret_cast<int*>(lr)[0] = total <= UMAX ? total : -1;
+    if (total > UMAX) atomicAdd(overflow, 1);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const int id = slot[k] != 0xFFFFu ? (int)hid[slot[k]] : UMAX;
+    const int l = id < UMAX ? id : UMAX;
+    ids_row[k][r] = (unsigned short)(l * 8 + (l & 7));
+  }
+  // sort the tile's rows by (parity class, occupancy mask): the 27 offsets split into 8 disjoint sets, one per class
+  // (offset (dx, dy, dz) is only ever occupied for rows that sit between two coarse voxels on exactly the axes with
+  // d != 0), so class-contiguous slots make every offset touch one short run of slots.  Rows past the end: mask 0, they
+  // sort first and carry row -1.
+  unsigned int cls = 0;
+  if (mask) {
+    const int k0 = __builtin_ctz(mask);
+    cls = (k0 % 3 != 1 ? 1u : 0u) | ((k0 / 3) % 3 != 1 ? 2u : 0u) | (k0 / 9 != 1 ? 4u : 0u);
+  }
+  key[r] = ((unsigned long long)cls << 40) | ((unsigned long long)mask << 8) | (unsigned)r;
+  __syncthreads();
+  for (int kk = 2; kk <= TILE; kk <<= 1)
+    for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+      const int p = r ^ jj;
+      if (p > r) {
+        const unsigned long long a = key[r], b = key[p];
+        const bool up = (r & kk) == 0;
+        if ((a > b) == up) { key[r] = b; key[p] = a; }
+      }
+      __syncthreads();
+    }
+  // thread s now owns slot s
+  const unsigned long long mine = key[r];
+  const int src = (int)(mine & 255u);
+  const unsigned int smask = (unsigned int)(mine >> 8) & 0x7FFFFFFu;
+  const int grow = tile * TILE + src;
+  reinterpret_cast<int*>(lr + OFF_ROW)[r] = grow < n_out ? grow : -1;
+  unsigned int gm = smask;
+  gm |= __shfl_xor(gm, 1, 64); gm |= __shfl_xor(gm, 2, 64); gm |= __shfl_xor(gm, 4, 64); gm |= __shfl_xor(gm, 8, 64);
+  if ((r & 15) == 0) reinterpret_cast<unsigned int*>(lr + OFF_GM)[r >> 4] = gm;
+  unsigned short* loc = reinterpret_cast<unsigned short*>(lr + OFF_LOC);
+  const int h = r >> 6, c = (r >> 4) & 3, j = r & 15;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) loc[(((size_t)(k * 4 + h) * 16) + j) * 4 + c] = ids_row[k][src];
+}
+
+template <int CC>
+__global__ __launch_bounds__(NWK * 64, 4) void spconv_up_kernel(SpconvArgs a, const unsigned char* __restrict__ local, int n_tiles) {
+  constexpr int NTW = 2, CTG = 64, NG = 4;                             // per wave: 64 slots (4 groups) x 32 output channels
+  extern __shared__ __attribute__((aligned(16))) unsigned char xs[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int g = lane >> 4, j = lane & 15;
+  const int n_cg = a.cout / CTG;
+  const int xcd = (int)blockIdx.x & 7, per = 8 / n_cg;
+  const int cg = xcd % n_cg, tile = ((int)blockIdx.x >> 3) * per + xcd / n_cg;
+  if (tile >= n_tiles) return;
+  const int sq = wave >> 1;                                            // slot quarter of the tile
+  const int ct0 = cg * CTG + (wave & 1) * 32;
+  const int CT = a.cout >= 128 ? 128 : a.cout;
+  const int n_slices = a.cout / CT, slice = ct0 / CT, nt0 = (ct0 - slice * CT) / 16;
+  constexpr int JQ = CC / 16;
+  const int ncc = a.cin / CC;
+  const int nqb = a.cin / 32;
+  constexpr int K = 27;
+
+  const unsigned char* lr = local + (size_t)tile * UP_LR_BYTES;
+  const int n_u = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(lr)[0]);
+  const int* __restrict__ U = reinterpret_cast<const int*>(lr + OFF_U);
+  const int* __restrict__ rowp = reinterpret_cast<const int*>(lr + OFF_ROW) + sq * 64;
+  const unsigned int* __restrict__ gmp = reinterpret_cast<const unsigned int*>(lr + OFF_GM) + sq * 4;
+  const uint2* __restrict__ locp = reinterpret_cast<const uint2*>(lr + OFF_LOC) + sq * 16 + j;     // entry k at [k * 64]
+  unsigned int gm[NG], wmask = 0;
+#pragma unroll
+  for (int c = 0; c < NG; ++c) { gm[c] = __builtin_amdgcn_readfirstlane(gmp[c]); wmask |= gm[c]; }
+  if (threadIdx.x < 8) *reinterpret_cast<float4*>(xs + UMAX * 128 + threadIdx.x * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, K * a.cin * a.cout * 4, 0x00020000);
+  const int tile4 = CC * CT / 4;
+  f32x4 acc[NG][NTW];
+#pragma unroll
+  for (int c = 0; c < NG; ++c)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int lane_off = lane * 16;
+  auto load_w = [&](int k, int qb, float4 (&W)[NTW][2]) {
+    const int cc = (qb * 32) / CC, qp = ((qb * 32) % CC) / 32;
+    const int wbase = __builtin_amdgcn_readfirstlane((((k * n_slices + slice) * ncc + cc) * tile4 + (nt0 * JQ + 2 * qp) * 64) * 16);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off + (t * JQ + p) * 1024, wbase, 0);
+        W[t][p] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      }
+  };
+  auto stage = [&](int qb) {
+    int Ureg[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int l = (it * NWK + wave) * 8 + (lane >> 3);
+      asm volatile("" : "+v"(l));
+      Ureg[it] = l < n_u ? U[l] : 0;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int l0 = (it * NWK + wave) * 8;
+      if (l0 < n_u) {                                                // wave-uniform
+        const int l = l0 + (lane >> 3);
+        const float* src = a.in + (size_t)Ureg[it] * a.ld_in + qb * 32 + (((lane & 7) ^ (l & 7)) << 2);
+        if (l < n_u)
+          __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(xs + l0 * 128), 16, 0, 0);
+      }
+    }
+  };
+  const unsigned int gh = (unsigned)g << 4, gl = (unsigned)(g ^ 4) << 4;
+  // one occupied offset: operands of all 8 groups from LDS (a group without neighbours reads the zero row), products
+  // only for the groups whose mask has the offset
+  auto compute = [&](int k, const uint2 L, const float4 (&W)[NTW][2]) {
+    float4 X[NG][2];
+    const unsigned int w4[2] = {L.x, L.y};
+#pragma unroll
+    for (int c = 0; c < NG; ++c) {
+      const unsigned int ad = ((w4[c >> 1] >> (16 * (c & 1))) & 0xFFFFu) << 4;
+      X[c][0] = *reinterpret_cast<const float4*>(xs + (ad ^ gh));
+      X[c][1] = *reinterpret_cast<const float4*>(xs + (ad ^ gl));
+    }
+#pragma unroll
+    for (int c = 0; c < NG; ++c) {
+      if (!((gm[c] >> k) & 1u)) continue;                              // scalar branch
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {
+        const half8_t xv = __builtin_bit_cast(half8_t, X[c][term == 1 ? 1 : 0]);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+          acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, W[t][term == 2 ? 1 : 0]), xv, acc[c][t], 0, 0, 0);
+      }
+    }
+  };
+
+  float4 WA[NTW][2], WB[NTW][2];
+  uint2 LA = make_uint2(0, 0), LB = make_uint2(0, 0);
+  for (int qb = 0; qb < nqb; ++qb) {
+    if (qb) __syncthreads();                                           // every wave is done with the previous block's rows
+    stage(qb);
+    unsigned int rest = wmask;
+    int kc = rest ? __builtin_ctz(rest) : 0;
+    if (rest) { load_w(kc, qb, WA); LA = locp[kc * 64]; }
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __syncthreads();
+    while (rest) {                                                     // wave-uniform: the offsets any of the 8 groups has
+      rest &= rest - 1;
+      int kn = rest ? __builtin_ctz(rest) : kc;
+      if (rest) { load_w(kn, qb, WB); LB = locp[kn * 64]; }
+      compute(kc, LA, WA);
+      kc = kn;
+      if (!rest) break;
+      rest &= rest - 1;
+      kn = rest ? __builtin_ctz(rest) : kc;
+      if (rest) { load_w(kn, qb, WA); LA = locp[kn * 64]; }
+      compute(kc, LB, WB);
+      kc = kn;
+    }
+  }
+
+  // ---- epilogue: lane (g, j) holds channels 16 t + 4 g .. +3 of tile slot 64 sq + 16 c + j
+  const float os = a.out_scale ? *a.out_scale : 1.0f;
+  float4 b4[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+    b4[t] = a.bias ? *reinterpret_cast<const float4*>(a.bias + ct0 + 16 * t + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int c = 0; c < NG; ++c) {
+    const int o = rowp[16 * c + j];
+    if (o < 0) continue;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int ch = ct0 + 16 * t + 4 * g;
+      float4 v = make_float4(acc[c][t][0] * os + b4[t].x, acc[c][t][1] * os + b4[t].y, acc[c][t][2] * os + b4[t].z,
+                             acc[c][t][3] * os + b4[t].w);
+      if (a.res) {
+        const float4 q = split16_load4(a.res + (size_t)o * a.ld_res, ch);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      }
+      if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (a.out_split) split16_store4(a.out + (size_t)o * a.ld_out, ch, v);
+      else *reinterpret_cast<float4*>(a.out + (size_t)o * a.ld_out + ch) = v;
+    }
+  }
+}
+
+}  // namespace
+
+namespace eyoc {
+
+size_t local_rulebook_up_bytes(int n_out) { return (size_t)cdiv(n_out, TILE) * UP_LR_BYTES; }
+
+// per-tile rulebooks of a transposed table; *overflow_dev (zeroed by the caller) counts tiles with more than 639 distinct
+// input rows (the kernel must not be used for the table then)
+int build_local_rulebook_up(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st) {
+  if (n_out <= 0) return EYOC_OK;
+  hipLaunchKernelGGL(k_local_rulebook_up, dim3(cdiv(n_out, TILE)), dim3(256), 0, st, nbr_dev, K, n_out, out_dev, overflow_dev);
+  EYOC_CHECK_HIP(hipGetLastError());
+  return EYOC_OK;
+}
+
+int launch_spconv_up(const SpconvArgs& a, const unsigned char* local_dev, hipStream_t st) {
+  EYOC_REQUIRE(a.math == 1 && local_dev && !a.l2norm && a.K == 27 && a.cout % 64 == 0 && a.cin % 32 == 0, EYOC_ERR_INVALID,
+               "spconv_up: unsupported layer (%d -> %d channels)", a.cin, a.cout);
+  const bool wide = spconv_cc(a.cin, a.cout) == 64;
+  const int n_cg = a.cout / 64;
+  EYOC_REQUIRE(n_cg >= 1 && n_cg <= 8 && 8 % n_cg == 0, EYOC_ERR_INVALID, "spconv_up: %d output channels", a.cout);
+  const int n_tiles = cdiv(a.n_out, TILE);
+  const dim3 grid((unsigned)(cdiv(n_tiles, 8 / n_cg) * 8)), block(NWK * 64);
+  int dev = 0;
+  EYOC_CHECK_HIP(hipGetDevice(&dev));
+  static bool attr_done[64][2] = {};
+  if (wide) {
+    if (dev >= 64 || !attr_done[dev][0]) {
+      EYOC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spconv_up_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, X_BYTES));
+      if (dev < 64) attr_done[dev][0] = true;
+    }
+    hipLaunchKernelGGL(spconv_up_kernel<64>, grid, block, (size_t)X_BYTES, st, a, local_dev, n_tiles);
+  } else {
+    if (dev >= 64 || !attr_done[dev][1]) {
+      EYOC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spconv_up_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, X_BYTES));
+      if (dev < 64) attr_done[dev][1] = true;
+    }
+    hipLaunchKernelGGL(spconv_up_kernel<32>, grid, block, (size_t)X_BYTES, st, a, local_dev, n_tiles);
+  }
+  EYOC_CHECK_HIP(hipGetLastError());
+  return EYOC_OK;
+}
+
+}  // namespace eyoc

@@ -153,6 +153,11 @@ int eyoc_spconv(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, const f
  * eyoc_spconv_select_split16_kernel forces one (0 wave-private, 2 row-stationary, 1 automatic; returns the previous
  * mode; process-wide, for tests and profiling). */
 int eyoc_spconv_select_split16_kernel(int mode);
+/* Staged kernel for the transposed 3^3 / stride-2 convolutions on Z-ordered maps (spconv_up.hip: tile rows sorted by
+ * parity class, only occupied (16-row group, offset) blocks multiplied): 0 off (default; the row-stationary kernel in
+ * windowed pattern order is as fast and needs no extra rulebooks), 1 on; other values only query.  Returns the previous
+ * state.  Process-wide, read when maps are built; for tests and profiling. */
+int eyoc_spconv_select_up_kernel(int on);
 /* Stride-1 (3^3) split16 layers with a tile-local input stage (spconv_st.hip): per 256-row tile the distinct input rows are
  * copied to LDS once per 32-channel block and all 27 offsets run from there.  Needs the table's per-tile "local
  * rulebooks" (built once per table; *overflow_dev counts 256-row tiles with more than 1278 distinct input rows - the staged

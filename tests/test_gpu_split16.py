@@ -216,15 +216,18 @@ def test_forward_on_z_ordered_rows_with_the_staged_kernel(request):
     model, sd = _model()
     want = orr.resunet_forward(sd, coords, feats).numpy()
     prev = lib.eyoc_maps_internal_order(1) - 2
+    prev_up = lib.eyoc_spconv_select_up_kernel(-1)
     try:
-        for mode in ("split16", "fp32"):
+        for mode, up in (("split16", 0), ("split16", 1), ("fp32", 0)):   # up = 1: transposed convolutions on spconv_up.hip
+            lib.eyoc_spconv_select_up_kernel(up)
             model.spconv_math = mode
             got = _forward(model, coords, feats)
             assert model.last_spconv_math == mode
             e = rel_err(got, want)
             cos = (got * want).sum(1)
-            print(f"z-ordered forward, {mode}: err {e:.2e}")
+            print(f"z-ordered forward, {mode}, staged transposed convolutions {up}: err {e:.2e}")
             assert e < REL and cos.min() > 1 - 1e-6, (mode, e, float(cos.min()))
+        lib.eyoc_spconv_select_up_kernel(0)
         # the permutation is invisible: permuting the caller's rows permutes the output
         rng = np.random.default_rng(3)
         perm = rng.permutation(len(coords))
@@ -233,6 +236,7 @@ def test_forward_on_z_ordered_rows_with_the_staged_kernel(request):
         assert rel_err(_forward(model, coords[perm], feats[perm]), a[perm]) < 1e-5
     finally:
         lib.eyoc_maps_internal_order(prev)
+        lib.eyoc_spconv_select_up_kernel(prev_up)
         model.spconv_math = "auto"
 
 
