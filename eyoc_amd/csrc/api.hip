@@ -11,7 +11,14 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace eyoc
 
-int eyoc_ctx::ensure_scratch(size_t bytes) {
+int eyoc_ctx::ensure_scratch(size_t bytes, hipStream_t st) {
+  if (scratch_owned && st != scratch_owner) {
+    if (!scratch_ev) EYOC_CHECK_HIP(hipEventCreateWithFlags(&scratch_ev, hipEventDisableTiming));
+    EYOC_CHECK_HIP(hipEventRecord(scratch_ev, scratch_owner));
+    EYOC_CHECK_HIP(hipStreamWaitEvent(st, scratch_ev, 0));
+  }
+  scratch_owner = st;
+  scratch_owned = true;
   if (bytes <= scratch_bytes) return EYOC_OK;
   size_t want = eyoc::align_up(bytes, 1 << 20);
   if (scratch) EYOC_CHECK_HIP(hipFree(scratch));
@@ -72,6 +79,7 @@ int eyoc_destroy(eyoc_ctx* ctx) {
     (void)hipEventDestroy(ctx->pool_fork);
   }
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->scratch_ev) (void)hipEventDestroy(ctx->scratch_ev);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   delete ctx;
   return EYOC_OK;

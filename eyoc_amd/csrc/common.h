@@ -60,7 +60,12 @@ struct eyoc_ctx {
   // pinned host staging for small read-backs
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
-  int ensure_scratch(size_t bytes);
+  // grow-only device scratch shared by kNN / label kernels / RANSAC / maps_info.  ONE user at a time: a call on another
+  // stream first waits (event) for everything the previous user's stream was given, so two torch streams cannot race on it
+  int ensure_scratch(size_t bytes, hipStream_t st);
+  hipStream_t scratch_owner = nullptr;
+  bool scratch_owned = false;
+  hipEvent_t scratch_ev = nullptr;
   // side streams for batches of small independent problems (eyoc_sc2pcr_batched): forked from and joined to the
   // caller's stream with events, created on first use
   static constexpr int POOL = 8;

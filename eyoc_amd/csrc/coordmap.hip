@@ -746,7 +746,7 @@ int eyoc_maps_copy_row_order(const eyoc_maps* maps, int32_t* out_dev, void* stre
 int eyoc_maps_info(eyoc_ctx* ctx, const eyoc_maps* m, int conv1_ks, void* stream, eyoc_maps_info_t* info) {
   EYOC_REQUIRE(ctx && m && info, EYOC_ERR_INVALID, "eyoc_maps_info: NULL argument");
   hipStream_t st = (hipStream_t)stream;
-  int rc = ctx->ensure_scratch(64 * sizeof(unsigned long long));
+  int rc = ctx->ensure_scratch(64 * sizeof(unsigned long long), st);
   if (rc) return rc;
   unsigned long long* cnt = (unsigned long long*)ctx->scratch;
   EYOC_CHECK_HIP(hipMemsetAsync(cnt, 0, 64 * sizeof(unsigned long long), st));

@@ -446,7 +446,7 @@ static int knn_run(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c,
   const size_t off_an = eyoc::align_up(off_bm + (prefilter ? (size_t)bm_floats * sizeof(float) : 0));
   const size_t off_fl = eyoc::align_up(off_an + (prefilter ? (size_t)n_total * sizeof(float) : 0));
   const size_t off_bx = eyoc::align_up(off_fl + (prefilter ? (size_t)n_total * sizeof(int) : 0));
-  int rc = ctx->ensure_scratch(off_bx + 2 * MAX_SEG * sizeof(int) + 64);
+  int rc = ctx->ensure_scratch(off_bx + 2 * MAX_SEG * sizeof(int) + 64, st);
   if (rc) return rc;
   unsigned long long* best = (unsigned long long*)ctx->scratch;
   float* Bt = (float*)((char*)ctx->scratch + off_bt);

@@ -117,7 +117,7 @@ int eyoc_lowe_topk(eyoc_ctx* ctx, const float* d1_dev, const float* d2_dev, int 
   const size_t tmp = align_up(sort_rows_tmp_bytes(n, 32));
   const size_t off_w = 0, off_k0 = align_up((size_t)n * 4), off_k1 = off_k0 + align_up((size_t)n * 4);
   const size_t off_r0 = off_k1 + align_up((size_t)n * 4), off_r1 = off_r0 + align_up((size_t)n * 4), off_tmp = off_r1 + align_up((size_t)n * 4);
-  int rc = ctx->ensure_scratch(off_tmp + tmp);
+  int rc = ctx->ensure_scratch(off_tmp + tmp, st);
   if (rc) return rc;
   char* sc = (char*)ctx->scratch;
   float* w = (float*)(sc + off_w);

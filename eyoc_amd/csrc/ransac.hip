@@ -421,7 +421,7 @@ extern "C" int eyoc_ransac_batched(eyoc_ctx* ctx, const float* src_dev, const fl
   const size_t off_cnt = 0, off_rec = align_up((size_t)chunk * CNT_STRIDE * 4), off_surv = align_up(off_rec + (size_t)total * 24);
   const size_t off_cnts = align_up(off_surv + (size_t)chunk * H * 4), off_rmse = align_up(off_cnts + (size_t)chunk * H * 4);
   const size_t off_xf = align_up(off_rmse + (size_t)chunk * H * 4);
-  int rc = ctx->ensure_scratch(off_xf + (size_t)chunk * cap_t * 96);
+  int rc = ctx->ensure_scratch(off_xf + (size_t)chunk * cap_t * 96, st);
   if (rc) return rc;
   char* sc = (char*)ctx->scratch;
   PairArgs a;

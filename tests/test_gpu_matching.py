@@ -232,3 +232,23 @@ def test_mfma_prefilter_decides_almost_every_row_of_the_bench_query(prefilter_al
     got = eyoc_amd.knn1_segmented(torch.from_numpy(F0).cuda(), torch.from_numpy(F1).cuda(), np.array([0, 5000]), np.array([0, 5000]),
                                   return_distance=False).cpu().numpy()
     np.testing.assert_array_equal(got, om.find_nn(F0, F1))
+
+
+def test_two_streams_share_the_scratch_safely():
+    """kNN calls issued back to back on two torch streams use the same grow-only scratch buffer of the context: the
+    library makes the second stream wait for the first one's work (eyoc_ctx::ensure_scratch), so both results are right."""
+    import eyoc_amd
+    from oracle import matching as om
+    cases = [(gi.unit_feats(400 + i, 3000), gi.unit_feats(410 + i, 3000)) for i in range(4)]
+    dev = [(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()) for a, b in cases]
+    want = [om.find_nn(a, b) for a, b in cases]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        got = []
+        for i, (a, b) in enumerate(dev):
+            with torch.cuda.stream(streams[i & 1]):
+                got.append(eyoc_amd.knn1_segmented(a, b, np.array([0, len(a)]), np.array([0, len(b)]), return_distance=False))
+        torch.cuda.synchronize()
+        for g, w in zip(got, want):
+            np.testing.assert_array_equal(g.cpu().numpy(), w)
