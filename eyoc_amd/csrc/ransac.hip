@@ -48,6 +48,9 @@ struct PairArgs {          // a chunk of pairs; segment bounds travel as kernel 
   unsigned int* rmse;      // [chunk][H] fp32 bits of the inlier RMSE (only written for survivors at the largest count)
   double* xf;              // [chunk][cap_t][12] transforms (R row-major, t) of the first cap_t survivors of a pair
   int cap_t;
+  float* rec_sorted;       // [total, 6] the records of every pair bucketed by their residual under the pair's reference transform
+  int* bucket_end;         // [chunk][NBUCKET + 1] records in buckets 0 .. b (prefix lengths); [NBUCKET] = n
+  double* pmax;            // [chunk] largest |source point| of the pair
 };
 
 __global__ void k_gather_targets(const float* __restrict__ src, const float* __restrict__ tgt,
@@ -205,23 +208,103 @@ __global__ __launch_bounds__(GEN_THREADS) void k_generate(PairArgs a) {
 // squared form of Open3D's `dist < max_correspondence_distance` (no fp64 square root per residual)
 __device__ inline double thr2_of(float max_dist) { return (double)max_dist * (double)max_dist; }
 
-// ---- count.  A wave takes a group of G <= 64 survivors and sweeps the correspondences in blocks of 64 * PPL held
-// in registers as doubles.  For one survivor of the group its transform arrives in SGPRs (scalar loads: the address
-// is wave-uniform), the residual test of the block is 16 VALU instructions per correspondence, and the inlier count
-// of the block is s_bcnt1 of the compare masks - scalar work.  Lane s of one VGPR accumulates survivor s's count, so
-// the group's counts are written with one coalesced store and nothing is ever reduced across lanes.
-constexpr int PPL = 4;
+// ---- reference pruning of the count.  Survivors of a pair are near-duplicates of one another (at an inlier ratio p
+// nearly all of them are all-inlier samples), and a correspondence that is a far outlier under ONE of them is an outlier
+// under all that are close to it: with T_ref = the pair's first survivor, d_s(i) >= d_ref(i) - delta_s,
+// delta_s = |R_s - R_ref|_F max_i |p_i| + |t_s - t_ref|.  k_bucket sorts the pair's records into NBUCKET buckets of
+// width max_distance by d_ref (the last one open-ended); survivor s then only evaluates the records of buckets
+// 0 .. floor((max_distance + delta_s) / width) + 1 - every other record is provably farther than max_distance.  The
+// counts are exactly those of the full sweep (tests/test_gpu_pose.py: bit-exact against the oracle's); at p = 0.3 a
+// survivor evaluates ~1600 of 5000 correspondences.  Which survivor holds slot 0 depends on atomics; only the amount of
+// skipped work depends on it.
+constexpr int NBUCKET = 64;
 
-__global__ __launch_bounds__(256) void k_count(PairArgs a, const double* __restrict__ xf_all) {
-  const int c = blockIdx.y;
+__global__ __launch_bounds__(256) void k_bucket(PairArgs a) {
+  __shared__ int hist[NBUCKET], start[NBUCKET];
+  __shared__ double red[4];
+  const int c = blockIdx.x;
   const int s0 = a.s0[c], n = a.n[c];
   const float* __restrict__ rec = a.rec + (size_t)s0 * 6;
+  float* __restrict__ out = a.rec_sorted + (size_t)s0 * 6;
+  int* bend = a.bucket_end + c * (NBUCKET + 1);
+  const int ns = a.n_surv[c * CNT_STRIDE];
+  if (threadIdx.x < NBUCKET) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const bool have_ref = ns > 0;                                        // block-uniform
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
+  if (have_ref) {
+    const double* x = a.xf + (size_t)c * a.cap_t * 12;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = x[i];
+    t[0] = x[9]; t[1] = x[10]; t[2] = x[11];
+  }
+  const double inv_w = 1.0 / (double)a.max_dist;
+  double pm = 0.0;
+  // pass 1: bucket of every record (kept in registers: at most 32 records per thread, n <= 8192)
+  int bkt[32];
+#pragma unroll
+  for (int u = 0; u < 32; ++u) {
+    const int i = u * 256 + (int)threadIdx.x;
+    bkt[u] = -1;
+    if (i < n) {
+      const float2* r = reinterpret_cast<const float2*>(rec + (size_t)i * 6);
+      const float2 p0 = r[0], p1 = r[1], p2 = r[2];
+      const double x = p0.x, y = p0.y, z = p1.x;
+      const double dx = fma(R[0], x, fma(R[1], y, fma(R[2], z, t[0] - (double)p1.y)));
+      const double dy = fma(R[3], x, fma(R[4], y, fma(R[5], z, t[1] - (double)p2.x)));
+      const double dz = fma(R[6], x, fma(R[7], y, fma(R[8], z, t[2] - (double)p2.y)));
+      const double d = sqrt(fma(dx, dx, fma(dy, dy, dz * dz)));
+      const double q = d * inv_w;
+      int b = have_ref ? (q < (double)(NBUCKET - 1) ? (int)q : NBUCKET - 1) : 0;   // NaN -> last bucket
+      if (!(q == q)) b = NBUCKET - 1;
+      bkt[u] = b;
+      atomicAdd(&hist[b], 1);
+      pm = fmax(pm, sqrt(fma(x, x, fma(y, y, z * z))));
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) pm = fmax(pm, __shfl_xor(pm, d, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pm;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int b = 0; b < NBUCKET; ++b) { start[b] = acc; acc += hist[b]; bend[b] = acc; }
+    bend[NBUCKET] = n;
+    a.pmax[c] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  }
+  __syncthreads();
+  // pass 2: scatter (the order inside a bucket is arbitrary - the counts do not depend on it)
+#pragma unroll
+  for (int u = 0; u < 32; ++u) {
+    const int i = u * 256 + (int)threadIdx.x;
+    if (bkt[u] >= 0) {
+      const int pos = atomicAdd(&start[bkt[u]], 1);
+      const float2* r = reinterpret_cast<const float2*>(rec + (size_t)i * 6);
+      float2* w = reinterpret_cast<float2*>(out + (size_t)pos * 6);
+      w[0] = r[0]; w[1] = r[1]; w[2] = r[2];
+    }
+  }
+}
+
+// ---- count.  A wave takes a group of G <= 64 survivors and sweeps the (bucketed) correspondences in blocks of 64 * PPL
+// held in registers as doubles.  For one survivor of the group its transform arrives in SGPRs (scalar loads: the address
+// is wave-uniform), the residual test of the block is 16 VALU instructions per correspondence, and the inlier count
+// of the block is s_bcnt1 of the compare masks - scalar work.  Lane s of one VGPR accumulates survivor s's count, so
+// the group's counts are written with one coalesced store and nothing is ever reduced across lanes.  A survivor skips
+// the blocks past its prefix (reference pruning above).
+constexpr int PPL = 4;
+
+__global__ __launch_bounds__(256) void k_count(PairArgs a, const double* __restrict__ xf_all, int pruned) {
+  const int c = blockIdx.y;
+  const int s0 = a.s0[c], n = a.n[c];
+  const float* __restrict__ rec = (pruned ? a.rec_sorted : a.rec) + (size_t)s0 * 6;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int ns_all = a.n_surv[c * CNT_STRIDE];
   const int ns = ns_all < a.cap_t ? ns_all : a.cap_t;
   const double thr2 = thr2_of(a.max_dist);
   const double* __restrict__ xf = xf_all + (size_t)c * a.cap_t * 12;
+  const int* __restrict__ bend = a.bucket_end + c * (NBUCKET + 1);
   int* cnts = a.cnts + (size_t)c * a.H;
   int G = 64;   // fewer survivors: smaller groups, so that a pair still gives every wave of its grid slice a group
   while (G > 8 && (ns + G - 1) / G < (int)gridDim.x * 4) G >>= 1;
@@ -230,8 +313,29 @@ __global__ __launch_bounds__(256) void k_count(PairArgs a, const double* __restr
   for (int grp = blockIdx.x * 4 + wave; grp < n_groups; grp += gridDim.x * 4) {
     const int sbase = grp * G;
     const int gs = min(G, ns - sbase);
+    // lane s: how many (bucketed) records survivor s has to look at
+    int hi = 0;
+    if (lane < gs) {
+      hi = n;
+      if (pruned) {
+        const double* __restrict__ T = xf + (size_t)(sbase + lane) * 12;
+        double fr = 0.0, dt = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { const double e = T[i] - xf[i]; fr = fma(e, e, fr); }
+#pragma unroll
+        for (int i = 9; i < 12; ++i) { const double e = T[i] - xf[i]; dt = fma(e, e, dt); }
+        const double delta = (sqrt(fr) * a.pmax[c] + sqrt(dt)) * (1.0 + 1e-9) + 1e-9;
+        const double q = ((double)a.max_dist + delta) / (double)a.max_dist;
+        const int b = q < (double)(NBUCKET - 2) ? (int)q + 1 : NBUCKET;   // one bucket of margin; NaN / huge: everything
+        hi = bend[b < NBUCKET ? b : NBUCKET];
+      }
+    }
+    int hi_max = hi;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) hi_max = max(hi_max, __shfl_xor(hi_max, d, 64));
+    hi_max = __builtin_amdgcn_readfirstlane(hi_max);
     int mycnt = 0;
-    for (int i0 = 0; i0 < n; i0 += 64 * PPL) {
+    for (int i0 = 0; i0 < hi_max; i0 += 64 * PPL) {
       double x[PPL], y[PPL], z[PPL], qx[PPL], qy[PPL], qz[PPL];
 #pragma unroll
       for (int u = 0; u < PPL; ++u) {
@@ -246,6 +350,7 @@ __global__ __launch_bounds__(256) void k_count(PairArgs a, const double* __restr
       }
 #pragma unroll 1
       for (int s = 0; s < gs; ++s) {
+        if (i0 >= __builtin_amdgcn_readlane(hi, s)) continue;          // wave-uniform: this survivor's prefix ends before the block
         const double* __restrict__ T = xf + (size_t)(sbase + s) * 12;   // wave-uniform
         const double r00 = T[0], r01 = T[1], r02 = T[2], r10 = T[3], r11 = T[4], r12 = T[5], r20 = T[6], r21 = T[7], r22 = T[8];
         const double t0 = T[9], t1 = T[10], t2 = T[11];
@@ -421,13 +526,19 @@ extern "C" int eyoc_ransac_batched(eyoc_ctx* ctx, const float* src_dev, const fl
   const size_t off_cnt = 0, off_rec = align_up((size_t)chunk * CNT_STRIDE * 4), off_surv = align_up(off_rec + (size_t)total * 24);
   const size_t off_cnts = align_up(off_surv + (size_t)chunk * H * 4), off_rmse = align_up(off_cnts + (size_t)chunk * H * 4);
   const size_t off_xf = align_up(off_rmse + (size_t)chunk * H * 4);
-  int rc = ctx->ensure_scratch(off_xf + (size_t)chunk * cap_t * 96, st);
+  const size_t off_rs = align_up(off_xf + (size_t)chunk * cap_t * 96);
+  const size_t off_be = align_up(off_rs + (size_t)total * 24);
+  const size_t off_pm = align_up(off_be + (size_t)chunk * (NBUCKET + 1) * 4);
+  int rc = ctx->ensure_scratch(off_pm + (size_t)chunk * 8, st);
   if (rc) return rc;
   char* sc = (char*)ctx->scratch;
   PairArgs a;
   a.rec = (float*)(sc + off_rec); a.seed = p->seed; a.H = H; a.edge_sim = p->edge_similarity; a.max_dist = p->max_distance;
   a.n_surv = (int*)(sc + off_cnt); a.surv = (int*)(sc + off_surv); a.cnts = (int*)(sc + off_cnts);
   a.rmse = (unsigned int*)(sc + off_rmse); a.xf = (double*)(sc + off_xf); a.cap_t = cap_t;
+  a.rec_sorted = (float*)(sc + off_rs); a.bucket_end = (int*)(sc + off_be); a.pmax = (double*)(sc + off_pm);
+  static const bool prune_env = !(getenv("EYOC_RANSAC_PRUNE") && atoi(getenv("EYOC_RANSAC_PRUNE")) == 0);
+  const int pruned = prune_env && max_n <= 8192 ? 1 : 0;
   const bool in_lds = max_n <= LDS_RECORDS;
   const size_t lds_bytes = in_lds ? (size_t)max_n * 24 : 0;
   if (in_lds) {
@@ -452,7 +563,8 @@ extern "C" int eyoc_ransac_batched(eyoc_ctx* ctx, const float* src_dev, const fl
     const int gen_blocks = GEN_BLOCKS_TOTAL / nc > GEN_BLOCKS_MIN ? GEN_BLOCKS_TOTAL / nc : GEN_BLOCKS_MIN;
     if (in_lds) hipLaunchKernelGGL(k_generate<true>, dim3(gen_blocks, nc), dim3(GEN_THREADS), lds_bytes, st, a);
     else hipLaunchKernelGGL(k_generate<false>, dim3(gen_blocks, nc), dim3(GEN_THREADS), 0, st, a);
-    hipLaunchKernelGGL(k_count, dim3(2048 / nc, nc), dim3(256), 0, st, a, (const double*)a.xf);
+    if (pruned) hipLaunchKernelGGL(k_bucket, dim3(nc), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_count, dim3(2048 / nc, nc), dim3(256), 0, st, a, (const double*)a.xf, pruned);
     if (H > cap_t) hipLaunchKernelGGL(k_count_overflow, dim3(256, nc), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_rmse, dim3(64, nc), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_select, dim3(nc), dim3(1024), 0, st, a, results_dev);
