@@ -542,6 +542,146 @@ __global__ __launch_bounds__(256) void conv1_tree_kernel(Conv1Args a) {
   }
 }
 
+// The same first convolution (C_in = 1, 5^3 or 3^3 window, 32 output channels) as MFMA work.  conv1_tree_kernel walks the
+// 216 (coarse block, child) slots of a row in lock step - a wave executes every slot although ~12 % of its lanes hold a
+// neighbour there - and pays 32 FMAs with lane-varying weight rows per slot: 1.65 ms on the 3.8 M-row batch.  Here a wave
+// takes 16 output rows, its four 16-lane groups walk a quarter of the coarse blocks each (a neighbour's feature goes to
+// column k = its window position of the row's line in an LDS tile, as fp16 hi / lo halves), and the products are ONE
+// [16 x 128] x [128 x 32] split16 GEMM per tile: 4 k-steps x 3 terms x 2 channel tiles = 24 MFMAs, weights resident in
+// registers (pre-scaled by 2^8 so that their lo halves stay normal).
+__global__ __launch_bounds__(256, 4) void conv1_mfma_kernel(Conv1Args a) {
+  constexpr int COUT = 32, KP = 128, NT = COUT / 16, NQ = KP / 32;
+  __shared__ __attribute__((aligned(16))) _Float16 xt[4][2][16][KP];   // [wave][hi / lo][row][window position]
+  __shared__ __attribute__((aligned(8))) signed char ktab[8][216];                                // window position of slot (block kc, child cs) for a row of parity class cls, -1: outside
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int K = a.ks * a.ks * a.ks, r = a.ks / 2;
+  for (int e = threadIdx.x; e < 8 * 216; e += 256) {
+    const int cls = e / 216, sl = e % 216, kc = sl >> 3, cs = sl & 7;
+    const int dx = 2 * (kc % 3 - 1) + (cs & 1) - (cls & 1), dy = 2 * ((kc / 3) % 3 - 1) + ((cs >> 1) & 1) - ((cls >> 1) & 1),
+              dz = 2 * (kc / 9 - 1) + (cs >> 2) - (cls >> 2);
+    const bool in = dx >= -r && dx <= r && dy >= -r && dy <= r && dz >= -r && dz <= r;
+    ktab[cls][sl] = (signed char)(in ? (dx + r) + a.ks * (dy + r) + a.ks * a.ks * (dz + r) : -1);
+  }
+  __syncthreads();
+  // weight fragments (A operand): lane (g, j): W[k = 32 q + 8 g + i][cout = 16 t + j] * 256, split
+  half8_t wh[NQ][NT], wl[NQ][NT];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = 32 * q + 8 * g + i;
+        const float w = k < K ? a.w[(size_t)k * COUT + 16 * t + j] * 256.0f : 0.0f;
+        const _Float16 h = (_Float16)w;
+        wh[q][t][i] = h;
+        wl[q][t][i] = (_Float16)(w - (float)h);
+      }
+  _Float16 (*xh)[KP] = xt[wave][0];
+  _Float16 (*xl)[KP] = xt[wave][1];
+  const int n_tiles = (a.n + 15) / 16;
+  // persistent waves: the weight fragments above are loaded once per wave, not once per 16 rows
+  for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+  const int o = tile * 16 + j;                                      // this lane's row (the 4 groups share it)
+  // clear the tile: 16 rows x 256 B x 2 = 8 KB per wave
+  {
+    float4* z = reinterpret_cast<float4*>(&xt[wave][0][0][0]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (o < a.n) {
+    const int4 c = reinterpret_cast<const int4*>(a.coords)[o];
+    const signed char* kt = ktab[(c.y & 1) | ((c.z & 1) << 1) | ((c.w & 1) << 2)];
+    const int p = a.parent[o];
+    // per half of the group's (up to 7) coarse blocks: three rounds of independent loads - the blocks, their child
+    // vectors, the features of ALL their children back to back (absent / outside slots read row 0; a load inside a
+    // branch would wait for its data before the next slot starts) - then the LDS writes
+    const float* __restrict__ fin = a.in;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      constexpr int NB = 4;
+      int Bk[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int kc = g + 4 * (half * NB + i);
+        Bk[i] = kc >= 27 ? -1 : kc == 13 ? p : a.s1c[(size_t)kc * a.nc + p];
+      }
+      int ch[NB][8];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        int4 lo = make_int4(-1, -1, -1, -1), hi = make_int4(-1, -1, -1, -1);
+        if (Bk[i] >= 0) {
+          lo = reinterpret_cast<const int4*>(a.children)[2 * (size_t)Bk[i]];
+          hi = reinterpret_cast<const int4*>(a.children)[2 * (size_t)Bk[i] + 1];
+        }
+        ch[i][0] = lo.x; ch[i][1] = lo.y; ch[i][2] = lo.z; ch[i][3] = lo.w;
+        ch[i][4] = hi.x; ch[i][5] = hi.y; ch[i][6] = hi.z; ch[i][7] = hi.w;
+      }
+      int kk[NB][8];
+      float fv[NB][8];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int kc = g + 4 * (half * NB + i);
+        const unsigned long long k8 = kc < 27 ? *reinterpret_cast<const unsigned long long*>(kt + kc * 8) : ~0ull;   // 8 positions
+#pragma unroll
+        for (int cs = 0; cs < 8; ++cs) {
+          const int idx = ch[i][cs];
+          const int kpos = (int)(signed char)(k8 >> (8 * cs));
+          const bool ok = idx >= 0 && kpos >= 0;
+          kk[i][cs] = ok ? kpos : -1;
+          fv[i][cs] = fin[ok ? idx : 0];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int cs = 0; cs < 8; ++cs)
+          if (kk[i][cs] >= 0) {
+            const float f = fv[i][cs];
+            const _Float16 h = (_Float16)f;
+            xh[j][kk[i][cs]] = h;
+            xl[j][kk[i][cs]] = (_Float16)(f - (float)h);
+          }
+    }
+  }
+  // the wave's LDS operations execute in order; the wait makes the writes of the other lanes visible to the reads below
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const half8_t vh = *reinterpret_cast<const half8_t*>(&xh[j][32 * q + 8 * g]);   // B operand: X[k = 32 q + 8 g + i][row j]
+    const half8_t vl = *reinterpret_cast<const half8_t*>(&xl[j][32 * q + 8 * g]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q][t], vh, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q][t], vl, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[q][t], vh, acc[t], 0, 0, 0);
+    }
+  }
+  if (o < a.n) {
+    // lane (g, j) holds channels 16 t + 4 g .. +3 of row o
+    float* dst = a.out + (size_t)o * a.ld_out;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int ch0 = 16 * t + 4 * g;
+      const float4 b = *reinterpret_cast<const float4*>(a.bias + ch0);
+      const float4 v = make_float4(acc[t][0] * (1.0f / 256.0f) + b.x, acc[t][1] * (1.0f / 256.0f) + b.y,
+                                   acc[t][2] * (1.0f / 256.0f) + b.z, acc[t][3] * (1.0f / 256.0f) + b.w);
+      if (a.out_split) split16_store4(dst, ch0, v);
+      else *reinterpret_cast<float4*>(dst + ch0) = v;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();                                   // the next tile's clear stays behind this tile's operand reads
+  }
+}
+
 // fp32 rows <-> SPLIT16 rows (tests, and callers that feed eyoc_spconv_ex directly)
 __global__ void k_split16_encode(const float* __restrict__ in, int n, int c, int ld_in, float* __restrict__ out, int ld_out) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -658,6 +798,15 @@ int launch_conv1(const Conv1Args& a, hipStream_t st) {
   dim3 grid(cdiv(a.n, 256));
   const size_t tree_lds = (size_t)a.ks * a.ks * a.ks * a.cin * (a.cout + 4) * sizeof(float);
   if (conv1_walks_octree(a)) {
+    // C_in = 1, 32 output channels, split16 activations downstream (the large-batch path): the MFMA formulation.  Its
+    // products carry 22-bit significands like every split16 layer; fp32 consumers keep the exact-fp32 walker
+    static const bool mfma_env = !(getenv("EYOC_CONV1_MFMA") && atoi(getenv("EYOC_CONV1_MFMA")) == 0);
+    if (mfma_env && a.cin == 1 && a.cout == 32 && a.out_split && a.ks * a.ks * a.ks < 128 && !a.in_perm) {
+      const int wgs = cdiv(a.n, 64);
+      hipLaunchKernelGGL(conv1_mfma_kernel, dim3(wgs < 2560 ? wgs : 2560), dim3(256), 0, st, a);   // 10 workgroups per CU, persistent
+      EYOC_CHECK_HIP(hipGetLastError());
+      return EYOC_OK;
+    }
     switch (a.cout) {
       case 32: hipLaunchKernelGGL(conv1_tree_kernel<32>, grid, dim3(256), tree_lds, st, a); break;
       case 64: hipLaunchKernelGGL(conv1_tree_kernel<64>, grid, dim3(256), tree_lds, st, a); break;
