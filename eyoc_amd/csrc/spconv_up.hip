@@ -53,9 +53,12 @@ __global__ __launch_bounds__(256) void k_local_rulebook_up(const int32_t* __rest
   __syncthreads();
   unsigned short slot[27];
   unsigned int mask = 0;
+  int idxs[27];                                                      // all 27 loads first: behind the CAS loops each would wait alone
+#pragma unroll
+  for (int k = 0; k < 27; ++k) idxs[k] = (k < K && row < n_out) ? nbr[(size_t)k * n_out + row] : -1;
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
-    const int idx = (k < K && row < n_out) ? nbr[(size_t)k * n_out + row] : -1;
+    const int idx = idxs[k];
     unsigned int s = 0xFFFFu;
     if (idx >= 0) {
       mask |= 1u << k;
