@@ -143,6 +143,64 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_compact(const int* __restrict__ 
   }
 }
 
+// ---- Z-ordered levels without a hash table: the rows of level l-1 are sorted by Morton key, so the rows of one coarse
+// voxel are adjacent and a coarse voxel's first occurrence is where the coarse coordinate changes.  (The hash insert of
+// the 3.8 M level-0 rows of the 64-pair batch cost 0.5 ms; it stays for the coarsest level, whose table the 27-probe
+// neighbour search needs, and for batches in the caller's order.)
+__global__ void k_flag_sorted(const int32_t* __restrict__ coords, int n, int ts2, int* __restrict__ flag, int* __restrict__ err,
+                              int* __restrict__ dup) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int b, x, y, z;
+  coarse_coord(coords + 4 * (size_t)i, ts2, b, x, y, z);
+  constexpr int LIM = COORD_BIAS - 16;
+  if (err && (b < 0 || b >= 1024 || x < -LIM || x >= LIM || y < -LIM || y >= LIM || z < -LIM || z >= LIM)) atomicAdd(err, 1);
+  int f = 1;
+  if (i > 0) {
+    int pb, px, py, pz;
+    coarse_coord(coords + 4 * (size_t)(i - 1), ts2, pb, px, py, pz);
+    f = (pb != b || px != x || py != y || pz != z) ? 1 : 0;
+    if (dup) {   // level 0 -> 1: two equal rows are a duplicate coordinate
+      const int4 c = reinterpret_cast<const int4*>(coords)[i], q = reinterpret_cast<const int4*>(coords)[i - 1];
+      if (c.x == q.x && c.y == q.y && c.z == q.z && c.w == q.w) atomicAdd(dup, 1);
+    }
+  }
+  flag[i] = f;
+}
+
+// compaction + octree links in one pass: first rows write their coarse coordinate, every row learns its parent (the
+// number of first rows up to and including it, minus one) and enters itself as that parent's child
+__global__ __launch_bounds__(SCAN_BLOCK) void k_compact_sorted(const int* __restrict__ flag, const int* __restrict__ partial,
+                                                               const int32_t* __restrict__ coords, int n, int ts2, int sh,
+                                                               int32_t* __restrict__ coords_out, int32_t* __restrict__ parent,
+                                                               int32_t* __restrict__ children) {
+  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  int f[SCAN_ITEMS];
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    f[j] = (base + j < n) ? flag[base + j] : 0;
+    s += f[j];
+  }
+  int tot;
+  int pos = partial[blockIdx.x] + block_exclusive_scan(s, &tot);
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    const int i = base + j;
+    if (i >= n) break;
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    if (f[j]) {
+      int b, x, y, z;
+      coarse_coord(coords + 4 * (size_t)i, ts2, b, x, y, z);
+      reinterpret_cast<int4*>(coords_out)[pos] = make_int4(b, x, y, z);
+      ++pos;
+    }
+    const int cs = ((c.y >> sh) & 1) | (((c.z >> sh) & 1) << 1) | (((c.w >> sh) & 1) << 2);
+    parent[i] = pos - 1;
+    children[(size_t)(pos - 1) * 8 + cs] = i;
+  }
+}
+
 // nbr[k][o] = row of table_in at c_out[o] + sign * off_k * step
 __global__ void k_neighbours(const int32_t* __restrict__ coords_out, int n_out, HashTable tin, int step, int sign,
                              int32_t* __restrict__ nbr) {
@@ -271,8 +329,8 @@ __global__ void k_derive_fine(const int32_t* __restrict__ coords, int n, int sh,
     const int kc = (ox + 1) + 3 * (oy + 1) + 9 * (oz + 1);
     blk[a] = a == 0 ? p : s1c[(size_t)kc * nc + p];
   }
-#pragma unroll 1
-  for (int k = 0; k < 27; ++k) {
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {   // unrolled: 27 independent child loads in flight (one per iteration waited alone before)
     const int off[3] = {k % 3 - 1, (k / 3) % 3 - 1, k / 9 - 1};
     int a = 0, cs = 0, a_up = 0;
     bool up_ok = true;
@@ -315,7 +373,7 @@ __global__ void k_derive_down(int nc, const int32_t* __restrict__ children, cons
     const int kc = (1 - (a & 1)) + 3 * (1 - ((a >> 1) & 1)) + 9 * (1 - ((a >> 2) & 1));
     blk[a] = a == 0 ? v : s1c[(size_t)kc * nc + v];
   }
-#pragma unroll 1
+#pragma unroll
   for (int k = 0; k < 27; ++k) {
     const int off[3] = {k % 3 - 1, (k / 3) % 3 - 1, k / 9 - 1};
     int a = 0, cs = 0;
@@ -451,34 +509,50 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
     const int n_src = m->rows[l - 1];
     const int32_t* src = m->coords[l - 1];
     const int ts2 = 1 << l;
-    const unsigned int cap = table_capacity(n_src);
-    HashTable& t = m->table[l];
-    t.keys = cv.take<unsigned long long>(cap);
-    t.vals = cv.take<int>(cap);
-    t.mask = cap - 1;
-    FAIL_HIP(hipMemsetAsync(t.keys, 0xFF, (size_t)cap * 8, st));
-    FAIL_HIP(hipMemsetAsync(t.vals, 0x7F, (size_t)cap * 4, st));
-    hipLaunchKernelGGL(k_insert, dim3(cdiv(n_src, 256)), dim3(256), 0, st, src, n_src, ts2, t, slot, counters);
-    hipLaunchKernelGGL(k_flag, dim3(cdiv(n_src, 256)), dim3(256), 0, st, slot, t.vals, n_src, flag, (int*)nullptr);
     const int nb = cdiv(n_src, SCAN_TILE);
+    const bool sorted_level = zorder && l + 1 < EYOC_MAX_LEVELS;       // no table: adjacent rows (see k_flag_sorted)
+    HashTable& t = m->table[l];
+    if (sorted_level) {
+      hipLaunchKernelGGL(k_flag_sorted, dim3(cdiv(n_src, 256)), dim3(256), 0, st, src, n_src, ts2, flag,
+                         l == 1 ? counters : (int*)nullptr, l == 1 ? counters + 1 : (int*)nullptr);
+    } else {
+      const unsigned int cap = table_capacity(n_src);
+      t.keys = cv.take<unsigned long long>(cap);
+      t.vals = cv.take<int>(cap);
+      t.mask = cap - 1;
+      FAIL_HIP(hipMemsetAsync(t.keys, 0xFF, (size_t)cap * 8, st));
+      FAIL_HIP(hipMemsetAsync(t.vals, 0x7F, (size_t)cap * 4, st));
+      hipLaunchKernelGGL(k_insert, dim3(cdiv(n_src, 256)), dim3(256), 0, st, src, n_src, ts2, t, slot, counters);
+      hipLaunchKernelGGL(k_flag, dim3(cdiv(n_src, 256)), dim3(256), 0, st, slot, t.vals, n_src, flag, (int*)nullptr);
+    }
     hipLaunchKernelGGL(k_scan_partials, dim3(nb), dim3(SCAN_BLOCK), 0, st, flag, n_src, partial);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, st, partial, nb, counters + 2 + l);
     FAIL_HIP(hipMemcpyAsync(host, counters + 2 + l, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (l == 1) FAIL_HIP(hipMemcpyAsync(host + 1, counters, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (l == 1) FAIL_HIP(hipMemcpyAsync(host + 1, counters, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     FAIL_HIP(hipStreamSynchronize(st));
     if (l == 1 && host[1] != 0) {
       set_error("eyoc_maps_build: %d coordinate rows outside the supported key range (|c| < 2^17 - 16, 0 <= batch < 1024)", host[1]);
       delete m;
       return EYOC_ERR_RANGE;
     }
+    if (l == 1 && sorted_level && host[2] != 0) {
+      set_error("eyoc_maps_build: %d duplicate coordinate rows (a sparse tensor needs unique coordinates)", host[2]);
+      delete m;
+      return EYOC_ERR_DUPLICATE;
+    }
     m->rows[l] = host[0];
     m->coords[l] = cv.take<int32_t>((size_t)m->rows[l] * 4);
-    hipLaunchKernelGGL(k_compact, dim3(nb), dim3(SCAN_BLOCK), 0, st, flag, partial, slot, src, n_src, ts2,
-                       m->coords[l], t.vals, (int32_t*)nullptr);
-    // octree links fine (l-1) <-> coarse (l); same stream, so k_compact's re-labelling is visible
     m->parent[l - 1] = cv.take<int32_t>((size_t)n_src);
     m->children[l - 1] = cv.take<int32_t>((size_t)m->rows[l] * 8);
     FAIL_HIP(hipMemsetAsync(m->children[l - 1], 0xFF, (size_t)m->rows[l] * 32, st));
+    if (sorted_level) {
+      hipLaunchKernelGGL(k_compact_sorted, dim3(nb), dim3(SCAN_BLOCK), 0, st, flag, partial, src, n_src, ts2, l - 1,
+                         m->coords[l], m->parent[l - 1], m->children[l - 1]);
+      continue;
+    }
+    hipLaunchKernelGGL(k_compact, dim3(nb), dim3(SCAN_BLOCK), 0, st, flag, partial, slot, src, n_src, ts2,
+                       m->coords[l], t.vals, (int32_t*)nullptr);
+    // octree links fine (l-1) <-> coarse (l); same stream, so k_compact's re-labelling is visible
     hipLaunchKernelGGL(k_children, dim3(cdiv(n_src, 256)), dim3(256), 0, st, slot, t.vals, src, n_src, l - 1,
                        m->parent[l - 1], m->children[l - 1], l == 1 ? counters + 1 : (int*)nullptr);
     if (l == 1) {

@@ -146,3 +146,19 @@ def test_maps_reject_duplicates_and_out_of_range():
         eyoc_amd.CoordinateManager(far).maps()
     with pytest.raises(eyoc_amd.EyocError):
         eyoc_amd.CoordinateManager(torch.zeros((0, 4), dtype=torch.int32).cuda()).maps()
+
+
+def test_z_ordered_maps_reject_duplicates_and_out_of_range(zorder_rows):
+    """The hash-free level construction of Z-ordered maps (adjacent rows of the sorted list) keeps the validation."""
+    import eyoc_amd
+    rng = np.random.default_rng(3)
+    base = np.unique(rng.integers(-30, 30, size=(4000, 3)), axis=0).astype(np.int32)
+    coords = np.concatenate([np.zeros((len(base), 1), np.int32), base], 1)
+    dup = np.concatenate([coords, coords[100:101]])                       # one duplicate, far apart in the caller's order
+    with pytest.raises(eyoc_amd.EyocError, match="duplicate"):
+        eyoc_amd.CoordinateManager(torch.from_numpy(dup).cuda()).maps()
+    far = coords.copy()
+    far[7, 1] = 1 << 17
+    with pytest.raises(eyoc_amd.EyocError, match="range"):
+        eyoc_amd.CoordinateManager(torch.from_numpy(far).cuda()).maps()
+    eyoc_amd.CoordinateManager(torch.from_numpy(coords).cuda()).maps()    # and the clean cloud builds
