@@ -707,7 +707,7 @@ static int g_split16_kernel = getenv("EYOC_SPCONV_RS") ? atoi(getenv("EYOC_SPCON
 
 int spconv_forced_kernel() { return g_kernel_mode; }
 // staged kernel for the transposed convolutions (spconv_up.hip): off by default - measured level with the row-stationary
-// kernel in windowed pattern order (0.75 / 1.16 / 1.50 vs 0.63 / 1.02 / 1.57 ms on the bench's three layers) while its
+// kernel in windowed pattern order (0.68 / 1.06 / 1.44 vs 0.63 / 1.02 / 1.57 ms on the bench's three layers) while its
 // rulebooks add 0.7 ms to the map build; it reads 20 GB less from HBM per forward
 int g_up_kernel = getenv("EYOC_SPCONV_UP") ? atoi(getenv("EYOC_SPCONV_UP")) : 0;
 bool spconv_up_enabled() { return g_up_kernel != 0; }

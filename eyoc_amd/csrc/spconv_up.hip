@@ -242,19 +242,23 @@ __global__ __launch_bounds__(NWK * 64, 4) void spconv_up_kernel(SpconvArgs a, co
     stage(qb);
     unsigned int rest = wmask;
     int kc = rest ? __builtin_ctz(rest) : 0;
-    if (rest) { load_w(kc, qb, WA); LA = locp[kc * 64]; }
+    load_w(kc, qb, WA);                                                // unconditional: a load inside a branch is waited for on the spot
+    LA = locp[kc * 64];
     __builtin_amdgcn_s_waitcnt(0x0070);
     __syncthreads();
-    while (rest) {                                                     // wave-uniform: the offsets any of the 8 groups has
+    const int n_off = __builtin_popcount(wmask);                       // wave-uniform: the offsets any of the wave's groups has
+    for (int i = 0; i < n_off; i += 2) {
       rest &= rest - 1;
       int kn = rest ? __builtin_ctz(rest) : kc;
-      if (rest) { load_w(kn, qb, WB); LB = locp[kn * 64]; }
+      load_w(kn, qb, WB);                                              // next occupied offset (the last one re-loads itself)
+      LB = locp[kn * 64];
       compute(kc, LA, WA);
       kc = kn;
-      if (!rest) break;
+      if (i + 1 >= n_off) break;
       rest &= rest - 1;
       kn = rest ? __builtin_ctz(rest) : kc;
-      if (rest) { load_w(kn, qb, WA); LA = locp[kn * 64]; }
+      load_w(kn, qb, WA);
+      LA = locp[kn * 64];
       compute(kc, LB, WB);
       kc = kn;
     }
