@@ -301,9 +301,10 @@ __global__ __launch_bounds__(256) void knn_mfma_kernel(const float* __restrict__
     for (int half = 0; half < 2; ++half) {
       const int tt = t + half;
       if (tt >= n16) break;                                          // wave-uniform
-      if (tt + 1 < n16) {
+      {   // unconditional (the last tile re-loads itself): a load inside a branch is waited for on the spot
+        const int tn = tt + 1 < n16 ? tt + 1 : tt;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) bf[half ^ 1][q] = bm[((size_t)(tt + 1) * NQ + q) * 64];
+        for (int q = 0; q < NQ; ++q) bf[half ^ 1][q] = bm[((size_t)tn * NQ + q) * 64];
       }
       const int jt = 16 * tt + jl;
 #pragma unroll
