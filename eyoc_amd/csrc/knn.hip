@@ -441,7 +441,7 @@ static int knn_run(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c,
     bm_floats += (long long)eyoc::cdiv(seg_b[s + 1] - seg_b[s], 16) * (c / 4 + 1) * 64;
   }
   const bool prefilter = prefilter_env != 0 && !dot && !second_dev && !dist_dev && dist_type == 0 && c == 32 && max_nb > 0 &&
-                         (waves >= 1024 || prefilter_env == 2);
+                         (waves >= 512 || prefilter_env == 2);
   const size_t off_bt = eyoc::align_up((size_t)n_total * sizeof(unsigned long long));
   const size_t off_bm = eyoc::align_up(off_bt + (size_t)bt_floats * sizeof(float) + 64);
   const size_t off_an = eyoc::align_up(off_bm + (prefilter ? (size_t)bm_floats * sizeof(float) : 0));

@@ -255,7 +255,7 @@ int eyoc_model_timing_slot(eyoc_model* model, int slot);
 
 /* MFMA pre-filter of eyoc_knn1's plain index query (SquareL2, idx only, C = 32): an fp32-MFMA score decides every row
  * whose runner-up is out of rounding reach, the exact kernel recomputes the rest - the indices are identical either way.
- * mode 0: never, 1 (default): when the query fills the chip (>= 1024 waves of 64 rows), 2: always; < 0 only queries.
+ * mode 0: never, 1 (default): when the query fills the chip (>= 512 waves of 64 rows), 2: always; < 0 only queries.
  * Returns the previous mode.  Process-wide; for tests and profiling. */
 int eyoc_knn_prefilter(int mode);
 /* ------------------------------------------------------------------------------------------------
