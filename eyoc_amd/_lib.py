@@ -60,6 +60,7 @@ PROTOTYPES = {
     "eyoc_destroy": (_i, [_vp]),
     "eyoc_maps_workspace_bytes": (_sz, [_i]),
     "eyoc_maps_build": (_i, [_vp, _vp, _i, _vp, _sz, _vp, C.POINTER(_vp)]),
+    "eyoc_maps_build_ordered": (_i, [_vp, _vp, _i, _vp, _sz, _vp, _i, C.POINTER(_vp)]),
     "eyoc_maps_free": (_i, [_vp]),
     "eyoc_maps_internal_order": (_i, [_i]),
     "eyoc_maps_order_window_shift": (_i, [_i]),

@@ -418,8 +418,11 @@ static int ORDER_MIN_ROWS = 65536;
 // Z-ordered levels: window of the tiling orders, log2 rows.  Measured on the 64-pair bench: 2^17-2^18 rows (2^12, 2^14
 // lose - too many short pattern runs; no windows: +23 % on the 1 -> 0 transposed convolution)
 static int ORDER_WINDOW_SHIFT = getenv("EYOC_ORDER_WINDOW_SHIFT") ? atoi(getenv("EYOC_ORDER_WINDOW_SHIFT")) : 18;
-static int INTERNAL_ORDER = -1;          // eyoc_maps_internal_order: -1 automatic (Z-order from 262144 rows), 0 caller's order, 1 Z-order
-constexpr int ZORDER_MIN_ROWS = 262144;  // the batch size from which the model runs split16 (model.hip)   // below this no convolution of the level reaches the wave-private kernel's tile count
+static int INTERNAL_ORDER = -1;          // eyoc_maps_internal_order: -1 automatic (Z-order from 8192 rows), 0 caller's order, 1 Z-order
+// Z-order (and with it the staged split16 kernels, model.hip) from 8192 rows: measured faster than the fp32 kernels on
+// the caller's row order at every size tried - maps + forward of a 15 k-row half cloud 2.30 -> 1.78 ms, one 31 k-row
+// cloud 2.45 -> 2.02, a pair 2.86 -> 2.17 (scripts/bench_small_forward.py).  Smaller inputs keep the caller's order.
+constexpr int ZORDER_MIN_ROWS = 8192;
 
 unsigned int table_capacity(int n) {
   unsigned int cap = 1024;
@@ -452,7 +455,13 @@ size_t eyoc_maps_workspace_bytes(int n_rows) {
 
 int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, size_t ws_bytes, void* stream,
                     eyoc_maps** out) {
+  return eyoc_maps_build_ordered(ctx, coords_dev, n, ws, ws_bytes, stream, -1, out);
+}
+
+int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, size_t ws_bytes, void* stream,
+                            int order, eyoc_maps** out) {
   EYOC_REQUIRE(ctx && out && ws, EYOC_ERR_INVALID, "eyoc_maps_build: NULL argument");
+  EYOC_REQUIRE(order >= -1 && order <= 1, EYOC_ERR_INVALID, "eyoc_maps_build_ordered: order %d", order);
   EYOC_REQUIRE(n > 0 && coords_dev, EYOC_ERR_INVALID, "eyoc_maps_build: empty coordinate set (n=%d)", n);
   EYOC_REQUIRE(((uintptr_t)ws & 255) == 0, EYOC_ERR_INVALID, "eyoc_maps_build: workspace must be 256-byte aligned");
   EYOC_REQUIRE(ws_bytes >= eyoc_maps_workspace_bytes(n), EYOC_ERR_WORKSPACE,
@@ -480,7 +489,8 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, s
   // ---- level 0: the caller's rows, in the caller's order
   m->rows[0] = n;
   m->coords[0] = cv.take<int32_t>((size_t)n * 4);
-  const bool zorder = INTERNAL_ORDER > 0 || (INTERNAL_ORDER < 0 && n >= ZORDER_MIN_ROWS);
+  const int order_mode = INTERNAL_ORDER >= 0 ? INTERNAL_ORDER : order;   // the process-wide switch (tests) beats the call's wish
+  const bool zorder = order_mode > 0 || (order_mode < 0 && n >= ZORDER_MIN_ROWS);
   if (zorder) {
     unsigned long long* zk_in = cv.take<unsigned long long>(n);
     unsigned long long* zk_out = cv.take<unsigned long long>(n);

@@ -290,13 +290,13 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
   buf[B_OUT] = out_dev;
   for (int i = B_X1; i < B_OUT; ++i) buf[i] = cv.take<float>((size_t)maps->rows[m->bufs[i].level] * m->bufs[i].width);
   // arithmetic of the sparse convolutions: SPLIT16 needs the wave-private kernel for EVERY layer (only it reads and
-  // writes the format), which pays off once the finest level alone fills the chip (>= 4096 wave tiles ~ 4 KITTI
+  // writes the format), which round 1 measured to pay off once the finest level alone fills the chip (>= 4096 wave tiles ~ 4 KITTI
   // pairs); small batches stay on fp32, where the launcher picks the workgroup-tiled kernel per layer
   static const int env_math = getenv("EYOC_SPCONV_MATH") ? atoi(getenv("EYOC_SPCONV_MATH")) : -1;
   const int want = m->math >= 0 ? m->math : env_math;
   const bool split_ok = spconv_forced_kernel() != 0 && !(m->desc.normalize_feature && m->desc.out_channels > 64) &&
                         m->desc.channels[1] % 32 == 0;
-  const bool split = split_ok && (want == 1 || (want < 0 && cdiv(maps->rows[0], 64) >= 4096));
+  const bool split = split_ok && (want == 1 || (want < 0 && maps->rows[0] >= 8192));   // = the Z-order threshold of eyoc_maps_build
   EYOC_REQUIRE(want != 1 || split, EYOC_ERR_INVALID,
                "eyoc_model_forward: split16 arithmetic is not available for this model / kernel selection");
   m->last_math = split ? 1 : 0;

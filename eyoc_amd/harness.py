@@ -170,7 +170,7 @@ class RegistrationPipeline:
             self._side = torch.cuda.Stream(device=batch.coords.device)
         with torch.cuda.stream(self._side):
             cm = CoordinateManager(batch.coords)
-            cm.maps()
+            cm.maps(-1)
             ready = torch.cuda.Event()
             ready.record(self._side)
         return cm, ready

@@ -219,7 +219,7 @@ class ResUNet2(nn.Module):
             self.pack(dev)       # parameters changed in place since the blob was packed (adopted blobs are exempt)
         lib = _lib.load()
         cm = x.coordinate_manager
-        maps = cm.maps()
+        maps = cm.maps(-1)        # automatic internal order (Z-order from 8192 rows); in and out stay in the caller's rows
         out = torch.empty((len(x), self.out_channels), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             ws = _lib.workspace(lib.eyoc_model_workspace_bytes(self._handle, maps), dev)
@@ -282,7 +282,7 @@ class ResUNet2(nn.Module):
         pairs = (C.c_int64 * n)()
         fl, gb, cb = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
         with torch.cuda.device(x.device):
-            _lib.check(lib.eyoc_model_layer_work(_lib.ctx(x.device.index), self._handle, x.coordinate_manager.maps(),
+            _lib.check(lib.eyoc_model_layer_work(_lib.ctx(x.device.index), self._handle, x.coordinate_manager.maps(-1),
                                                  _lib.stream_ptr(), names, pairs, fl, gb, cb), "eyoc_model_layer_work")
         return [{"name": names[i].decode(), "pairs": int(pairs[i]), "flop": fl[i], "gather_bytes": gb[i],
                  "compulsory_bytes": cb[i]} for i in range(n)]

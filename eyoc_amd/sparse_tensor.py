@@ -33,16 +33,21 @@ class CoordinateManager:
     def device(self):
         return self.coordinates.device
 
-    def maps(self):
+    def maps(self, order: int = 0):
+        """The device-side maps, built on first use.  ``order``: internal row order of a build that happens now -
+        ``-1`` automatic (Z-order from 8192 rows: what the network forward is fastest on - ``model(x)`` asks for it),
+        ``0`` (default of the accessors below and of the autograd layer functions) the caller's order, so that
+        ``level_coordinates`` / ``table`` line up with the caller's feature rows; ``1`` Z-order.  Once built the maps
+        stay as they are; ``row_order()`` tells which order that is."""
         if self._maps is None:
             lib = _lib.load()
             n = self.coordinates.shape[0]
             with torch.cuda.device(self.device):
                 self._ws = _lib.workspace(lib.eyoc_maps_workspace_bytes(n), self.device)
                 h = C.c_void_p()
-                _lib.check(lib.eyoc_maps_build(_lib.ctx(self.device.index), _lib.ptr(self.coordinates), n,
-                                               _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr(), C.byref(h)),
-                           "eyoc_maps_build")
+                _lib.check(lib.eyoc_maps_build_ordered(_lib.ctx(self.device.index), _lib.ptr(self.coordinates), n,
+                                                       _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr(), int(order),
+                                                       C.byref(h)), "eyoc_maps_build")
             self._maps = h
         return self._maps
 
@@ -68,8 +73,8 @@ class CoordinateManager:
         return out
 
     def row_order(self) -> torch.Tensor | None:
-        """``int32 [rows(0)]``: caller's row of every internal row when the maps keep their rows in Z-order (large
-        batches), ``None`` when the caller's order was kept.  Level coordinates and tables are in internal rows; the
+        """``int32 [rows(0)]``: caller's row of every internal row when the maps keep their rows in Z-order (built by a
+        network forward on >= 8192 rows, or asked for), ``None`` when the caller's order was kept.  Level coordinates and tables are in internal rows; the
         network's input and output stay in the caller's order either way."""
         lib = _lib.load()
         if not lib.eyoc_maps_row_order(self.maps()):

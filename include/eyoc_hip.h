@@ -77,6 +77,11 @@ typedef struct {
 size_t eyoc_maps_workspace_bytes(int n_rows);
 int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n_rows, void* workspace_dev,
                     size_t workspace_bytes, void* stream, eyoc_maps** out);
+/* The same with the internal row order chosen by the caller: -1 automatic (Z-order from 8192 rows: what
+ * eyoc_model_forward is fastest on), 0 the caller's order (the level coordinates and tables the accessors below return
+ * are then in the caller's rows), 1 Z-order.  eyoc_maps_internal_order(0 / 1) overrides it process-wide. */
+int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n_rows, void* workspace_dev,
+                            size_t workspace_bytes, void* stream, int order, eyoc_maps** out);
 int eyoc_maps_free(eyoc_maps* maps);
 /* Row order the transposed convolutions tile their outputs in: the rows of `level` (a fine level, 0 <= level <
  * n_levels-1) sorted, stably, by the pattern of coarse blocks their transposed map reaches.  Purely a
@@ -90,7 +95,7 @@ int eyoc_maps_order_min_rows(int min_rows);
  * their neighbours stay cache-resident while its pattern runs are walked).  Process-wide; shift < 0 only queries.
  * Returns the previous value.  For tests / profiling. */
 int eyoc_maps_order_window_shift(int shift);
-/* Internal row order.  From 262144 rows on (mode -1, the default) the maps store level 0 in Z-order (Morton order of
+/* Internal row order.  From 8192 rows on (mode -1, the default) the maps store level 0 in Z-order (Morton order of
  * (batch, x, y, z)) instead of the caller's order, so that 64 consecutive rows are a compact blob of voxels - what
  * the tile-local input stage of the sparse convolution needs.  eyoc_maps_coords / _table then describe the INTERNAL
  * rows; eyoc_maps_row_order returns the device array perm[i] = caller's row of internal row i (NULL: the caller's order
@@ -240,7 +245,7 @@ int eyoc_model_layer_work(eyoc_ctx* ctx, const eyoc_model* model, const eyoc_map
                           const char** names, int64_t* pairs, double* flops, double* gather_bytes,
                           double* compulsory_bytes);
 /* Arithmetic of the sparse convolutions inside eyoc_model_forward: -1 automatic (default: split16 once the batch
- * fills the chip - >= 262144 level-0 rows - else fp32), 0 fp32 MFMA, 1 split16 (three fp16 MFMAs per product on
+ * has >= 8192 level-0 rows - else fp32), 0 fp32 MFMA, 1 split16 (three fp16 MFMAs per product on
  * hi/lo-split operands: 22-bit significands, fp32 accumulation; activations must stay below 65504).  Returns the
  * previous mode + 2, or a negative status.  eyoc_model_last_math: what the last forward used (0 / 1). */
 int eyoc_model_set_math(eyoc_model* model, int mode);
