@@ -277,7 +277,18 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_kernel(SpconvArgs a, con
           if (hn < 27 * NH) read_x(L[kn % 3][hhn], XB);
           multiply(h, XA, W[k % 3]);
         }
+#if defined(EYOC_ST_ABL) && (EYOC_ST_ABL & 256)
+        // explicit interleave: one LDS operand read per three MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);             // the prefetch loads first
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+#endif
+#if !(defined(EYOC_ST_ABL) && (EYOC_ST_ABL & 128))
         __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting later offsets' loads up here (register budget: 256)
+#endif
       }
     }
   }
