@@ -212,43 +212,70 @@ __global__ void knn1_unpack(const unsigned long long* __restrict__ best, int n, 
 // MFMA pre-filter for the plain index query (SquareL2, no distances asked for, enough rows to fill the chip).
 //
 // The contract above costs 3 VALU ops per (query, target, channel) - 3.3 ms for the bench's 64 x 5000 x 5000 x 32.  The
-// arg-min, however, is almost always decided by a far cheaper score: s(i, j) = |b_j|^2 - 2 <a_i, b_j> on the fp32
-// matrix pipe (v_mfma_f32_16x16x4_f32; the norm rides along as a 33rd "channel" against a constant 1).  With
+// arg-min, however, is almost always decided by a far cheaper score: s(i, j) = |b_j|^2 - 2 <a_i, b_j> with the inner
+// product on the fp16 matrix pipe at fp32 accuracy - three v_mfma_f32_16x16x32_f16 on hi / lo-split operands, ONE
+// instruction spanning all 32 channels (rows are scaled by a power of two first so that both halves of the split are
+// accurate whatever the magnitude of the features; the first version used nine v_mfma_f32_16x16x4_f32: 288 instead
+// of 48 matrix cycles per 16 x 16 tile, 1.25 ms instead of 0.45 for the bench's query).  With
 // |s(i, j) - (d(i, j) - |a_i|^2)| <= e for every j - d the contract's fp32 value - the contract's arg-min j* satisfies
 // s(j*) <= min_j s + 2 e.  So every wave tracks, per query, the smallest score with its index AND the second smallest
 // score: if the runner-up is farther than 2 e, the index is final (exact ties included: they would both be within
 // 2 e); otherwise the row is flagged and the exact kernel above recomputes it (waves without a flagged row exit at
 // once).  e = 128 u (|a_i| + max_j |b_j|)^2, u = 2^-24, covers the rounding of both evaluations with a wide margin
-// (K = 36 products and sums of magnitude <= (|a| + |b|)^2 on either side).  Rows with non-finite scores are flagged too.
+// (the split products err by <= 2^-20 |a||b|, the norm and the contract's own 96 roundings by <= 64 u (|a| + |b|)^2).  Rows with non-finite scores are flagged too.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 struct SegMfma { long long bm_off[MAX_SEG]; };
 constexpr int MF_ROWS = 64;                    // query rows per wave (4 MFMA row tiles)
 
-// B operand fragments: tile t (16 targets), slice q (4 channels; slice C/4 = the norm): 64 floats, lane l = element
-// (k = 4 q + l / 16, j = 16 t + l % 16): -2 b[j][k], or |b_j|^2 against the constant 1 of the queries (padding: +inf)
+// power of two that lifts a row's largest |element| into [128, 256): both halves of the fp16 split of the scaled row are
+// then as accurate as they can be (a row of all zeros, or with a non-finite element, keeps scale 1)
+__device__ inline float split_scale(float maxabs) {
+  if (!(maxabs > 0.0f) || !(maxabs < __builtin_inff())) return 1.0f;
+  int e;
+  (void)frexpf(maxabs, &e);                                          // maxabs = m 2^e, m in [0.5, 1)
+  return ldexpf(1.0f, 8 - e);
+}
+
+// B operand of v_mfma_f32_16x16x32_f16 per tile of 16 targets, 3 x 64 float4: [0] lane (g, j): the fp16 hi halves of
+// channels 8 g .. 8 g + 7 of target 16 t + j, scaled by the target's split_scale; [1] the lo halves; [2] (|b_j|^2,
+// 1 / scale_j, 0, 0) (padding targets: norm +inf, everything else 0)
 template <int C>
 __global__ void knn_pack_targets_mfma(const float* __restrict__ B, SegArgs seg, SegMfma sm, float* __restrict__ Bm,
                                       int* __restrict__ bmax_bits) {
-  constexpr int NQ = C / 4 + 1;
+  static_assert(C == 32, "one 16x16x32 MFMA spans the 32 channels");
   const int s = blockIdx.z;
   const int b0 = seg.b[s], nb = seg.b[s + 1] - b0;
   const int n16 = (nb + 15) / 16;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;        // (tile, lane)
   if (idx >= n16 * 64) return;
-  const int t = idx >> 6, l = idx & 63, j = 16 * t + (l & 15), kq = l >> 4;
-  float* dst = Bm + sm.bm_off[s] + (size_t)t * NQ * 64 + l;
+  const int t = idx >> 6, l = idx & 63, j = 16 * t + (l & 15), g = l >> 4;
+  float4* dst = reinterpret_cast<float4*>(Bm + sm.bm_off[s]) + (size_t)t * 3 * 64 + l;
   const bool ok = j < nb;
   const float* row = B + (size_t)(b0 + (ok ? j : 0)) * C;
-  float n2 = 0.f;
+  float n2 = 0.f, mx = 0.f;
+  float mine[8];
 #pragma unroll
   for (int q = 0; q < C / 4; ++q) {
     const float4 v = *reinterpret_cast<const float4*>(row + 4 * q);
     n2 += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-    const float mine = kq == 0 ? v.x : kq == 1 ? v.y : kq == 2 ? v.z : v.w;
-    dst[q * 64] = ok ? -2.0f * mine : 0.0f;
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    if ((q >> 1) == g) { mine[4 * (q & 1)] = v.x; mine[4 * (q & 1) + 1] = v.y; mine[4 * (q & 1) + 2] = v.z; mine[4 * (q & 1) + 3] = v.w; }
   }
-  dst[(C / 4) * 64] = kq == 0 ? (ok ? n2 : __builtin_inff()) : 0.0f;
-  if (ok && kq == 0 && n2 == n2) atomicMax(bmax_bits + s, __float_as_int(n2));   // non-negative floats order like ints
+  if (!(n2 == n2)) mx = __builtin_nanf("");                            // a NaN element: fmaxf would have dropped it
+  const float sc = split_scale(mx);
+  half8_t hi, lo;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float x = ok ? mine[i] * sc : 0.0f;
+    const _Float16 h = (_Float16)x;
+    hi[i] = h;
+    lo[i] = (_Float16)(x - (float)h);
+  }
+  dst[0] = __builtin_bit_cast(float4, hi);
+  dst[64] = __builtin_bit_cast(float4, lo);
+  dst[128] = make_float4(ok ? n2 : __builtin_inff(), ok ? 1.0f / sc : 0.0f, 0.f, 0.f);
+  if (ok && g == 0 && n2 == n2) atomicMax(bmax_bits + s, __float_as_int(n2));   // non-negative floats order like ints
 }
 
 __global__ void knn_row_norms(const float* __restrict__ A, int n, int C, float* __restrict__ out) {
@@ -265,7 +292,8 @@ __global__ __launch_bounds__(256) void knn_mfma_kernel(const float* __restrict__
                                                        const int* __restrict__ bmax_bits,
                                                        unsigned long long* __restrict__ best, int* __restrict__ flist,
                                                        int* __restrict__ fcnt) {
-  constexpr int NQ = C / 4 + 1, RT = MF_ROWS / 16;
+  static_assert(C == 32, "one 16x16x32 MFMA spans the 32 channels");
+  constexpr int RT = MF_ROWS / 16;
   const int s = blockIdx.z;
   const int a0 = seg.a[s], na = seg.a[s + 1] - a0;
   const int nb = seg.b[s + 1] - seg.b[s];
@@ -274,15 +302,35 @@ __global__ __launch_bounds__(256) void knn_mfma_kernel(const float* __restrict__
   const int q0 = (blockIdx.x * 4 + wave) * MF_ROWS;
   if (q0 >= na || nb <= 0) return;                                  // wave-uniform; no barrier in this kernel
   const int jl = lane & 15, g = lane >> 4;
-  // A fragments: row tile r, slice q: element (i = q0 + 16 r + jl, k = 4 q + g); the last slice is the constant 1
-  float af[RT][NQ];
+  // A fragments: row tile r: channels 8 g .. 8 g + 7 of query q0 + 16 r + jl, scaled per row, split into fp16 hi / lo;
+  // mrow[r][e] = -2 / scale of query 16 r + 4 g + e (the rows this lane holds in the MFMA result)
+  half8_t ah[RT], al[RT];
+  float mrow[RT][4];
 #pragma unroll
   for (int r = 0; r < RT; ++r) {
     const int i = q0 + 16 * r + jl;
-    const float* row = A + (size_t)(a0 + (i < na ? i : na - 1)) * C;
+    const float* row = A + (size_t)(a0 + (i < na ? i : na - 1)) * C + 8 * g;
+    const float4 v0 = *reinterpret_cast<const float4*>(row), v1 = *reinterpret_cast<const float4*>(row + 4);
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    float mx = 0.f, sum = 0.f;
 #pragma unroll
-    for (int q = 0; q < C / 4; ++q) af[r][q] = row[4 * q + g];
-    af[r][C / 4] = g == 0 ? 1.0f : 0.0f;
+    for (int k = 0; k < 8; ++k) { mx = fmaxf(mx, fabsf(x[k])); sum += x[k]; }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    if (!(sum == sum)) mx = __builtin_nanf("");                        // a NaN anywhere in the row
+    const float sc = split_scale(mx);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float y = x[k] * sc;
+      const _Float16 h = (_Float16)y;
+      ah[r][k] = h;
+      al[r][k] = (_Float16)(y - (float)h);
+    }
+    const float inv = -2.0f / sc;                                      // of row jl of the tile
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mrow[r][e] = __shfl(inv, 4 * g + e, 64);
   }
   // per lane: queries 16 r + 4 g + e (e = 0..3) against the targets j = jl (mod 16)
   float m1[RT][4], m2[RT][4];
@@ -291,11 +339,11 @@ __global__ __launch_bounds__(256) void knn_mfma_kernel(const float* __restrict__
   for (int r = 0; r < RT; ++r)
 #pragma unroll
     for (int e = 0; e < 4; ++e) { m1[r][e] = __builtin_inff(); m2[r][e] = __builtin_inff(); j1[r][e] = 0x7FFFFFFF; }
-  const float* bm = Bm + sm.bm_off[s] + lane;
+  const float4* bm = reinterpret_cast<const float4*>(Bm + sm.bm_off[s]) + lane;
   const int n16 = (nb + 15) / 16;
-  float bf[2][NQ];
+  float4 bf[2][3];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) bf[0][q] = bm[q * 64];
+  for (int q = 0; q < 3; ++q) bf[0][q] = bm[q * 64];
   for (int t = 0; t < n16; t += 2) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -304,17 +352,20 @@ __global__ __launch_bounds__(256) void knn_mfma_kernel(const float* __restrict__
       {   // unconditional (the last tile re-loads itself): a load inside a branch is waited for on the spot
         const int tn = tt + 1 < n16 ? tt + 1 : tt;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) bf[half ^ 1][q] = bm[((size_t)tn * NQ + q) * 64];
+        for (int q = 0; q < 3; ++q) bf[half ^ 1][q] = bm[((size_t)tn * 3 + q) * 64];
       }
       const int jt = 16 * tt + jl;
+      const half8_t bh = __builtin_bit_cast(half8_t, bf[half][0]), bl = __builtin_bit_cast(half8_t, bf[half][1]);
+      const float bn = bf[half][2].x, binv = bf[half][2].y;          // of target jt
 #pragma unroll
       for (int r = 0; r < RT; ++r) {
         f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][q], bf[half][q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], bh, acc, 0, 0, 0);   // D[query 4 g + e][target jl]
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[r], bh, acc, 0, 0, 0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = acc[e];
+          const float v = fmaf(acc[e] * binv, mrow[r][e], bn);         // |b|^2 - 2 <a, b>
           const bool better = v < m1[r][e];
           const float lose = better ? m1[r][e] : v;                  // NaN scores never enter
           m2[r][e] = lose < m2[r][e] ? lose : m2[r][e];
@@ -438,7 +489,7 @@ static int knn_run(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c,
   for (int s = 0; s < nseg; ++s) {
     waves += eyoc::cdiv(seg_a[s + 1] - seg_a[s], MF_ROWS);
     sm.bm_off[s] = bm_floats;
-    bm_floats += (long long)eyoc::cdiv(seg_b[s + 1] - seg_b[s], 16) * (c / 4 + 1) * 64;
+    bm_floats += (long long)eyoc::cdiv(seg_b[s + 1] - seg_b[s], 16) * 3 * 64 * 4;   // 3 x 64 float4 per tile of 16 targets
   }
   const bool prefilter = prefilter_env != 0 && !dot && !second_dev && !dist_dev && dist_type == 0 && c == 32 && max_nb > 0 &&
                          (waves >= 512 || prefilter_env == 2);
