@@ -746,7 +746,11 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
     // measured per layer of the 64-pair bench: the row-stationary kernel wins on the stride-1, transposed and 1x1 layers
     // with C_in >= 64 (-5 .. -15 %); the 32-channel layers and the strided convolutions (few, scattered pairs per
     // output row: 2.9x more zero MFMAs buy nothing there) stay on the wave-private kernel
-    if (a.math == 1 && a.local && use_rs != 0 && a.K == 27 && !a.l2norm) {   // stride-1 table with local rulebooks: staged kernel
+    // stride-1 table with local rulebooks: staged kernel (its workgroups cover 64 - or 32 - output channels each and
+    // 1, 2, 4 or 8 of them share a tile; other widths stay on the gathering kernels)
+    const int st_ctg = a.cout >= 64 ? 64 : 32;
+    const bool st_ok = a.cout % st_ctg == 0 && a.cout / st_ctg <= 8 && 8 % (a.cout / st_ctg) == 0 && a.cin % 32 == 0;
+    if (a.math == 1 && a.local && use_rs != 0 && a.K == 27 && !a.l2norm && st_ok) {
       SpconvArgs b = a;
       b.perm = nullptr;
       return launch_spconv_st(b, a.local, st);

@@ -342,7 +342,8 @@ int launch_spconv_st(const SpconvArgs& a, const unsigned char* local_dev, hipStr
   const int ctg = a.cout >= 64 ? 64 : 32;                            // output channels per workgroup
   const bool wide = spconv_cc(a.cin, a.cout) == 64;
   const int n_cg = a.cout / ctg;
-  EYOC_REQUIRE(n_cg >= 1 && n_cg <= 8 && 8 % n_cg == 0, EYOC_ERR_INVALID, "spconv_st: %d output channels", a.cout);
+  EYOC_REQUIRE(a.cout % ctg == 0 && n_cg >= 1 && n_cg <= 8 && 8 % n_cg == 0 && a.cin % 32 == 0, EYOC_ERR_INVALID,
+               "spconv_st: %d -> %d channels", a.cin, a.cout);
   const int n_tiles = cdiv(a.n_out, TILE);
   const dim3 grid((unsigned)(cdiv(n_tiles, 8 / n_cg) * 8)), block(NW * 64);
   const size_t lds = (size_t)X_BYTES;

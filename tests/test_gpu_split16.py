@@ -334,3 +334,14 @@ def test_staged_kernel_vs_fp64(morton_maps, cin, cout, level):
     print(f"staged {cin}->{cout} level {level}: n {n} err {e:.2e} / {e32:.2e}  distinct rows per tile mean {n_u.mean():.0f} max {n_u.max()}"
           f"  re-use {pairs / n_u.sum():.2f}x")
     assert e < 2e-6 and e32 < 2e-6 and n_u.max() <= 1278 and n_u.min() >= 1
+
+
+def test_staged_kernel_refuses_channel_widths_it_cannot_tile(morton_maps):
+    """96 output channels are neither one 64-channel workgroup nor a power-of-two number of them: the staged entry point
+    says so instead of computing two thirds of the layer (launch_spconv keeps such layers on the gathering kernels)."""
+    nbr = morton_maps["s1"][2]
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(nbr.shape[1], 64)).astype(np.float32)
+    W = (rng.normal(size=(27, 64, 96)) / 10).astype(np.float32)
+    with pytest.raises(Exception):
+        run_layer_staged(nbr, x, W)
