@@ -345,3 +345,22 @@ def test_staged_kernel_refuses_channel_widths_it_cannot_tile(morton_maps):
     W = (rng.normal(size=(27, 64, 96)) / 10).astype(np.float32)
     with pytest.raises(Exception):
         run_layer_staged(nbr, x, W)
+
+
+def test_first_convolution_as_mfma_gemm_with_a_3x3x3_window():
+    """conv1_mfma_kernel (C_in = 1, 32 output channels, split16 consumers) with the 27-position window; the bench's 5^3
+    window is covered by every split16 forward above."""
+    from eyoc_amd import synthetic as syn
+    from oracle import resunet as orr
+    import eyoc_amd
+    p = syn.make_pair(6, beams=32, azimuths=1000, band=None)
+    coords = syn.batch_coords([p["coords0"]])
+    sd = syn.make_weights(seed=7, in_channels=1, conv1_kernel_size=3)
+    m = eyoc_amd.load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, conv1_kernel_size=3, normalize_feature=True)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m = m.cuda().eval()
+    m.spconv_math = "split16"
+    feats = np.random.default_rng(2).uniform(0.5, 2.0, size=(len(coords), 1)).astype(np.float32)
+    got = _forward(m, coords, feats)
+    want = orr.resunet_forward(sd, coords, feats, conv1_kernel_size=3).numpy()
+    assert m.last_spconv_math == "split16" and rel_err(got, want) < REL
