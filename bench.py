@@ -405,7 +405,7 @@ def worker(args):
     achieved_tf = flops / (conv_ms * 1e-3) / 1e12
     achieved_gbs = gather / (conv_ms * 1e-3) / 1e9
     math_mode = model.last_spconv_math
-    kernel = ("spconv_st_kernel<2, 64, 2> (12 of the launches; + spconv_st_kernel<2, 32, 1>, spconv_rs_kernel, spconv_wave_kernel)"
+    kernel = ("spconv_st_kernel<2, 64, 2> (12 of the launches; + spconv_st_kernel<2, 32, 1>, spconv_up_kernel, spconv_wave_kernel, spconv_rs_kernel)"
               if math_mode == "split16" else "spconv_wave_kernel<...>") + " - the 22 sparse-conv launches of one forward, summed"
     if math_mode == "split16":
         # split16: every algorithmic fp32 multiply-add is three fp16 MFMA multiply-adds (2.5 PFLOP/s dense peak), i.e. an

@@ -159,8 +159,8 @@ int eyoc_spconv(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, const f
  * mode; process-wide, for tests and profiling). */
 int eyoc_spconv_select_split16_kernel(int mode);
 /* Staged kernel for the transposed 3^3 / stride-2 convolutions on Z-ordered maps (spconv_up.hip: tile rows sorted by
- * parity class, only occupied (16-row group, offset) blocks multiplied): 0 off (default; the row-stationary kernel in
- * windowed pattern order is as fast and needs no extra rulebooks), 1 on; other values only query.  Returns the previous
+ * parity class, only occupied (16-row group, offset) blocks multiplied): 1 on (default: as fast as the row-stationary
+ * kernel in windowed pattern order, 18 GB less HBM traffic per 128-cloud forward), 0 off; other values only query.  Returns the previous
  * state.  Process-wide, read when maps are built; for tests and profiling. */
 int eyoc_spconv_select_up_kernel(int on);
 /* Stride-1 (3^3) split16 layers with a tile-local input stage (spconv_st.hip): per 256-row tile the distinct input rows are

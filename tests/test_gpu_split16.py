@@ -227,7 +227,7 @@ def test_forward_on_z_ordered_rows_with_the_staged_kernel(request):
             cos = (got * want).sum(1)
             print(f"z-ordered forward, {mode}, staged transposed convolutions {up}: err {e:.2e}")
             assert e < REL and cos.min() > 1 - 1e-6, (mode, e, float(cos.min()))
-        lib.eyoc_spconv_select_up_kernel(0)
+        lib.eyoc_spconv_select_up_kernel(prev_up)
         # the permutation is invisible: permuting the caller's rows permutes the output
         rng = np.random.default_rng(3)
         perm = rng.permutation(len(coords))
