@@ -54,8 +54,17 @@ class CoordinateManager:
     def rows(self, level: int) -> int:
         return int(_lib.load().eyoc_maps_rows(self.maps(), level))
 
-    def level_coordinates(self, level: int) -> torch.Tensor:
+    def _check_order(self, internal):
+        """Level coordinates, tables and tiling orders are in the maps' INTERNAL rows.  When those are Z-ordered (the
+        maps were first built by a network forward on >= 8192 rows) they do not line up with the caller's feature rows:
+        refuse unless the caller says it knows (``internal=True``; ``row_order()`` is the permutation)."""
+        if not internal and _lib.load().eyoc_maps_row_order(self.maps()):
+            raise ValueError("these maps keep their rows in Z-order (built by model(x)); pass internal=True and use "
+                             "row_order(), or read the accessors BEFORE the first forward (they build the maps in the caller's order)")
+
+    def level_coordinates(self, level: int, internal: bool = False) -> torch.Tensor:
         """Copy of the level's coordinates ``int32 [rows,4]`` (diagnostics / tests)."""
+        self._check_order(internal)
         n = self.rows(level)
         out = torch.empty((n, 4), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
@@ -63,8 +72,9 @@ class CoordinateManager:
                        "eyoc_maps_copy_coords")
         return out
 
-    def table(self, kind: int, level: int) -> torch.Tensor:
-        """Copy of a rulebook ``int32 [27, n_out]`` (diagnostics / tests)."""
+    def table(self, kind: int, level: int, internal: bool = False) -> torch.Tensor:
+        """Copy of a rulebook ``int32 [27, n_out]`` (diagnostics / tests, the autograd layer functions)."""
+        self._check_order(internal)
         n_out = {0: self.rows(level), 1: self.rows(level + 1), 2: self.rows(level)}[kind]
         out = torch.empty((27, n_out), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
@@ -84,8 +94,9 @@ class CoordinateManager:
             _lib.check(lib.eyoc_maps_copy_row_order(self.maps(), _lib.ptr(out), _lib.stream_ptr()), "eyoc_maps_copy_row_order")
         return out
 
-    def up_order(self, level: int) -> torch.Tensor:
+    def up_order(self, level: int, internal: bool = False) -> torch.Tensor:
         """Copy of the row order ``int32 [rows(level)]`` the transposed convolutions tile their outputs in."""
+        self._check_order(internal)
         out = torch.empty((self.rows(level),), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().eyoc_maps_copy_up_order(self.maps(), level, _lib.ptr(out), _lib.stream_ptr()),

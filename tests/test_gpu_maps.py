@@ -115,19 +115,19 @@ def test_maps_in_z_order_equal_the_oracle_maps_of_the_z_ordered_cloud(zorder_row
     cm = eyoc_amd.CoordinateManager(torch.from_numpy(coords).cuda())
     perm = cm.row_order().cpu().numpy()
     np.testing.assert_array_equal(perm, morton_order(coords))
-    np.testing.assert_array_equal(cm.level_coordinates(0).cpu().numpy(), coords[perm])
+    np.testing.assert_array_equal(cm.level_coordinates(0, internal=True).cpu().numpy(), coords[perm])
     from oracle import coords as oc
     from eyoc_amd import _lib
     maps = oc.build_maps(coords[perm], conv1_kernel_size=5)
     info = cm.info(conv1_kernel_size=5)
     assert info["rows"] == oc.map_stats(maps)["rows"] and info["pairs_conv1"] == oc.map_stats(maps)["pairs_k5"]
     for l in range(4):
-        np.testing.assert_array_equal(cm.level_coordinates(l).cpu().numpy(), maps["cm"][l].coords)
-        np.testing.assert_array_equal(cm.table(_lib.MAP_S1, l).cpu().numpy(), maps["s1"][l])
+        np.testing.assert_array_equal(cm.level_coordinates(l, internal=True).cpu().numpy(), maps["cm"][l].coords)
+        np.testing.assert_array_equal(cm.table(_lib.MAP_S1, l, internal=True).cpu().numpy(), maps["s1"][l])
         if l < 3:
-            np.testing.assert_array_equal(cm.table(_lib.MAP_DOWN, l).cpu().numpy(), maps["down"][l])
-            np.testing.assert_array_equal(cm.table(_lib.MAP_UP, l).cpu().numpy(), maps["up"][l])
-            check_up_order(cm.up_order(l).cpu().numpy(), maps["up"][l], window_shift=12)
+            np.testing.assert_array_equal(cm.table(_lib.MAP_DOWN, l, internal=True).cpu().numpy(), maps["down"][l])
+            np.testing.assert_array_equal(cm.table(_lib.MAP_UP, l, internal=True).cpu().numpy(), maps["up"][l])
+            check_up_order(cm.up_order(l, internal=True).cpu().numpy(), maps["up"][l], window_shift=12)
 
 
 def test_maps_keep_the_callers_order_for_small_clouds():
@@ -162,3 +162,27 @@ def test_z_ordered_maps_reject_duplicates_and_out_of_range(zorder_rows):
     with pytest.raises(eyoc_amd.EyocError, match="range"):
         eyoc_amd.CoordinateManager(torch.from_numpy(far).cuda()).maps()
     eyoc_amd.CoordinateManager(torch.from_numpy(coords).cuda()).maps()    # and the clean cloud builds
+
+
+def test_accessors_refuse_z_ordered_maps_unless_told():
+    """A forward on >= 8192 rows builds Z-ordered maps; their tables are in internal rows and the accessors say so
+    instead of handing them to code that indexes features in the caller's order."""
+    import eyoc_amd
+    from eyoc_amd import synthetic as syn
+    from test_gpu_round2 import _model
+    p = syn.make_pair(1)
+    coords = syn.batch_coords([p["coords0"]])
+    model, _sd = _model()
+    x = eyoc_amd.SparseTensor(torch.from_numpy(p["feats0"]).cuda(), coordinates=torch.from_numpy(coords).cuda())
+    model(x)
+    cm = x.coordinate_manager
+    assert cm.row_order() is not None
+    with pytest.raises(ValueError, match="Z-order"):
+        cm.table(0, 0)
+    assert cm.table(0, 0, internal=True).shape == (27, len(coords))
+    # the other way round: accessors first -> the caller's order, and the forward then runs on those maps
+    x2 = eyoc_amd.SparseTensor(torch.from_numpy(p["feats0"]).cuda(), coordinates=torch.from_numpy(coords).cuda())
+    t = x2.coordinate_manager.table(0, 0)
+    assert x2.coordinate_manager.row_order() is None and t.shape == (27, len(coords))
+    f1, f2 = model(x).F, model(x2).F
+    assert float((f1 - f2).abs().max()) < 1e-5
