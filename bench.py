@@ -387,6 +387,7 @@ def worker(args):
     if total_mode:
         out["config"]["total_pairs"] = args.total_pairs
         out["config"]["batches_per_rank"] = [len(ids) for ids, _ in batches]
+        out["pose_tx_first8"] = allrec[:8, 3].tolist()        # x translation of the first records (global pair order)
     # ---- algorithmic work of one forward on the first batch's geometry
     x = eyoc_amd.SparseTensor(b0.feats, coordinates=b0.coords)
     work = model.layer_work(x)

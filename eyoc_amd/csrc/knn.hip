@@ -45,15 +45,19 @@ __global__ void knn_transpose_targets(const float* __restrict__ B, SegArgs seg, 
 // Two targets share one v_pk_* instruction; each (query, target) still sees the scalar contract.
 // DOT: the value minimised is -<a, b> (one packed FMA per channel and target pair) instead of the squared distance:
 // the arg-max of the inner product of util/transform_estimation.py:131-133 without its [N0, N1] matrix.
+// MODE 2 (dist_type 2, "GemmL2"): the quantity minimised is the reference's sqrt(2 - 2 S + 1e-6) of
+// scripts/SC2_PCR/SC2_PCR.py:296-298 with S the same FMA chain as DOT, every later step rounded separately in fp32; a NaN
+// (S > 1 + 5e-7: un-normalised descriptors) is smaller than every number and the first one wins, like torch.argmin.
 // TOP2: also track the second smallest distance (Lowe's ratio test of the label generator,
 // lib/trainer.py:1060-1072); the target range is then NOT split over blocks (a 64-bit atomicMin cannot merge a
 // runner-up) and the four waves of the block merge their partial results through LDS.
-template <int C, bool TOP2, bool DOT>
+template <int C, bool TOP2, int MODE>
 __global__ __launch_bounds__(256) void knn1_kernel(const float* __restrict__ A, const float* __restrict__ Bt,
                                                    SegArgs seg, int split_len, int dist_type,
                                                    unsigned long long* __restrict__ best, float* __restrict__ second,
                                                    const int* __restrict__ only = nullptr, const int* __restrict__ only_cnt = nullptr) {
 #pragma clang fp contract(off)
+  constexpr bool DOT = MODE != 0;
   const int s = blockIdx.z;
   const int a0 = seg.a[s], na = seg.a[s + 1] - a0;
   const int nb = seg.b[s + 1] - seg.b[s], ld = seg.ld[s];
@@ -147,6 +151,11 @@ __global__ __launch_bounds__(256) void knn1_kernel(const float* __restrict__ A, 
       // compare and keeps every scalar-loaded operand alive until then (SGPR spills)
       float v = (e & 1) ? acc[e / 2].y : acc[e / 2].x;
       v = dist_type == 1 ? sqrtf(v + 1e-7f) : v;
+      if (MODE == 2) {          // acc = -S exactly (the negated chain rounds symmetrically)
+        const float w = (2.0f - 2.0f * (-v)) + 1e-6f;
+        const float d = sqrtf(w);
+        v = d != d ? -1.0f : d;                                        // NaN first: below every distance
+      }
       const bool valid = t + e < t_end;
       const bool better = valid & (v < best_d);
       if (TOP2) {   // the displaced best, or a value between the two, becomes the runner-up (NaNs never enter)
@@ -205,7 +214,10 @@ __global__ void knn1_unpack(const unsigned long long* __restrict__ best, int n, 
   if (idx) idx[i] = (long long)(unsigned)(p & 0xFFFFFFFFull);
   unsigned int bits = (unsigned)(p >> 32);
   if (dot) bits = (bits & 0x80000000u) ? (bits & 0x7FFFFFFFu) : ~bits;   // undo the key, then negate: the inner product
-  if (dist) dist[i] = dot ? -__uint_as_float(bits) : __uint_as_float(bits);
+  if (dist) {
+    const float v = __uint_as_float(bits);
+    dist[i] = dot == 1 ? -v : dot == 2 ? (v < 0.0f ? __builtin_nanf("") : v) : v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -242,7 +254,7 @@ __device__ inline float split_scale(float maxabs) {
 // 1 / scale_j, 0, 0) (padding targets: norm +inf, everything else 0)
 template <int C>
 __global__ void knn_pack_targets_mfma(const float* __restrict__ B, SegArgs seg, SegMfma sm, float* __restrict__ Bm,
-                                      int* __restrict__ bmax_bits) {
+                                      int* __restrict__ bmax_bits, int zero_norm) {
   static_assert(C == 32, "one 16x16x32 MFMA spans the 32 channels");
   const int s = blockIdx.z;
   const int b0 = seg.b[s], nb = seg.b[s + 1] - b0;
@@ -274,7 +286,7 @@ __global__ void knn_pack_targets_mfma(const float* __restrict__ B, SegArgs seg, 
   }
   dst[0] = __builtin_bit_cast(float4, hi);
   dst[64] = __builtin_bit_cast(float4, lo);
-  dst[128] = make_float4(ok ? n2 : __builtin_inff(), ok ? 1.0f / sc : 0.0f, 0.f, 0.f);
+  dst[128] = make_float4(ok ? (zero_norm ? 0.0f : n2) : __builtin_inff(), ok ? 1.0f / sc : 0.0f, 0.f, 0.f);   // zero_norm: score -2 <a, b>
   if (ok && g == 0 && n2 == n2) atomicMax(bmax_bits + s, __float_as_int(n2));   // non-negative floats order like ints
 }
 
@@ -286,7 +298,7 @@ __global__ void knn_row_norms(const float* __restrict__ A, int n, int C, float* 
   out[i] = n2;
 }
 
-template <int C>
+template <int C, int MODE>
 __global__ __launch_bounds__(256) void knn_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Bm, SegArgs seg,
                                                        SegMfma sm, const float* __restrict__ anorm,
                                                        const int* __restrict__ bmax_bits,
@@ -400,7 +412,15 @@ __global__ __launch_bounds__(256) void knn_mfma_kernel(const float* __restrict__
         const float an = sqrtf(anorm[a0 + i]);
         const float err = 128.0f * 5.9604645e-8f * (an + bmax) * (an + bmax);
         // decided: a finite best whose runner-up is out of reach.  (a2 - a1 <= 2 err, NaN / inf anywhere: not decided)
-        const bool decided = (a1 < __builtin_inff()) & (a1 > -__builtin_inff()) & (a2 - a1 > 2.0f * err) & (k1 != 0x7FFFFFFF);
+        bool decided = (a1 < __builtin_inff()) & (a1 > -__builtin_inff()) & (a2 - a1 > 2.0f * err) & (k1 != 0x7FFFFFFF);
+        if (MODE == 2) {
+          // score = -2 S.  sqrt(2 - 2 S + 1e-6) in fp32 can round two different S to one distance (then the LOWER
+          // index wins, not the larger S): S1 > S2 + 3 * 2^-22 (1 + |S|) guarantees d1 < d2 strictly, so the runner-up
+          // must also be farther than cm = 2^-19 (1 + |a| |b|max) in score units; and no S may exceed 1 (a NaN
+          // distance beats everything): every S_j < 1 is implied by a1 > -2 + err
+          const float cm = 1.9073486e-6f * (1.0f + an * bmax);
+          decided = decided & (a2 - a1 > 2.0f * err + cm) & (a1 > -2.0f + err);
+        }
         best[a0 + i] = decided ? (unsigned long long)(unsigned)k1 : ~0ull;
         if (!decided) flist[a0 + atomicAdd(fcnt + s, 1)] = i;            // the segment's undecided rows, densely (any order)
       }
@@ -438,9 +458,10 @@ void launch_knn(const float* A, const float* Bt, const SegArgs& seg, int nseg, i
   int split_len = eyoc::cdiv(eyoc::cdiv(max_nb, nsplit), SPLIT_ALIGN) * SPLIT_ALIGN;
   nsplit = eyoc::cdiv(max_nb, split_len);
   dim3 grid(qtiles, nsplit, nseg);
-  if (second) hipLaunchKernelGGL((knn1_kernel<C, true, false>), grid, dim3(256), 0, st, A, Bt, seg, split_len, dist_type, best, second, (const int*)nullptr, (const int*)nullptr);
-  else if (dot) hipLaunchKernelGGL((knn1_kernel<C, false, true>), grid, dim3(256), 0, st, A, Bt, seg, split_len, 0, best, second, (const int*)nullptr, (const int*)nullptr);
-  else hipLaunchKernelGGL((knn1_kernel<C, false, false>), grid, dim3(256), 0, st, A, Bt, seg, split_len, dist_type, best, second, only, only_cnt);
+  if (second) hipLaunchKernelGGL((knn1_kernel<C, true, 0>), grid, dim3(256), 0, st, A, Bt, seg, split_len, dist_type, best, second, (const int*)nullptr, (const int*)nullptr);
+  else if (dot) hipLaunchKernelGGL((knn1_kernel<C, false, 1>), grid, dim3(256), 0, st, A, Bt, seg, split_len, 0, best, second, (const int*)nullptr, (const int*)nullptr);
+  else if (dist_type == 2) hipLaunchKernelGGL((knn1_kernel<C, false, 2>), grid, dim3(256), 0, st, A, Bt, seg, split_len, 0, best, second, only, only_cnt);
+  else hipLaunchKernelGGL((knn1_kernel<C, false, 0>), grid, dim3(256), 0, st, A, Bt, seg, split_len, dist_type, best, second, only, only_cnt);
 }
 
 }  // namespace
@@ -457,7 +478,8 @@ static int knn_run(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c,
                    void* stream, bool dot = false) {
   EYOC_REQUIRE(ctx && A_dev && B_dev && seg_a && seg_b, EYOC_ERR_INVALID, "eyoc_knn1: NULL argument");
   EYOC_REQUIRE(nseg >= 1 && nseg <= MAX_SEG, EYOC_ERR_INVALID, "eyoc_knn1: nseg %d not in [1,%d]", nseg, MAX_SEG);
-  EYOC_REQUIRE(dist_type == 0 || dist_type == 1, EYOC_ERR_INVALID, "eyoc_knn1: dist_type %d", dist_type);
+  EYOC_REQUIRE(dist_type >= 0 && dist_type <= 2, EYOC_ERR_INVALID, "eyoc_knn1: dist_type %d", dist_type);
+  EYOC_REQUIRE(!(dist_type == 2 && (dot || second_dev)), EYOC_ERR_INVALID, "eyoc_knn1: dist_type 2 is a 1-NN mode");
   EYOC_REQUIRE(c == 4 || c == 16 || c == 32 || c == 64 || c == 128, EYOC_ERR_INVALID,
                "eyoc_knn1: feature dimension %d not supported (4/16/32/64/128)", c);
   hipStream_t st = (hipStream_t)stream;
@@ -491,7 +513,7 @@ static int knn_run(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c,
     sm.bm_off[s] = bm_floats;
     bm_floats += (long long)eyoc::cdiv(seg_b[s + 1] - seg_b[s], 16) * 3 * 64 * 4;   // 3 x 64 float4 per tile of 16 targets
   }
-  const bool prefilter = prefilter_env != 0 && !dot && !second_dev && !dist_dev && dist_type == 0 && c == 32 && max_nb > 0 &&
+  const bool prefilter = prefilter_env != 0 && !dot && !second_dev && !dist_dev && dist_type != 1 && c == 32 && max_nb > 0 &&
                          (waves >= 512 || prefilter_env == 2);
   const size_t off_bt = eyoc::align_up((size_t)n_total * sizeof(unsigned long long));
   const size_t off_bm = eyoc::align_up(off_bt + (size_t)bt_floats * sizeof(float) + 64);
@@ -512,10 +534,14 @@ static int knn_run(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c,
     int* fcnt = bmax + MAX_SEG;
     EYOC_CHECK_HIP(hipMemsetAsync(bmax, 0, 2 * MAX_SEG * sizeof(int), st));
     hipLaunchKernelGGL(knn_pack_targets_mfma<32>, dim3(eyoc::cdiv((long long)eyoc::cdiv(max_nb, 16) * 64, 256), 1, nseg), dim3(256), 0, st,
-                       B_dev, seg, sm, Bm, bmax);
+                       B_dev, seg, sm, Bm, bmax, dist_type == 2 ? 1 : 0);
     hipLaunchKernelGGL(knn_row_norms, dim3(eyoc::cdiv(n_total, 256)), dim3(256), 0, st, A_dev, n_total, c, anorm);
-    hipLaunchKernelGGL(knn_mfma_kernel<32>, dim3(eyoc::cdiv(max_na, 4 * MF_ROWS), 1, nseg), dim3(256), 0, st, A_dev, Bm, seg, sm,
-                       anorm, bmax, best, flags, fcnt);
+    if (dist_type == 2)
+      hipLaunchKernelGGL((knn_mfma_kernel<32, 2>), dim3(eyoc::cdiv(max_na, 4 * MF_ROWS), 1, nseg), dim3(256), 0, st, A_dev, Bm, seg,
+                         sm, anorm, bmax, best, flags, fcnt);
+    else
+      hipLaunchKernelGGL((knn_mfma_kernel<32, 0>), dim3(eyoc::cdiv(max_na, 4 * MF_ROWS), 1, nseg), dim3(256), 0, st, A_dev, Bm, seg,
+                         sm, anorm, bmax, best, flags, fcnt);
     only = flags;
     only_cnt = fcnt;
   }
@@ -531,7 +557,7 @@ static int knn_run(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c,
     }
   }
   hipLaunchKernelGGL(knn1_unpack, dim3(eyoc::cdiv(n_total, 256)), dim3(256), 0, st, best, n_total,
-                     (long long*)idx_dev, dist_dev, dot ? 1 : 0);
+                     (long long*)idx_dev, dist_dev, dot ? 1 : dist_type == 2 ? 2 : 0);
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
 }

@@ -17,7 +17,8 @@ import torch
 
 from . import _lib
 
-_DIST = {"SquareL2": 0, "L2": 1}
+# "GemmL2" is not a reference name: it selects Matcher.match_pair's sqrt(2 - 2 <a,b> + 1e-6) (SC2_PCR.py:296-298)
+_DIST = {"SquareL2": 0, "L2": 1, "GemmL2": 2}
 
 
 def _cuda_f32(t, device=None) -> torch.Tensor:
@@ -112,6 +113,8 @@ def find_nn_gpu(F0, F1, nn_max_n=-1, return_distance=False, dist_type='SquareL2'
     F1 = _cuda_f32(F1, F0.device)
     if F0.shape[1] != F1.shape[1]:
         raise ValueError("feature dimensions differ")
+    if dist_type not in ("SquareL2", "L2"):          # lib/metrics.py:29
+        raise NotImplementedError('Not implemented')
     idx, dist = knn1_segmented(F0, F1, [0, F0.shape[0]], [0, F1.shape[0]], dist_type)
     inds = idx.cpu()
     if return_distance:
@@ -121,7 +124,7 @@ def find_nn_gpu(F0, F1, nn_max_n=-1, return_distance=False, dist_type='SquareL2'
 
 def pdist(A, B, dist_type='L2'):
     """lib/metrics.py:22-29 - dense ``[n,m]`` distance matrix on the device of ``A``."""
-    if dist_type not in _DIST:
+    if dist_type not in ("SquareL2", "L2"):
         raise NotImplementedError('Not implemented')
     A = _cuda_f32(A)
     B = _cuda_f32(B, A.device)

@@ -222,7 +222,7 @@ class RegistrationPipeline:
         src_k = batch.xyz0.reshape(-1, 3).index_select(0, idx[0])
         tgt_k = batch.xyz1.reshape(-1, 3).index_select(0, idx[1])
         seg = np.arange(P + 1) * nn_pts
-        nn = knn1_segmented(src_d, tgt_d, seg, seg, "SquareL2", return_distance=False)
+        nn = knn1_segmented(src_d, tgt_d, seg, seg, "GemmL2", return_distance=False)      # match_pair's own formula
         self._mark(2)
         base = torch.arange(P, device=F.device).repeat_interleave(nn_pts) * nn_pts     # local -> packed target row
         keep = min(nn_pts, int(m.max_points))                                            # SC2_PCR.py:318-319 truncation

@@ -127,9 +127,10 @@ class Matcher:
 
     def match_pair(self, src_keypts, tgt_keypts, src_features, tgt_features, rng=None):
         """:280-305.  ``rng`` replaces the reference's global ``np.random`` for the resampling to
-        ``num_node`` (with replacement).  The nearest neighbour uses the difference-form squared L2
-        kernel: for unit-norm descriptors it orders candidates exactly like the reference's
-        ``sqrt(2 - 2 <s,t> + 1e-6)``."""
+        ``num_node`` (with replacement).  The nearest neighbour is the reference's own quantity,
+        ``argmin_j sqrt(2 - 2 <s_i,t_j> + 1e-6)`` (:296-298, ``eyoc_knn1`` dist_type 2): for descriptors that are not
+        unit-norm that is an arg-max of the inner product, not an L2 neighbour, and a NaN (inner product above 1)
+        wins the row at its first occurrence - both reproduced."""
         rng = np.random if rng is None else rng
         N_src, N_tgt = src_features.shape[1], tgt_features.shape[1]
         if self.num_node == 'all':
@@ -142,7 +143,7 @@ class Matcher:
         src_keypts = src_keypts[:, src_sel_ind, :]
         tgt_keypts = tgt_keypts[:, tgt_sel_ind, :]
         idx = knn1_segmented(src_desc[0], tgt_desc[0], [0, src_desc.shape[1]], [0, tgt_desc.shape[1]],
-                             "SquareL2", return_distance=False)
+                             "GemmL2", return_distance=False)
         return src_keypts, tgt_keypts[:, idx.to(tgt_keypts.device)]
 
     def SC2_PCR(self, src_keypts, tgt_keypts):

@@ -258,7 +258,7 @@ int eyoc_model_layer_ms(eyoc_model* model, float* ms /*[num_layers]*/);
  * can enqueue step k + 1 before it reads step k's durations, and the GPU never waits for the host between steps. */
 int eyoc_model_timing_slot(eyoc_model* model, int slot);
 
-/* MFMA pre-filter of eyoc_knn1's plain index query (SquareL2, idx only, C = 32): an fp32-MFMA score decides every row
+/* MFMA pre-filter of eyoc_knn1's plain index query (dist_type 0 or 2, idx only, C = 32): an fp32-MFMA score decides every row
  * whose runner-up is out of rounding reach, the exact kernel recomputes the rest - the indices are identical either way.
  * mode 0: never, 1 (default): when the query fills the chip (>= 512 waves of 64 rows), 2: always; < 0 only queries.
  * Returns the previous mode.  Process-wide; for tests and profiling. */
@@ -269,7 +269,10 @@ int eyoc_knn_prefilter(int mode);
  *             and the nearest-neighbour step of Matcher.match_pair (scripts/SC2_PCR/SC2_PCR.py:296-298).
  *   For every row of A the index of the nearest row of B.  dist_type 0: squared L2 (difference
  *   form, fp32, channels left to right, no FMA - bit-exact with oracle/matching.py); 1: L2 =
- *   sqrt(d2 + 1e-7); ties go to the lowest index.  Segmented form: nseg independent problems,
+ *   sqrt(d2 + 1e-7); 2: the GEMM form of Matcher.match_pair, sqrt(2 - 2 S + 1e-6) with S = <A_i, B_j> accumulated by
+ *   fp32 FMAs over the channels in order and every later step rounded in fp32 - NOT an L2 distance unless the rows
+ *   have unit norm; a NaN distance (S > 1 + 5e-7) is below every number and the first NaN wins, as in torch.argmin.
+ *   Ties go to the lowest index.  Segmented form: nseg independent problems,
  *   rows [seg_a[s], seg_a[s+1]) of A against rows [seg_b[s], seg_b[s+1]) of B; indices are local to
  *   the B segment.  seg arrays are HOST arrays; nseg <= 128.  c in {4, 16, 32, 64, 128}.
  * --------------------------------------------------------------------------------------------- */

@@ -8,7 +8,8 @@ Restated functions:
   * ``find_nn_gpu``     lib/eval.py:18-48
   * ``find_corr``       scripts/test_kitti.py:28-42 (twin at lib/trainer.py:405-419)
   * ``random_sample``   scripts/test_kitti.py:54-73
-  * ``match_pair``      scripts/SC2_PCR/SC2_PCR.py:280-305 (GEMM-form nearest neighbour)
+  * ``match_pair``      scripts/SC2_PCR/SC2_PCR.py:280-305 (GEMM-form nearest neighbour; pinned by golden g6 from the
+                        reference's own ``Matcher.match_pair``)
 
 Arithmetic contract shared with the HIP kernel (``eyoc_knn1``), chosen so indices are bit-exact
 between the two: per (i, j) the squared distance is accumulated in fp32, channels left to right,
@@ -86,11 +87,48 @@ def random_sample(pcd, feats, N, rng):
     return pcd[choice], feats[choice]
 
 
-def match_pair_indices(src_desc, tgt_desc):
-    """scripts/SC2_PCR/SC2_PCR.py:296-298: ``argmin_j sqrt(2 - 2 <s_i, t_j> + 1e-6)``.
+def fmaf(a, b, c):
+    """Correctly rounded fp32 ``a * b + c`` on arrays (what ``v_fma_f32`` / C ``fmaf`` return), without an fma in
+    numpy: the product of two fp32 numbers is exact in fp64; the fp64 sum with ``c`` is made round-to-odd (TwoSum gives
+    the rounding error's sign; an inexact even result moves one ulp towards it), and rounding an odd-rounded fp64 value
+    to fp32 equals rounding the exact value (29 guard bits)."""
+    p = np.asarray(a, np.float32).astype(np.float64) * np.asarray(b, np.float32).astype(np.float64)
+    c = np.broadcast_to(np.asarray(c, np.float32).astype(np.float64), p.shape)
+    with np.errstate(invalid="ignore", over="ignore"):
+        s = p + c
+        bb = s - p
+        err = (p - (s - bb)) + (c - bb)
+        fix = (err != 0) & np.isfinite(s) & ((s.view(np.int64) & 1) == 0)
+        s = np.where(fix, np.nextafter(s, np.where(err > 0, np.inf, -np.inf)), s)
+        return s.astype(np.float32)
 
-    Evaluated with one fp32 matmul like the reference; used by tests to build the correspondences
-    fed to both ``Matcher.SC2_PCR`` implementations."""
-    S = np.ascontiguousarray(src_desc, np.float32) @ np.ascontiguousarray(tgt_desc, np.float32).T
-    dist = np.sqrt(np.float32(2) - np.float32(2) * S + np.float32(1e-6))
-    return np.argmin(dist, axis=1).astype(np.int64)
+
+def dot_rows(A, B):
+    """``S[i,j] = <A_i, B_j>`` as the fp32 FMA chain over the channels in order, starting from 0 - the arithmetic
+    contract of ``eyoc_dotmax`` and of ``eyoc_knn1`` dist_type 2."""
+    A = np.ascontiguousarray(A, np.float32)
+    B = np.ascontiguousarray(B, np.float32)
+    acc = np.zeros((A.shape[0], B.shape[0]), np.float32)
+    for ch in range(A.shape[1]):
+        acc = fmaf(A[:, ch][:, None], B[:, ch][None, :], acc)
+    return acc
+
+
+def match_pair_distance(src_desc, tgt_desc):
+    """scripts/SC2_PCR/SC2_PCR.py:296: ``sqrt(2 - 2 * (src @ tgt.T) + 1e-6)`` in fp32, each step rounded (the
+    reference's sgemm sums the 32 products in an implementation-defined order; here, and in the HIP kernel, it is
+    ``dot_rows``' chain - results can differ from the reference only where two candidates are within rounding)."""
+    S = dot_rows(src_desc, tgt_desc)
+    with np.errstate(invalid="ignore"):
+        return np.sqrt((np.float32(2) - np.float32(2) * S) + np.float32(1e-6))
+
+
+def match_pair_indices(src_desc, tgt_desc, chunk=512):
+    """scripts/SC2_PCR/SC2_PCR.py:296-298: ``argmin_j sqrt(2 - 2 <s_i, t_j> + 1e-6)`` with ``torch.argmin``'s rules:
+    the first NaN wins its row (inner products above 1 + 5e-7 - descriptors that are not unit-norm), otherwise the
+    first minimum.  (``numpy.argmin`` treats NaN the same way.)"""
+    src_desc = np.ascontiguousarray(src_desc, np.float32)
+    out = np.empty(len(src_desc), np.int64)
+    for s in range(0, len(src_desc), chunk):
+        out[s:s + chunk] = np.argmin(match_pair_distance(src_desc[s:s + chunk], tgt_desc), axis=1)
+    return out

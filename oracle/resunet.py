@@ -48,38 +48,40 @@ def sparse_conv(x: torch.Tensor, nbr: np.ndarray, W: torch.Tensor) -> torch.Tens
 
 
 def batch_norm(x, sd, name):
-    """Eval-mode ``MinkowskiBatchNorm`` (model/common.py:6)."""
-    w, b = _t(sd[f"{name}.bn.weight"]).float(), _t(sd[f"{name}.bn.bias"]).float()
-    m, v = _t(sd[f"{name}.bn.running_mean"]).float(), _t(sd[f"{name}.bn.running_var"]).float()
+    """Eval-mode ``MinkowskiBatchNorm`` (model/common.py:6); computed in the dtype of ``x``."""
+    w, b = _t(sd[f"{name}.bn.weight"]).to(x.dtype), _t(sd[f"{name}.bn.bias"]).to(x.dtype)
+    m, v = _t(sd[f"{name}.bn.running_mean"]).to(x.dtype), _t(sd[f"{name}.bn.running_var"]).to(x.dtype)
     return (x - m) / torch.sqrt(v + BN_EPS) * w + b
 
 
-def _kernel(sd, name):
-    w = _t(sd[f"{name}.kernel"]).float()
+def _kernel(sd, name, dtype=torch.float32):
+    w = _t(sd[f"{name}.kernel"]).to(dtype)
     return w[None] if w.dim() == 2 else w       # 1x1 convs store a 2-D kernel
 
 
 def basic_block(x, nbr, sd, name):
     """model/residual_block.py:37-53 (downsample is always None, model/resunet.py:41-42)."""
-    out = sparse_conv(x, nbr, _kernel(sd, f"{name}.conv1"))
+    out = sparse_conv(x, nbr, _kernel(sd, f"{name}.conv1", x.dtype))
     out = torch.relu(batch_norm(out, sd, f"{name}.norm1"))
-    out = sparse_conv(out, nbr, _kernel(sd, f"{name}.conv2"))
+    out = sparse_conv(out, nbr, _kernel(sd, f"{name}.conv2", x.dtype))
     out = batch_norm(out, sd, f"{name}.norm2")
     return torch.relu(out + x)
 
 
 def resunet_forward(sd: dict, coords: np.ndarray, feats, normalize_feature=True,
-                    conv1_kernel_size=5, maps=None, return_intermediate=False):
+                    conv1_kernel_size=5, maps=None, return_intermediate=False, dtype=torch.float32):
     """Forward of ``ResUNet2`` (any BN channel table - shapes come from ``sd``).
 
-    ``coords int [N,4] (b,x,y,z)``, ``feats f32 [N,C_in]`` -> ``f32 [N,C_out]`` in input row order.
+    ``coords int [N,4] (b,x,y,z)``, ``feats f32 [N,C_in]`` -> ``[N,C_out]`` in input row order.  ``dtype``: the
+    arithmetic (fp32 like the reference; ``torch.float64`` gives the error yardstick the split16 tests use).
     """
     if maps is None:
         maps = oc.build_maps(coords, conv1_kernel_size)
     s1, down, up = maps["s1"], maps["down"], maps["up"]
     ident = lambda n: np.arange(n, dtype=np.int32)[None, :]
-    x = _t(feats).float()
+    x = _t(feats).to(dtype)
     inter = {}
+    _kernel = lambda sd_, name: globals()["_kernel"](sd_, name, dtype)
 
     # encoder (model/resunet.py:143-161)
     out_s1 = batch_norm(sparse_conv(x, maps["k5"], _kernel(sd, "conv1")), sd, "norm1")
@@ -109,7 +111,7 @@ def resunet_forward(sd: dict, coords: np.ndarray, feats, normalize_feature=True,
     inter.update(out_s4_tr=out_s4_tr, out_s2_tr=out_s2_tr, out_s1_tr=out_s1_tr)
     n = out.shape[0]
     out = torch.relu(sparse_conv(out, ident(n), _kernel(sd, "conv1_tr")))
-    out = sparse_conv(out, ident(n), _kernel(sd, "final")) + _t(sd["final.bias"]).float().reshape(1, -1)
+    out = sparse_conv(out, ident(n), _kernel(sd, "final")) + _t(sd["final.bias"]).to(dtype).reshape(1, -1)
     inter["pre_norm"] = out
     if normalize_feature:
         # model/resunet.py:187-191 - no epsilon: a zero row yields NaN, as in the reference

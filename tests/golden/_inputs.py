@@ -55,3 +55,23 @@ def corr_case(seed, n, T, inlier_frac, noise=0.02, extent=(60.0, 60.0, 6.0)):
     out = _u(seed + 2, n) >= inlier_frac
     p1[out] = (_u(seed + 3, n, 3)[out] - 0.5) * np.array(extent)
     return p0.astype(np.float32), p1.astype(np.float32), ~out
+
+
+def match_pair_case(kind, seed, n0, n1, c=32):
+    """Descriptors for ``Matcher.match_pair``: ``unit`` = noisy unit-norm copies (``nn_case``); ``ties`` = unit-norm with
+    every target present three times (exact ties: the lowest index must win) and 200 targets one ulp apart; ``raw`` =
+    rows of norm 0.5 .. 1.6, NOT normalised (inner products above 1 make the reference's sqrt NaN for some rows)."""
+    if kind == "unit":
+        return nn_case(seed, n0, n1, c)
+    if kind == "ties":
+        F0, F1 = nn_case(seed, n0, n1 // 3, c)
+        F1 = np.concatenate([F1, F1, F1])[:n1].copy()
+        k = min(200, len(F1))
+        F1[:k, 0] = np.nextafter(F1[:k, 0], np.float32(2.0))
+        return F0, F1
+    if kind == "raw":
+        F0, F1 = nn_case(seed, n0, n1, c)
+        s0 = (0.5 + 1.1 * _u(seed + 5, n0)).astype(np.float32)
+        s1 = (0.5 + 1.1 * _u(seed + 6, n1)).astype(np.float32)
+        return F0 * s0[:, None], F1 * s1[:, None]
+    raise ValueError(kind)

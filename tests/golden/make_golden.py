@@ -11,6 +11,8 @@ reference's numeric outputs only.
   g3_kabsch.npz  scripts.SC2_PCR.common.rigid_transform_3d
   g4_sc2pcr.npz  scripts.SC2_PCR.SC2_PCR.Matcher.SC2_PCR / cal_leading_eigenvector (KITTI config)
   g5_se3.npz     scripts.SC2_PCR.utils.SE3.transform / integrate_trans
+  g6_match.npz   scripts.SC2_PCR.SC2_PCR.Matcher.match_pair (the method hard-codes one ``.cuda()`` on an index tensor,
+                 SC2_PCR.py:299; it runs here with ``torch.Tensor.cuda`` patched to the identity - nothing else changes)
 """
 import json
 import os
@@ -135,7 +137,34 @@ def g5():
     np.savez_compressed(os.path.join(HERE, "g5_se3.npz"), **out)
 
 
+MATCH_CASES = [  # (kind, seed, n0, n1, num_node)
+    ("unit", 61, 3000, 3000, "all"), ("ties", 62, 1500, 1800, "all"), ("raw", 63, 2000, 2500, "all"),
+    ("unit", 64, 1500, 1200, 2000), ("raw", 65, 700, 900, 1000),
+]
+
+
+def g6():
+    """Key points are index-coded (x = row number), so the returned matched key points reveal the sampled rows and the
+    arg-min indices; for an integer ``num_node`` the global ``np.random`` is seeded with the case's seed."""
+    out = {"cases": np.array(json.dumps(MATCH_CASES))}
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for i, (kind, seed, n0, n1, num_node) in enumerate(MATCH_CASES):
+            F0, F1 = gi.match_pair_case(kind, seed, n0, n1)
+            k0 = np.zeros((1, n0, 3), np.float32); k0[0, :, 0] = np.arange(n0)
+            k1 = np.zeros((1, n1, 3), np.float32); k1[0, :, 0] = np.arange(n1)
+            m = Matcher(**{**KITTI_CFG, "num_node": num_node})
+            np.random.seed(seed)
+            sc, tc = m.match_pair(torch.from_numpy(k0), torch.from_numpy(k1), torch.from_numpy(F0)[None], torch.from_numpy(F1)[None])
+            out[f"src{i}"] = sc[0, :, 0].numpy().astype(np.int32)
+            out[f"tgt{i}"] = tc[0, :, 0].numpy().astype(np.int32)
+    finally:
+        torch.Tensor.cuda = real_cuda
+    np.savez_compressed(os.path.join(HERE, "g6_match.npz"), **out)
+
+
 if __name__ == "__main__":
-    for fn in (g1, g2, g3, g4, g5):
+    for fn in (g1, g2, g3, g4, g5, g6):
         fn()
         print("wrote", fn.__name__)

@@ -111,3 +111,61 @@ def test_layer_linearity_at_full_size(big_batch):
     scale = float(rhs.abs().max())
     assert float((lhs - rhs).abs().max()) < 2e-5 * scale
     assert float(conv(torch.zeros_like(x)).abs().max()) == 0.0
+
+
+def test_bench_geometry_forward_rows_vs_oracle(big_batch):
+    """Parity at the BENCH's own geometry: 128 clouds / ~3.9 M voxels in one batched forward (level-0 tiles beyond
+    65 536 rows: windowed tiling orders, two-pass local rulebooks at level 3, Z-ordered maps, split16 arithmetic in
+    automatic mode).  The 16 distinct clouds are stacked 8 times under different batch indices - neighbourhoods never
+    cross the batch column, so every replica must reproduce the oracle's features of its cloud.  2 000+ sampled rows
+    of three clouds in three different replicas against oracle/resunet.py run on those clouds alone."""
+    from eyoc_amd import synthetic as syn
+    from oracle import resunet as orr
+    clouds, _ = big_batch
+    reps = 8
+    coords = syn.batch_coords(clouds * reps)
+    assert len(coords) > 3_500_000
+    model = _model()
+    F = _forward(model, coords)
+    assert model.last_spconv_math == "split16"
+    np.testing.assert_allclose(torch.linalg.norm(F[::997], dim=1).cpu().numpy(), 1.0, atol=1e-5)
+    sd = syn.make_weights()
+    offs = np.concatenate([[0], np.cumsum([len(c) for c in clouds * reps])])
+    rng = np.random.default_rng(0)
+    checked = 0
+    for cloud, rep in ((0, 0), (5, 3), (15, 7)):
+        ref = orr.resunet_forward(sd, syn.batch_coords([clouds[cloud]]), np.ones((len(clouds[cloud]), 1), np.float32)).numpy()
+        rows = rng.choice(len(ref), 700, replace=False)
+        got = F[offs[rep * len(clouds) + cloud] + torch.from_numpy(rows).cuda()].cpu().numpy()
+        assert float(np.abs(got - ref[rows]).max()) <= 1e-4 * float(np.abs(ref).max())
+        assert float((got * ref[rows]).sum(1).min()) >= 1 - 1e-6
+        checked += len(rows)
+    assert checked >= 2000
+    # and the replicas agree with each other bit for bit (same kernels, same tile-internal arithmetic order is NOT
+    # guaranteed across tiles of different neighbours, so only closeness is asserted between replicas)
+    a = F[offs[0]:offs[1]]
+    b = F[offs[5 * len(clouds)]:offs[5 * len(clouds) + 1]]
+    assert float((a - b).abs().max()) < 2e-5
+
+
+def test_bench_total_pairs_split_runs_on_the_gpu():
+    """configs[3]'s code path (``bench.py --total-pairs``: fixed split, ragged last batch, records gathered in global
+    pair order) on one GPU: 21 pairs in batches of 8 / 8 / 5 from a pool of 4 scenes.  Run as its own process - bench.py
+    forks its scene generators before it touches the GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--total-pairs", "21", "--pairs", "8",
+                        "--pool", "4", "--steps", "1", "--warmup", "1", "--no-extras", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["records_gathered"] == 21 and line["scaling"] == "strong"
+    assert line["config"]["total_pairs"] == 21 and line["config"]["batches_per_rank"] == [8, 8, 5]
+    assert line["steps"] == 3 and line["ranks_seen"] == [0]
+    assert line["success_rate"] >= 0.9
+    # global pair order: pair i is scene i % 4 of rank 0's pool, and a registered pair's pose is that scene's T_gt
+    tx = line["pose_tx_first8"]
+    assert len(tx) == 8 and np.allclose(tx[:4], tx[4:8], atol=0.5) and len({round(v, 1) for v in tx[:4]}) > 1

@@ -252,3 +252,111 @@ def test_two_streams_share_the_scratch_safely():
         torch.cuda.synchronize()
         for g, w in zip(got, want):
             np.testing.assert_array_equal(g.cpu().numpy(), w)
+
+
+# ----------------------------------------------------------------------------- Matcher.match_pair
+def _gemm_l2(A, B, seg_a=None, seg_b=None, dist=True):
+    import eyoc_amd
+    seg_a = np.array([0, len(A)]) if seg_a is None else seg_a
+    seg_b = np.array([0, len(B)]) if seg_b is None else seg_b
+    out = eyoc_amd.knn1_segmented(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(), seg_a, seg_b, "GemmL2", return_distance=dist)
+    return (out[0].cpu().numpy(), out[1].cpu().numpy()) if dist else out.cpu().numpy()
+
+
+def _match_cases():
+    rng = np.random.default_rng(77)
+    F0, F1 = gi.nn_case(500, 5000, 5000)                        # unit-norm, the path's size
+    F1 = F1.copy()
+    F1[1000:1400] = F1[:400]                                    # exact ties (lowest index must win)
+    F1[2000:2300] = F1[:300]
+    F1[2000:2300, 7] = np.nextafter(F1[2000:2300, 7], np.float32(2.0))     # ... and one-ulp near-ties
+    yield "unit+ties", F0, F1
+    centre = gi.unit_feats(501, 1)                              # hundreds of candidates whose distances round together
+    yield "cluster", (centre + 1e-6 * rng.normal(size=(300, 32))).astype(np.float32), \
+        (centre + 1e-6 * rng.normal(size=(3000, 32))).astype(np.float32)
+    R0, R1 = gi.match_pair_case("raw", 502, 3000, 4000)         # NOT unit-norm: arg-max of <a,b>, NaN rows
+    yield "raw", R0, R1
+    yield "raw-big", (R0 * 40).astype(np.float32), (R1 * 0.03).astype(np.float32)
+    yield "odd", *gi.match_pair_case("raw", 503, 257, 129)
+
+
+@pytest.mark.parametrize("prefilter", [0, 2])
+def test_match_pair_nn_bit_exact_vs_oracle(prefilter):
+    """eyoc_knn1 dist_type 2 = the reference's ``argmin sqrt(2 - 2 S + 1e-6)`` (SC2_PCR.py:296-298): indices AND distance
+    bits equal to oracle.matching (first NaN wins, ties to the lowest index, distances that round together), with the
+    MFMA pre-filter forced on and off."""
+    from eyoc_amd import _lib
+    from oracle import matching as om
+    lib = _lib.load()
+    prev = lib.eyoc_knn_prefilter(prefilter)
+    try:
+        saw_nan = False
+        for name, A, B in _match_cases():
+            want = om.match_pair_indices(A, B)
+            got = _gemm_l2(A, B, dist=False)
+            np.testing.assert_array_equal(got, want, err_msg=name)
+            gi_, gd = _gemm_l2(A, B)                              # with distances: the exact kernel alone
+            np.testing.assert_array_equal(gi_, want, err_msg=name)
+            rows = slice(0, 400)
+            D = om.match_pair_distance(A[rows], B)
+            wd = D[np.arange(D.shape[0]), want[rows]]
+            fin = ~np.isnan(wd)
+            np.testing.assert_array_equal(gd[rows][fin].view(np.uint32), wd[fin].view(np.uint32), err_msg=name)
+            assert np.array_equal(np.isnan(gd[rows]), np.isnan(wd)), name
+            saw_nan |= bool(np.isnan(wd).any())
+        assert saw_nan
+    finally:
+        lib.eyoc_knn_prefilter(prev)
+
+
+def test_match_pair_segments_and_l2_difference():
+    """Segmented dist_type 2 equals per-segment calls; on descriptors that are not unit-norm it is NOT the L2 neighbour
+    (the substitution round 2 made silently) - the two disagree on most rows of the raw case."""
+    import eyoc_amd
+    from oracle import matching as om
+    sizes_a, sizes_b = [100, 1, 257, 1000], [300, 50, 129, 17]
+    A = np.concatenate([gi.match_pair_case("raw", 510 + i, n, 8)[0] for i, n in enumerate(sizes_a)])
+    B = np.concatenate([gi.match_pair_case("raw", 520 + i, 8, n)[1] for i, n in enumerate(sizes_b)])
+    sa, sb = np.cumsum([0] + sizes_a), np.cumsum([0] + sizes_b)
+    got = _gemm_l2(A, B, sa, sb, dist=False)
+    for s in range(len(sizes_a)):
+        np.testing.assert_array_equal(got[sa[s]:sa[s + 1]], om.match_pair_indices(A[sa[s]:sa[s + 1]], B[sb[s]:sb[s + 1]]))
+    R0, R1 = gi.match_pair_case("raw", 502, 3000, 4000)
+    l2 = eyoc_amd.find_nn_gpu(torch.from_numpy(R0).cuda(), torch.from_numpy(R1).cuda()).numpy()
+    assert (l2 != om.match_pair_indices(R0, R1)).mean() > 0.3
+
+
+def test_matcher_match_pair_vs_reference_golden_and_oracle():
+    """Matcher.match_pair itself (resampling draw + NN + gathers) against the reference's own output (golden g6) -
+    index-coded key points reveal the rows - with the same near-tie audit as the oracle's CPU test, and against the
+    oracle exactly."""
+    import json
+    import eyoc_amd
+    from oracle import matching as om
+    g = _golden("g6_match.npz")
+    for i, (kind, seed, n0, n1, num_node) in enumerate(json.loads(str(g["cases"]))):
+        F0, F1 = gi.match_pair_case(kind, seed, n0, n1)
+        k0 = np.zeros((1, n0, 3), np.float32); k0[0, :, 0] = np.arange(n0)
+        k1 = np.zeros((1, n1, 3), np.float32); k1[0, :, 0] = np.arange(n1)
+        m = eyoc_amd.Matcher(inlier_threshold=0.6, num_node=num_node, use_mutual=False, d_thre=0.1, num_iterations=20,
+                             ratio=0.2, nms_radius=0.6, max_points=8000, k1=30, k2=20)
+        sc, tc = m.match_pair(torch.from_numpy(k0).cuda(), torch.from_numpy(k1).cuda(), torch.from_numpy(F0)[None].cuda(),
+                              torch.from_numpy(F1)[None].cuda(), rng=np.random.RandomState(seed))
+        src, tgt = sc[0, :, 0].cpu().numpy().astype(np.int64), tc[0, :, 0].cpu().numpy().astype(np.int64)
+        np.testing.assert_array_equal(src, g[f"src{i}"])                       # the reference's draw
+        if num_node == "all":
+            t_sel = np.arange(n1)
+        else:
+            rs = np.random.RandomState(seed)
+            rs.choice(n0, num_node)
+            t_sel = rs.choice(n1, num_node)
+        A, B = F0[src], F1[t_sel]
+        want = om.match_pair_indices(A, B)
+        np.testing.assert_array_equal(tgt, t_sel[want])                        # vs oracle: exact
+        ref = g[f"tgt{i}"].astype(np.int64)
+        diff = np.nonzero(tgt != ref)[0]
+        assert len(diff) <= max(2, len(A) // 500)
+        for row in diff:                                                         # vs reference: only rounding-level ties
+            cand = np.nonzero(t_sel == ref[row])[0][:1]
+            d = om.match_pair_distance(A[row:row + 1], B[[want[row], cand[0]]])[0]
+            assert np.isnan(d).any() or abs(float(d[0]) - float(d[1])) <= 2e-4 * max(1.0, float(d[0]))

@@ -53,6 +53,73 @@ def test_find_nn_tie_goes_to_lowest_index():
     assert om.find_nn(F0, F1).tolist() == [1, 0]
 
 
+# ----------------------------------------------------------------------------- G6
+def _match_pair_draws(seed, n0, n1, num_node):
+    """The rows ``Matcher.match_pair`` samples (SC2_PCR.py:284-289) from the global ``np.random`` seeded by the case."""
+    if num_node == "all":
+        return np.arange(n0), np.arange(n1)
+    rs = np.random.RandomState(seed)
+    return rs.choice(n0, num_node), rs.choice(n1, num_node)
+
+
+def test_match_pair_matches_reference(golden_dir):
+    """oracle.match_pair_indices vs the reference's own Matcher.match_pair (golden g6): unit-norm descriptors, exact
+    ties, descriptors that are not unit-norm (NaN rows) and the with-replacement resampling.  The reference sums the
+    32 products inside sgemm; indices may differ from the oracle's FMA chain only where two candidates' distances
+    are within rounding - those rows are audited one by one."""
+    g = _load(golden_dir, "g6_match.npz")
+    n_nan_rows = 0
+    for i, (kind, seed, n0, n1, num_node) in enumerate(json.loads(str(g["cases"]))):
+        F0, F1 = gi.match_pair_case(kind, seed, n0, n1)
+        s_sel, t_sel = _match_pair_draws(seed, n0, n1, num_node)
+        np.testing.assert_array_equal(g[f"src{i}"], s_sel)                 # the draw itself is reproduced
+        A, B = F0[s_sel], F1[t_sel]
+        idx = om.match_pair_indices(A, B)
+        ref_local = g[f"tgt{i}"].astype(np.int64)                           # = t_sel[argmin]: original target row
+        got = t_sel[idx]
+        diff = np.nonzero(got != ref_local)[0]
+        assert len(diff) <= max(2, len(A) // 500), f"case {i}: {len(diff)} index mismatches"
+        D = om.match_pair_distance(A[diff], B) if len(diff) else None
+        for r, row in enumerate(diff):
+            cand = np.nonzero(t_sel == ref_local[row])[0]                   # the reference's pick, in local numbering
+            d_ref, d_got = D[r, cand[0]], D[r, idx[row]]
+            if np.isnan(d_got):      # a NaN row: the reference must have picked a (near-)NaN candidate too
+                assert np.isnan(d_ref) or om.dot_rows(A[row:row + 1], B[cand[:1]])[0, 0] > 1.0 - 1e-5
+            else:
+                assert abs(float(d_ref) - float(d_got)) <= 2e-4 * max(1.0, float(d_got)), f"case {i} row {row}"
+        n_nan_rows += int(np.isnan(om.match_pair_distance(A[:256], B)).any(axis=1).sum())
+        if kind == "ties":           # exact duplicates: never the third copy; the second only where the first was nudged
+            assert (idx < n1 // 3 + 200).all()
+    assert n_nan_rows > 0, "the raw cases must exercise the NaN rule"
+
+
+def test_match_pair_nan_and_tie_rules():
+    A = np.array([[1.0, 0, 0, 0], [2.0, 0, 0, 0], [0.5, 0, 0, 0]], np.float32)
+    B = np.array([[0.2, 0, 0, 0], [1.0, 0, 0, 0], [1.0, 0, 0, 0], [3.0, 0, 0, 0]], np.float32)
+    # row 0: S = .2, 1, 1, 3 -> w < 0 only for S = 3: NaN at index 3 wins;  row 1: S = .4, 2, 2, 6: first NaN = 1;
+    # row 2: S = .1, .5, .5, 1.5: NaN at 3
+    assert om.match_pair_indices(A, B).tolist() == [3, 1, 3]
+    assert om.match_pair_indices(A, B[:3]).tolist() == [1, 1, 1]           # ties -> lowest index
+    t = torch.sqrt(2 - 2 * (torch.from_numpy(A) @ torch.from_numpy(B).T) + 1e-6).argmin(dim=1)
+    assert t.tolist() == [3, 1, 3]                                          # torch.argmin's NaN rule, as assumed
+
+
+def test_fmaf_emulation_is_correctly_rounded():
+    from fractions import Fraction
+    rng = np.random.default_rng(5)
+    n = 3000
+    a, b = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    c = (rng.standard_normal(n) * 10.0 ** rng.integers(-8, 8, n)).astype(np.float32)
+    c[:50] = -(a[:50].astype(np.float64) * b[:50]).astype(np.float32)       # cancellation
+    r = om.fmaf(a, b, c)
+    for i in range(n):
+        ex = Fraction(float(a[i])) * Fraction(float(b[i])) + Fraction(float(c[i]))
+        f = np.float32(float(ex))
+        cands = [f, np.nextafter(f, np.float32(np.inf)), np.nextafter(f, np.float32(-np.inf))]
+        best = min(cands, key=lambda x: (abs(Fraction(float(x)) - ex), int(x.view(np.uint32)) & 1))
+        assert best == r[i]
+
+
 # ----------------------------------------------------------------------------- G2
 def test_irls_matches_reference(golden_dir):
     g = _load(golden_dir, "g2_irls.npz")
