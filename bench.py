@@ -301,6 +301,7 @@ def worker(args):
         s_, res_, slot_ = item[:3]
         batch_ = batches[s_ % len(batches)][1]
         host = res_.cpu()
+        model.check_range()          # split16 range guard: raises if a forward since the last check overflowed
         last[s_ % len(batches)] = [eyoc_amd.registration.decode_ransac_result(host[p], batch_.n_points) for p in range(batch_.P)] \
             if cfg.use_RANSAC else res_
         if model is not None:

@@ -49,6 +49,8 @@ struct eyoc_model {
   std::vector<hipEvent_t> events;     // two sets of layers + 1 events (eyoc_model_timing_slot)
   int slot = 0;
   int events_valid[2] = {0, 0};
+  unsigned int* range = nullptr;      // device: {overflow flag, max |activation| bits (probe), probe switch, pad} - split16_guard in spconv.h
+  int probe = 0;
 };
 
 namespace {
@@ -221,6 +223,16 @@ int eyoc_model_create(eyoc_ctx* ctx, const eyoc_model_desc* desc, const eyoc_lay
       return EYOC_ERR_HIP;
     }
   }
+  {   // the SPLIT16 range-guard words (16 bytes; part of the handle like the timing events)
+    hipError_t e = hipMalloc((void**)&m->range, 16);
+    if (e == hipSuccess) e = hipMemset(m->range, 0, 16);
+    if (e != hipSuccess) {
+      set_error("eyoc_model_create: range-guard allocation failed: %s", hipGetErrorString(e));
+      if (m->range) (void)hipFree(m->range);
+      delete m;
+      return EYOC_ERR_HIP;
+    }
+  }
   *out = m;
   return EYOC_OK;
 }
@@ -228,7 +240,34 @@ int eyoc_model_create(eyoc_ctx* ctx, const eyoc_model_desc* desc, const eyoc_lay
 int eyoc_model_destroy(eyoc_model* m) {
   if (!m) return EYOC_OK;
   for (auto e : m->events) (void)hipEventDestroy(e);
+  if (m->range) (void)hipFree(m->range);
   delete m;
+  return EYOC_OK;
+}
+
+int eyoc_model_set_probe(eyoc_model* m, int on) {
+  EYOC_REQUIRE(m, EYOC_ERR_INVALID, "eyoc_model_set_probe: NULL model");
+  const unsigned int words[2] = {0u, on ? 1u : 0u};                   // max |x| reset, probe switch
+  EYOC_CHECK_HIP(hipMemcpy(m->range + 1, words, 8, hipMemcpyHostToDevice));
+  m->probe = on ? 1 : 0;
+  return EYOC_OK;
+}
+
+int eyoc_model_range_check(eyoc_model* m, void* stream, float* max_abs) {
+  EYOC_REQUIRE(m, EYOC_ERR_INVALID, "eyoc_model_range_check: NULL model");
+  unsigned int words[4] = {0, 0, 0, 0};
+  hipStream_t st = (hipStream_t)stream;
+  EYOC_CHECK_HIP(hipMemcpyAsync(words, m->range, 16, hipMemcpyDeviceToHost, st));
+  EYOC_CHECK_HIP(hipStreamSynchronize(st));
+  float mx;
+  memcpy(&mx, &words[1], 4);
+  if (max_abs) *max_abs = m->probe ? mx : -1.0f;
+  if (words[0]) {
+    EYOC_CHECK_HIP(hipMemsetAsync(m->range, 0, 4, st));                // reported once; the next forward starts clean
+    set_error("split16 arithmetic overflowed: an activation reached %g (fp16 hi halves end at 65504) - the features of that "
+              "forward are NaN; run the model with spconv math \"fp32\"", (double)SPLIT16_LIMIT);
+    return EYOC_ERR_RANGE;
+  }
   return EYOC_OK;
 }
 
@@ -312,6 +351,7 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
       a.in = buf[p.in_buf]; a.cin = p.cin; a.w = m->blob + p.w_off; a.bias = m->blob + p.b_off; a.cout = p.cout;
       a.out = buf[p.out_buf] + p.out_col; a.ld_out = m->bufs[p.out_buf].width;
       a.out_split = split ? 1 : 0;
+      a.range = split ? m->range : nullptr;
       a.in_perm = maps->row_perm;                        // Z-ordered maps: the caller's features are read through the permutation
       if (a.in_perm) {
         // ... once: a copy in internal order in a buffer nothing uses yet (an indirection per probed neighbour cost the
@@ -348,6 +388,7 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
         a.w = m->blob + p.w16_off;
         a.out_scale = m->blob + p.s_off;
         a.out_split = p.out_buf != B_OUT;
+        a.range = m->range;
         // stride-1 layers on Z-ordered rows: tile-local input stage (spconv_st.hip)
         if (p.map == M_S1 && p.cin >= 32 && p.cin % 32 == 0) a.local = maps->local_s1[p.level];
         if (p.map == M_UP && p.cin % 32 == 0 && p.cout % 64 == 0) a.local_up = maps->local_up[p.level];   // spconv_up.hip

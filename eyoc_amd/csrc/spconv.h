@@ -38,6 +38,8 @@ struct SpconvArgs {
   // wave-private kernel only: the first `small_rows` rows (in tiling order; a multiple of 64) are cut into 32-row
   // tiles.  They run last (heavy tiles first), so the kernel's tail is made of short-lived waves.  0 = none.
   int small_rows = 0;
+  // SPLIT16 range guard (see split16_guard below): device words {overflow flag, max |x| bits, probe switch} or NULL
+  unsigned int* range = nullptr;
 };
 
 // ---- SPLIT16 row format: every block of 32 channels takes 128 bytes (one cache line), the 32 fp16 "hi" halves (x rounded
@@ -81,6 +83,22 @@ __device__ inline float4 split16_load4(const float* row, int c) {
   return split16_decode4(*reinterpret_cast<const uint2*>(p), *reinterpret_cast<const uint2*>(p + SPLIT16_LO));
 }
 
+// ---- SPLIT16 range guard.  The hi half of an activation at or above 65520 is inf (and the lo half x - inf): every
+// epilogue that WRITES SPLIT16 rows tracks the largest magnitude it stores (one v_max per value) and raises word 0 of
+// `range` once a value reaches SPLIT16_LIMIT - before anything became inf; the fp32-writing last layer of the network
+// then answers with NaN rows (split16_poisoned) and eyoc_model_range_check reports EYOC_ERR_RANGE.  Word 2 != 0 (the debug
+// probe, eyoc_model_set_probe) also keeps the running maximum of |x| over all stored activations in word 1.
+constexpr float SPLIT16_LIMIT = 6.0e4f;
+__device__ inline void split16_track(float& mx, const float4 v) {
+  mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+__device__ inline void split16_report(unsigned int* range, float mx) {
+  if (!range) return;
+  if (mx >= SPLIT16_LIMIT) atomicOr(range, 1u);                       // rare
+  if (__builtin_nontemporal_load(range + 2)) atomicMax(range + 1, __float_as_uint(mx));   // probe mode only (non-negative floats order like ints)
+}
+__device__ inline bool split16_poisoned(const unsigned int* range) { return range && __builtin_nontemporal_load(range) != 0u; }
+
 // Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits for
 // every global load the wave has in flight - which turns a software pipeline whose loads are meant to land a stage
 // later (gathers, weight pieces) into a blocking one: each stage then pays a full memory latency at its barrier.
@@ -114,6 +132,7 @@ struct Conv1Args {
   float* out;             // rows of ld_out floats
   int ld_out;
   int out_split = 0;      // write SPLIT16 rows (see above) instead of fp32 rows
+  unsigned int* range = nullptr;      // SPLIT16 range guard words (split16_guard) or NULL
   const int32_t* in_perm = nullptr;   // input row i is read from row in_perm[i] of `in` (the network input in the caller's order)
   // octree links (level 0 <-> 1) and the level-1 stride-1 table: with them a 3^3 / 5^3 window is read
   // from the 27 coarse blocks around the parent without any hash probe; NULL -> probe the hash table

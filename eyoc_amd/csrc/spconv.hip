@@ -475,14 +475,17 @@ __global__ __launch_bounds__(256) void conv1_kernel(Conv1Args a) {
   }
   if (ok) {
     float* dst = a.out + (size_t)o * a.ld_out;
+    float mx = 0.f;
 #pragma unroll
     for (int i = 0; i < COUT; i += 4) {
       float4 v;
       v.x = acc[i] + a.bias[i]; v.y = acc[i + 1] + a.bias[i + 1];
       v.z = acc[i + 2] + a.bias[i + 2]; v.w = acc[i + 3] + a.bias[i + 3];
+      split16_track(mx, v);
       if (a.out_split) split16_store4(dst, i, v);
       else *reinterpret_cast<float4*>(dst + i) = v;
     }
+    if (a.out_split) split16_report(a.range, mx);
   }
 }
 
@@ -532,14 +535,17 @@ __global__ __launch_bounds__(256) void conv1_tree_kernel(Conv1Args a) {
     }
   }
   float* dst = a.out + (size_t)o * a.ld_out;
+  float mx = 0.f;
 #pragma unroll
   for (int i = 0; i < COUT; i += 4) {
     float4 v;
     v.x = acc[i] + a.bias[i]; v.y = acc[i + 1] + a.bias[i + 1];
     v.z = acc[i + 2] + a.bias[i + 2]; v.w = acc[i + 3] + a.bias[i + 3];
+    split16_track(mx, v);
     if (a.out_split) split16_store4(dst, i, v);
     else *reinterpret_cast<float4*>(dst + i) = v;
   }
+  if (a.out_split) split16_report(a.range, mx);
 }
 
 // The same first convolution (C_in = 1, 5^3 or 3^3 window, 32 output channels) as MFMA work.  conv1_tree_kernel walks the
@@ -668,15 +674,18 @@ __global__ __launch_bounds__(256, 4) void conv1_mfma_kernel(Conv1Args a) {
   if (o < a.n) {
     // lane (g, j) holds channels 16 t + 4 g .. +3 of row o
     float* dst = a.out + (size_t)o * a.ld_out;
+    float mx = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int ch0 = 16 * t + 4 * g;
       const float4 b = *reinterpret_cast<const float4*>(a.bias + ch0);
       const float4 v = make_float4(acc[t][0] * (1.0f / 256.0f) + b.x, acc[t][1] * (1.0f / 256.0f) + b.y,
                                    acc[t][2] * (1.0f / 256.0f) + b.z, acc[t][3] * (1.0f / 256.0f) + b.w);
+      split16_track(mx, v);
       if (a.out_split) split16_store4(dst, ch0, v);
       else *reinterpret_cast<float4*>(dst + ch0) = v;
     }
+    if (a.out_split) split16_report(a.range, mx);
   }
   __builtin_amdgcn_wave_barrier();                                   // the next tile's clear stays behind this tile's operand reads
   }

@@ -230,6 +230,9 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_rs_kernel(SpconvArgs a) {
 
   // ---- epilogue straight from the registers: lane (g, j) holds channels 16 t + 4 g .. +3 of row 16 c + j
   const float os = a.out_scale ? *a.out_scale : 1.0f;
+  float mx = 0.f;
+  const bool poisoned = !a.out_split && split16_poisoned(a.range);     // the network's fp32 output after an overflow upstream
+  const float qnan = __builtin_nanf("");
   float4 b4[NTW];
 #pragma unroll
   for (int t = 0; t < NTW; ++t)
@@ -266,10 +269,11 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_rs_kernel(SpconvArgs a) {
         }
       }
       const size_t oo = a.out_perm ? (size_t)a.out_perm[o] : (size_t)o;
-      if (a.out_split) split16_store4(a.out + oo * a.ld_out, ch, v[t]);
-      else *reinterpret_cast<float4*>(a.out + oo * a.ld_out + ch) = v[t];
+      if (a.out_split) { split16_track(mx, v[t]); split16_store4(a.out + oo * a.ld_out, ch, v[t]); }
+      else *reinterpret_cast<float4*>(a.out + oo * a.ld_out + ch) = poisoned ? make_float4(qnan, qnan, qnan, qnan) : v[t];
     }
   }
+  if (a.out_split) split16_report(a.range, mx);
 }
 
 }  // namespace

@@ -299,6 +299,7 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_kernel(SpconvArgs a, con
 #pragma unroll
   for (int t = 0; t < NTW; ++t)
     b4[t] = a.bias ? *reinterpret_cast<const float4*>(a.bias + ct0 + 16 * t + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float mx = 0.f;
 #pragma unroll
   for (int hc = 0; hc < NH * NC; ++hc) {
     const int h = hc / NC, c = hc % NC;
@@ -314,10 +315,12 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_kernel(SpconvArgs a, con
         v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
       }
       if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      split16_track(mx, v);
       if (a.out_split) split16_store4(a.out + (size_t)o * a.ld_out, ch, v);
       else *reinterpret_cast<float4*>(a.out + (size_t)o * a.ld_out + ch) = v;
     }
   }
+  if (a.out_split) split16_report(a.range, mx);
 }
 
 }  // namespace

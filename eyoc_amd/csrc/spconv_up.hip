@@ -270,6 +270,7 @@ __global__ __launch_bounds__(NWK * 64, 4) void spconv_up_kernel(SpconvArgs a, co
 #pragma unroll
   for (int t = 0; t < NTW; ++t)
     b4[t] = a.bias ? *reinterpret_cast<const float4*>(a.bias + ct0 + 16 * t + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float mx = 0.f;
 #pragma unroll
   for (int c = 0; c < NG; ++c) {
     const int o = rowp[16 * c + j];
@@ -284,10 +285,12 @@ __global__ __launch_bounds__(NWK * 64, 4) void spconv_up_kernel(SpconvArgs a, co
         v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
       }
       if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      split16_track(mx, v);
       if (a.out_split) split16_store4(a.out + (size_t)o * a.ld_out, ch, v);
       else *reinterpret_cast<float4*>(a.out + (size_t)o * a.ld_out + ch) = v;
     }
   }
+  if (a.out_split) split16_report(a.range, mx);
 }
 
 }  // namespace

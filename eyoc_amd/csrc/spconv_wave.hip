@@ -390,6 +390,9 @@ __global__ __launch_bounds__((WCfg<CTW, BMW, CC, NCMAX>::WPB * 64), OCC) void sp
   float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + ct0 + ec4 * 4);
   const float os = a.out_scale ? *a.out_scale : 1.0f;   // undoes the weight pre-scale of the SPLIT16 packing (a power of two)
+  float mx = 0.f;
+  const bool poisoned = MATH && !a.out_split && split16_poisoned(a.range);   // the network's fp32 output after an overflow upstream
+  const float qnan = __builtin_nanf("");
   for (int r = er; r < rows_here; r += RPI) {
     const size_t o = (size_t)list[r];
     float4 v = *reinterpret_cast<const float4*>(acc + acc_off(r, ec4));
@@ -411,9 +414,10 @@ __global__ __launch_bounds__((WCfg<CTW, BMW, CC, NCMAX>::WPB * 64), OCC) void sp
       }
     }
     const size_t oo = a.out_perm ? (size_t)a.out_perm[o] : o;
-    if (a.out_split) split16_store4(a.out + oo * a.ld_out, ct0 + ec4 * 4, v);
-    else *reinterpret_cast<float4*>(a.out + oo * a.ld_out + ct0 + ec4 * 4) = v;
+    if (a.out_split) { split16_track(mx, v); split16_store4(a.out + oo * a.ld_out, ct0 + ec4 * 4, v); }
+    else *reinterpret_cast<float4*>(a.out + oo * a.ld_out + ct0 + ec4 * 4) = poisoned ? make_float4(qnan, qnan, qnan, qnan) : v;
   }
+  if (MATH && a.out_split) split16_report(a.range, mx);
   TR();
 }
 

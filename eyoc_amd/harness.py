@@ -153,11 +153,31 @@ class RegistrationPipeline:
     def features(self, batch: DeviceBatch, maps=None) -> SparseTensor:
         """scripts/test_kitti.py:141-150 for all 2P clouds at once (the maps are rebuilt per call, like
         the reference rebuilds its coordinate manager for every SparseTensor - or taken from ``prepare_maps``)."""
-        if maps is not None:
-            cm, ready = maps
-            torch.cuda.current_stream().wait_event(ready)
-            return self.model(SparseTensor(batch.feats, coordinate_manager=cm))
-        return self.model(SparseTensor(batch.feats, coordinates=batch.coords))
+        # the split16 range check is deferred to where ``register`` synchronises anyway (no host wait after the forward)
+        check, self.model.range_check = self.model.range_check, False
+        try:
+            if maps is not None:
+                cm, ready = maps
+                torch.cuda.current_stream().wait_event(ready)
+                return self.model(SparseTensor(batch.feats, coordinate_manager=cm))
+            return self.model(SparseTensor(batch.feats, coordinates=batch.coords))
+        finally:
+            self.model.range_check = check
+
+    def _checked(self, batch, seed, maps):
+        """After the results were read back: raise on a split16 overflow - or, in automatic mode, switch the model to
+        fp32 MFMAs for good and run the step again."""
+        from . import _lib
+        try:
+            self.model.check_range()
+            return None
+        except _lib.EyocError:
+            if self.model.spconv_math != "auto":
+                raise
+            import logging
+            logging.warning("eyoc_amd: split16 overflow in the registration pipeline; switching the model to fp32 MFMAs")
+            self.model.spconv_math = "fp32"
+            return self.register(batch, seed, False, maps)
 
     @torch.no_grad()
     def prepare_maps(self, batch: DeviceBatch):
@@ -195,9 +215,9 @@ class RegistrationPipeline:
                 self.cfg.voxel_size * 1.0, self.cfg.ransac_max_iteration, seed=seed)   # [P, 84] bytes on the device
             self._mark(3)
             if return_device:
-                return res
+                return res                # the caller reads back later - and calls model.check_range() then
             host = res.cpu()
-            return [reg.decode_ransac_result(host[p], n) for p in range(batch.P)]
+            return self._checked(batch, seed, maps) or [reg.decode_ransac_result(host[p], n) for p in range(batch.P)]
         # SC2-PCR path (scripts/test_kitti.py:179-181): Matcher.estimator re-samples both clouds to num_node with
         # replacement, matches them and registers the matched pairs.  Same draws (pair by pair from one seeded
         # RandomState, source before target) and the same arithmetic as a per-pair loop over ``matcher.estimator``,
@@ -235,7 +255,7 @@ class RegistrationPipeline:
         if return_device:
             return T
         Th = T.cpu().numpy().astype(np.float64)
-        return [reg.RegistrationResult(Th[p], 0.0, 0.0) for p in range(P)]
+        return self._checked(batch, seed, maps) or [reg.RegistrationResult(Th[p], 0.0, 0.0) for p in range(P)]
 
     def correspondence_inlier_ratio(self, batch: DeviceBatch, nn_idx=None, thresh=None):
         """Diagnostic (outside the timed path): per pair, the fraction of the feature correspondences of the last

@@ -91,6 +91,10 @@ class ResUNet2(nn.Module):
         self._packed_version = None
         self._timing = False
         self._math = -1          # sparse-conv arithmetic: -1 automatic, 0 fp32 MFMA, 1 split16 (see spconv_math)
+        # split16 range guard: True = every split16 forward is followed by eyoc_model_range_check (one stream
+        # synchronisation); pipelined callers set it False and call check_range() where they synchronise anyway
+        self.range_check = True
+        self._probe = False
 
     # ------------------------------------------------------------------ packing
     def _desc(self):
@@ -104,14 +108,20 @@ class ResUNet2(nn.Module):
         return d
 
     def _weights_version(self):
-        """Changes whenever a parameter / buffer is rebound or modified in place (``copy_``, ``.data`` edits bump
-        ``_version``): the EMA labeler sync of lib/trainer.py:1509-1513 updates weights exactly that way."""
-        v = 0
-        for t in self.parameters():
-            v += t._version + (t.data_ptr() & 0xFFFFFFFF)
-        for t in self.buffers():
-            v += t._version + (t.data_ptr() & 0xFFFFFFFF)
-        return v
+        """Fingerprint of (storage, autograd version counter) of every parameter / buffer: it changes when a tensor is
+        rebound (``load_state_dict``, ``.to()``) or modified in place THROUGH the tensor itself (``p.copy_()``,
+        ``p.mul_()`` under ``no_grad`` - the EMA labeler sync of lib/trainer.py:1509-1513 works that way).  It does NOT
+        see edits made through ``p.data`` (``p.data.mul_()`` leaves ``p._version`` alone) nor writes through another
+        view of the storage: after those call ``repack()`` - the forward would silently run the old packed weights.
+        Inference-mode tensors have no version counter; they contribute their storage address only."""
+        v = []
+        for t in list(self.parameters()) + list(self.buffers()):
+            try:
+                ver = t._version
+            except RuntimeError:
+                ver = -1
+            v.append((t.data_ptr(), ver))
+        return hash(tuple(v))
 
     def _invalidate(self):
         if self._handle is not None:
@@ -161,8 +171,8 @@ class ResUNet2(nn.Module):
         return (_lib.LayerParams * len(items))(*items), len(items), keep
 
     def repack(self):
-        """Fold and upload the current parameters again (explicit form of what ``forward`` does on its own when it
-        sees that a parameter changed in place)."""
+        """Fold and upload the current parameters again.  ``forward`` does this on its own when ``_weights_version``
+        changed; it is MANDATORY after edits that fingerprint cannot see (``p.data`` edits, writes through views)."""
         return self.pack(self._packed_device)
 
     def pack(self, device=None, blob: torch.Tensor | None = None, from_blob=False):
@@ -195,6 +205,8 @@ class ResUNet2(nn.Module):
             _lib.check(lib.eyoc_model_set_timing(h, 1), "eyoc_model_set_timing")
         if self._math != -1:
             lib.eyoc_model_set_math(h, self._math)
+        if self._probe:
+            _lib.check(lib.eyoc_model_set_probe(h, 1), "eyoc_model_set_probe")
         return blob
 
     @property
@@ -223,9 +235,44 @@ class ResUNet2(nn.Module):
         out = torch.empty((len(x), self.out_channels), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             ws = _lib.workspace(lib.eyoc_model_workspace_bytes(self._handle, maps), dev)
-            _lib.check(lib.eyoc_model_forward(_lib.ctx(dev.index), self._handle, maps, _lib.ptr(x.F), _lib.ptr(out),
-                                              _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "eyoc_model_forward")
+
+            def run():
+                _lib.check(lib.eyoc_model_forward(_lib.ctx(dev.index), self._handle, maps, _lib.ptr(x.F), _lib.ptr(out),
+                                                  _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "eyoc_model_forward")
+            run()
+            if self.range_check and lib.eyoc_model_last_math(self._handle) == 1:
+                try:
+                    self.check_range()
+                except _lib.EyocError:
+                    if self._math != -1:          # split16 was asked for explicitly
+                        raise
+                    # automatic mode: the same forward in the reference's arithmetic (fp32 MFMA has no range limit)
+                    logging.warning("eyoc_amd: split16 arithmetic overflowed (an activation reached 6e4); re-running "
+                                    "this forward with fp32 MFMAs - set model.spconv_math = 'fp32' for this checkpoint")
+                    lib.eyoc_model_set_math(self._handle, 0)
+                    try:
+                        run()
+                    finally:
+                        lib.eyoc_model_set_math(self._handle, -1)
         return SparseTensor(out, coordinate_map_key=x.coordinate_map_key, coordinate_manager=cm)
+
+    def check_range(self):
+        """Raise ``EyocError`` (EYOC_ERR_RANGE) if a split16 forward since the last check stored an activation of
+        magnitude >= 6e4 (its features are NaN); synchronises the current stream.  Returns the largest |activation|
+        seen since ``probe_activations(True)`` (``None`` when the probe is off)."""
+        if self._handle is None:
+            return None
+        mx = C.c_float(-1.0)
+        with torch.cuda.device(self._packed_device):
+            _lib.check(_lib.load().eyoc_model_range_check(self._handle, _lib.stream_ptr(), C.byref(mx)), "eyoc_model_range_check")
+        return float(mx.value) if mx.value >= 0 else None
+
+    def probe_activations(self, on=True):
+        """Debug probe: keep the running maximum of |activation| over everything the split16 forwards store
+        (``check_range()`` returns it) - tells how far a checkpoint is from the fp16 range before trusting split16."""
+        self._probe = bool(on)
+        if self._handle is not None:
+            _lib.check(_lib.load().eyoc_model_set_probe(self._handle, 1 if on else 0), "eyoc_model_set_probe")
 
     # ------------------------------------------------------------------ arithmetic of the sparse convolutions
     _MATH = {"auto": -1, "fp32": 0, "split16": 1}
@@ -234,7 +281,8 @@ class ResUNet2(nn.Module):
     def spconv_math(self) -> str:
         """"auto" (default: split16 for batches that fill the chip, else fp32), "fp32" (v_mfma_f32_16x16x4_f32) or
         "split16" (three fp16 MFMAs per product on hi/lo-split fp16 operands - 22-bit significands, fp32
-        accumulation; activations must stay below 65504)."""
+        accumulation; activations must stay below 6e4: guarded - ``range_check`` / ``check_range()`` - and in "auto"
+        an overflowing forward is re-run in fp32)."""
         return {v: k for k, v in self._MATH.items()}[self._math]
 
     @spconv_math.setter

@@ -11,8 +11,11 @@
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises
  *     unless stated (eyoc_maps_build does: it must learn the data-dependent level sizes);
  *   - one eyoc_ctx per (process, device); a ctx is not re-entrant (one stream at a time).
- *   - floating point is fp32 throughout (the reference's dtype); indices are int32 on the device
- *     side and int64 where the reference hands int64 to its callers.
+ *   - every tensor that crosses this boundary is fp32 (the reference's dtype) and fp32 accumulates every sum; the
+ *     sparse-convolution PRODUCTS inside eyoc_model_forward run either as fp32 MFMAs or - "split16", automatic for
+ *     batches of >= 8192 rows - as three fp16 MFMAs on hi/lo-split operands (22-bit significands, range-guarded:
+ *     eyoc_model_set_math / eyoc_model_range_check); indices are int32 on the device side and int64 where the
+ *     reference hands int64 to its callers.
  */
 #ifndef EYOC_HIP_H
 #define EYOC_HIP_H
@@ -246,10 +249,19 @@ int eyoc_model_layer_work(eyoc_ctx* ctx, const eyoc_model* model, const eyoc_map
                           double* compulsory_bytes);
 /* Arithmetic of the sparse convolutions inside eyoc_model_forward: -1 automatic (default: split16 once the batch
  * has >= 8192 level-0 rows - else fp32), 0 fp32 MFMA, 1 split16 (three fp16 MFMAs per product on
- * hi/lo-split operands: 22-bit significands, fp32 accumulation; activations must stay below 65504).  Returns the
+ * hi/lo-split operands: 22-bit significands, fp32 accumulation; activations must stay below 6e4 - guarded, see
+ * eyoc_model_range_check).  Returns the
  * previous mode + 2, or a negative status.  eyoc_model_last_math: what the last forward used (0 / 1). */
 int eyoc_model_set_math(eyoc_model* model, int mode);
 int eyoc_model_last_math(const eyoc_model* model);
+/* Range guard of the split16 arithmetic.  Every kernel that stores split16 activations tracks the largest magnitude it
+ * writes; once one reaches 6e4 (before any fp16 half became inf) a sticky device flag is raised and the network's fp32
+ * output of that and every later split16 forward is all-NaN - never plausible-looking garbage.
+ * eyoc_model_range_check synchronises `stream`, returns EYOC_ERR_RANGE if the flag was raised since the last check (and
+ * clears it) else EYOC_OK; *max_abs (may be NULL) = largest |activation| stored since eyoc_model_set_probe(model, 1)
+ * switched the debug probe on (-1 when the probe is off).  fp32 forwards never raise it. */
+int eyoc_model_range_check(eyoc_model* model, void* stream, float* max_abs);
+int eyoc_model_set_probe(eyoc_model* model, int on);
 /* when `on`, eyoc_model_forward brackets every layer with hipEvents on `stream` and
  * eyoc_model_layer_ms returns the per-layer durations of the last forward (synchronises) */
 int eyoc_model_set_timing(eyoc_model* model, int on);
