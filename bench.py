@@ -54,6 +54,7 @@ from eyoc_amd.metrics import registration_errors  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_16x16x4_f32 dense peak
+MFMA_F16_PEAK_TF = 2500.0  # v_mfma_f32_16x16x32_f16 dense peak (MI355X_MICROARCH.md; never the 2:1-sparsity figure)
 REC = 20                   # floats per result record: 16 pose + RTE + RRE + success + rank
 
 
@@ -365,7 +366,7 @@ def worker(args):
         "n_gpus": world, "steps": steps_timed, "warmup": args.warmup,
         "ms_per_step": elapsed / steps_timed * 1e3,
         "higher_is_better": True, "scaling": "strong" if total_mode else "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic",        # refined below once the arithmetic of the forward is known
         "ranks_seen": ranks_seen,
         "per_rank_pairs_per_s": pairs_done / elapsed / world,
         "success_rate": float(np.nanmean(allrec[:, 18])),
@@ -410,26 +411,28 @@ def worker(args):
     kernel = ("spconv_st_kernel<2, 64, 2> (12 of the launches; + spconv_st_kernel<2, 32, 1>, spconv_up_kernel, spconv_wave_kernel, spconv_rs_kernel)"
               if math_mode == "split16" else "spconv_wave_kernel<...>") + " - the 22 sparse-conv launches of one forward, summed"
     if math_mode == "split16":
-        # split16: every algorithmic fp32 multiply-add is three fp16 MFMA multiply-adds (2.5 PFLOP/s dense peak), i.e. an
-        # ideal matrix time of 3 * flop / 2500 TF ~ 4 ms against SURVEY 8(d)'s gather bytes / 8 TB/s ~ 12 ms: by the
-        # survey's per-unit figures the HBM-side gather is the binding roof.  (The staged kernel re-uses gathered rows in
-        # LDS, so the measured traffic is BELOW the algorithmic gather bytes; what limits it in practice is MFMA issue
-        # over all 27 offsets of a tile, zero blocks included - DESIGN.md 3.2c.)
-        out["roofline"] = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None, "kernel": kernel,
-                           "algorithmic_bytes_per_forward": gather, "ms_per_forward": conv_ms, "math": math_mode}
+        # split16: every algorithmic fp32 multiply-add is three fp16 MFMA multiply-adds.  What binds these kernels is the
+        # fp16 matrix pipe (counters: the pipe is busy >50 % of the kernel time while HBM runs at ~20 % - the staged kernel
+        # re-uses gathered rows in LDS, so SURVEY 8(d)'s gather bytes mostly never reach HBM): the roofline is priced
+        # against the dense fp16 MFMA peak with the USEFUL products (3 x algorithmic flop; zero blocks the dense offset
+        # sweep also multiplies are not counted).  The survey's HBM-side gather figure stays in `hbm_gather`.
+        out["dtype"] = "f32 (split16 products: fp32 storage/accumulation, 3 fp16 MFMAs on hi/lo-split operands per product)"
+        out["roofline"] = {"bound": "mfma", "pipe": "fp16 matrix pipe (v_mfma_f32_16x16x32_f16), useful split16 products",
+                           "achieved": 3 * achieved_tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
+                           "frac": 3 * achieved_tf / MFMA_F16_PEAK_TF, "traffic": None, "traffic_measured_in_run": False,
+                           "kernel": kernel, "algorithmic_flop_per_forward": flops, "useful_fp16_flop_per_forward": 3 * flops,
+                           "ms_per_forward": conv_ms, "math": math_mode,
+                           "fp32_equivalent_TFLOPs": achieved_tf, "vs_fp32_mfma_peak": achieved_tf / MFMA_F32_PEAK_TF}
         out["dtype_note"] = ("fp32 storage and accumulation; sparse-conv products as three fp16 MFMAs on hi/lo-split operands "
-                             "(22-bit significands): error against fp64 equals the fp32-MFMA path's (tests/test_gpu_split16.py); "
-                             "--math fp32 runs v_mfma_f32_16x16x4_f32 instead")
-        out["mfma"] = {"fp32_equivalent_TFLOPs": achieved_tf, "fp16_mfma_issued_TFLOPs": 3 * achieved_tf,
-                       "fp16_mfma_peak_TFLOPs": 2500.0, "frac_of_fp16_peak": 3 * achieved_tf / 2500.0,
-                       "vs_fp32_mfma_peak": achieved_tf / MFMA_F32_PEAK_TF, "algorithmic_flop_per_forward": flops}
+                             "(22-bit significands): error against an fp64 forward <= 2x the fp32-MFMA path's "
+                             "(tests/test_gpu_split16.py); the same run's fp32-MFMA figure is in `fp32_math`")
     else:
         # fp32 MFMA: ideal matrix time (flop / 157.3 TF) is ~1.8x the ideal HBM time (gather bytes / 8 TB/s), so the
         # fp32 matrix pipe is the binding roof of these kernels
-        out["roofline"] = {"bound": "mfma", "achieved": achieved_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                           "frac": achieved_tf / MFMA_F32_PEAK_TF, "traffic": None, "kernel": kernel,
-                           "algorithmic_flop_per_forward": flops, "ms_per_forward": conv_ms, "math": math_mode}
+        out["roofline"] = {"bound": "mfma", "pipe": "fp32 matrix pipe (v_mfma_f32_16x16x4_f32)",
+                           "achieved": achieved_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                           "frac": achieved_tf / MFMA_F32_PEAK_TF, "traffic": None, "traffic_measured_in_run": False,
+                           "kernel": kernel, "algorithmic_flop_per_forward": flops, "ms_per_forward": conv_ms, "math": math_mode}
     out["hbm_gather"] = {"achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_forward": gather, "compulsory_bytes_per_forward": compulsory,
                          "traffic_over_compulsory": None}
@@ -461,6 +464,35 @@ def worker(args):
             b8 = DeviceBatch(pairs0[:8], seeds0[:8], device, cfg.n_points, descriptor=descriptor)
             out["batch8_pairs_per_s"] = 8 / timed_rate(pipe, b8, 10, 2)
         log("latency probes done")
+        # the SAME step at the reference's own arithmetic (fp32 products on v_mfma_f32_16x16x4_f32), same process, same
+        # batch: the figure to hold against a reference that multiplies in fp32 (model/resunet.py:31-140 -> sgemm)
+        if math_mode == "split16":
+            model.spconv_math = "fp32"
+            try:
+                pipe.register(b0)                                      # warm-up (maps in the caller's order, fp32 kernels)
+                model.set_timing(True)
+                model.timing_slot(0)
+                n32, ms32, lay32 = 5, 0.0, None
+                for _ in range(n32):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    pipe.register(b0)
+                    torch.cuda.synchronize()
+                    ms32 += (time.perf_counter() - t1) * 1e3
+                    l_ = np.array(model.layer_ms())
+                    lay32 = l_ if lay32 is None else lay32 + l_
+                assert model.last_spconv_math == "fp32"
+                conv32 = float(sum(lay32[i] for i in conv)) / n32
+                tf32 = flops / (conv32 * 1e-3) / 1e12
+                out["fp32_math"] = {"value": b0.P / (ms32 / n32 * 1e-3), "unit": "pairs/s", "ms_per_step": ms32 / n32, "steps": n32,
+                                    "note": "un-pipelined steps (each one synchronised), otherwise the headline's workload",
+                                    "roofline": {"bound": "mfma", "pipe": "fp32 matrix pipe (v_mfma_f32_16x16x4_f32)",
+                                                 "achieved": tf32, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                                 "frac": tf32 / MFMA_F32_PEAK_TF, "ms_per_forward": conv32}}
+            finally:
+                model.set_timing(False)
+                model.spconv_math = args.math
+            log("fp32-math leg done")
         # RANSAC cost against the inlier ratio (the number of surviving hypotheses grows like p^4)
         sweep = []
         for ratio in (0.0, 0.15, 0.3, 0.6):

@@ -103,6 +103,7 @@ PROTOTYPES = {
     "eyoc_model_set_probe": (_i, [_vp, _i]),
     "eyoc_spconv": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "eyoc_model_blob_floats": (_sz, [C.POINTER(ModelDesc)]),
+    "eyoc_model_pack_host": (_i, [C.POINTER(ModelDesc), C.POINTER(LayerParams), _i, _vp, _sz]),
     "eyoc_model_create": (_i, [_vp, C.POINTER(ModelDesc), C.POINTER(LayerParams), _i, _vp, _sz, C.POINTER(_vp)]),
     "eyoc_model_destroy": (_i, [_vp]),
     "eyoc_model_workspace_bytes": (_sz, [_vp, _vp]),

@@ -89,45 +89,44 @@ def sparse_conv(x: torch.Tensor, weight: torch.Tensor, table: torch.Tensor | Non
     return _SparseConv.apply(x, weight, table, table if mirror else table_t, mirror, n_out)
 
 
+def _draw_loss_samples(rng, n0, n1, n_pairs, num_hn_samples, num_pos):
+    """The three draws of lib/trainer.py:946-955 in the reference's ORDER (the order is contract: it fixes which numbers a
+    seeded ``np.random`` hands out): candidates of cloud 0, candidates of cloud 1, then - only when there are more
+    positives than ``num_pos`` - the positive subsample (``None`` = keep all)."""
+    cand = [rng.choice(n, min(n, num_hn_samples), replace=False) for n in (n0, n1)]
+    keep = rng.choice(n_pairs, num_pos, replace=False) if n_pairs > num_pos else None
+    return cand[0], cand[1], keep
+
+
+def _hardest_negative_term(anchor, cand_feats, cand_ids, anchor_key, cand_key_scale, known_positive_keys, neg_thresh):
+    """One direction of the negative term (lib/trainer.py:962-987): for every anchor row the nearest row of
+    ``cand_feats`` (``eyoc_knn1`` in "L2" mode, ties to the lowest index), dropped when (anchor, candidate) is itself a
+    known positive, penalised by ``relu(neg_thresh - d)^2``.  The distance is re-evaluated with torch ops on the two
+    gathered rows so the gradient reaches both ends, exactly where ``D.min(1)`` sends it."""
+    n = anchor.shape[0]
+    with torch.no_grad():
+        nearest = knn1_segmented(anchor.detach(), cand_feats.detach(), [0, n], [0, cand_feats.shape[0]], "L2", return_distance=False)
+    dist = torch.sqrt((anchor - cand_feats[nearest]).pow(2).sum(1) + 1e-7)
+    keys = anchor_key + cand_ids[nearest.cpu().numpy()] * cand_key_scale
+    is_negative = torch.from_numpy(~np.isin(keys, known_positive_keys)).to(anchor.device)
+    return torch.relu(neg_thresh - dist[is_negative]).pow(2).mean()
+
+
 def contrastive_hardest_negative_loss(F0, F1, positive_pairs, num_pos=5192, num_hn_samples=2048, pos_thresh=0.1, neg_thresh=1.4,
                                       rng=None):
-    """lib/trainer.py:935-991 -> ``(pos_loss, neg_loss)`` (0-dim tensors with grad).
-
-    ``rng`` replaces the reference's global ``np.random`` (three ``choice`` draws: the two hard-negative candidate
-    sets, then the positive subsample).  The nearest candidate of every positive comes from ``eyoc_knn1`` in "L2" mode
-    (``sqrt(d2 + 1e-7)``, ties to the lowest index); its distance is re-evaluated with torch ops on the two gathered
-    rows so that the gradient reaches both ends, exactly where ``D01.min(1)`` sends it."""
-    rng = np.random if rng is None else rng
-    N0, N1 = len(F0), len(F1)
-    pp = positive_pairs if isinstance(positive_pairs, torch.Tensor) else torch.as_tensor(np.asarray(positive_pairs))
-    N_pos_pairs = len(pp)
-    hash_seed = max(N0, N1)
-    sel0 = rng.choice(N0, min(N0, num_hn_samples), replace=False)
-    sel1 = rng.choice(N1, min(N1, num_hn_samples), replace=False)
-    if N_pos_pairs > num_pos:
-        pos_sel = rng.choice(N_pos_pairs, num_pos, replace=False)
-        sample_pos_pairs = pp[torch.as_tensor(pos_sel)]
-    else:
-        sample_pos_pairs = pp
+    """lib/trainer.py:935-991 -> ``(pos_loss, neg_loss)`` (0-dim tensors with grad).  ``rng`` replaces the reference's
+    global ``np.random``.  Pairs are identified by ``i + j * max(N0, N1)`` (util/misc.py:6-18 ``_hash``)."""
+    pairs = torch.as_tensor(np.asarray(positive_pairs)) if not isinstance(positive_pairs, torch.Tensor) else positive_pairs
+    pairs = pairs.long().cpu()
+    scale = max(len(F0), len(F1))
+    cand0, cand1, keep = _draw_loss_samples(np.random if rng is None else rng, len(F0), len(F1), len(pairs), num_hn_samples, num_pos)
+    used = pairs if keep is None else pairs[torch.as_tensor(keep)]
     dev = F0.device
-    sel0_d, sel1_d = torch.as_tensor(sel0).to(dev), torch.as_tensor(sel1).to(dev)
-    pos_ind0 = sample_pos_pairs[:, 0].long().to(dev)
-    pos_ind1 = sample_pos_pairs[:, 1].long().to(dev)
-    posF0, posF1 = F0[pos_ind0], F1[pos_ind1]
-    subF0, subF1 = F0[sel0_d], F1[sel1_d]
-    with torch.no_grad():
-        n_pos, c = posF0.shape
-        i01 = knn1_segmented(posF0.detach(), subF1.detach(), [0, n_pos], [0, len(sel1)], "L2", return_distance=False)
-        i10 = knn1_segmented(posF1.detach(), subF0.detach(), [0, n_pos], [0, len(sel0)], "L2", return_distance=False)
-    D01min = torch.sqrt((posF0 - subF1[i01]).pow(2).sum(1) + 1e-7)
-    D10min = torch.sqrt((posF1 - subF0[i10]).pow(2).sum(1) + 1e-7)
-    # hardest negatives that are themselves positives are masked out (hash of the index pair, like util/misc.py:6-18)
-    pos_keys = pp[:, 0].long().cpu().numpy() + pp[:, 1].long().cpu().numpy() * hash_seed
-    neg0 = pos_ind0.cpu().numpy() + sel1[i01.cpu().numpy()] * hash_seed
-    neg1 = sel0[i10.cpu().numpy()] + pos_ind1.cpu().numpy() * hash_seed
-    mask0 = torch.from_numpy(np.logical_not(np.isin(neg0, pos_keys))).to(dev)
-    mask1 = torch.from_numpy(np.logical_not(np.isin(neg1, pos_keys))).to(dev)
-    pos_loss = torch.relu((posF0 - posF1).pow(2).sum(1) - pos_thresh)
-    neg_loss0 = torch.relu(neg_thresh - D01min[mask0]).pow(2)
-    neg_loss1 = torch.relu(neg_thresh - D10min[mask1]).pow(2)
-    return pos_loss.mean(), (neg_loss0.mean() + neg_loss1.mean()) / 2
+    i0, i1 = used[:, 0].numpy(), used[:, 1].numpy()
+    a0, a1 = F0[used[:, 0].to(dev)], F1[used[:, 1].to(dev)]
+    all_keys = pairs[:, 0].numpy() + pairs[:, 1].numpy() * scale
+    # keys: (row of cloud 0) + (row of cloud 1) * scale in both directions
+    neg01 = _hardest_negative_term(a0, F1[torch.as_tensor(cand1).to(dev)], cand1, i0, scale, all_keys, neg_thresh)
+    neg10 = _hardest_negative_term(a1, F0[torch.as_tensor(cand0).to(dev)], cand0, i1 * scale, 1, all_keys, neg_thresh)
+    pos = torch.relu((a0 - a1).pow(2).sum(1) - pos_thresh).mean()
+    return pos, (neg01 + neg10) / 2

@@ -163,6 +163,51 @@ size_t eyoc_model_blob_floats(const eyoc_model_desc* desc) {
   return plan_blob_floats(L);
 }
 
+// Folds batch norm into every convolution and writes the packed blob (fp32 fragment order + split16 packing + shifts) into
+// HOST memory.  Pure host code: no device is touched, so a rank can build (or verify) the blob it broadcasts without a GPU.
+int eyoc_model_pack_host(const eyoc_model_desc* desc, const eyoc_layer_params* layers, int n_layers, float* blob_host,
+                         size_t blob_floats) {
+  EYOC_REQUIRE(layers && blob_host, EYOC_ERR_INVALID, "eyoc_model_pack_host: NULL argument");
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  std::vector<LayerPlan> plan;
+  BufPlan bufs[B_COUNT];
+  build_plan(*desc, plan, bufs);
+  const size_t need = plan_blob_floats(plan);
+  EYOC_REQUIRE(blob_floats >= need, EYOC_ERR_INVALID, "eyoc_model_pack_host: blob of %zu floats required, got %zu", need, blob_floats);
+  std::fill(blob_host, blob_host + need, 0.0f);
+  for (auto& p : plan) {
+    const eyoc_layer_params* cv = find_layer(layers, n_layers, p.name);
+    EYOC_REQUIRE(cv && cv->kernel && cv->K == p.K && cv->cin == p.cin && cv->cout == p.cout, EYOC_ERR_INVALID,
+                 "eyoc_model_create: layer '%s' missing or shape mismatch (expected K=%d cin=%d cout=%d, got %d %d %d)",
+                 p.name.c_str(), p.K, p.cin, p.cout, cv ? cv->K : -1, cv ? cv->cin : -1, cv ? cv->cout : -1);
+    std::vector<float> scale(p.cout, 1.0f), shift(p.cout, 0.0f);
+    if (!p.norm.empty()) {
+      const eyoc_layer_params* bn = find_layer(layers, n_layers, p.norm);
+      EYOC_REQUIRE(bn && bn->bn_weight && bn->bn_bias && bn->bn_mean && bn->bn_var && bn->cout == p.cout, EYOC_ERR_INVALID,
+                   "eyoc_model_create: norm '%s' missing or wrong width", p.norm.c_str());
+      for (int c = 0; c < p.cout; ++c) {
+        const float s = bn->bn_weight[c] / std::sqrt(bn->bn_var[c] + desc->bn_eps);
+        scale[c] = s;
+        shift[c] = bn->bn_bias[c] - bn->bn_mean[c] * s;
+      }
+    }
+    if (p.has_bias && cv->bias)
+      for (int c = 0; c < p.cout; ++c) shift[c] += cv->bias[c];
+    float* w = blob_host + p.w_off;
+    if (p.map == M_CONV1) {  // plain [K][cin][cout] with the scale folded in
+      for (size_t i = 0; i < (size_t)p.K * p.cin * p.cout; ++i) w[i] = cv->kernel[i] * scale[i % p.cout];
+    } else {
+      rc = eyoc_spconv_pack_weights(cv->kernel, scale.data(), p.K, p.cin, p.cout, w);
+      if (!rc) rc = eyoc_spconv_pack_weights_split16(cv->kernel, scale.data(), p.K, p.cin, p.cout, blob_host + p.w16_off,
+                                                     blob_host + p.s_off);
+      if (rc) return rc;
+    }
+    memcpy(blob_host + p.b_off, shift.data(), p.cout * sizeof(float));
+  }
+  return EYOC_OK;
+}
+
 int eyoc_model_create(eyoc_ctx* ctx, const eyoc_model_desc* desc, const eyoc_layer_params* layers, int n_layers,
                       float* blob_dev, size_t blob_floats, eyoc_model** out) {
   EYOC_REQUIRE(ctx && out && blob_dev, EYOC_ERR_INVALID, "eyoc_model_create: NULL argument");
@@ -181,41 +226,8 @@ int eyoc_model_create(eyoc_ctx* ctx, const eyoc_model_desc* desc, const eyoc_lay
   }
   if (layers) {
     std::vector<float> host(m->blob_floats, 0.0f);
-    for (auto& p : m->layers) {
-      const eyoc_layer_params* cv = find_layer(layers, n_layers, p.name);
-      if (!cv || !cv->kernel || cv->K != p.K || cv->cin != p.cin || cv->cout != p.cout) {
-        set_error("eyoc_model_create: layer '%s' missing or shape mismatch (expected K=%d cin=%d cout=%d, got %d %d %d)",
-                  p.name.c_str(), p.K, p.cin, p.cout, cv ? cv->K : -1, cv ? cv->cin : -1, cv ? cv->cout : -1);
-        delete m;
-        return EYOC_ERR_INVALID;
-      }
-      std::vector<float> scale(p.cout, 1.0f), shift(p.cout, 0.0f);
-      if (!p.norm.empty()) {
-        const eyoc_layer_params* bn = find_layer(layers, n_layers, p.norm);
-        if (!bn || !bn->bn_weight || !bn->bn_bias || !bn->bn_mean || !bn->bn_var || bn->cout != p.cout) {
-          set_error("eyoc_model_create: norm '%s' missing or wrong width", p.norm.c_str());
-          delete m;
-          return EYOC_ERR_INVALID;
-        }
-        for (int c = 0; c < p.cout; ++c) {
-          const float s = bn->bn_weight[c] / std::sqrt(bn->bn_var[c] + desc->bn_eps);
-          scale[c] = s;
-          shift[c] = bn->bn_bias[c] - bn->bn_mean[c] * s;
-        }
-      }
-      if (p.has_bias && cv->bias)
-        for (int c = 0; c < p.cout; ++c) shift[c] += cv->bias[c];
-      float* w = host.data() + p.w_off;
-      if (p.map == M_CONV1) {  // plain [K][cin][cout] with the scale folded in
-        for (size_t i = 0; i < (size_t)p.K * p.cin * p.cout; ++i) w[i] = cv->kernel[i] * scale[i % p.cout];
-      } else {
-        rc = eyoc_spconv_pack_weights(cv->kernel, scale.data(), p.K, p.cin, p.cout, w);
-        if (!rc) rc = eyoc_spconv_pack_weights_split16(cv->kernel, scale.data(), p.K, p.cin, p.cout, host.data() + p.w16_off,
-                                                       host.data() + p.s_off);
-        if (rc) { delete m; return rc; }
-      }
-      memcpy(host.data() + p.b_off, shift.data(), p.cout * sizeof(float));
-    }
+    rc = eyoc_model_pack_host(desc, layers, n_layers, host.data(), host.size());
+    if (rc) { delete m; return rc; }
     hipError_t e = hipMemcpy(blob_dev, host.data(), m->blob_floats * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       set_error("eyoc_model_create: weight upload failed: %s", hipGetErrorString(e));

@@ -45,18 +45,28 @@ def broadcast_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
     return blob
 
 
+def _aligned_blob(n: int, device) -> torch.Tensor:
+    """``n`` floats at a 256-byte aligned address (``eyoc_model_create`` requires it)."""
+    raw = torch.zeros(n + 64, dtype=torch.float32, device=device)
+    off = ((-raw.data_ptr()) % 256) // 4
+    return raw[off:off + n]
+
+
 def broadcast_model(model, device, src: int = 0):
-    """Rank ``src`` packs its parameters; everyone else adopts the broadcast blob."""
+    """Rank ``src`` packs its parameters; everyone else adopts the broadcast blob (one message).
+
+    On a GPU the blob is packed into / received in device memory (RCCL) and every rank ends with a device-side model.
+    With ``device = cpu`` (gloo; tests/test_dist_gloo.py) the same message travels between host buffers
+    (``model.pack_host()`` on ``src``) and nothing is adopted - the returned tensor is what a GPU rank would adopt."""
+    device = torch.device(device)
     rank = dist.get_rank() if dist.is_initialized() else 0
+    on_gpu = device.type == "cuda"
     if rank == src:
-        blob = model.pack(device)
+        blob = model.pack(device) if on_gpu else model.pack_host()
     else:
-        n = model.blob_floats()
-        raw = torch.zeros(n + 64, dtype=torch.float32, device=device)
-        off = ((-raw.data_ptr()) % 256) // 4
-        blob = raw[off:off + n]
+        blob = _aligned_blob(model.blob_floats(), device)
     broadcast_blob(blob, src)
-    if rank != src:
+    if rank != src and on_gpu:
         model.pack(device, blob=blob, from_blob=True)
     return blob
 

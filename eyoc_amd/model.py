@@ -175,6 +175,17 @@ class ResUNet2(nn.Module):
         changed; it is MANDATORY after edits that fingerprint cannot see (``p.data`` edits, writes through views)."""
         return self.pack(self._packed_device)
 
+    def pack_host(self) -> torch.Tensor:
+        """The packed blob as a CPU tensor (``eyoc_model_pack_host``: batch norms folded, fp32 fragment order + split16
+        packing) - byte for byte what ``pack()`` uploads.  Needs the shared library but no GPU."""
+        lib = _lib.load()
+        blob = torch.zeros(self.blob_floats(), dtype=torch.float32)
+        d = self._desc()
+        layers, nl, keep = self._layer_params()
+        _lib.check(lib.eyoc_model_pack_host(C.byref(d), layers, nl, C.c_void_p(blob.data_ptr()), blob.numel()), "eyoc_model_pack_host")
+        del keep
+        return blob
+
     def pack(self, device=None, blob: torch.Tensor | None = None, from_blob=False):
         """(Re)create the device-side model.  ``from_blob=True`` adopts an already packed blob (the
         receiving side of the weight broadcast) instead of packing this module's parameters."""

@@ -53,33 +53,38 @@ def voxelize(xyz, voxel_size: float, batch_index: int = 0):
     return pts, coords, torch.ones((len(sel), 1), dtype=torch.float32, device=coords.device)
 
 
+def _optional_channels(name, arr, n_points, upper):
+    """One optional per-point attribute of ``extract_features``: ``None`` or a ``[n_points, 3]`` array with no value
+    above ``upper`` (the reference refuses colours / normals above 1, util/misc.py:47-57)."""
+    if arr is None:
+        return None
+    a = np.asarray(arr)
+    if a.ndim != 2 or a.shape != (n_points, 3):
+        raise AssertionError(f"{name} must be [{n_points}, 3], got {tuple(a.shape)}")
+    if float(a.max(initial=-np.inf)) > upper:
+        raise ValueError("Invalid color. Color must range from [0, 1]" if name == "rgb"
+                         else "Invalid normal. Normal must range from [-1, 1]")
+    return a
+
+
 def extract_features(model, xyz, rgb=None, normal=None, voxel_size=0.05, device=None, skip_check=False, is_eval=True):
-    """util/misc.py:21-93 - voxelise one cloud, run the model, return ``(xyz[inds], features)``."""
+    """Voxelise one cloud, run ``model`` on it and return ``(xyz of the kept points, their features)`` - the one-call API
+    of util/misc.py:21-93.  Input channels, in the reference's order: colour shifted to [-0.5, 0.5], normal halved, or a
+    single column of ones when neither is given.  The de-duplication runs on the GPU first; only the kept rows of the
+    attributes are shifted / scaled and uploaded."""
     if is_eval:
         model.eval()
-    xyz = np.asarray(xyz)
+    pts = np.asarray(xyz)
     if not skip_check:
-        assert xyz.shape[1] == 3
-        N = xyz.shape[0]
-        if rgb is not None:
-            assert N == len(rgb) and rgb.shape[1] == 3
-            if np.any(rgb > 1):
-                raise ValueError('Invalid color. Color must range from [0, 1]')
-        if normal is not None:
-            assert N == len(normal) and normal.shape[1] == 3
-            if np.any(normal > 1):
-                raise ValueError('Invalid normal. Normal must range from [-1, 1]')
-    if device is None:
-        device = torch.device("cuda:0")
-    feats = []
-    if rgb is not None:
-        feats.append(rgb - 0.5)
-    if normal is not None:
-        feats.append(normal / 2)
-    if rgb is None and normal is None:
-        feats.append(np.ones((len(xyz), 1)))
-    feats = np.hstack(feats)
-    coords, inds = sparse_quantize(torch.from_numpy(xyz.astype(np.float32)).to(device), voxel_size)
-    inds_h = inds.cpu().numpy()
-    stensor = SparseTensor(torch.tensor(feats[inds_h], dtype=torch.float32, device=device), coordinates=coords)
-    return xyz[inds_h], model(stensor).F
+        if pts.ndim != 2 or pts.shape[1] != 3:
+            raise AssertionError(f"xyz must be [N, 3], got {tuple(pts.shape)}")
+        rgb = _optional_channels("rgb", rgb, len(pts), 1.0)
+        normal = _optional_channels("normal", normal, len(pts), 1.0)
+    dev = torch.device("cuda:0") if device is None else torch.device(device)
+    coords, kept = sparse_quantize(torch.from_numpy(np.ascontiguousarray(pts, np.float32)).to(dev), voxel_size)
+    kept_host = kept.cpu().numpy()
+    # arithmetic in the attribute's own dtype, then ONE rounding to fp32 (what `torch.tensor(rgb - 0.5, float32)` does)
+    columns = [torch.as_tensor(np.asarray(a)[kept_host] * scale + shift, dtype=torch.float32, device=dev)
+               for a, scale, shift in ((rgb, 1.0, -0.5), (normal, 0.5, 0.0)) if a is not None]
+    feats = torch.cat(columns, dim=1) if columns else torch.ones((len(kept_host), 1), dtype=torch.float32, device=dev)
+    return pts[kept_host], model(SparseTensor(feats, coordinates=coords)).F

@@ -233,6 +233,11 @@ typedef struct {
 } eyoc_layer_params;
 
 size_t eyoc_model_blob_floats(const eyoc_model_desc* desc);
+/* Host-only packing (touches no device): folds the batch norms and writes the blob eyoc_model_create would upload into
+ * blob_host (>= eyoc_model_blob_floats() floats).  Lets the broadcasting rank build - and a CPU test verify - the exact
+ * bytes that travel over RCCL; eyoc_model_create(layers != NULL) = this + one hipMemcpy. */
+int eyoc_model_pack_host(const eyoc_model_desc* desc, const eyoc_layer_params* layers, int n_layers,
+                         float* blob_host, size_t blob_floats);
 int eyoc_model_create(eyoc_ctx* ctx, const eyoc_model_desc* desc, const eyoc_layer_params* layers,
                       int n_layers, float* blob_dev, size_t blob_floats, eyoc_model** out);
 int eyoc_model_destroy(eyoc_model* model);

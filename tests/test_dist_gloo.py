@@ -59,3 +59,39 @@ def test_single_process_is_a_no_op():
     assert edist.gather_records(t[None]) is not None
     assert edist.max_over_ranks(3.5, torch.device("cpu")) == 3.5
     edist.barrier()
+
+
+def _model_worker(rank, world, port, out_dir):
+    """``broadcast_model`` itself, on the real packed blob (eyoc_model_pack_host: no GPU needed): rank 0 holds the seeded
+    weights, rank 1 a differently initialised module; after the broadcast rank 1's buffer must be rank 0's bytes."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import eyoc_amd
+    from eyoc_amd import synthetic as syn
+    edist.init(backend="gloo")
+    Model = eyoc_amd.load_model("ResUNetBN2C")
+    model = Model(1, 32, bn_momentum=0.05, conv1_kernel_size=5, normalize_feature=True)
+    if rank == 0:
+        sd = syn.make_weights()
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    own = model.pack_host()                                    # what this rank would pack from its own parameters
+    blob = edist.broadcast_model(model, torch.device("cpu"), src=0)
+    assert blob.numel() == model.blob_floats()
+    if rank == 0:
+        assert torch.equal(blob, own)
+    else:
+        assert not torch.equal(blob, own), "rank 1 packed different weights - the test would prove nothing"
+    np.save(os.path.join(out_dir, f"blob{rank}.npy"), blob.numpy().view(np.uint32))
+    dist.destroy_process_group()
+
+
+def test_broadcast_model_ships_the_real_packed_blob(tmp_path):
+    from eyoc_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libeyoc_hip.so not built")
+    world = 2
+    mp.spawn(_model_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "blob0.npy"), np.load(tmp_path / "blob1.npy")
+    assert a.size > 8_000_000                                       # BN2C: fp32 + split16 packing of every layer
+    np.testing.assert_array_equal(a, b)                             # bit-identical on both ranks
+    assert np.count_nonzero(a) > a.size // 2

@@ -136,7 +136,8 @@ def test_split16_layer_is_as_accurate_as_fp32_mfma(maps, cin, cout):
     got16s = run_layer_split(nbr, x, W, bias=b, scale=s, res=r, relu=True, out_split=True)
     e32, e16, e16s = rel_err(got32, want), rel_err(got16, want), rel_err(got16s, want)
     print(f"{cin}->{cout}: vs fp64  fp32-mfma {e32:.2e}  split16 {e16:.2e}  split16 + split store {e16s:.2e}")
-    assert e16 < 2e-6 and e16s < 2e-6 and e16 < 8 * e32 + 2e-7
+    # the claim of DESIGN 3.2b, as worded: split16's error is the fp32-MFMA path's own (not merely 'inside 1e-4')
+    assert e16 < 2e-6 and e16s < 2e-6 and e16 <= 2 * e32 + 1e-7 and e16s <= 2 * e32 + 1e-7
 
 
 def test_split16_identity_strided_transposed_and_ragged(maps):
@@ -159,6 +160,28 @@ def test_split16_identity_strided_transposed_and_ragged(maps):
         x = rng.normal(size=(len(c), 32)).astype(np.float32)
         W = (rng.normal(size=(27, 32, 32)) / 10).astype(np.float32)
         assert rel_err(run_layer_split(nbr, x, W), layer_f64(nbr, x, W)) < 2e-6
+
+
+def test_split16_forward_error_growth_against_fp64():
+    """Error growth over the 23 layers: the whole forward of a ~5k-voxel cloud in both arithmetics against the oracle run
+    in float64 (oracle/resunet.py dtype=torch.float64).  split16 must not be worse than twice the fp32-MFMA path."""
+    from eyoc_amd import synthetic as syn
+    from oracle import resunet as orr
+    from test_gpu_round2 import _model
+    p = syn.make_pair(5, beams=24, azimuths=700, band=None)
+    coords = syn.batch_coords([p["coords0"]])
+    assert 3000 < len(coords) < 12000, len(coords)
+    model, sd = _model()
+    want = orr.resunet_forward(sd, coords, p["feats0"], dtype=torch.float64).numpy()
+    errs = {}
+    for mode in ("fp32", "split16"):
+        model.spconv_math = mode
+        got = _forward(model, coords, p["feats0"]).astype(np.float64)
+        assert model.last_spconv_math == mode
+        errs[mode] = float(np.abs(got - want).max() / np.abs(want).max())
+    model.spconv_math = "auto"
+    print(f"forward vs fp64 oracle ({len(coords)} voxels): fp32-mfma {errs['fp32']:.2e}  split16 {errs['split16']:.2e}")
+    assert errs["fp32"] < 1e-5 and errs["split16"] <= 2 * errs["fp32"] + 1e-7, errs
 
 
 def _forward(model, coords, feats):
