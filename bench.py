@@ -79,6 +79,8 @@ def parse_args(argv=None):
     ap.add_argument("--overlap-maps", action="store_true",
                     help="build the next step's coordinate maps on a side stream while the current step runs (measured: "
                          "+0.5 % - the conv and RANSAC kernels fill the register files, the side stream only runs in their tails)")
+    ap.add_argument("--st-variant", type=int, default=-1,
+                    help="diagnostics: staged-kernel implementation (eyoc_spconv_select_st_kernel: 0 C++ loop, 1 assembly loop, 2 assembly without empty-block branches)")
     ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
     return ap.parse_args(argv)
 
@@ -263,6 +265,9 @@ def worker(args):
         torch.cuda.set_device(device)
         model, sd = build_model(device, rank)
         model.spconv_math = args.math
+        if args.st_variant >= 0:
+            from eyoc_amd import _lib as _l
+            _l.load().eyoc_spconv_select_st_kernel(args.st_variant)
         log("model packed")
         cfg = RegistrationConfig(ransac_max_iteration=args.ransac_iters)
         pipe, Batch = RegistrationPipeline(model, cfg), DeviceBatch

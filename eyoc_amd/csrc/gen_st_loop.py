@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Generates spconv_st_loop.inc: the hand-scheduled offset loop of the staged sparse convolution (spconv_st.hip) as
+gfx950 inline-assembly text, one blob per (pass, 32-channel block) of a tile.
+
+Why generated assembly: the C++ version of this loop (27 offsets x NH half-steps, fully unrolled) came out of hipcc at
+256 VGPRs with spills, its LDS operand reads issued BEHIND the MFMAs that free their registers (each half-step then
+starts with an exposed `s_waitcnt lgkmcnt(0)`), and any scalar branch around an MFMA group made the compiler drain its
+load counters at the join.  Here every register is assigned by hand (192 VGPRs), the operand reads of half-step s+1 are
+issued ahead of the MFMAs of half-step s (true double buffer), weight fragments run WD offsets ahead and rulebook
+entries two, every wait is an exact in-order count, and an EMPTY (16-row chunk, offset) block - no row of the chunk has
+a neighbour at the offset, one bit of a mask the rulebook builder stores - costs two scalar instructions and a short
+forward branch instead of 6 MFMAs (scripts/micro/mfma_dep.hip: a skipped group costs ~12 cycles next to active ones,
+108 when multiplied; out-of-line stubs cost ~30 more).
+
+Register map (per wave; NH row halves of 64 rows, NC = 4 chunks of 16 rows, NTW = 2 output-channel tiles of 16):
+  v[64 ..]   accumulators  ACC(h, c, t) = 64 + ((h*4 + c)*2 + t)*4          (pinned operands of the asm statement)
+  v[128:191] operand sets  X(s, c, p)   = 128 + s*32 + (c*2 + p)*4          s: half-step parity, p: 0 hi / 1 lo halves
+  v[192:239] weight sets   W(s, t, p)   = 192 + s*16 + (t*2 + p)*4          s = k % (WD+1); lane constants behind them
+  v[240:251] rulebook sets L(s, h)      = 240 + (s*NH + h)*2                s = k % 3; uint2 = four 16-bit LDS slots
+  v[252:255] address temporaries
+  s[36:49]   occupancy masks: bit (k&1)*16 + h*4 + c of s[36 + k/2]         (pinned operands)
+"""
+import sys
+
+K, NC, NTW = 27, 4, 2
+
+
+def gen(NH, WD, skip=True, abl=()):
+    NWS = WD + 1
+    ACC = lambda h, c, t: 64 + ((h * NC + c) * NTW + t) * 4
+    XS = lambda s, c, p: 128 + s * 32 + (c * 2 + p) * 4
+    WS = lambda s, t, p: 192 + s * 16 + (t * 2 + p) * 4
+    LS = lambda s, h: 240 + (s * NH + h) * 2
+    T = [252, 253, 254, 255]
+    # lane constants, computed in the prologue (no VGPR operands: nothing for the compiler to spill around the blob):
+    # GH = (lane >> 4) << 4 (XOR term of the hi piece), WL0 / WL1 = byte offsets of the lane's weight fragments of channel
+    # tiles 0 / 1, LV = (lane & 15) * 8 (+ 4096 per 8 offsets) = offset of the lane's rulebook entries, C4 = 4
+    CR = 224 if WD == 1 else (96 if NH == 1 else None)
+    assert CR is not None, "no free registers for the lane constants (NH = 2 needs WD = 1)"
+    GH, WL0, WL1, LV, C4 = (f"v{CR + i}" for i in range(5))
+    vr = lambda n, w=4: f"v[{n}:{n + w - 1}]"
+    out, stubs = [], []
+    vmq, lgq = [], []          # issue history of VMEM / LDS operations (tags), oldest first
+
+    def emit(s):
+        out.append(s)
+
+    done = [-1]                # VMEM operations up to this index of vmq are known to have landed
+
+    def wait_vm(tag):
+        if tag not in vmq:
+            return
+        idx = len(vmq) - 1 - vmq[::-1].index(tag)
+        if idx <= done[0]:
+            return
+        emit(f"s_waitcnt vmcnt({min(len(vmq) - 1 - idx, 63)})")
+        done[0] = idx
+
+    def lg_count(tag):
+        if tag not in lgq:
+            return 15
+        idx = len(lgq) - 1 - lgq[::-1].index(tag)
+        return min(len(lgq) - 1 - idx, 15)
+
+    def issue_w(k):
+        s = k % NWS
+        if "now" in abl:
+            return
+        for t in range(NTW):
+            for p in range(2):
+                emit(f"buffer_load_dwordx4 {vr(WS(s, t, p))}, {(WL0, WL1)[t]}, %[wr], %[so] offen offset:{p * 1024}")
+                vmq.append(("W", k))
+        emit("s_add_u32 %[so], %[so], %[ks]")
+
+    def issue_l(k):
+        if k % 8 == 0 and k > 0:
+            emit(f"v_add_u32 {LV}, 0x1000, {LV}")
+        for h in range(NH):
+            emit(f"global_load_dwordx2 {vr(LS(k % 3, h), 2)}, {LV}, %[lb] offset:{(k % 8) * 512 + h * 128}")
+            vmq.append(("L", k))
+
+    def addr(k, h, c, t0, t1):
+        """LDS addresses of the hi / lo pieces of chunk c's rows at (k, h): slot field << 4, XOR lane piece, + base"""
+        reg = LS(k % 3, h) + (c >> 1)
+        if "nov" in abl:
+            return
+        emit(f"v_lshlrev_b32_sdwa v{t0}, {C4}, v{reg} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_{c & 1}")
+        emit(f"v_xad_u32 v{t0}, v{t0}, {GH}, %[xb]")
+        emit(f"v_xor_b32 v{t1}, 64, v{t0}")
+
+    def read(hs, c, p, t):
+        if "nox" in abl:
+            return
+        emit(f"ds_read_b128 {vr(XS(hs & 1, c, p))}, v{t}")
+        lgq.append(("X", hs, c))
+
+    def mfma(h, c, t, term, k, hs):
+        a = WS(k % NWS, t, 1 if term == 2 else 0)
+        b = XS(hs & 1, c, 1 if term == 1 else 0)
+        acc = vr(ACC(h, c, t))
+        emit(f"v_mfma_f32_16x16x32_f16 {acc}, {vr(a)}, {vr(b)}, {acc}")
+
+    # ---- prologue: first weights / rulebook entries, stage landed, barrier, operands of half-step 0
+    emit("s_mov_b32 %[so], %[ws0]")
+    emit(f"v_mbcnt_lo_u32_b32 {LV}, -1, 0")
+    emit(f"v_mbcnt_hi_u32_b32 {LV}, -1, {LV}")
+    emit(f"v_and_b32 {GH}, 48, {LV}")
+    emit(f"v_lshlrev_b32 {WL0}, 4, {LV}")
+    emit(f"v_add_u32 {WL1}, %[w1], {WL0}")
+    emit(f"v_and_b32 {LV}, 15, {LV}")
+    emit(f"v_lshlrev_b32 {LV}, 3, {LV}")
+    emit(f"v_mov_b32 {C4}, 4")
+    for k in range(WD):
+        issue_w(k)
+    issue_l(0)
+    issue_l(1)
+    emit("s_waitcnt vmcnt(0)")
+    done[0] = len(vmq) - 1
+    emit("s_barrier")
+    for c in range(NC):
+        t0, t1 = T[(c & 1) * 2], T[(c & 1) * 2 + 1]
+        addr(0, 0, c, t0, t1)
+        read(0, c, 0, t0)
+        read(0, c, 1, t1)
+
+    # ---- the half-steps
+    for k in range(K):
+        for h in range(NH):
+            hs = k * NH + h
+            has_next = hs + 1 < K * NH
+            kn, hn = divmod(hs + 1, NH)
+            if h == 0:
+                if k + WD < K:
+                    issue_w(k + WD)
+                if k + 2 < K:
+                    issue_l(k + 2)
+                wait_vm(("W", k))
+            if has_next:
+                wait_vm(("L", kn))
+            for c in range(NC):
+                t0, t1 = T[(c & 1) * 2], T[(c & 1) * 2 + 1]
+                if has_next:
+                    addr(kn, hn, c, t0, t1)
+                lab = f"k{k}h{h}c{c}"
+                if has_next:
+                    read(hs + 1, c, 0, t0)
+                    read(hs + 1, c, 1, t1)
+                if skip:
+                    emit(f"s_bitcmp1_b32 s{36 + (k >> 1)}, {(k & 1) * 16 + h * 4 + c}")
+                    emit(f"s_cbranch_scc0 .Lst%=_{lab}")
+                emit(f"s_waitcnt lgkmcnt({lg_count(('X', hs, c))})")
+                for term in range(3):
+                    mfma(h, c, 0, term, k, hs)
+                    mfma(h, c, 1, term, k, hs)
+                if skip:
+                    emit(f".Lst%=_{lab}:")
+    emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    emit("s_nop 7")
+    emit("s_nop 7")
+    emit("s_nop 7")
+    return out
+
+
+def clobbers():
+    return ", ".join(f'"v{i}"' for i in range(128, 256))
+
+
+def main(path):
+    with open(path, "w") as f:
+        f.write("// GENERATED by gen_st_loop.py - do not edit.  The offset loop of spconv_st_kernel as gfx950 assembly text\n")
+        f.write("// (register map, schedule and wait counts: see the generator).\n")
+        for name, NH, WD, skip, abl in (("NH2", 2, 1, True, ()), ("NH1", 1, 2, True, ()), ("NH2_NOSKIP", 2, 1, False, ()),
+                                        ("NH2_NOW", 2, 1, True, ("now",)), ("NH2_NOX", 2, 1, True, ("nox", "nov")),
+                                        ("NH2_NOV", 2, 1, True, ("nov",))):
+            lines = gen(NH, WD, skip, abl)
+            f.write(f"#define EYOC_ST_LOOP_{name} \\\n")
+            for ln in lines:
+                f.write(f'  "{ln}\\n\\t" \\\n')
+            f.write('  ""\n')
+        f.write(f"#define EYOC_ST_LOOP_CLOBBERS {clobbers()}\n")
+        f.write('#define EYOC_ST_LOOP_CLOBBERS_NH1 EYOC_ST_LOOP_CLOBBERS, "v96", "v97", "v98", "v99", "v100"\n')
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else __file__.replace("gen_st_loop.py", "spconv_st_loop.inc"))

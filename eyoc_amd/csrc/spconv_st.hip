@@ -20,7 +20,7 @@
 // waves of a SIMD fill each other's LDS / L2 latencies.  (The first version of this kernel staged per WAVE, 32 KB each,
 // one wave per SIMD: every stage, prologue and epilogue was exposed - 2.3 ms on the 3.8M-row 64 -> 64 layer, MFMA
 // pipe 43% busy; scripts/bench_staged.py + the EYOC_ST_ABL builds have the breakdown.)
-#include <cstdlib>
+#include <atomic>
 
 #include "spconv.h"
 
@@ -44,7 +44,11 @@ constexpr int NIT = XROWS / (8 * NW);                      // staging instructio
 // int U[UCAP]; uint2 loc[NPASS][27][64]: entry (pass, k, 16 w + j) packs, as four 16-bit values v = 8 l + (l & 7), the
 // LDS slots l of the neighbours at offset k of output rows 64 w + 16 c + j, c = 0..3 (slot UMAX = no neighbour, or a
 // neighbour staged in the other pass).  v << 4 is the LDS address of the row's first piece with the swizzle applied.
-constexpr int LR_BYTES = 16 + UCAP * 4 + NPASS * 27 * 64 * 8;   // 32784
+// Then, per pass, 27 (+1 pad) 16-bit occupancy masks: bit 4 w + c of mask (pass, k) = some row of rows 64 w + 16 c .. +15 has a
+// neighbour at offset k that is staged in this pass (the hand-scheduled loop skips the MFMAs of a chunk whose bit is clear).
+constexpr int MASK_OFF = 16 + UCAP * 4 + NPASS * 27 * 64 * 8;   // 32784
+constexpr int MASK_PASS_BYTES = 56;
+constexpr int LR_BYTES = MASK_OFF + NPASS * MASK_PASS_BYTES;    // 32896
 constexpr int HSLOTS = 8192;                               // > 256 * 27 possible distinct rows: probing always terminates
 
 __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restrict__ nbr, int K, int n_out, unsigned char* __restrict__ out,
@@ -105,6 +109,8 @@ __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restric
   __syncthreads();
   // 3. LDS slot of every (offset, row): row r = 64 w + 16 c + j goes to 16-bit lane c of entry (k, 16 w + j)
   unsigned short* loc = reinterpret_cast<unsigned short*>(lr + 16 + UCAP * 4);
+  unsigned char* msk = lr + MASK_OFF;
+  __shared__ unsigned char nib[NPASS][27][NW];
   const int r = (int)threadIdx.x, w = r >> 6, c = (r >> 4) & 3, j = r & 15;
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
@@ -114,7 +120,18 @@ __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restric
       if (p > 0 && total <= p * UMAX) continue;                         // nobody reads the entries of a pass that does not happen
       const int l = (id >= p * UMAX && id < (p + 1) * UMAX) ? id - p * UMAX : UMAX;
       loc[(((size_t)(p * 27 + k) * 64) + w * 16 + j) * 4 + c] = (unsigned short)(l * 8 + (l & 7));
+      const unsigned long long b = __ballot(l != UMAX);                  // 16 lanes per chunk
+      if (lane == 0)
+        nib[p][k][w] = (unsigned char)(((b & 0xFFFFull) != 0) | (((b >> 16) & 0xFFFFull) != 0) << 1 | (((b >> 32) & 0xFFFFull) != 0) << 2 |
+                                       (((b >> 48) & 0xFFFFull) != 0) << 3);
     }
+  }
+  __syncthreads();
+  if (threadIdx.x < NPASS * 28) {
+    const int p = (int)threadIdx.x / 28, k = (int)threadIdx.x % 28;
+    unsigned short m = 0;
+    if (k < 27 && !(p > 0 && total <= p * UMAX)) m = (unsigned short)(nib[p][k][0] | nib[p][k][1] << 4 | nib[p][k][2] << 8 | nib[p][k][3] << 12);
+    reinterpret_cast<unsigned short*>(msk)[p * 28 + k] = m;
   }
 }
 
@@ -323,6 +340,159 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_kernel(SpconvArgs a, con
   if (a.out_split) split16_report(a.range, mx);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same kernel with the offset loop as hand-scheduled assembly (spconv_st_loop.inc, generated by gen_st_loop.py: register
+// map, double-buffered operand reads interleaved with the MFMAs, exact wait counts, scalar branches around the MFMAs of
+// empty (16-row chunk, offset) blocks).  NTW = 2 output-channel tiles per wave; NH = 2: 128 rows x 32 channels per wave
+// (2 row halves x 2 channel halves per workgroup, >= 64 output channels), NH = 1: 64 rows x 32 channels (32-channel layers).
+// The stage lives in STATIC shared memory (80 KB; gfx950 allows 160 KB per workgroup), so the LDS base is 0 by
+// construction and no per-device function attribute is needed.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
+
+#include "spconv_st_loop.inc"
+
+template <int CC, int NH, int SKIP>
+__global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a, const unsigned char* __restrict__ local, int n_tiles) {
+  constexpr int NTW = 2, CTW = NTW * 16, NC = 4;
+  constexpr int CTG = CTW * NH;
+  __shared__ __attribute__((aligned(128))) unsigned char xs[X_BYTES];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int g = lane >> 4, j = lane & 15;
+  const int n_cg = a.cout / CTG;
+  const int xcd = (int)blockIdx.x & 7, per = 8 / n_cg;
+  const int cg = xcd % n_cg, tile = ((int)blockIdx.x >> 3) * per + xcd / n_cg;
+  if (tile >= n_tiles) return;
+  const int w0 = NH == 1 ? wave : 2 * (wave >> 1);
+  const int row0 = tile * TILE + w0 * 64;
+  const int ct0 = cg * CTG + (NH == 2 ? (wave & 1) * CTW : 0);
+  const int CT = a.cout >= 128 ? 128 : a.cout;
+  const int n_slices = a.cout / CT, slice = ct0 / CT, nt0 = (ct0 - slice * CT) / 16;
+  constexpr int JQ = CC / 16;
+  const int ncc = a.cin / CC;
+  const int nqb = a.cin / 32;
+  constexpr int K = 27;
+
+  const unsigned char* lr = local + (size_t)tile * LR_BYTES;
+  const int n_u = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(lr)[0]);
+  const int* __restrict__ U = reinterpret_cast<const int*>(lr + 16);
+  const int n_pass = n_u > UMAX ? 2 : 1;
+  if (threadIdx.x < 8) *reinterpret_cast<float4*>(xs + UMAX * 128 + threadIdx.x * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // raw buffer resource of the packed weights (stride 0, byte-granular bounds, the flags make_buffer_rsrc takes elsewhere)
+  const unsigned long long wbits = (unsigned long long)(size_t)a.w;
+  u32x4 wr;
+  wr[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wbits);
+  wr[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(wbits >> 32) & 0xFFFFu));
+  wr[2] = (unsigned)__builtin_amdgcn_readfirstlane(K * a.cin * a.cout * 4);
+  wr[3] = 0x00020000u;
+  const int tile4 = CC * CT / 4;
+  const unsigned int kstride = (unsigned)(n_slices * ncc * tile4 * 16);
+  const unsigned int w1off = JQ * 1024;                                // byte distance of the second channel tile's fragments
+  const unsigned int xb = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)xs;
+
+  f32x16 A0, A1, A2, A3;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { A0[i] = 0.f; A1[i] = 0.f; A2[i] = 0.f; A3[i] = 0.f; }
+
+  int n_up = 0;
+  auto stage = [&](int pass, int qb) {
+    if constexpr (SKIP == 6) return;                                   // EYOC_ST_ABLATIONS: no stage
+    int Ureg[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int l = (it * NW + wave) * 8 + (lane >> 3);
+      asm volatile("" : "+v"(l));
+      Ureg[it] = l < n_up ? U[pass * UMAX + l] : 0;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int l0 = (it * NW + wave) * 8;
+      if (l0 < n_up) {
+        const int l = l0 + (lane >> 3);
+        const float* src = a.in + (size_t)Ureg[it] * a.ld_in + qb * 32 + (((lane & 7) ^ (l & 7)) << 2);
+        if (l < n_up)
+          __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(xs + l0 * 128), 16, 0, 0);
+      }
+    }
+  };
+
+  bool first = true;
+  for (int pass = 0; pass < n_pass; ++pass) {
+    n_up = min(n_u - pass * UMAX, UMAX);
+    // this wave's occupancy masks of the pass: 14 dwords through the scalar cache, shifted so that bit (k & 1) * 16 + 4 h + c
+    // of dword k / 2 is chunk c of the wave's row half h
+    const unsigned int* mp = reinterpret_cast<const unsigned int*>(lr + MASK_OFF + pass * MASK_PASS_BYTES);
+    u32x8 M0, M1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      M0[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)mp[i]) >> (w0 * 4);
+      M1[i] = i < 6 ? (unsigned)__builtin_amdgcn_readfirstlane((int)mp[8 + i]) >> (w0 * 4) : 0u;
+    }
+    // rulebook entries of (pass, k, h): 8 bytes at lb + lv + (k * 64 + h * 16) * 8
+    const unsigned char* lb = lr + 16 + UCAP * 4 + ((size_t)pass * 27 * 64 + w0 * 16) * 8;
+    for (int qb = 0; qb < nqb; ++qb) {
+      if (!first) __syncthreads();                                     // every wave is done with the previous block's rows
+      first = false;
+      stage(pass, qb);
+      const int cc = (qb * 32) / CC, qp = ((qb * 32) % CC) / 32;
+      const unsigned int ws0 = (unsigned)__builtin_amdgcn_readfirstlane(((slice * ncc + cc) * tile4 + (nt0 * JQ + 2 * qp) * 64) * 16);
+      unsigned int so;
+#define EYOC_ST_OPERANDS                                                                                                            \
+  [wr] "s"(wr), [ws0] "s"(ws0), [ks] "s"(kstride), [lb] "s"(lb), [xb] "s"(xb), [w1] "s"(w1off), "{s[36:43]}"(M0), "{s[44:51]}"(M1)
+#define EYOC_ST_ASM_NH2(TEXT)                                                                                                       \
+  asm volatile(TEXT : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), "+{v[96:111]}"(A2), "+{v[112:127]}"(A3), [so] "=&s"(so)                   \
+               : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS)
+      if constexpr (NH == 2 && (SKIP == 1 || SKIP >= 6)) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2);
+      else if constexpr (NH == 2 && SKIP == 0) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOSKIP);
+#ifdef EYOC_ST_ABLATIONS       // timing-only builds of the loop (results are garbage): no weight loads / no operand reads / no address VALU
+      else if constexpr (NH == 2 && SKIP == 3) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOW);
+      else if constexpr (NH == 2 && SKIP == 4) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOX);
+      else if constexpr (NH == 2 && SKIP == 5) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOV);
+#endif
+      else
+        asm volatile(EYOC_ST_LOOP_NH1 : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), [so] "=&s"(so)
+                     : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS_NH1);
+#undef EYOC_ST_ASM_NH2
+#undef EYOC_ST_OPERANDS
+    }
+  }
+
+  // ---- epilogue straight from the registers: lane (g, j) holds channels 16 t + 4 g .. +3 of row 64 h + 16 c + j
+  const float os = a.out_scale ? *a.out_scale : 1.0f;
+  float4 b4[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+    b4[t] = a.bias ? *reinterpret_cast<const float4*>(a.bias + ct0 + 16 * t + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float mx = 0.f;
+#pragma unroll
+  for (int hc = 0; hc < NH * NC; ++hc) {
+    const int h = hc / NC, c = hc % NC;
+    const int o = row0 + 64 * h + 16 * c + j;
+    if (o >= a.n_out) continue;
+    if (SKIP == 7 && os != 12345.f) continue;                          // EYOC_ST_ABLATIONS: no epilogue (the accumulators stay live)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int ch = ct0 + 16 * t + 4 * g;
+      const int ai = (hc * NTW + t) * 4;                                // register ACC(h, c, t) - 64 of the generator's map
+      const f32x16& A = ai < 16 ? A0 : ai < 32 ? A1 : ai < 48 ? A2 : A3;
+      float4 v = make_float4(A[ai % 16 + 0] * os + b4[t].x, A[ai % 16 + 1] * os + b4[t].y, A[ai % 16 + 2] * os + b4[t].z,
+                             A[ai % 16 + 3] * os + b4[t].w);
+      if (a.res) {
+        const float4 q = split16_load4(a.res + (size_t)o * a.ld_res, ch);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      }
+      if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      split16_track(mx, v);
+      if (a.out_split) split16_store4(a.out + (size_t)o * a.ld_out, ch, v);
+      else *reinterpret_cast<float4*>(a.out + (size_t)o * a.ld_out + ch) = v;
+    }
+  }
+  if (a.out_split) split16_report(a.range, mx);
+}
+
 }  // namespace
 
 namespace eyoc {
@@ -338,10 +508,19 @@ int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char
   return EYOC_OK;
 }
 
+// which staged kernel runs: 0 = the C++ offset loop (spconv_st_kernel), 1 = the assembly loop (default), 2 = the assembly loop
+// without the empty-block branches (diagnostics)
+static std::atomic<int> g_st_variant{1};
+#ifdef EYOC_ST_ABLATIONS
+constexpr int ST_VARIANTS = 8;
+#else
+constexpr int ST_VARIANTS = 3;
+#endif
+int select_st_variant(int v) { return (v >= 0 && v < ST_VARIANTS) ? g_st_variant.exchange(v) : g_st_variant.load(); }
+
 // stride-1 SPLIT16 layers whose table has a local rulebook (rows in natural = Morton order, no tiling permutation)
 int launch_spconv_st(const SpconvArgs& a, const unsigned char* local_dev, hipStream_t st) {
   EYOC_REQUIRE(a.math == 1 && local_dev && !a.l2norm && a.K == 27 && !a.perm, EYOC_ERR_INVALID, "spconv_st: unsupported layer");
-  static const int shape = [] { const char* e = getenv("EYOC_ST_SHAPE"); return e ? atoi(e) : 1; }();   // 0: 64 x 64 per wave, 1: 128 x 32
   const int ctg = a.cout >= 64 ? 64 : 32;                            // output channels per workgroup
   const bool wide = spconv_cc(a.cin, a.cout) == 64;
   const int n_cg = a.cout / ctg;
@@ -349,24 +528,33 @@ int launch_spconv_st(const SpconvArgs& a, const unsigned char* local_dev, hipStr
                "spconv_st: %d -> %d channels", a.cin, a.cout);
   const int n_tiles = cdiv(a.n_out, TILE);
   const dim3 grid((unsigned)(cdiv(n_tiles, 8 / n_cg) * 8)), block(NW * 64);
-  const size_t lds = (size_t)X_BYTES;
-  int dev = 0;
-  EYOC_CHECK_HIP(hipGetDevice(&dev));
-  static bool attr_done[64][6] = {};
-#define EYOC_ST(NTW_, CC_, NH_, I_)                                                                                         \
+  const int variant = g_st_variant.load();
+  if (variant == 0) {
+    // the dynamic-LDS attribute is per (function, device): set on every launch of this diagnostics path (no process-wide cache)
+#define EYOC_ST(NTW_, CC_, NH_)                                                                                             \
   do {                                                                                                                      \
-    if (dev >= 64 || !attr_done[dev][I_]) {                                                                                 \
-      EYOC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spconv_st_kernel<NTW_, CC_, NH_>),                   \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, X_BYTES));                             \
-      if (dev < 64) attr_done[dev][I_] = true;                                                                              \
-    }                                                                                                                       \
-    hipLaunchKernelGGL((spconv_st_kernel<NTW_, CC_, NH_>), grid, block, lds, st, a, local_dev, n_tiles);                    \
+    EYOC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spconv_st_kernel<NTW_, CC_, NH_>),                     \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, X_BYTES));                               \
+    hipLaunchKernelGGL((spconv_st_kernel<NTW_, CC_, NH_>), grid, block, (size_t)X_BYTES, st, a, local_dev, n_tiles);        \
   } while (0)
-  if (ctg == 64) {
-    if (shape == 1) { if (wide) EYOC_ST(2, 64, 2, 4); else EYOC_ST(2, 32, 2, 5); }
-    else { if (wide) EYOC_ST(4, 64, 1, 0); else EYOC_ST(4, 32, 1, 1); }
-  } else { if (wide) EYOC_ST(2, 64, 1, 2); else EYOC_ST(2, 32, 1, 3); }
+    if (ctg == 64) { if (wide) EYOC_ST(2, 64, 2); else EYOC_ST(2, 32, 2); }
+    else { if (wide) EYOC_ST(2, 64, 1); else EYOC_ST(2, 32, 1); }
 #undef EYOC_ST
+  } else {
+#define EYOC_STA(CC_, NH_, SK_) hipLaunchKernelGGL((spconv_st_asm_kernel<CC_, NH_, SK_>), grid, block, 0, st, a, local_dev, n_tiles)
+    if (ctg == 64) {
+      if (variant == 2) { if (wide) EYOC_STA(64, 2, 0); else EYOC_STA(32, 2, 0); }
+#ifdef EYOC_ST_ABLATIONS
+      else if (variant == 3) EYOC_STA(64, 2, 3);
+      else if (variant == 4) EYOC_STA(64, 2, 4);
+      else if (variant == 5) EYOC_STA(64, 2, 5);
+      else if (variant == 6) EYOC_STA(64, 2, 6);
+      else if (variant == 7) EYOC_STA(64, 2, 7);
+#endif
+      else { if (wide) EYOC_STA(64, 2, 1); else EYOC_STA(32, 2, 1); }
+    } else { if (wide) EYOC_STA(64, 1, 1); else EYOC_STA(32, 1, 1); }
+#undef EYOC_STA
+  }
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
 }

@@ -170,7 +170,11 @@ int eyoc_spconv_select_up_kernel(int on);
  * copied to LDS once per 32-channel block and all 27 offsets run from there.  Needs the table's per-tile "local
  * rulebooks" (built once per table; *overflow_dev counts 256-row tiles with more than 1278 distinct input rows - the staged
  * kernel must not be used when it is non-zero; rows in Morton order never overflow).  eyoc_model_forward builds and
- * uses them itself; these entry points exist for tests and profiling. */
+ * uses them itself; these entry points exist for tests and profiling.
+ * eyoc_spconv_select_st_kernel picks the implementation of the offset loop: 1 (default) = hand-scheduled gfx950 assembly
+ * with scalar branches around the MFMAs of empty (16-row chunk, offset) blocks; 2 = the same without the branches;
+ * 0 = the compiler-scheduled C++ loop.  Any other value only queries.  Returns the previous variant; process-wide, for tests and profiling. */
+int eyoc_spconv_select_st_kernel(int variant);
 size_t eyoc_spconv_local_rulebook_bytes(int n_out);
 int eyoc_spconv_build_local_rulebook(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, void* out_dev,
                                      int32_t* overflow_dev, void* stream);

@@ -39,5 +39,18 @@ for lvl, cin, cout in LAYERS:
         lib.eyoc_spconv_select_split16_kernel(mode)
         res[name] = timeit(lambda: _lib.check(lib.eyoc_spconv_ex(_lib.ctx(), tab, 27, n, n, _lib.ptr(xs), cin, cin, _lib.ptr(wd), cout, None, None, 0, 0, _lib.ptr(out), cout, 1, 1, _lib.ptr(osd), _lib.stream_ptr())))
     lib.eyoc_spconv_select_split16_kernel(1)
-    res["staged"] = timeit(lambda: _lib.check(lib.eyoc_spconv_staged(_lib.ctx(), tab, _lib.ptr(local), n, n, _lib.ptr(xs), cin, cin, _lib.ptr(wd), cout, None, None, 0, 0, _lib.ptr(out), cout, 1, _lib.ptr(osd), _lib.stream_ptr())))
+    ref_out = None
+    variants = [int(v) for v in os.environ.get("ST_VARIANTS", "0,1,2").split(",")]
+    run_st = lambda: _lib.check(lib.eyoc_spconv_staged(_lib.ctx(), tab, _lib.ptr(local), n, n, _lib.ptr(xs), cin, cin, _lib.ptr(wd), cout, None, None, 0, 0, _lib.ptr(out), cout, 1, _lib.ptr(osd), _lib.stream_ptr()))
+    best = {v: [] for v in variants}
+    for rnd in range(int(os.environ.get("ROUNDS", "5"))):      # variants interleaved over several rounds: clocks drift with load
+        for variant in variants:
+            lib.eyoc_spconv_select_st_kernel(variant)
+            best[variant].append(timeit(run_st, reps=5))
+            if rnd == 0:
+                torch.cuda.synchronize()
+                if ref_out is None: ref_out = out.clone()
+                elif not torch.equal(ref_out, out): best[variant].append(-1e6)   # a mismatch shows as an absurd time
+    for v in variants: res[f"st{v}"] = float(np.median(best[v])); res[f"st{v}min"] = min(best[v])
+    lib.eyoc_spconv_select_st_kernel(1)
     print(f"lvl{lvl} {cin}->{cout} n={n} pairs={prs} overflow={int(ovf.item())} local-rulebook {t_lr:.3f} ms | " + "  ".join(f"{k} {v:.3f} ms ({2*prs*cin*cout/v/1e9:.0f} TF)" for k, v in res.items()), flush=True)
