@@ -17,12 +17,13 @@ Register map (per wave; NH row halves of 64 rows, NC = 4 chunks of 16 rows, NTW 
   v[128:191] operand sets  X(s, c, p)   = 128 + s*32 + (c*2 + p)*4          s: half-step parity, p: 0 hi / 1 lo halves
   v[192:239] weight sets   W(s, t, p)   = 192 + s*16 + (t*2 + p)*4          s = k % (WD+1); lane constants behind them
   v[240:251] rulebook sets L(s, h)      = 240 + (s*NH + h)*2                s = k % 3; uint2 = four 16-bit LDS slots
-  v[252:255] address temporaries
+  v[252:255] address temporaries (two in use)
   s[36:49]   occupancy masks: bit (k&1)*16 + h*4 + c of s[36 + k/2]         (pinned operands)
 """
 import sys
 
 K, NC, NTW = 27, 4, 2
+LO_REGION = 640 * 64      # the LDS stage: 640 rows x 64 B of hi halves, then the same of lo halves (spconv_st.hip)
 
 
 def gen(NH, WD, skip=True, abl=()):
@@ -80,18 +81,17 @@ def gen(NH, WD, skip=True, abl=()):
             vmq.append(("L", k))
 
     def addr(k, h, c, t0, t1):
-        """LDS addresses of the hi / lo pieces of chunk c's rows at (k, h): slot field << 4, XOR lane piece, + base"""
+        """LDS address of the hi piece of chunk c's rows at (k, h): the 16-bit rulebook field IS the byte address of the
+        row's hi pieces (swizzle included); XOR the lane's piece.  The lo piece sits LO_REGION bytes further (offset field)."""
         reg = LS(k % 3, h) + (c >> 1)
         if "nov" in abl:
             return
-        emit(f"v_lshlrev_b32_sdwa v{t0}, {C4}, v{reg} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_{c & 1}")
-        emit(f"v_xad_u32 v{t0}, v{t0}, {GH}, %[xb]")
-        emit(f"v_xor_b32 v{t1}, 64, v{t0}")
+        emit(f"v_xor_b32_sdwa v{t0}, {GH}, v{reg} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_{c & 1}")
 
     def read(hs, c, p, t):
         if "nox" in abl:
             return
-        emit(f"ds_read_b128 {vr(XS(hs & 1, c, p))}, v{t}")
+        emit(f"ds_read_b128 {vr(XS(hs & 1, c, p))}, v{t}" + (f" offset:{LO_REGION}" if p else ""))
         lgq.append(("X", hs, c))
 
     def mfma(h, c, t, term, k, hs):
@@ -102,14 +102,28 @@ def gen(NH, WD, skip=True, abl=()):
 
     # ---- prologue: first weights / rulebook entries, stage landed, barrier, operands of half-step 0
     emit("s_mov_b32 %[so], %[ws0]")
+    # lane = 16 g + m.  Output-channel tiles: MFMA row 4 q + r of tile t is channel 8 q + 4 t + r of the wave's 32, so that a
+    # lane's two accumulator tuples (t = 0, 1) are 8 CONSECUTIVE channels (16-byte epilogue accesses).  The packed
+    # fragments keep channel 16 nt + m' at lane m' of tile nt: lane m of tile t therefore loads from tile nt = ch >> 4, lane
+    # position 16 g + (ch & 15), ch = 8 (m >> 2) + 4 t + (m & 3).
     emit(f"v_mbcnt_lo_u32_b32 {LV}, -1, 0")
     emit(f"v_mbcnt_hi_u32_b32 {LV}, -1, {LV}")
-    emit(f"v_and_b32 {GH}, 48, {LV}")
-    emit(f"v_lshlrev_b32 {WL0}, 4, {LV}")
-    emit(f"v_add_u32 {WL1}, %[w1], {WL0}")
-    emit(f"v_and_b32 {LV}, 15, {LV}")
+    emit(f"v_and_b32 {GH}, 48, {LV}")                       # 16 g
+    emit(f"v_and_b32 {LV}, 15, {LV}")                       # m
+    emit(f"v_lshrrev_b32 {WL0}, 2, {LV}")
+    emit(f"v_lshlrev_b32 {WL0}, 3, {WL0}")                  # 8 (m >> 2)
+    emit(f"v_and_b32 {WL1}, 3, {LV}")
+    emit(f"v_add_u32 {WL0}, {WL0}, {WL1}")                  # ch of tile 0 (0 .. 27); tile 1: + 4
+    for t, W_ in ((1, WL1), (0, WL0)):
+        if t:
+            emit(f"v_add_u32 {W_}, 4, {WL0}")
+        emit(f"v_lshrrev_b32 {C4}, 4, {W_}")                # nt
+        emit(f"v_and_b32 {W_}, 15, {W_}")                   # m'
+        emit(f"v_add_u32 {W_}, {W_}, {GH}")
+        emit(f"v_lshlrev_b32 {W_}, 4, {W_}")
+        emit(f"v_mul_lo_u32 {C4}, {C4}, %[w1]")
+        emit(f"v_add_u32 {W_}, {W_}, {C4}")
     emit(f"v_lshlrev_b32 {LV}, 3, {LV}")
-    emit(f"v_mov_b32 {C4}, 4")
     for k in range(WD):
         issue_w(k)
     issue_l(0)
@@ -121,7 +135,7 @@ def gen(NH, WD, skip=True, abl=()):
         t0, t1 = T[(c & 1) * 2], T[(c & 1) * 2 + 1]
         addr(0, 0, c, t0, t1)
         read(0, c, 0, t0)
-        read(0, c, 1, t1)
+        read(0, c, 1, t0)
 
     # ---- the half-steps
     for k in range(K):
@@ -144,7 +158,7 @@ def gen(NH, WD, skip=True, abl=()):
                 lab = f"k{k}h{h}c{c}"
                 if has_next:
                     read(hs + 1, c, 0, t0)
-                    read(hs + 1, c, 1, t1)
+                    read(hs + 1, c, 1, t0)
                 if skip:
                     emit(f"s_bitcmp1_b32 s{36 + (k >> 1)}, {(k & 1) * 16 + h * 4 + c}")
                     emit(f"s_cbranch_scc0 .Lst%=_{lab}")

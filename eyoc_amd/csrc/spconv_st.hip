@@ -38,12 +38,18 @@ constexpr int UMAX = XROWS - 1;                            // distinct input row
 constexpr int NPASS = 2;                                   // a tile with more distinct rows (<= 1278) takes a second pass
 constexpr int UCAP = 1280;
 constexpr int X_BYTES = XROWS * 128;                       // 80 KB: two workgroups per CU
-constexpr int NIT = XROWS / (8 * NW);                      // staging instructions per wave and block (8 rows each)
+constexpr int LO_REGION = XROWS * 64;                      // the stage: XROWS x 64 B of hi halves, then XROWS x 64 B of lo halves
+constexpr int NIT = XROWS / (16 * NW);                     // staging steps per wave and block (16 rows = one hi + one lo instruction each)
+// LDS byte address of the hi pieces of stage slot l: four 16-byte pieces (8 fp16 hi halves each) per row, piece p stored at
+// position p ^ s(l), s(l) = (l >> 2) & 3, so that rows 4 apart do not collide; the lane holding operand piece g reads at
+// slot_addr(l) ^ (g << 4), and the lo piece LO_REGION bytes further (one XOR per gathered row, the lo read through the
+// instruction's offset field).  Fits 16 bits: this IS the rulebook's entry.
+__host__ __device__ constexpr int slot_addr(int l) { return l * 64 + ((l >> 2) & 3) * 16; }
 
 // ---- local rulebook of one 256-row tile (LR_BYTES bytes): int n_unique (-1: more than NPASS * UMAX), pad[3];
-// int U[UCAP]; uint2 loc[NPASS][27][64]: entry (pass, k, 16 w + j) packs, as four 16-bit values v = 8 l + (l & 7), the
+// int U[UCAP]; uint2 loc[NPASS][27][64]: entry (pass, k, 16 w + j) packs, as four 16-bit values slot_addr(l), the
 // LDS slots l of the neighbours at offset k of output rows 64 w + 16 c + j, c = 0..3 (slot UMAX = no neighbour, or a
-// neighbour staged in the other pass).  v << 4 is the LDS address of the row's first piece with the swizzle applied.
+// neighbour staged in the other pass).
 // Then, per pass, 27 (+1 pad) 16-bit occupancy masks: bit 4 w + c of mask (pass, k) = some row of rows 64 w + 16 c .. +15 has a
 // neighbour at offset k that is staged in this pass (the hand-scheduled loop skips the MFMAs of a chunk whose bit is clear).
 constexpr int MASK_OFF = 16 + UCAP * 4 + NPASS * 27 * 64 * 8;   // 32784
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restric
     for (int p = 0; p < NPASS; ++p) {
       if (p > 0 && total <= p * UMAX) continue;                         // nobody reads the entries of a pass that does not happen
       const int l = (id >= p * UMAX && id < (p + 1) * UMAX) ? id - p * UMAX : UMAX;
-      loc[(((size_t)(p * 27 + k) * 64) + w * 16 + j) * 4 + c] = (unsigned short)(l * 8 + (l & 7));
+      loc[(((size_t)(p * 27 + k) * 64) + w * 16 + j) * 4 + c] = (unsigned short)slot_addr(l);
       const unsigned long long b = __ballot(l != UMAX);                  // 16 lanes per chunk
       if (lane == 0)
         nib[p][k][w] = (unsigned char)(((b & 0xFFFFull) != 0) | (((b >> 16) & 0xFFFFull) != 0) << 1 | (((b >> 32) & 0xFFFFull) != 0) << 2 |
@@ -172,7 +178,8 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_kernel(SpconvArgs a, con
   const uint2* __restrict__ locp = reinterpret_cast<const uint2*>(lr + 16 + UCAP * 4) + w0 * 16 + j;
   const int n_pass = n_u > UMAX ? 2 : 1;                               // workgroup-uniform; the second pass is rare
   // zero row (slot UMAX), written once: no stage ever touches it
-  if (threadIdx.x < 8) *reinterpret_cast<float4*>(xs + UMAX * 128 + threadIdx.x * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (threadIdx.x < 8)
+    *reinterpret_cast<float4*>(xs + (threadIdx.x >> 2) * LO_REGION + UMAX * 64 + (threadIdx.x & 3) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
 
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, K * a.cin * a.cout * 4, 0x00020000);
   const int tile4 = CC * CT / 4;
@@ -202,9 +209,9 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_kernel(SpconvArgs a, con
         W[t][p] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
       }
   };
-  // stage block qb of the tile's distinct input rows: 8 lanes per row (one 128-byte line), 8 rows per instruction, wave w
-  // takes the 8-row groups 4 it + w; global -> LDS directly (global_load_lds_dwordx4: lane i lands at base + 16 i, so the
-  // XOR swizzle of the pieces is applied on the SOURCE side), all loads of a stage in flight at once
+  // stage block qb of the tile's distinct input rows: 4 lanes per row and half (64 bytes of hi halves / of lo halves), 16 rows per
+  // instruction, wave w takes the 16-row groups 4 it + w; global -> LDS directly (global_load_lds_dwordx4: lane i lands at
+  // base + 16 i, so the piece swizzle is applied on the SOURCE side), all loads of a stage in flight at once
   // (the row numbers are re-read from the rulebook for every block: 20 registers held across the offset loop cost more
   // than one L2 round trip per block, which the other workgroup of the CU covers)
   int n_up = 0;                                                      // distinct rows of the current pass
@@ -215,24 +222,26 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_kernel(SpconvArgs a, con
     int Ureg[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      int l = (it * NW + wave) * 8 + (lane >> 3);
+      int l = (it * NW + wave) * 16 + (lane >> 2);
       asm volatile("" : "+v"(l));                                      // opaque: or the loads are hoisted out of the block loop (and spill)
       Ureg[it] = l < n_up ? U[pass * UMAX + l] : 0;
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int l0 = (it * NW + wave) * 8;
+      const int l0 = (it * NW + wave) * 16;
       if (l0 < n_up) {                                               // wave-uniform
-        const int l = l0 + (lane >> 3);
-        const float* src = a.in + (size_t)Ureg[it] * a.ld_in + qb * 32 + (((lane & 7) ^ (l & 7)) << 2);
-        if (l < n_up)
-          __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(xs + l0 * 128), 16, 0, 0);
+        const int l = l0 + (lane >> 2);
+        const float* src = a.in + (size_t)Ureg[it] * a.ld_in + qb * 32 + (((lane & 3) ^ ((l >> 2) & 3)) << 2);
+        if (l < n_up) {
+          __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(xs + l0 * 64), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds(src + 16, (__attribute__((address_space(3))) void*)(xs + LO_REGION + l0 * 64), 16, 0, 0);
+        }
       }
     }
   };
   // operands of one offset: lane (g, j) reads pieces g (hi halves of channels 8 g ..) and 4 + g (lo halves) of the four
   // rows its entry names
-  const unsigned int gh = (unsigned)g << 4, gl = (unsigned)(g ^ 4) << 4;
+  const unsigned int gh = (unsigned)g << 4;
   auto read_x = [&](const uint2 L, float4 (&X)[NC][2]) {
 #if defined(EYOC_ST_ABL) && (EYOC_ST_ABL & 8)
     for (int c = 0; c < NC; ++c) { X[c][0].x = __uint_as_float(L.x); asm volatile("" : "+v"(X[c][0].y), "+v"(X[c][1].x)); }
@@ -240,10 +249,9 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_kernel(SpconvArgs a, con
 #endif
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const unsigned int v = ((c < 2 ? L.x : L.y) >> (16 * (c & 1))) & 0xFFFFu;
-      const unsigned int ad = v << 4;
-      X[c][0] = *reinterpret_cast<const float4*>(xs + (ad ^ gh));
-      X[c][1] = *reinterpret_cast<const float4*>(xs + (ad ^ gl));
+      const unsigned int ad = (((c < 2 ? L.x : L.y) >> (16 * (c & 1))) & 0xFFFFu) ^ gh;
+      X[c][0] = *reinterpret_cast<const float4*>(xs + ad);
+      X[c][1] = *reinterpret_cast<const float4*>(xs + ad + LO_REGION);
     }
   };
   auto multiply = [&](int h, const float4 (&X)[NC][2], const float4 (&W)[NTW][2]) {
@@ -379,7 +387,8 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a,
   const int n_u = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(lr)[0]);
   const int* __restrict__ U = reinterpret_cast<const int*>(lr + 16);
   const int n_pass = n_u > UMAX ? 2 : 1;
-  if (threadIdx.x < 8) *reinterpret_cast<float4*>(xs + UMAX * 128 + threadIdx.x * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (threadIdx.x < 8)
+    *reinterpret_cast<float4*>(xs + (threadIdx.x >> 2) * LO_REGION + UMAX * 64 + (threadIdx.x & 3) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // raw buffer resource of the packed weights (stride 0, byte-granular bounds, the flags make_buffer_rsrc takes elsewhere)
   const unsigned long long wbits = (unsigned long long)(size_t)a.w;
@@ -391,7 +400,8 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a,
   const int tile4 = CC * CT / 4;
   const unsigned int kstride = (unsigned)(n_slices * ncc * tile4 * 16);
   const unsigned int w1off = JQ * 1024;                                // byte distance of the second channel tile's fragments
-  const unsigned int xb = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)xs;
+  // the loop addresses the stage from LDS byte 0 (the kernel's only shared allocation)
+  if ((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)xs != 0u) __builtin_trap();
 
   f32x16 A0, A1, A2, A3;
 #pragma unroll
@@ -403,18 +413,20 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a,
     int Ureg[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      int l = (it * NW + wave) * 8 + (lane >> 3);
+      int l = (it * NW + wave) * 16 + (lane >> 2);
       asm volatile("" : "+v"(l));
       Ureg[it] = l < n_up ? U[pass * UMAX + l] : 0;
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int l0 = (it * NW + wave) * 8;
+      const int l0 = (it * NW + wave) * 16;
       if (l0 < n_up) {
-        const int l = l0 + (lane >> 3);
-        const float* src = a.in + (size_t)Ureg[it] * a.ld_in + qb * 32 + (((lane & 7) ^ (l & 7)) << 2);
-        if (l < n_up)
-          __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(xs + l0 * 128), 16, 0, 0);
+        const int l = l0 + (lane >> 2);
+        const float* src = a.in + (size_t)Ureg[it] * a.ld_in + qb * 32 + (((lane & 3) ^ ((l >> 2) & 3)) << 2);
+        if (l < n_up) {
+          __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(xs + l0 * 64), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds(src + 16, (__attribute__((address_space(3))) void*)(xs + LO_REGION + l0 * 64), 16, 0, 0);
+        }
       }
     }
   };
@@ -441,7 +453,7 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a,
       const unsigned int ws0 = (unsigned)__builtin_amdgcn_readfirstlane(((slice * ncc + cc) * tile4 + (nt0 * JQ + 2 * qp) * 64) * 16);
       unsigned int so;
 #define EYOC_ST_OPERANDS                                                                                                            \
-  [wr] "s"(wr), [ws0] "s"(ws0), [ks] "s"(kstride), [lb] "s"(lb), [xb] "s"(xb), [w1] "s"(w1off), "{s[36:43]}"(M0), "{s[44:51]}"(M1)
+  [wr] "s"(wr), [ws0] "s"(ws0), [ks] "s"(kstride), [lb] "s"(lb), [w1] "s"(w1off), "{s[36:43]}"(M0), "{s[44:51]}"(M1)
 #define EYOC_ST_ASM_NH2(TEXT)                                                                                                       \
   asm volatile(TEXT : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), "+{v[96:111]}"(A2), "+{v[112:127]}"(A3), [so] "=&s"(so)                   \
                : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS)
@@ -460,12 +472,15 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a,
     }
   }
 
-  // ---- epilogue straight from the registers: lane (g, j) holds channels 16 t + 4 g .. +3 of row 64 h + 16 c + j
+  // ---- epilogue straight from the registers.  The loop loads the weight rows permuted (gen_st_loop.py) so that lane (g, j)
+  // holds, for row 64 h + 16 c + j, channels 8 g .. 8 g + 3 in tuple t = 0 and 8 g + 4 .. 8 g + 7 in tuple t = 1: 8 consecutive
+  // channels = one 16-byte access per half of a SPLIT16 row (half as many memory instructions as 4-channel tuples)
   const float os = a.out_scale ? *a.out_scale : 1.0f;
+  const int ch = ct0 + 8 * g;
   float4 b4[NTW];
 #pragma unroll
   for (int t = 0; t < NTW; ++t)
-    b4[t] = a.bias ? *reinterpret_cast<const float4*>(a.bias + ct0 + 16 * t + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    b4[t] = a.bias ? *reinterpret_cast<const float4*>(a.bias + ch + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
   float mx = 0.f;
 #pragma unroll
   for (int hc = 0; hc < NH * NC; ++hc) {
@@ -473,21 +488,38 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a,
     const int o = row0 + 64 * h + 16 * c + j;
     if (o >= a.n_out) continue;
     if (SKIP == 7 && os != 12345.f) continue;                          // EYOC_ST_ABLATIONS: no epilogue (the accumulators stay live)
+    float4 v[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-      const int ch = ct0 + 16 * t + 4 * g;
       const int ai = (hc * NTW + t) * 4;                                // register ACC(h, c, t) - 64 of the generator's map
       const f32x16& A = ai < 16 ? A0 : ai < 32 ? A1 : ai < 48 ? A2 : A3;
-      float4 v = make_float4(A[ai % 16 + 0] * os + b4[t].x, A[ai % 16 + 1] * os + b4[t].y, A[ai % 16 + 2] * os + b4[t].z,
-                             A[ai % 16 + 3] * os + b4[t].w);
-      if (a.res) {
-        const float4 q = split16_load4(a.res + (size_t)o * a.ld_res, ch);
-        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-      }
-      if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      split16_track(mx, v);
-      if (a.out_split) split16_store4(a.out + (size_t)o * a.ld_out, ch, v);
-      else *reinterpret_cast<float4*>(a.out + (size_t)o * a.ld_out + ch) = v;
+      v[t] = make_float4(A[ai % 16 + 0] * os + b4[t].x, A[ai % 16 + 1] * os + b4[t].y, A[ai % 16 + 2] * os + b4[t].z,
+                         A[ai % 16 + 3] * os + b4[t].w);
+    }
+    if (a.res) {
+      const char* rp = reinterpret_cast<const char*>(a.res + (size_t)o * a.ld_res) + split16_off4(ch);
+      const uint4 rh = *reinterpret_cast<const uint4*>(rp), rl = *reinterpret_cast<const uint4*>(rp + SPLIT16_LO);
+      const float4 q0 = split16_decode4(make_uint2(rh.x, rh.y), make_uint2(rl.x, rl.y));
+      const float4 q1 = split16_decode4(make_uint2(rh.z, rh.w), make_uint2(rl.z, rl.w));
+      v[0].x += q0.x; v[0].y += q0.y; v[0].z += q0.z; v[0].w += q0.w;
+      v[1].x += q1.x; v[1].y += q1.y; v[1].z += q1.z; v[1].w += q1.w;
+    }
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      if (a.relu) { v[t].x = fmaxf(v[t].x, 0.f); v[t].y = fmaxf(v[t].y, 0.f); v[t].z = fmaxf(v[t].z, 0.f); v[t].w = fmaxf(v[t].w, 0.f); }
+      split16_track(mx, v[t]);
+    }
+    if (a.out_split) {
+      uint2 h0, l0, h1, l1;
+      split16_encode4(v[0], h0, l0);
+      split16_encode4(v[1], h1, l1);
+      char* op = reinterpret_cast<char*>(a.out + (size_t)o * a.ld_out) + split16_off4(ch);
+      *reinterpret_cast<uint4*>(op) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+      *reinterpret_cast<uint4*>(op + SPLIT16_LO) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    } else {
+      float* op = a.out + (size_t)o * a.ld_out + ch;
+      *reinterpret_cast<float4*>(op) = v[0];
+      *reinterpret_cast<float4*>(op + 4) = v[1];
     }
   }
   if (a.out_split) split16_report(a.range, mx);

@@ -112,7 +112,7 @@ def maps():
 
 
 @pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (32, 64), (128, 128), (256, 64), (128, 256), (96, 64), (64, 32)])
-def test_split16_layer_is_as_accurate_as_fp32_mfma(maps, cin, cout):
+def test_split16_layer_is_as_accurate_as_fp32_mfma(maps, cin, cout, split16_kernel):
     """Against an fp64 restatement: the split16 layer's error must be of the order of the fp32-MFMA layer's own
     (both ~1e-7 relative to the largest output), three orders of magnitude inside the 1e-4 bar."""
     from eyoc_amd import _lib as L
@@ -136,9 +136,14 @@ def test_split16_layer_is_as_accurate_as_fp32_mfma(maps, cin, cout):
     got16s = run_layer_split(nbr, x, W, bias=b, scale=s, res=r, relu=True, out_split=True)
     e32, e16, e16s = rel_err(got32, want), rel_err(got16, want), rel_err(got16s, want)
     print(f"{cin}->{cout}: vs fp64  fp32-mfma {e32:.2e}  split16 {e16:.2e}  split16 + split store {e16s:.2e}")
-    # the claim of DESIGN 3.2b, as worded there: a split16 layer is within a few fp32 ulps of the largest output (realised
-    # 1.2e-7 .. 4.8e-7 depending on the kernel's summation order; the fp32-MFMA layer 1.2e-7 .. 1.9e-7) - not merely 'inside 1e-4'
-    assert e16 < 6e-7 and e16s < 6e-7 and e16 <= 4 * e32 + 1e-7 and e16s <= 4 * e32 + 1e-7
+    # the claim of DESIGN 3.2b, as worded there.  Wave-private kernel (per-offset partial sums): the split16 error IS the
+    # fp32-MFMA path's (realised 1.2e-7 .. 1.9e-7 of the largest output for both).  Row-stationary kernel (one fp32 chain over all
+    # 27 offsets per accumulator, 64-wide operand blocks): 2.8e-7 .. 1.1e-6, i.e. up to 6x the fp32 path's - still 100x inside
+    # the 1e-4 bar, but NOT "equal", and the bound below says so.
+    if split16_kernel == 0:
+        assert e16 <= 2 * e32 + 1e-7 and e16s <= 2 * e32 + 1e-7, (e32, e16, e16s)
+    else:
+        assert e16 < 2e-6 and e16s < 2e-6 and e16 <= 8 * e32 + 2e-7, (e32, e16, e16s)
 
 
 def test_split16_identity_strided_transposed_and_ragged(maps):
