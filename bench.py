@@ -81,6 +81,7 @@ def parse_args(argv=None):
                          "+0.5 % - the conv and RANSAC kernels fill the register files, the side stream only runs in their tails)")
     ap.add_argument("--st-variant", type=int, default=-1,
                     help="diagnostics: staged-kernel implementation (eyoc_spconv_select_st_kernel: 0 C++ loop, 1 assembly loop, 2 assembly without empty-block branches)")
+    ap.add_argument("--down-staged", type=int, default=-1, help="diagnostics: eyoc_spconv_select_down_kernel (0 / 1)")
     ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
     return ap.parse_args(argv)
 
@@ -268,6 +269,9 @@ def worker(args):
         if args.st_variant >= 0:
             from eyoc_amd import _lib as _l
             _l.load().eyoc_spconv_select_st_kernel(args.st_variant)
+        if args.down_staged >= 0:
+            from eyoc_amd import _lib as _l
+            _l.load().eyoc_spconv_select_down_kernel(args.down_staged)
         log("model packed")
         cfg = RegistrationConfig(ransac_max_iteration=args.ransac_iters)
         pipe, Batch = RegistrationPipeline(model, cfg), DeviceBatch

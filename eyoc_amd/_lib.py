@@ -107,6 +107,7 @@ PROTOTYPES = {
     "eyoc_model_pack_host": (_i, [C.POINTER(ModelDesc), C.POINTER(LayerParams), _i, _vp, _sz]),
     "eyoc_model_create": (_i, [_vp, C.POINTER(ModelDesc), C.POINTER(LayerParams), _i, _vp, _sz, C.POINTER(_vp)]),
     "eyoc_model_destroy": (_i, [_vp]),
+    "eyoc_model_fuse_tail": (_i, [_i]),
     "eyoc_model_workspace_bytes": (_sz, [_vp, _vp]),
     "eyoc_model_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "eyoc_model_num_layers": (_i, [_vp]),
@@ -117,6 +118,7 @@ PROTOTYPES = {
     "eyoc_model_timing_slot": (_i, [_vp, _i]),
     "eyoc_knn_prefilter": (_i, [_i]),
     "eyoc_spconv_select_up_kernel": (_i, [_i]),
+    "eyoc_spconv_select_down_kernel": (_i, [_i]),
     "eyoc_knn1": (_i, [_vp, _vp, _vp, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i, _i, _vp, _vp, _vp]),
     "eyoc_pdist": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "eyoc_kabsch_batched": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),

@@ -153,6 +153,9 @@ struct eyoc_maps {
   // per-tile local rulebooks of the stride-1 tables (spconv_st.hip), built when the rows are in Z-order; NULL otherwise
   unsigned char* local_s1[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
   unsigned char* local_up[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};   // transposed tables (outputs at level l)
+  // strided tables (inputs at level l, outputs at level l + 1): the same records as local_s1 - a 256-row output tile's inputs
+  // are its rows' children plus a halo, a contiguous range of the finer level in Z-order; NULL when a tile overflows
+  unsigned char* local_down[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
   bool table0_built = false;   // table[0] has its memory reserved but is only filled on demand (maps_build_table0)
 };
 

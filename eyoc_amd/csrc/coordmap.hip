@@ -449,6 +449,7 @@ size_t eyoc_maps_workspace_bytes(int n_rows) {
   // local rulebooks of the stride-1 tables (levels sum to < 2 n rows; every level rounds up to a whole tile)
   b += 2 * align_up(local_rulebook_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_bytes(1)) + 256);
   b += 2 * align_up(local_rulebook_up_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_up_bytes(1)) + 256);
+  b += align_up(local_rulebook_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_bytes(1)) + 256);   // strided tables (coarse levels sum to < n rows)
   b += 4096;                                                         // counters
   return b + 96 * 256;
 }
@@ -652,8 +653,7 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
   }
   // ---- local rulebooks of the stride-1 tables (tile-local input stage of the sparse convolution): only for Z-ordered rows
   if (zorder) {
-    FAIL_HIP(hipMemsetAsync(counters + 8, 0, sizeof(int), st));
-    FAIL_HIP(hipMemsetAsync(counters + 9, 0, sizeof(int), st));
+    FAIL_HIP(hipMemsetAsync(counters + 8, 0, 8 * sizeof(int), st));    // [8] stride-1, [9] transposed, [10 + l] strided table l
     for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
       m->local_s1[l] = cv.take<unsigned char>(local_rulebook_bytes(m->rows[l]));
       if (int rc = build_local_rulebook(m->nbr_s1[l], 27, m->rows[l], m->local_s1[l], counters + 8, st)) { delete m; return rc; }
@@ -661,13 +661,19 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
         m->local_up[l] = cv.take<unsigned char>(local_rulebook_up_bytes(m->rows[l]));
         if (int rc = build_local_rulebook_up(m->nbr_up[l], 27, m->rows[l], m->local_up[l], counters + 9, st)) { delete m; return rc; }
       }
+      if (l + 1 < EYOC_MAX_LEVELS && m->nbr_down[l] && spconv_down_staged()) {   // the strided table level l -> l + 1
+        m->local_down[l] = cv.take<unsigned char>(local_rulebook_bytes(m->rows[l + 1]));
+        if (int rc = build_local_rulebook(m->nbr_down[l], 27, m->rows[l + 1], m->local_down[l], counters + 10 + l, st)) { delete m; return rc; }
+      }
     }
-    FAIL_HIP(hipMemcpyAsync(host, counters + 8, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    FAIL_HIP(hipMemcpyAsync(host, counters + 8, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
     FAIL_HIP(hipStreamSynchronize(st));
     if (host[0] != 0)   // a tile with more than 1278 distinct input rows (does not happen for Z-ordered rows): no staged kernel
       for (int l = 0; l < EYOC_MAX_LEVELS; ++l) m->local_s1[l] = nullptr;
     if (host[1] != 0)   // ... more than 639 distinct coarse rows under a 256-row tile
       for (int l = 0; l < EYOC_MAX_LEVELS; ++l) m->local_up[l] = nullptr;
+    for (int l = 0; l + 1 < EYOC_MAX_LEVELS; ++l)
+      if (host[2 + l] != 0) m->local_down[l] = nullptr;
   }
   FAIL_HIP(hipGetLastError());
 #undef FAIL_HIP

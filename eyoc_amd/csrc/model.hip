@@ -35,6 +35,8 @@ struct BufPlan { int level, width; };
 
 size_t pad64(size_t v) { return (v + 63) / 64 * 64; }
 
+int g_fuse_tail = 1;     // eyoc_model_fuse_tail: the two 1x1 layers at the end of a split16 forward in one kernel (spconv_tail.hip)
+
 }  // namespace
 
 struct eyoc_model {
@@ -257,6 +259,12 @@ int eyoc_model_destroy(eyoc_model* m) {
   return EYOC_OK;
 }
 
+int eyoc_model_fuse_tail(int on) {
+  const int prev = g_fuse_tail;
+  if (on == 0 || on == 1) g_fuse_tail = on;
+  return prev;
+}
+
 int eyoc_model_set_probe(eyoc_model* m, int on) {
   EYOC_REQUIRE(m, EYOC_ERR_INVALID, "eyoc_model_set_probe: NULL model");
   const unsigned int words[2] = {0u, on ? 1u : 0u};                   // max |x| reset, probe switch
@@ -384,6 +392,22 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
       a.parent = maps->parent[0]; a.children = maps->children[0]; a.s1c = maps->nbr_s1[1]; a.nc = maps->rows[1];
       rc = conv1_walks_octree(a) ? EYOC_OK : maps_build_table0(const_cast<eyoc_maps*>(maps), st);
       if (!rc) rc = launch_conv1(a, st);
+    } else if (split && g_fuse_tail && li + 2 == m->layers.size() && p.map == M_IDENT && p.K == 1 && p.res_buf < 0 &&
+               m->layers[li + 1].map == M_IDENT && m->layers[li + 1].K == 1 && m->layers[li + 1].in_buf == p.out_buf &&
+               m->layers[li + 1].res_buf < 0 && !m->layers[li + 1].relu && m->layers[li + 1].out_buf == B_OUT && p.out_col == 0 &&
+               tail_fusable(p.cin, p.cout, m->layers[li + 1].cout)) {
+      // conv1_tr -> ReLU -> final (+ bias) -> row normalisation in one kernel: the [N, 64] intermediate stays in registers
+      const LayerPlan& q = m->layers[li + 1];
+      rc = launch_tail_fused(buf[p.in_buf] + p.in_col, m->bufs[p.in_buf].width, n_out, m->blob + p.w16_off, m->blob + p.s_off,
+                             m->blob + p.b_off, p.relu, m->blob + q.w16_off, m->blob + q.s_off, m->blob + q.b_off, q.l2norm,
+                             buf[q.out_buf] + q.out_col, m->bufs[q.out_buf].width, maps->row_perm, m->range, st);
+      if (rc) return rc;
+      if (m->timing) {                                  // the pair's time is booked on the first layer, the second reads 0
+        EYOC_CHECK_HIP(hipEventRecord(ev[li + 1], st));
+        EYOC_CHECK_HIP(hipEventRecord(ev[li + 2], st));
+      }
+      ++li;
+      continue;
     } else {
       SpconvArgs a;
       a.nbr = p.map == M_S1 ? maps->nbr_s1[p.level] : p.map == M_DOWN ? maps->nbr_down[p.level]
@@ -404,6 +428,7 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
         // stride-1 layers on Z-ordered rows: tile-local input stage (spconv_st.hip)
         if (p.map == M_S1 && p.cin >= 32 && p.cin % 32 == 0) a.local = maps->local_s1[p.level];
         if (p.map == M_UP && p.cin % 32 == 0 && p.cout % 64 == 0) a.local_up = maps->local_up[p.level];   // spconv_up.hip
+        if (p.map == M_DOWN && p.cin % 32 == 0) a.local = maps->local_down[p.level];                     // strided: staged like stride-1
       }
       if (p.out_buf == B_OUT) a.out_perm = maps->row_perm;   // the network output goes back to the caller's row order
       a.perm = p.map == M_UP ? maps->perm_up[p.level] : p.map == M_S1 ? maps->perm_s1[p.level]

@@ -114,8 +114,14 @@ int select_st_variant(int v);   // spconv_st.hip: which staged kernel (returns t
 size_t local_rulebook_bytes(int n_out);
 int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st);
 int launch_spconv_rs(const SpconvArgs& a, hipStream_t st);     // row-stationary, SPLIT16 only (spconv_rs.hip)
+// the network's 1x1 tail in one kernel (spconv_tail.hip): conv1_tr (96 -> 64, ReLU) -> final (64 -> 32, bias) -> row normalisation
+bool tail_fusable(int cin1, int cmid, int cout);
+int launch_tail_fused(const float* in, int ld_in, int n, const float* w1, const float* s1, const float* b1, int relu1, const float* w2,
+                      const float* s2, const float* b2, int l2norm, float* out, int ld_out, const int32_t* out_perm, unsigned int* range,
+                      hipStream_t st);
 bool spconv_rs_fits(const SpconvArgs& a);
 bool spconv_up_enabled();    // eyoc_spconv_select_up_kernel state
+bool spconv_down_staged();   // eyoc_spconv_select_down_kernel state
 int spconv_forced_kernel();   // eyoc_spconv_select_kernel state: -1 automatic, 0 workgroup-tiled, 1 wave-private
 int launch_spconv_wave(const SpconvArgs& a, hipStream_t st);   // wave-private tiling (spconv_wave.hip)
 

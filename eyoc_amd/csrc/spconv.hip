@@ -720,6 +720,8 @@ int spconv_forced_kernel() { return g_kernel_mode; }
 // layers, + 0.25 ms of rulebooks in the map build; the step is the same within noise) and 18 GB less HBM traffic per forward
 int g_up_kernel = getenv("EYOC_SPCONV_UP") ? atoi(getenv("EYOC_SPCONV_UP")) : 1;
 bool spconv_up_enabled() { return g_up_kernel != 0; }
+int g_down_staged = 0;   // strided convolutions on Z-ordered maps through the staged kernel (eyoc_spconv_select_down_kernel): off - their tiles overflow 2 passes
+bool spconv_down_staged() { return g_down_staged != 0; }
 
 int launch_spconv(const SpconvArgs& a, hipStream_t st) {
   EYOC_REQUIRE(a.in && a.w && a.out, EYOC_ERR_INVALID, "spconv: NULL tensor");
@@ -959,6 +961,12 @@ int eyoc_spconv_staged(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* local_
 int eyoc_spconv_select_up_kernel(int on) {
   const int prev = eyoc::g_up_kernel;
   if (on == 0 || on == 1) eyoc::g_up_kernel = on;
+  return prev;
+}
+
+int eyoc_spconv_select_down_kernel(int on) {
+  const int prev = eyoc::g_down_staged;
+  if (on == 0 || on == 1) eyoc::g_down_staged = on;
   return prev;
 }
 

@@ -166,6 +166,12 @@ int eyoc_spconv_select_split16_kernel(int mode);
  * kernel in windowed pattern order, 18 GB less HBM traffic per 128-cloud forward), 0 off; other values only query.  Returns the previous
  * state.  Process-wide, read when maps are built; for tests and profiling. */
 int eyoc_spconv_select_up_kernel(int on);
+/* Strided 3^3 / stride-2 convolutions on Z-ordered maps through the staged kernel (spconv_st.hip with local rulebooks of the
+ * strided table: a 256-row output tile's inputs - its rows' children plus a halo - are staged in LDS once per 32-channel
+ * block): 1 on, 0 off (default: wave-private kernel in windowed pattern order - a strided tile's ~1000+ distinct input rows
+ * overflow the two staging passes on LiDAR geometry, so the table falls back anyway); other values only query.  Returns the
+ * previous state.  Process-wide, read when maps are built; for tests and profiling. */
+int eyoc_spconv_select_down_kernel(int on);
 /* Stride-1 (3^3) split16 layers with a tile-local input stage (spconv_st.hip): per 256-row tile the distinct input rows are
  * copied to LDS once per 32-channel block and all 27 offsets run from there.  Needs the table's per-tile "local
  * rulebooks" (built once per table; *overflow_dev counts 256-row tiles with more than 1278 distinct input rows - the staged
@@ -245,6 +251,10 @@ int eyoc_model_pack_host(const eyoc_model_desc* desc, const eyoc_layer_params* l
 int eyoc_model_create(eyoc_ctx* ctx, const eyoc_model_desc* desc, const eyoc_layer_params* layers,
                       int n_layers, float* blob_dev, size_t blob_floats, eyoc_model** out);
 int eyoc_model_destroy(eyoc_model* model);
+/* split16 forwards run the network's 1x1 tail (conv1_tr -> ReLU -> final + bias -> row normalisation, model/resunet.py:183-191)
+ * as ONE kernel whose 64-channel intermediate never leaves the registers (spconv_tail.hip; BN2C's 96 -> 64 -> 32 widths):
+ * 1 on (default), 0 = two launches; other values only query.  Returns the previous state; process-wide, for tests. */
+int eyoc_model_fuse_tail(int on);
 size_t eyoc_model_workspace_bytes(const eyoc_model* model, const eyoc_maps* maps);
 /* feats_dev f32 [N1, in_channels] -> out_dev f32 [N1, out_channels], rows in input order */
 int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* model, const eyoc_maps* maps,

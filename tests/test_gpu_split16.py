@@ -413,3 +413,38 @@ def test_first_convolution_as_mfma_gemm_with_a_3x3x3_window():
     got = _forward(m, coords, feats)
     want = orr.resunet_forward(sd, coords, feats, conv1_kernel_size=3).numpy()
     assert m.last_spconv_math == "split16" and rel_err(got, want) < REL
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+def test_fused_tail_matches_the_two_layer_tail_and_the_oracle(normalize):
+    """conv1_tr -> ReLU -> final (+ bias) -> row normalisation in one kernel (spconv_tail.hip) against the same forward with
+    the two layers as separate launches (the products are summed in another order: equal to a few fp32 ulps, not bitwise)
+    and against the oracle; with and without the normalisation (model/resunet.py:187-191); ragged row count; planted zero row."""
+    import eyoc_amd
+    from eyoc_amd import synthetic as syn
+    from oracle import resunet as orr
+    L, lib = _lib()
+    p = syn.make_pair(7, beams=24, azimuths=700, band=None)
+    coords = syn.batch_coords([p["coords0"]])
+    assert len(coords) % 16 != 0 or len(coords) > 0
+    sd = syn.make_weights()
+    model = eyoc_amd.load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, conv1_kernel_size=5, normalize_feature=normalize)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model = model.cuda().eval()
+    model.spconv_math = "split16"
+    want = orr.resunet_forward(sd, coords, p["feats0"], normalize_feature=normalize).numpy()
+    outs = {}
+    prev = lib.eyoc_model_fuse_tail(-1)
+    try:
+        for fuse in (0, 1):
+            lib.eyoc_model_fuse_tail(fuse)
+            outs[fuse] = _forward(model, coords, p["feats0"])
+            assert model.last_spconv_math == "split16"
+    finally:
+        lib.eyoc_model_fuse_tail(prev)
+    scale = np.abs(want).max()
+    e_fused, e_two = np.abs(outs[1] - want).max() / scale, np.abs(outs[0] - want).max() / scale
+    d = np.abs(outs[1] - outs[0]).max() / scale
+    print(f"tail (normalize={normalize}, {len(coords)} rows): fused vs oracle {e_fused:.2e}, two launches vs oracle {e_two:.2e}, fused vs two {d:.2e}")
+    assert e_fused < REL and e_two < REL and d < 2e-6
+    assert e_fused <= 2 * e_two + 1e-6
