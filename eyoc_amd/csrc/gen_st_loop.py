@@ -98,6 +98,8 @@ def gen(NH, WD, skip=True, abl=()):
         a = WS(k % NWS, t, 1 if term == 2 else 0)
         b = XS(hs & 1, c, 1 if term == 1 else 0)
         acc = vr(ACC(h, c, t))
+        if "nom" in abl:
+            return
         emit(f"v_mfma_f32_16x16x32_f16 {acc}, {vr(a)}, {vr(b)}, {acc}")
 
     # ---- prologue: first weights / rulebook entries, stage landed, barrier, operands of half-step 0
@@ -131,6 +133,8 @@ def gen(NH, WD, skip=True, abl=()):
     emit("s_waitcnt vmcnt(0)")
     done[0] = len(vmq) - 1
     emit("s_barrier")
+    if "trace" in abl:          # diagnostics build: when did the stage land and the barrier open
+        emit("s_memtime %[tb]")
     for c in range(NC):
         t0, t1 = T[(c & 1) * 2], T[(c & 1) * 2 + 1]
         addr(0, 0, c, t0, t1)
@@ -185,7 +189,9 @@ def main(path):
         f.write("// (register map, schedule and wait counts: see the generator).\n")
         for name, NH, WD, skip, abl in (("NH2", 2, 1, True, ()), ("NH1", 1, 2, True, ()), ("NH2_NOSKIP", 2, 1, False, ()),
                                         ("NH2_NOW", 2, 1, True, ("now",)), ("NH2_NOX", 2, 1, True, ("nox", "nov")),
-                                        ("NH2_NOV", 2, 1, True, ("nov",))):
+                                        ("NH2_NOV", 2, 1, True, ("nov",)), ("NH2_NOM", 2, 1, True, ("nom",)),
+                                        ("NH2_NOMW", 2, 1, True, ("nom", "now")),
+                                        ("NH2_TRACE", 2, 1, True, ("trace",))):
             lines = gen(NH, WD, skip, abl)
             f.write(f"#define EYOC_ST_LOOP_{name} \\\n")
             for ln in lines:

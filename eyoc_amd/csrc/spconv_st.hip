@@ -21,6 +21,7 @@
 // one wave per SIMD: every stage, prologue and epilogue was exposed - 2.3 ms on the 3.8M-row 64 -> 64 layer, MFMA
 // pipe 43% busy; scripts/bench_staged.py + the EYOC_ST_ABL builds have the breakdown.)
 #include <atomic>
+#include <cstdlib>
 
 #include "spconv.h"
 
@@ -163,7 +164,6 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_kernel(SpconvArgs a, con
   const int cg = xcd % n_cg, tile = ((int)blockIdx.x >> 3) * per + xcd / n_cg;
   if (tile >= n_tiles) return;
   const int w0 = NH == 1 ? wave : 2 * (wave >> 1);                     // first 64-row quarter of this wave
-  const int row0 = tile * TILE + w0 * 64;                              // past n_out: the wave stages and multiplies zeros, stores nothing
   const int ct0 = cg * CTG + (NH == 2 ? (wave & 1) * CTW : 0);
   const int CT = a.cout >= 128 ? 128 : a.cout;
   const int n_slices = a.cout / CT, slice = ct0 / CT, nt0 = (ct0 - slice * CT) / 16;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_kernel(SpconvArgs a, con
 #pragma unroll
   for (int hc = 0; hc < NH * NC; ++hc) {
     const int h = hc / NC, c = hc % NC;
-    const int o = row0 + 64 * h + 16 * c + j;
+    const int o = tile * TILE + (w0 + h) * 64 + 16 * c + j;
     if (o >= a.n_out) continue;
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
@@ -356,6 +356,14 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_kernel(SpconvArgs a, con
 // (2 row halves x 2 channel halves per workgroup, >= 64 output channels), NH = 1: 64 rows x 32 channels (32-channel layers).
 // The stage lives in STATIC shared memory (80 KB; gfx950 allows 160 KB per workgroup), so the LDS base is 0 by
 // construction and no per-device function attribute is needed.
+#ifdef EYOC_ST_TRACE
+// diagnostics (scripts/trace_staged.py): per workgroup {start, header read, [blob in, barrier open, blob out] x 2, end, HW_ID}
+constexpr int TRACE_WGS = 16384, TRACE_N = 12;
+__device__ unsigned long long g_st_trace[TRACE_WGS * TRACE_N];
+#define ST_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < TRACE_WGS) g_st_trace[blockIdx.x * TRACE_N + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ST_STAMP(i) do {} while (0)
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
 
@@ -374,7 +382,6 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a,
   const int cg = xcd % n_cg, tile = ((int)blockIdx.x >> 3) * per + xcd / n_cg;
   if (tile >= n_tiles) return;
   const int w0 = NH == 1 ? wave : 2 * (wave >> 1);
-  const int row0 = tile * TILE + w0 * 64;
   const int ct0 = cg * CTG + (NH == 2 ? (wave & 1) * CTW : 0);
   const int CT = a.cout >= 128 ? 128 : a.cout;
   const int n_slices = a.cout / CT, slice = ct0 / CT, nt0 = (ct0 - slice * CT) / 16;
@@ -383,10 +390,9 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a,
   const int nqb = a.cin / 32;
   constexpr int K = 27;
 
+  ST_STAMP(0);
   const unsigned char* lr = local + (size_t)tile * LR_BYTES;
-  const int n_u = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(lr)[0]);
   const int* __restrict__ U = reinterpret_cast<const int*>(lr + 16);
-  const int n_pass = n_u > UMAX ? 2 : 1;
   if (threadIdx.x < 8)
     *reinterpret_cast<float4*>(xs + (threadIdx.x >> 2) * LO_REGION + UMAX * 64 + (threadIdx.x & 3) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -407,16 +413,18 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a,
 #pragma unroll
   for (int i = 0; i < 16; ++i) { A0[i] = 0.f; A1[i] = 0.f; A2[i] = 0.f; A3[i] = 0.f; }
 
+  // the row numbers of a pass are loaded ONCE, before anything depends on the tile's header (the list has UCAP entries whatever
+  // n_unique says; entries past it are never staged), and stay in 10 registers over the pass's 32-channel blocks: between two
+  // blocks the stage is then only a barrier and the DMA issue, not a dependent load -> DMA chain (the trace of
+  // scripts/trace_staged.py had 15 % of a workgroup's life between its blocks and 10 % before the first one)
   int n_up = 0;
+  int Ureg[NIT];
+  auto load_rows = [&](int pass) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) Ureg[it] = U[pass * UMAX + (it * NW + wave) * 16 + (lane >> 2)];
+  };
   auto stage = [&](int pass, int qb) {
     if constexpr (SKIP == 6) return;                                   // EYOC_ST_ABLATIONS: no stage
-    int Ureg[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      int l = (it * NW + wave) * 16 + (lane >> 2);
-      asm volatile("" : "+v"(l));
-      Ureg[it] = l < n_up ? U[pass * UMAX + l] : 0;
-    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int l0 = (it * NW + wave) * 16;
@@ -431,9 +439,13 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a,
     }
   };
 
+  load_rows(0);
+  const int n_u = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(lr)[0]);
+  const int n_pass = n_u > UMAX ? 2 : 1;
   bool first = true;
   for (int pass = 0; pass < n_pass; ++pass) {
     n_up = min(n_u - pass * UMAX, UMAX);
+    if (pass > 0) load_rows(pass);
     // this wave's occupancy masks of the pass: 14 dwords through the scalar cache, shifted so that bit (k & 1) * 16 + 4 h + c
     // of dword k / 2 is chunk c of the wave's row half h
     const unsigned int* mp = reinterpret_cast<const unsigned int*>(lr + MASK_OFF + pass * MASK_PASS_BYTES);
@@ -452,17 +464,35 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a,
       const int cc = (qb * 32) / CC, qp = ((qb * 32) % CC) / 32;
       const unsigned int ws0 = (unsigned)__builtin_amdgcn_readfirstlane(((slice * ncc + cc) * tile4 + (nt0 * JQ + 2 * qp) * 64) * 16);
       unsigned int so;
+#ifdef EYOC_ST_TRACE
+      unsigned long long tb = 0;
+      const int blk_i = pass * nqb + qb;
+      if (blk_i < 2) ST_STAMP(2 + 3 * blk_i);
+      if (blk_i == 0) ST_STAMP(1);
+#endif
 #define EYOC_ST_OPERANDS                                                                                                            \
   [wr] "s"(wr), [ws0] "s"(ws0), [ks] "s"(kstride), [lb] "s"(lb), [w1] "s"(w1off), "{s[36:43]}"(M0), "{s[44:51]}"(M1)
 #define EYOC_ST_ASM_NH2(TEXT)                                                                                                       \
   asm volatile(TEXT : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), "+{v[96:111]}"(A2), "+{v[112:127]}"(A3), [so] "=&s"(so)                   \
                : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS)
-      if constexpr (NH == 2 && (SKIP == 1 || SKIP >= 6)) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2);
+#ifdef EYOC_ST_TRACE
+      if constexpr (NH == 2 && SKIP == 1) {
+        asm volatile(EYOC_ST_LOOP_NH2_TRACE : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), "+{v[96:111]}"(A2), "+{v[112:127]}"(A3), [so] "=&s"(so), [tb] "=&s"(tb)
+                     : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS);
+        if (blk_i < 2) {
+          if (threadIdx.x == 0 && blockIdx.x < TRACE_WGS) g_st_trace[blockIdx.x * TRACE_N + 3 + 3 * blk_i] = tb;
+          ST_STAMP(4 + 3 * blk_i);
+        }
+      } else
+#endif
+      if constexpr (NH == 2 && (SKIP == 1 || SKIP == 6 || SKIP == 7)) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2);
       else if constexpr (NH == 2 && SKIP == 0) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOSKIP);
 #ifdef EYOC_ST_ABLATIONS       // timing-only builds of the loop (results are garbage): no weight loads / no operand reads / no address VALU
       else if constexpr (NH == 2 && SKIP == 3) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOW);
       else if constexpr (NH == 2 && SKIP == 4) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOX);
       else if constexpr (NH == 2 && SKIP == 5) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOV);
+      else if constexpr (NH == 2 && SKIP == 8) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOM);
+      else if constexpr (NH == 2 && SKIP == 9) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOMW);
 #endif
       else
         asm volatile(EYOC_ST_LOOP_NH1 : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), [so] "=&s"(so)
@@ -485,7 +515,7 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a,
 #pragma unroll
   for (int hc = 0; hc < NH * NC; ++hc) {
     const int h = hc / NC, c = hc % NC;
-    const int o = row0 + 64 * h + 16 * c + j;
+    const int o = tile * TILE + (w0 + h) * 64 + 16 * c + j;
     if (o >= a.n_out) continue;
     if (SKIP == 7 && os != 12345.f) continue;                          // EYOC_ST_ABLATIONS: no epilogue (the accumulators stay live)
     float4 v[NTW];
@@ -523,9 +553,31 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a,
     }
   }
   if (a.out_split) split16_report(a.range, mx);
+#ifdef EYOC_ST_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ST_STAMP(8);
+  if (threadIdx.x == 0 && blockIdx.x < TRACE_WGS) {
+    unsigned int hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_st_trace[blockIdx.x * TRACE_N + 9] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
 }
 
 }  // namespace
+
+#ifdef EYOC_ST_TRACE
+extern "C" int eyoc_debug_st_trace(unsigned long long* host, size_t n) {
+  if (n > (size_t)TRACE_WGS * TRACE_N) n = (size_t)TRACE_WGS * TRACE_N;
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_st_trace), n * 8) != hipSuccess) return -1;
+  unsigned long long* z = (unsigned long long*)calloc(n, 8);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_st_trace), z, n * 8);
+  free(z);
+  return 0;
+}
+#endif
 
 namespace eyoc {
 
@@ -544,14 +596,15 @@ int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char
 // without the empty-block branches (diagnostics)
 static std::atomic<int> g_st_variant{1};
 #ifdef EYOC_ST_ABLATIONS
-constexpr int ST_VARIANTS = 8;
+constexpr int ST_VARIANTS = 10;
 #else
 constexpr int ST_VARIANTS = 3;
 #endif
 int select_st_variant(int v) { return (v >= 0 && v < ST_VARIANTS) ? g_st_variant.exchange(v) : g_st_variant.load(); }
 
 // stride-1 SPLIT16 layers whose table has a local rulebook (rows in natural = Morton order, no tiling permutation)
-int launch_spconv_st(const SpconvArgs& a, const unsigned char* local_dev, hipStream_t st) {
+int launch_spconv_st(const SpconvArgs& a_in, const unsigned char* local_dev, hipStream_t st) {
+  const SpconvArgs& a = a_in;
   EYOC_REQUIRE(a.math == 1 && local_dev && !a.l2norm && a.K == 27 && !a.perm, EYOC_ERR_INVALID, "spconv_st: unsupported layer");
   const int ctg = a.cout >= 64 ? 64 : 32;                            // output channels per workgroup
   const bool wide = spconv_cc(a.cin, a.cout) == 64;
@@ -582,6 +635,8 @@ int launch_spconv_st(const SpconvArgs& a, const unsigned char* local_dev, hipStr
       else if (variant == 5) EYOC_STA(64, 2, 5);
       else if (variant == 6) EYOC_STA(64, 2, 6);
       else if (variant == 7) EYOC_STA(64, 2, 7);
+      else if (variant == 8) EYOC_STA(64, 2, 8);
+      else if (variant == 9) EYOC_STA(64, 2, 9);
 #endif
       else { if (wide) EYOC_STA(64, 2, 1); else EYOC_STA(32, 2, 1); }
     } else { if (wide) EYOC_STA(64, 1, 1); else EYOC_STA(32, 1, 1); }
