@@ -179,7 +179,15 @@ __global__ __launch_bounds__(NWK * 64, 4) void spconv_up_kernel(SpconvArgs a, co
 #pragma unroll
     for (int t = 0; t < NTW; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int lane_off = lane * 16;
+  // MFMA row 4 q + r of channel tile t is made channel 8 q + 4 t + r of the wave's 32 (instead of 16 t + 4 q + r), so that a
+  // lane's two accumulator tuples are 8 CONSECUTIVE channels = 16-byte epilogue accesses: lane (g, m) of tile t takes its
+  // weight row from the packed fragment of tile ch >> 4 at lane position 16 g + (ch & 15), ch = 8 (m >> 2) + 4 t + (m & 3)
+  int lane_off[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int ch = 8 * (j >> 2) + 4 * t + (j & 3);
+    lane_off[t] = (ch >> 4) * JQ * 1024 + (g * 16 + (ch & 15)) * 16;
+  }
   auto load_w = [&](int k, int qb, float4 (&W)[NTW][2]) {
     const int cc = (qb * 32) / CC, qp = ((qb * 32) % CC) / 32;
     const int wbase = __builtin_amdgcn_readfirstlane((((k * n_slices + slice) * ncc + cc) * tile4 + (nt0 * JQ + 2 * qp) * 64) * 16);
@@ -187,18 +195,16 @@ __global__ __launch_bounds__(NWK * 64, 4) void spconv_up_kernel(SpconvArgs a, co
     for (int t = 0; t < NTW; ++t)
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off + (t * JQ + p) * 1024, wbase, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off[t] + p * 1024, wbase, 0);
         W[t][p] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
       }
   };
-  auto stage = [&](int qb) {
-    int Ureg[NIT];
+  // the tile's row numbers: loaded once, before the header is needed (the list has XROWS entries whatever n_unique says),
+  // kept in registers over the 32-channel blocks - between two blocks the stage is then a barrier and the DMA issue only
+  int Ureg[NIT];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      int l = (it * NWK + wave) * 8 + (lane >> 3);
-      asm volatile("" : "+v"(l));
-      Ureg[it] = l < n_u ? U[l] : 0;
-    }
+  for (int it = 0; it < NIT; ++it) Ureg[it] = U[(it * NWK + wave) * 8 + (lane >> 3)];
+  auto stage = [&](int qb) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int l0 = (it * NWK + wave) * 8;
@@ -264,30 +270,46 @@ __global__ __launch_bounds__(NWK * 64, 4) void spconv_up_kernel(SpconvArgs a, co
     }
   }
 
-  // ---- epilogue: lane (g, j) holds channels 16 t + 4 g .. +3 of tile slot 64 sq + 16 c + j
+  // ---- epilogue: lane (g, j) holds channels 8 g .. 8 g + 7 (tuples t = 0, 1) of tile slot 64 sq + 16 c + j
   const float os = a.out_scale ? *a.out_scale : 1.0f;
+  const int ch = ct0 + 8 * g;
   float4 b4[NTW];
 #pragma unroll
   for (int t = 0; t < NTW; ++t)
-    b4[t] = a.bias ? *reinterpret_cast<const float4*>(a.bias + ct0 + 16 * t + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    b4[t] = a.bias ? *reinterpret_cast<const float4*>(a.bias + ch + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
   float mx = 0.f;
 #pragma unroll
   for (int c = 0; c < NG; ++c) {
     const int o = rowp[16 * c + j];
     if (o < 0) continue;
+    float4 v[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+      v[t] = make_float4(acc[c][t][0] * os + b4[t].x, acc[c][t][1] * os + b4[t].y, acc[c][t][2] * os + b4[t].z, acc[c][t][3] * os + b4[t].w);
+    if (a.res) {
+      const char* rp = reinterpret_cast<const char*>(a.res + (size_t)o * a.ld_res) + split16_off4(ch);
+      const uint4 rh = *reinterpret_cast<const uint4*>(rp), rl = *reinterpret_cast<const uint4*>(rp + SPLIT16_LO);
+      const float4 q0 = split16_decode4(make_uint2(rh.x, rh.y), make_uint2(rl.x, rl.y));
+      const float4 q1 = split16_decode4(make_uint2(rh.z, rh.w), make_uint2(rl.z, rl.w));
+      v[0].x += q0.x; v[0].y += q0.y; v[0].z += q0.z; v[0].w += q0.w;
+      v[1].x += q1.x; v[1].y += q1.y; v[1].z += q1.z; v[1].w += q1.w;
+    }
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-      const int ch = ct0 + 16 * t + 4 * g;
-      float4 v = make_float4(acc[c][t][0] * os + b4[t].x, acc[c][t][1] * os + b4[t].y, acc[c][t][2] * os + b4[t].z,
-                             acc[c][t][3] * os + b4[t].w);
-      if (a.res) {
-        const float4 q = split16_load4(a.res + (size_t)o * a.ld_res, ch);
-        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-      }
-      if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      split16_track(mx, v);
-      if (a.out_split) split16_store4(a.out + (size_t)o * a.ld_out, ch, v);
-      else *reinterpret_cast<float4*>(a.out + (size_t)o * a.ld_out + ch) = v;
+      if (a.relu) { v[t].x = fmaxf(v[t].x, 0.f); v[t].y = fmaxf(v[t].y, 0.f); v[t].z = fmaxf(v[t].z, 0.f); v[t].w = fmaxf(v[t].w, 0.f); }
+      split16_track(mx, v[t]);
+    }
+    if (a.out_split) {
+      uint2 h0, l0, h1, l1;
+      split16_encode4(v[0], h0, l0);
+      split16_encode4(v[1], h1, l1);
+      char* op = reinterpret_cast<char*>(a.out + (size_t)o * a.ld_out) + split16_off4(ch);
+      *reinterpret_cast<uint4*>(op) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+      *reinterpret_cast<uint4*>(op + SPLIT16_LO) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    } else {
+      float* op = a.out + (size_t)o * a.ld_out + ch;
+      *reinterpret_cast<float4*>(op) = v[0];
+      *reinterpret_cast<float4*>(op + 4) = v[1];
     }
   }
   if (a.out_split) split16_report(a.range, mx);
