@@ -606,12 +606,19 @@ int select_st_variant(int v) { return (v >= 0 && v < ST_VARIANTS) ? g_st_variant
 int launch_spconv_st(const SpconvArgs& a_in, const unsigned char* local_dev, hipStream_t st) {
   const SpconvArgs& a = a_in;
   EYOC_REQUIRE(a.math == 1 && local_dev && !a.l2norm && a.K == 27 && !a.perm, EYOC_ERR_INVALID, "spconv_st: unsupported layer");
-  const int ctg = a.cout >= 64 ? 64 : 32;                            // output channels per workgroup
+  const int n_tiles = cdiv(a.n_out, TILE);
+  // output channels per workgroup: 64 (waves of 128 rows x 32 channels) when that gives the 512 workgroup slots of the chip a few
+  // rounds of work; small problems (a batch of 8 pairs: 70 tiles at the coarsest level) take 32 (waves of 64 rows x 32 channels,
+  // twice the workgroups, each half as long) - below ~2 rounds a layer lasts as long as ONE workgroup does
+  // (measured: single pair 2.08 -> 1.84 ms with the threshold at 1024 workgroups; a batch of 8 pairs does not care)
+  constexpr int split_below = 1024;
+  const int variant0 = g_st_variant.load();
+  const bool small = variant0 != 0 && a.cout >= 64 && a.cout <= 256 && (long long)n_tiles * (a.cout / 64) < split_below;
+  const int ctg = a.cout >= 64 && !small ? 64 : 32;                  // output channels per workgroup
   const bool wide = spconv_cc(a.cin, a.cout) == 64;
   const int n_cg = a.cout / ctg;
   EYOC_REQUIRE(a.cout % ctg == 0 && n_cg >= 1 && n_cg <= 8 && 8 % n_cg == 0 && a.cin % 32 == 0, EYOC_ERR_INVALID,
                "spconv_st: %d -> %d channels", a.cin, a.cout);
-  const int n_tiles = cdiv(a.n_out, TILE);
   const dim3 grid((unsigned)(cdiv(n_tiles, 8 / n_cg) * 8)), block(NW * 64);
   const int variant = g_st_variant.load();
   if (variant == 0) {
