@@ -440,6 +440,10 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a,
   };
 
   load_rows(0);
+  // pull the tile's rulebook entries (13.8 KB, last touched by the builder: HBM by now) into L2 while the stage is in flight: the
+  // loop requests them only two offsets (~2000 cycles) ahead, less than an HBM round trip under load - one dword per 128-byte line
+  int warm = 0;
+  if (threadIdx.x < 27 * 64 * 8 / 128) warm = *reinterpret_cast<const int*>(lr + 16 + UCAP * 4 + threadIdx.x * 128);
   const int n_u = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(lr)[0]);
   const int n_pass = n_u > UMAX ? 2 : 1;
   bool first = true;
@@ -502,6 +506,7 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a,
     }
   }
 
+  asm volatile("" :: "v"(warm));
   // ---- epilogue straight from the registers.  The loop loads the weight rows permuted (gen_st_loop.py) so that lane (g, j)
   // holds, for row 64 h + 16 c + j, channels 8 g .. 8 g + 3 in tuple t = 0 and 8 g + 4 .. 8 g + 7 in tuple t = 1: 8 consecutive
   // channels = one 16-byte access per half of a SPLIT16 row (half as many memory instructions as 4-channel tuples)
