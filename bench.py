@@ -417,8 +417,8 @@ def worker(args):
     achieved_tf = flops / (conv_ms * 1e-3) / 1e12
     achieved_gbs = gather / (conv_ms * 1e-3) / 1e9
     math_mode = model.last_spconv_math
-    kernel = ("spconv_st_kernel<2, 64, 2> (12 of the launches; + spconv_st_kernel<2, 32, 1>, spconv_up_kernel, spconv_wave_kernel, spconv_rs_kernel)"
-              if math_mode == "split16" else "spconv_wave_kernel<...>") + " - the 22 sparse-conv launches of one forward, summed"
+    kernel = ("spconv_st_asm_kernel<64, 2, 1> (12 of the launches; + spconv_st_asm_kernel<32, 1, 1>, spconv_up_kernel, spconv_wave_kernel, "
+              "tail_fused_kernel)" if math_mode == "split16" else "spconv_wave_kernel<...>") + " - the sparse-conv launches of one forward, summed"
     if math_mode == "split16":
         # split16: every algorithmic fp32 multiply-add is three fp16 MFMA multiply-adds.  What binds these kernels is the
         # fp16 matrix pipe (counters: the pipe is busy >50 % of the kernel time while HBM runs at ~20 % - the staged kernel
@@ -450,7 +450,7 @@ def worker(args):
     out["survivors_per_pair"] = float(np.mean([r.survivors for b in last.values() for r in b]))
     # HBM traffic of the same kernels from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
     # WRITE_SIZE, separate passes; profiles/README.md) - quoted only when they were taken on this workload
-    for tag in ("r2", "r1"):
+    for tag in ("r3", "r2", "r1"):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_spconv_traffic.json")))
             if prof["workload"] == out["config"]["workload"]:

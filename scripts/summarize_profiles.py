@@ -40,7 +40,7 @@ t["hbm_read_GB_per_step_x2corr"] = t["FETCH_SIZE_KB_total"] * 1024 * 2 / steps /
 t["hbm_write_GB_per_step"] = t["WRITE_SIZE_KB_total"] * 1024 / steps / 1e9
 t = t.sort_values("hbm_read_GB_per_step_x2corr", ascending=False)
 t.to_csv(os.path.join(out, f"{tag}_hbm_traffic.csv"), index=False)
-sp = t[t.kernel.str.startswith("spconv_")]   # spconv_wave_kernel<...> and spconv_kernel<...>
+sp = t[t.kernel.str.startswith("spconv_") | t.kernel.str.startswith("tail_fused")]   # every sparse-conv launch (the fused 1x1 tail included)
 summary = {"steps_profiled": steps,
            "spconv_read_GB_per_forward_x2corr": float(sp.hbm_read_GB_per_step_x2corr.sum()),
            "spconv_read_GB_per_forward_raw": float(sp.FETCH_SIZE_KB_total.sum() * 1024 / steps / 1e9),
