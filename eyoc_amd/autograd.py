@@ -19,7 +19,20 @@ from . import _lib
 from .eval import knn1_segmented
 
 
+_PACK_CACHE: dict = {}      # (storage address, shape, content fingerprint, kind) -> packed device tensor; bounded below
+
+
 def _pack(weight: torch.Tensor, transposed: bool, mirror: bool) -> torch.Tensor:
+    """Weights in the MFMA fragment order the kernels consume (host packer of the library).  Cached on a CONTENT fingerprint
+    (three fp64 sums, one small read-back) next to address and shape: a forward and its backward - and every further step
+    until the parameter changes - share one D2H copy / pack / upload of the whole tensor instead of paying it two to three
+    times per layer and step; edits through ``.data`` or a recycled allocation cannot hit a stale entry."""
+    with torch.no_grad():
+        wd = weight.detach().double()
+        fp = torch.stack([wd.sum(), wd.abs().sum(), (wd * wd).sum()]).cpu().numpy().tobytes()
+    key = (weight.data_ptr(), tuple(weight.shape), fp, transposed, mirror, str(weight.device))
+    if key in _PACK_CACHE:
+        return _PACK_CACHE[key]
     lib = _lib.load()
     w = np.ascontiguousarray(weight.detach().cpu().numpy().astype(np.float32))
     K, cin, cout = w.shape
@@ -29,7 +42,11 @@ def _pack(weight: torch.Tensor, transposed: bool, mirror: bool) -> torch.Tensor:
     else:
         rc = lib.eyoc_spconv_pack_weights(w.ctypes.data, None, K, cin, cout, packed.ctypes.data)
     _lib.check(rc, "eyoc_spconv_pack_weights")
-    return torch.from_numpy(packed).to(weight.device)
+    out = torch.from_numpy(packed).to(weight.device)
+    if len(_PACK_CACHE) >= 128:         # stale contents of trained parameters: drop everything, the live ones come back
+        _PACK_CACHE.clear()
+    _PACK_CACHE[key] = out
+    return out
 
 
 def _run(table, n_out, x, packed, cin, cout):
@@ -63,7 +80,7 @@ class _SparseConv(torch.autograd.Function):
             dx = _run(ctx.table_t, ctx.n_in, dy, _pack(weight, True, ctx.mirror), cout, cin)
         if ctx.needs_input_grad[1]:
             n_out = dy.shape[0]
-            dw = torch.empty_like(weight, dtype=torch.float32)
+            dw = torch.empty(weight.shape, dtype=torch.float32, device=weight.device)   # dense [K, C_in, C_out], whatever the strides of `weight`
             with torch.cuda.device(x.device):
                 ws = _lib.workspace(lib.eyoc_spconv_grad_weight_workspace_bytes(K, n_out, cin, cout), x.device)
                 _lib.check(lib.eyoc_spconv_grad_weight(_lib.ctx(x.device.index), _lib.ptr(ctx.table), K, n_out, _lib.ptr(x), x.stride(0),

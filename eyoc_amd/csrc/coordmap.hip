@@ -456,7 +456,7 @@ size_t eyoc_maps_workspace_bytes(int n_rows) {
 
 int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, size_t ws_bytes, void* stream,
                     eyoc_maps** out) {
-  return eyoc_maps_build_ordered(ctx, coords_dev, n, ws, ws_bytes, stream, -1, out);
+  return eyoc_maps_build_ordered(ctx, coords_dev, n, ws, ws_bytes, stream, 0, out);   // the caller's row order: what the accessors promise
 }
 
 int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, void* ws, size_t ws_bytes, void* stream,

@@ -907,8 +907,14 @@ int eyoc_sc2pcr(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, int n
 //   params[b]: per pair (the seed count int(ratio * n) depends on n);  T_dev f32 [n_pairs,16];
 //   fitness_dev f32 [n_pairs, fitness_stride] (row b holds the n_seed_b seedwise values).
 size_t eyoc_sc2pcr_batched_workspace_bytes(int max_n, const eyoc_sc2pcr_params* params) {
+  return eyoc_sc2pcr_batched_workspace_bytes_n(max_n, SC2_CHUNK, params);
+}
+
+// ... for a call of n_pairs pairs: min(n_pairs, 16) slices (a single pair of 8000 points needs 0.11 GB, not 1.8)
+size_t eyoc_sc2pcr_batched_workspace_bytes_n(int max_n, int n_pairs, const eyoc_sc2pcr_params* params) {
   const size_t one = eyoc_sc2pcr_workspace_bytes(max_n, params);
-  return one ? align_up(one) * SC2_CHUNK : 0;
+  const int slices = n_pairs < 1 ? 1 : n_pairs < SC2_CHUNK ? n_pairs : SC2_CHUNK;
+  return one ? align_up(one) * slices : 0;
 }
 
 int eyoc_sc2pcr_batched(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int32_t* seg_host, int n_pairs,
@@ -928,8 +934,9 @@ int eyoc_sc2pcr_batched(eyoc_ctx* ctx, const float* src_dev, const float* tgt_de
     slice = need > slice ? need : slice;
   }
   slice = align_up(slice);
-  EYOC_REQUIRE(ws_bytes >= slice * SC2_CHUNK && ((uintptr_t)ws & 255) == 0, EYOC_ERR_WORKSPACE,
-               "eyoc_sc2pcr_batched: workspace %zu < required %zu bytes (256-byte aligned)", ws_bytes, slice * SC2_CHUNK);
+  const size_t slices = n_pairs < SC2_CHUNK ? n_pairs : SC2_CHUNK;
+  EYOC_REQUIRE(ws_bytes >= slice * slices && ((uintptr_t)ws & 255) == 0, EYOC_ERR_WORKSPACE,
+               "eyoc_sc2pcr_batched: workspace %zu < required %zu bytes (256-byte aligned)", ws_bytes, slice * slices);
   for (int b0 = 0; b0 < n_pairs; b0 += SC2_CHUNK) {   // chunks run back to back on `stream` and reuse the workspace slices
     const int nc = n_pairs - b0 < SC2_CHUNK ? n_pairs - b0 : SC2_CHUNK;
     int rc = sc2pcr_chunk(ctx, src_dev, tgt_dev, seg_host + b0, nc, params + b0, T_dev + 16 * (size_t)b0,

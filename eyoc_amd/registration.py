@@ -187,7 +187,7 @@ class Matcher:
         lib = _lib.load()
         i_max = int(np.argmax(ns))
         with torch.cuda.device(dev):
-            ws = _lib.workspace(lib.eyoc_sc2pcr_batched_workspace_bytes(ns[i_max], C.byref(params[i_max])), dev)
+            ws = _lib.workspace(lib.eyoc_sc2pcr_batched_workspace_bytes_n(ns[i_max], B, C.byref(params[i_max])), dev)
             _lib.check(lib.eyoc_sc2pcr_batched(_lib.ctx(dev.index), _lib.ptr(src), _lib.ptr(tgt), segc, B, params, _lib.ptr(T),
                                                _lib.ptr(fit), stride, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
                        "eyoc_sc2pcr_batched")

@@ -28,58 +28,64 @@ class CoordinateManager:
         self.coordinates = coordinates.to(torch.int32).contiguous()
         self._maps = None
         self._ws = None
+        self._maps_caller = None      # a second set in the caller's row order, built only if an accessor needs one
+        self._ws_caller = None
 
     @property
     def device(self):
         return self.coordinates.device
 
+    def _build(self, order: int):
+        lib = _lib.load()
+        n = self.coordinates.shape[0]
+        with torch.cuda.device(self.device):
+            ws = _lib.workspace(lib.eyoc_maps_workspace_bytes(n), self.device)
+            h = C.c_void_p()
+            _lib.check(lib.eyoc_maps_build_ordered(_lib.ctx(self.device.index), _lib.ptr(self.coordinates), n,
+                                                   _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), int(order),
+                                                   C.byref(h)), "eyoc_maps_build")
+        return h, ws
+
     def maps(self, order: int = 0):
         """The device-side maps, built on first use.  ``order``: internal row order of a build that happens now -
         ``-1`` automatic (Z-order from 8192 rows: what the network forward is fastest on - ``model(x)`` asks for it),
-        ``0`` (default of the accessors below and of the autograd layer functions) the caller's order, so that
-        ``level_coordinates`` / ``table`` line up with the caller's feature rows; ``1`` Z-order.  Once built the maps
-        stay as they are; ``row_order()`` tells which order that is."""
+        ``0`` the caller's order; ``1`` Z-order.  Once built the maps stay as they are; ``row_order()`` tells which
+        order that is.  The accessors below (``level_coordinates``, ``table``, ``up_order``) always answer in the
+        CALLER's rows: if these maps are Z-ordered they build - once - a second set in the caller's order."""
         if self._maps is None:
-            lib = _lib.load()
-            n = self.coordinates.shape[0]
-            with torch.cuda.device(self.device):
-                self._ws = _lib.workspace(lib.eyoc_maps_workspace_bytes(n), self.device)
-                h = C.c_void_p()
-                _lib.check(lib.eyoc_maps_build_ordered(_lib.ctx(self.device.index), _lib.ptr(self.coordinates), n,
-                                                       _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr(), int(order),
-                                                       C.byref(h)), "eyoc_maps_build")
-            self._maps = h
+            self._maps, self._ws = self._build(order)
         return self._maps
+
+    def _caller_maps(self):
+        """Maps whose internal rows are the caller's rows (what the autograd layer functions and diagnostics index
+        features with): the main set when it kept the caller's order, else a second set built on first use."""
+        if not _lib.load().eyoc_maps_row_order(self.maps()):
+            return self._maps
+        if self._maps_caller is None:
+            self._maps_caller, self._ws_caller = self._build(0)
+        return self._maps_caller
 
     def rows(self, level: int) -> int:
         return int(_lib.load().eyoc_maps_rows(self.maps(), level))
 
-    def _check_order(self, internal):
-        """Level coordinates, tables and tiling orders are in the maps' INTERNAL rows.  When those are Z-ordered (the
-        maps were first built by a network forward on >= 8192 rows) they do not line up with the caller's feature rows:
-        refuse unless the caller says it knows (``internal=True``; ``row_order()`` is the permutation)."""
-        if not internal and _lib.load().eyoc_maps_row_order(self.maps()):
-            raise ValueError("these maps keep their rows in Z-order (built by model(x)); pass internal=True and use "
-                             "row_order(), or read the accessors BEFORE the first forward (they build the maps in the caller's order)")
-
     def level_coordinates(self, level: int, internal: bool = False) -> torch.Tensor:
-        """Copy of the level's coordinates ``int32 [rows,4]`` (diagnostics / tests)."""
-        self._check_order(internal)
+        """Copy of the level's coordinates ``int32 [rows,4]`` in the caller's rows (``internal=True``: in the rows of the
+        maps the network forward uses - Z-ordered for large inputs, see ``row_order()``)."""
+        m = self.maps() if internal else self._caller_maps()
         n = self.rows(level)
         out = torch.empty((n, 4), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(_lib.load().eyoc_maps_copy_coords(self.maps(), level, _lib.ptr(out), _lib.stream_ptr()),
-                       "eyoc_maps_copy_coords")
+            _lib.check(_lib.load().eyoc_maps_copy_coords(m, level, _lib.ptr(out), _lib.stream_ptr()), "eyoc_maps_copy_coords")
         return out
 
     def table(self, kind: int, level: int, internal: bool = False) -> torch.Tensor:
-        """Copy of a rulebook ``int32 [27, n_out]`` (diagnostics / tests, the autograd layer functions)."""
-        self._check_order(internal)
+        """Copy of a rulebook ``int32 [27, n_out]`` in the caller's rows (the autograd layer functions index features
+        with it); ``internal=True``: the forward's own (possibly Z-ordered) table."""
+        m = self.maps() if internal else self._caller_maps()
         n_out = {0: self.rows(level), 1: self.rows(level + 1), 2: self.rows(level)}[kind]
         out = torch.empty((27, n_out), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(_lib.load().eyoc_maps_copy_table(self.maps(), kind, level, _lib.ptr(out), _lib.stream_ptr()),
-                       "eyoc_maps_copy_table")
+            _lib.check(_lib.load().eyoc_maps_copy_table(m, kind, level, _lib.ptr(out), _lib.stream_ptr()), "eyoc_maps_copy_table")
         return out
 
     def row_order(self) -> torch.Tensor | None:
@@ -96,11 +102,10 @@ class CoordinateManager:
 
     def up_order(self, level: int, internal: bool = False) -> torch.Tensor:
         """Copy of the row order ``int32 [rows(level)]`` the transposed convolutions tile their outputs in."""
-        self._check_order(internal)
+        m = self.maps() if internal else self._caller_maps()
         out = torch.empty((self.rows(level),), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(_lib.load().eyoc_maps_copy_up_order(self.maps(), level, _lib.ptr(out), _lib.stream_ptr()),
-                       "eyoc_maps_copy_up_order")
+            _lib.check(_lib.load().eyoc_maps_copy_up_order(m, level, _lib.ptr(out), _lib.stream_ptr()), "eyoc_maps_copy_up_order")
         return out
 
     def info(self, conv1_kernel_size: int = 0) -> dict:
@@ -115,9 +120,10 @@ class CoordinateManager:
 
     def __del__(self):
         try:
-            if self._maps is not None:
-                _lib.load().eyoc_maps_free(self._maps)
-                self._maps = None
+            for name in ("_maps", "_maps_caller"):
+                if getattr(self, name, None) is not None:
+                    _lib.load().eyoc_maps_free(getattr(self, name))
+                    setattr(self, name, None)
         except Exception:
             pass
 

@@ -80,7 +80,8 @@ typedef struct {
 size_t eyoc_maps_workspace_bytes(int n_rows);
 int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n_rows, void* workspace_dev,
                     size_t workspace_bytes, void* stream, eyoc_maps** out);
-/* The same with the internal row order chosen by the caller: -1 automatic (Z-order from 8192 rows: what
+/* eyoc_maps_build keeps the CALLER's row order (the accessors below return level coordinates and tables in the caller's
+ * rows).  The same with the internal row order chosen by the caller: -1 automatic (Z-order from 8192 rows: what
  * eyoc_model_forward is fastest on), 0 the caller's order (the level coordinates and tables the accessors below return
  * are then in the caller's rows), 1 Z-order.  eyoc_maps_internal_order(0 / 1) overrides it process-wide. */
 int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n_rows, void* workspace_dev,
@@ -421,7 +422,9 @@ int eyoc_sc2pcr(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, int n
  * pair b = rows [seg[b], seg[b+1]) of src / tgt (seg: HOST array of n_pairs + 1 ints), params[b] per pair,
  * T_dev f32 [n_pairs,16], fitness_dev f32 [n_pairs, fitness_stride].  Pairs run concurrently on internal side
  * streams, forked from / joined to `stream`; results are bit-identical to eyoc_sc2pcr on each pair. */
-size_t eyoc_sc2pcr_batched_workspace_bytes(int max_n, const eyoc_sc2pcr_params* params);
+size_t eyoc_sc2pcr_batched_workspace_bytes(int max_n, const eyoc_sc2pcr_params* params);   /* for any n_pairs (16 slices) */
+/* ... for a call of exactly n_pairs pairs: min(n_pairs, 16) slices of the largest pair's workspace */
+size_t eyoc_sc2pcr_batched_workspace_bytes_n(int max_n, int n_pairs, const eyoc_sc2pcr_params* params);
 int eyoc_sc2pcr_batched(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int32_t* seg_host,
                         int n_pairs, const eyoc_sc2pcr_params* params, float* T_dev, float* fitness_dev,
                         int fitness_stride, void* workspace_dev, size_t workspace_bytes, void* stream);

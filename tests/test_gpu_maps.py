@@ -164,25 +164,32 @@ def test_z_ordered_maps_reject_duplicates_and_out_of_range(zorder_rows):
     eyoc_amd.CoordinateManager(torch.from_numpy(coords).cuda()).maps()    # and the clean cloud builds
 
 
-def test_accessors_refuse_z_ordered_maps_unless_told():
-    """A forward on >= 8192 rows builds Z-ordered maps; their tables are in internal rows and the accessors say so
-    instead of handing them to code that indexes features in the caller's order."""
+def test_accessors_answer_in_the_callers_rows_after_a_z_ordered_forward():
+    """A forward on >= 8192 rows builds Z-ordered maps.  The accessors (what the autograd layer functions index the caller's
+    feature rows with) still answer in the CALLER's rows - from a second map set built on first use - and equal the oracle's
+    tables of the cloud as given; ``internal=True`` hands out the forward's own rows."""
     import eyoc_amd
-    from eyoc_amd import synthetic as syn
+    from eyoc_amd import _lib, synthetic as syn
+    from oracle import coords as oc
     from test_gpu_round2 import _model
     p = syn.make_pair(1)
     coords = syn.batch_coords([p["coords0"]])
     model, _sd = _model()
     x = eyoc_amd.SparseTensor(torch.from_numpy(p["feats0"]).cuda(), coordinates=torch.from_numpy(coords).cuda())
-    model(x)
+    f1 = model(x).F
     cm = x.coordinate_manager
-    assert cm.row_order() is not None
-    with pytest.raises(ValueError, match="Z-order"):
-        cm.table(0, 0)
-    assert cm.table(0, 0, internal=True).shape == (27, len(coords))
+    perm = cm.row_order()
+    assert perm is not None                                              # the forward's maps are Z-ordered
+    want = oc.build_maps(coords)
+    np.testing.assert_array_equal(cm.table(_lib.MAP_S1, 0).cpu().numpy(), want["s1"][0])
+    np.testing.assert_array_equal(cm.level_coordinates(1).cpu().numpy(), want["cm"][1].coords)
+    np.testing.assert_array_equal(cm.table(_lib.MAP_DOWN, 0).cpu().numpy(), want["down"][0])
+    assert cm.row_order() is not None                                    # ... and the forward's maps were left alone
+    inner = cm.level_coordinates(0, internal=True).cpu().numpy()
+    np.testing.assert_array_equal(inner, coords[perm.cpu().numpy()])
     # the other way round: accessors first -> the caller's order, and the forward then runs on those maps
     x2 = eyoc_amd.SparseTensor(torch.from_numpy(p["feats0"]).cuda(), coordinates=torch.from_numpy(coords).cuda())
     t = x2.coordinate_manager.table(0, 0)
     assert x2.coordinate_manager.row_order() is None and t.shape == (27, len(coords))
-    f1, f2 = model(x).F, model(x2).F
+    f2 = model(x2).F
     assert float((f1 - f2).abs().max()) < 1e-5
