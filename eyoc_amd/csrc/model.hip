@@ -390,6 +390,7 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
         }
       }
       a.parent = maps->parent[0]; a.children = maps->children[0]; a.s1c = maps->nbr_s1[1]; a.nc = maps->rows[1];
+      a.local1 = maps->row_perm ? maps->local_s1[1] : nullptr;          // Z-ordered maps: the level-1 tile rulebooks
       rc = conv1_walks_octree(a) ? EYOC_OK : maps_build_table0(const_cast<eyoc_maps*>(maps), st);
       if (!rc) rc = launch_conv1(a, st);
     } else if (split && g_fuse_tail && li + 2 == m->layers.size() && p.map == M_IDENT && p.K == 1 && p.res_buf < 0 &&

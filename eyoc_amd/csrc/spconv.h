@@ -147,7 +147,12 @@ struct Conv1Args {
   const int32_t* children;  // [nc][8]
   const int32_t* s1c;       // [27][nc]
   int nc;
+  // tile-local rulebooks of the level-1 stride-1 table (build_local_rulebook; Z-ordered maps) or NULL: with them the first
+  // convolution stages the child features of a 256-parent tile's neighbourhood in LDS once (conv1_st_kernel)
+  const unsigned char* local1 = nullptr;
 };
+// layout of a local rulebook record (spconv_st.hip owns it; conv1_st_kernel in spconv.hip reads the row list and the entries)
+constexpr int ST_TILE = 256, ST_UMAX = 639, ST_UCAP = 1280, ST_NPASS = 2, ST_LOC_OFF = 16 + ST_UCAP * 4, ST_LR_BYTES = 32896;
 int launch_conv1(const Conv1Args& a, hipStream_t st);
 bool conv1_walks_octree(const Conv1Args& a);   // false: launch_conv1 will probe a.table (it must be built)
 

@@ -556,8 +556,10 @@ __global__ __launch_bounds__(256) void conv1_tree_kernel(Conv1Args a) {
 // [16 x 128] x [128 x 32] split16 GEMM per tile: 4 k-steps x 3 terms x 2 channel tiles = 24 MFMAs, weights resident in
 // registers (pre-scaled by 2^8 so that their lo halves stay normal).
 __global__ __launch_bounds__(256, 4) void conv1_mfma_kernel(Conv1Args a) {
-  constexpr int COUT = 32, KP = 128, NT = COUT / 16, NQ = KP / 32;
-  __shared__ __attribute__((aligned(16))) _Float16 xt[4][2][16][KP];   // [wave][hi / lo][row][window position]
+  constexpr int COUT = 32, KP = 128, KPS = KP + 8, NT = COUT / 16, NQ = KP / 32;
+  // row stride KP + 8 halves = 272 B = 68 dwords: the 16 rows of a tile that write the SAME window position (one ds_write_b16, lanes of
+  // one parity class) land in 16 different banks - at 256 B they all hit one (a 16-way conflict on every write: measured 1.1 -> ? ms)
+  __shared__ __attribute__((aligned(16))) _Float16 xt[4][2][16][KPS];   // [wave][hi / lo][row][window position]
   __shared__ __attribute__((aligned(8))) signed char ktab[8][216];                                // window position of slot (block kc, child cs) for a row of parity class cls, -1: outside
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -584,8 +586,8 @@ __global__ __launch_bounds__(256, 4) void conv1_mfma_kernel(Conv1Args a) {
         wh[q][t][i] = h;
         wl[q][t][i] = (_Float16)(w - (float)h);
       }
-  _Float16 (*xh)[KP] = xt[wave][0];
-  _Float16 (*xl)[KP] = xt[wave][1];
+  _Float16 (*xh)[KPS] = xt[wave][0];
+  _Float16 (*xl)[KPS] = xt[wave][1];
   const int n_tiles = (a.n + 15) / 16;
   // persistent waves: the weight fragments above are loaded once per wave, not once per 16 rows
   for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
@@ -594,7 +596,8 @@ __global__ __launch_bounds__(256, 4) void conv1_mfma_kernel(Conv1Args a) {
   {
     float4* z = reinterpret_cast<float4*>(&xt[wave][0][0][0]);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) z[i * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < (2 * 16 * KPS * 2 / 16 + 63) / 64; ++i)
+      if (i * 64 + lane < 2 * 16 * KPS * 2 / 16) z[i * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (o < a.n) {
     const int4 c = reinterpret_cast<const int4*>(a.coords)[o];
@@ -720,6 +723,7 @@ int spconv_forced_kernel() { return g_kernel_mode; }
 // layers, + 0.25 ms of rulebooks in the map build; the step is the same within noise) and 18 GB less HBM traffic per forward
 int g_up_kernel = getenv("EYOC_SPCONV_UP") ? atoi(getenv("EYOC_SPCONV_UP")) : 1;
 bool spconv_up_enabled() { return g_up_kernel != 0; }
+int g_conv1_staged = getenv("EYOC_CONV1_ST") ? atoi(getenv("EYOC_CONV1_ST")) : 1;   // diagnostics switch of conv1_st_kernel
 int g_down_staged = 0;   // strided convolutions on Z-ordered maps through the staged kernel (eyoc_spconv_select_down_kernel): off - their tiles overflow 2 passes
 bool spconv_down_staged() { return g_down_staged != 0; }
 
@@ -805,6 +809,232 @@ int launch_permute_rows(const float* in, const int32_t* perm, int n, int c, floa
   return EYOC_OK;
 }
 
+// ---- first convolution with a tile-local stage (round 3; Z-ordered maps, C_in = 1, 32 output channels, split16 downstream).
+// conv1_mfma_kernel above probes, for EVERY fine row, the 27 coarse blocks around its parent and their 8 children each: ~60
+// dependent loads per lane and 16-row tile although the ~2.4 children of a parent share all of them and neighbouring parents most.
+// Here a workgroup takes one 256-row tile of LEVEL 1 (the parents) and its local rulebook (the one the staged convolution of level
+// 1 uses: the distinct level-1 rows U its 27-neighbourhoods touch, and per (offset, parent) the slot of the neighbour):
+//   1. for every slot of U: the block's 8 child links and their input features -> cf[slot][8] in LDS (0 for a missing child):
+//      ~6 loads per fine row instead of ~216;
+//   2. the tile's fine rows are a contiguous row range (Z-order: children of consecutive parents are consecutive); a wave takes 16 of
+//      them; lane (g, j) walks a quarter of the 27 offsets of row j's parent: slot from the rulebook entry (one 2-byte load), the 8
+//      child features from LDS, the window position of (offset, child) for the row's parity class from a table, and writes the
+//      hi / lo halves into the row's line of the [16 x 128] operand tile;
+//   3. the same 24 MFMAs ([16 x 128] x [128 x 32], split16) and epilogue as conv1_mfma_kernel.
+__global__ __launch_bounds__(256, 2) void conv1_st_kernel(Conv1Args a) {
+  constexpr int COUT = 32, KP = 128, KPS = KP + 8, NT = COUT / 16, NQ = KP / 32;
+  constexpr int NSLOT = ST_NPASS * ST_UMAX + 1;                                        // + one block without children: "no neighbour"
+  constexpr int ZSLOT = NSLOT - 1;
+  __shared__ __attribute__((aligned(16))) _Float16 cfh[NSLOT][8], cfl[NSLOT][8];     // hi / lo halves of the 8 child features of a staged block
+  __shared__ unsigned char cval[NSLOT];                                              // which children carry a non-zero feature
+  __shared__ __attribute__((aligned(16))) _Float16 xt[4][2][16][KPS];                // [wave][hi / lo][row][window position], padded rows
+  __shared__ __attribute__((aligned(8))) signed char ktab[8][216];                   // window position of (block kc, child cs) for parity class cls
+  __shared__ unsigned char wmask[8][28];                                             // children of block kc inside the window, per class
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int K = a.ks * a.ks * a.ks, r = a.ks / 2;
+  const int tile = blockIdx.x;
+  for (int e = threadIdx.x; e < 8 * 27; e += 256) {
+    const int cls = e / 27, kc = e % 27;
+    unsigned int m = 0;
+    for (int cs = 0; cs < 8; ++cs) {
+      const int dx = 2 * (kc % 3 - 1) + (cs & 1) - (cls & 1), dy = 2 * ((kc / 3) % 3 - 1) + ((cs >> 1) & 1) - ((cls >> 1) & 1),
+                dz = 2 * (kc / 9 - 1) + (cs >> 2) - (cls >> 2);
+      const bool in = dx >= -r && dx <= r && dy >= -r && dy <= r && dz >= -r && dz <= r;
+      ktab[cls][kc * 8 + cs] = (signed char)(in ? (dx + r) + a.ks * (dy + r) + a.ks * a.ks * (dz + r) : -1);
+      m |= (in ? 1u : 0u) << cs;
+    }
+    wmask[cls][kc] = (unsigned char)m;
+  }
+  // ---- 1. stage: child features of the tile's distinct level-1 rows, already split into fp16 hi / lo halves
+  const unsigned char* lr = a.local1 + (size_t)tile * ST_LR_BYTES;
+  const int n_u = *reinterpret_cast<const int*>(lr);
+  const int* __restrict__ U = reinterpret_cast<const int*>(lr + 16);
+  const float* __restrict__ fin = a.in;
+  {
+    // three rounds of independent loads (row numbers, child links, child features): a dependent chain per slot would cost
+    // three memory round trips for each of a thread's (up to 5) slots in turn
+    constexpr int NS = (NSLOT + 255) / 256;                                            // 5
+    int u[NS];
+    int4 c0[NS], c1[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int s = (int)threadIdx.x + 256 * i;
+      u[i] = s < n_u ? U[s] : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      c0[i] = c1[i] = make_int4(-1, -1, -1, -1);
+      if (u[i] >= 0) {
+        c0[i] = reinterpret_cast<const int4*>(a.children)[2 * (size_t)u[i]];
+        c1[i] = reinterpret_cast<const int4*>(a.children)[2 * (size_t)u[i] + 1];
+      }
+    }
+    float f[NS][8];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int v[8] = {c0[i].x, c0[i].y, c0[i].z, c0[i].w, c1[i].x, c1[i].y, c1[i].z, c1[i].w};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) f[i][q] = (256 * i < n_u && v[q] >= 0) ? fin[v[q]] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int s = (int)threadIdx.x + 256 * i;
+      if (s < n_u || s == ZSLOT) {
+        half8_t h8, l8;
+        unsigned int m = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float x = s < n_u ? f[i][q] : 0.f;
+          h8[q] = (_Float16)x;
+          l8[q] = (_Float16)(x - (float)h8[q]);
+          m |= (x != 0.f ? 1u : 0u) << q;
+        }
+        *reinterpret_cast<half8_t*>(&cfh[s][0]) = h8;
+        *reinterpret_cast<half8_t*>(&cfl[s][0]) = l8;
+        cval[s] = (unsigned char)m;
+      }
+    }
+  }
+  // the tile's fine rows: from the first child of its first parent to the first child of the next tile's first parent
+  auto first_child = [&](int prow) {
+    if (prow >= a.nc) return a.n;
+    const int4 c0 = reinterpret_cast<const int4*>(a.children)[2 * (size_t)prow], c1 = reinterpret_cast<const int4*>(a.children)[2 * (size_t)prow + 1];
+    const int v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    int m = a.n;
+    for (int i = 0; i < 8; ++i) if (v[i] >= 0 && v[i] < m) m = v[i];
+    return m;
+  };
+  const int f0 = first_child(tile * ST_TILE), f1 = first_child((tile + 1) * ST_TILE);
+  // weight fragments (A operand): lane (g, j): W[k = 32 q + 8 g + i][cout = 16 t + j] * 256, split
+  half8_t wh[NQ][NT], wl[NQ][NT];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = 32 * q + 8 * g + i;
+        const float w = k < K ? a.w[(size_t)k * COUT + 16 * t + j] * 256.0f : 0.0f;
+        const _Float16 h = (_Float16)w;
+        wh[q][t][i] = h;
+        wl[q][t][i] = (_Float16)(w - (float)h);
+      }
+  __syncthreads();
+  _Float16 (*xh)[KPS] = xt[wave][0];
+  _Float16 (*xl)[KPS] = xt[wave][1];
+  const int n_pass = n_u > ST_UMAX ? 2 : 1;
+  const unsigned short* __restrict__ loc = reinterpret_cast<const unsigned short*>(lr + ST_LOC_OFF);
+  float mx = 0.f;
+  // ---- 2. + 3. 16 fine rows per wave and step; lane (g, j) walks offsets g, g + 4, ... of row j's parent.  Two dependent global
+  // round trips stand before a step's LDS work (row -> parent, parent -> rulebook entries) and 8 waves per CU hide nothing: they
+  // are software-pipelined - coordinates / parent two steps ahead, entries one step ahead, all loads unconditional (clamped
+  // rows; a load inside a branch is waited for on the spot)
+  auto load_row = [&](int base, int& cls, int& ew, int& ec) {
+    int o = base + j;
+    o = o < a.n ? o : a.n - 1;
+    const int4 c = reinterpret_cast<const int4*>(a.coords)[o];
+    int pl = a.parent[o] - tile * ST_TILE;
+    pl = pl < 0 ? 0 : pl > ST_TILE - 1 ? ST_TILE - 1 : pl;                              // rows of other tiles (past f1): any valid entry
+    cls = (c.y & 1) | ((c.z & 1) << 1) | ((c.w & 1) << 2);
+    ew = (pl >> 6) * 16 + (pl & 15);                                                   // the parent's place in an entry: (16 w + j, c)
+    ec = (pl >> 4) & 3;
+  };
+  auto load_entries = [&](int ew, int ec, int (&e)[7]) {
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      const int kc = g + 4 * t < 27 ? g + 4 * t : 26;
+      e[t] = loc[((size_t)kc * 64 + ew) * 4 + ec];
+    }
+  };
+  const int base_first = f0 + 16 * wave;
+  int clsB, ewB, ecB, clsA, ewA, ecA, eB[7];
+  load_row(base_first, clsB, ewB, ecB);
+  load_row(base_first + 64, clsA, ewA, ecA);
+  load_entries(ewB, ecB, eB);
+  for (int base = base_first; base < f1; base += 64) {
+    const int o = base + j;
+    // this step's data (loaded a step ago), then the requests of the next two steps
+    const int cls = clsB, ew = ewB, ec = ecB;
+    int ecur[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) ecur[t] = eB[t];
+    clsB = clsA; ewB = ewA; ecB = ecA;
+    load_entries(ewB, ecB, eB);
+    load_row(base + 128, clsA, ewA, ecA);
+    {
+      float4* z = reinterpret_cast<float4*>(&xt[wave][0][0][0]);
+#pragma unroll
+      for (int q = 0; q < (2 * 16 * KPS * 2 / 16 + 63) / 64; ++q)
+        if (q * 64 + lane < 2 * 16 * KPS * 2 / 16) z[q * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (o < f1) {
+      int slot[7];
+#pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        const int kc = g + 4 * t;
+        int sl = ZSLOT;
+        if (kc < 27) {
+          const int e0 = ecur[t] >> 6;                                                   // entry = 64 l + swizzle
+          if (e0 != ST_UMAX) sl = e0;
+          else if (n_pass > 1) {                                                        // rare: the neighbour sits in the second pass
+            const int e1 = loc[((size_t)(27 + kc) * 64 + ew) * 4 + ec] >> 6;
+            if (e1 != ST_UMAX) sl = ST_UMAX + e1;
+          }
+        }
+        slot[t] = sl;
+      }
+      // only the children that exist, carry a feature and fall inside the window are visited (~1 of 8 per block)
+#pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        const int kc = g + 4 * t;
+        unsigned int m = kc < 27 ? (unsigned)cval[slot[t]] & (unsigned)wmask[cls][kc] : 0u;
+        while (m) {
+          const int cs = __builtin_ctz(m);
+          m &= m - 1;
+          const int kpos = ktab[cls][kc * 8 + cs];
+          xh[j][kpos] = cfh[slot[t]][cs];
+          xl[j][kpos] = cfl[slot[t]][cs];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const half8_t vh = *reinterpret_cast<const half8_t*>(&xh[j][32 * q + 8 * g]);
+      const half8_t vl = *reinterpret_cast<const half8_t*>(&xl[j][32 * q + 8 * g]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q][t], vh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q][t], vl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[q][t], vh, acc[t], 0, 0, 0);
+      }
+    }
+    if (o < f1) {
+      float* dst = a.out + (size_t)o * a.ld_out;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int ch0 = 16 * t + 4 * g;
+        const float4 b = *reinterpret_cast<const float4*>(a.bias + ch0);
+        const float4 v = make_float4(acc[t][0] * (1.0f / 256.0f) + b.x, acc[t][1] * (1.0f / 256.0f) + b.y,
+                                     acc[t][2] * (1.0f / 256.0f) + b.z, acc[t][3] * (1.0f / 256.0f) + b.w);
+        split16_track(mx, v);
+        if (a.out_split) split16_store4(dst, ch0, v);
+        else *reinterpret_cast<float4*>(dst + ch0) = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (a.out_split) split16_report(a.range, mx);
+}
+
 int launch_conv1(const Conv1Args& a, hipStream_t st) {
   EYOC_REQUIRE(a.ks == 1 || a.ks == 3 || a.ks == 5 || a.ks == 7, EYOC_ERR_INVALID, "conv1: kernel size %d", a.ks);
   EYOC_REQUIRE(a.cin >= 1 && a.cin * a.cout <= 8192, EYOC_ERR_INVALID, "conv1: C_in %d x C_out %d too large", a.cin, a.cout);
@@ -817,6 +1047,11 @@ int launch_conv1(const Conv1Args& a, hipStream_t st) {
     // products carry 22-bit significands like every split16 layer; fp32 consumers keep the exact-fp32 walker
     static const bool mfma_env = !(getenv("EYOC_CONV1_MFMA") && atoi(getenv("EYOC_CONV1_MFMA")) == 0);
     if (mfma_env && a.cin == 1 && a.cout == 32 && a.out_split && a.ks * a.ks * a.ks < 128 && !a.in_perm) {
+      if (a.local1 && g_conv1_staged) {                               // Z-ordered maps: child features staged per 256-parent tile
+        hipLaunchKernelGGL(conv1_st_kernel, dim3(cdiv(a.nc, ST_TILE)), dim3(256), 0, st, a);
+        EYOC_CHECK_HIP(hipGetLastError());
+        return EYOC_OK;
+      }
       const int wgs = cdiv(a.n, 64);
       hipLaunchKernelGGL(conv1_mfma_kernel, dim3(wgs < 2560 ? wgs : 2560), dim3(256), 0, st, a);   // 10 workgroups per CU, persistent
       EYOC_CHECK_HIP(hipGetLastError());

@@ -56,6 +56,7 @@ __host__ __device__ constexpr int slot_addr(int l) { return l * 64 + ((l >> 2) &
 constexpr int MASK_OFF = 16 + UCAP * 4 + NPASS * 27 * 64 * 8;   // 32784
 constexpr int MASK_PASS_BYTES = 56;
 constexpr int LR_BYTES = MASK_OFF + NPASS * MASK_PASS_BYTES;    // 32896
+static_assert(TILE == ST_TILE && UMAX == ST_UMAX && UCAP == ST_UCAP && NPASS == ST_NPASS && LR_BYTES == ST_LR_BYTES, "spconv.h mirrors this layout");
 constexpr int HSLOTS = 8192;                               // > 256 * 27 possible distinct rows: probing always terminates
 
 __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restrict__ nbr, int K, int n_out, unsigned char* __restrict__ out,
