@@ -168,6 +168,29 @@ __global__ void k_flag_sorted(const int32_t* __restrict__ coords, int n, int ts2
   flag[i] = f;
 }
 
+// Z-ordered rows: the row counts of ALL coarser levels from the sorted level-0 rows in one pass (a level's voxels are runs of
+// adjacent rows at every level), so that eyoc_maps_build reads them with ONE synchronisation instead of one per level
+__global__ void k_count_levels(const int32_t* __restrict__ coords, int n, int* __restrict__ counts /* [EYOC_MAX_LEVELS] */) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int4 c = make_int4(0, 0, 0, 0), q = c;
+  if (i < n) {
+    c = reinterpret_cast<const int4*>(coords)[i];
+    q = i > 0 ? reinterpret_cast<const int4*>(coords)[i - 1] : c;
+  }
+  // validation here too: the build must not run its table kernels on keys outside the supported range
+  constexpr int LIM = COORD_BIAS - 16;
+  if (i < n && (c.x < 0 || c.x >= 1024 || c.y < -LIM || c.y >= LIM || c.z < -LIM || c.z >= LIM || c.w < -LIM || c.w >= LIM))
+    atomicAdd(counts + EYOC_MAX_LEVELS, 1);
+  if (i > 0 && i < n && c.x == q.x && c.y == q.y && c.z == q.z && c.w == q.w) atomicAdd(counts + EYOC_MAX_LEVELS + 1, 1);
+#pragma unroll
+  for (int l = 1; l < EYOC_MAX_LEVELS; ++l) {
+    const int m = ~((1 << l) - 1);
+    const bool first = i < n && (i == 0 || c.x != q.x || (c.y & m) != (q.y & m) || (c.z & m) != (q.z & m) || (c.w & m) != (q.w & m));
+    const unsigned long long b = __ballot(first);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(counts + l, __popcll(b));
+  }
+}
+
 // compaction + octree links in one pass: first rows write their coarse coordinate, every row learns its parent (the
 // number of first rows up to and including it, minus one) and enters itself as that parent's child
 __global__ __launch_bounds__(SCAN_BLOCK) void k_compact_sorted(const int* __restrict__ flag, const int* __restrict__ partial,
@@ -492,6 +515,7 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
   m->coords[0] = cv.take<int32_t>((size_t)n * 4);
   const int order_mode = INTERNAL_ORDER >= 0 ? INTERNAL_ORDER : order;   // the process-wide switch (tests) beats the call's wish
   const bool zorder = order_mode > 0 || (order_mode < 0 && n >= ZORDER_MIN_ROWS);
+  int pre_rows[EYOC_MAX_LEVELS] = {n, 0, 0, 0};                          // Z-order: known before the levels are built
   if (zorder) {
     unsigned long long* zk_in = cv.take<unsigned long long>(n);
     unsigned long long* zk_out = cv.take<unsigned long long>(n);
@@ -502,6 +526,22 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
     hipLaunchKernelGGL(k_morton_key, dim3(cdiv(n, 256)), dim3(256), 0, st, coords_dev, n, zk_in, zr_in);
     if (int rc = sort_rows_by_key64(ztmp, zb, zk_in, zk_out, zr_in, m->row_perm, n, st)) { delete m; return rc; }
     hipLaunchKernelGGL(k_gather_coords, dim3(cdiv(n, 256)), dim3(256), 0, st, coords_dev, m->row_perm, n, m->coords[0]);
+    // every level's row count - and the validation - now, with one read-back
+    hipLaunchKernelGGL(k_count_levels, dim3(cdiv(n, 256)), dim3(256), 0, st, m->coords[0], n, counters + 16);
+    FAIL_HIP(hipMemcpyAsync(host + 16, counters + 16, (EYOC_MAX_LEVELS + 2) * sizeof(int), hipMemcpyDeviceToHost, st));
+    FAIL_HIP(hipStreamSynchronize(st));
+    if (host[16 + EYOC_MAX_LEVELS] != 0) {
+      set_error("eyoc_maps_build: %d coordinate rows outside the supported key range (|c| < 2^17 - 16, 0 <= batch < 1024)",
+                host[16 + EYOC_MAX_LEVELS]);
+      delete m;
+      return EYOC_ERR_RANGE;
+    }
+    if (host[16 + EYOC_MAX_LEVELS + 1] != 0) {
+      set_error("eyoc_maps_build: %d duplicate coordinate rows (a sparse tensor needs unique coordinates)", host[16 + EYOC_MAX_LEVELS + 1]);
+      delete m;
+      return EYOC_ERR_DUPLICATE;
+    }
+    for (int l = 1; l < EYOC_MAX_LEVELS; ++l) pre_rows[l] = host[16 + l];
   } else {
     FAIL_HIP(hipMemcpyAsync(m->coords[0], coords_dev, (size_t)n * 16, hipMemcpyDeviceToDevice, st));
   }
@@ -538,6 +578,9 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
     }
     hipLaunchKernelGGL(k_scan_partials, dim3(nb), dim3(SCAN_BLOCK), 0, st, flag, n_src, partial);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, st, partial, nb, counters + 2 + l);
+    if (zorder) {
+      m->rows[l] = pre_rows[l];
+    } else {
     FAIL_HIP(hipMemcpyAsync(host, counters + 2 + l, sizeof(int), hipMemcpyDeviceToHost, st));
     if (l == 1) FAIL_HIP(hipMemcpyAsync(host + 1, counters, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     FAIL_HIP(hipStreamSynchronize(st));
@@ -552,6 +595,7 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
       return EYOC_ERR_DUPLICATE;
     }
     m->rows[l] = host[0];
+    }
     m->coords[l] = cv.take<int32_t>((size_t)m->rows[l] * 4);
     m->parent[l - 1] = cv.take<int32_t>((size_t)n_src);
     m->children[l - 1] = cv.take<int32_t>((size_t)m->rows[l] * 8);
@@ -667,7 +711,24 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
       }
     }
     FAIL_HIP(hipMemcpyAsync(host, counters + 8, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+    FAIL_HIP(hipMemcpyAsync(host + 32, counters, 8 * sizeof(int), hipMemcpyDeviceToHost, st));   // errors + the scans' own totals
     FAIL_HIP(hipStreamSynchronize(st));
+    if (host[32] != 0) {
+      set_error("eyoc_maps_build: %d coordinate rows outside the supported key range (|c| < 2^17 - 16, 0 <= batch < 1024)", host[32]);
+      delete m;
+      return EYOC_ERR_RANGE;
+    }
+    if (host[33] != 0) {
+      set_error("eyoc_maps_build: %d duplicate coordinate rows (a sparse tensor needs unique coordinates)", host[33]);
+      delete m;
+      return EYOC_ERR_DUPLICATE;
+    }
+    for (int l = 1; l < EYOC_MAX_LEVELS; ++l)
+      if (host[32 + 2 + l] != m->rows[l]) {
+        set_error("eyoc_maps_build: internal error - level %d has %d rows by its scan, %d by the up-front count", l, host[32 + 2 + l], m->rows[l]);
+        delete m;
+        return EYOC_ERR_INVALID;
+      }
     if (host[0] != 0)   // a tile with more than 1278 distinct input rows (does not happen for Z-ordered rows): no staged kernel
       for (int l = 0; l < EYOC_MAX_LEVELS; ++l) m->local_s1[l] = nullptr;
     if (host[1] != 0)   // ... more than 639 distinct coarse rows under a 256-row tile
