@@ -119,6 +119,7 @@ PROTOTYPES = {
     "eyoc_knn_prefilter": (_i, [_i]),
     "eyoc_spconv_select_up_kernel": (_i, [_i]),
     "eyoc_spconv_select_down_kernel": (_i, [_i]),
+    "eyoc_spconv_select_conv1_kernel": (_i, [_i]),
     "eyoc_knn1": (_i, [_vp, _vp, _vp, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i, _i, _vp, _vp, _vp]),
     "eyoc_pdist": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "eyoc_kabsch_batched": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),

@@ -723,7 +723,7 @@ int spconv_forced_kernel() { return g_kernel_mode; }
 // layers, + 0.25 ms of rulebooks in the map build; the step is the same within noise) and 18 GB less HBM traffic per forward
 int g_up_kernel = getenv("EYOC_SPCONV_UP") ? atoi(getenv("EYOC_SPCONV_UP")) : 1;
 bool spconv_up_enabled() { return g_up_kernel != 0; }
-int g_conv1_staged = getenv("EYOC_CONV1_ST") ? atoi(getenv("EYOC_CONV1_ST")) : 1;   // diagnostics switch of conv1_st_kernel
+int g_conv1_staged = 1;   // eyoc_spconv_select_conv1_kernel: the first convolution of Z-ordered split16 forwards on conv1_st_kernel
 int g_down_staged = 0;   // strided convolutions on Z-ordered maps through the staged kernel (eyoc_spconv_select_down_kernel): off - their tiles overflow 2 passes
 bool spconv_down_staged() { return g_down_staged != 0; }
 
@@ -1196,6 +1196,12 @@ int eyoc_spconv_staged(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* local_
 int eyoc_spconv_select_up_kernel(int on) {
   const int prev = eyoc::g_up_kernel;
   if (on == 0 || on == 1) eyoc::g_up_kernel = on;
+  return prev;
+}
+
+int eyoc_spconv_select_conv1_kernel(int on) {
+  const int prev = eyoc::g_conv1_staged;
+  if (on == 0 || on == 1) eyoc::g_conv1_staged = on;
   return prev;
 }
 

@@ -173,6 +173,10 @@ int eyoc_spconv_select_up_kernel(int on);
  * overflow the two staging passes on LiDAR geometry, so the table falls back anyway); other values only query.  Returns the
  * previous state.  Process-wide, read when maps are built; for tests and profiling. */
 int eyoc_spconv_select_down_kernel(int on);
+/* First convolution (C_in = 1, 32 output channels) of split16 forwards on Z-ordered maps: 1 (default) = conv1_st_kernel - the child
+ * features of a 256-parent tile's neighbourhood staged in LDS through the level-1 tile rulebook; 0 = conv1_mfma_kernel, which probes
+ * the octree per fine row.  Other values only query.  Returns the previous state; process-wide, for tests and profiling. */
+int eyoc_spconv_select_conv1_kernel(int on);
 /* Stride-1 (3^3) split16 layers with a tile-local input stage (spconv_st.hip): per 256-row tile the distinct input rows are
  * copied to LDS once per 32-channel block and all 27 offsets run from there.  Needs the table's per-tile "local
  * rulebooks" (built once per table; *overflow_dev counts 256-row tiles with more than 1278 distinct input rows - the staged

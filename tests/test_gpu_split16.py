@@ -448,3 +448,43 @@ def test_fused_tail_matches_the_two_layer_tail_and_the_oracle(normalize):
     print(f"tail (normalize={normalize}, {len(coords)} rows): fused vs oracle {e_fused:.2e}, two launches vs oracle {e_two:.2e}, fused vs two {d:.2e}")
     assert e_fused < REL and e_two < REL and d < 2e-6
     assert e_fused <= 2 * e_two + 1e-6
+
+
+@pytest.mark.parametrize("ks", [5, 3])
+def test_staged_first_convolution_matches_the_probing_kernel_and_the_oracle(ks):
+    """conv1_st_kernel (Z-ordered maps: child features of a 256-parent tile's neighbourhood staged in LDS) against
+    conv1_mfma_kernel (octree probing per fine row) - same products in the same order per window position, so the features
+    agree to fp32 rounding - and against the oracle; two clouds in a batch, non-unit features with planted zeros, both
+    window sizes; the strided convolutions through the staged kernel ride along (eyoc_spconv_select_down_kernel)."""
+    import eyoc_amd
+    from eyoc_amd import synthetic as syn
+    from oracle import resunet as orr
+    L, lib = _lib()
+    p = syn.make_pair(9, beams=32, azimuths=1000, band=None)
+    coords = syn.batch_coords([p["coords0"], p["coords1"]])
+    rng = np.random.default_rng(ks)
+    feats = rng.uniform(0.25, 2.0, size=(len(coords), 1)).astype(np.float32)
+    feats[rng.random(len(coords)) < 0.05] = 0.0
+    sd = syn.make_weights(seed=11, in_channels=1, conv1_kernel_size=ks)
+    m = eyoc_amd.load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, conv1_kernel_size=ks, normalize_feature=True)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m = m.cuda().eval()
+    m.spconv_math = "split16"
+    want = orr.resunet_forward(sd, coords, feats, conv1_kernel_size=ks).numpy()
+    prev_order = lib.eyoc_maps_internal_order(1) - 2                   # Z-ordered maps whatever the size
+    prev_c1, prev_dn = lib.eyoc_spconv_select_conv1_kernel(-1), lib.eyoc_spconv_select_down_kernel(-1)
+    outs = {}
+    try:
+        for staged in (0, 1):
+            lib.eyoc_spconv_select_conv1_kernel(staged)
+            lib.eyoc_spconv_select_down_kernel(staged)
+            outs[staged] = _forward(m, coords, feats)
+            assert m.last_spconv_math == "split16"
+    finally:
+        lib.eyoc_spconv_select_conv1_kernel(prev_c1)
+        lib.eyoc_spconv_select_down_kernel(prev_dn)
+        lib.eyoc_maps_internal_order(prev_order)
+    e1, e0 = rel_err(outs[1], want), rel_err(outs[0], want)
+    d = rel_err(outs[1], outs[0])
+    print(f"first convolution {ks}^3, {len(coords)} rows: staged vs oracle {e1:.2e}, probing vs oracle {e0:.2e}, staged vs probing {d:.2e}")
+    assert e1 < REL and e0 < REL and d < 2e-6
