@@ -151,7 +151,7 @@ def cpu_baseline(pairs, seeds, sd, descriptor, sample_hyp=200000, full_hyp=40000
     from oracle import ransac as orn
     from oracle import resunet as orr
     torch.set_num_threads(usable_cores())
-    times = []
+    times, t_sc2 = [], 0.0
     for k in range(min(n_pairs + 1, len(pairs))):
         pair, seed = pairs[k], seeds[k]
         t0 = time.perf_counter()
@@ -173,9 +173,22 @@ def cpu_baseline(pairs, seeds, sd, descriptor, sample_hyp=200000, full_hyp=40000
         orn.ransac(pair["xyz0"][i0], pair["xyz1"][i1], nn, 0.3, sample_hyp, seed=0)
         t_ransac = (time.perf_counter() - t0) * (full_hyp / sample_hyp)
         times.append((t_feat + t_nn + t_ransac, t_feat, t_nn, t_ransac))
+        if k == 1:
+            # the SC2-PCR back-end (scripts/test_kitti.py:179-181) on the same pair's descriptors: Matcher.estimator of the
+            # oracle (resample to num_node = 8000 with replacement, match, SC2-PCR) - one pair, the forwards' time added
+            from oracle import sc2pcr as osc
+            from eyoc_amd.harness import RegistrationConfig as _RC
+            m = osc.Matcher(**_RC(use_RANSAC=False).sc2pcr)
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                m.estimator(torch.from_numpy(pair["xyz0"][i0])[None], torch.from_numpy(pair["xyz1"][i1])[None],
+                            torch.from_numpy(F0)[None], torch.from_numpy(F1)[None], rng=np.random.default_rng(seed))
+            t_sc2 = time.perf_counter() - t0 + t_feat
     timed = times[1:] if len(times) > 1 else times
     med = sorted(timed)[len(timed) // 2]
-    return {"value": 1.0 / med[0], "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+    extra = {"sc2pcr_path": {"value": 1.0 / t_sc2, "unit": "pairs/s", "sample": f"1 pair: 2 oracle forwards + Matcher.estimator ({t_sc2:.1f} s)"}} \
+        if len(times) > 1 else {}
+    return {**extra, "value": 1.0 / med[0], "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": (f"median of {len(timed)} pairs after 1 warm-up pair; per pair: 2 oracle forwards ({med[1]:.2f} s) + "
                        f"5000x5000 NN ({med[2]:.2f} s) + {sample_hyp} of {full_hyp} RANSAC hypotheses "
                        f"(time x{full_hyp // sample_hyp} = {med[3]:.1f} s)")}
