@@ -53,3 +53,26 @@ def test_round_robin_shard_covers_every_pair_once():
         assert seen == list(range(total))
         sizes = [len(edist.shard(total, r, world)) for r in range(world)]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_generated_staged_loop_is_what_the_generator_writes(tmp_path):
+    """eyoc_amd/csrc/spconv_st_loop.inc (the hand-scheduled offset loop of the staged convolution, committed) is exactly the
+    output of gen_st_loop.py; the generator's own bookkeeping holds: every MFMA of the 27 x NH half-steps is there once, every
+    skip branch has its label, wait counts stay inside the counters' ranges."""
+    import os
+    import re
+    import subprocess
+    import sys
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "eyoc_amd", "csrc")
+    out = tmp_path / "loop.inc"
+    subprocess.check_call([sys.executable, os.path.join(here, "gen_st_loop.py"), str(out)])
+    assert out.read_text() == open(os.path.join(here, "spconv_st_loop.inc")).read()
+    text = out.read_text()
+    blob = text[text.index("#define EYOC_ST_LOOP_NH2 "):text.index("#define EYOC_ST_LOOP_NH1 ")]
+    assert blob.count("v_mfma_f32_16x16x32_f16") == 27 * 2 * 4 * 6          # offsets x halves x chunks x (2 tiles x 3 terms)
+    assert blob.count("s_cbranch_scc0") == 27 * 2 * 4
+    labels = re.findall(r"s_cbranch_scc0 (\.Lst%=_\w+)", blob)
+    assert len(set(labels)) == len(labels) and all(f"{l}:" in blob for l in labels)
+    assert max(int(v) for v in re.findall(r"vmcnt\((\d+)\)", blob)) <= 63 and max(int(v) for v in re.findall(r"lgkmcnt\((\d+)\)", blob)) <= 15
+    regs = [int(v) for v in re.findall(r"v\[(\d+):", blob)]
+    assert min(regs) >= 64 and max(regs) <= 252                                   # v0 - v63 stay with the compiler
