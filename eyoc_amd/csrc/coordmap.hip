@@ -660,7 +660,9 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
       seg_dn[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l + 1];
     }
     if (m->rows[l] < ORDER_MIN_ROWS) continue;
-    if (l + 1 < EYOC_MAX_LEVELS) { seg_up[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l]; }
+    // the transposed tables' order serves the gathering kernels only: Z-ordered maps with the staged transposed kernel (which sorts
+    // inside its tiles) skip it - and with it the whole radix sort, nothing else being ordered there (0.3 ms per 128-cloud batch)
+    if (l + 1 < EYOC_MAX_LEVELS && !(zorder && spconv_up_enabled())) { seg_up[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l]; }
     if (s1_order && !zorder) { seg_s1[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l]; }
   }
   constexpr int TAG_SHIFT = UP_KEY_BITS, TAG_BITS = 4;   // pattern keys < 2^11, window number, segment tag above (at most 10 segments)
