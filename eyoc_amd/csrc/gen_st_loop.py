@@ -26,19 +26,22 @@ K, NC, NTW = 27, 4, 2
 LO_REGION = 640 * 64      # the LDS stage: 640 rows x 64 B of hi halves, then the same of lo halves (spconv_st.hip)
 
 
-def gen(NH, WD, skip=True, abl=()):
-    NWS = WD + 1
+def gen(NH, WD, LD=2, skip=True, abl=()):
+    NWS, NLS = WD + 1, LD + 1
     ACC = lambda h, c, t: 64 + ((h * NC + c) * NTW + t) * 4
     XS = lambda s, c, p: 128 + s * 32 + (c * 2 + p) * 4
     WS = lambda s, t, p: 192 + s * 16 + (t * 2 + p) * 4
-    LS = lambda s, h: 240 + (s * NH + h) * 2
-    T = [252, 253, 254, 255]
+    LB = 192 + NWS * 16
+    LS = lambda s, h: LB + (s * NH + h) * 2
     # lane constants, computed in the prologue (no VGPR operands: nothing for the compiler to spill around the blob):
-    # GH = (lane >> 4) << 4 (XOR term of the hi piece), WL0 / WL1 = byte offsets of the lane's weight fragments of channel
-    # tiles 0 / 1, LV = (lane & 15) * 8 (+ 4096 per 8 offsets) = offset of the lane's rulebook entries, C4 = 4
-    CR = 224 if WD == 1 else (96 if NH == 1 else None)
-    assert CR is not None, "no free registers for the lane constants (NH = 2 needs WD = 1)"
-    GH, WL0, WL1, LV, C4 = (f"v{CR + i}" for i in range(5))
+    # GH = (lane >> 4) << 4 (XOR term of the hi piece), WL0 = byte offset of the lane's weight fragments of channel tile 0
+    # (tile 1: + 64, in the offset field), LV = (lane & 15) * 8 (+ 4096 per 8 offsets) = offset of the lane's rulebook
+    # entries, C4 = a prologue temporary; T = the two address temporaries.  They sit behind the rulebook sets when v[..255]
+    # has room, else in v[96..] (NH = 1: half the accumulators) or v[56:63] (clobbered on top; the compiler keeps no value there)
+    free = 256 - (LB + NLS * NH * 2)
+    CR = LB + NLS * NH * 2 if free >= 6 else (96 if NH == 1 else 56)
+    GH, WL0, LV, C4 = (f"v{CR + i}" for i in range(4))
+    T = [CR + 4, None, CR + 5, None]
     vr = lambda n, w=4: f"v[{n}:{n + w - 1}]"
     out, stubs = [], []
     vmq, lgq = [], []          # issue history of VMEM / LDS operations (tags), oldest first
@@ -69,21 +72,23 @@ def gen(NH, WD, skip=True, abl=()):
             return
         for t in range(NTW):
             for p in range(2):
-                emit(f"buffer_load_dwordx4 {vr(WS(s, t, p))}, {(WL0, WL1)[t]}, %[wr], %[so] offen offset:{p * 1024}")
+                emit(f"buffer_load_dwordx4 {vr(WS(s, t, p))}, {WL0}, %[wr], %[so] offen offset:{p * 1024 + t * 64}")
                 vmq.append(("W", k))
         emit("s_add_u32 %[so], %[so], %[ks]")
 
     def issue_l(k):
+        if "nol" in abl:
+            return
         if k % 8 == 0 and k > 0:
             emit(f"v_add_u32 {LV}, 0x1000, {LV}")
         for h in range(NH):
-            emit(f"global_load_dwordx2 {vr(LS(k % 3, h), 2)}, {LV}, %[lb] offset:{(k % 8) * 512 + h * 128}")
+            emit(f"global_load_dwordx2 {vr(LS(k % NLS, h), 2)}, {LV}, %[lb] offset:{(k % 8) * 512 + h * 128}")
             vmq.append(("L", k))
 
     def addr(k, h, c, t0, t1):
         """LDS address of the hi piece of chunk c's rows at (k, h): the 16-bit rulebook field IS the byte address of the
         row's hi pieces (swizzle included); XOR the lane's piece.  The lo piece sits LO_REGION bytes further (offset field)."""
-        reg = LS(k % 3, h) + (c >> 1)
+        reg = LS(k % NLS, h) + (c >> 1)
         if "nov" in abl:
             return
         emit(f"v_xor_b32_sdwa v{t0}, {GH}, v{reg} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_{c & 1}")
@@ -114,22 +119,19 @@ def gen(NH, WD, skip=True, abl=()):
     emit(f"v_and_b32 {LV}, 15, {LV}")                       # m
     emit(f"v_lshrrev_b32 {WL0}, 2, {LV}")
     emit(f"v_lshlrev_b32 {WL0}, 3, {WL0}")                  # 8 (m >> 2)
-    emit(f"v_and_b32 {WL1}, 3, {LV}")
-    emit(f"v_add_u32 {WL0}, {WL0}, {WL1}")                  # ch of tile 0 (0 .. 27); tile 1: + 4
-    for t, W_ in ((1, WL1), (0, WL0)):
-        if t:
-            emit(f"v_add_u32 {W_}, 4, {WL0}")
-        emit(f"v_lshrrev_b32 {C4}, 4, {W_}")                # nt
-        emit(f"v_and_b32 {W_}, 15, {W_}")                   # m'
-        emit(f"v_add_u32 {W_}, {W_}, {GH}")
-        emit(f"v_lshlrev_b32 {W_}, 4, {W_}")
-        emit(f"v_mul_lo_u32 {C4}, {C4}, %[w1]")
-        emit(f"v_add_u32 {W_}, {W_}, {C4}")
+    emit(f"v_and_b32 {C4}, 3, {LV}")
+    emit(f"v_add_u32 {WL0}, {WL0}, {C4}")                   # ch of tile 0 (0 .. 27); tile 1: + 4 = the next 64 bytes of the same tile nt
+    emit(f"v_lshrrev_b32 {C4}, 4, {WL0}")                   # nt
+    emit(f"v_and_b32 {WL0}, 15, {WL0}")                     # m'
+    emit(f"v_add_u32 {WL0}, {WL0}, {GH}")
+    emit(f"v_lshlrev_b32 {WL0}, 4, {WL0}")
+    emit(f"v_mul_lo_u32 {C4}, {C4}, %[w1]")
+    emit(f"v_add_u32 {WL0}, {WL0}, {C4}")
     emit(f"v_lshlrev_b32 {LV}, 3, {LV}")
     for k in range(WD):
         issue_w(k)
-    issue_l(0)
-    issue_l(1)
+    for k in range(LD):
+        issue_l(k)
     emit("s_waitcnt vmcnt(0)")
     done[0] = len(vmq) - 1
     emit("s_barrier")
@@ -150,8 +152,8 @@ def gen(NH, WD, skip=True, abl=()):
             if h == 0:
                 if k + WD < K:
                     issue_w(k + WD)
-                if k + 2 < K:
-                    issue_l(k + 2)
+                if k + LD < K:
+                    issue_l(k + LD)
                 wait_vm(("W", k))
             if has_next:
                 wait_vm(("L", kn))
@@ -179,26 +181,149 @@ def gen(NH, WD, skip=True, abl=()):
     return out
 
 
-def clobbers():
-    return ", ".join(f'"v{i}"' for i in range(128, 256))
+def gen_w8(D=2, WD=1, LD=2, skip=True):
+    """The 8-wave workgroup's loop (4 row quarters x 2 channel halves: 64 rows x 32 channels per wave) inside 128 VGPRs, so
+    that FOUR waves share a SIMD (two workgroups per CU as before - the LDS stage is unchanged): a workgroup that waits for
+    its stage or stores its tile leaves two waves per SIMD on the matrix pipe instead of one (one wave alone reaches ~60 % of
+    the pipe in this loop).  Operand reads run D chunk groups ahead in a ring of D + 1 register slots.
+      v[0:27]   the compiler's      v[28:51] operand ring X(slot, p) = 28 + slot*8 + p*4      v[52:83] weight sets (2)
+      v[84:89]  rulebook sets (3)   v[90:95] lane constants / address temporaries                v[96:127] accumulators"""
+    NXS, NWS, NLS = D + 1, WD + 1, LD + 1
+    assert NXS * 8 <= 24 and NWS * 16 <= 32 and NLS * 2 <= 6
+    ACC = lambda c, t: 96 + (c * NTW + t) * 4
+    XS = lambda slot, p: 28 + slot * 8 + p * 4
+    WS = lambda s, t, p: 52 + s * 16 + (t * 2 + p) * 4
+    LS = lambda s: 84 + s * 2
+    GH, WL0, LV, C4 = (f"v{90 + i}" for i in range(4))
+    T = [94, 95]
+    vr = lambda n, w=4: f"v[{n}:{n + w - 1}]"
+    out, vmq, lgq, done = [], [], [], [-1]
+    emit = out.append
+
+    def wait_vm(tag):
+        if tag not in vmq:
+            return
+        idx = len(vmq) - 1 - vmq[::-1].index(tag)
+        if idx <= done[0]:
+            return
+        emit(f"s_waitcnt vmcnt({min(len(vmq) - 1 - idx, 63)})")
+        done[0] = idx
+
+    def lg_count(tag):
+        idx = len(lgq) - 1 - lgq[::-1].index(tag)
+        return min(len(lgq) - 1 - idx, 15)
+
+    def issue_w(k):
+        for t in range(NTW):
+            for p in range(2):
+                emit(f"buffer_load_dwordx4 {vr(WS(k % NWS, t, p))}, {WL0}, %[wr], %[so] offen offset:{p * 1024 + t * 64}")
+                vmq.append(("W", k))
+        emit("s_add_u32 %[so], %[so], %[ks]")
+
+    def issue_l(k):
+        if k % 8 == 0 and k > 0:
+            emit(f"v_add_u32 {LV}, 0x1000, {LV}")
+        emit(f"global_load_dwordx2 {vr(LS(k % NLS), 2)}, {LV}, %[lb] offset:{(k % 8) * 512}")
+        vmq.append(("L", k))
+
+    def fetch(q):
+        """address + the two operand reads of chunk group q = 4 k + c into ring slot q % NXS"""
+        k, c = divmod(q, NC)
+        if c == 0:
+            wait_vm(("L", k))
+        t = T[q & 1]
+        emit(f"v_xor_b32_sdwa v{t}, {GH}, v{LS(k % NLS) + (c >> 1)} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_{c & 1}")
+        for p in range(2):
+            emit(f"ds_read_b128 {vr(XS(q % NXS, p))}, v{t}" + (f" offset:{LO_REGION}" if p else ""))
+            lgq.append(("X", q))
+
+    emit("s_mov_b32 %[so], %[ws0]")
+    emit(f"v_mbcnt_lo_u32_b32 {LV}, -1, 0")
+    emit(f"v_mbcnt_hi_u32_b32 {LV}, -1, {LV}")
+    emit(f"v_and_b32 {GH}, 48, {LV}")
+    emit(f"v_and_b32 {LV}, 15, {LV}")
+    emit(f"v_lshrrev_b32 {WL0}, 2, {LV}")
+    emit(f"v_lshlrev_b32 {WL0}, 3, {WL0}")
+    emit(f"v_and_b32 {C4}, 3, {LV}")
+    emit(f"v_add_u32 {WL0}, {WL0}, {C4}")
+    emit(f"v_lshrrev_b32 {C4}, 4, {WL0}")
+    emit(f"v_and_b32 {WL0}, 15, {WL0}")
+    emit(f"v_add_u32 {WL0}, {WL0}, {GH}")
+    emit(f"v_lshlrev_b32 {WL0}, 4, {WL0}")
+    emit(f"v_mul_lo_u32 {C4}, {C4}, %[w1]")
+    emit(f"v_add_u32 {WL0}, {WL0}, {C4}")
+    emit(f"v_lshlrev_b32 {LV}, 3, {LV}")
+    for k in range(WD):
+        issue_w(k)
+    for k in range(LD):
+        issue_l(k)
+    emit("s_waitcnt vmcnt(0)")
+    done[0] = len(vmq) - 1
+    emit("s_barrier")
+    for q in range(D):
+        fetch(q)
+    for q in range(K * NC):
+        k, c = divmod(q, NC)
+        if c == 0:
+            if k + WD < K:
+                issue_w(k + WD)
+            if k + LD < K:
+                issue_l(k + LD)
+            wait_vm(("W", k))
+        if q + D < K * NC:
+            fetch(q + D)
+        if skip:
+            emit(f"s_bitcmp1_b32 s{36 + (k >> 1)}, {(k & 1) * 16 + c}")
+            emit(f"s_cbranch_scc0 .Lst%=_q{q}")
+        emit(f"s_waitcnt lgkmcnt({lg_count(('X', q))})")
+        for term in range(3):
+            for t in range(NTW):
+                a = WS(k % NWS, t, 1 if term == 2 else 0)
+                b = XS(q % NXS, 1 if term == 1 else 0)
+                emit(f"v_mfma_f32_16x16x32_f16 {vr(ACC(c, t))}, {vr(a)}, {vr(b)}, {vr(ACC(c, t))}")
+        if skip:
+            emit(f".Lst%=_q{q}:")
+    emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    emit("s_nop 7")
+    emit("s_nop 7")
+    emit("s_nop 7")
+    return out
+
+
+def clobbers(lo=128):
+    return ", ".join(f'"v{i}"' for i in range(lo, 256))
+
+
+WD2, LD2 = 1, 2            # NH = 2 (measured: weights two offsets ahead and rulebook entries three, lane constants in v[56:61], gain nothing)
+
+
+def write_blob(f, name, lines):
+    f.write(f"#define EYOC_ST_LOOP_{name} \\\n")
+    for ln in lines:
+        f.write(f'  "{ln}\\n\\t" \\\n')
+    f.write('  ""\n')
 
 
 def main(path):
+    """spconv_st_loop.inc (committed): the loops the library runs.  spconv_st_loop_abl.inc (not committed; the Makefile writes
+    it for -DEYOC_ST_ABLATIONS / -DEYOC_ST_TRACE builds): timing-only ablations, the trace build and measured-not-kept schedules."""
     with open(path, "w") as f:
         f.write("// GENERATED by gen_st_loop.py - do not edit.  The offset loop of spconv_st_kernel as gfx950 assembly text\n")
         f.write("// (register map, schedule and wait counts: see the generator).\n")
-        for name, NH, WD, skip, abl in (("NH2", 2, 1, True, ()), ("NH1", 1, 2, True, ()), ("NH2_NOSKIP", 2, 1, False, ()),
-                                        ("NH2_NOW", 2, 1, True, ("now",)), ("NH2_NOX", 2, 1, True, ("nox", "nov")),
-                                        ("NH2_NOV", 2, 1, True, ("nov",)), ("NH2_NOM", 2, 1, True, ("nom",)),
-                                        ("NH2_NOMW", 2, 1, True, ("nom", "now")),
-                                        ("NH2_TRACE", 2, 1, True, ("trace",))):
-            lines = gen(NH, WD, skip, abl)
-            f.write(f"#define EYOC_ST_LOOP_{name} \\\n")
-            for ln in lines:
-                f.write(f'  "{ln}\\n\\t" \\\n')
-            f.write('  ""\n')
+        write_blob(f, "NH2", gen(2, WD2, LD2))
+        write_blob(f, "NH1", gen(1, 2, 2))
+        write_blob(f, "NH2_NOSKIP", gen(2, WD2, LD2, skip=False))
         f.write(f"#define EYOC_ST_LOOP_CLOBBERS {clobbers()}\n")
-        f.write('#define EYOC_ST_LOOP_CLOBBERS_NH1 EYOC_ST_LOOP_CLOBBERS, "v96", "v97", "v98", "v99", "v100"\n')
+    with open(path.replace(".inc", "_abl.inc"), "w") as f:
+        f.write("// GENERATED by gen_st_loop.py - diagnostics builds only (EYOC_ST_ABLATIONS / EYOC_ST_TRACE); results are garbage\n")
+        for name, abl in (("NOW", ("now",)), ("NOX", ("nox", "nov")), ("NOV", ("nov",)), ("NOM", ("nom",)), ("NOMW", ("nom", "now")),
+                          ("NOL", ("nol",)), ("NOWL", ("now", "nol")), ("NOMWL", ("nom", "now", "nol")),
+                          ("EMPTY", ("nom", "now", "nol", "nox", "nov")), ("TRACE", ("trace",))):
+            write_blob(f, "NH2_" + name, gen(2, WD2, LD2, True, abl))
+        write_blob(f, "NH2_W2L3", gen(2, 2, 3))       # weights two offsets ahead, rulebook entries three: no gain
+        write_blob(f, "W8", gen_w8())                 # 8 waves of 64 rows x 32 channels in 128 VGPRs (four per SIMD): no gain
+        f.write("#define EYOC_ST_LOOP_CLOBBERS_LOW EYOC_ST_LOOP_CLOBBERS, " + ", ".join(f'"v{i}"' for i in range(56, 62)) + "\n")
+        f.write("#define EYOC_ST_LOOP_CLOBBERS_W8 " + ", ".join(f'"v{i}"' for i in range(28, 96)) + "\n")
 
 
 if __name__ == "__main__":

@@ -111,6 +111,7 @@ int launch_spconv_up(const SpconvArgs& a, const unsigned char* local_dev, hipStr
 size_t local_rulebook_up_bytes(int n_out);
 int build_local_rulebook_up(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st);
 int select_st_variant(int v);   // spconv_st.hip: which staged kernel (returns the previous one)
+int select_st_split_below(int workgroups);   // layers with fewer 64-channel workgroups take 32-channel ones (returns the previous threshold)
 size_t local_rulebook_bytes(int n_out);
 int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st);
 int launch_spconv_rs(const SpconvArgs& a, hipStream_t st);     // row-stationary, SPLIT16 only (spconv_rs.hip)

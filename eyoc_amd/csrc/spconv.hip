@@ -1215,6 +1215,10 @@ int eyoc_spconv_select_st_kernel(int variant) {
   return eyoc::select_st_variant(variant);
 }
 
+int eyoc_spconv_st_split_below(int workgroups) {
+  return eyoc::select_st_split_below(workgroups);
+}
+
 int eyoc_spconv_select_split16_kernel(int mode) {
   const int prev = eyoc::g_split16_kernel;
   if (mode >= 0 && mode <= 2) eyoc::g_split16_kernel = mode;

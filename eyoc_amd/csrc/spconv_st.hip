@@ -369,12 +369,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
 
 #include "spconv_st_loop.inc"
+#if defined(EYOC_ST_ABLATIONS) || defined(EYOC_ST_TRACE)
+#include "spconv_st_loop_abl.inc"
+#endif
 
-template <int CC, int NH, int SKIP>
-__global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a, const unsigned char* __restrict__ local, int n_tiles) {
+template <int CC, int NH, int SKIP, int NWV = NW>
+__global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(SpconvArgs a, const unsigned char* __restrict__ local, int n_tiles) {
   constexpr int NTW = 2, CTW = NTW * 16, NC = 4;
-  constexpr int CTG = CTW * NH;
-  __shared__ __attribute__((aligned(128))) unsigned char xs[X_BYTES];
+  constexpr int CTG = CTW * NH * (NWV / NW);                            // NWV = 8: 4 row quarters x 2 channel halves, NH = 1
+  constexpr int NITV = XROWS / (16 * NWV);
+  static_assert(NWV == NW || (NWV == 2 * NW && NH == 1), "8 waves: 64 rows x 32 channels each");
+  // (EYOC_ST_ABLATIONS 15-17: a padded stage = ONE workgroup per CU, to time a workgroup that has its CU to itself)
+  __shared__ __attribute__((aligned(128))) unsigned char xs[X_BYTES + (SKIP >= 15 && SKIP <= 17 ? 8192 : 0)];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int g = lane >> 4, j = lane & 15;
@@ -382,8 +388,8 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a,
   const int xcd = (int)blockIdx.x & 7, per = 8 / n_cg;
   const int cg = xcd % n_cg, tile = ((int)blockIdx.x >> 3) * per + xcd / n_cg;
   if (tile >= n_tiles) return;
-  const int w0 = NH == 1 ? wave : 2 * (wave >> 1);
-  const int ct0 = cg * CTG + (NH == 2 ? (wave & 1) * CTW : 0);
+  const int w0 = NH == 1 ? (wave & 3) : 2 * (wave >> 1);
+  const int ct0 = cg * CTG + (NH == 2 ? (wave & 1) * CTW : (wave >> 2) * CTW);
   const int CT = a.cout >= 128 ? 128 : a.cout;
   const int n_slices = a.cout / CT, slice = ct0 / CT, nt0 = (ct0 - slice * CT) / 16;
   constexpr int JQ = CC / 16;
@@ -419,16 +425,16 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a,
   // blocks the stage is then only a barrier and the DMA issue, not a dependent load -> DMA chain (the trace of
   // scripts/trace_staged.py had 15 % of a workgroup's life between its blocks and 10 % before the first one)
   int n_up = 0;
-  int Ureg[NIT];
+  int Ureg[NITV];
   auto load_rows = [&](int pass) {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) Ureg[it] = U[pass * UMAX + (it * NW + wave) * 16 + (lane >> 2)];
+    for (int it = 0; it < NITV; ++it) Ureg[it] = U[pass * UMAX + (it * NWV + wave) * 16 + (lane >> 2)];
   };
   auto stage = [&](int pass, int qb) {
     if constexpr (SKIP == 6) return;                                   // EYOC_ST_ABLATIONS: no stage
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int l0 = (it * NW + wave) * 16;
+    for (int it = 0; it < NITV; ++it) {
+      const int l0 = (it * NWV + wave) * 16;
       if (l0 < n_up) {
         const int l = l0 + (lane >> 2);
         const float* src = a.in + (size_t)Ureg[it] * a.ld_in + qb * 32 + (((lane & 3) ^ ((l >> 2) & 3)) << 2);
@@ -490,7 +496,7 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a,
         }
       } else
 #endif
-      if constexpr (NH == 2 && (SKIP == 1 || SKIP == 6 || SKIP == 7)) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2);
+      if constexpr (NH == 2 && (SKIP == 1 || SKIP == 6 || SKIP == 7 || SKIP == 15)) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2);
       else if constexpr (NH == 2 && SKIP == 0) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOSKIP);
 #ifdef EYOC_ST_ABLATIONS       // timing-only builds of the loop (results are garbage): no weight loads / no operand reads / no address VALU
       else if constexpr (NH == 2 && SKIP == 3) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOW);
@@ -498,10 +504,24 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_asm_kernel(SpconvArgs a,
       else if constexpr (NH == 2 && SKIP == 5) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOV);
       else if constexpr (NH == 2 && SKIP == 8) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOM);
       else if constexpr (NH == 2 && SKIP == 9) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOMW);
+      else if constexpr (NH == 2 && SKIP == 10) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOL);
+      else if constexpr (NH == 2 && SKIP == 11) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOWL);
+      else if constexpr (NH == 2 && SKIP == 12) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOMWL);
+      else if constexpr (NH == 2 && SKIP == 13) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_EMPTY);
+      else if constexpr (NH == 2 && SKIP == 14)
+        asm volatile(EYOC_ST_LOOP_NH2_W2L3 : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), "+{v[96:111]}"(A2), "+{v[112:127]}"(A3), [so] "=&s"(so)
+                     : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS_LOW);
+      else if constexpr (NH == 2 && SKIP == 16) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOWL);
+      else if constexpr (NH == 2 && SKIP == 17) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_EMPTY);
+#endif
+#ifdef EYOC_ST_ABLATIONS
+      else if constexpr (NWV == 2 * NW)
+        asm volatile(EYOC_ST_LOOP_W8 : "+{v[96:111]}"(A0), "+{v[112:127]}"(A1), [so] "=&s"(so)
+                     : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS_W8);
 #endif
       else
         asm volatile(EYOC_ST_LOOP_NH1 : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), [so] "=&s"(so)
-                     : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS_NH1);
+                     : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS);
 #undef EYOC_ST_ASM_NH2
 #undef EYOC_ST_OPERANDS
     }
@@ -599,13 +619,16 @@ int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char
 }
 
 // which staged kernel runs: 0 = the C++ offset loop (spconv_st_kernel), 1 = the assembly loop (default), 2 = the assembly loop
-// without the empty-block branches (diagnostics)
+// without the empty-block branches (diagnostics); -DEYOC_ST_ABLATIONS builds add 3 = 8 waves of 64 rows x 32 channels (four per
+// SIMD, 128 VGPRs) and 13 ... = timing-only ablations
 static std::atomic<int> g_st_variant{1};
 #ifdef EYOC_ST_ABLATIONS
-constexpr int ST_VARIANTS = 10;
+constexpr int ST_VARIANTS = 28;
 #else
 constexpr int ST_VARIANTS = 3;
 #endif
+static std::atomic<int> g_st_split_below{1024};
+int select_st_split_below(int workgroups) { return workgroups >= 0 ? g_st_split_below.exchange(workgroups) : g_st_split_below.load(); }
 int select_st_variant(int v) { return (v >= 0 && v < ST_VARIANTS) ? g_st_variant.exchange(v) : g_st_variant.load(); }
 
 // stride-1 SPLIT16 layers whose table has a local rulebook (rows in natural = Morton order, no tiling permutation)
@@ -617,7 +640,7 @@ int launch_spconv_st(const SpconvArgs& a_in, const unsigned char* local_dev, hip
   // rounds of work; small problems (a batch of 8 pairs: 70 tiles at the coarsest level) take 32 (waves of 64 rows x 32 channels,
   // twice the workgroups, each half as long) - below ~2 rounds a layer lasts as long as ONE workgroup does
   // (measured: single pair 2.08 -> 1.84 ms with the threshold at 1024 workgroups; a batch of 8 pairs does not care)
-  constexpr int split_below = 1024;
+  const int split_below = g_st_split_below.load();
   const int variant0 = g_st_variant.load();
   const bool small = variant0 != 0 && a.cout >= 64 && a.cout <= 256 && (long long)n_tiles * (a.cout / 64) < split_below;
   const int ctg = a.cout >= 64 && !small ? 64 : 32;                  // output channels per workgroup
@@ -643,13 +666,25 @@ int launch_spconv_st(const SpconvArgs& a_in, const unsigned char* local_dev, hip
     if (ctg == 64) {
       if (variant == 2) { if (wide) EYOC_STA(64, 2, 0); else EYOC_STA(32, 2, 0); }
 #ifdef EYOC_ST_ABLATIONS
-      else if (variant == 3) EYOC_STA(64, 2, 3);
-      else if (variant == 4) EYOC_STA(64, 2, 4);
-      else if (variant == 5) EYOC_STA(64, 2, 5);
-      else if (variant == 6) EYOC_STA(64, 2, 6);
-      else if (variant == 7) EYOC_STA(64, 2, 7);
-      else if (variant == 8) EYOC_STA(64, 2, 8);
-      else if (variant == 9) EYOC_STA(64, 2, 9);
+      else if (variant == 3) {                                         // 8 waves of 64 rows x 32 channels, four per SIMD
+        if (wide) hipLaunchKernelGGL((spconv_st_asm_kernel<64, 1, 1, 2 * NW>), grid, dim3(2 * NW * 64), 0, st, a, local_dev, n_tiles);
+        else hipLaunchKernelGGL((spconv_st_asm_kernel<32, 1, 1, 2 * NW>), grid, dim3(2 * NW * 64), 0, st, a, local_dev, n_tiles);
+      }
+      else if (variant == 13) EYOC_STA(64, 2, 3);
+      else if (variant == 14) EYOC_STA(64, 2, 4);
+      else if (variant == 15) EYOC_STA(64, 2, 5);
+      else if (variant == 16) EYOC_STA(64, 2, 6);
+      else if (variant == 17) EYOC_STA(64, 2, 7);
+      else if (variant == 18) EYOC_STA(64, 2, 8);
+      else if (variant == 19) EYOC_STA(64, 2, 9);
+      else if (variant == 20) EYOC_STA(64, 2, 10);
+      else if (variant == 21) EYOC_STA(64, 2, 11);
+      else if (variant == 22) EYOC_STA(64, 2, 12);
+      else if (variant == 23) EYOC_STA(64, 2, 13);
+      else if (variant == 24) EYOC_STA(64, 2, 14);
+      else if (variant == 25) EYOC_STA(64, 2, 15);
+      else if (variant == 26) EYOC_STA(64, 2, 16);
+      else if (variant == 27) EYOC_STA(64, 2, 17);
 #endif
       else { if (wide) EYOC_STA(64, 2, 1); else EYOC_STA(32, 2, 1); }
     } else { if (wide) EYOC_STA(64, 1, 1); else EYOC_STA(32, 1, 1); }

@@ -186,6 +186,10 @@ int eyoc_spconv_select_conv1_kernel(int on);
  * with scalar branches around the MFMAs of empty (16-row chunk, offset) blocks; 2 = the same without the branches;
  * 0 = the compiler-scheduled C++ loop.  Any other value only queries.  Returns the previous variant; process-wide, for tests and profiling. */
 int eyoc_spconv_select_st_kernel(int variant);
+/* A layer with fewer than `workgroups` 64-output-channel workgroups (default 1024 = two rounds of the chip's 512 slots) runs
+ * in 32-channel workgroups instead (twice as many, each half as long: single pairs and small batches).  0 = never (tests force
+ * the wide kernels onto small clouds with it); negative only queries.  Returns the previous threshold; process-wide. */
+int eyoc_spconv_st_split_below(int workgroups);
 size_t eyoc_spconv_local_rulebook_bytes(int n_out);
 int eyoc_spconv_build_local_rulebook(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, void* out_dev,
                                      int32_t* overflow_dev, void* stream);

@@ -356,17 +356,21 @@ def test_staged_kernel_vs_fp64(morton_maps, cin, cout, level):
     got, local = run_layer_staged(nbr, x, W, bias=b, scale=s, res=r, relu=True)
     got32, _ = run_layer_staged(nbr, x, W, bias=b, scale=s, res=r, relu=True, out_split=False)
     e, e32 = rel_err(got, want), rel_err(got32, want)
-    # the three implementations of the offset loop (assembly with / without empty-block branches, compiler-scheduled C++)
+    # the implementations of the offset loop (assembly with / without empty-block branches,
+    # compiler-scheduled C++), in 64- and in 32-channel workgroups,
     # multiply the same products in the same order: bit-identical outputs
     L, lib = _lib()
-    prev = lib.eyoc_spconv_select_st_kernel(-1)
+    prev, prev_split = lib.eyoc_spconv_select_st_kernel(-1), lib.eyoc_spconv_st_split_below(-1)
     try:
-        for variant in (0, 1, 2):
-            lib.eyoc_spconv_select_st_kernel(variant)
-            alt, _ = run_layer_staged(nbr, x, W, bias=b, scale=s, res=r, relu=True, out_split=False)
-            np.testing.assert_array_equal(alt, got32, err_msg=f"staged kernel variant {variant}")
+        for split in (prev_split, 0):                      # a cloud this small takes 32-channel workgroups; 0: the wide kernels
+            lib.eyoc_spconv_st_split_below(split)
+            for variant in (0, 1, 2):
+                lib.eyoc_spconv_select_st_kernel(variant)
+                alt, _ = run_layer_staged(nbr, x, W, bias=b, scale=s, res=r, relu=True, out_split=False)
+                np.testing.assert_array_equal(alt, got32, err_msg=f"staged kernel variant {variant}, split below {split}")
     finally:
         lib.eyoc_spconv_select_st_kernel(prev)
+        lib.eyoc_spconv_st_split_below(prev_split)
     # the local rulebook: one record per 256-row tile - n_unique first, then the row list, the slot entries and, last, per pass
     # 28 16-bit occupancy masks (bit 4 w + c of mask k: some row of rows 64 w + 16 c .. + 15 has a neighbour at offset k)
     REC, MASK_OFF = 32896, 32784
