@@ -7,8 +7,9 @@
 // (row, offset) pair from L2 / HBM - 10 GB for the 3.8 M-row 1 -> 0 layer whose distinct inputs are 0.8 GB, 1.6 ms at
 // the HBM limit.  This kernel does both things right:
 //
-//   * tile = 256 consecutive (Z-ordered) output rows; their ~100-200 distinct coarse input rows are staged in LDS once
-//     per 32-channel block, exactly like spconv_st.hip;
+//   * tile = 256 consecutive (Z-ordered) output rows; their ~100-200 distinct coarse input rows are staged in LDS like in
+//     spconv_st.hip - as many 32-channel blocks at once as the 640 row slots hold (all four of a 128-channel layer for most
+//     tiles: one global -> LDS round trip per tile instead of four);
 //   * INSIDE the tile the rows are sorted by their occupancy mask (k_local_rulebook_up: a 256-key bitonic sort), so a
 //     16-row MFMA group holds rows of one or two patterns; the rulebook carries the union mask of every group and the
 //     wave only multiplies the (group, offset) blocks whose mask bit is set (~5 of 27 instead of 27);
@@ -33,7 +34,8 @@ constexpr int NWK = 8;                                      // kernel: 8 waves =
 constexpr int XROWS = 640, UMAX = XROWS - 1, X_BYTES = XROWS * 128, NIT = XROWS / (8 * NWK);   // 80 KB: 2 workgroups = 16 waves per CU
 // rulebook of one tile: int n_unique (-1: more than UMAX), pad[3]; int U[640]; int row[256] (output row of slot s, -1:
 // none); unsigned gmask[16] (union of the occupancy masks of slots 16 g ..); uint2 loc[27][4][16]: entry (k, w, j) packs
-// the LDS slots v = 8 l + (l & 7) of the neighbours at offset k of tile slots 64 w + 16 c + j, c = 0..3 (UMAX: none)
+// the LDS slots v = 8 l + (l & 7) of the neighbours at offset k of tile slots 64 w + 16 c + j, c = 0..3 (l = n_unique: none -
+// the zero row behind the tile's rows in every block's region of the stage)
 constexpr int OFF_U = 16, OFF_ROW = OFF_U + XROWS * 4, OFF_GM = OFF_ROW + TILE * 4, OFF_LOC = OFF_GM + 16 * 4;
 constexpr int UP_LR_BYTES = OFF_LOC + 27 * 4 * 16 * 8;      // 17488
 constexpr int HSLOTS = 4096;                                // >= 2 x (256 rows x 8 neighbours)
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void k_local_rulebook_up(const int32_t* __rest
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
-    const int id = slot[k] != 0xFFFFu ? (int)hid[slot[k]] : UMAX;
+    const int id = slot[k] != 0xFFFFu ? (int)hid[slot[k]] : total;     // no neighbour: the zero row right behind the tile's rows
     const int l = id < UMAX ? id : UMAX;
     ids_row[k][r] = (unsigned short)(l * 8 + (l & 7));
   }
@@ -169,7 +171,14 @@ __global__ __launch_bounds__(NWK * 64, 4) void spconv_up_kernel(SpconvArgs a, co
   unsigned int gm[NG], wmask = 0;
 #pragma unroll
   for (int c = 0; c < NG; ++c) { gm[c] = __builtin_amdgcn_readfirstlane(gmp[c]); wmask |= gm[c]; }
-  if (threadIdx.x < 8) *reinterpret_cast<float4*>(xs + UMAX * 128 + threadIdx.x * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+  // The stage holds SEVERAL 32-channel blocks of the tile's rows at once when they fit (a tile has ~150 distinct input rows, the
+  // stage 640 row slots): region b = rows of block b + one zero row (what "no neighbour" entries point at), padded to the swizzle
+  // period.  A 128-channel layer then pays one or two global -> LDS round trips per tile instead of four - the offset loop of one
+  // block (4-9 offsets) is as short as such a round trip, and with two workgroups per CU nothing else hides it.
+  const int srows = (n_u + 8) & ~7;
+  const int nb_max = min(XROWS / srows, nqb);
+  if ((int)threadIdx.x < 8 * nb_max)
+    *reinterpret_cast<float4*>(xs + (((int)threadIdx.x >> 3) * srows + n_u) * 128 + (threadIdx.x & 7) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
 
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, K * a.cin * a.cout * 4, 0x00020000);
   const int tile4 = CC * CT / 4;
@@ -204,29 +213,31 @@ __global__ __launch_bounds__(NWK * 64, 4) void spconv_up_kernel(SpconvArgs a, co
   int Ureg[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) Ureg[it] = U[(it * NWK + wave) * 8 + (lane >> 3)];
-  auto stage = [&](int qb) {
+  auto stage = [&](int qb0, int nb) {
+    for (int b = 0; b < nb; ++b)
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int l0 = (it * NWK + wave) * 8;
-      if (l0 < n_u) {                                                // wave-uniform
-        const int l = l0 + (lane >> 3);
-        const float* src = a.in + (size_t)Ureg[it] * a.ld_in + qb * 32 + (((lane & 7) ^ (l & 7)) << 2);
-        if (l < n_u)
-          __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(xs + l0 * 128), 16, 0, 0);
+      for (int it = 0; it < NIT; ++it) {
+        const int l0 = (it * NWK + wave) * 8;
+        if (l0 < n_u) {                                              // wave-uniform
+          const int l = l0 + (lane >> 3);
+          const float* src = a.in + (size_t)Ureg[it] * a.ld_in + (qb0 + b) * 32 + (((lane & 7) ^ (l & 7)) << 2);
+          if (l < n_u)
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(xs + (b * srows + l0) * 128), 16, 0, 0);
+        }
       }
-    }
   };
   const unsigned int gh = (unsigned)g << 4, gl = (unsigned)(g ^ 4) << 4;
   // one occupied offset: operands of all 8 groups from LDS (a group without neighbours reads the zero row), products
   // only for the groups whose mask has the offset
-  auto compute = [&](int k, const uint2 L, const float4 (&W)[NTW][2]) {
+  auto compute = [&](int k, const uint2 L, const float4 (&W)[NTW][2], int b) {
     float4 X[NG][2];
     const unsigned int w4[2] = {L.x, L.y};
+    const unsigned char* xb = xs + b * srows * 128;                    // region of the block (a multiple of the swizzle period)
 #pragma unroll
     for (int c = 0; c < NG; ++c) {
       const unsigned int ad = ((w4[c >> 1] >> (16 * (c & 1))) & 0xFFFFu) << 4;
-      X[c][0] = *reinterpret_cast<const float4*>(xs + (ad ^ gh));
-      X[c][1] = *reinterpret_cast<const float4*>(xs + (ad ^ gl));
+      X[c][0] = *reinterpret_cast<const float4*>(xb + (ad ^ gh));
+      X[c][1] = *reinterpret_cast<const float4*>(xb + (ad ^ gl));
     }
 #pragma unroll
     for (int c = 0; c < NG; ++c) {
@@ -243,30 +254,37 @@ __global__ __launch_bounds__(NWK * 64, 4) void spconv_up_kernel(SpconvArgs a, co
 
   float4 WA[NTW][2], WB[NTW][2];
   uint2 LA = make_uint2(0, 0), LB = make_uint2(0, 0);
-  for (int qb = 0; qb < nqb; ++qb) {
-    if (qb) __syncthreads();                                           // every wave is done with the previous block's rows
-    stage(qb);
+  const int n_off = __builtin_popcount(wmask);                         // wave-uniform: the offsets any of the wave's groups has
+  for (int qb0 = 0; qb0 < nqb; qb0 += nb_max) {
+    const int nb = min(nb_max, nqb - qb0);
+    if (qb0) __syncthreads();                                          // every wave is done with the previous round's rows
+    stage(qb0, nb);
     unsigned int rest = wmask;
-    int kc = rest ? __builtin_ctz(rest) : 0;
-    load_w(kc, qb, WA);                                                // unconditional: a load inside a branch is waited for on the spot
+    int kc = rest ? __builtin_ctz(rest) : 0, bc = 0;                   // the (offset, block of the round) being multiplied
+    load_w(kc, qb0, WA);                                               // unconditional: a load inside a branch is waited for on the spot
     LA = locp[kc * 64];
     __builtin_amdgcn_s_waitcnt(0x0070);
     __syncthreads();
-    const int n_off = __builtin_popcount(wmask);                       // wave-uniform: the offsets any of the wave's groups has
-    for (int i = 0; i < n_off; i += 2) {
+    // the walk over (block, occupied offset): weights and rulebook entries of the next step are in flight while this one multiplies
+    auto next = [&](int& k, int& bb) {
       rest &= rest - 1;
-      int kn = rest ? __builtin_ctz(rest) : kc;
-      load_w(kn, qb, WB);                                              // next occupied offset (the last one re-loads itself)
+      if (!rest) { rest = wmask; bb = bb + 1 < nb ? bb + 1 : bb; }     // past the last step: re-loads the last block's first offset
+      k = __builtin_ctz(rest);
+    };
+    const int steps = nb * n_off;
+    for (int i = 0; i < steps; i += 2) {
+      int kn = kc, bn = bc;
+      next(kn, bn);
+      load_w(kn, qb0 + bn, WB);
       LB = locp[kn * 64];
-      compute(kc, LA, WA);
-      kc = kn;
-      if (i + 1 >= n_off) break;
-      rest &= rest - 1;
-      kn = rest ? __builtin_ctz(rest) : kc;
-      load_w(kn, qb, WA);
+      compute(kc, LA, WA, bc);
+      kc = kn; bc = bn;
+      if (i + 1 >= steps) break;
+      next(kn, bn);
+      load_w(kn, qb0 + bn, WA);
       LA = locp[kn * 64];
-      compute(kc, LB, WB);
-      kc = kn;
+      compute(kc, LB, WB, bc);
+      kc = kn; bc = bn;
     }
   }
 
