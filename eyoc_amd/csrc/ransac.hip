@@ -94,6 +94,22 @@ __device__ inline bool sample_and_check_edges(const float* __restrict__ rec, uns
   return true;
 }
 
+// the first of the six edge checks alone (samples 0 and 1: one hash, two records) - the same expressions as above, so a
+// hypothesis it rejects is one sample_and_check_edges rejects
+__device__ inline bool first_edge_ok(const float* __restrict__ rec, unsigned int n, unsigned long long base, unsigned int h,
+                                     double edge_sim) {
+  unsigned int i0, i1;
+  sample_pair(base, 2ull * h, n, i0, i1);
+  const float2* ra = reinterpret_cast<const float2*>(rec + (size_t)i0 * 6);
+  const float2* rb = reinterpret_cast<const float2*>(rec + (size_t)i1 * 6);
+  const float2 a0 = ra[0], a1 = ra[1], a2 = ra[2], b0 = rb[0], b1 = rb[1], b2 = rb[2];
+  const double sa[3] = {a0.x, a0.y, a1.x}, qa[3] = {a1.y, a2.x, a2.y}, sb[3] = {b0.x, b0.y, b1.x}, qb[3] = {b1.y, b2.x, b2.y};
+  const double e2 = edge_sim * edge_sim;
+  const double ds2 = (sa[0] - sb[0]) * (sa[0] - sb[0]) + (sa[1] - sb[1]) * (sa[1] - sb[1]) + (sa[2] - sb[2]) * (sa[2] - sb[2]);
+  const double dt2 = (qa[0] - qb[0]) * (qa[0] - qb[0]) + (qa[1] - qb[1]) * (qa[1] - qb[1]) + (qa[2] - qb[2]) * (qa[2] - qb[2]);
+  return !(ds2 < dt2 * e2 || dt2 < ds2 * e2);
+}
+
 // 4-point Kabsch and the distance checker
 __device__ inline bool fit_and_check_distance(const double s[4][3], const double q[4][3], double max_dist, double R[3][3],
                                               double t[3]) {
@@ -137,7 +153,7 @@ __device__ inline bool hypothesis(const float* __restrict__ rec, unsigned int n,
 constexpr int CNT_STRIDE = 64;
 constexpr int GEN_THREADS = 1024;
 constexpr int GEN_BLOCKS_MIN = 64, GEN_BLOCKS_TOTAL = 512;   // workgroups per pair: enough to fill the chip even for one pair
-constexpr int LDS_RECORDS = 6400;                    // 6400 * 24 B = 150 KB of the 160 KB LDS
+constexpr int LDS_RECORDS = 6016;                    // 6016 * 24 B = 141 KB of the 160 KB LDS (+ 16 KB of queues)
 
 __device__ inline unsigned long long pair_base(unsigned int seed, int b) {
   return (unsigned long long)(seed + (unsigned)b) * 0x9E3779B97F4A7C15ull;
@@ -152,7 +168,7 @@ __device__ inline unsigned long long pair_base(unsigned int seed, int b) {
 template <bool IN_LDS>
 __global__ __launch_bounds__(GEN_THREADS) void k_generate(PairArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lrec[];
-  __shared__ int queue[GEN_THREADS / 64][128];
+  __shared__ int queue[GEN_THREADS / 64][128], queue1[GEN_THREADS / 64][128];
   const int c = blockIdx.y, b = a.pair0 + c;
   const int s0 = a.s0[c], n = a.n[c];
   const float* rec = a.rec + (size_t)s0 * 6;
@@ -185,21 +201,39 @@ __global__ __launch_bounds__(GEN_THREADS) void k_generate(PairArgs a) {
       }
     }
   };
+  // Two queues per wave: every hypothesis takes the FIRST edge check only (one hash, two records: most fail it); the ones that
+  // pass are queued and take the full six-edge check 64 at a time; the ones that pass that are queued for the fit.
+  // (No nested lambdas here: a closure that captures another one ends up in scratch memory, and the records with it behind
+  // generic pointers - flat loads instead of LDS reads, 5 x slower.)
+  int* wq1 = queue1[threadIdx.x >> 6];
+  int queued1 = 0;
   const int stride = gridDim.x * GEN_THREADS;
   const int rounds = (a.H + stride - 1) / stride;
-  for (int r = 0; r < rounds; ++r) {
-    const int h = r * stride + blockIdx.x * GEN_THREADS + threadIdx.x;
-    bool pass = false;
-    if (h < a.H) {
-      double s[4][3], q[4][3];
-      pass = sample_and_check_edges(rec, (unsigned)n, base, (unsigned)h, edge_sim, s, q);
+  for (int r = 0; r <= rounds; ++r) {                       // the extra round drains the first queue
+    if (r < rounds) {
+      const int h = r * stride + blockIdx.x * GEN_THREADS + threadIdx.x;
+      const bool pass1 = h < a.H && first_edge_ok(rec, (unsigned)n, base, (unsigned)h, edge_sim);
+      const unsigned long long m1 = __ballot(pass1);
+      if (pass1) wq1[queued1 + __popcll(m1 & ((1ull << lane) - 1ull))] = h;
+      queued1 += __popcll(m1);
     }
-    const unsigned long long m = __ballot(pass);
-    if (pass) wq[queued + __popcll(m & ((1ull << lane) - 1ull))] = h;
-    queued += __popcll(m);
-    if (queued >= 64) {   // wave-uniform
-      queued -= 64;
-      fit(wq[queued + lane]);
+    const bool drain = r == rounds;
+    if (queued1 >= 64 || (drain && queued1 > 0)) {          // wave-uniform
+      int h2;
+      if (drain) { h2 = lane < queued1 ? wq1[lane] : -1; queued1 = 0; }
+      else { queued1 -= 64; h2 = wq1[queued1 + lane]; }
+      bool pass = false;
+      if (h2 >= 0) {
+        double s[4][3], q[4][3];
+        pass = sample_and_check_edges(rec, (unsigned)n, base, (unsigned)h2, edge_sim, s, q);
+      }
+      const unsigned long long m = __ballot(pass);
+      if (pass) wq[queued + __popcll(m & ((1ull << lane) - 1ull))] = h2;
+      queued += __popcll(m);
+      if (queued >= 64) {
+        queued -= 64;
+        fit(wq[queued + lane]);
+      }
     }
   }
   fit(lane < queued ? wq[lane] : -1);
