@@ -34,14 +34,18 @@ for lvl, cin, cout in LAYERS:
         for _ in range(reps): fn()
         e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / reps
     t_lr = timeit(lambda: lib.eyoc_spconv_build_local_rulebook(_lib.ctx(), tab, 27, n, _lib.ptr(local), _lib.ptr(ovf), _lib.stream_ptr()))
-    res = {}
+    res_t = {}
     for name, mode in (() if os.environ.get("ONLY_ST") else (("wave", 0), ("rs", 2))):
         lib.eyoc_spconv_select_split16_kernel(mode)
-        res[name] = timeit(lambda: _lib.check(lib.eyoc_spconv_ex(_lib.ctx(), tab, 27, n, n, _lib.ptr(xs), cin, cin, _lib.ptr(wd), cout, None, None, 0, 0, _lib.ptr(out), cout, 1, 1, _lib.ptr(osd), _lib.stream_ptr())))
+        res_t[name] = timeit(lambda: _lib.check(lib.eyoc_spconv_ex(_lib.ctx(), tab, 27, n, n, _lib.ptr(xs), cin, cin, _lib.ptr(wd), cout, None, None, 0, 0, _lib.ptr(out), cout, 1, 1, _lib.ptr(osd), _lib.stream_ptr())))
     lib.eyoc_spconv_select_split16_kernel(1)
     ref_out = None
     variants = [int(v) for v in os.environ.get("ST_VARIANTS", "0,1,2").split(",")]
-    run_st = lambda: _lib.check(lib.eyoc_spconv_staged(_lib.ctx(), tab, _lib.ptr(local), n, n, _lib.ptr(xs), cin, cin, _lib.ptr(wd), cout, None, None, 0, 0, _lib.ptr(out), cout, 1, _lib.ptr(osd), _lib.stream_ptr()))
+    res = None
+    if os.environ.get("RES") and cin == cout:      # residual layers (the second convolution of a block): RES=1
+        res = torch.empty_like(x)
+        lib.eyoc_split16_encode(_lib.ctx(), _lib.ptr(torch.randn(n, cout, device="cuda")), n, cout, cout, _lib.ptr(res), cout, _lib.stream_ptr())
+    run_st = lambda: _lib.check(lib.eyoc_spconv_staged(_lib.ctx(), tab, _lib.ptr(local), n, n, _lib.ptr(xs), cin, cin, _lib.ptr(wd), cout, None, _lib.ptr(res), 0 if res is None else cout, 0, _lib.ptr(out), cout, 1, _lib.ptr(osd), _lib.stream_ptr()))
     best = {v: [] for v in variants}
     for rnd in range(int(os.environ.get("ROUNDS", "5"))):      # variants interleaved over several rounds: clocks drift with load
         for variant in variants:
@@ -51,6 +55,6 @@ for lvl, cin, cout in LAYERS:
                 torch.cuda.synchronize()
                 if ref_out is None: ref_out = out.clone()
                 elif not torch.equal(ref_out, out): best[variant].append(-1e6)   # a mismatch shows as an absurd time
-    for v in variants: res[f"st{v}"] = float(np.median(best[v])); res[f"st{v}min"] = min(best[v])
+    for v in variants: res_t[f"st{v}"] = float(np.median(best[v])); res_t[f"st{v}min"] = min(best[v])
     lib.eyoc_spconv_select_st_kernel(1)
-    print(f"lvl{lvl} {cin}->{cout} n={n} pairs={prs} overflow={int(ovf.item())} local-rulebook {t_lr:.3f} ms | " + "  ".join(f"{k} {v:.3f} ms ({2*prs*cin*cout/v/1e9:.0f} TF)" for k, v in res.items()), flush=True)
+    print(f"lvl{lvl} {cin}->{cout} n={n} pairs={prs} overflow={int(ovf.item())} local-rulebook {t_lr:.3f} ms | " + "  ".join(f"{k} {v:.3f} ms ({2*prs*cin*cout/v/1e9:.0f} TF)" for k, v in res_t.items()), flush=True)
