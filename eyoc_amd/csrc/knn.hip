@@ -287,14 +287,27 @@ __global__ void knn_pack_targets_mfma(const float* __restrict__ B, SegArgs seg, 
   dst[0] = __builtin_bit_cast(float4, hi);
   dst[64] = __builtin_bit_cast(float4, lo);
   dst[128] = make_float4(ok ? (zero_norm ? 0.0f : n2) : __builtin_inff(), ok ? 1.0f / sc : 0.0f, 0.f, 0.f);   // zero_norm: score -2 <a, b>
-  if (ok && g == 0 && n2 == n2) atomicMax(bmax_bits + s, __float_as_int(n2));   // non-negative floats order like ints
+  // the segment's largest |b|^2: one atomic per wave (= per tile of 16 targets), not per target - 5000 atomics on one word
+  // per segment were most of this kernel's time
+  int nb2 = (ok && n2 == n2) ? __float_as_int(n2) : 0;                // non-negative floats order like ints
+#pragma unroll
+  for (int d = 8; d >= 1; d >>= 1) nb2 = max(nb2, __shfl_xor(nb2, d, 64));
+  if (l == 0 && nb2 > 0) atomicMax(bmax_bits + s, nb2);
 }
 
 __global__ void knn_row_norms(const float* __restrict__ A, int n, int C, float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float n2 = 0.f;
-  for (int c = 0; c < C; ++c) n2 += A[(size_t)i * C + c] * A[(size_t)i * C + c];
+  if ((C & 3) == 0) {                                                  // 16-byte loads, the same sum in the same order
+    const float4* row = reinterpret_cast<const float4*>(A + (size_t)i * C);
+    for (int q = 0; q < C / 4; ++q) {
+      const float4 v = row[q];
+      n2 += v.x * v.x; n2 += v.y * v.y; n2 += v.z * v.z; n2 += v.w * v.w;
+    }
+  } else {
+    for (int c = 0; c < C; ++c) n2 += A[(size_t)i * C + c] * A[(size_t)i * C + c];
+  }
   out[i] = n2;
 }
 
