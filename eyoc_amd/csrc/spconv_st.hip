@@ -57,17 +57,22 @@ constexpr int MASK_OFF = 16 + UCAP * 4 + NPASS * 27 * 64 * 8;   // 32784
 constexpr int MASK_PASS_BYTES = 56;
 constexpr int LR_BYTES = MASK_OFF + NPASS * MASK_PASS_BYTES;    // 32896
 static_assert(TILE == ST_TILE && UMAX == ST_UMAX && UCAP == ST_UCAP && NPASS == ST_NPASS && LR_BYTES == ST_LR_BYTES, "spconv.h mirrors this layout");
-constexpr int HSLOTS = 8192;                               // > 256 * 27 possible distinct rows: probing always terminates
+// LDS hash of a tile's distinct input rows.  A usable tile has at most NPASS * UMAX = 1278 of them (31 % load); a tile with more
+// than HSLOTS (rows in no spatial order) gives up after a full round of probing and counts as overflowed.  (8192 slots - room
+// for all 256 * 27 possible rows - cost twice the clearing and numbering work and a third of the occupancy: 278 -> ~190 us at level 0.)
+constexpr int HSLOTS = 4096;
 
 __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restrict__ nbr, int K, int n_out, unsigned char* __restrict__ out,
                                                         int* __restrict__ overflow) {
   __shared__ int hk[HSLOTS];
   __shared__ unsigned short hid[HSLOTS];
   __shared__ int wave_cnt[NW];
+  __shared__ int too_many;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = blockIdx.x;
   const int row = tile * TILE + (int)threadIdx.x;
   for (int i = threadIdx.x; i < HSLOTS; i += 256) hk[i] = -1;
+  if (threadIdx.x == 0) too_many = 0;
   __syncthreads();
   // 1. insert every valid entry (linear probing; duplicates meet their own key); the slot found stays in a register
   unsigned short slot[27];
@@ -79,16 +84,25 @@ __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restric
     const int idx = idxs[k];
     unsigned int s = 0xFFFFu;
     if (idx >= 0) {
-      s = ((unsigned)idx * 2654435761u) >> 19;
+      s = ((unsigned)idx * 2654435761u) >> 20;
+      int probes = 0;
       while (true) {
         const int prev = atomicCAS(&hk[s], -1, idx);
         if (prev == -1 || prev == idx) break;
         s = (s + 1) & (HSLOTS - 1);
+        if (++probes >= HSLOTS) { too_many = 1; s = 0xFFFFu; break; }   // the table is full: more than HSLOTS distinct rows
       }
     }
     slot[k] = (unsigned short)s;
   }
   __syncthreads();
+  if (too_many) {                                                      // workgroup-uniform
+    if (threadIdx.x == 0) {
+      reinterpret_cast<int*>(out + (size_t)tile * LR_BYTES)[0] = -1;
+      atomicAdd(overflow, 1);
+    }
+    return;
+  }
   // 2. number the occupied slots in slot order (deterministic): every wave owns a quarter of the table
   constexpr int PER_WAVE = HSLOTS / NW;
   int cnt = 0;

@@ -389,6 +389,36 @@ def test_staged_kernel_vs_fp64(morton_maps, cin, cout, level):
     assert e < 2e-6 and e32 < 2e-6 and n_u.max() <= 1278 and n_u.min() >= 1
 
 
+def test_local_rulebook_counts_tiles_it_cannot_stage_instead_of_hanging():
+    """Rows in NO spatial order: a 256-row tile of a dense grid then references up to 256 x 27 distinct rows - more than the
+    1278 the stage takes in two passes, and more than the builder's 4096-slot LDS hash holds.  The builder gives up on such a
+    tile (n_unique = -1), counts it in *overflow and terminates; tiles of the same cloud in Morton order build cleanly."""
+    from oracle import coords as oc
+    L, lib = _lib()
+    g = np.stack(np.meshgrid(np.arange(26), np.arange(26), np.arange(26), indexing="ij"), -1).reshape(-1, 3)
+    coords = np.concatenate([np.zeros((len(g), 1), np.int64), g], 1).astype(np.int32)
+    dev = torch.device("cuda")
+    REC = 32896
+    for order, expect_overflow in ((np.random.default_rng(0).permutation(len(coords)), True), (morton_order(coords), False)):
+        nbr = oc.build_maps(coords[order])["s1"][0]
+        n = nbr.shape[1]
+        nd = torch.from_numpy(np.ascontiguousarray(nbr, np.int32)).to(dev)
+        local = torch.zeros(int(lib.eyoc_spconv_local_rulebook_bytes(n)), dtype=torch.uint8, device=dev)
+        ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.check(lib.eyoc_spconv_build_local_rulebook(L.ctx(), L.ptr(nd), 27, n, L.ptr(local), L.ptr(ovf), L.stream_ptr()))
+        torch.cuda.synchronize()
+        n_tiles = (n + 255) // 256
+        n_u = local.cpu().numpy()[:n_tiles * REC].reshape(-1, REC)[:, :4].copy().view(np.int32)[:, 0]
+        distinct = np.array([len(np.unique(t[t >= 0])) for t in np.array_split(nbr, np.arange(256, n, 256), axis=1)])
+        if expect_overflow:
+            assert distinct.max() > 4096                                   # the case the hash cannot hold at all
+            assert int(ovf.item()) == int((distinct > 1278).sum()) > 0
+            np.testing.assert_array_equal(n_u[distinct > 1278], -1)
+        else:
+            assert int(ovf.item()) == 0
+        np.testing.assert_array_equal(n_u[distinct <= 1278], distinct[distinct <= 1278])
+
+
 def test_staged_kernel_refuses_channel_widths_it_cannot_tile(morton_maps):
     """96 output channels are neither one 64-channel workgroup nor a power-of-two number of them: the staged entry point
     says so instead of computing two thirds of the layer (launch_spconv keeps such layers on the gathering kernels)."""
