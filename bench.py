@@ -54,7 +54,8 @@ from eyoc_amd.metrics import registration_errors  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_16x16x4_f32 dense peak
-MFMA_F16_PEAK_TF = 2500.0  # v_mfma_f32_16x16x32_f16 dense peak (MI355X_MICROARCH.md; never the 2:1-sparsity figure)
+MFMA_F16_PEAK_TF = 2500
+MFMA_F16_SUSTAINED_TF = 1600.0     # scripts/micro/mfma_power.hip: dense v_mfma_f32_16x16x32_f16 stream, random fp16 operands, 2 waves per SIMD.0  # v_mfma_f32_16x16x32_f16 dense peak (MI355X_MICROARCH.md; never the 2:1-sparsity figure)
 REC = 20                   # floats per result record: 16 pose + RTE + RRE + success + rank
 
 
@@ -471,6 +472,18 @@ def worker(args):
                 out["roofline"]["traffic"] = traffic
                 out["roofline"]["traffic_source"] = f"profiles/{tag}_spconv_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
                 out["hbm_gather"]["traffic_over_compulsory"] = traffic / compulsory
+                if math_mode == "split16" and "spconv_issued_fp16_mfma_flop_per_forward" in prof:
+                    # what the matrix pipe actually executes (zero rows of partly empty 16-row blocks included), from the
+                    # same committed counter passes, against the rate a dense stream of the same instruction SUSTAINS with
+                    # random operands: the pipe's clock is power-managed, scripts/micro/mfma_power.hip measures 2.09
+                    # PFLOP/s with all-zero operands and 1.6 with random ones
+                    issued = prof["spconv_issued_fp16_mfma_flop_per_forward"]
+                    out["roofline"]["issued_mfma"] = {
+                        "flop_per_forward": issued, "TFLOP/s": issued / (conv_ms * 1e-3) / 1e12,
+                        "useful_fraction": 3 * flops / issued, "measured_in_run": False,
+                        "source": f"profiles/{tag}_mfma_counters.csv (SQ_INSTS_VALU_MFMA_MOPS_F16 x 512)",
+                        "sustained_peak_random_operands_TFLOP/s": MFMA_F16_SUSTAINED_TF,
+                        "frac_of_sustained_peak": issued / (conv_ms * 1e-3) / 1e12 / MFMA_F16_SUSTAINED_TF}
                 break
         except (OSError, KeyError, ValueError):
             pass

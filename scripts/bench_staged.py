@@ -18,7 +18,7 @@ LAYERS = ((0, 64, 64), (2, 128, 128)) if os.environ.get("ONLY_ST") else ((0, 64,
 for lvl, cin, cout in LAYERS:
     n = info["rows"][lvl]; prs = info["pairs_s1"][lvl]
     tab = lib.eyoc_maps_table(maps, 0, lvl)
-    x = torch.randn(n, cin, device="cuda"); xs = torch.empty_like(x)
+    x = torch.randn(n, cin, device="cuda") * float(os.environ.get("XSCALE", "1")); xs = torch.empty_like(x)   # XSCALE=0: all-zero activations (same instruction stream, fewer toggling bits: a power / clock probe)
     lib.eyoc_split16_encode(_lib.ctx(), _lib.ptr(x), n, cin, cin, _lib.ptr(xs), cin, _lib.stream_ptr())
     W = np.random.default_rng(0).normal(size=(27, cin, cout)).astype(np.float32)
     packed = np.zeros(W.size, np.float32); osc = np.ones(1, np.float32)

@@ -63,3 +63,9 @@ if os.path.exists(mf):
     piv = piv.sort_values(piv.columns[0], ascending=False)
     piv.to_csv(os.path.join(out, f"{tag}_mfma_counters.csv"))
     print(piv.head(12).to_string())
+    if "SQ_INSTS_VALU_MFMA_MOPS_F16" in piv:
+        # fp16 MFMA work the sparse-conv kernels ISSUE per forward (one MOP = 512 flop: 32 per v_mfma_f32_16x16x32_f16), zero
+        # rows of partly empty 16-row blocks included - next to the useful products bench.py prices the roofline with
+        sel = piv[[k.startswith("spconv_") or k.startswith("tail_fused") for k in piv.index]]
+        summary["spconv_issued_fp16_mfma_flop_per_forward"] = float(sel["SQ_INSTS_VALU_MFMA_MOPS_F16"].sum()) * 512 / steps
+        json.dump(summary, open(os.path.join(out, f"{tag}_spconv_traffic.json"), "w"), indent=1)
