@@ -552,44 +552,62 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
   for (int t = 0; t < NTW; ++t)
     b4[t] = a.bias ? *reinterpret_cast<const float4*>(a.bias + ch + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
   float mx = 0.f;
+  // Three passes over the wave's NH * NC row groups - all residual loads, all values, all stores - instead of one: written as one
+  // loop the compiler re-used a group's store registers for the next group and put `s_waitcnt vmcnt(0)` (which counts stores as
+  // well) in front of every group, i.e. a store round trip AND a residual round trip per group, eight times in a row at the end of
+  // every tile.  After the loop the 128 registers of the assembly blob are free: everything is in flight at once.
+  constexpr int NG = NH * NC;
+  uint4 rh[NG], rl[NG];
+  if (a.res) {
 #pragma unroll
-  for (int hc = 0; hc < NH * NC; ++hc) {
-    const int h = hc / NC, c = hc % NC;
-    const int o = tile * TILE + (w0 + h) * 64 + 16 * c + j;
-    if (o >= a.n_out) continue;
-    if (SKIP == 7 && os != 12345.f) continue;                          // EYOC_ST_ABLATIONS: no epilogue (the accumulators stay live)
-    float4 v[NTW];
+    for (int hc = 0; hc < NG; ++hc) {
+      const int o = tile * TILE + (w0 + hc / NC) * 64 + 16 * (hc % NC) + j;
+      if (o < a.n_out) {
+        const char* rp = reinterpret_cast<const char*>(a.res + (size_t)o * a.ld_res) + split16_off4(ch);
+        rh[hc] = *reinterpret_cast<const uint4*>(rp);
+        rl[hc] = *reinterpret_cast<const uint4*>(rp + SPLIT16_LO);
+      }
+    }
+  }
+  float4 v[NG][NTW];
+#pragma unroll
+  for (int hc = 0; hc < NG; ++hc) {
+    const int o = tile * TILE + (w0 + hc / NC) * 64 + 16 * (hc % NC) + j;
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
       const int ai = (hc * NTW + t) * 4;                                // register ACC(h, c, t) - 64 of the generator's map
       const f32x16& A = ai < 16 ? A0 : ai < 32 ? A1 : ai < 48 ? A2 : A3;
-      v[t] = make_float4(A[ai % 16 + 0] * os + b4[t].x, A[ai % 16 + 1] * os + b4[t].y, A[ai % 16 + 2] * os + b4[t].z,
-                         A[ai % 16 + 3] * os + b4[t].w);
+      v[hc][t] = make_float4(A[ai % 16 + 0] * os + b4[t].x, A[ai % 16 + 1] * os + b4[t].y, A[ai % 16 + 2] * os + b4[t].z,
+                             A[ai % 16 + 3] * os + b4[t].w);
     }
-    if (a.res) {
-      const char* rp = reinterpret_cast<const char*>(a.res + (size_t)o * a.ld_res) + split16_off4(ch);
-      const uint4 rh = *reinterpret_cast<const uint4*>(rp), rl = *reinterpret_cast<const uint4*>(rp + SPLIT16_LO);
-      const float4 q0 = split16_decode4(make_uint2(rh.x, rh.y), make_uint2(rl.x, rl.y));
-      const float4 q1 = split16_decode4(make_uint2(rh.z, rh.w), make_uint2(rl.z, rl.w));
-      v[0].x += q0.x; v[0].y += q0.y; v[0].z += q0.z; v[0].w += q0.w;
-      v[1].x += q1.x; v[1].y += q1.y; v[1].z += q1.z; v[1].w += q1.w;
+    if (a.res && o < a.n_out) {
+      const float4 q0 = split16_decode4(make_uint2(rh[hc].x, rh[hc].y), make_uint2(rl[hc].x, rl[hc].y));
+      const float4 q1 = split16_decode4(make_uint2(rh[hc].z, rh[hc].w), make_uint2(rl[hc].z, rl[hc].w));
+      v[hc][0].x += q0.x; v[hc][0].y += q0.y; v[hc][0].z += q0.z; v[hc][0].w += q0.w;
+      v[hc][1].x += q1.x; v[hc][1].y += q1.y; v[hc][1].z += q1.z; v[hc][1].w += q1.w;
     }
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-      if (a.relu) { v[t].x = fmaxf(v[t].x, 0.f); v[t].y = fmaxf(v[t].y, 0.f); v[t].z = fmaxf(v[t].z, 0.f); v[t].w = fmaxf(v[t].w, 0.f); }
-      split16_track(mx, v[t]);
+      if (a.relu) { v[hc][t].x = fmaxf(v[hc][t].x, 0.f); v[hc][t].y = fmaxf(v[hc][t].y, 0.f); v[hc][t].z = fmaxf(v[hc][t].z, 0.f); v[hc][t].w = fmaxf(v[hc][t].w, 0.f); }
+      if (o < a.n_out) split16_track(mx, v[hc][t]);
     }
+  }
+#pragma unroll
+  for (int hc = 0; hc < NG; ++hc) {
+    const int o = tile * TILE + (w0 + hc / NC) * 64 + 16 * (hc % NC) + j;
+    if (o >= a.n_out) continue;
+    if (SKIP == 7 && os != 12345.f) continue;                          // EYOC_ST_ABLATIONS: no epilogue (the accumulators stay live)
     if (a.out_split) {
       uint2 h0, l0, h1, l1;
-      split16_encode4(v[0], h0, l0);
-      split16_encode4(v[1], h1, l1);
+      split16_encode4(v[hc][0], h0, l0);
+      split16_encode4(v[hc][1], h1, l1);
       char* op = reinterpret_cast<char*>(a.out + (size_t)o * a.ld_out) + split16_off4(ch);
       *reinterpret_cast<uint4*>(op) = make_uint4(h0.x, h0.y, h1.x, h1.y);
       *reinterpret_cast<uint4*>(op + SPLIT16_LO) = make_uint4(l0.x, l0.y, l1.x, l1.y);
     } else {
       float* op = a.out + (size_t)o * a.ld_out + ch;
-      *reinterpret_cast<float4*>(op) = v[0];
-      *reinterpret_cast<float4*>(op + 4) = v[1];
+      *reinterpret_cast<float4*>(op) = v[hc][0];
+      *reinterpret_cast<float4*>(op + 4) = v[hc][1];
     }
   }
   if (a.out_split) split16_report(a.range, mx);

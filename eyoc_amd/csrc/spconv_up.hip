@@ -296,38 +296,55 @@ __global__ __launch_bounds__(NWK * 64, 4) void spconv_up_kernel(SpconvArgs a, co
   for (int t = 0; t < NTW; ++t)
     b4[t] = a.bias ? *reinterpret_cast<const float4*>(a.bias + ch + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
   float mx = 0.f;
+  // Two passes: (1) the four output rows (one round trip, not one per group), the residual rows, the values of all four groups;
+  // (2) the stores, back to back.  In one pass the compiler re-used a group's store registers for the next group and waited for
+  // the stores (vmcnt counts them) before every group: four dependent round trips at the end of every tile.
+  int orow[NG];
+#pragma unroll
+  for (int c = 0; c < NG; ++c) orow[c] = rowp[16 * c + j];
+  uint4 rh[NG], rl[NG];
+  if (a.res) {
+#pragma unroll
+    for (int c = 0; c < NG; ++c)
+      if (orow[c] >= 0) {
+        const char* rp = reinterpret_cast<const char*>(a.res + (size_t)orow[c] * a.ld_res) + split16_off4(ch);
+        rh[c] = *reinterpret_cast<const uint4*>(rp);
+        rl[c] = *reinterpret_cast<const uint4*>(rp + SPLIT16_LO);
+      }
+  }
+  float4 v[NG][NTW];
 #pragma unroll
   for (int c = 0; c < NG; ++c) {
-    const int o = rowp[16 * c + j];
-    if (o < 0) continue;
-    float4 v[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t)
-      v[t] = make_float4(acc[c][t][0] * os + b4[t].x, acc[c][t][1] * os + b4[t].y, acc[c][t][2] * os + b4[t].z, acc[c][t][3] * os + b4[t].w);
-    if (a.res) {
-      const char* rp = reinterpret_cast<const char*>(a.res + (size_t)o * a.ld_res) + split16_off4(ch);
-      const uint4 rh = *reinterpret_cast<const uint4*>(rp), rl = *reinterpret_cast<const uint4*>(rp + SPLIT16_LO);
-      const float4 q0 = split16_decode4(make_uint2(rh.x, rh.y), make_uint2(rl.x, rl.y));
-      const float4 q1 = split16_decode4(make_uint2(rh.z, rh.w), make_uint2(rl.z, rl.w));
-      v[0].x += q0.x; v[0].y += q0.y; v[0].z += q0.z; v[0].w += q0.w;
-      v[1].x += q1.x; v[1].y += q1.y; v[1].z += q1.z; v[1].w += q1.w;
+      v[c][t] = make_float4(acc[c][t][0] * os + b4[t].x, acc[c][t][1] * os + b4[t].y, acc[c][t][2] * os + b4[t].z, acc[c][t][3] * os + b4[t].w);
+    if (a.res && orow[c] >= 0) {
+      const float4 q0 = split16_decode4(make_uint2(rh[c].x, rh[c].y), make_uint2(rl[c].x, rl[c].y));
+      const float4 q1 = split16_decode4(make_uint2(rh[c].z, rh[c].w), make_uint2(rl[c].z, rl[c].w));
+      v[c][0].x += q0.x; v[c][0].y += q0.y; v[c][0].z += q0.z; v[c][0].w += q0.w;
+      v[c][1].x += q1.x; v[c][1].y += q1.y; v[c][1].z += q1.z; v[c][1].w += q1.w;
     }
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-      if (a.relu) { v[t].x = fmaxf(v[t].x, 0.f); v[t].y = fmaxf(v[t].y, 0.f); v[t].z = fmaxf(v[t].z, 0.f); v[t].w = fmaxf(v[t].w, 0.f); }
-      split16_track(mx, v[t]);
+      if (a.relu) { v[c][t].x = fmaxf(v[c][t].x, 0.f); v[c][t].y = fmaxf(v[c][t].y, 0.f); v[c][t].z = fmaxf(v[c][t].z, 0.f); v[c][t].w = fmaxf(v[c][t].w, 0.f); }
+      if (orow[c] >= 0) split16_track(mx, v[c][t]);
     }
+  }
+#pragma unroll
+  for (int c = 0; c < NG; ++c) {
+    const int o = orow[c];
+    if (o < 0) continue;
     if (a.out_split) {
       uint2 h0, l0, h1, l1;
-      split16_encode4(v[0], h0, l0);
-      split16_encode4(v[1], h1, l1);
+      split16_encode4(v[c][0], h0, l0);
+      split16_encode4(v[c][1], h1, l1);
       char* op = reinterpret_cast<char*>(a.out + (size_t)o * a.ld_out) + split16_off4(ch);
       *reinterpret_cast<uint4*>(op) = make_uint4(h0.x, h0.y, h1.x, h1.y);
       *reinterpret_cast<uint4*>(op + SPLIT16_LO) = make_uint4(l0.x, l0.y, l1.x, l1.y);
     } else {
       float* op = a.out + (size_t)o * a.ld_out + ch;
-      *reinterpret_cast<float4*>(op) = v[0];
-      *reinterpret_cast<float4*>(op + 4) = v[1];
+      *reinterpret_cast<float4*>(op) = v[c][0];
+      *reinterpret_cast<float4*>(op + 4) = v[c][1];
     }
   }
   if (a.out_split) split16_report(a.range, mx);
