@@ -142,6 +142,15 @@ __global__ __launch_bounds__(256) void k_local_rulebook_up(const int32_t* __rest
   for (int k = 0; k < 27; ++k) loc[(((size_t)(k * 4 + h) * 16) + j) * 4 + c] = ids_row[k][src];
 }
 
+#ifdef EYOC_UP_TRACE
+// diagnostics (scripts/trace_up.py): per workgroup of the 128 -> 64 layer {start, stage issued, stage landed, loops done, values ready, end, HW_ID}
+constexpr int UP_TRACE_WGS = 16384, UP_TRACE_N = 8;
+__device__ unsigned long long g_up_trace[UP_TRACE_WGS * UP_TRACE_N];
+#define UP_STAMP(i) do { if (a.cin == 128 && a.cout == 64 && threadIdx.x == 0 && blockIdx.x < UP_TRACE_WGS) g_up_trace[blockIdx.x * UP_TRACE_N + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define UP_STAMP(i) do {} while (0)
+#endif
+
 template <int CC>
 __global__ __launch_bounds__(NWK * 64, 4) void spconv_up_kernel(SpconvArgs a, const unsigned char* __restrict__ local, int n_tiles) {
   constexpr int NTW = 2, CTG = 64, NG = 4;                             // per wave: 64 slots (4 groups) x 32 output channels
@@ -162,9 +171,24 @@ __global__ __launch_bounds__(NWK * 64, 4) void spconv_up_kernel(SpconvArgs a, co
   const int nqb = a.cin / 32;
   constexpr int K = 27;
 
+  UP_STAMP(0);
+  // L2 warm-up of the record (header, row list, slot entries: 17 KB, written by the builder long ago) of the tile that will
+  // most likely take this workgroup's slot next - 512 workgroups further on, same XCD: a tile spends a third of its life getting
+  // its header, its row list and its rows (scripts/trace_up.py), the first two as dependent HBM round trips
+  int warm = 0;
+  {
+    const int tn = tile + 64 * per;
+    if (tn < n_tiles && (int)threadIdx.x * 128 < UP_LR_BYTES)
+      warm = *reinterpret_cast<const int*>(local + (size_t)tn * UP_LR_BYTES + threadIdx.x * 128);
+  }
   const unsigned char* lr = local + (size_t)tile * UP_LR_BYTES;
-  const int n_u = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(lr)[0]);
   const int* __restrict__ U = reinterpret_cast<const int*>(lr + OFF_U);
+  // the tile's row numbers: requested FIRST - before the header is waited for (the list has XROWS entries whatever n_unique
+  // says) - and kept in registers over the 32-channel blocks: between two rounds the stage is then a barrier and the DMA issue only
+  int Ureg[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) Ureg[it] = U[(it * NWK + wave) * 8 + (lane >> 3)];
+  const int n_u = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(lr)[0]);
   const int* __restrict__ rowp = reinterpret_cast<const int*>(lr + OFF_ROW) + sq * 64;
   const unsigned int* __restrict__ gmp = reinterpret_cast<const unsigned int*>(lr + OFF_GM) + sq * 4;
   const uint2* __restrict__ locp = reinterpret_cast<const uint2*>(lr + OFF_LOC) + sq * 16 + j;     // entry k at [k * 64]
@@ -177,6 +201,7 @@ __global__ __launch_bounds__(NWK * 64, 4) void spconv_up_kernel(SpconvArgs a, co
   // block (4-9 offsets) is as short as such a round trip, and with two workgroups per CU nothing else hides it.
   const int srows = (n_u + 8) & ~7;
   const int nb_max = min(XROWS / srows, nqb);
+  UP_STAMP(7);
   if ((int)threadIdx.x < 8 * nb_max)
     *reinterpret_cast<float4*>(xs + (((int)threadIdx.x >> 3) * srows + n_u) * 128 + (threadIdx.x & 7) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -208,11 +233,6 @@ __global__ __launch_bounds__(NWK * 64, 4) void spconv_up_kernel(SpconvArgs a, co
         W[t][p] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
       }
   };
-  // the tile's row numbers: loaded once, before the header is needed (the list has XROWS entries whatever n_unique says),
-  // kept in registers over the 32-channel blocks - between two blocks the stage is then a barrier and the DMA issue only
-  int Ureg[NIT];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) Ureg[it] = U[(it * NWK + wave) * 8 + (lane >> 3)];
   auto stage = [&](int qb0, int nb) {
     for (int b = 0; b < nb; ++b)
 #pragma unroll
@@ -259,12 +279,14 @@ __global__ __launch_bounds__(NWK * 64, 4) void spconv_up_kernel(SpconvArgs a, co
     const int nb = min(nb_max, nqb - qb0);
     if (qb0) __syncthreads();                                          // every wave is done with the previous round's rows
     stage(qb0, nb);
+    if (qb0 == 0) UP_STAMP(1);
     unsigned int rest = wmask;
     int kc = rest ? __builtin_ctz(rest) : 0, bc = 0;                   // the (offset, block of the round) being multiplied
     load_w(kc, qb0, WA);                                               // unconditional: a load inside a branch is waited for on the spot
     LA = locp[kc * 64];
     __builtin_amdgcn_s_waitcnt(0x0070);
     __syncthreads();
+    if (qb0 == 0) UP_STAMP(2);
     // the walk over (block, occupied offset): weights and rulebook entries of the next step are in flight while this one multiplies
     auto next = [&](int& k, int& bb) {
       rest &= rest - 1;
@@ -288,6 +310,8 @@ __global__ __launch_bounds__(NWK * 64, 4) void spconv_up_kernel(SpconvArgs a, co
     }
   }
 
+  UP_STAMP(3);
+  asm volatile("" :: "v"(warm));
   // ---- epilogue: lane (g, j) holds channels 8 g .. 8 g + 7 (tuples t = 0, 1) of tile slot 64 sq + 16 c + j
   const float os = a.out_scale ? *a.out_scale : 1.0f;
   const int ch = ct0 + 8 * g;
@@ -330,6 +354,7 @@ __global__ __launch_bounds__(NWK * 64, 4) void spconv_up_kernel(SpconvArgs a, co
       if (orow[c] >= 0) split16_track(mx, v[c][t]);
     }
   }
+  UP_STAMP(4);
 #pragma unroll
   for (int c = 0; c < NG; ++c) {
     const int o = orow[c];
@@ -348,9 +373,29 @@ __global__ __launch_bounds__(NWK * 64, 4) void spconv_up_kernel(SpconvArgs a, co
     }
   }
   if (a.out_split) split16_report(a.range, mx);
+#ifdef EYOC_UP_TRACE
+  UP_STAMP(5);
+  if (a.cin == 128 && a.cout == 64 && threadIdx.x == 0 && blockIdx.x < UP_TRACE_WGS) {
+    unsigned int hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_up_trace[blockIdx.x * UP_TRACE_N + 6] = ((unsigned long long)(xcc & 0xF) << 32) | hw;
+  }
+#endif
 }
 
 }  // namespace
+
+#ifdef EYOC_UP_TRACE
+extern "C" int eyoc_debug_up_trace(unsigned long long* host, size_t n) {
+  if (n > (size_t)UP_TRACE_WGS * UP_TRACE_N) n = (size_t)UP_TRACE_WGS * UP_TRACE_N;
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_up_trace), n * 8) != hipSuccess) return -1;
+  unsigned long long* z = (unsigned long long*)calloc(n, 8);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_up_trace), z, n * 8);
+  free(z);
+  return 0;
+}
+#endif
 
 namespace eyoc {
 
