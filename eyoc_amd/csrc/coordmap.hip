@@ -203,30 +203,41 @@ __global__ __launch_bounds__(256) void k_count_levels(const int32_t* __restrict_
 
 // compaction + octree links in one pass: first rows write their coarse coordinate, every row learns its parent (the
 // number of first rows up to and including it, minus one) and enters itself as that parent's child
+// One lane per row, 64 consecutive rows per wave step (coalesced coordinate reads and parent writes; the first version gave
+// every thread 8 consecutive rows - every load instruction of a wave then touched 64 different lines): the position of a row's
+// coarse voxel is the block's scanned base + the flags before it, counted with ballots.
 __global__ __launch_bounds__(SCAN_BLOCK) void k_compact_sorted(const int* __restrict__ flag, const int* __restrict__ partial,
                                                                const int32_t* __restrict__ coords, int n, int ts2, int sh,
                                                                int32_t* __restrict__ coords_out, int32_t* __restrict__ parent,
                                                                int32_t* __restrict__ children) {
-  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-  int f[SCAN_ITEMS];
-  int s = 0;
+  constexpr int NWV = SCAN_BLOCK / 64, PER_WAVE = SCAN_TILE / NWV, STEPS = PER_WAVE / 64;
+  __shared__ int wave_tot[NWV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int base = blockIdx.x * SCAN_TILE + wave * PER_WAVE;
+  int f[STEPS];
+  int tot = 0;
 #pragma unroll
-  for (int j = 0; j < SCAN_ITEMS; ++j) {
-    f[j] = (base + j < n) ? flag[base + j] : 0;
-    s += f[j];
+  for (int j = 0; j < STEPS; ++j) {
+    const int i = base + j * 64 + lane;
+    f[j] = i < n ? flag[i] : 0;
+    tot += __popcll(__ballot(f[j] != 0));
   }
-  int tot;
-  int pos = partial[blockIdx.x] + block_exclusive_scan(s, &tot);
+  if (lane == 0) wave_tot[wave] = tot;
+  __syncthreads();
+  int pos0 = partial[blockIdx.x];
+  for (int w = 0; w < wave; ++w) pos0 += wave_tot[w];
 #pragma unroll
-  for (int j = 0; j < SCAN_ITEMS; ++j) {
-    const int i = base + j;
-    if (i >= n) break;
+  for (int j = 0; j < STEPS; ++j) {
+    const int i = base + j * 64 + lane;
+    const unsigned long long m = __ballot(f[j] != 0);
+    const int pos = pos0 + __popcll(m & ((2ull << lane) - 1ull));      // flags up to and including this row
+    pos0 += __popcll(m);
+    if (i >= n) continue;
     const int4 c = reinterpret_cast<const int4*>(coords)[i];
     if (f[j]) {
       int b, x, y, z;
       coarse_coord(coords + 4 * (size_t)i, ts2, b, x, y, z);
-      reinterpret_cast<int4*>(coords_out)[pos] = make_int4(b, x, y, z);
-      ++pos;
+      reinterpret_cast<int4*>(coords_out)[pos - 1] = make_int4(b, x, y, z);
     }
     const int cs = ((c.y >> sh) & 1) | (((c.z >> sh) & 1) << 1) | (((c.w >> sh) & 1) << 2);
     parent[i] = pos - 1;
