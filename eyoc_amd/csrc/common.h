@@ -76,6 +76,10 @@ struct eyoc_ctx {
   int ensure_pool();
   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remembered per ctx, not per process
   bool ransac_attr_set = false, sc2_attr_set = false;
+  // Z-order sort of eyoc_maps_build: how many bits the Morton key needs is SPECULATED from the previous build of this ctx
+  // (coordinates within +-2^zorder_kbits, batch index below 2^zorder_bbits); a build whose rows do not fit redoes its sort with
+  // the full 18 + 10 bits.  The permutation is the same either way (the bias is order-preserving); only the number of radix passes differs.
+  int zorder_kbits = 17, zorder_bbits = 10;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -163,7 +167,7 @@ namespace eyoc {
 int maps_build_table0(eyoc_maps* maps, hipStream_t st);
 size_t sort_rows64_tmp_bytes(int n);
 int sort_rows_by_key64(void* tmp, size_t tmp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out, const int* vals_in,
-                       int* vals_out, int n, hipStream_t st);
+                       int* vals_out, int n, int bits, hipStream_t st);
 size_t sort_rows_tmp_bytes(int n, int bits);
 int sort_rows_by_key(void* tmp, size_t tmp_bytes, const unsigned int* keys_in, unsigned int* keys_out, const int* vals_in,
                      int* vals_out, int n, int bits, hipStream_t st);

@@ -170,17 +170,25 @@ __global__ void k_flag_sorted(const int32_t* __restrict__ coords, int n, int ts2
 
 // Z-ordered rows: the row counts of ALL coarser levels from the sorted level-0 rows in one pass (a level's voxels are runs of
 // adjacent rows at every level), so that eyoc_maps_build reads them with ONE synchronisation instead of one per level
-__global__ __launch_bounds__(256) void k_count_levels(const int32_t* __restrict__ coords, int n, int* __restrict__ counts /* [EYOC_MAX_LEVELS + 2] */) {
+// counts[0]: rows that do not fit the speculated key width (+-2^kbits, batch < 2^bbits); counts[EYOC_MAX_LEVELS + 2 / + 3]: the
+// largest |coordinate| / batch index (the next build's speculation)
+__global__ __launch_bounds__(256) void k_count_levels(const int32_t* __restrict__ coords, int n, int kbits, int bbits,
+                                                      int* __restrict__ counts /* [EYOC_MAX_LEVELS + 4] */) {
   // grid-stride: a few thousand atomics on the counters in all (one per level and workgroup), not one per wave of 64 rows -
   // 180 k atomics on three words cost 2 ms on the 3.8 M-row batch
   __shared__ int part[EYOC_MAX_LEVELS + 2];
   if (threadIdx.x < EYOC_MAX_LEVELS + 2) part[threadIdx.x] = 0;
   __syncthreads();
   int cnt[EYOC_MAX_LEVELS + 2] = {};
+  int amax = 0, bmax = 0;
   constexpr int LIM = COORD_BIAS - 16;
+  const int klim = 1 << kbits;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int4 c = reinterpret_cast<const int4*>(coords)[i];
     const int4 q = i > 0 ? reinterpret_cast<const int4*>(coords)[i - 1] : c;
+    if (c.x < 0 || (c.x >> bbits) != 0 || c.y < -klim || c.y >= klim || c.z < -klim || c.z >= klim || c.w < -klim || c.w >= klim) ++cnt[0];
+    amax = max(amax, max(max(c.y < 0 ? ~c.y : c.y, c.z < 0 ? ~c.z : c.z), c.w < 0 ? ~c.w : c.w));   // v fits iff -2^k <= v < 2^k iff (v < 0 ? ~v : v) < 2^k
+    bmax = max(bmax, c.x);
     // validation here too: the build must not run its table kernels on keys outside the supported range
     if (c.x < 0 || c.x >= 1024 || c.y < -LIM || c.y >= LIM || c.z < -LIM || c.z >= LIM || c.w < -LIM || c.w >= LIM) ++cnt[EYOC_MAX_LEVELS];
     if (i > 0 && c.x == q.x && c.y == q.y && c.z == q.z && c.w == q.w) ++cnt[EYOC_MAX_LEVELS + 1];
@@ -191,14 +199,21 @@ __global__ __launch_bounds__(256) void k_count_levels(const int32_t* __restrict_
     }
   }
 #pragma unroll
-  for (int l = 1; l < EYOC_MAX_LEVELS + 2; ++l) {
+  for (int l = 0; l < EYOC_MAX_LEVELS + 2; ++l) {
     int v = cnt[l];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(&part[l], v);
   }
+  __shared__ int pmax[2];
+  if (threadIdx.x < 2) pmax[threadIdx.x] = 0;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { amax = max(amax, __shfl_xor(amax, d, 64)); bmax = max(bmax, __shfl_xor(bmax, d, 64)); }
   __syncthreads();
-  if (threadIdx.x >= 1 && threadIdx.x < EYOC_MAX_LEVELS + 2 && part[threadIdx.x]) atomicAdd(counts + threadIdx.x, part[threadIdx.x]);
+  if ((threadIdx.x & 63) == 0) { atomicMax(&pmax[0], amax); atomicMax(&pmax[1], bmax); }
+  __syncthreads();
+  if (threadIdx.x < EYOC_MAX_LEVELS + 2 && part[threadIdx.x]) atomicAdd(counts + threadIdx.x, part[threadIdx.x]);
+  if (threadIdx.x < 2 && pmax[threadIdx.x] > 0) atomicMax(counts + EYOC_MAX_LEVELS + 2 + threadIdx.x, pmax[threadIdx.x]);
 }
 
 // compaction + octree links in one pass: first rows write their coarse coordinate, every row learns its parent (the
@@ -307,12 +322,16 @@ __device__ inline unsigned long long spread18(unsigned int v) {
   x = (x | (x << 2)) & 0x1249249249249249ull;
   return x;
 }
-__global__ void k_morton_key(const int32_t* __restrict__ coords, int n, unsigned long long* __restrict__ key, int* __restrict__ row) {
+// (coordinates biased by 2^kbits, kbits + 1 bits per axis, the batch index above them: 3 (kbits + 1) + bbits significant bits.  A row
+// outside +-2^kbits gets a meaningless key - k_count_levels reports it and the build sorts again with kbits = 17.)
+__global__ void k_morton_key(const int32_t* __restrict__ coords, int n, int kbits, unsigned long long* __restrict__ key, int* __restrict__ row) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int4 c = reinterpret_cast<const int4*>(coords)[i];
-  key[i] = ((unsigned long long)(unsigned)c.x << 54) | spread18((unsigned)(c.y + COORD_BIAS)) | (spread18((unsigned)(c.z + COORD_BIAS)) << 1) |
-           (spread18((unsigned)(c.w + COORD_BIAS)) << 2);
+  const int bias = 1 << kbits;
+  const unsigned int m = (2u << kbits) - 1u;
+  key[i] = ((unsigned long long)(unsigned)c.x << (3 * (kbits + 1))) | spread18((unsigned)(c.y + bias) & m) | (spread18((unsigned)(c.z + bias) & m) << 1) |
+           (spread18((unsigned)(c.w + bias) & m) << 2);
   row[i] = i;
 }
 __global__ void k_gather_coords(const int32_t* __restrict__ coords, const int* __restrict__ perm, int n, int32_t* __restrict__ out) {
@@ -544,13 +563,30 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
     m->row_perm = cv.take<int32_t>(n);
     const size_t zb = sort_rows64_tmp_bytes(n);
     void* ztmp = cv.take<char>(zb);
-    hipLaunchKernelGGL(k_morton_key, dim3(cdiv(n, 256)), dim3(256), 0, st, coords_dev, n, zk_in, zr_in);
-    if (int rc = sort_rows_by_key64(ztmp, zb, zk_in, zk_out, zr_in, m->row_perm, n, st)) { delete m; return rc; }
-    hipLaunchKernelGGL(k_gather_coords, dim3(cdiv(n, 256)), dim3(256), 0, st, coords_dev, m->row_perm, n, m->coords[0]);
-    // every level's row count - and the validation - now, with one read-back
-    hipLaunchKernelGGL(k_count_levels, dim3(cdiv(n, 256) < 1024 ? cdiv(n, 256) : 1024), dim3(256), 0, st, m->coords[0], n, counters + 16);
-    FAIL_HIP(hipMemcpyAsync(host + 16, counters + 16, (EYOC_MAX_LEVELS + 2) * sizeof(int), hipMemcpyDeviceToHost, st));
-    FAIL_HIP(hipStreamSynchronize(st));
+    // The key width is speculated from the ctx's previous build (KITTI-shaped clouds: 10 + 10 + 10 + 7 bits = five 8-bit radix
+    // passes instead of eight); a batch that does not fit sorts once more with the full width.
+    int kbits = ctx->zorder_kbits, bbits = ctx->zorder_bbits;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      if (attempt) FAIL_HIP(hipMemsetAsync(counters + 16, 0, (EYOC_MAX_LEVELS + 4) * sizeof(int), st));
+      hipLaunchKernelGGL(k_morton_key, dim3(cdiv(n, 256)), dim3(256), 0, st, coords_dev, n, kbits, zk_in, zr_in);
+      if (int rc = sort_rows_by_key64(ztmp, zb, zk_in, zk_out, zr_in, m->row_perm, n, 3 * (kbits + 1) + bbits, st)) { delete m; return rc; }
+      hipLaunchKernelGGL(k_gather_coords, dim3(cdiv(n, 256)), dim3(256), 0, st, coords_dev, m->row_perm, n, m->coords[0]);
+      // every level's row count - and the validation - now, with one read-back
+      hipLaunchKernelGGL(k_count_levels, dim3(cdiv(n, 256) < 1024 ? cdiv(n, 256) : 1024), dim3(256), 0, st, m->coords[0], n, kbits, bbits,
+                         counters + 16);
+      FAIL_HIP(hipMemcpyAsync(host + 16, counters + 16, (EYOC_MAX_LEVELS + 4) * sizeof(int), hipMemcpyDeviceToHost, st));
+      FAIL_HIP(hipStreamSynchronize(st));
+      if (host[16] == 0) break;                                         // every row fitted the speculated width
+      kbits = 17; bbits = 10;
+    }
+    {
+      // next build: one bit of head room over what this one needed
+      int kb = 1, bb = 1;
+      while (kb < 17 && (1 << kb) <= host[16 + EYOC_MAX_LEVELS + 2]) ++kb;
+      while (bb < 10 && (1 << bb) <= host[16 + EYOC_MAX_LEVELS + 3]) ++bb;
+      ctx->zorder_kbits = kb + 1 < 17 ? kb + 1 : 17;
+      ctx->zorder_bbits = bb + 1 < 10 ? bb + 1 : 10;
+    }
     if (host[16 + EYOC_MAX_LEVELS] != 0) {
       set_error("eyoc_maps_build: %d coordinate rows outside the supported key range (|c| < 2^17 - 16, 0 <= batch < 1024)",
                 host[16 + EYOC_MAX_LEVELS]);

@@ -33,9 +33,9 @@ size_t sort_rows64_tmp_bytes(int n) {
 
 // the same with 64-bit keys (Z-order of the coordinates)
 int sort_rows_by_key64(void* tmp, size_t tmp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out, const int* vals_in,
-                       int* vals_out, int n, hipStream_t st) {
-  size_t need = tmp_bytes;
-  EYOC_CHECK_HIP(rocprim::radix_sort_pairs(tmp, need, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, 64u, st));
+                       int* vals_out, int n, int bits, hipStream_t st) {
+  size_t need = tmp_bytes;                                             // sized for 64 bits: enough for any narrower sort
+  EYOC_CHECK_HIP(rocprim::radix_sort_pairs(tmp, need, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, (unsigned)bits, st));
   return EYOC_OK;
 }
 
