@@ -134,6 +134,23 @@ def test_maps_in_z_order_equal_the_oracle_maps_of_the_z_ordered_cloud(zorder_row
             check_up_order(cm.up_order(l, internal=True).cpu().numpy(), maps["up"][l], window_shift=12)
 
 
+def test_z_order_sort_with_a_speculated_key_width_falls_back_to_the_full_width(zorder_rows):
+    """The Morton key is as wide as the previous build of the context needed (fewer radix passes); a batch that does not fit -
+    larger coordinates, a larger batch index - is sorted again with the full width: same permutation as the stable Morton
+    order either way, in whatever order the builds come."""
+    import eyoc_amd
+    from test_gpu_split16 import morton_order
+    rng = np.random.default_rng(11)
+    def cloud(extent, batch):
+        c = np.unique(rng.integers(-extent, extent, size=(3000, 3)), axis=0).astype(np.int32)
+        rng.shuffle(c)
+        return np.concatenate([np.full((len(c), 1), batch, np.int32), c], 1)
+    for extent, batch in ((20, 0), (4000, 0), (20, 0), (300, 700), (60000, 3), (5, 1)):
+        coords = cloud(extent, batch)
+        cm = eyoc_amd.CoordinateManager(torch.from_numpy(coords).cuda())
+        np.testing.assert_array_equal(cm.row_order().cpu().numpy(), morton_order(coords), err_msg=f"extent {extent}, batch {batch}")
+
+
 def test_maps_keep_the_callers_order_for_small_clouds():
     import eyoc_amd
     cm = eyoc_amd.CoordinateManager(torch.from_numpy(random_cloud(6, 500)).cuda())
