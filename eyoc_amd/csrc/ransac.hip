@@ -34,7 +34,7 @@ __device__ inline void sample_pair(unsigned long long base, unsigned long long c
 }
 
 // Correspondence records of all pairs of a batch: 6 floats (source point, matched target point).
-constexpr int CHUNK = 8;   // pairs per launch
+constexpr int CHUNK = 64;  // pairs per launch (the per-pair kernels - bucket, rmse, select - are one workgroup per pair: 8 pairs per launch left them at 8 workgroups on 256 CUs, eight times per 64-pair batch)
 struct PairArgs {          // a chunk of pairs; segment bounds travel as kernel arguments (no H2D copy)
   int s0[CHUNK], n[CHUNK], t0[CHUNK];   // first source row, correspondences, first target row of each pair
   int pair0;               // index of the chunk's first pair (seed offset, result slot)
@@ -553,10 +553,13 @@ extern "C" int eyoc_ransac_batched(eyoc_ctx* ctx, const float* src_dev, const fl
   const int total = seg_src_host[n_pairs];
   // survivor lists are sized for the worst case (every hypothesis survives): run the pairs in chunks so the
   // scratch stays bounded (12 bytes per hypothesis and pair of the chunk)
-  const int chunk = n_pairs < CHUNK ? n_pairs : CHUNK;
   // transforms are stored for the first cap_t survivors of a pair (96 B each; 1M = the survivors of an inlier ratio
   // of 0.7); the rest - only ever reached by degenerate inputs - are re-derived by k_count_overflow
   const int cap_t = H < (1 << 20) ? H : (1 << 20);
+  // chunk: as many pairs as 16 GB of scratch hold (144 MB per pair at 4 M hypotheses: all 64 of the bench's batch)
+  const size_t per_pair = (size_t)H * 12 + (size_t)cap_t * 96;
+  int chunk = n_pairs < CHUNK ? n_pairs : CHUNK;
+  while (chunk > 1 && (size_t)chunk * per_pair > ((size_t)16 << 30)) chunk >>= 1;
   const size_t off_cnt = 0, off_rec = align_up((size_t)chunk * CNT_STRIDE * 4), off_surv = align_up(off_rec + (size_t)total * 24);
   const size_t off_cnts = align_up(off_surv + (size_t)chunk * H * 4), off_rmse = align_up(off_cnts + (size_t)chunk * H * 4);
   const size_t off_xf = align_up(off_rmse + (size_t)chunk * H * 4);
