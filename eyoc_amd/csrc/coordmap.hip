@@ -618,7 +618,7 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
     const int32_t* src = m->coords[l - 1];
     const int ts2 = 1 << l;
     const int nb = cdiv(n_src, SCAN_TILE);
-    const bool sorted_level = zorder && l + 1 < EYOC_MAX_LEVELS;       // no table: adjacent rows (see k_flag_sorted)
+    const bool sorted_level = zorder;                                  // adjacent rows (see k_flag_sorted); only the coarsest level gets a table, below
     HashTable& t = m->table[l];
     if (sorted_level) {
       hipLaunchKernelGGL(k_flag_sorted, dim3(cdiv(n_src, 256)), dim3(256), 0, st, src, n_src, ts2, flag,
@@ -660,6 +660,17 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
     if (sorted_level) {
       hipLaunchKernelGGL(k_compact_sorted, dim3(nb), dim3(SCAN_BLOCK), 0, st, flag, partial, src, n_src, ts2, l - 1,
                          m->coords[l], m->parent[l - 1], m->children[l - 1]);
+      if (l + 1 == EYOC_MAX_LEVELS) {
+        // the coarsest level's table (k_neighbours probes it): its UNIQUE rows are inserted - one uncontended CAS per voxel
+        // instead of one per finer row, four neighbouring lanes fighting over every slot (118 -> ~20 us on the bench batch)
+        const unsigned int cap = table_capacity(n_src);
+        t.keys = cv.take<unsigned long long>(cap);
+        t.vals = cv.take<int>(cap);
+        t.mask = cap - 1;
+        FAIL_HIP(hipMemsetAsync(t.keys, 0xFF, (size_t)cap * 8, st));
+        FAIL_HIP(hipMemsetAsync(t.vals, 0x7F, (size_t)cap * 4, st));
+        hipLaunchKernelGGL(k_insert, dim3(cdiv(m->rows[l], 256)), dim3(256), 0, st, m->coords[l], m->rows[l], ts2, t, (int*)nullptr, counters);
+      }
       continue;
     }
     hipLaunchKernelGGL(k_compact, dim3(nb), dim3(SCAN_BLOCK), 0, st, flag, partial, slot, src, n_src, ts2,
