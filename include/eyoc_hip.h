@@ -411,7 +411,10 @@ int eyoc_ransac(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const
  * collapsed; SURVEY 8f "batched registration").  Pair b owns source rows / correspondences
  * [seg_src[b], seg_src[b+1]) and target rows starting at seg_tgt[b]; corr_tgt holds target indices LOCAL to the
  * pair's target segment; pair b samples with seed params->seed + b, so results[b] is bit-identical to
- * eyoc_ransac on that pair with that seed.  seg_* are HOST arrays of n_pairs + 1 ints. */
+ * eyoc_ransac on that pair with that seed.  seg_* are HOST arrays of n_pairs + 1 ints.
+ * Up to 64 pairs go through one set of launches; the ctx's grow-only scratch holds 12 bytes per hypothesis plus 96 bytes per
+ * stored survivor transform (at most 2^20) for every pair of such a chunk - 144 MB per pair at 4 000 000 hypotheses, chunks
+ * halved until they fit 16 GB. */
 int eyoc_ransac_batched(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int64_t* corr_tgt_dev,
                         const int32_t* seg_src_host, const int32_t* seg_tgt_host, int n_pairs,
                         const eyoc_ransac_params* params, eyoc_ransac_result* results_dev, void* stream);
