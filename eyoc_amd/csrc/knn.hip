@@ -311,6 +311,63 @@ __global__ void knn_row_norms(const float* __restrict__ A, int n, int C, float* 
   out[i] = n2;
 }
 
+// Second pass of the pre-filter for the plain SquareL2 query, lane = TARGET: the handful of rows the MFMA scores could not
+// decide are few (0.35 % on the bench) but every one needs all targets of its segment.  With lane = query (knn1_kernel) a wave
+// has 17 of its 64 lanes busy and walks its targets through dependent scalar loads (152 us, plus the 50 us transposition of
+// the targets that only this pass needed).  Here a workgroup keeps 256 targets in registers (one row per lane), stages the
+// listed queries in LDS (256 at a time) and evaluates the contract - d = a - b; acc = acc + d * d over the channels in order, no
+// contraction - for every (listed query, its target); the wave's smallest (distance bits, index) goes to the same 64-bit
+// atomicMin.  Same values, same tie rule (lowest index), NaN / inf candidates never enter.
+template <int C>
+__global__ __launch_bounds__(256) void knn1_list_kernel(const float* __restrict__ A, const float* __restrict__ B, SegArgs seg,
+                                                        unsigned long long* __restrict__ best, const int* __restrict__ only,
+                                                        const int* __restrict__ only_cnt) {
+#pragma clang fp contract(off)
+  constexpr int QB = 256;
+  __shared__ __attribute__((aligned(16))) float qs[QB][C];
+  __shared__ int qrow[QB];
+  const int s = blockIdx.z;
+  const int cnt = only_cnt[s];
+  const int a0 = seg.a[s], b0 = seg.b[s], nb = seg.b[s + 1] - b0;
+  if (cnt <= 0 || (int)blockIdx.x * 256 >= nb) return;                 // workgroup-uniform
+  const int lane = threadIdx.x & 63;
+  const int j = (int)blockIdx.x * 256 + (int)threadIdx.x;              // this lane's target
+  float b[C];
+  {
+    const float4* src = reinterpret_cast<const float4*>(B + (size_t)(b0 + (j < nb ? j : nb - 1)) * C);
+#pragma unroll
+    for (int i = 0; i < C / 4; ++i) { const float4 v = src[i]; b[4 * i] = v.x; b[4 * i + 1] = v.y; b[4 * i + 2] = v.z; b[4 * i + 3] = v.w; }
+  }
+  for (int q0 = 0; q0 < cnt; q0 += QB) {
+    const int nq = min(QB, cnt - q0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < nq * (C / 4); e += 256) {
+      const int qi = e / (C / 4), part = e % (C / 4);
+      const int row = only[a0 + q0 + qi];
+      if (part == 0) qrow[qi] = row;
+      reinterpret_cast<float4*>(qs[qi])[part] = reinterpret_cast<const float4*>(A + (size_t)(a0 + row) * C)[part];
+    }
+    __syncthreads();
+    for (int i = 0; i < nq; ++i) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        float d = qs[i][c] - b[c];
+        d = d * d;
+        acc = acc + d;
+      }
+      unsigned long long p = (j < nb && acc < __builtin_inff()) ? (((unsigned long long)__float_as_uint(acc) << 32) | (unsigned)j) : ~0ull;
+#pragma unroll
+      for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+        const unsigned int lo = __shfl_xor((unsigned int)p, dlt, 64), hi = __shfl_xor((unsigned int)(p >> 32), dlt, 64);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        p = o < p ? o : p;
+      }
+      if (lane == 0 && p != ~0ull) atomicMin(&best[a0 + qrow[i]], p);
+    }
+  }
+}
+
 template <int C, int MODE>
 __global__ __launch_bounds__(256) void knn_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Bm, SegArgs seg,
                                                        SegMfma sm, const float* __restrict__ anorm,
@@ -558,7 +615,10 @@ static int knn_run(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c,
     only = flags;
     only_cnt = fcnt;
   }
-  if (max_nb > 0) {
+  if (prefilter && dist_type == 0 && max_nb > 0) {
+    // the undecided rows, lane = target (no transposed copy of the targets needed)
+    hipLaunchKernelGGL(knn1_list_kernel<32>, dim3(eyoc::cdiv(max_nb, 256), 1, nseg), dim3(256), 0, st, A_dev, B_dev, seg, best, only, only_cnt);
+  } else if (max_nb > 0) {
     hipLaunchKernelGGL(knn_transpose_targets, dim3(eyoc::cdiv((long long)max_ld * (c / 4), 256), 1, nseg), dim3(256), 0, st, B_dev,
                        seg, c, Bt);
     switch (c) {
