@@ -392,24 +392,72 @@ __global__ void k_derive_fine(const int32_t* __restrict__ coords, int n, int sh,
     const int kc = (ox + 1) + 3 * (oy + 1) + 9 * (oz + 1);
     blk[a] = a == 0 ? p : s1c[(size_t)kc * nc + p];
   }
+  // The 27 neighbours of a fine voxel are a 3 x 3 x 3 window of the 4 x 4 x 4 cube of children of its 8 reachable coarse blocks;
+  // which window is decided by the voxel's parity (per axis: positions -1..1 or 0..2 of the cube).  The 8 child RECORDS are
+  // loaded whole (32 bytes each: 16 wide loads instead of 27 four-byte loads that each pull a 32-byte sector) and the window is
+  // cut out with per-axis selects; nothing is indexed by a run-time value.
+  int rec[8][8];
 #pragma unroll
-  for (int k = 0; k < 27; ++k) {   // unrolled: 27 independent child loads in flight (one per iteration waited alone before)
-    const int off[3] = {k % 3 - 1, (k / 3) % 3 - 1, k / 9 - 1};
-    int a = 0, cs = 0, a_up = 0;
-    bool up_ok = true;
+  for (int a = 0; a < 8; ++a) {
+    int4 lo = make_int4(-1, -1, -1, -1), hi = lo;
+    if (blk[a] >= 0) {
+      lo = reinterpret_cast<const int4*>(children)[2 * (size_t)blk[a]];
+      hi = reinterpret_cast<const int4*>(children)[2 * (size_t)blk[a] + 1];
+    }
+    rec[a][0] = lo.x; rec[a][1] = lo.y; rec[a][2] = lo.z; rec[a][3] = lo.w; rec[a][4] = hi.x; rec[a][5] = hi.y; rec[a][6] = hi.z; rec[a][7] = hi.w;
+  }
+  // cube position u per axis: 0 / 1 = own block, child bit 0 / 1; 2 / 3 = the neighbouring block, child bit 0 / 1.
+  // Window position k (offset k - 1) of an axis with parity bit p: p = 0 -> u = 3, 0, 1 (the block at -1 ends with its bit-1
+  // child); p = 1 -> u = 0, 1, 2 (the block at +1 starts with its bit-0 child).
+  int wx[4][4][3];                                                     // [uz][uy][kx]
 #pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-      const int t = b[ax] + off[ax];
-      a |= ((t < 0 || t > 1) ? 1 : 0) << ax;
-      cs |= (t & 1) << ax;
+  for (int uz = 0; uz < 4; ++uz)
+#pragma unroll
+    for (int uy = 0; uy < 4; ++uy) {
+      int in[4];
+#pragma unroll
+      for (int ux = 0; ux < 4; ++ux) in[ux] = rec[(ux >> 1) | ((uy >> 1) << 1) | ((uz >> 1) << 2)][(ux & 1) | ((uy & 1) << 1) | ((uz & 1) << 2)];
+      wx[uz][uy][0] = b[0] ? in[0] : in[3];
+      wx[uz][uy][1] = b[0] ? in[1] : in[0];
+      wx[uz][uy][2] = b[0] ? in[2] : in[1];
+    }
+  int wy[4][3][3];                                                     // [uz][ky][kx]
+#pragma unroll
+  for (int uz = 0; uz < 4; ++uz)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      wy[uz][0][kx] = b[1] ? wx[uz][0][kx] : wx[uz][3][kx];
+      wy[uz][1][kx] = b[1] ? wx[uz][1][kx] : wx[uz][0][kx];
+      wy[uz][2][kx] = b[1] ? wx[uz][2][kx] : wx[uz][1][kx];
+    }
+  // blocks of the transposed map: per axis the own block (offset 0 on an even position, +1 on an odd one) or, for offset -1
+  // on an odd position, the neighbouring one: bl[m] = blk[m & parity class]
+  int bl[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    int sx[2][2];
+#pragma unroll
+    for (int az = 0; az < 2; ++az)
+#pragma unroll
+      for (int ay = 0; ay < 2; ++ay) sx[az][ay] = ((m & 1) && b[0]) ? blk[1 | (ay << 1) | (az << 2)] : blk[(ay << 1) | (az << 2)];
+    const int sy0 = ((m & 2) && b[1]) ? sx[0][1] : sx[0][0], sy1 = ((m & 2) && b[1]) ? sx[1][1] : sx[1][0];
+    bl[m] = ((m & 4) && b[2]) ? sy1 : sy0;
+  }
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const int kx = k % 3, ky = (k / 3) % 3, kz = k / 9;
+    const int v = kz == 0 ? (b[2] ? wy[0][ky][kx] : wy[3][ky][kx]) : kz == 1 ? (b[2] ? wy[1][ky][kx] : wy[0][ky][kx]) : (b[2] ? wy[2][ky][kx] : wy[1][ky][kx]);
+    s1[(size_t)k * n + o] = v;
+    if (up) {
+      const int off[3] = {kx - 1, ky - 1, kz - 1};
       // transposed map: c_u - off*ts must be a coarse coordinate: even position needs off == 0,
       // odd position needs off == +1 (the parent) or off == -1 (the next block)
-      up_ok = up_ok && (b[ax] ? off[ax] != 0 : off[ax] == 0);
-      a_up |= ((b[ax] && off[ax] < 0) ? 1 : 0) << ax;
+      bool up_ok = true;
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) up_ok = up_ok && (b[ax] ? off[ax] != 0 : off[ax] == 0);
+      const int m = (off[0] < 0 ? 1 : 0) | (off[1] < 0 ? 2 : 0) | (off[2] < 0 ? 4 : 0);
+      up[(size_t)k * n + o] = up_ok ? bl[m] : -1;
     }
-    const int B = blk[a];
-    s1[(size_t)k * n + o] = B >= 0 ? children[(size_t)B * 8 + cs] : -1;
-    if (up) up[(size_t)k * n + o] = up_ok ? blk[a_up] : -1;
   }
   if (up_key) {
     // pattern of the transposed map: parity class (which axes sit on an odd position) and which of the coarse
@@ -436,6 +484,18 @@ __global__ void k_derive_down(int nc, const int32_t* __restrict__ children, cons
     const int kc = (1 - (a & 1)) + 3 * (1 - ((a >> 1) & 1)) + 9 * (1 - ((a >> 2) & 1));
     blk[a] = a == 0 ? v : s1c[(size_t)kc * nc + v];
   }
+  // the 8 child records whole (32 bytes each) instead of 27 four-byte loads out of them; block and child slot of an offset are
+  // compile-time constants here
+  int rec[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    int4 lo = make_int4(-1, -1, -1, -1), hi = lo;
+    if (blk[a] >= 0) {
+      lo = reinterpret_cast<const int4*>(children)[2 * (size_t)blk[a]];
+      hi = reinterpret_cast<const int4*>(children)[2 * (size_t)blk[a] + 1];
+    }
+    rec[a][0] = lo.x; rec[a][1] = lo.y; rec[a][2] = lo.z; rec[a][3] = lo.w; rec[a][4] = hi.x; rec[a][5] = hi.y; rec[a][6] = hi.z; rec[a][7] = hi.w;
+  }
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
     const int off[3] = {k % 3 - 1, (k / 3) % 3 - 1, k / 9 - 1};
@@ -445,8 +505,7 @@ __global__ void k_derive_down(int nc, const int32_t* __restrict__ children, cons
       a |= (off[ax] < 0 ? 1 : 0) << ax;
       cs |= (off[ax] != 0 ? 1 : 0) << ax;
     }
-    const int B = blk[a];
-    down[(size_t)k * nc + v] = B >= 0 ? children[(size_t)B * 8 + cs] : -1;
+    down[(size_t)k * nc + v] = rec[a][cs];
   }
 }
 
