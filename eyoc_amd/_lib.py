@@ -126,6 +126,12 @@ PROTOTYPES = {
     "eyoc_kabsch_batched": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "eyoc_irls_quad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "eyoc_ransac": (_i, [_vp, _vp, _vp, _vp, _i, C.POINTER(RansacParams), _vp, _vp]),
+    "eyoc_maps_select_orders": (_i, [_i, _i]),
+    "eyoc_ransac_select_pruning": (_i, [_i]),
+    "eyoc_ransac_transform_store": (_i, [_i]),
+    "eyoc_ransac_workspace_bytes": (_sz, [_i, _i, _i, _sz]),
+    "eyoc_ransac_batched_ws": (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i,
+                                    C.POINTER(RansacParams), _vp, _vp, _sz, _vp]),
     "eyoc_ransac_batched": (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i,
                                  C.POINTER(RansacParams), _vp, _vp]),
     "eyoc_sc2pcr_workspace_bytes": (_sz, [_i, C.POINTER(Sc2pcrParams)]),
@@ -137,8 +143,15 @@ PROTOTYPES = {
 }
 
 
+ERR_INVALID, ERR_HIP, ERR_WORKSPACE, ERR_DUPLICATE, ERR_RANGE = -1, -2, -3, -4, -5     # eyoc_status
+
+
 class EyocError(RuntimeError):
-    pass
+    """``code``: the ``eyoc_status`` the library returned (``None`` for errors raised on the Python side)."""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
 
 
 _lib = None
@@ -168,7 +181,7 @@ def load():
 def check(rc: int, what: str = ""):
     if rc != 0:
         msg = load().eyoc_last_error().decode("utf-8", "replace")
-        raise EyocError(f"{what or 'libeyoc_hip'} failed ({rc}): {msg}")
+        raise EyocError(f"{what or 'libeyoc_hip'} failed ({rc}): {msg}", rc)
 
 
 def ctx(device_index: int | None = None):

@@ -76,6 +76,7 @@ struct eyoc_ctx {
   int ensure_pool();
   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remembered per ctx, not per process
   bool ransac_attr_set = false, sc2_attr_set = false;
+  bool up_attr_set[2] = {false, false};   // spconv_up_kernel<64> / <32>
   // Z-order sort of eyoc_maps_build: how many bits the Morton key needs is SPECULATED from the previous build of this ctx
   // (coordinates within +-2^zorder_kbits, batch index below 2^zorder_bbits); a build whose rows do not fit redoes its sort with
   // the full 18 + 10 bits.  The permutation is the same either way (the bias is order-preserving); only the number of radix passes differs.

@@ -539,7 +539,8 @@ constexpr int UP_KEY_BITS = KEY_PATTERN_BITS + KEY_WINDOW_BITS;
 static int ORDER_MIN_ROWS = 65536;
 // Z-ordered levels: window of the tiling orders, log2 rows.  Measured on the 64-pair bench: 2^17-2^18 rows (2^12, 2^14
 // lose - too many short pattern runs; no windows: +23 % on the 1 -> 0 transposed convolution)
-static int ORDER_WINDOW_SHIFT = getenv("EYOC_ORDER_WINDOW_SHIFT") ? atoi(getenv("EYOC_ORDER_WINDOW_SHIFT")) : 18;
+static int ORDER_WINDOW_SHIFT = 18;      // eyoc_maps_order_window_shift
+static int S1_ORDER = 1, DOWN_ORDER = 0;   // eyoc_maps_select_orders: tiling orders of the stride-1 / strided tables
 static int INTERNAL_ORDER = -1;          // eyoc_maps_internal_order: -1 automatic (Z-order from 8192 rows), 0 caller's order, 1 Z-order
 // Z-order (and with it the staged split16 kernels, model.hip) from 8192 rows: measured faster than the fp32 kernels on
 // the caller's row order at every size tried - maps + forward of a 15 k-row half cloud 2.30 -> 1.78 ms, one 31 k-row
@@ -764,15 +765,15 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
   // its segment number in the high key bits, and ONE stable radix sort orders all segments at once (seven separate
   // rocPRIM sorts cost 38 small launches, 0.7 ms per 64-cloud batch).  The orders only serve the wave-private
   // convolution kernel, which takes over above ~4000 row tiles: small levels (single-pair latency path) skip them.
-  static const bool s1_order = !(getenv("EYOC_S1_ORDER") && atoi(getenv("EYOC_S1_ORDER")) == 0);
+  const bool s1_order = S1_ORDER != 0;
   int seg_up[EYOC_MAX_LEVELS], seg_s1[EYOC_MAX_LEVELS], seg_dn[EYOC_MAX_LEVELS], seg_base[3 * EYOC_MAX_LEVELS], n_seg = 0;
   size_t total = 0;
   for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
     seg_up[l] = seg_s1[l] = seg_dn[l] = -1;
     // Z-ordered maps tile the strided convolutions in natural order: a tile's 64 coarse rows read their (adjacent)
-    // children, which beats the pattern order's fuller chunks (2.38 -> 2.25 ms for the three layers; EYOC_DOWN_ORDER=1
-    // restores the sort)
-    static const bool dn_order = getenv("EYOC_DOWN_ORDER") && atoi(getenv("EYOC_DOWN_ORDER")) == 1;
+    // children, which beats the pattern order's fuller chunks (2.38 -> 2.25 ms for the three layers;
+    // eyoc_maps_select_orders(-1, 1) restores the sort)
+    const bool dn_order = DOWN_ORDER == 1;
     if (l + 1 < EYOC_MAX_LEVELS && m->rows[l + 1] >= ORDER_MIN_ROWS && (dn_order || !zorder)) {   // outputs of the strided conv l -> l+1
       seg_dn[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l + 1];
     }
@@ -989,6 +990,13 @@ int eyoc_maps_internal_order(int mode) {
 }
 
 const int32_t* eyoc_maps_row_order(const eyoc_maps* maps) { return maps ? maps->row_perm : nullptr; }
+
+int eyoc_maps_select_orders(int s1, int down) {
+  const int prev = S1_ORDER | DOWN_ORDER << 1;
+  if (s1 == 0 || s1 == 1) S1_ORDER = s1;
+  if (down == 0 || down == 1) DOWN_ORDER = down;
+  return prev;
+}
 
 int eyoc_maps_order_window_shift(int shift) {
   const int prev = ORDER_WINDOW_SHIFT;

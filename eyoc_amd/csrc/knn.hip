@@ -536,7 +536,7 @@ void launch_knn(const float* A, const float* Bt, const SegArgs& seg, int nseg, i
 
 }  // namespace
 
-static int g_knn_prefilter = getenv("EYOC_KNN_PREFILTER") ? atoi(getenv("EYOC_KNN_PREFILTER")) : 1;
+static int g_knn_prefilter = 1;
 extern "C" int eyoc_knn_prefilter(int mode) {
   const int prev = g_knn_prefilter;
   if (mode >= 0 && mode <= 2) g_knn_prefilter = mode;

@@ -51,7 +51,7 @@ struct eyoc_model {
   std::vector<hipEvent_t> events;     // two sets of layers + 1 events (eyoc_model_timing_slot)
   int slot = 0;
   int events_valid[2] = {0, 0};
-  unsigned int* range = nullptr;      // device: {overflow flag, max |activation| bits (probe), probe switch, pad} - split16_guard in spconv.h
+  unsigned int* range = nullptr;      // device: {overflow flag of the forward in flight, max |activation| bits (probe), probe switch, sticky overflow flag} - split16_guard in spconv.h
   int probe = 0;
 };
 
@@ -114,10 +114,11 @@ void build_plan(const eyoc_model_desc& d, std::vector<LayerPlan>& L, BufPlan* bu
   }
   // second half of the blob: the SPLIT16 packing of every sparse-conv layer (spconv_wave.hip, MATH = 1)
   for (auto& p : L) {
-    if (p.map == M_CONV1) continue;
-    p.w16_off = off;
-    off += pad64((size_t)p.K * p.cin * p.cout);
-    p.s_off = off;
+    if (p.map != M_CONV1) {
+      p.w16_off = off;
+      off += pad64((size_t)p.K * p.cin * p.cout);
+    }
+    p.s_off = off;      // sparse-conv layers: out_scale; the first convolution: {2^sh, 2^-sh} of its MFMA kernels' weight halves
     off += 64;
   }
 }
@@ -126,7 +127,7 @@ size_t plan_blob_floats(const std::vector<LayerPlan>& L) {
   size_t end = 0;
   for (auto& p : L) {
     end = std::max(end, p.b_off + pad64(p.cout));
-    if (p.map != M_CONV1) end = std::max(end, p.s_off + 64);
+    end = std::max(end, p.s_off + 64);
   }
   return end;
 }
@@ -198,7 +199,16 @@ int eyoc_model_pack_host(const eyoc_model_desc* desc, const eyoc_layer_params* l
       for (int c = 0; c < p.cout; ++c) shift[c] += cv->bias[c];
     float* w = blob_host + p.w_off;
     if (p.map == M_CONV1) {  // plain [K][cin][cout] with the scale folded in
-      for (size_t i = 0; i < (size_t)p.K * p.cin * p.cout; ++i) w[i] = cv->kernel[i] * scale[i % p.cout];
+      float wmax = 0.0f;
+      for (size_t i = 0; i < (size_t)p.K * p.cin * p.cout; ++i) {
+        w[i] = cv->kernel[i] * scale[i % p.cout];
+        if (std::isfinite(w[i])) wmax = std::max(wmax, std::fabs(w[i]));
+      }
+      int e = 1;                                        // wmax = f 2^e, f in [0.5, 1): wmax 2^(9 - e) lies in [256, 512)
+      if (wmax > 0.0f) (void)std::frexp(wmax, &e);
+      const int sh = std::min(24, std::max(-6, 9 - e));   // same clamp as eyoc_spconv_pack_weights_split16
+      blob_host[p.s_off] = std::ldexp(1.0f, sh);
+      blob_host[p.s_off + 1] = std::ldexp(1.0f, -sh);
     } else {
       rc = eyoc_spconv_pack_weights(cv->kernel, scale.data(), p.K, p.cin, p.cout, w);
       if (!rc) rc = eyoc_spconv_pack_weights_split16(cv->kernel, scale.data(), p.K, p.cin, p.cout, blob_host + p.w16_off,
@@ -282,10 +292,10 @@ int eyoc_model_range_check(eyoc_model* m, void* stream, float* max_abs) {
   float mx;
   memcpy(&mx, &words[1], 4);
   if (max_abs) *max_abs = m->probe ? mx : -1.0f;
-  if (words[0]) {
-    EYOC_CHECK_HIP(hipMemsetAsync(m->range, 0, 4, st));                // reported once; the next forward starts clean
-    set_error("split16 arithmetic overflowed: an activation reached %g (fp16 hi halves end at 65504) - the features of that "
-              "forward are NaN; run the model with spconv math \"fp32\"", (double)SPLIT16_LIMIT);
+  if (words[3]) {
+    EYOC_CHECK_HIP(hipMemsetAsync(m->range + 3, 0, 4, st));            // reported once; word 0 is per forward (cleared when one starts)
+    set_error("split16 arithmetic overflowed: an activation reached %g (fp16 hi halves end at 65504) in a forward since the last "
+              "check - the features of every such forward are NaN; run the model with spconv math \"fp32\"", (double)SPLIT16_LIMIT);
     return EYOC_ERR_RANGE;
   }
   return EYOC_OK;
@@ -351,14 +361,14 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
   // arithmetic of the sparse convolutions: SPLIT16 needs the wave-private kernel for EVERY layer (only it reads and
   // writes the format), which round 1 measured to pay off once the finest level alone fills the chip (>= 4096 wave tiles ~ 4 KITTI
   // pairs); small batches stay on fp32, where the launcher picks the workgroup-tiled kernel per layer
-  static const int env_math = getenv("EYOC_SPCONV_MATH") ? atoi(getenv("EYOC_SPCONV_MATH")) : -1;
-  const int want = m->math >= 0 ? m->math : env_math;
+  const int want = m->math;
   const bool split_ok = spconv_forced_kernel() != 0 && !(m->desc.normalize_feature && m->desc.out_channels > 64) &&
                         m->desc.channels[1] % 32 == 0;
   const bool split = split_ok && (want == 1 || (want < 0 && maps->rows[0] >= 8192));   // = the Z-order threshold of eyoc_maps_build
   EYOC_REQUIRE(want != 1 || split, EYOC_ERR_INVALID,
                "eyoc_model_forward: split16 arithmetic is not available for this model / kernel selection");
   m->last_math = split ? 1 : 0;
+  if (split) EYOC_CHECK_HIP(hipMemsetAsync(m->range, 0, 4, st));       // the overflow flag of THIS forward (the sticky copy is word 3)
   hipEvent_t* ev = m->timing ? m->events.data() + (size_t)m->slot * (m->layers.size() + 1) : nullptr;
   if (m->timing) EYOC_CHECK_HIP(hipEventRecord(ev[0], st));
   for (size_t li = 0; li < m->layers.size(); ++li) {
@@ -372,6 +382,7 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
       a.out = buf[p.out_buf] + p.out_col; a.ld_out = m->bufs[p.out_buf].width;
       a.out_split = split ? 1 : 0;
       a.range = split ? m->range : nullptr;
+      a.wscale = m->blob + p.s_off;
       a.in_perm = maps->row_perm;                        // Z-ordered maps: the caller's features are read through the permutation
       if (a.in_perm) {
         // ... once: a copy in internal order in a buffer nothing uses yet (an indirection per probed neighbour cost the
@@ -420,6 +431,7 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
       a.res = p.res_buf >= 0 ? buf[p.res_buf] : nullptr; a.ld_res = p.res_buf >= 0 ? m->bufs[p.res_buf].width : 0;
       a.relu = p.relu; a.l2norm = p.l2norm;
       a.out = buf[p.out_buf] + p.out_col; a.ld_out = m->bufs[p.out_buf].width;
+      a.ctx = ctx;
       if (split) {
         a.math = 1;
         a.w = m->blob + p.w16_off;

@@ -535,47 +535,53 @@ __global__ __launch_bounds__(1024) void k_select(PairArgs a, eyoc_ransac_result*
 
 }  // namespace
 
-extern "C" int eyoc_ransac_batched(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int64_t* corr_tgt_dev,
-                                   const int32_t* seg_src_host, const int32_t* seg_tgt_host, int n_pairs,
-                                   const eyoc_ransac_params* p, eyoc_ransac_result* results_dev, void* stream) {
-  EYOC_REQUIRE(ctx && src_dev && tgt_dev && corr_tgt_dev && seg_src_host && seg_tgt_host && p && results_dev, EYOC_ERR_INVALID,
-               "eyoc_ransac_batched: NULL argument");
-  EYOC_REQUIRE(n_pairs >= 1, EYOC_ERR_INVALID, "eyoc_ransac_batched: n_pairs %d", n_pairs);
-  EYOC_REQUIRE(p->max_iteration >= 1, EYOC_ERR_INVALID, "eyoc_ransac: max_iteration %d", p->max_iteration);
-  int max_n = 0;
-  for (int b = 0; b < n_pairs; ++b) {
-    const int n = seg_src_host[b + 1] - seg_src_host[b];
-    EYOC_REQUIRE(n >= 4, EYOC_ERR_INVALID, "eyoc_ransac: need at least 4 correspondences, got %d (pair %d)", n, b);
-    max_n = n > max_n ? n : max_n;
-  }
-  hipStream_t st = (hipStream_t)stream;
+namespace {
+
+// scratch layout of one launch chunk (`chunk` pairs of a batch holding `total` correspondences, H hypotheses per pair):
+// survivor lists are sized for the worst case (every hypothesis survives) - 12 bytes per hypothesis and pair - and
+// transforms are stored for the first cap_t survivors of a pair (96 B each; 2^20 = the survivors of an inlier ratio of 0.7);
+// the rest - only ever reached by degenerate inputs - are re-derived by k_count_overflow
+struct RansacLayout {
+  size_t off_cnt, off_rec, off_surv, off_cnts, off_rmse, off_xf, off_rs, off_be, off_pm, bytes;
+};
+int g_ransac_cap_t = 1 << 20;   // eyoc_ransac_transform_store
+inline int ransac_cap_t(int H) { return H < g_ransac_cap_t ? H : g_ransac_cap_t; }
+RansacLayout ransac_layout(int chunk, int total, int H) {
+  RansacLayout l;
+  const int cap_t = ransac_cap_t(H);
+  l.off_cnt = 0;
+  l.off_rec = align_up((size_t)chunk * CNT_STRIDE * 4);
+  l.off_surv = align_up(l.off_rec + (size_t)total * 24);
+  l.off_cnts = align_up(l.off_surv + (size_t)chunk * H * 4);
+  l.off_rmse = align_up(l.off_cnts + (size_t)chunk * H * 4);
+  l.off_xf = align_up(l.off_rmse + (size_t)chunk * H * 4);
+  l.off_rs = align_up(l.off_xf + (size_t)chunk * cap_t * 96);
+  l.off_be = align_up(l.off_rs + (size_t)total * 24);
+  l.off_pm = align_up(l.off_be + (size_t)chunk * (NBUCKET + 1) * 4);
+  l.bytes = align_up(l.off_pm + (size_t)chunk * 8);
+  return l;
+}
+// the largest chunk (n_pairs capped at CHUNK, then halved) whose layout stays within `budget` bytes; never below one pair
+int ransac_pick_chunk(int n_pairs, int total, int H, size_t budget) {
+  int chunk = n_pairs < CHUNK ? n_pairs : CHUNK;
+  while (chunk > 1 && ransac_layout(chunk, total, H).bytes > budget) chunk >>= 1;
+  return chunk;
+}
+int g_ransac_prune = 1;       // eyoc_ransac_select_pruning
+
+int ransac_run(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int64_t* corr_tgt_dev, const int32_t* seg_src_host,
+               const int32_t* seg_tgt_host, int n_pairs, const eyoc_ransac_params* p, eyoc_ransac_result* results_dev, char* sc,
+               int chunk, int max_n, hipStream_t st) {
   const int H = p->max_iteration;
   const int total = seg_src_host[n_pairs];
-  // survivor lists are sized for the worst case (every hypothesis survives): run the pairs in chunks so the
-  // scratch stays bounded (12 bytes per hypothesis and pair of the chunk)
-  // transforms are stored for the first cap_t survivors of a pair (96 B each; 1M = the survivors of an inlier ratio
-  // of 0.7); the rest - only ever reached by degenerate inputs - are re-derived by k_count_overflow
-  const int cap_t = H < (1 << 20) ? H : (1 << 20);
-  // chunk: as many pairs as 16 GB of scratch hold (144 MB per pair at 4 M hypotheses: all 64 of the bench's batch)
-  const size_t per_pair = (size_t)H * 12 + (size_t)cap_t * 96;
-  int chunk = n_pairs < CHUNK ? n_pairs : CHUNK;
-  while (chunk > 1 && (size_t)chunk * per_pair > ((size_t)16 << 30)) chunk >>= 1;
-  const size_t off_cnt = 0, off_rec = align_up((size_t)chunk * CNT_STRIDE * 4), off_surv = align_up(off_rec + (size_t)total * 24);
-  const size_t off_cnts = align_up(off_surv + (size_t)chunk * H * 4), off_rmse = align_up(off_cnts + (size_t)chunk * H * 4);
-  const size_t off_xf = align_up(off_rmse + (size_t)chunk * H * 4);
-  const size_t off_rs = align_up(off_xf + (size_t)chunk * cap_t * 96);
-  const size_t off_be = align_up(off_rs + (size_t)total * 24);
-  const size_t off_pm = align_up(off_be + (size_t)chunk * (NBUCKET + 1) * 4);
-  int rc = ctx->ensure_scratch(off_pm + (size_t)chunk * 8, st);
-  if (rc) return rc;
-  char* sc = (char*)ctx->scratch;
+  const int cap_t = ransac_cap_t(H);
+  const RansacLayout l = ransac_layout(chunk, total, H);
   PairArgs a;
-  a.rec = (float*)(sc + off_rec); a.seed = p->seed; a.H = H; a.edge_sim = p->edge_similarity; a.max_dist = p->max_distance;
-  a.n_surv = (int*)(sc + off_cnt); a.surv = (int*)(sc + off_surv); a.cnts = (int*)(sc + off_cnts);
-  a.rmse = (unsigned int*)(sc + off_rmse); a.xf = (double*)(sc + off_xf); a.cap_t = cap_t;
-  a.rec_sorted = (float*)(sc + off_rs); a.bucket_end = (int*)(sc + off_be); a.pmax = (double*)(sc + off_pm);
-  static const bool prune_env = !(getenv("EYOC_RANSAC_PRUNE") && atoi(getenv("EYOC_RANSAC_PRUNE")) == 0);
-  const int pruned = prune_env && max_n <= 8192 ? 1 : 0;
+  a.rec = (float*)(sc + l.off_rec); a.seed = p->seed; a.H = H; a.edge_sim = p->edge_similarity; a.max_dist = p->max_distance;
+  a.n_surv = (int*)(sc + l.off_cnt); a.surv = (int*)(sc + l.off_surv); a.cnts = (int*)(sc + l.off_cnts);
+  a.rmse = (unsigned int*)(sc + l.off_rmse); a.xf = (double*)(sc + l.off_xf); a.cap_t = cap_t;
+  a.rec_sorted = (float*)(sc + l.off_rs); a.bucket_end = (int*)(sc + l.off_be); a.pmax = (double*)(sc + l.off_pm);
+  const int pruned = g_ransac_prune && max_n <= 8192 ? 1 : 0;
   const bool in_lds = max_n <= LDS_RECORDS;
   const size_t lds_bytes = in_lds ? (size_t)max_n * 24 : 0;
   if (in_lds) {
@@ -609,6 +615,88 @@ extern "C" int eyoc_ransac_batched(eyoc_ctx* ctx, const float* src_dev, const fl
   }
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
+}
+
+int ransac_validate(const float* src_dev, const float* tgt_dev, const int64_t* corr_tgt_dev, const int32_t* seg_src_host,
+                    const int32_t* seg_tgt_host, int n_pairs, const eyoc_ransac_params* p, eyoc_ransac_result* results_dev, int* max_n) {
+  EYOC_REQUIRE(src_dev && tgt_dev && corr_tgt_dev && seg_src_host && seg_tgt_host && p && results_dev, EYOC_ERR_INVALID,
+               "eyoc_ransac_batched: NULL argument");
+  EYOC_REQUIRE(n_pairs >= 1, EYOC_ERR_INVALID, "eyoc_ransac_batched: n_pairs %d", n_pairs);
+  EYOC_REQUIRE(p->max_iteration >= 1, EYOC_ERR_INVALID, "eyoc_ransac: max_iteration %d", p->max_iteration);
+  *max_n = 0;
+  for (int b = 0; b < n_pairs; ++b) {
+    const int n = seg_src_host[b + 1] - seg_src_host[b];
+    EYOC_REQUIRE(n >= 4, EYOC_ERR_INVALID, "eyoc_ransac: need at least 4 correspondences, got %d (pair %d)", n, b);
+    *max_n = n > *max_n ? n : *max_n;
+  }
+  return EYOC_OK;
+}
+
+}  // namespace
+
+extern "C" int eyoc_ransac_transform_store(int survivors) {
+  const int prev = g_ransac_cap_t;
+  if (survivors >= 1) g_ransac_cap_t = survivors;
+  return prev;
+}
+
+extern "C" int eyoc_ransac_select_pruning(int on) {
+  const int prev = g_ransac_prune;
+  if (on == 0 || on == 1) g_ransac_prune = on;
+  return prev;
+}
+
+extern "C" size_t eyoc_ransac_workspace_bytes(int n_pairs, int total_corr, int max_iteration, size_t budget_bytes) {
+  if (n_pairs < 1 || total_corr < 0 || max_iteration < 1) return 0;
+  const int chunk = ransac_pick_chunk(n_pairs, total_corr, max_iteration, budget_bytes ? budget_bytes : ~(size_t)0);
+  return ransac_layout(chunk, total_corr, max_iteration).bytes;
+}
+
+extern "C" int eyoc_ransac_batched_ws(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int64_t* corr_tgt_dev,
+                                      const int32_t* seg_src_host, const int32_t* seg_tgt_host, int n_pairs,
+                                      const eyoc_ransac_params* p, eyoc_ransac_result* results_dev, void* workspace_dev,
+                                      size_t workspace_bytes, void* stream) {
+  EYOC_REQUIRE(ctx && workspace_dev, EYOC_ERR_INVALID, "eyoc_ransac_batched_ws: NULL argument");
+  EYOC_REQUIRE(((uintptr_t)workspace_dev & 255) == 0, EYOC_ERR_INVALID, "eyoc_ransac_batched_ws: workspace must be 256-byte aligned");
+  int max_n = 0;
+  int rc = ransac_validate(src_dev, tgt_dev, corr_tgt_dev, seg_src_host, seg_tgt_host, n_pairs, p, results_dev, &max_n);
+  if (rc) return rc;
+  const int total = seg_src_host[n_pairs];
+  const int chunk = ransac_pick_chunk(n_pairs, total, p->max_iteration, workspace_bytes);
+  const size_t need = ransac_layout(chunk, total, p->max_iteration).bytes;
+  EYOC_REQUIRE(need <= workspace_bytes, EYOC_ERR_WORKSPACE,
+               "eyoc_ransac_batched_ws: workspace %zu < %zu bytes (one pair per launch; eyoc_ransac_workspace_bytes)", workspace_bytes, need);
+  return ransac_run(ctx, src_dev, tgt_dev, corr_tgt_dev, seg_src_host, seg_tgt_host, n_pairs, p, results_dev, (char*)workspace_dev, chunk,
+                    max_n, (hipStream_t)stream);
+}
+
+// the same with scratch the context owns (grow-only): the chunk is sized from the device's FREE memory - at most a quarter
+// of what is free plus what the context already holds, and never more than 16 GB - and halved again when the allocation
+// fails all the same (another process on the GPU); a one-pair chunk (144 MB at 4 M hypotheses) is the floor
+extern "C" int eyoc_ransac_batched(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int64_t* corr_tgt_dev,
+                                   const int32_t* seg_src_host, const int32_t* seg_tgt_host, int n_pairs,
+                                   const eyoc_ransac_params* p, eyoc_ransac_result* results_dev, void* stream) {
+  EYOC_REQUIRE(ctx, EYOC_ERR_INVALID, "eyoc_ransac_batched: NULL argument");
+  int max_n = 0;
+  int rc = ransac_validate(src_dev, tgt_dev, corr_tgt_dev, seg_src_host, seg_tgt_host, n_pairs, p, results_dev, &max_n);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int total = seg_src_host[n_pairs];
+  size_t free_b = 0, total_b = 0;
+  EYOC_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
+  size_t budget = (free_b + ctx->scratch_bytes) / 4;
+  if (budget > ((size_t)16 << 30)) budget = (size_t)16 << 30;
+  if (budget < ctx->scratch_bytes) budget = ctx->scratch_bytes;          // what is already there is free to use
+  int chunk = ransac_pick_chunk(n_pairs, total, p->max_iteration, budget);
+  for (;;) {
+    rc = ctx->ensure_scratch(ransac_layout(chunk, total, p->max_iteration).bytes, st);
+    if (rc == EYOC_OK) break;
+    if (chunk == 1) return rc;
+    (void)hipGetLastError();                                             // the failed hipMalloc's sticky error
+    chunk >>= 1;
+  }
+  return ransac_run(ctx, src_dev, tgt_dev, corr_tgt_dev, seg_src_host, seg_tgt_host, n_pairs, p, results_dev, (char*)ctx->scratch, chunk,
+                    max_n, st);
 }
 
 extern "C" int eyoc_ransac(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int64_t* corr_tgt_dev, int n,

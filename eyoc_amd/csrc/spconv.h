@@ -40,6 +40,7 @@ struct SpconvArgs {
   int small_rows = 0;
   // SPLIT16 range guard (see split16_guard below): device words {overflow flag, max |x| bits, probe switch} or NULL
   unsigned int* range = nullptr;
+  eyoc_ctx* ctx = nullptr;         // the caller's context (per-device launch state, e.g. function attributes already set) or NULL
 };
 
 // ---- SPLIT16 row format: every block of 32 channels takes 128 bytes (one cache line), the 32 fp16 "hi" halves (x rounded
@@ -84,18 +85,29 @@ __device__ inline float4 split16_load4(const float* row, int c) {
 }
 
 // ---- SPLIT16 range guard.  The hi half of an activation at or above 65520 is inf (and the lo half x - inf): every
-// epilogue that WRITES SPLIT16 rows tracks the largest magnitude it stores (one v_max per value) and raises word 0 of
-// `range` once a value reaches SPLIT16_LIMIT - before anything became inf; the fp32-writing last layer of the network
-// then answers with NaN rows (split16_poisoned) and eyoc_model_range_check reports EYOC_ERR_RANGE.  Word 2 != 0 (the debug
-// probe, eyoc_model_set_probe) also keeps the running maximum of |x| over all stored activations in word 1.
+// epilogue that WRITES SPLIT16 rows tracks the largest magnitude it stores (one v_max per value) and raises words 0 and 3
+// of `range` once a value reaches SPLIT16_LIMIT - before anything became inf.  Word 0 belongs to ONE forward (cleared, in
+// stream order, when a split16 forward starts): the fp32-writing last layer of that forward answers with NaN rows
+// (split16_poisoned).  Word 3 is sticky until eyoc_model_range_check reads it (EYOC_ERR_RANGE), so a caller that pipelines
+// several forwards before it checks learns that one of them overflowed - and only the forwards that overflowed carry NaN
+// rows.  Word 2 != 0 (the debug probe, eyoc_model_set_probe) also keeps the running maximum of |x| over all stored
+// activations in word 1.
+// The running maximum is kept as the BIT PATTERN of |x| compared as an unsigned integer (carried in a float register): finite
+// magnitudes order like their bits, and inf / NaN - a weight or an input feature beyond fp16, an overflowed product - sort
+// ABOVE every finite value, so they trip the guard too (v_max_f32 would drop a NaN and report a clean layer).
 constexpr float SPLIT16_LIMIT = 6.0e4f;
+__device__ inline float split16_merge(float a, float b) {              // both are magnitudes (sign bit clear) or NaN patterns
+  const unsigned int x = __float_as_uint(a) & 0x7FFFFFFFu, y = __float_as_uint(b) & 0x7FFFFFFFu;
+  return __uint_as_float(x > y ? x : y);
+}
+__device__ inline bool split16_over(float mx) { return (__float_as_uint(mx) & 0x7FFFFFFFu) >= __float_as_uint(SPLIT16_LIMIT); }
 __device__ inline void split16_track(float& mx, const float4 v) {
-  mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  mx = split16_merge(split16_merge(split16_merge(mx, v.x), split16_merge(v.y, v.z)), v.w);
 }
 __device__ inline void split16_report(unsigned int* range, float mx) {
   if (!range) return;
-  if (mx >= SPLIT16_LIMIT) atomicOr(range, 1u);                       // rare
-  if (__builtin_nontemporal_load(range + 2)) atomicMax(range + 1, __float_as_uint(mx));   // probe mode only (non-negative floats order like ints)
+  if (split16_over(mx)) { atomicOr(range, 1u); atomicOr(range + 3, 1u); }   // rare
+  if (__builtin_nontemporal_load(range + 2)) atomicMax(range + 1, __float_as_uint(mx) & 0x7FFFFFFFu);   // probe mode only
 }
 __device__ inline bool split16_poisoned(const unsigned int* range) { return range && __builtin_nontemporal_load(range) != 0u; }
 
@@ -137,6 +149,7 @@ struct Conv1Args {
   const float* w;         // [K][cin][cout] with the BN scale folded in
   const float* bias;      // [cout]
   int cout;               // 32 <= cout <= 128, multiple of 32
+  const float* wscale = nullptr;   // MFMA kernels: device {2^sh, 2^-sh}, the power of two their fp16 weight halves are lifted by (NULL: 2^8)
   float* out;             // rows of ld_out floats
   int ld_out;
   int out_split = 0;      // write SPLIT16 rows (see above) instead of fp32 rows

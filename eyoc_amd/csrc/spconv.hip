@@ -572,7 +572,9 @@ __global__ __launch_bounds__(256, 4) void conv1_mfma_kernel(Conv1Args a) {
     ktab[cls][sl] = (signed char)(in ? (dx + r) + a.ks * (dy + r) + a.ks * a.ks * (dz + r) : -1);
   }
   __syncthreads();
-  // weight fragments (A operand): lane (g, j): W[k = 32 q + 8 g + i][cout = 16 t + j] * 256, split
+  // weight fragments (A operand): lane (g, j): W[k = 32 q + 8 g + i][cout = 16 t + j] * 2^sh, split (2^sh lifts the layer's
+  // largest weight into [256, 512): the lo halves stay normal and no hi half leaves the fp16 range; 2^8 without a.wscale)
+  const float wsc = a.wscale ? a.wscale[0] : 256.0f, iwsc = a.wscale ? a.wscale[1] : 1.0f / 256.0f;
   half8_t wh[NQ][NT], wl[NQ][NT];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(256, 4) void conv1_mfma_kernel(Conv1Args a) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int k = 32 * q + 8 * g + i;
-        const float w = k < K ? a.w[(size_t)k * COUT + 16 * t + j] * 256.0f : 0.0f;
+        const float w = k < K ? a.w[(size_t)k * COUT + 16 * t + j] * wsc : 0.0f;
         const _Float16 h = (_Float16)w;
         wh[q][t][i] = h;
         wl[q][t][i] = (_Float16)(w - (float)h);
@@ -682,8 +684,8 @@ __global__ __launch_bounds__(256, 4) void conv1_mfma_kernel(Conv1Args a) {
     for (int t = 0; t < NT; ++t) {
       const int ch0 = 16 * t + 4 * g;
       const float4 b = *reinterpret_cast<const float4*>(a.bias + ch0);
-      const float4 v = make_float4(acc[t][0] * (1.0f / 256.0f) + b.x, acc[t][1] * (1.0f / 256.0f) + b.y,
-                                   acc[t][2] * (1.0f / 256.0f) + b.z, acc[t][3] * (1.0f / 256.0f) + b.w);
+      const float4 v = make_float4(acc[t][0] * iwsc + b.x, acc[t][1] * iwsc + b.y,
+                                   acc[t][2] * iwsc + b.z, acc[t][3] * iwsc + b.w);
       split16_track(mx, v);
       if (a.out_split) split16_store4(dst, ch0, v);
       else *reinterpret_cast<float4*>(dst + ch0) = v;
@@ -712,18 +714,18 @@ __global__ void k_split16_decode(const float* __restrict__ in, int n, int c, int
 
 namespace eyoc {
 
-static int g_kernel_mode = getenv("EYOC_SPCONV_WAVE") ? atoi(getenv("EYOC_SPCONV_WAVE")) : -1;
+static int g_kernel_mode = -1;            // eyoc_spconv_select_kernel
 
 // split16 layers: 1 = choose per layer (default), 0 = always the wave-private kernel, 2 = always the row-stationary one
-static int g_split16_kernel = getenv("EYOC_SPCONV_RS") ? atoi(getenv("EYOC_SPCONV_RS")) : 1;
+static int g_split16_kernel = 1;          // eyoc_spconv_select_split16_kernel
 
 int spconv_forced_kernel() { return g_kernel_mode; }
 // staged kernel for the transposed convolutions (spconv_up.hip), on by default on Z-ordered maps: level with the
 // row-stationary kernel in windowed pattern order in time (0.68 / 1.06 / 1.44 vs 0.63 / 1.02 / 1.57 ms on the bench's three
 // layers, + 0.25 ms of rulebooks in the map build; the step is the same within noise) and 18 GB less HBM traffic per forward
-int g_up_kernel = getenv("EYOC_SPCONV_UP") ? atoi(getenv("EYOC_SPCONV_UP")) : 1;
+int g_up_kernel = 1;                      // eyoc_spconv_select_up_kernel
 bool spconv_up_enabled() { return g_up_kernel != 0; }
-int g_conv1_staged = 1;   // eyoc_spconv_select_conv1_kernel: the first convolution of Z-ordered split16 forwards on conv1_st_kernel
+int g_conv1_staged = 1;   // eyoc_spconv_select_conv1_kernel: 1 the first convolution of Z-ordered split16 forwards on conv1_st_kernel, 0 on conv1_mfma_kernel, 2 on the exact-fp32 octree walker
 int g_down_staged = 0;   // strided convolutions on Z-ordered maps through the staged kernel (eyoc_spconv_select_down_kernel): off - their tiles overflow 2 passes
 bool spconv_down_staged() { return g_down_staged != 0; }
 
@@ -746,7 +748,7 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
   if (a.n_out == 0) return EYOC_OK;
   // Two decompositions: the wave-private kernel (spconv_wave.hip) wins once its 64-row tiles give every SIMD
   // a few waves' worth of work (measured cross-over ~4000 tiles on MI355X); below that the workgroup-tiled
-  // kernel here balances better.  eyoc_spconv_select_kernel (or EYOC_SPCONV_WAVE=0 / 1 in the environment) forces one of them.
+  // kernel here balances better.  eyoc_spconv_select_kernel forces one of them.
   const int force = g_kernel_mode;
   const long long wave_tiles = (long long)cdiv(a.n_out, 64) * (a.cout >= 64 ? a.cout / 64 : 1);
   // row normalisation needs the whole output row in one tile: the wave-private kernel's tiles are at most 64
@@ -756,7 +758,7 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
     EYOC_REQUIRE(wave_ok, EYOC_ERR_INVALID, "spconv: a normalised %d-channel layer has no split16 kernel", a.cout);
     EYOC_REQUIRE(a.math == 0 || (a.cin % 32 == 0 && a.ld_in % 32 == 0), EYOC_ERR_INVALID, "spconv: split16 rows come in blocks of 32 channels");
     EYOC_REQUIRE(!a.out_split || a.ld_out % 32 == 0, EYOC_ERR_INVALID, "spconv: split16 output rows come in blocks of 32 channels");
-    // split16 layers: the row-stationary kernel (spconv_rs.hip) unless EYOC_SPCONV_RS=0 asks for the wave-private one
+    // split16 layers: the row-stationary kernel (spconv_rs.hip) unless eyoc_spconv_select_split16_kernel(0) asks for the wave-private one
     const int use_rs = g_split16_kernel;
     // measured per layer of the 64-pair bench: the row-stationary kernel wins on the stride-1, transposed and 1x1 layers
     // with C_in >= 64 (-5 .. -15 %); the 32-channel layers and the strided convolutions (few, scattered pairs per
@@ -906,7 +908,9 @@ __global__ __launch_bounds__(256, 2) void conv1_st_kernel(Conv1Args a) {
     return m;
   };
   const int f0 = first_child(tile * ST_TILE), f1 = first_child((tile + 1) * ST_TILE);
-  // weight fragments (A operand): lane (g, j): W[k = 32 q + 8 g + i][cout = 16 t + j] * 256, split
+  // weight fragments (A operand): lane (g, j): W[k = 32 q + 8 g + i][cout = 16 t + j] * 2^sh, split (2^sh lifts the layer's
+  // largest weight into [256, 512): the lo halves stay normal and no hi half leaves the fp16 range; 2^8 without a.wscale)
+  const float wsc = a.wscale ? a.wscale[0] : 256.0f, iwsc = a.wscale ? a.wscale[1] : 1.0f / 256.0f;
   half8_t wh[NQ][NT], wl[NQ][NT];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
@@ -915,7 +919,7 @@ __global__ __launch_bounds__(256, 2) void conv1_st_kernel(Conv1Args a) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int k = 32 * q + 8 * g + i;
-        const float w = k < K ? a.w[(size_t)k * COUT + 16 * t + j] * 256.0f : 0.0f;
+        const float w = k < K ? a.w[(size_t)k * COUT + 16 * t + j] * wsc : 0.0f;
         const _Float16 h = (_Float16)w;
         wh[q][t][i] = h;
         wl[q][t][i] = (_Float16)(w - (float)h);
@@ -1023,8 +1027,8 @@ __global__ __launch_bounds__(256, 2) void conv1_st_kernel(Conv1Args a) {
       for (int t = 0; t < NT; ++t) {
         const int ch0 = 16 * t + 4 * g;
         const float4 b = *reinterpret_cast<const float4*>(a.bias + ch0);
-        const float4 v = make_float4(acc[t][0] * (1.0f / 256.0f) + b.x, acc[t][1] * (1.0f / 256.0f) + b.y,
-                                     acc[t][2] * (1.0f / 256.0f) + b.z, acc[t][3] * (1.0f / 256.0f) + b.w);
+        const float4 v = make_float4(acc[t][0] * iwsc + b.x, acc[t][1] * iwsc + b.y,
+                                     acc[t][2] * iwsc + b.z, acc[t][3] * iwsc + b.w);
         split16_track(mx, v);
         if (a.out_split) split16_store4(dst, ch0, v);
         else *reinterpret_cast<float4*>(dst + ch0) = v;
@@ -1045,9 +1049,8 @@ int launch_conv1(const Conv1Args& a, hipStream_t st) {
   if (conv1_walks_octree(a)) {
     // C_in = 1, 32 output channels, split16 activations downstream (the large-batch path): the MFMA formulation.  Its
     // products carry 22-bit significands like every split16 layer; fp32 consumers keep the exact-fp32 walker
-    static const bool mfma_env = !(getenv("EYOC_CONV1_MFMA") && atoi(getenv("EYOC_CONV1_MFMA")) == 0);
-    if (mfma_env && a.cin == 1 && a.cout == 32 && a.out_split && a.ks * a.ks * a.ks < 128 && !a.in_perm) {
-      if (a.local1 && g_conv1_staged) {                               // Z-ordered maps: child features staged per 256-parent tile
+    if (g_conv1_staged != 2 && a.cin == 1 && a.cout == 32 && a.out_split && a.ks * a.ks * a.ks < 128 && !a.in_perm) {
+      if (a.local1 && g_conv1_staged == 1) {                               // Z-ordered maps: child features staged per 256-parent tile
         hipLaunchKernelGGL(conv1_st_kernel, dim3(cdiv(a.nc, ST_TILE)), dim3(256), 0, st, a);
         EYOC_CHECK_HIP(hipGetLastError());
         return EYOC_OK;
@@ -1201,7 +1204,7 @@ int eyoc_spconv_select_up_kernel(int on) {
 
 int eyoc_spconv_select_conv1_kernel(int on) {
   const int prev = eyoc::g_conv1_staged;
-  if (on == 0 || on == 1) eyoc::g_conv1_staged = on;
+  if (on >= 0 && on <= 2) eyoc::g_conv1_staged = on;
   return prev;
 }
 

@@ -109,11 +109,12 @@ __global__ __launch_bounds__(256, 1) void tail_fused_kernel(TailArgs a) {
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[t][cc][term == 2 ? 1 : 0], X[cc][term == 1 ? 1 : 0], acc[t], 0, 0, 0);
     // bias, ReLU, hi / lo split: the lane's 16 values ARE its K elements of the second product (kb = t >> 1, e = 4 (t & 1) + r)
     half8_t Y[2][2];
+    float cmx = 0.f;                                                   // largest |intermediate| of this lane's quarter of row j
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       float4 v = make_float4(acc[t][0] * os1 + b1[t].x, acc[t][1] * os1 + b1[t].y, acc[t][2] * os1 + b1[t].z, acc[t][3] * os1 + b1[t].w);
       if (a.relu1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      split16_track(mx, v);
+      split16_track(cmx, v);
       uint2 h, l;
       split16_encode4(v, h, l);
       const half4_t h4 = __builtin_bit_cast(half4_t, h), l4 = __builtin_bit_cast(half4_t, l);
@@ -144,12 +145,18 @@ __global__ __launch_bounds__(256, 1) void tail_fused_kernel(TailArgs a) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) { v[t].x *= inv; v[t].y *= inv; v[t].z *= inv; v[t].w *= inv; }
     }
+    // range guard: an overflow upstream poisons every row of this forward; one in THIS kernel's intermediate (it never leaves
+    // the registers, so no later layer could answer for it) poisons the row it happened in
+    mx = split16_merge(mx, cmx);
+    cmx = split16_merge(cmx, __shfl_xor(cmx, 16, 64));
+    cmx = split16_merge(cmx, __shfl_xor(cmx, 32, 64));
+    const bool bad = poisoned || split16_over(cmx);
     const int o = chunk * 16 + j;
     if (o < a.n) {
       const size_t oo = a.out_perm ? (size_t)a.out_perm[o] : (size_t)o;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
-        *reinterpret_cast<float4*>(a.out + oo * a.ld_out + 16 * t + 4 * g) = poisoned ? make_float4(qnan, qnan, qnan, qnan) : v[t];
+        *reinterpret_cast<float4*>(a.out + oo * a.ld_out + 16 * t + 4 * g) = bad ? make_float4(qnan, qnan, qnan, qnan) : v[t];
     }
   };
 

@@ -418,19 +418,18 @@ int launch_spconv_up(const SpconvArgs& a, const unsigned char* local_dev, hipStr
   EYOC_REQUIRE(n_cg >= 1 && n_cg <= 8 && 8 % n_cg == 0, EYOC_ERR_INVALID, "spconv_up: %d output channels", a.cout);
   const int n_tiles = cdiv(a.n_out, TILE);
   const dim3 grid((unsigned)(cdiv(n_tiles, 8 / n_cg) * 8)), block(NWK * 64);
-  int dev = 0;
-  EYOC_CHECK_HIP(hipGetDevice(&dev));
-  static bool attr_done[64][2] = {};
+  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remembered in the caller's context (set on every launch without one)
+  bool* attr_done = a.ctx ? a.ctx->up_attr_set : nullptr;
   if (wide) {
-    if (dev >= 64 || !attr_done[dev][0]) {
+    if (!attr_done || !attr_done[0]) {
       EYOC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spconv_up_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, X_BYTES));
-      if (dev < 64) attr_done[dev][0] = true;
+      if (attr_done) attr_done[0] = true;
     }
     hipLaunchKernelGGL(spconv_up_kernel<64>, grid, block, (size_t)X_BYTES, st, a, local_dev, n_tiles);
   } else {
-    if (dev >= 64 || !attr_done[dev][1]) {
+    if (!attr_done || !attr_done[1]) {
       EYOC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spconv_up_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, X_BYTES));
-      if (dev < 64) attr_done[dev][1] = true;
+      if (attr_done) attr_done[1] = true;
     }
     hipLaunchKernelGGL(spconv_up_kernel<32>, grid, block, (size_t)X_BYTES, st, a, local_dev, n_tiles);
   }

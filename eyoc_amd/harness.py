@@ -171,8 +171,8 @@ class RegistrationPipeline:
         try:
             self.model.check_range()
             return None
-        except _lib.EyocError:
-            if self.model.spconv_math != "auto":
+        except _lib.EyocError as e:
+            if e.code != _lib.ERR_RANGE or self.model.spconv_math != "auto":
                 raise
             import logging
             logging.warning("eyoc_amd: split16 overflow in the registration pipeline; switching the model to fp32 MFMAs")

@@ -95,6 +95,7 @@ class ResUNet2(nn.Module):
         # synchronisation); pipelined callers set it False and call check_range() where they synchronise anyway
         self.range_check = True
         self._probe = False
+        self.last_max_activation = None
 
     # ------------------------------------------------------------------ packing
     def _desc(self):
@@ -254,8 +255,8 @@ class ResUNet2(nn.Module):
             if self.range_check and lib.eyoc_model_last_math(self._handle) == 1:
                 try:
                     self.check_range()
-                except _lib.EyocError:
-                    if self._math != -1:          # split16 was asked for explicitly
+                except _lib.EyocError as e:
+                    if e.code != _lib.ERR_RANGE or self._math != -1:    # a HIP error, or split16 was asked for explicitly
                         raise
                     # automatic mode: the same forward in the reference's arithmetic (fp32 MFMA has no range limit)
                     logging.warning("eyoc_amd: split16 arithmetic overflowed (an activation reached 6e4); re-running "
@@ -268,15 +269,19 @@ class ResUNet2(nn.Module):
         return SparseTensor(out, coordinate_map_key=x.coordinate_map_key, coordinate_manager=cm)
 
     def check_range(self):
-        """Raise ``EyocError`` (EYOC_ERR_RANGE) if a split16 forward since the last check stored an activation of
-        magnitude >= 6e4 (its features are NaN); synchronises the current stream.  Returns the largest |activation|
-        seen since ``probe_activations(True)`` (``None`` when the probe is off)."""
+        """Raise ``EyocError`` (``code == EYOC_ERR_RANGE``) if ANY split16 forward since the last check stored an
+        activation of magnitude >= 6e4; synchronises the current stream.  The forwards that overflowed are the ones whose
+        features are NaN - forwards enqueued behind them are judged on their own (the device flag is per forward, the
+        one this call reads is sticky).  Returns the largest |activation| seen since ``probe_activations(True)``
+        (``None`` when the probe is off)."""
         if self._handle is None:
             return None
         mx = C.c_float(-1.0)
         with torch.cuda.device(self._packed_device):
-            _lib.check(_lib.load().eyoc_model_range_check(self._handle, _lib.stream_ptr(), C.byref(mx)), "eyoc_model_range_check")
-        return float(mx.value) if mx.value >= 0 else None
+            rc = _lib.load().eyoc_model_range_check(self._handle, _lib.stream_ptr(), C.byref(mx))
+        self.last_max_activation = float(mx.value) if mx.value >= 0 else None    # valid whether or not the check raises
+        _lib.check(rc, "eyoc_model_range_check")
+        return self.last_max_activation
 
     def probe_activations(self, on=True):
         """Debug probe: keep the running maximum of |activation| over everything the split16 forwards store

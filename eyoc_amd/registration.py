@@ -40,18 +40,15 @@ def ransac_from_correspondences(src, tgt, corr_tgt, max_correspondence_distance,
     t = _cuda_f32(tgt, s.device)
     c = corr_tgt.to(s.device, torch.int64).contiguous()
     n = s.shape[0]
-    p = _lib.RansacParams(float(max_correspondence_distance), float(edge_similarity), int(max_iteration), int(seed))
-    res = torch.empty(C.sizeof(_lib.RansacResult), dtype=torch.uint8, device=s.device)
-    with torch.cuda.device(s.device):
-        _lib.check(_lib.load().eyoc_ransac(_lib.ctx(s.device.index), _lib.ptr(s), _lib.ptr(t), _lib.ptr(c), n,
-                                           C.byref(p), _lib.ptr(res), _lib.stream_ptr()), "eyoc_ransac")
+    res = ransac_batched_from_correspondences(s, t, c, [0, n], [0, 0], max_correspondence_distance, max_iteration, seed,
+                                              edge_similarity)[0]
     if as_device_result:
         return res
     return decode_ransac_result(res, n)
 
 
 def ransac_batched_from_correspondences(src, tgt, corr_tgt, seg_src, seg_tgt, max_correspondence_distance,
-                                        max_iteration=4000000, seed=0, edge_similarity=0.9):
+                                        max_iteration=4000000, seed=0, edge_similarity=0.9, workspace_budget=None):
     """All pairs of a batch in a few launches: ``src [N,3]`` / ``corr_tgt int64 [N]`` hold the pairs back to back
     (pair ``b`` = rows ``seg_src[b]:seg_src[b+1]``), ``tgt [M,3]`` likewise with ``seg_tgt``; ``corr_tgt`` indexes
     INSIDE the pair's target segment.  Pair ``b`` uses ``seed + b``.  Returns the ``[P, 84]`` byte tensor of
@@ -64,10 +61,23 @@ def ransac_batched_from_correspondences(src, tgt, corr_tgt, seg_src, seg_tgt, ma
     st = (C.c_int32 * (P + 1))(*[int(v) for v in seg_tgt])
     p = _lib.RansacParams(float(max_correspondence_distance), float(edge_similarity), int(max_iteration), int(seed))
     res = torch.empty((P, C.sizeof(_lib.RansacResult)), dtype=torch.uint8, device=s.device)
+    lib = _lib.load()
     with torch.cuda.device(s.device):
-        _lib.check(_lib.load().eyoc_ransac_batched(_lib.ctx(s.device.index), _lib.ptr(s), _lib.ptr(t), _lib.ptr(c), ss, st, P,
-                                                   C.byref(p), _lib.ptr(res), _lib.stream_ptr()), "eyoc_ransac_batched")
+        # the scratch (survivor lists: 144 MB per pair at 4 M hypotheses) is the caller's, i.e. torch's caching allocator's:
+        # the largest launch chunk that fits ``workspace_budget`` bytes (default: a quarter of what the device and the
+        # allocator's cache have free, at most 16 GB); any chunk size gives the same results
+        budget = int(workspace_budget) if workspace_budget else _ransac_budget(s.device)
+        ws = _lib.workspace(lib.eyoc_ransac_workspace_bytes(P, int(seg_src[-1]), int(max_iteration), budget), s.device)
+        _lib.check(lib.eyoc_ransac_batched_ws(_lib.ctx(s.device.index), _lib.ptr(s), _lib.ptr(t), _lib.ptr(c), ss, st, P,
+                                              C.byref(p), _lib.ptr(res), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+                   "eyoc_ransac_batched_ws")
     return res
+
+
+def _ransac_budget(device) -> int:
+    free, _ = torch.cuda.mem_get_info(device)
+    cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+    return max(min((free + cached) // 4, 16 << 30), 1)
 
 
 def decode_ransac_result(res: torch.Tensor, n: int) -> RegistrationResult:

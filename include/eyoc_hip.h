@@ -37,7 +37,7 @@ typedef enum {
   EYOC_ERR_HIP = -2,         /* a HIP runtime call failed                   */
   EYOC_ERR_WORKSPACE = -3,   /* caller-provided workspace too small         */
   EYOC_ERR_DUPLICATE = -4,   /* duplicate coordinates in a sparse tensor    */
-  EYOC_ERR_RANGE = -5        /* coordinate / batch index out of key range   */
+  EYOC_ERR_RANGE = -5        /* coordinate / batch index out of key range; split16 activation out of fp16 range */
 } eyoc_status;
 
 #define EYOC_MAX_LEVELS 4
@@ -99,6 +99,10 @@ int eyoc_maps_order_min_rows(int min_rows);
  * their neighbours stay cache-resident while its pattern runs are walked).  Process-wide; shift < 0 only queries.
  * Returns the previous value.  For tests / profiling. */
 int eyoc_maps_order_window_shift(int shift);
+/* Which tables get a pattern-sorted tiling order at all: s1 = the stride-1 tables (default 1), down = the strided tables of
+ * Z-ordered maps (default 0: natural order wins there).  0 / 1 set, anything else leaves the switch alone.  Returns the
+ * previous state (s1 | down << 1).  Process-wide, read when maps are built; for tests / profiling. */
+int eyoc_maps_select_orders(int s1, int down);
 /* Internal row order.  From 8192 rows on (mode -1, the default) the maps store level 0 in Z-order (Morton order of
  * (batch, x, y, z)) instead of the caller's order, so that 64 consecutive rows are a compact blob of voxels - what
  * the tile-local input stage of the sparse convolution needs.  eyoc_maps_coords / _table then describe the INTERNAL
@@ -175,7 +179,7 @@ int eyoc_spconv_select_up_kernel(int on);
 int eyoc_spconv_select_down_kernel(int on);
 /* First convolution (C_in = 1, 32 output channels) of split16 forwards on Z-ordered maps: 1 (default) = conv1_st_kernel - the child
  * features of a 256-parent tile's neighbourhood staged in LDS through the level-1 tile rulebook; 0 = conv1_mfma_kernel, which probes
- * the octree per fine row.  Other values only query.  Returns the previous state; process-wide, for tests and profiling. */
+ * the octree per fine row; 2 = the exact-fp32 octree walker (conv1_tree_kernel) even in front of split16 consumers.  Other values only query.  Returns the previous state; process-wide, for tests and profiling. */
 int eyoc_spconv_select_conv1_kernel(int on);
 /* Stride-1 (3^3) split16 layers with a tile-local input stage (spconv_st.hip): per 256-row tile the distinct input rows are
  * copied to LDS once per 32-channel block and all 27 offsets run from there.  Needs the table's per-tile "local
@@ -283,10 +287,13 @@ int eyoc_model_layer_work(eyoc_ctx* ctx, const eyoc_model* model, const eyoc_map
 int eyoc_model_set_math(eyoc_model* model, int mode);
 int eyoc_model_last_math(const eyoc_model* model);
 /* Range guard of the split16 arithmetic.  Every kernel that stores split16 activations tracks the largest magnitude it
- * writes; once one reaches 6e4 (before any fp16 half became inf) a sticky device flag is raised and the network's fp32
- * output of that and every later split16 forward is all-NaN - never plausible-looking garbage.
- * eyoc_model_range_check synchronises `stream`, returns EYOC_ERR_RANGE if the flag was raised since the last check (and
- * clears it) else EYOC_OK; *max_abs (may be NULL) = largest |activation| stored since eyoc_model_set_probe(model, 1)
+ * writes; once one reaches 6e4 (before any fp16 half became inf) the forward's own device flag is raised - its fp32 output
+ * is all-NaN, never plausible-looking garbage (an overflow inside the fused 1x1 tail, whose intermediate never leaves the
+ * registers, NaNs the rows it happened in) - together with a sticky flag.  The per-forward flag is cleared, in stream order,
+ * when the next split16 forward starts, so forwards enqueued behind an overflowing one are judged on their own.
+ * eyoc_model_range_check synchronises `stream`, returns EYOC_ERR_RANGE if ANY forward since the last check overflowed (and
+ * clears the sticky flag) else EYOC_OK: a caller that pipelines k forwards and then checks must, on EYOC_ERR_RANGE, treat all
+ * k outputs as suspect (the ones that overflowed are the ones holding NaN rows); *max_abs (may be NULL) = largest |activation| stored since eyoc_model_set_probe(model, 1)
  * switched the debug probe on (-1 when the probe is off).  fp32 forwards never raise it. */
 int eyoc_model_range_check(eyoc_model* model, void* stream, float* max_abs);
 int eyoc_model_set_probe(eyoc_model* model, int on);
@@ -412,12 +419,34 @@ int eyoc_ransac(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const
  * [seg_src[b], seg_src[b+1]) and target rows starting at seg_tgt[b]; corr_tgt holds target indices LOCAL to the
  * pair's target segment; pair b samples with seed params->seed + b, so results[b] is bit-identical to
  * eyoc_ransac on that pair with that seed.  seg_* are HOST arrays of n_pairs + 1 ints.
- * Up to 64 pairs go through one set of launches; the ctx's grow-only scratch holds 12 bytes per hypothesis plus 96 bytes per
- * stored survivor transform (at most 2^20) for every pair of such a chunk - 144 MB per pair at 4 000 000 hypotheses, chunks
- * halved until they fit 16 GB. */
+ * Up to 64 pairs go through one set of launches (a "chunk"); the scratch holds 12 bytes per hypothesis plus 96 bytes per
+ * stored survivor transform (at most 2^20) for every pair of a chunk - 144 MB per pair at 4 000 000 hypotheses.  The results
+ * do not depend on the chunk size.
+ *
+ * eyoc_ransac_batched_ws: CALLER-OWNED scratch (256-byte aligned device memory; nothing is allocated inside the call).
+ * eyoc_ransac_workspace_bytes(n_pairs, total_corr = seg_src[n_pairs], max_iteration, budget) = the bytes of the largest
+ * chunk (n_pairs capped at 64, then halved) that stays within `budget` bytes (0 = no limit), never less than a one-pair
+ * chunk; the call derives its chunk from workspace_bytes the same way and returns EYOC_ERR_WORKSPACE if not even one pair
+ * fits.
+ * eyoc_ransac_batched (and eyoc_ransac): the same on the ctx's grow-only scratch, for callers without an allocator - the
+ * chunk is sized so that the scratch takes at most a quarter of the device's free memory (hipMemGetInfo) and at most
+ * 16 GB, and is halved again (down to one pair) if the allocation fails all the same. */
+size_t eyoc_ransac_workspace_bytes(int n_pairs, int total_corr, int max_iteration, size_t budget_bytes);
+int eyoc_ransac_batched_ws(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int64_t* corr_tgt_dev,
+                           const int32_t* seg_src_host, const int32_t* seg_tgt_host, int n_pairs,
+                           const eyoc_ransac_params* params, eyoc_ransac_result* results_dev, void* workspace_dev,
+                           size_t workspace_bytes, void* stream);
 int eyoc_ransac_batched(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int64_t* corr_tgt_dev,
                         const int32_t* seg_src_host, const int32_t* seg_tgt_host, int n_pairs,
                         const eyoc_ransac_params* params, eyoc_ransac_result* results_dev, void* stream);
+/* Reference pruning of the scorer (k_bucket: a survivor only evaluates the correspondences that can be inliers given its
+ * distance to the pair's first survivor; counts are exactly those of the full sweep): 1 on (default), 0 off, other values
+ * only query.  Returns the previous state.  Process-wide; for tests / profiling. */
+int eyoc_ransac_select_pruning(int on);
+/* How many survivor transforms per pair are stored for the scorer (default 2^20 = 96 MB per pair; survivors beyond it are
+ * re-derived from their hypothesis number by k_count_overflow - same counts, more work).  survivors >= 1 sets, anything else
+ * only queries; returns the previous value.  Process-wide; tests set it tiny to drive every survivor through the overflow path. */
+int eyoc_ransac_transform_store(int survivors);
 
 /* replaces: Matcher.SC2_PCR (scripts/SC2_PCR/SC2_PCR.py:307-384) for bs == 1.
  * src,tgt f32 [n,3] matched correspondences -> T f32 [4,4], seedwise_fitness f32 [int(ratio*n)]. */

@@ -59,13 +59,19 @@ def _kernel(sd, name, dtype=torch.float32):
     return w[None] if w.dim() == 2 else w       # 1x1 convs store a 2-D kernel
 
 
-def basic_block(x, nbr, sd, name):
-    """model/residual_block.py:37-53 (downsample is always None, model/resunet.py:41-42)."""
+def basic_block(x, nbr, sd, name, stored=None):
+    """model/residual_block.py:37-53 (downsample is always None, model/resunet.py:41-42).  ``stored``: optional dict that
+    receives the two tensors a fused implementation materialises (after conv1 + norm1 + ReLU, after the residual ReLU)."""
     out = sparse_conv(x, nbr, _kernel(sd, f"{name}.conv1", x.dtype))
     out = torch.relu(batch_norm(out, sd, f"{name}.norm1"))
+    if stored is not None:
+        stored[f"{name}.conv1"] = out
     out = sparse_conv(out, nbr, _kernel(sd, f"{name}.conv2", x.dtype))
     out = batch_norm(out, sd, f"{name}.norm2")
-    return torch.relu(out + x)
+    out = torch.relu(out + x)
+    if stored is not None:
+        stored[f"{name}.conv2"] = out
+    return out
 
 
 def resunet_forward(sd: dict, coords: np.ndarray, feats, normalize_feature=True,
@@ -81,37 +87,46 @@ def resunet_forward(sd: dict, coords: np.ndarray, feats, normalize_feature=True,
     ident = lambda n: np.arange(n, dtype=np.int32)[None, :]
     x = _t(feats).to(dtype)
     inter = {}
+    # per conv layer (state_dict name), the tensor an implementation that fuses norm / ReLU / residual into the convolution
+    # keeps in memory after it - what the split16 range-guard tests compare the product's activation probe with
+    stored = {} if return_intermediate else None
     _kernel = lambda sd_, name: globals()["_kernel"](sd_, name, dtype)
 
+    def keep(name, t):
+        if stored is not None:
+            stored[name] = t
+        return t
+
     # encoder (model/resunet.py:143-161)
-    out_s1 = batch_norm(sparse_conv(x, maps["k5"], _kernel(sd, "conv1")), sd, "norm1")
-    out_s1 = basic_block(out_s1, s1[0], sd, "block1")
+    out_s1 = keep("conv1", batch_norm(sparse_conv(x, maps["k5"], _kernel(sd, "conv1")), sd, "norm1"))
+    out_s1 = basic_block(out_s1, s1[0], sd, "block1", stored)
     out = torch.relu(out_s1)
-    out_s2 = batch_norm(sparse_conv(out, down[0], _kernel(sd, "conv2")), sd, "norm2")
-    out_s2 = basic_block(out_s2, s1[1], sd, "block2")
+    out_s2 = keep("conv2", batch_norm(sparse_conv(out, down[0], _kernel(sd, "conv2")), sd, "norm2"))
+    out_s2 = basic_block(out_s2, s1[1], sd, "block2", stored)
     out = torch.relu(out_s2)
-    out_s4 = batch_norm(sparse_conv(out, down[1], _kernel(sd, "conv3")), sd, "norm3")
-    out_s4 = basic_block(out_s4, s1[2], sd, "block3")
+    out_s4 = keep("conv3", batch_norm(sparse_conv(out, down[1], _kernel(sd, "conv3")), sd, "norm3"))
+    out_s4 = basic_block(out_s4, s1[2], sd, "block3", stored)
     out = torch.relu(out_s4)
-    out_s8 = batch_norm(sparse_conv(out, down[2], _kernel(sd, "conv4")), sd, "norm4")
-    out_s8 = basic_block(out_s8, s1[3], sd, "block4")
+    out_s8 = keep("conv4", batch_norm(sparse_conv(out, down[2], _kernel(sd, "conv4")), sd, "norm4"))
+    out_s8 = basic_block(out_s8, s1[3], sd, "block4", stored)
     out = torch.relu(out_s8)
     inter.update(out_s1=out_s1, out_s2=out_s2, out_s4=out_s4, out_s8=out_s8)
 
     # decoder (model/resunet.py:163-186); ME.cat order is [decoder | skip]
-    out = batch_norm(sparse_conv(out, up[2], _kernel(sd, "conv4_tr")), sd, "norm4_tr")
-    out_s4_tr = torch.relu(basic_block(out, s1[2], sd, "block4_tr"))
+    out = keep("conv4_tr", batch_norm(sparse_conv(out, up[2], _kernel(sd, "conv4_tr")), sd, "norm4_tr"))
+    out_s4_tr = torch.relu(basic_block(out, s1[2], sd, "block4_tr", stored))
     out = torch.cat([out_s4_tr, out_s4], 1)
-    out = batch_norm(sparse_conv(out, up[1], _kernel(sd, "conv3_tr")), sd, "norm3_tr")
-    out_s2_tr = torch.relu(basic_block(out, s1[1], sd, "block3_tr"))
+    out = keep("conv3_tr", batch_norm(sparse_conv(out, up[1], _kernel(sd, "conv3_tr")), sd, "norm3_tr"))
+    out_s2_tr = torch.relu(basic_block(out, s1[1], sd, "block3_tr", stored))
     out = torch.cat([out_s2_tr, out_s2], 1)
-    out = batch_norm(sparse_conv(out, up[0], _kernel(sd, "conv2_tr")), sd, "norm2_tr")
-    out_s1_tr = torch.relu(basic_block(out, s1[0], sd, "block2_tr"))
+    out = keep("conv2_tr", batch_norm(sparse_conv(out, up[0], _kernel(sd, "conv2_tr")), sd, "norm2_tr"))
+    out_s1_tr = torch.relu(basic_block(out, s1[0], sd, "block2_tr", stored))
     out = torch.cat([out_s1_tr, out_s1], 1)
     inter.update(out_s4_tr=out_s4_tr, out_s2_tr=out_s2_tr, out_s1_tr=out_s1_tr)
     n = out.shape[0]
-    out = torch.relu(sparse_conv(out, ident(n), _kernel(sd, "conv1_tr")))
+    out = keep("conv1_tr", torch.relu(sparse_conv(out, ident(n), _kernel(sd, "conv1_tr"))))
     out = sparse_conv(out, ident(n), _kernel(sd, "final")) + _t(sd["final.bias"]).to(dtype).reshape(1, -1)
+    inter["stored"] = stored
     inter["pre_norm"] = out
     if normalize_feature:
         # model/resunet.py:187-191 - no epsilon: a zero row yields NaN, as in the reference

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 export K8=1 PAIRS=16
 for mode in 0 2; do
-  EYOC_SPCONV_RS=$mode timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/k8_$mode -o p -- python scripts/bench_spconv_layer.py > gpurun_out/k8_$mode.log 2>&1
+  RS=$mode timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/k8_$mode -o p -- python scripts/bench_spconv_layer.py > gpurun_out/k8_$mode.log 2>&1
   grep "lvl" gpurun_out/k8_$mode.log
   python - <<PY
 import pandas as pd, glob
