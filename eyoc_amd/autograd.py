@@ -19,34 +19,36 @@ from . import _lib
 from .eval import knn1_segmented
 
 
-_PACK_CACHE: dict = {}      # (storage address, shape, content fingerprint, kind) -> packed device tensor; bounded below
+_PERM_CACHE: dict = {}      # (K, cin, cout, transposed, mirror, device) -> int64 gather indices; one entry per layer SHAPE, never stale
+
+
+def _pack_perm(K, cin, cout, transposed, mirror, device) -> torch.Tensor:
+    """The library's host packers only MOVE values (fragment order of the MFMA kernels, zeros in padding slots): packing
+    the sequence 1, 2, 3 ... once per layer shape yields the permutation, and every later pack is one gather on the device."""
+    key = (K, cin, cout, bool(transposed), bool(mirror), str(device))
+    if key not in _PERM_CACHE:
+        lib = _lib.load()
+        n = K * cin * cout
+        assert n < (1 << 24)                               # the sequence must be exact in fp32
+        w = np.arange(1, n + 1, dtype=np.float32)
+        packed = np.zeros(n, np.float32)
+        if transposed:
+            rc = lib.eyoc_spconv_pack_weights_transposed(w.ctypes.data, K, cin, cout, 1 if mirror else 0, packed.ctypes.data)
+        else:
+            rc = lib.eyoc_spconv_pack_weights(w.ctypes.data, None, K, cin, cout, packed.ctypes.data)
+        _lib.check(rc, "eyoc_spconv_pack_weights")
+        _PERM_CACHE[key] = torch.from_numpy(packed.astype(np.int64)).to(device)    # 0 = padding slot, i + 1 = element i
+    return _PERM_CACHE[key]
 
 
 def _pack(weight: torch.Tensor, transposed: bool, mirror: bool) -> torch.Tensor:
-    """Weights in the MFMA fragment order the kernels consume (host packer of the library).  Cached on a CONTENT fingerprint
-    (three fp64 sums, one small read-back) next to address and shape: a forward and its backward - and every further step
-    until the parameter changes - share one D2H copy / pack / upload of the whole tensor instead of paying it two to three
-    times per layer and step; edits through ``.data`` or a recycled allocation cannot hit a stale entry."""
+    """Weights in the MFMA fragment order the kernels consume: a device-side gather through the shape's permutation - no
+    host round trip, no synchronisation, nothing cached that depends on the parameter's contents."""
+    K, cin, cout = weight.shape
+    perm = _pack_perm(K, cin, cout, transposed, mirror, weight.device)
     with torch.no_grad():
-        wd = weight.detach().double()
-        fp = torch.stack([wd.sum(), wd.abs().sum(), (wd * wd).sum()]).cpu().numpy().tobytes()
-    key = (weight.data_ptr(), tuple(weight.shape), fp, transposed, mirror, str(weight.device))
-    if key in _PACK_CACHE:
-        return _PACK_CACHE[key]
-    lib = _lib.load()
-    w = np.ascontiguousarray(weight.detach().cpu().numpy().astype(np.float32))
-    K, cin, cout = w.shape
-    packed = np.zeros(w.size, np.float32)
-    if transposed:
-        rc = lib.eyoc_spconv_pack_weights_transposed(w.ctypes.data, K, cin, cout, 1 if mirror else 0, packed.ctypes.data)
-    else:
-        rc = lib.eyoc_spconv_pack_weights(w.ctypes.data, None, K, cin, cout, packed.ctypes.data)
-    _lib.check(rc, "eyoc_spconv_pack_weights")
-    out = torch.from_numpy(packed).to(weight.device)
-    if len(_PACK_CACHE) >= 128:         # stale contents of trained parameters: drop everything, the live ones come back
-        _PACK_CACHE.clear()
-    _PACK_CACHE[key] = out
-    return out
+        src = torch.cat([weight.new_zeros(1), weight.detach().reshape(-1).float()])
+        return src[perm]
 
 
 def _run(table, n_out, x, packed, cin, cout):

@@ -61,7 +61,7 @@ def _optional_channels(name, arr, n_points, upper):
     a = np.asarray(arr)
     if a.ndim != 2 or a.shape != (n_points, 3):
         raise AssertionError(f"{name} must be [{n_points}, 3], got {tuple(a.shape)}")
-    if float(a.max(initial=-np.inf)) > upper:
+    if bool(np.any(a > upper)):              # the reference's own test (np.any(rgb > 1)); any dtype, empty arrays included
         raise ValueError("Invalid color. Color must range from [0, 1]" if name == "rgb"
                          else "Invalid normal. Normal must range from [-1, 1]")
     return a

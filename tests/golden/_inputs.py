@@ -33,6 +33,21 @@ def nn_case(seed, n0, n1, c=32, noise=0.35):
     return _rownorm(F0).astype(np.float32), _rownorm(F1).astype(np.float32)
 
 
+def loss_case(seed, n0, n1, n_pairs, c=32, noise=0.25):
+    """Two descriptor sets and ``positive_pairs [n_pairs, 2]`` for the hardest-contrastive loss: the partner of a positive
+    is a noisy copy (so positives are close, some beyond the positive margin), a tenth of the pairs is listed twice, and
+    the candidate sets hold near-duplicates of anchors (hard negatives, some of them known positives: the mask matters)."""
+    F0 = _normal(seed, n0, c)
+    i0 = (_u(seed + 1, n_pairs) * n0).astype(np.int64)
+    i1 = (_u(seed + 2, n_pairs) * n1).astype(np.int64)
+    dup = np.nonzero(_u(seed + 3, n_pairs) < 0.1)[0]
+    i0[dup] = i0[(dup * 7) % n_pairs]
+    i1[dup] = i1[(dup * 7) % n_pairs]
+    F1 = _normal(seed + 4, n1, c)
+    F1[i1] = F0[i0] + noise * _normal(seed + 5, n_pairs, c)      # later pairs overwrite earlier ones: some positives end up far apart
+    return _rownorm(F0).astype(np.float32), _rownorm(F1).astype(np.float32), np.stack([i0, i1], 1)
+
+
 def rot_zyx(rx, ry, rz):
     cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
     Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])

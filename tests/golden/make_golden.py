@@ -13,6 +13,12 @@ reference's numeric outputs only.
   g5_se3.npz     scripts.SC2_PCR.utils.SE3.transform / integrate_trans
   g6_match.npz   scripts.SC2_PCR.SC2_PCR.Matcher.match_pair (the method hard-codes one ``.cuda()`` on an index tensor,
                  SC2_PCR.py:299; it runs here with ``torch.Tensor.cuda`` patched to the identity - nothing else changes)
+  g7_loss.npz    lib.trainer.CorrespondenceExtensionTrainer.contrastive_hardest_negative_loss (lib/trainer.py:935-991): both
+                 loss terms AND d(pos + neg)/dF0, /dF1, global ``np.random`` seeded per case
+  g8_labels.npz  lib.trainer.CorrespondenceExtensionTrainer.calculate_ratio_test / get_topk_matches (lib/trainer.py:993-1016)
+  g9_eval.npz    scripts.test_kitti.find_corr / random_sample / apply_transform / evaluate_nn_dist (scripts/test_kitti.py:28-73)
+``lib.trainer`` and ``scripts.test_kitti`` import through ``_refimport.install()`` (codec alias + EMPTY stand-ins for the
+absent libraries; no arithmetic is stubbed).
 """
 import json
 import os
@@ -26,8 +32,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference"
 sys.path.insert(0, HERE)
 sys.path.insert(0, REF)
-for name in ("open3d", "MinkowskiEngine"):
-    sys.modules.setdefault(name, types.ModuleType(name))
+import _refimport  # noqa: E402
+_refimport.install()
 
 import _inputs as gi  # noqa: E402
 from lib.eval import find_nn_gpu  # noqa: E402
@@ -164,7 +170,97 @@ def g6():
     np.savez_compressed(os.path.join(HERE, "g6_match.npz"), **out)
 
 
+LOSS_CASES = [  # (seed, n0, n1, n_pairs, num_pos, num_hn_samples)
+    (71, 1500, 1400, 1300, 1000, 512),      # more positives than num_pos: the third draw happens
+    (72, 900, 1100, 600, 5192, 2048),       # fewer: every positive is used; clouds smaller than num_hn_samples, so every anchor's
+                                            # nearest candidate is its own partner, all negatives are masked and the reference's
+                                            # mean over nothing is NaN (kept: that is what the trainer would log)
+    (73, 300, 280, 2000, 256, 64),          # many duplicates among the positives, tiny candidate sets
+]
+
+
+def g7():
+    from types import SimpleNamespace
+    from lib.trainer import CorrespondenceExtensionTrainer, HardestContrastiveLossTrainer
+    out = {"cases": np.array(json.dumps(LOSS_CASES))}
+    me = SimpleNamespace(pos_thresh=0.1, neg_thresh=1.4)          # config.py:113-114 defaults
+    torch.set_num_threads(1)                                      # index_add over duplicated rows: one thread = one summation order = a reproducible fixture
+    for i, (seed, n0, n1, npairs, num_pos, nhn) in enumerate(LOSS_CASES):
+        F0n, F1n, pairs = gi.loss_case(seed, n0, n1, npairs)
+        res = []
+        for cls in (CorrespondenceExtensionTrainer, HardestContrastiveLossTrainer):   # :935 and its twin :428
+            F0 = torch.from_numpy(F0n).requires_grad_(True)
+            F1 = torch.from_numpy(F1n).requires_grad_(True)
+            np.random.seed(seed)
+            pos, neg = cls.contrastive_hardest_negative_loss(me, F0, F1, torch.from_numpy(pairs), num_pos=num_pos, num_hn_samples=nhn)
+            (pos + neg).backward()
+            res.append((float(pos), float(neg), F0.grad.numpy().copy(), F1.grad.numpy().copy()))
+        # the twins agree; the gradients only to rounding (index_add over duplicated rows sums in thread order)
+        assert np.array_equal(res[0][:2], res[1][:2], equal_nan=True), (res[0][:2], res[1][:2])
+        for a, b in ((res[0][2], res[1][2]), (res[0][3], res[1][3])):
+            assert np.abs(a - b).max() <= 1e-7 * max(np.abs(a).max(), 1e-30), np.abs(a - b).max()
+        out[f"pos{i}"], out[f"neg{i}"] = np.array(res[0][0], np.float64), np.array(res[0][1], np.float64)
+        out[f"gF0_{i}"], out[f"gF1_{i}"] = res[0][2], res[0][3]
+    torch.set_num_threads(8)
+    np.savez_compressed(os.path.join(HERE, "g7_loss.npz"), **out)
+
+
+LABEL_CASES = [(81, 3000, 3000, 1000), (82, 500, 800, 5000), (83, 1200, 37, 64)]   # (seed, n0, n1, num_corres)
+
+
+def g8():
+    """Inputs: the two smallest squared distances and the nearest index of every row of F0 among F1 (what pytorch3d's
+    ``knn_points(K = 2)`` hands the trainer at :1060; computed by the test-side numpy restatement and STORED, inputs are data).
+    Outputs: the reference's weights (:1066-1070 feed ``calculate_ratio_test`` the cosines ``1 - 0.5 d``) and its top-k."""
+    from lib.trainer import CorrespondenceExtensionTrainer as Tr
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle.labels import knn2
+    out = {"cases": np.array(json.dumps(LABEL_CASES))}
+    for i, (seed, n0, n1, k) in enumerate(LABEL_CASES):
+        F0, F1 = gi.nn_case(seed, n0, n1)
+        idx, d1, d2 = knn2(F0, F1)
+        dists = torch.from_numpy(np.stack([d1, d2], 1))[None]                # (1, P, 2) squared L2
+        w = Tr.calculate_ratio_test(None, 1 - 0.5 * dists)                   # (1, P, 1)
+        src, tgt, top = Tr.get_topk_matches(None, w, torch.from_numpy(idx)[None, :, None], k)
+        out[f"d1_{i}"], out[f"d2_{i}"], out[f"idx{i}"] = d1, d2, idx.astype(np.int32)
+        out[f"w{i}"] = w[0, :, 0].numpy()
+        out[f"src{i}"], out[f"tgt{i}"], out[f"top{i}"] = src[0, :, 0].numpy().astype(np.int32), tgt[0, :, 0].numpy().astype(np.int32), top[0, :, 0].numpy()
+    np.savez_compressed(os.path.join(HERE, "g8_labels.npz"), **out)
+
+
+EVAL_CASES = [(91, 3000, 2600, 1000), (92, 400, 500, 1000), (93, 800, 800, -1)]    # (seed, n0, n1, subsample_size)
+
+
+def g9():
+    """Points are index-coded (x = row number) so the returned arrays reveal the drawn rows; the global ``np.random`` is
+    seeded with the case's seed right before each call."""
+    import scripts.test_kitti as tk
+    out = {"cases": np.array(json.dumps(EVAL_CASES))}
+    for i, (seed, n0, n1, sub) in enumerate(EVAL_CASES):
+        F0, F1 = gi.nn_case(seed, n0, n1)
+        x0 = np.zeros((n0, 3), np.float32); x0[:, 0] = np.arange(n0)
+        x1 = np.zeros((n1, 3), np.float32); x1[:, 0] = np.arange(n1)
+        np.random.seed(seed)
+        a, b = tk.find_corr(torch.from_numpy(x0), torch.from_numpy(x1), torch.from_numpy(F0), torch.from_numpy(F1), subsample_size=sub)
+        out[f"corr0_{i}"], out[f"corr1_{i}"] = a[:, 0].numpy().astype(np.int32), b[:, 0].numpy().astype(np.int32)
+    # random_sample: n > N (permutation prefix), n < N (with replacement), n == N (identity); numpy and torch inputs
+    for j, (n, N) in enumerate(((1000, 300), (200, 500), (64, 64))):
+        pts = np.zeros((n, 3), np.float32); pts[:, 0] = np.arange(n)
+        feats = np.arange(n * 4, dtype=np.float32).reshape(n, 4)
+        np.random.seed(100 + j)
+        p, f = tk.random_sample(pts, torch.from_numpy(feats), N)
+        out[f"rs_p{j}"], out[f"rs_f{j}"] = np.asarray(p)[:, 0].astype(np.int32), f.numpy()
+    T = gi.rigid(0.03, -0.02, 0.4, 7.0, -1.0, 0.3).astype(np.float32)
+    pts = ((gi._u(95, 500, 3) - 0.5) * 60).astype(np.float32)
+    tgt = (pts @ T[:3, :3].T + T[:3, 3] + 0.05 * gi._normal(96, 500, 3)).astype(np.float32)
+    out["T"] = T
+    out["applied"] = tk.apply_transform(torch.from_numpy(pts), torch.from_numpy(T)).numpy()
+    # called like scripts/test_kitti.py:166 does - torch tensors in (apply_transform uses Tensor.t()), a list of floats out
+    out["nn_dist"] = np.array(tk.evaluate_nn_dist(torch.from_numpy(pts), torch.from_numpy(tgt), torch.from_numpy(T)), np.float64)
+    np.savez_compressed(os.path.join(HERE, "g9_eval.npz"), **out)
+
+
 if __name__ == "__main__":
-    for fn in (g1, g2, g3, g4, g5, g6):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
         fn()
         print("wrote", fn.__name__)
