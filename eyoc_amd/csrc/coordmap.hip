@@ -571,6 +571,7 @@ size_t eyoc_maps_workspace_bytes(int n_rows) {
   b += align_up(n * 8) * 2 + align_up(n * 4) * 2 + align_up(sort_rows64_tmp_bytes(n_rows));   // Z-order: keys in / out, rows in, permutation
   // local rulebooks of the stride-1 tables (levels sum to < 2 n rows; every level rounds up to a whole tile)
   b += 2 * align_up(local_rulebook_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_bytes(1)) + 256);
+  b += 2 * align_up(local_rulebook128_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook128_bytes(1)) + 256);   // 128-row tile records (+ level 1 twice)
   b += 2 * align_up(local_rulebook_up_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_up_bytes(1)) + 256);
   b += align_up(local_rulebook_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_bytes(1)) + 256);   // strided tables (coarse levels sum to < n rows)
   b += 4096;                                                         // counters
@@ -828,9 +829,20 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
   // ---- local rulebooks of the stride-1 tables (tile-local input stage of the sparse convolution): only for Z-ordered rows
   if (zorder) {
     FAIL_HIP(hipMemsetAsync(counters + 8, 0, 8 * sizeof(int), st));    // [8] stride-1, [9] transposed, [10 + l] strided table l
+    m->local_tile = select_st_tile(-1);
     for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
-      m->local_s1[l] = cv.take<unsigned char>(local_rulebook_bytes(m->rows[l]));
-      if (int rc = build_local_rulebook(m->nbr_s1[l], 27, m->rows[l], m->local_s1[l], counters + 8, st)) { delete m; return rc; }
+      if (m->local_tile == 128) {
+        m->local_s1[l] = cv.take<unsigned char>(local_rulebook128_bytes(m->rows[l]));
+        if (int rc = build_local_rulebook128(m->nbr_s1[l], 27, m->rows[l], m->local_s1[l], counters + 8, st)) { delete m; return rc; }
+        if (l == 1) {   // the staged first convolution reads 256-parent tiles of this table
+          m->local1_256 = cv.take<unsigned char>(local_rulebook_bytes(m->rows[l]));
+          if (int rc = build_local_rulebook(m->nbr_s1[l], 27, m->rows[l], m->local1_256, counters + 14, st)) { delete m; return rc; }
+        }
+      } else {
+        m->local_s1[l] = cv.take<unsigned char>(local_rulebook_bytes(m->rows[l]));
+        if (int rc = build_local_rulebook(m->nbr_s1[l], 27, m->rows[l], m->local_s1[l], counters + 8, st)) { delete m; return rc; }
+        if (l == 1) m->local1_256 = m->local_s1[l];
+      }
       if (l + 1 < EYOC_MAX_LEVELS && spconv_up_enabled()) {   // the transposed table whose outputs are this level's rows
         m->local_up[l] = cv.take<unsigned char>(local_rulebook_up_bytes(m->rows[l]));
         if (int rc = build_local_rulebook_up(m->nbr_up[l], 27, m->rows[l], m->local_up[l], counters + 9, st)) { delete m; return rc; }
@@ -859,8 +871,9 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
         delete m;
         return EYOC_ERR_INVALID;
       }
-    if (host[0] != 0)   // a tile with more than 1278 distinct input rows (does not happen for Z-ordered rows): no staged kernel
+    if (host[0] != 0)   // a tile with more distinct input rows than two passes stage (does not happen for Z-ordered rows): no staged kernel
       for (int l = 0; l < EYOC_MAX_LEVELS; ++l) m->local_s1[l] = nullptr;
+    if (host[0] != 0 || host[6] != 0) m->local1_256 = nullptr;
     if (host[1] != 0)   // ... more than 639 distinct coarse rows under a 256-row tile
       for (int l = 0; l < EYOC_MAX_LEVELS; ++l) m->local_up[l] = nullptr;
     for (int l = 0; l + 1 < EYOC_MAX_LEVELS; ++l)

@@ -181,8 +181,10 @@ def gen(NH, WD, LD=2, skip=True, abl=()):
     return out
 
 
-def gen_w8(D=2, WD=1, LD=2, skip=True):
-    """The 8-wave workgroup's loop (4 row quarters x 2 channel halves: 64 rows x 32 channels per wave) inside 128 VGPRs, so
+def gen_w8(D=2, WD=1, LD=2, skip=True, lo_region=LO_REGION, lrows=64):
+    """``lo_region``: byte distance between the hi and the lo halves of a staged row; ``lrows``: rulebook entries per offset
+    (64 for the 256-row tile records; the 128-row tiles of spconv_st128.hip hold 32 and a 320-row stage).
+    The 8-wave workgroup's loop (4 row quarters x 2 channel halves: 64 rows x 32 channels per wave) inside 128 VGPRs, so
     that FOUR waves share a SIMD (two workgroups per CU as before - the LDS stage is unchanged): a workgroup that waits for
     its stage or stores its tile leaves two waves per SIMD on the matrix pipe instead of one (one wave alone reaches ~60 % of
     the pipe in this loop).  Operand reads run D chunk groups ahead in a ring of D + 1 register slots.
@@ -220,10 +222,12 @@ def gen_w8(D=2, WD=1, LD=2, skip=True):
                 vmq.append(("W", k))
         emit("s_add_u32 %[so], %[so], %[ks]")
 
+    kper = 4096 // (lrows * 8)          # offsets per 4 KB of rulebook entries (the instruction's offset field ends at 4095)
+
     def issue_l(k):
-        if k % 8 == 0 and k > 0:
+        if k % kper == 0 and k > 0:
             emit(f"v_add_u32 {LV}, 0x1000, {LV}")
-        emit(f"global_load_dwordx2 {vr(LS(k % NLS), 2)}, {LV}, %[lb] offset:{(k % 8) * 512}")
+        emit(f"global_load_dwordx2 {vr(LS(k % NLS), 2)}, {LV}, %[lb] offset:{(k % kper) * lrows * 8}")
         vmq.append(("L", k))
 
     def fetch(q):
@@ -234,7 +238,7 @@ def gen_w8(D=2, WD=1, LD=2, skip=True):
         t = T[q & 1]
         emit(f"v_xor_b32_sdwa v{t}, {GH}, v{LS(k % NLS) + (c >> 1)} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_{c & 1}")
         for p in range(2):
-            emit(f"ds_read_b128 {vr(XS(q % NXS, p))}, v{t}" + (f" offset:{LO_REGION}" if p else ""))
+            emit(f"ds_read_b128 {vr(XS(q % NXS, p))}, v{t}" + (f" offset:{lo_region}" if p else ""))
             lgq.append(("X", q))
 
     emit("s_mov_b32 %[so], %[ws0]")
@@ -314,6 +318,10 @@ def main(path):
         write_blob(f, "NH1", gen(1, 2, 2))
         write_blob(f, "NH2_NOSKIP", gen(2, WD2, LD2, skip=False))
         f.write(f"#define EYOC_ST_LOOP_CLOBBERS {clobbers()}\n")
+        # spconv_st128.hip: 128-row tiles, 64 rows x 32 channels per wave inside 128 VGPRs (four waves per SIMD, four workgroups per CU)
+        write_blob(f, "T128", gen_w8(lo_region=320 * 64, lrows=32))
+        write_blob(f, "T128_NOSKIP", gen_w8(skip=False, lo_region=320 * 64, lrows=32))
+        f.write("#define EYOC_ST_LOOP_CLOBBERS_T128 " + ", ".join(f'"v{i}"' for i in range(28, 96)) + "\n")
     with open(path.replace(".inc", "_abl.inc"), "w") as f:
         f.write("// GENERATED by gen_st_loop.py - diagnostics builds only (EYOC_ST_ABLATIONS / EYOC_ST_TRACE); results are garbage\n")
         for name, abl in (("NOW", ("now",)), ("NOX", ("nox", "nov")), ("NOV", ("nov",)), ("NOM", ("nom",)), ("NOMW", ("nom", "now")),

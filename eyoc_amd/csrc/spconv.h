@@ -29,7 +29,8 @@ struct SpconvArgs {
   int math = 0;
   int out_split = 0;               // write SPLIT16 rows (internal activations) instead of fp32 rows
   const int32_t* out_perm = nullptr;      // output row o is written to row out_perm[o] of `out` (the network output in the caller's order); res is not permuted
-  const unsigned char* local = nullptr;   // per-tile local rulebooks of `nbr` (build_local_rulebook) or NULL: enables the staged kernel
+  const unsigned char* local = nullptr;   // per-tile local rulebooks of `nbr` (build_local_rulebook / build_local_rulebook128) or NULL: enables the staged kernel
+  int local_tile = 256;                   // rows per tile of `local`: 256 (spconv_st.hip) or 128 (spconv_st128.hip)
   const unsigned char* local_up = nullptr;   // ... of a transposed table (build_local_rulebook_up): enables spconv_up.hip
   const float* out_scale = nullptr;  // device scalar multiplied into the accumulated sums (undoes the weight pre-scale); NULL = 1
   // optional: a permutation of the output rows; tiles take rows in this order (any order gives the same result,
@@ -125,6 +126,11 @@ int build_local_rulebook_up(const int32_t* nbr_dev, int K, int n_out, unsigned c
 int select_st_variant(int v);   // spconv_st.hip: which staged kernel (returns the previous one)
 int select_st_split_below(int workgroups);   // layers with fewer 64-channel workgroups take 32-channel ones (returns the previous threshold)
 size_t local_rulebook_bytes(int n_out);
+// 128-row tiles (spconv_st128.hip): four workgroups per CU, four waves per SIMD
+int select_st_tile(int rows);   // 128 / 256 set the tile shape new maps build their stride-1 records for; anything else only queries
+size_t local_rulebook128_bytes(int n_out);
+int build_local_rulebook128(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st);
+int launch_spconv_st128(const SpconvArgs& a, const unsigned char* local_dev, int skip_empty_blocks, hipStream_t st);
 int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st);
 int launch_spconv_rs(const SpconvArgs& a, hipStream_t st);     // row-stationary, SPLIT16 only (spconv_rs.hip)
 // the network's 1x1 tail in one kernel (spconv_tail.hip): conv1_tr (96 -> 64, ReLU) -> final (64 -> 32, bias) -> row normalisation

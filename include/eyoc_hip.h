@@ -194,6 +194,19 @@ int eyoc_spconv_select_st_kernel(int variant);
  * in 32-channel workgroups instead (twice as many, each half as long: single pairs and small batches).  0 = never (tests force
  * the wide kernels onto small clouds with it); negative only queries.  Returns the previous threshold; process-wide. */
 int eyoc_spconv_st_split_below(int workgroups);
+/* The same on 128-ROW tiles (spconv_st128.hip: a 40 KB stage and 128 VGPRs per wave, so four workgroups share a CU and four
+ * waves a SIMD - a tile's stage / loop / store phases overlap with three other tiles' instead of one).  eyoc_spconv_st_tile(128 |
+ * 256) selects the tile shape NEW maps build their stride-1 records for (default 256 - the 128-row kernel measured level or slightly behind; other values only query; returns the
+ * previous value; process-wide, read by eyoc_maps_build).  The *_tile entry points take the shape explicitly (records of one
+ * shape are not readable as the other). */
+int eyoc_spconv_st_tile(int rows);
+size_t eyoc_spconv_local_rulebook_bytes_tile(int n_out, int tile);
+int eyoc_spconv_build_local_rulebook_tile(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, int tile, void* out_dev,
+                                          int32_t* overflow_dev, void* stream);
+int eyoc_spconv_staged_tile(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* local_dev, int tile, int n_out, int n_in,
+                            const float* in_dev, int ld_in, int cin, const float* wpacked_dev, int cout, const float* bias_dev,
+                            const float* res_dev, int ld_res, int relu, float* out_dev, int ld_out, int out_split,
+                            const float* out_scale_dev, void* stream);
 size_t eyoc_spconv_local_rulebook_bytes(int n_out);
 int eyoc_spconv_build_local_rulebook(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, void* out_dev,
                                      int32_t* overflow_dev, void* stream);

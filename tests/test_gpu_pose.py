@@ -142,3 +142,48 @@ def test_feature_matching_ransac_end_to_end():
     rte, rre, ok = eyoc_amd.registration_errors(res.transformation, T)
     assert ok and rte < 0.1 and rre < np.deg2rad(0.5)
     assert res.fitness > 0.5
+
+
+def test_open3d_shaped_call_site_runs_unchanged():
+    """The reference's RANSAC call site in its own shape (scripts/test_kitti.py:159-177 with util/pointcloud.py:9-21 building
+    the arguments): ``PointCloud`` + ``Vector3dVector``, ``Feature.resize`` + ``[C, n]`` float64 ``data``, the estimation /
+    checker / criteria objects, ``result.transformation``.  Same answer as the array-level entry point."""
+    import eyoc_amd
+    import eyoc_amd.o3d as o3d
+    T = gi.rigid(0.0, 0.01, -0.1, 6.0, -0.4, 0.05)
+    n = 3000
+    xyz0np, xyz1np, _ = gi.corr_case(71, n, T, 1.0, noise=0.02)
+    F0 = torch.from_numpy(gi.unit_feats(72, n)).cuda()
+    perm = np.random.default_rng(1).permutation(n)
+    F1 = F0[torch.from_numpy(perm).cuda()].clone()
+    F1[::3] = torch.from_numpy(gi.unit_feats(73, n)[::3]).cuda()
+    xyz1np = xyz1np[perm]
+
+    def make_open3d_point_cloud(xyz):
+        pcd = o3d.geometry.PointCloud()
+        pcd.points = o3d.utility.Vector3dVector(xyz)
+        return pcd
+
+    def make_open3d_feature(data, dim, npts):
+        feature = o3d.pipelines.registration.Feature()
+        feature.resize(dim, npts)
+        feature.data = data.cpu().numpy().astype('d').transpose()
+        return feature
+    pcd0, pcd1 = make_open3d_point_cloud(xyz0np), make_open3d_point_cloud(xyz1np)
+    feat0, feat1 = make_open3d_feature(F0, 32, F0.shape[0]), make_open3d_feature(F1, 32, F1.shape[0])
+    distance_threshold = 0.3
+    ransac_result = o3d.pipelines.registration.registration_ransac_based_on_feature_matching(
+        pcd0, pcd1, feat0, feat1, False, distance_threshold,
+        o3d.pipelines.registration.TransformationEstimationPointToPoint(False), 4, [
+            o3d.pipelines.registration.CorrespondenceCheckerBasedOnEdgeLength(0.9),
+            o3d.pipelines.registration.CorrespondenceCheckerBasedOnDistance(distance_threshold)
+        ], o3d.pipelines.registration.RANSACConvergenceCriteria(100000, 10000))
+    T_ransac = torch.from_numpy(ransac_result.transformation.astype(np.float32))
+    direct = eyoc_amd.registration_ransac_based_on_feature_matching(xyz0np, xyz1np, F0, F1, False, 0.3, criteria=(100000, 10000))
+    np.testing.assert_array_equal(ransac_result.transformation, direct.transformation)
+    rte, rre, ok = eyoc_amd.registration_errors(T_ransac.numpy(), T)
+    assert ok and rte < 0.1 and ransac_result.fitness > 0.5
+    with pytest.raises(NotImplementedError):
+        o3d.pipelines.registration.registration_ransac_based_on_feature_matching(
+            pcd0, pcd1, feat0, feat1, False, distance_threshold,
+            o3d.pipelines.registration.TransformationEstimationPointToPoint(True), 4, [], o3d.pipelines.registration.RANSACConvergenceCriteria(1000, 1.0))

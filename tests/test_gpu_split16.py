@@ -302,7 +302,7 @@ def morton_order(coords):
     return np.argsort((b << 54) | spread(x) | (spread(y) << 1) | (spread(z) << 2), kind="stable")
 
 
-def run_layer_staged(nbr, x, W, bias=None, scale=None, res=None, relu=False, out_split=True):
+def run_layer_staged(nbr, x, W, bias=None, scale=None, res=None, relu=False, out_split=True, tile=256):
     L, lib = _lib()
     K, cin, cout = W.shape
     packed = np.zeros(K * cin * cout, np.float32)
@@ -313,18 +313,27 @@ def run_layer_staged(nbr, x, W, bias=None, scale=None, res=None, relu=False, out
     dev = torch.device("cuda")
     n_out = nbr.shape[1]
     nd = torch.from_numpy(np.ascontiguousarray(nbr, np.int32)).to(dev)
-    local = torch.zeros(int(lib.eyoc_spconv_local_rulebook_bytes(n_out)), dtype=torch.uint8, device=dev)
+    local = torch.zeros(int(lib.eyoc_spconv_local_rulebook_bytes_tile(n_out, tile)), dtype=torch.uint8, device=dev)
+    assert tile != 256 or local.numel() == int(lib.eyoc_spconv_local_rulebook_bytes(n_out))
     ovf = torch.zeros(1, dtype=torch.int32, device=dev)
-    L.check(lib.eyoc_spconv_build_local_rulebook(L.ctx(), L.ptr(nd), K, n_out, L.ptr(local), L.ptr(ovf), L.stream_ptr()))
-    assert int(ovf.item()) == 0, "a tile has more than 1278 distinct input rows"
+    if tile == 256:
+        L.check(lib.eyoc_spconv_build_local_rulebook(L.ctx(), L.ptr(nd), K, n_out, L.ptr(local), L.ptr(ovf), L.stream_ptr()))
+    else:
+        L.check(lib.eyoc_spconv_build_local_rulebook_tile(L.ctx(), L.ptr(nd), K, n_out, tile, L.ptr(local), L.ptr(ovf), L.stream_ptr()))
+    assert int(ovf.item()) == 0, "a tile has more distinct input rows than two passes stage"
     xin = encode(torch.from_numpy(x).to(dev))
     rin = None if res is None else encode(torch.from_numpy(res).to(dev))
     out = torch.full((n_out, cout), -555.0, device=dev)
     wd, osd = torch.from_numpy(packed).to(dev), torch.from_numpy(os_).to(dev)
     bd = None if bias is None else torch.from_numpy(np.ascontiguousarray(bias, np.float32)).to(dev)
-    L.check(lib.eyoc_spconv_staged(L.ctx(), L.ptr(nd), L.ptr(local), n_out, x.shape[0], L.ptr(xin), xin.stride(0), cin, L.ptr(wd), cout,
-                                   L.ptr(bd), L.ptr(rin), 0 if rin is None else rin.stride(0), 1 if relu else 0, L.ptr(out),
-                                   out.stride(0), 1 if out_split else 0, L.ptr(osd), L.stream_ptr()), "eyoc_spconv_staged")
+    if tile == 256:
+        L.check(lib.eyoc_spconv_staged(L.ctx(), L.ptr(nd), L.ptr(local), n_out, x.shape[0], L.ptr(xin), xin.stride(0), cin, L.ptr(wd), cout,
+                                       L.ptr(bd), L.ptr(rin), 0 if rin is None else rin.stride(0), 1 if relu else 0, L.ptr(out),
+                                       out.stride(0), 1 if out_split else 0, L.ptr(osd), L.stream_ptr()), "eyoc_spconv_staged")
+    else:
+        L.check(lib.eyoc_spconv_staged_tile(L.ctx(), L.ptr(nd), L.ptr(local), tile, n_out, x.shape[0], L.ptr(xin), xin.stride(0), cin, L.ptr(wd),
+                                            cout, L.ptr(bd), L.ptr(rin), 0 if rin is None else rin.stride(0), 1 if relu else 0, L.ptr(out),
+                                            out.stride(0), 1 if out_split else 0, L.ptr(osd), L.stream_ptr()), "eyoc_spconv_staged_tile")
     if out_split:
         out = decode(out)
     torch.cuda.synchronize()
@@ -387,6 +396,53 @@ def test_staged_kernel_vs_fp64(morton_maps, cin, cout, level):
     print(f"staged {cin}->{cout} level {level}: n {n} err {e:.2e} / {e32:.2e}  distinct rows per tile mean {n_u.mean():.0f} max {n_u.max()}"
           f"  re-use {pairs / n_u.sum():.2f}x  empty (16-row chunk, offset) blocks {1 - (want_masks[:, :, None] >> np.arange(16) & 1).mean():.2f}")
     assert e < 2e-6 and e32 < 2e-6 and n_u.max() <= 1278 and n_u.min() >= 1
+
+
+@pytest.mark.parametrize("cin,cout,level", [(64, 64, 0), (32, 32, 0), (128, 128, 1), (256, 256, 2), (96, 64, 1), (64, 128, 3)])
+def test_staged_kernel_on_128_row_tiles_vs_fp64(morton_maps, cin, cout, level):
+    """spconv_st128.hip (128-row tiles, 40 KB stage, 128 VGPRs: four workgroups per CU) against the fp64 restatement at the
+    split16 bar and against the 256-row kernel (same products; tiles that take a second pass sum in another order, so equal to
+    fp32 rounding, not bitwise); with and without the empty-block branches bit-identical; the records: distinct rows per tile
+    and the 8-bit occupancy masks."""
+    nbr = morton_maps["s1"][level]
+    n = nbr.shape[1]
+    rng = np.random.default_rng(1000 + cin + cout + level)
+    x = np.abs(rng.normal(size=(n, cin))).astype(np.float32)
+    W = (rng.normal(size=(27, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    s = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    b = rng.normal(size=cout).astype(np.float32)
+    r = rng.normal(size=(n, cout)).astype(np.float32)
+    want = layer_f64(nbr, x, W, bias=b, scale=s, res=r, relu=True)
+    got, local = run_layer_staged(nbr, x, W, bias=b, scale=s, res=r, relu=True, tile=128)
+    got32, _ = run_layer_staged(nbr, x, W, bias=b, scale=s, res=r, relu=True, out_split=False, tile=128)
+    big, _ = run_layer_staged(nbr, x, W, bias=b, scale=s, res=r, relu=True, out_split=False, tile=256)
+    L, lib = _lib()
+    prev = lib.eyoc_spconv_select_st_kernel(2)                       # no empty-block branches
+    try:
+        noskip, _ = run_layer_staged(nbr, x, W, bias=b, scale=s, res=r, relu=True, out_split=False, tile=128)
+    finally:
+        lib.eyoc_spconv_select_st_kernel(prev)
+    np.testing.assert_array_equal(noskip, got32)
+    e, e32, d = rel_err(got, want), rel_err(got32, want), rel_err(got32, big)
+    REC, MASK_OFF, UOFF = 16512, 16400, 16
+    n_tiles = (n + 127) // 128
+    lr = local.cpu().numpy()[:n_tiles * REC].reshape(-1, REC)
+    n_u = lr[:, :4].copy().view(np.int32)[:, 0]
+    distinct = np.array([len(np.unique(t[t >= 0])) for t in np.array_split(nbr, np.arange(128, n, 128), axis=1)])
+    np.testing.assert_array_equal(n_u, distinct)
+    U = lr[:, UOFF:UOFF + 4 * 638].copy().view(np.int32)
+    for t in (0, n_tiles // 2, n_tiles - 1):                         # the row list is the set of distinct rows
+        cols = nbr[:, t * 128:(t + 1) * 128]
+        assert sorted(U[t, :n_u[t]].tolist()) == sorted(np.unique(cols[cols >= 0]).tolist())
+    masks = lr[:, MASK_OFF:MASK_OFF + 56].copy().view(np.uint16)[:, :27]
+    occ = np.zeros((n_tiles * 128, 27), bool)
+    occ[:n] = (nbr >= 0).T
+    want_masks = (occ.reshape(n_tiles, 8, 16, 27).any(axis=2) * (1 << np.arange(8))[None, :, None]).sum(axis=1)
+    single = n_u <= 319
+    np.testing.assert_array_equal(masks[single], want_masks[single].astype(np.uint16))
+    print(f"staged/128 {cin}->{cout} level {level}: n {n} err {e:.2e} / {e32:.2e}, vs 256-row kernel {d:.2e}; distinct rows per tile mean "
+          f"{n_u.mean():.0f} max {n_u.max()}, two-pass tiles {(n_u > 319).mean():.3f}")
+    assert e < 2e-6 and e32 < 2e-6 and d < 2e-6 and n_u.max() <= 638
 
 
 def test_local_rulebook_counts_tiles_it_cannot_stage_instead_of_hanging():

@@ -76,3 +76,39 @@ def test_generated_staged_loop_is_what_the_generator_writes(tmp_path):
     assert max(int(v) for v in re.findall(r"vmcnt\((\d+)\)", blob)) <= 63 and max(int(v) for v in re.findall(r"lgkmcnt\((\d+)\)", blob)) <= 15
     regs = [int(v) for v in re.findall(r"v\[(\d+):", blob)]
     assert min(regs) >= 64 and max(regs) <= 252                                   # v0 - v63 stay with the compiler
+
+
+def test_o3d_shim_covers_every_open3d_name_the_reference_call_site_uses():
+    """``import eyoc_amd.o3d as o3d`` must let scripts/test_kitti.py:159-177 and util/pointcloud.py:9-21 run unchanged: every
+    ``o3d.<...>`` attribute chain in those line ranges (read from the reference tree at run time - this container only) resolves
+    in the shim.  The call itself runs in tests/test_gpu_pose.py."""
+    import ast
+    import os
+    import pytest
+    ref = "/root/reference"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present")
+    import eyoc_amd.o3d as shim
+
+    def chains(path, lo, hi, encoding="utf-8"):
+        src = open(path, encoding=encoding).read().split("\n")
+        body = "\n".join(src[lo - 1:hi])
+        import textwrap
+        tree = ast.parse(textwrap.dedent(body))
+        out = set()
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Attribute):
+                parts, cur = [], node
+                while isinstance(cur, ast.Attribute):
+                    parts.append(cur.attr)
+                    cur = cur.value
+                if isinstance(cur, ast.Name) and cur.id == "o3d":
+                    out.add(tuple(reversed(parts)))
+        return out
+    used = chains(f"{ref}/scripts/test_kitti.py", 162, 177) | chains(f"{ref}/util/pointcloud.py", 9, 21)
+    assert ("pipelines", "registration", "registration_ransac_based_on_feature_matching") in used and len(used) >= 8
+    for chain in used:
+        obj = shim
+        for name in chain:
+            assert hasattr(obj, name), "eyoc_amd.o3d lacks o3d." + ".".join(chain)
+            obj = getattr(obj, name)
