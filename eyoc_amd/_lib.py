@@ -121,6 +121,10 @@ PROTOTYPES = {
     "eyoc_model_set_timing": (_i, [_vp, _i]),
     "eyoc_model_layer_ms": (_i, [_vp, C.POINTER(C.c_float)]),
     "eyoc_model_timing_slot": (_i, [_vp, _i]),
+    "eyoc_bn_workspace_bytes": (_sz, [_i, _i]),
+    "eyoc_bn_train_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, C.c_float, _i, _vp, _i, _vp, _vp, _sz, _vp]),
+    "eyoc_bn_train_backward": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, C.c_float, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "eyoc_maps_gather_window": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "eyoc_knn_prefilter": (_i, [_i]),
     "eyoc_spconv_select_up_kernel": (_i, [_i]),
     "eyoc_spconv_select_down_kernel": (_i, [_i]),

@@ -6,9 +6,10 @@ name registry of ``model/__init__.py:8-30``.  Parameters carry MinkowskiEngine's
 (``conv1.kernel [K,Cin,Cout]``, ``norm1.bn.weight``, ``block1.conv1.kernel``, ``final.bias [1,Cout]`` ...)
 so ``model.load_state_dict(torch.load(...)['state_dict'])`` works as in ``scripts/test_kitti.py:90-91``.
 
-Only the eval-mode forward exists (the path EYOC's test / labelling code uses); it runs entirely in
-``libeyoc_hip.so``: the parameters are folded (BN into conv) and packed once per weight version into a
-single device blob, which is also what ``eyoc_amd.dist`` broadcasts between ranks.
+The eval-mode forward (the path EYOC's test / labelling code uses) runs entirely in ``libeyoc_hip.so``: the parameters
+are folded (BN into conv) and packed once per weight version into a single device blob, which is also what
+``eyoc_amd.dist`` broadcasts between ranks.  In training mode ``model(x)`` is a differentiable layer-by-layer forward with
+batch statistics (``eyoc_amd/train.py``).
 """
 from __future__ import annotations
 
@@ -229,13 +230,14 @@ class ResUNet2(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: SparseTensor) -> SparseTensor:
-        if self.training:
-            raise NotImplementedError("training-mode forward (batch statistics, autograd) is outside the "
-                                      "registration hot path; call model.eval()")
         if not isinstance(x, SparseTensor):
             raise TypeError("expected an eyoc_amd.SparseTensor")
         if x.F.shape[1] != self.in_channels:
             raise ValueError(f"features have {x.F.shape[1]} channels, model expects {self.in_channels}")
+        if self.training:
+            # batch statistics + autograd (lib/trainer.py:1655-1676): layer-by-layer autograd Functions, eyoc_amd/train.py
+            from .train import forward_train
+            return forward_train(self, x)
         dev = x.device
         if self._handle is None or self._packed_device != dev:
             self.pack(dev)

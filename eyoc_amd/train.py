@@ -1,0 +1,131 @@
+"""Training-mode forward of ``ResUNet2`` with autograd.
+
+``lib/trainer.py:1655-1676`` runs ``model(sinput)`` in train mode and ``loss.backward()`` through MinkowskiEngine.  Here
+``model.train()(x)`` returns a ``SparseTensor`` whose ``.F`` carries a graph of ``torch.autograd.Function`` nodes that run in
+``libeyoc_hip.so``:
+
+  * every sparse convolution = ``autograd.sparse_conv`` (fp32 MFMA forward; grad-input = the forward kernel over the transposed
+    rulebook; grad-weight = ``eyoc_spconv_grad_weight``);
+  * the first convolution (C_in = 1 in production: nothing for the 32-channel-block kernels to chew on) = the 5^3 window
+    gathered into a dense ``[N, 125]`` matrix by ``eyoc_maps_gather_window`` and one plain product with the ``[125, 32]``
+    kernel (a library GEMM; its weight gradient is the transposed product);
+  * batch normalisation with batch statistics = ``eyoc_bn_train_forward / _backward`` (fp64 sums in a fixed order), the ReLU that
+    follows a norm fused into it; running statistics updated like ``nn.BatchNorm1d`` (momentum, unbiased variance);
+  * the two 1x1 layers at the end are plain ``[N, C] x [C, C']`` products (library GEMMs); residual adds, concatenations and
+    the final row normalisation are element-wise torch ops.
+
+Same layer graph as the eval forward (model/resunet.py:142-193, model/residual_block.py:37-53); the maps are built in the
+caller's row order.  Eval-mode inference does not come through here (it runs the fused, folded kernels of ``model.hip``)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .autograd import sparse_conv
+from .sparse_tensor import SparseTensor
+
+MAP_S1, MAP_DOWN, MAP_UP = 0, 1, 2
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu):
+        x = x.contiguous()
+        n, c = x.shape
+        lib = _lib.load()
+        y = torch.empty_like(x)
+        stats = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            ws = _lib.workspace(lib.eyoc_bn_workspace_bytes(n, c), x.device)
+            _lib.check(lib.eyoc_bn_train_forward(_lib.ctx(x.device.index), _lib.ptr(x), n, c, x.stride(0), _lib.ptr(gamma.contiguous()),
+                                                 _lib.ptr(beta.contiguous()), float(eps), 1 if relu else 0, _lib.ptr(y), y.stride(0),
+                                                 _lib.ptr(stats), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "eyoc_bn_train_forward")
+        ctx.save_for_backward(x, y if relu else None, gamma, stats)
+        ctx.eps, ctx.relu = float(eps), bool(relu)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        x, y, gamma, stats = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, c = x.shape
+        lib = _lib.load()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            ws = _lib.workspace(lib.eyoc_bn_workspace_bytes(n, c), x.device)
+            _lib.check(lib.eyoc_bn_train_backward(_lib.ctx(x.device.index), _lib.ptr(x), x.stride(0), _lib.ptr(y), 0 if y is None else y.stride(0),
+                                                  _lib.ptr(dy), dy.stride(0), n, c, _lib.ptr(gamma.contiguous()), _lib.ptr(stats), ctx.eps,
+                                                  _lib.ptr(dx), dx.stride(0), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), ws.numel(),
+                                                  _lib.stream_ptr()), "eyoc_bn_train_backward")
+        return dx, dgamma, dbeta, None, None
+
+
+def batch_norm_train(x: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool = False) -> torch.Tensor:
+    """``MinkowskiBatchNorm`` in training mode (model/common.py:4-6): normalise with the batch's own statistics and move
+    the running statistics by ``momentum`` (unbiased variance, ``num_batches_tracked + 1``) exactly like ``nn.BatchNorm1d``."""
+    y, stats = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps, relu)
+    if bn.track_running_stats and bn.running_mean is not None:
+        n, c = x.shape
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            mean, var = stats[:c], stats[c:]
+            bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+            bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
+    return y
+
+
+def gather_window(cm, feats: torch.Tensor, ks: int) -> torch.Tensor:
+    """``[N, ks^3 * C_in]``: every row's ``ks^3`` window of input features (zeros where no voxel is), caller's row order."""
+    n, cin = feats.shape
+    out = torch.empty((n, ks ** 3 * cin), dtype=torch.float32, device=feats.device)
+    with torch.cuda.device(feats.device):
+        _lib.check(_lib.load().eyoc_maps_gather_window(_lib.ctx(feats.device.index), cm._caller_maps(), int(ks), _lib.ptr(feats.contiguous()),
+                                                       cin, _lib.ptr(out), _lib.stream_ptr()), "eyoc_maps_gather_window")
+    return out
+
+
+def forward_train(model, x: SparseTensor, taps: dict | None = None) -> SparseTensor:
+    """model/resunet.py:142-193 with batch statistics; every parameter of ``model`` receives a gradient from ``.backward()``.
+    ``taps`` (tests / diagnostics): receives every rectified tensor under its layer's name (``block1.conv1`` = after the
+    block's first norm + ReLU, ``block1.conv2`` = the block's output, ..., ``conv1_tr``) - the ReLU decisions of this forward."""
+    cm = x.coordinate_manager
+    s1 = [cm.table(MAP_S1, l) for l in range(4)]
+    down = [cm.table(MAP_DOWN, l) for l in range(3)]
+    up = [cm.table(MAP_UP, l) for l in range(3)]
+
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = t
+        return t
+
+    def block(t, blk, table, name):
+        """BasicBlockBN (model/residual_block.py:37-53): relu(bn2(conv2(relu(bn1(conv1(x))))) + x)"""
+        out = tap(name + ".conv1", batch_norm_train(sparse_conv(t, blk.conv1.kernel, table), blk.norm1.bn, relu=True))
+        out = batch_norm_train(sparse_conv(out, blk.conv2.kernel, table), blk.norm2.bn)
+        return tap(name + ".conv2", torch.relu(out + t))
+
+    # encoder (:143-161).  conv1: window gather + one dense product (C_in is tiny)
+    G = gather_window(cm, x.F, model.conv1_kernel_size)
+    out_s1 = block(batch_norm_train(G @ model.conv1.kernel.reshape(-1, model.conv1.cout), model.norm1.bn), model.block1, s1[0], "block1")
+    out_s2 = block(batch_norm_train(sparse_conv(out_s1, model.conv2.kernel, down[0], up[0]), model.norm2.bn), model.block2, s1[1], "block2")
+    out_s4 = block(batch_norm_train(sparse_conv(out_s2, model.conv3.kernel, down[1], up[1]), model.norm3.bn), model.block3, s1[2], "block3")
+    out_s8 = block(batch_norm_train(sparse_conv(out_s4, model.conv4.kernel, down[2], up[2]), model.norm4.bn), model.block4, s1[3], "block4")
+    # decoder (:163-186); ME.cat order is [decoder | skip]
+    out = block(batch_norm_train(sparse_conv(out_s8, model.conv4_tr.kernel, up[2], down[2]), model.norm4_tr.bn), model.block4_tr, s1[2], "block4_tr")
+    out = torch.cat([out, out_s4], 1)
+    out = block(batch_norm_train(sparse_conv(out, model.conv3_tr.kernel, up[1], down[1]), model.norm3_tr.bn), model.block3_tr, s1[1], "block3_tr")
+    out = torch.cat([out, out_s2], 1)
+    out = block(batch_norm_train(sparse_conv(out, model.conv2_tr.kernel, up[0], down[0]), model.norm2_tr.bn), model.block2_tr, s1[0], "block2_tr")
+    out = torch.cat([out, out_s1], 1)
+    # the two 1x1 layers (:183-186) are plain dense products (96 -> 64 -> 32): library GEMMs, forward and backward
+    out = tap("conv1_tr", torch.relu(out @ model.conv1_tr.kernel))
+    out = out @ model.final.kernel + model.final.bias
+    if model.normalize_feature:
+        out = out / torch.norm(out, p=2, dim=1, keepdim=True)          # no epsilon (model/resunet.py:187-191)
+    return SparseTensor(out, coordinate_map_key=x.coordinate_map_key, coordinate_manager=cm)

@@ -404,6 +404,29 @@ int eyoc_kabsch_batched(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, c
 int eyoc_irls_quad(eyoc_ctx* ctx, const float* p0_dev, const float* p1_dev, const float* w_dev, int n,
                    int iters, float* T_dev, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * training-mode support (lib/trainer.py:1655-1676 back-propagates through the network in train mode)
+ * --------------------------------------------------------------------------------------------- */
+/* replaces: MinkowskiBatchNorm in training mode (model/common.py:4-6 = nn.BatchNorm1d over the rows): per-channel batch mean
+ * and BIASED variance of x f32 [n, c] (rows ld_x floats apart) -> mean_var_dev f32 [2 c] = {mean, variance};
+ * y = (x - mean) / sqrt(var + eps) * gamma + beta, then ReLU if `relu`.  c must divide 256 (32 ... 256 in this model family).
+ * The statistics are summed in fp64 in a fixed order (bit-reproducible).  The running-statistics update (momentum, unbiased
+ * variance) is host glue on the returned 2 c floats.  Workspace: eyoc_bn_workspace_bytes(n, c), caller-owned. */
+size_t eyoc_bn_workspace_bytes(int n, int c);
+int eyoc_bn_train_forward(eyoc_ctx* ctx, const float* x_dev, int n, int c, int ld_x, const float* gamma_dev, const float* beta_dev,
+                          float eps, int relu, float* y_dev, int ld_y, float* mean_var_dev, void* workspace_dev, size_t workspace_bytes,
+                          void* stream);
+/* Its backward: dy' = dy where y > 0 (y_dev = the forward's output when a ReLU was fused, else NULL);
+ * dbeta = sum dy', dgamma = sum dy' xhat, dx = gamma / sigma (dy' - dbeta / n - xhat dgamma / n). */
+int eyoc_bn_train_backward(eyoc_ctx* ctx, const float* x_dev, int ld_x, const float* y_dev, int ld_y, const float* dy_dev, int ld_dy, int n,
+                           int c, const float* gamma_dev, const float* mean_var_dev, float eps, float* dx_dev, int ld_dx,
+                           float* dgamma_dev, float* dbeta_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+/* The first convolution's window as a dense matrix (model/resunet.py:31-38, C_in = 1 in production, K = ks^3):
+ * out f32 [n, ks^3 * cin], out[row][k * cin + c] = feats[voxel at window offset k of row][c] or 0 (offsets x fastest, like every
+ * rulebook) - the convolution and its weight gradient are then plain [n, K cin] x [K cin, C_out] products.  The maps must keep the
+ * caller's row order (eyoc_maps_build_ordered with order 0); builds the level-0 hash table on first use. */
+int eyoc_maps_gather_window(eyoc_ctx* ctx, eyoc_maps* maps, int ks, const float* feats_dev, int cin, float* out_dev, void* stream);
+
 /* replaces: o3d.pipelines.registration.registration_ransac_based_on_feature_matching(..., 4,
  * [EdgeLength(0.9), Distance(d)], RANSACConvergenceCriteria(4000000, 10000))
  * (scripts/test_kitti.py:169-177) given the feature correspondences.  Hypothesis h samples

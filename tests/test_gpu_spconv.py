@@ -248,8 +248,8 @@ def test_model_api_surface():
     assert tuple(m.state_dict()["final.bias"].shape) == (1, 32)
     x = eyoc_amd.SparseTensor(torch.ones(4, 1).cuda(), coordinates=torch.tensor([[0, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0],
                                                                                [0, 5, 5, 5]], dtype=torch.int32).cuda())
-    with pytest.raises(NotImplementedError):
-        m.cuda().train()(x)
+    tr = m.cuda().train()(x)                              # training mode: batch statistics + autograd (tests/test_gpu_train.py)
+    assert tr.F.shape == (4, 32) and tr.F.requires_grad
     out = m.cuda().eval()(x)
     assert out.F.shape == (4, 32) and len(out) == 4 and out.C.shape == (4, 4)
     cs, fs = out.decomposed_coordinates_and_features

@@ -1,0 +1,140 @@
+"""A training step through the whole network (lib/trainer.py:1655-1676: forward in train mode, loss,
+``loss.backward()``, optimiser step).  ``model.train()(x)`` = eyoc_amd/train.py: batch-statistics batch norm kernels, the first
+convolution as window gather + dense product, every other convolution as an autograd Function over the HIP kernels.  Checker:
+``oracle/resunet.py`` in training mode under torch autograd on the CPU (its batch norm is pinned to ``nn.BatchNorm1d`` in
+tests/test_oracle_sparse.py).  Bar: features and every parameter gradient within 1e-4 of the tensor's largest entry."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import eyoc_amd
+    from eyoc_amd import synthetic as syn
+    p = syn.make_pair(5, beams=16, azimuths=500, band=None)             # two ~2.5k-voxel clouds
+    coords = syn.batch_coords([p["coords0"], p["coords1"]])
+    feats = np.random.default_rng(0).uniform(0.5, 1.5, size=(len(coords), 1)).astype(np.float32)
+    sd = syn.make_weights(seed=21)
+    model = eyoc_amd.load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, conv1_kernel_size=5, normalize_feature=True)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    return model.cuda(), sd, coords, feats
+
+
+def test_one_sgd_step_matches_the_oracle_under_autograd(setup):
+    import eyoc_amd
+    from oracle import resunet as orr
+    model, sd, coords, feats = setup
+    assert 3000 <= len(coords) <= 12000
+    rng = np.random.default_rng(1)
+    target = rng.normal(size=(len(coords), 32)).astype(np.float32)
+
+    # ---- product first: its ReLU decisions are handed to the oracle (two fp32 implementations agree on a pre-activation to
+    # ~1e-7, so the one or two of the ~5 M that round across zero get opposite decisions - the value does not care, the
+    # gradient entry flips between g and 0 and takes its neighbourhood with it: measured 7e-3 on block3.conv2.kernel from ONE
+    # such entry).  Checked separately below: the decisions differ from the oracle's own only where both values are ~0.
+    from eyoc_amd.train import forward_train
+    model.train()
+    x = eyoc_amd.SparseTensor(torch.from_numpy(feats).cuda(), coordinates=torch.from_numpy(coords).cuda())
+    opt = torch.optim.SGD(model.parameters(), lr=0.01)
+    opt.zero_grad()
+    taps = {}
+    out = forward_train(model, x, taps)
+    assert out.F.requires_grad and out.F.shape == (len(coords), 32)
+    (out.F * torch.from_numpy(target).cuda()).sum().backward()
+    masks = {k: (v.detach() > 0).float().cpu() for k, v in taps.items()}
+    assert len(masks) == 15
+
+    def oracle(dtype, relu_masks):
+        sdt = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in sd.items()}
+        for k in sdt:
+            if sdt[k].is_floating_point():
+                sdt[k] = sdt[k].to(dtype)
+        params = [k for k in sdt if k.endswith(".kernel") or k.endswith("bn.weight") or k.endswith("bn.bias") or k == "final.bias"]
+        for k in params:
+            sdt[k].requires_grad_(True)
+        running = {}
+        want, inter, _ = orr.resunet_forward(sdt, coords, feats, train=True, bn_momentum=0.05, running_out=running, dtype=dtype,
+                                             relu_masks=relu_masks, return_intermediate=True)
+        (want * torch.from_numpy(target).to(dtype)).sum().backward()
+        return sdt, params, running, want, inter["stored"]
+    sdt, params, running, want, _ = oracle(torch.float32, masks)
+    _, _, _, want_free, stored_free = oracle(torch.float32, None)
+    # the decisions: identical to the oracle's own except where the rectified value is within rounding of zero on both sides
+    flips = 0
+    for k, m in masks.items():
+        own = stored_free[k].detach() > 0
+        diff = own != (m > 0)
+        flips += int(diff.sum())
+        if diff.any():
+            assert float(stored_free[k].detach()[diff].abs().max()) < 1e-5 and float(taps[k].detach().cpu()[diff].abs().max()) < 1e-5, k
+    assert flips <= 20
+    e_f = rel_err(out.F.detach().cpu().numpy(), want_free.detach().numpy())
+    named = dict(model.named_parameters())
+    assert set(named) == set(params)
+    errs = {}
+    for k in params:
+        g = named[k].grad
+        assert g is not None, f"{k} has no gradient"
+        errs[k] = rel_err(g.cpu().numpy().reshape(-1), sdt[k].grad.numpy().reshape(-1))
+    worst = max(errs, key=errs.get)
+    print(f"train step on {len(coords)} voxels: features {e_f:.2e}; {flips} ReLU decisions differ from the oracle's own (all at |x| < 1e-5); "
+          f"worst parameter gradient {worst} {errs[worst]:.2e}")
+    assert e_f < REL and errs[worst] < REL, (worst, errs[worst])
+    # model(x) in training mode is that forward (run under a snapshot of the running statistics: a second forward moves them again)
+    snap = {k: v.clone() for k, v in model.named_buffers()}
+    again = model(x)
+    assert again.F.requires_grad and torch.equal(again.F.detach(), out.F.detach())
+    with torch.no_grad():
+        for k, v in model.named_buffers():
+            v.copy_(snap[k])
+    # running statistics moved like nn.BatchNorm1d (momentum 0.05, unbiased variance)
+    bufs = dict(model.named_buffers())
+    for k, v in running.items():
+        np.testing.assert_allclose(bufs[k].cpu().numpy(), v.numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+    assert int(bufs["norm1.bn.num_batches_tracked"]) == 1
+
+    # ---- the optimiser step lands in the eval forward: same features as the oracle with the same SGD update applied
+    opt.step()
+    sd2 = {k: v.detach().numpy().copy() for k, v in sdt.items()}
+    for k in params:
+        sd2[k] = sd2[k] - 0.01 * sdt[k].grad.numpy()
+    sd2.update({k: v.numpy() for k, v in running.items()})
+    model.eval()
+    with torch.no_grad():
+        got_eval = model(x).F.cpu().numpy()
+    want_eval = orr.resunet_forward(sd2, coords, feats).numpy()
+    assert rel_err(got_eval, want_eval) < REL
+    model.train()
+
+
+def test_batch_norm_kernels_against_torch(setup):
+    """eyoc_bn_train_forward / _backward alone: every channel count of the model family, ragged row counts, with and without the
+    fused ReLU, strided rows; statistics bit-reproducible."""
+    from eyoc_amd.train import _BatchNormTrain
+    rng = np.random.default_rng(2)
+    for n, c, relu in ((1, 32, False), (63, 64, True), (5000, 128, True), (70001, 256, False), (4097, 32, True)):
+        x = torch.from_numpy(rng.normal(0.5, 1.5, size=(n, c)).astype(np.float32)).cuda().requires_grad_(True)
+        g = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)).cuda().requires_grad_(True)
+        b = torch.from_numpy(rng.normal(size=c).astype(np.float32)).cuda().requires_grad_(True)
+        dy = torch.from_numpy(rng.normal(size=(n, c)).astype(np.float32)).cuda()
+        y, stats = _BatchNormTrain.apply(x, g, b, 1e-5, relu)
+        y.backward(dy)
+        xr, gr, br = (t.detach().cpu().double().requires_grad_(True) for t in (x, g, b))
+        ref = torch.nn.functional.batch_norm(xr, None, None, gr, br, training=True, eps=1e-5) if n > 1 else (xr - xr) * gr + br
+        if relu:
+            ref = torch.relu(ref)
+        ref.backward(dy.cpu().double())
+        assert rel_err(y.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
+        for got, want in ((x.grad, xr.grad), (g.grad, gr.grad), (b.grad, br.grad)):
+            assert rel_err(got.cpu().numpy(), want.numpy()) < 1e-4, (n, c, relu)
+        y2, stats2 = _BatchNormTrain.apply(x, g, b, 1e-5, relu)
+        assert torch.equal(stats, stats2) and torch.equal(y, y2)

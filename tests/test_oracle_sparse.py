@@ -201,3 +201,39 @@ def test_similarity_mask_against_an_independent_torch_formulation():
         got = ol.similarity_mask(C0, C1, a, b, table, frame_distance, 0.4)
         # torch.norm and the oracle's fixed-order fp32 norm can differ in the last bit: allow the cells on a boundary
         assert (got != want).sum() <= 3, int((got != want).sum())
+
+
+def test_training_mode_batch_norm_is_torch_batchnorm1d():
+    """MinkowskiBatchNorm is ``nn.BatchNorm1d`` applied to the feature rows (model/common.py:4-6 -> ME's wrapper): the oracle's
+    training-mode norm (batch mean, biased variance, running statistics moved by ``momentum`` with the unbiased variance) against
+    torch's own module - output, both gradients and the running statistics it leaves behind."""
+    import torch
+    from oracle import resunet as orr
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.normal(1.0, 2.0, size=(257, 32)).astype(np.float32))
+    bn = torch.nn.BatchNorm1d(32, momentum=0.05)
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, 32).astype(np.float32)))
+        bn.bias.copy_(torch.from_numpy(rng.normal(size=32).astype(np.float32)))
+        bn.running_mean.copy_(torch.from_numpy(rng.normal(size=32).astype(np.float32)))
+        bn.running_var.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, 32).astype(np.float32)))
+    sd = {f"n.bn.{k}": v.detach().clone() for k, v in bn.state_dict().items()}
+    sd["n.bn.weight"].requires_grad_(True); sd["n.bn.bias"].requires_grad_(True)
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    g = torch.from_numpy(rng.normal(size=(257, 32)).astype(np.float32))
+    bn.train()
+    want = bn(x1)
+    want.backward(g)
+    running = {}
+    orr._TRAIN.update(on=True, momentum=0.05, running=running)
+    try:
+        got = orr.batch_norm(x2, sd, "n")
+    finally:
+        orr._TRAIN.update(on=False, running=None)
+    got.backward(g)
+    np.testing.assert_allclose(got.detach().numpy(), want.detach().numpy(), atol=2e-6)
+    np.testing.assert_allclose(x2.grad.numpy(), x1.grad.numpy(), atol=2e-6)
+    np.testing.assert_allclose(sd["n.bn.weight"].grad.numpy(), bn.weight.grad.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(sd["n.bn.bias"].grad.numpy(), bn.bias.grad.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(running["n.bn.running_mean"].numpy(), bn.running_mean.numpy(), atol=1e-6)
+    np.testing.assert_allclose(running["n.bn.running_var"].numpy(), bn.running_var.numpy(), atol=1e-6)
