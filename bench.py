@@ -190,7 +190,7 @@ def cpu_baseline(pairs, seeds, sd, descriptor, sample_hyp=200000, full_hyp=40000
     extra = {"sc2pcr_path": {"value": 1.0 / t_sc2, "unit": "pairs/s", "sample": f"1 pair: 2 oracle forwards + Matcher.estimator ({t_sc2:.1f} s)"}} \
         if len(times) > 1 else {}
     return {**extra, "value": 1.0 / med[0], "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": (f"median of {len(timed)} pairs after 1 warm-up pair; per pair: 2 oracle forwards ({med[1]:.2f} s) + "
+            "sample": (f"extrapolated: the RANSAC leg times {sample_hyp} of {full_hyp} hypotheses and scales; median of {len(timed)} pairs after 1 warm-up pair; per pair: 2 oracle forwards ({med[1]:.2f} s) + "
                        f"5000x5000 NN ({med[2]:.2f} s) + {sample_hyp} of {full_hyp} RANSAC hypotheses "
                        f"(time x{full_hyp // sample_hyp} = {med[3]:.1f} s)")}
 
@@ -219,6 +219,18 @@ def records_of(results, batch, rank, cfg):
         rec[p, :16] = r.transformation.astype(np.float32).reshape(16)
         rec[p, 16:] = (rte, np.rad2deg(rre), float(ok), float(rank))
     return rec
+
+
+def csrc_sha16():
+    """Fingerprint of the kernel sources (eyoc_amd/csrc: *.hip, *.h, the generator): what a committed counter profile is valid for."""
+    import hashlib
+    d = os.path.join(ROOT, "eyoc_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".py")) :
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def timed_rate(pipe, batch, reps, warm=1):
@@ -464,9 +476,15 @@ def worker(args):
     out["survivors_per_pair"] = float(np.mean([r.survivors for b in last.values() for r in b]))
     # HBM traffic of the same kernels from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
     # WRITE_SIZE, separate passes; profiles/README.md) - quoted only when they were taken on this workload
-    for tag in ("r3", "r2", "r1"):
+    # AND on these kernel sources (the profile records a hash of eyoc_amd/csrc; a kernel change without a profile refresh must
+    # not keep quoting the old counters)
+    for tag in ("r4", "r3", "r2", "r1"):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_spconv_traffic.json")))
+            if prof["workload"] == out["config"]["workload"] and prof.get("csrc_sha16") != csrc_sha16():
+                out["roofline"]["traffic_note"] = (f"profiles/{tag}_spconv_traffic.json was taken on other kernel sources "
+                                                   f"(csrc {prof.get('csrc_sha16')} != {csrc_sha16()}): not quoted")
+                continue
             if prof["workload"] == out["config"]["workload"]:
                 traffic = (prof["spconv_read_GB_per_forward_x2corr"] + prof["spconv_write_GB_per_forward"]) * 1e9
                 out["roofline"]["traffic"] = traffic

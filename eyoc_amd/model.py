@@ -55,6 +55,7 @@ class _Block(nn.Module):
 
 
 class ResUNet2(nn.Module):
+    EXPANDED = False
     NORM_TYPE = None
     BLOCK_NORM_TYPE = 'BN'
     CHANNELS = [None, 32, 64, 128, 256]
@@ -84,6 +85,10 @@ class ResUNet2(nn.Module):
         self.conv4_tr = _Conv(27, Cn[4], T[4]); self.norm4_tr = _Norm(T[4], m); self.block4_tr = _Block(T[4], m)
         self.conv3_tr = _Conv(27, Cn[3] + T[4], T[3]); self.norm3_tr = _Norm(T[3], m); self.block3_tr = _Block(T[3], m)
         self.conv2_tr = _Conv(27, Cn[2] + T[3], T[2]); self.norm2_tr = _Norm(T[2], m); self.block2_tr = _Block(T[2], m)
+        if self.EXPANDED:            # ResUNetExpanded (model/resunet.py:254-425): a second norm + block per stage
+            for i, c in (("1", Cn[1]), ("2", Cn[2]), ("3", Cn[3]), ("4", Cn[4]), ("4_tr", T[4]), ("3_tr", T[3]), ("2_tr", T[2])):
+                setattr(self, f"norm{i}_2", _Norm(c, m))
+                setattr(self, f"block{i}_2", _Block(c, m))
         self.conv1_tr = _Conv(1, Cn[1] + T[2], T[1])
         self.final = _Conv(1, T[1], out_channels, bias=True)
         self._handle = None      # eyoc_model*
@@ -234,10 +239,14 @@ class ResUNet2(nn.Module):
             raise TypeError("expected an eyoc_amd.SparseTensor")
         if x.F.shape[1] != self.in_channels:
             raise ValueError(f"features have {x.F.shape[1]} channels, model expects {self.in_channels}")
-        if self.training:
-            # batch statistics + autograd (lib/trainer.py:1655-1676): layer-by-layer autograd Functions, eyoc_amd/train.py
-            from .train import forward_train
-            return forward_train(self, x)
+        if self.training or self.EXPANDED:
+            # training mode: batch statistics + autograd (lib/trainer.py:1655-1676).  The Expanded variants (a second norm behind
+            # every ReLU: not foldable into a convolution) run layer by layer in eval mode too - functional, not the fused path
+            from .train import forward_layers
+            if self.training:
+                return forward_layers(self, x)
+            with torch.no_grad():
+                return forward_layers(self, x)
         dev = x.device
         if self._handle is None or self._packed_device != dev:
             self.pack(dev)
@@ -395,7 +404,20 @@ class ResUNetFatBN(ResUNet2):
     TR_CHANNELS = [None, 128, 128, 128, 256]
 
 
-MODELS = [ResUNet2, ResUNetBN2, ResUNetBN2B, ResUNetBN2C, ResUNetBN2D, ResUNetBN2E, ResUNetFatBN]
+class ResUNetExpanded(ResUNet2):
+    """model/resunet.py:254-484: ``ResUNet2`` with ``norm<i>_2`` + ``block<i>_2`` behind every stage's block.  Runs layer by layer
+    (``eyoc_amd/train.py``) in both modes; the packed / fused eval kernels serve the ``ResUNet2`` family only."""
+    EXPANDED = True
+    NORM_TYPE = None
+
+
+class ResUNetExpBN2C(ResUNetExpanded):
+    NORM_TYPE = 'BN'
+    CHANNELS = [None, 32, 64, 128, 256]
+    TR_CHANNELS = [None, 64, 64, 64, 128]
+
+
+MODELS = [ResUNet2, ResUNetBN2, ResUNetBN2B, ResUNetBN2C, ResUNetBN2D, ResUNetBN2E, ResUNetFatBN, ResUNetExpanded, ResUNetExpBN2C]
 
 
 def load_model(name):

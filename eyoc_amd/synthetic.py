@@ -378,7 +378,7 @@ def plant_correspondences(pair, seed, n_points=5000, inlier_ratio=0.3, plant_rad
 # (name, kernel volume, C_in, C_out) in the order ResUNet2.__init__ creates them
 # (model/resunet.py:31-140 with the ResUNetBN2C tables at :206-209).
 def RESUNET_BN2C_LAYOUT(in_channels=1, out_channels=32, conv1_kernel_size=5,
-                        channels=(None, 32, 64, 128, 256), tr_channels=(None, 64, 64, 64, 128)):
+                        channels=(None, 32, 64, 128, 256), tr_channels=(None, 64, 64, 64, 128), expanded=False):
     C, T = channels, tr_channels
     k1 = conv1_kernel_size ** 3
     convs = [("conv1", k1, in_channels, C[1])]
@@ -395,6 +395,11 @@ def RESUNET_BN2C_LAYOUT(in_channels=1, out_channels=32, conv1_kernel_size=5,
     convs.append(("conv2_tr", 27, C[2] + T[3], T[2])); bns.append(("norm2_tr", T[2])); block("block2_tr", T[2])
     convs.append(("conv1_tr", 1, C[1] + T[2], T[1]))
     convs.append(("final", 1, T[1], out_channels))
+    if expanded:       # ResUNetExpanded (model/resunet.py:254-425): norm<i>_2 + block<i>_2 per stage, appended so the plain layout's draws stay put
+        last = convs.pop()
+        for i, c in (("1", C[1]), ("2", C[2]), ("3", C[3]), ("4", C[4]), ("4_tr", T[4]), ("3_tr", T[3]), ("2_tr", T[2])):
+            bns.append((f"norm{i}_2", c)); block(f"block{i}_2", c)
+        convs.append(last)
     return convs, bns
 
 

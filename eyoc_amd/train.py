@@ -94,36 +94,59 @@ def forward_train(model, x: SparseTensor, taps: dict | None = None) -> SparseTen
     """model/resunet.py:142-193 with batch statistics; every parameter of ``model`` receives a gradient from ``.backward()``.
     ``taps`` (tests / diagnostics): receives every rectified tensor under its layer's name (``block1.conv1`` = after the
     block's first norm + ReLU, ``block1.conv2`` = the block's output, ..., ``conv1_tr``) - the ReLU decisions of this forward."""
+    return forward_layers(model, x, taps)
+
+
+def forward_layers(model, x: SparseTensor, taps: dict | None = None) -> SparseTensor:
+    """The network layer by layer through the autograd Functions above - ``ResUNet2`` (model/resunet.py:142-193) and
+    ``ResUNetExpanded`` (:254-484: every stage runs a second norm + block, ``norm<i>_2`` / ``block<i>_2``).  In training mode
+    every norm uses batch statistics; in eval mode its running statistics (a per-channel affine, element-wise)."""
     cm = x.coordinate_manager
     s1 = [cm.table(MAP_S1, l) for l in range(4)]
     down = [cm.table(MAP_DOWN, l) for l in range(3)]
     up = [cm.table(MAP_UP, l) for l in range(3)]
+    expanded = bool(getattr(model, "EXPANDED", False))
 
     def tap(name, t):
         if taps is not None:
             taps[name] = t
         return t
 
+    def norm(t, n, relu=False):
+        if model.training:
+            return batch_norm_train(t, n.bn, relu)
+        bn = n.bn
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        y = t * scale + (bn.bias - bn.running_mean * scale)
+        return torch.relu(y) if relu else y
+
     def block(t, blk, table, name):
         """BasicBlockBN (model/residual_block.py:37-53): relu(bn2(conv2(relu(bn1(conv1(x))))) + x)"""
-        out = tap(name + ".conv1", batch_norm_train(sparse_conv(t, blk.conv1.kernel, table), blk.norm1.bn, relu=True))
-        out = batch_norm_train(sparse_conv(out, blk.conv2.kernel, table), blk.norm2.bn)
+        out = tap(name + ".conv1", norm(sparse_conv(t, blk.conv1.kernel, table), blk.norm1, relu=True))
+        out = norm(sparse_conv(out, blk.conv2.kernel, table), blk.norm2)
         return tap(name + ".conv2", torch.relu(out + t))
 
-    # encoder (:143-161).  conv1: window gather + one dense product (C_in is tiny)
+    def stage(t, name, table):
+        """``norm -> block (-> relu, already rectified) [-> norm_2 -> block_2]`` on the output of the stage's convolution"""
+        out = block(norm(t, getattr(model, "norm" + name)), getattr(model, "block" + name), table, "block" + name)
+        if expanded:
+            out = block(norm(out, getattr(model, f"norm{name}_2")), getattr(model, f"block{name}_2"), table, f"block{name}_2")
+        return out
+
+    # encoder.  conv1: window gather + one dense product (C_in is tiny)
     G = gather_window(cm, x.F, model.conv1_kernel_size)
-    out_s1 = block(batch_norm_train(G @ model.conv1.kernel.reshape(-1, model.conv1.cout), model.norm1.bn), model.block1, s1[0], "block1")
-    out_s2 = block(batch_norm_train(sparse_conv(out_s1, model.conv2.kernel, down[0], up[0]), model.norm2.bn), model.block2, s1[1], "block2")
-    out_s4 = block(batch_norm_train(sparse_conv(out_s2, model.conv3.kernel, down[1], up[1]), model.norm3.bn), model.block3, s1[2], "block3")
-    out_s8 = block(batch_norm_train(sparse_conv(out_s4, model.conv4.kernel, down[2], up[2]), model.norm4.bn), model.block4, s1[3], "block4")
-    # decoder (:163-186); ME.cat order is [decoder | skip]
-    out = block(batch_norm_train(sparse_conv(out_s8, model.conv4_tr.kernel, up[2], down[2]), model.norm4_tr.bn), model.block4_tr, s1[2], "block4_tr")
+    out_s1 = stage(G @ model.conv1.kernel.reshape(-1, model.conv1.cout), "1", s1[0])
+    out_s2 = stage(sparse_conv(out_s1, model.conv2.kernel, down[0], up[0]), "2", s1[1])
+    out_s4 = stage(sparse_conv(out_s2, model.conv3.kernel, down[1], up[1]), "3", s1[2])
+    out_s8 = stage(sparse_conv(out_s4, model.conv4.kernel, down[2], up[2]), "4", s1[3])
+    # decoder; ME.cat order is [decoder | skip]
+    out = stage(sparse_conv(out_s8, model.conv4_tr.kernel, up[2], down[2]), "4_tr", s1[2])
     out = torch.cat([out, out_s4], 1)
-    out = block(batch_norm_train(sparse_conv(out, model.conv3_tr.kernel, up[1], down[1]), model.norm3_tr.bn), model.block3_tr, s1[1], "block3_tr")
+    out = stage(sparse_conv(out, model.conv3_tr.kernel, up[1], down[1]), "3_tr", s1[1])
     out = torch.cat([out, out_s2], 1)
-    out = block(batch_norm_train(sparse_conv(out, model.conv2_tr.kernel, up[0], down[0]), model.norm2_tr.bn), model.block2_tr, s1[0], "block2_tr")
+    out = stage(sparse_conv(out, model.conv2_tr.kernel, up[0], down[0]), "2_tr", s1[0])
     out = torch.cat([out, out_s1], 1)
-    # the two 1x1 layers (:183-186) are plain dense products (96 -> 64 -> 32): library GEMMs, forward and backward
+    # the two 1x1 layers are plain dense products (96 -> 64 -> 32): library GEMMs, forward and backward
     out = tap("conv1_tr", torch.relu(out @ model.conv1_tr.kernel))
     out = out @ model.final.kernel + model.final.bias
     if model.normalize_feature:

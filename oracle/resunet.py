@@ -27,6 +27,7 @@ CHANNEL_TABLES = {
     "ResUNetBN2D": ((None, 32, 64, 128, 256), (None, 64, 64, 128, 128)),
     "ResUNetBN2E": ((None, 128, 128, 128, 256), (None, 64, 128, 128, 128)),
     "ResUNetFatBN": ((None, 32, 64, 128, 256), (None, 128, 128, 128, 256)),
+    "ResUNetExpBN2C": ((None, 32, 64, 128, 256), (None, 64, 64, 64, 128)),      # model/resunet.py:487-490 (ResUNetExpanded)
 }
 
 
@@ -120,6 +121,14 @@ def resunet_forward(sd: dict, coords: np.ndarray, feats, normalize_feature=True,
         _TRAIN.update(on=False, running=None, masks=None)
 
 
+def _second(out, nbr, sd, i, stored):
+    """``ResUNetExpanded`` (model/resunet.py:426-471): ``relu -> norm<i>_2 -> block<i>_2`` behind a stage's block, when the state
+    dict has those layers."""
+    if f"norm{i}_2.bn.weight" not in sd:
+        return out
+    return basic_block(batch_norm(_relu(out, None), sd, f"norm{i}_2"), nbr, sd, f"block{i}_2", stored)
+
+
 def _resunet_forward(sd, coords, feats, normalize_feature, conv1_kernel_size, maps, return_intermediate, dtype):
     if maps is None:
         maps = oc.build_maps(coords, conv1_kernel_size)
@@ -140,27 +149,31 @@ def _resunet_forward(sd, coords, feats, normalize_feature, conv1_kernel_size, ma
     # encoder (model/resunet.py:143-161)
     out_s1 = keep("conv1", batch_norm(sparse_conv(x, maps["k5"], _kernel(sd, "conv1")), sd, "norm1"))
     out_s1 = basic_block(out_s1, s1[0], sd, "block1", stored)
+    out_s1 = _second(out_s1, s1[0], sd, "1", stored)
     out = _relu(out_s1, None)
     out_s2 = keep("conv2", batch_norm(sparse_conv(out, down[0], _kernel(sd, "conv2")), sd, "norm2"))
     out_s2 = basic_block(out_s2, s1[1], sd, "block2", stored)
+    out_s2 = _second(out_s2, s1[1], sd, "2", stored)
     out = _relu(out_s2, None)
     out_s4 = keep("conv3", batch_norm(sparse_conv(out, down[1], _kernel(sd, "conv3")), sd, "norm3"))
     out_s4 = basic_block(out_s4, s1[2], sd, "block3", stored)
+    out_s4 = _second(out_s4, s1[2], sd, "3", stored)
     out = _relu(out_s4, None)
     out_s8 = keep("conv4", batch_norm(sparse_conv(out, down[2], _kernel(sd, "conv4")), sd, "norm4"))
     out_s8 = basic_block(out_s8, s1[3], sd, "block4", stored)
+    out_s8 = _second(out_s8, s1[3], sd, "4", stored)
     out = _relu(out_s8, None)
     inter.update(out_s1=out_s1, out_s2=out_s2, out_s4=out_s4, out_s8=out_s8)
 
     # decoder (model/resunet.py:163-186); ME.cat order is [decoder | skip]
     out = keep("conv4_tr", batch_norm(sparse_conv(out, up[2], _kernel(sd, "conv4_tr")), sd, "norm4_tr"))
-    out_s4_tr = _relu(basic_block(out, s1[2], sd, "block4_tr", stored), None)
+    out_s4_tr = _relu(_second(basic_block(out, s1[2], sd, "block4_tr", stored), s1[2], sd, "4_tr", stored), None)
     out = torch.cat([out_s4_tr, out_s4], 1)
     out = keep("conv3_tr", batch_norm(sparse_conv(out, up[1], _kernel(sd, "conv3_tr")), sd, "norm3_tr"))
-    out_s2_tr = _relu(basic_block(out, s1[1], sd, "block3_tr", stored), None)
+    out_s2_tr = _relu(_second(basic_block(out, s1[1], sd, "block3_tr", stored), s1[1], sd, "3_tr", stored), None)
     out = torch.cat([out_s2_tr, out_s2], 1)
     out = keep("conv2_tr", batch_norm(sparse_conv(out, up[0], _kernel(sd, "conv2_tr")), sd, "norm2_tr"))
-    out_s1_tr = _relu(basic_block(out, s1[0], sd, "block2_tr", stored), None)
+    out_s1_tr = _relu(_second(basic_block(out, s1[0], sd, "block2_tr", stored), s1[0], sd, "2_tr", stored), None)
     out = torch.cat([out_s1_tr, out_s1], 1)
     inter.update(out_s4_tr=out_s4_tr, out_s2_tr=out_s2_tr, out_s1_tr=out_s1_tr)
     n = out.shape[0]

@@ -46,6 +46,9 @@ summary = {"steps_profiled": steps,
            "spconv_read_GB_per_forward_raw": float(sp.FETCH_SIZE_KB_total.sum() * 1024 / steps / 1e9),
            "spconv_write_GB_per_forward": float(sp.hbm_write_GB_per_step.sum()),
            "workload": json.loads(bench)["config"]["workload"]}
+sys.path.insert(0, ROOT)
+import bench as _bench  # noqa: E402
+summary["csrc_sha16"] = _bench.csrc_sha16()          # bench.py quotes these counters only while the kernel sources are these
 json.dump(summary, open(os.path.join(out, f"{tag}_spconv_traffic.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
 

@@ -138,3 +138,34 @@ def test_batch_norm_kernels_against_torch(setup):
             assert rel_err(got.cpu().numpy(), want.numpy()) < 1e-4, (n, c, relu)
         y2, stats2 = _BatchNormTrain.apply(x, g, b, 1e-5, relu)
         assert torch.equal(stats, stats2) and torch.equal(y, y2)
+
+
+def test_expanded_variant_eval_and_train_match_the_oracle():
+    """``ResUNetExpBN2C`` (model/resunet.py:254-490: a second norm + block behind every stage; named in scripts/train_kitti.sh):
+    ``load_model`` finds it, the ME-named state dict loads, eval features and a training-mode forward match the oracle."""
+    import eyoc_amd
+    from eyoc_amd import synthetic as syn
+    from oracle import resunet as orr
+    p = syn.make_pair(6, beams=16, azimuths=500, band=None)
+    coords = syn.batch_coords([p["coords0"]])
+    feats = np.ones((len(coords), 1), np.float32)
+    sd = syn.make_weights(seed=31, expanded=True)
+    Model = eyoc_amd.load_model("ResUNetExpBN2C")
+    assert Model is not None and eyoc_amd.load_model("ResUNetExpanded") is not None
+    model = Model(1, 32, bn_momentum=0.05, conv1_kernel_size=5, normalize_feature=True)
+    assert "block3_2.conv1.kernel" in model.state_dict() and "norm4_tr_2.bn.running_var" in model.state_dict()
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model = model.cuda().eval()
+    x = eyoc_amd.SparseTensor(torch.from_numpy(feats).cuda(), coordinates=torch.from_numpy(coords).cuda())
+    got = model(x).F
+    assert not got.requires_grad
+    want = orr.resunet_forward(sd, coords, feats).numpy()
+    e_eval = rel_err(got.cpu().numpy(), want)
+    model.train()
+    out = model(x).F
+    want_t = orr.resunet_forward({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, coords, feats, train=True, bn_momentum=0.05).numpy()
+    e_train = rel_err(out.detach().cpu().numpy(), want_t)
+    out.sum().backward()
+    assert all(q.grad is not None for q in model.parameters())
+    print(f"ResUNetExpBN2C on {len(coords)} voxels: eval {e_eval:.2e}, train {e_train:.2e}")
+    assert e_eval < REL and e_train < REL
