@@ -160,8 +160,8 @@ struct eyoc_maps {
   int local_tile = 256;                    // rows per tile of the local_s1 records: 256 (spconv_st.hip) or 128 (spconv_st128.hip)
   unsigned char* local1_256 = nullptr;     // 256-row records of the level-1 stride-1 table for the staged first convolution when local_s1 holds 128-row ones
   unsigned char* local_up[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};   // transposed tables (outputs at level l)
-  // strided tables (inputs at level l, outputs at level l + 1): the same records as local_s1 - a 256-row output tile's inputs
-  // are its rows' children plus a halo, a contiguous range of the finer level in Z-order; NULL when a tile overflows
+  // strided tables (inputs at level l, outputs at level l + 1): 64-row-tile records (spconv_st128.hip) - a 64-row output tile's
+  // inputs are its rows' children plus a halo, 190-330 distinct fine rows; NULL when a tile overflows or the kernel is off
   unsigned char* local_down[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
   bool table0_built = false;   // table[0] has its memory reserved but is only filled on demand (maps_build_table0)
 };

@@ -573,7 +573,7 @@ size_t eyoc_maps_workspace_bytes(int n_rows) {
   b += 2 * align_up(local_rulebook_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_bytes(1)) + 256);
   b += 2 * align_up(local_rulebook128_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook128_bytes(1)) + 256);   // 128-row tile records (+ level 1 twice)
   b += 2 * align_up(local_rulebook_up_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_up_bytes(1)) + 256);
-  b += align_up(local_rulebook_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_bytes(1)) + 256);   // strided tables (coarse levels sum to < n rows)
+  b += align_up(local_rulebook64_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook64_bytes(1)) + 256);   // strided tables (coarse levels sum to < n rows), 64-row tiles
   b += 4096;                                                         // counters
   return b + 96 * 256;
 }
@@ -847,9 +847,11 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
         m->local_up[l] = cv.take<unsigned char>(local_rulebook_up_bytes(m->rows[l]));
         if (int rc = build_local_rulebook_up(m->nbr_up[l], 27, m->rows[l], m->local_up[l], counters + 9, st)) { delete m; return rc; }
       }
-      if (l + 1 < EYOC_MAX_LEVELS && m->nbr_down[l] && spconv_down_staged()) {   // the strided table level l -> l + 1
-        m->local_down[l] = cv.take<unsigned char>(local_rulebook_bytes(m->rows[l + 1]));
-        if (int rc = build_local_rulebook(m->nbr_down[l], 27, m->rows[l + 1], m->local_down[l], counters + 10 + l, st)) { delete m; return rc; }
+      // the strided table level l -> l + 1: 64-row-tile records for the two fine ones (32 -> 64 and 64 -> 128 channels measured
+      // -25 % / -16 % on them; the coarsest, 128 -> 256 on few rows, is level with the gathering kernel and keeps it)
+      if (l + 1 < EYOC_MAX_LEVELS - 1 && m->nbr_down[l] && spconv_down_staged()) {
+        m->local_down[l] = cv.take<unsigned char>(local_rulebook64_bytes(m->rows[l + 1]));     // 64-row output tiles (spconv_st128.hip)
+        if (int rc = build_local_rulebook64(m->nbr_down[l], 27, m->rows[l + 1], m->local_down[l], counters + 10 + l, st)) { delete m; return rc; }
       }
     }
     FAIL_HIP(hipMemcpyAsync(host, counters + 8, 8 * sizeof(int), hipMemcpyDeviceToHost, st));

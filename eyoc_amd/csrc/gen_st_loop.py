@@ -321,6 +321,8 @@ def main(path):
         # spconv_st128.hip: 128-row tiles, 64 rows x 32 channels per wave inside 128 VGPRs (four waves per SIMD, four workgroups per CU)
         write_blob(f, "T128", gen_w8(lo_region=320 * 64, lrows=32))
         write_blob(f, "T128_NOSKIP", gen_w8(skip=False, lo_region=320 * 64, lrows=32))
+        write_blob(f, "T64", gen_w8(lo_region=320 * 64, lrows=16))          # 64-row tiles (strided tables): one row group per tile
+        write_blob(f, "T64_NOSKIP", gen_w8(skip=False, lo_region=320 * 64, lrows=16))
         f.write("#define EYOC_ST_LOOP_CLOBBERS_T128 " + ", ".join(f'"v{i}"' for i in range(28, 96)) + "\n")
     with open(path.replace(".inc", "_abl.inc"), "w") as f:
         f.write("// GENERATED by gen_st_loop.py - diagnostics builds only (EYOC_ST_ABLATIONS / EYOC_ST_TRACE); results are garbage\n")

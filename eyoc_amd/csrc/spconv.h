@@ -30,7 +30,7 @@ struct SpconvArgs {
   int out_split = 0;               // write SPLIT16 rows (internal activations) instead of fp32 rows
   const int32_t* out_perm = nullptr;      // output row o is written to row out_perm[o] of `out` (the network output in the caller's order); res is not permuted
   const unsigned char* local = nullptr;   // per-tile local rulebooks of `nbr` (build_local_rulebook / build_local_rulebook128) or NULL: enables the staged kernel
-  int local_tile = 256;                   // rows per tile of `local`: 256 (spconv_st.hip) or 128 (spconv_st128.hip)
+  int local_tile = 256;                   // rows per tile of `local`: 256 (spconv_st.hip), 128 or 64 (spconv_st128.hip)
   const unsigned char* local_up = nullptr;   // ... of a transposed table (build_local_rulebook_up): enables spconv_up.hip
   const float* out_scale = nullptr;  // device scalar multiplied into the accumulated sums (undoes the weight pre-scale); NULL = 1
   // optional: a permutation of the output rows; tiles take rows in this order (any order gives the same result,
@@ -130,7 +130,9 @@ size_t local_rulebook_bytes(int n_out);
 int select_st_tile(int rows);   // 128 / 256 set the tile shape new maps build their stride-1 records for; anything else only queries
 size_t local_rulebook128_bytes(int n_out);
 int build_local_rulebook128(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st);
-int launch_spconv_st128(const SpconvArgs& a, const unsigned char* local_dev, int skip_empty_blocks, hipStream_t st);
+size_t local_rulebook64_bytes(int n_out);     // 64-row tiles: the strided tables (a 64-row coarse tile reads 190-330 distinct fine rows)
+int build_local_rulebook64(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st);
+int launch_spconv_st128(const SpconvArgs& a, const unsigned char* local_dev, int tile, int skip_empty_blocks, hipStream_t st);
 int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st);
 int launch_spconv_rs(const SpconvArgs& a, hipStream_t st);     // row-stationary, SPLIT16 only (spconv_rs.hip)
 // the network's 1x1 tail in one kernel (spconv_tail.hip): conv1_tr (96 -> 64, ReLU) -> final (64 -> 32, bias) -> row normalisation

@@ -770,7 +770,7 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
     if (a.math == 1 && a.local && use_rs != 0 && a.K == 27 && !a.l2norm && st_ok) {
       SpconvArgs b = a;
       b.perm = nullptr;
-      if (a.local_tile == 128) return launch_spconv_st128(b, a.local, select_st_variant(-1) != 2, st);
+      if (a.local_tile == 128 || a.local_tile == 64) return launch_spconv_st128(b, a.local, a.local_tile, select_st_variant(-1) != 2, st);
       return launch_spconv_st(b, a.local, st);
     }
     if (a.math == 1 && a.local_up && use_rs != 0 && a.K == 27 && !a.l2norm && a.cout % 64 == 0) {   // transposed table with tile rulebooks
@@ -1200,13 +1200,15 @@ int eyoc_spconv_staged(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* local_
 int eyoc_spconv_st_tile(int rows) { return eyoc::select_st_tile(rows); }
 
 size_t eyoc_spconv_local_rulebook_bytes_tile(int n_out, int tile) {
-  return tile == 128 ? eyoc::local_rulebook128_bytes(n_out) : tile == 256 ? eyoc::local_rulebook_bytes(n_out) : 0;
+  return tile == 128 ? eyoc::local_rulebook128_bytes(n_out) : tile == 64 ? eyoc::local_rulebook64_bytes(n_out)
+                                                              : tile == 256 ? eyoc::local_rulebook_bytes(n_out) : 0;
 }
 
 int eyoc_spconv_build_local_rulebook_tile(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, int tile, void* out_dev, int32_t* overflow_dev,
                                           void* stream) {
-  EYOC_REQUIRE(ctx && nbr_dev && out_dev && overflow_dev && K == 27 && (tile == 128 || tile == 256), EYOC_ERR_INVALID,
+  EYOC_REQUIRE(ctx && nbr_dev && out_dev && overflow_dev && K == 27 && (tile == 64 || tile == 128 || tile == 256), EYOC_ERR_INVALID,
                "eyoc_spconv_build_local_rulebook_tile: bad argument (K %d, tile %d)", K, tile);
+  if (tile == 64) return build_local_rulebook64(nbr_dev, K, n_out, (unsigned char*)out_dev, overflow_dev, (hipStream_t)stream);
   if (tile == 128) return build_local_rulebook128(nbr_dev, K, n_out, (unsigned char*)out_dev, overflow_dev, (hipStream_t)stream);
   return build_local_rulebook(nbr_dev, K, n_out, (unsigned char*)out_dev, overflow_dev, (hipStream_t)stream);
 }
@@ -1214,7 +1216,7 @@ int eyoc_spconv_build_local_rulebook_tile(eyoc_ctx* ctx, const int32_t* nbr_dev,
 int eyoc_spconv_staged_tile(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* local_dev, int tile, int n_out, int n_in, const float* in_dev,
                             int ld_in, int cin, const float* wpacked_dev, int cout, const float* bias_dev, const float* res_dev, int ld_res,
                             int relu, float* out_dev, int ld_out, int out_split, const float* out_scale_dev, void* stream) {
-  EYOC_REQUIRE(ctx && nbr_dev && local_dev && (tile == 128 || tile == 256), EYOC_ERR_INVALID, "eyoc_spconv_staged_tile: bad argument");
+  EYOC_REQUIRE(ctx && nbr_dev && local_dev && (tile == 64 || tile == 128 || tile == 256), EYOC_ERR_INVALID, "eyoc_spconv_staged_tile: bad argument");
   SpconvArgs a;
   a.nbr = nbr_dev; a.K = 27; a.n_out = n_out; a.n_in = n_in; a.in = in_dev; a.ld_in = ld_in; a.cin = cin; a.w = wpacked_dev;
   a.cout = cout; a.bias = bias_dev; a.res = res_dev; a.ld_res = ld_res; a.relu = relu; a.l2norm = 0;

@@ -16,7 +16,7 @@
 // effective clock of both kernels is power-managed (GRBM_GUI_ACTIVE / duration: 1.81-1.95 GHz here, 1.88-2.06 for the 256-row
 // kernel, scripts/pmc_clock.sh), i.e. the matrix pipe's 529 k busy clocks per SIMD are 60 % of the REAL clocks of the launch.
 //
-// Tile records (k_local_rulebook128, 16512 bytes per tile): the 256-row layout of spconv_st.hip with 32 entries per offset
+// Tile records (k_local_rulebook_t, 17792 bytes per 128-row tile): the 256-row layout of spconv_st.hip with 32 entries per offset
 // and 319 + 1 stage slots per pass; a tile with more than 319 distinct rows takes a second pass (4 % of the level-0 tiles,
 // 20 % at the coarsest level), more than 638 is an overflow (the table then falls back to the gathering kernels).
 #include <atomic>
@@ -33,32 +33,39 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
 
 // waves per workgroup: 2 row halves (64 rows) x 2 output-channel halves (32 channels); 32-channel layers take 2 waves
-constexpr int TILE = 128;
+// (the record / kernel code below is templated on the tile's row count: 128 for the stride-1 tables, 64 for the strided ones,
+// whose 64-row output tiles touch 190-330 distinct fine rows - 128-row tiles would need two passes half of the time)
 constexpr int XROWS = 320;                  // stage rows of one 32-channel block (64 B of hi halves + 64 B of lo halves each)
 constexpr int UMAX = XROWS - 1;             // slot UMAX holds zeros
-constexpr int NPASS = 2;
-constexpr int UCAP = 2 * XROWS;
+constexpr int NPASS_MAX = 3;
+constexpr int UCAP = NPASS_MAX * XROWS;     // row-list capacity of a record (both tile shapes)
 constexpr int X_BYTES = XROWS * 128;        // 40 KB: four workgroups per CU
 constexpr int LO_REGION = XROWS * 64;
-constexpr int LROWS = TILE / 4;             // rulebook entries per offset: one uint2 (four 16-bit slots) per (row half, j)
 constexpr int LOC_OFF = 16 + UCAP * 4;
-constexpr int MASK_OFF = LOC_OFF + NPASS * 27 * LROWS * 8;   // 16400
 constexpr int MASK_PASS_BYTES = 56;
-constexpr int LR_BYTES = MASK_OFF + NPASS * MASK_PASS_BYTES;  // 16512
+template <int TILE>
+struct Rec {
+  static constexpr int NPASS = TILE == 64 ? 3 : 2;   // staging passes a tile may take: 638 distinct rows for 128-row tiles, 957 for the strided tables' 64-row tiles
+  static constexpr int LROWS = TILE / 4;             // rulebook entries per offset: one uint2 (four 16-bit slots) per (64-row group, j)
+  static constexpr int MASK_OFF = LOC_OFF + NPASS * 27 * LROWS * 8;
+  static constexpr int LR_BYTES = (MASK_OFF + NPASS * MASK_PASS_BYTES + 127) / 128 * 128;   // 17792 (128 rows) / 14464 (64 rows)
+  static_assert(LR_BYTES % 128 == 0, "records start on cache lines");
+};
 constexpr int HSLOTS = 2048;
-static_assert(LR_BYTES % 128 == 0, "records start on cache lines");
 __host__ __device__ constexpr int slot_addr(int l) { return l * 64 + ((l >> 2) & 3) * 16; }   // as in spconv_st.hip
 
 // One workgroup (128 threads) per 128-row tile: the distinct input rows of the tile's 27-neighbourhoods through an LDS hash
 // (slots numbered in table order: deterministic), the stage slot of every (offset, row) as a 16-bit LDS byte address, and
 // per (pass, offset) an 8-bit occupancy mask (bit 4 w + c: some row of rows 64 w + 16 c .. + 15 has a neighbour staged in the pass).
-__global__ __launch_bounds__(TILE) void k_local_rulebook128(const int32_t* __restrict__ nbr, int K, int n_out, unsigned char* __restrict__ out,
-                                                            int* __restrict__ overflow) {
+template <int TILE>
+__global__ __launch_bounds__(TILE) void k_local_rulebook_t(const int32_t* __restrict__ nbr, int K, int n_out, unsigned char* __restrict__ out,
+                                                           int* __restrict__ overflow) {
+  constexpr int NWB = TILE / 64, LROWS = Rec<TILE>::LROWS, MASK_OFF = Rec<TILE>::MASK_OFF, LR_BYTES = Rec<TILE>::LR_BYTES, NPASS = Rec<TILE>::NPASS;
   __shared__ int hk[HSLOTS];
   __shared__ unsigned short hid[HSLOTS];
-  __shared__ int wave_cnt[2];
+  __shared__ int wave_cnt[NWB];
   __shared__ int too_many;
-  __shared__ unsigned char nib[NPASS][27][2];
+  __shared__ unsigned char nib[NPASS][27][NWB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = blockIdx.x;
   const int row = tile * TILE + (int)threadIdx.x;
@@ -91,13 +98,13 @@ __global__ __launch_bounds__(TILE) void k_local_rulebook128(const int32_t* __res
     if (threadIdx.x == 0) { reinterpret_cast<int*>(lr)[0] = -1; atomicAdd(overflow, 1); }
     return;
   }
-  constexpr int PER_WAVE = HSLOTS / 2;
+  constexpr int PER_WAVE = HSLOTS / NWB;
   int cnt = 0;
   for (int i0 = 0; i0 < PER_WAVE; i0 += 64) cnt += __popcll(__ballot(hk[wave * PER_WAVE + i0 + lane] >= 0));
   if (lane == 0) wave_cnt[wave] = cnt;
   __syncthreads();
-  int base = wave ? wave_cnt[0] : 0;
-  const int total = wave_cnt[0] + wave_cnt[1];
+  int base = 0, total = 0;
+  for (int w = 0; w < NWB; ++w) { if (w < wave) base += wave_cnt[w]; total += wave_cnt[w]; }
   int* U = reinterpret_cast<int*>(lr + 16);
   for (int i0 = 0; i0 < PER_WAVE; i0 += 64) {
     const int s = wave * PER_WAVE + i0 + lane;
@@ -132,21 +139,24 @@ __global__ __launch_bounds__(TILE) void k_local_rulebook128(const int32_t* __res
     }
   }
   __syncthreads();
-  if (threadIdx.x < NPASS * 28) {
-    const int p = (int)threadIdx.x / 28, k = (int)threadIdx.x % 28;
+  for (int i = threadIdx.x; i < NPASS * 28; i += TILE) {
+    const int p = i / 28, k = i % 28;
     unsigned short m = 0;
-    if (k < 27 && !(p > 0 && total <= p * UMAX)) m = (unsigned short)(nib[p][k][0] | nib[p][k][1] << 4);
+    if (k < 27 && !(p > 0 && total <= p * UMAX)) m = (unsigned short)(nib[p][k][0] | (NWB > 1 ? nib[p][k][NWB - 1] << 4 : 0));
     reinterpret_cast<unsigned short*>(lr + MASK_OFF)[p * 28 + k] = m;
   }
 }
 
 #include "spconv_st_loop.inc"
 
-// NWV = 4: 128 rows x 64 output channels per workgroup (>= 64-channel layers); NWV = 2: 128 rows x 32 (32-channel layers).
-template <int CC, int SKIP, int NWV>
+// A workgroup = TILE rows x CTG output channels: TILE / 64 row groups x CTG / 32 channel parts, one wave (64 rows x 32 channels) each.
+//   TILE = 128: NWV = 4 -> 64 output channels (>= 64-channel layers), NWV = 2 -> 32 (32-channel layers);
+//   TILE = 64 (strided tables): NWV = 2 -> 64 output channels, NWV = 4 -> 128.
+template <int TILE, int CC, int SKIP, int NWV>
 __global__ __launch_bounds__(NWV * 64, NWV) void spconv_st128_kernel(SpconvArgs a, const unsigned char* __restrict__ local, int n_tiles) {
-  constexpr int NTW = 2, CTW = NTW * 16, NC = 4;
-  constexpr int CTG = CTW * (NWV / 2);
+  constexpr int NTW = 2, CTW = NTW * 16, NC = 4, RW = TILE / 64;
+  constexpr int LROWS = Rec<TILE>::LROWS, MASK_OFF = Rec<TILE>::MASK_OFF, LR_BYTES = Rec<TILE>::LR_BYTES;
+  constexpr int CTG = CTW * (NWV / RW);
   constexpr int NITV = XROWS / (16 * NWV);
   __shared__ __attribute__((aligned(128))) unsigned char xs[X_BYTES];
   const int lane = threadIdx.x & 63;
@@ -156,8 +166,8 @@ __global__ __launch_bounds__(NWV * 64, NWV) void spconv_st128_kernel(SpconvArgs 
   const int xcd = (int)blockIdx.x & 7, per = 8 / n_cg;
   const int cg = xcd % n_cg, tile = ((int)blockIdx.x >> 3) * per + xcd / n_cg;
   if (tile >= n_tiles) return;
-  const int w0 = wave & 1;
-  const int ct0 = cg * CTG + (wave >> 1) * CTW;
+  const int w0 = wave % RW;
+  const int ct0 = cg * CTG + (wave / RW) * CTW;
   const int CT = a.cout >= 128 ? 128 : a.cout;
   const int n_slices = a.cout / CT, slice = ct0 / CT, nt0 = (ct0 - slice * CT) / 16;
   constexpr int JQ = CC / 16;
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(NWV * 64, NWV) void spconv_st128_kernel(SpconvArgs 
   int warm = 0;      // the tile's rulebook entries (6.9 KB per pass) into L2 while the stage is in flight: one dword per line
   if (threadIdx.x < 27 * LROWS * 8 / 128) warm = *reinterpret_cast<const int*>(lr + LOC_OFF + threadIdx.x * 128);
   const int n_u = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(lr)[0]);
-  const int n_pass = n_u > UMAX ? 2 : 1;
+  const int n_pass = (n_u + UMAX - 1) / UMAX;
   bool first = true;
   for (int pass = 0; pass < n_pass; ++pass) {
     n_up = min(n_u - pass * UMAX, UMAX);
@@ -234,8 +244,10 @@ __global__ __launch_bounds__(NWV * 64, NWV) void spconv_st128_kernel(SpconvArgs 
   asm volatile(TEXT : "+{v[96:111]}"(A0), "+{v[112:127]}"(A1), [so] "=&s"(so)                                                                  \
                : [wr] "s"(wr), [ws0] "s"(ws0), [ks] "s"(kstride), [lb] "s"(lb), [w1] "s"(w1off), "{s[36:43]}"(M0), "{s[44:51]}"(M1)         \
                : "memory", "scc", EYOC_ST_LOOP_CLOBBERS_T128)
-      if constexpr (SKIP) EYOC_ST128_ASM(EYOC_ST_LOOP_T128);
-      else EYOC_ST128_ASM(EYOC_ST_LOOP_T128_NOSKIP);
+      if constexpr (TILE == 128 && SKIP) EYOC_ST128_ASM(EYOC_ST_LOOP_T128);
+      else if constexpr (TILE == 128) EYOC_ST128_ASM(EYOC_ST_LOOP_T128_NOSKIP);
+      else if constexpr (SKIP) EYOC_ST128_ASM(EYOC_ST_LOOP_T64);
+      else EYOC_ST128_ASM(EYOC_ST_LOOP_T64_NOSKIP);
 #undef EYOC_ST128_ASM
     }
   }
@@ -316,32 +328,43 @@ namespace eyoc {
 
 int select_st_tile(int rows) { return (rows == 128 || rows == 256) ? g_st_tile.exchange(rows) : g_st_tile.load(); }
 
-size_t local_rulebook128_bytes(int n_out) { return (size_t)cdiv(n_out, TILE) * LR_BYTES; }
+size_t local_rulebook128_bytes(int n_out) { return (size_t)cdiv(n_out, 128) * Rec<128>::LR_BYTES; }
+size_t local_rulebook64_bytes(int n_out) { return (size_t)cdiv(n_out, 64) * Rec<64>::LR_BYTES; }
 
 int build_local_rulebook128(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st) {
   if (n_out <= 0) return EYOC_OK;
-  hipLaunchKernelGGL(k_local_rulebook128, dim3(cdiv(n_out, TILE)), dim3(TILE), 0, st, nbr_dev, K, n_out, out_dev, overflow_dev);
+  hipLaunchKernelGGL(k_local_rulebook_t<128>, dim3(cdiv(n_out, 128)), dim3(128), 0, st, nbr_dev, K, n_out, out_dev, overflow_dev);
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
 }
 
-int launch_spconv_st128(const SpconvArgs& a, const unsigned char* local_dev, int skip, hipStream_t st) {
-  EYOC_REQUIRE(a.math == 1 && local_dev && !a.l2norm && a.K == 27 && !a.perm, EYOC_ERR_INVALID, "spconv_st128: unsupported layer");
-  const int n_tiles = cdiv(a.n_out, TILE);
-  const int ctg = a.cout >= 64 ? 64 : 32;
+int build_local_rulebook64(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st) {
+  if (n_out <= 0) return EYOC_OK;
+  hipLaunchKernelGGL(k_local_rulebook_t<64>, dim3(cdiv(n_out, 64)), dim3(64), 0, st, nbr_dev, K, n_out, out_dev, overflow_dev);
+  EYOC_CHECK_HIP(hipGetLastError());
+  return EYOC_OK;
+}
+
+// tile = 128 (stride-1 tables) or 64 (strided tables: 64 .. 256 output channels)
+int launch_spconv_st128(const SpconvArgs& a, const unsigned char* local_dev, int tile, int skip, hipStream_t st) {
+  EYOC_REQUIRE(a.math == 1 && local_dev && !a.l2norm && a.K == 27 && !a.perm && (tile == 128 || tile == 64), EYOC_ERR_INVALID,
+               "spconv_st128: unsupported layer");
+  const int n_tiles = cdiv(a.n_out, tile);
+  const int ctg = tile == 128 ? (a.cout >= 64 ? 64 : 32) : (a.cout >= 128 ? 128 : 64);
   const bool wide = spconv_cc(a.cin, a.cout) == 64;
   const int n_cg = a.cout / ctg;
   EYOC_REQUIRE(a.cout % ctg == 0 && n_cg >= 1 && n_cg <= 8 && 8 % n_cg == 0 && a.cin % 32 == 0, EYOC_ERR_INVALID,
-               "spconv_st128: %d -> %d channels", a.cin, a.cout);
+               "spconv_st128: %d -> %d channels on %d-row tiles", a.cin, a.cout, tile);
   const dim3 grid((unsigned)(cdiv(n_tiles, 8 / n_cg) * 8));
-#define EYOC_ST128(CC_, SK_, NWV_) hipLaunchKernelGGL((spconv_st128_kernel<CC_, SK_, NWV_>), grid, dim3(NWV_ * 64), 0, st, a, local_dev, n_tiles)
-  if (ctg == 64) {
-    if (skip) { if (wide) EYOC_ST128(64, 1, 4); else EYOC_ST128(32, 1, 4); }
-    else { if (wide) EYOC_ST128(64, 0, 4); else EYOC_ST128(32, 0, 4); }
-  } else {
-    if (skip) { if (wide) EYOC_ST128(64, 1, 2); else EYOC_ST128(32, 1, 2); }
-    else { if (wide) EYOC_ST128(64, 0, 2); else EYOC_ST128(32, 0, 2); }
-  }
+#define EYOC_ST128(T_, CC_, SK_, NWV_) hipLaunchKernelGGL((spconv_st128_kernel<T_, CC_, SK_, NWV_>), grid, dim3(NWV_ * 64), 0, st, a, local_dev, n_tiles)
+#define EYOC_ST128_CC(T_, NWV_)                                                                    \
+  do {                                                                                             \
+    if (skip) { if (wide) EYOC_ST128(T_, 64, 1, NWV_); else EYOC_ST128(T_, 32, 1, NWV_); }         \
+    else { if (wide) EYOC_ST128(T_, 64, 0, NWV_); else EYOC_ST128(T_, 32, 0, NWV_); }              \
+  } while (0)
+  if (tile == 128) { if (ctg == 64) EYOC_ST128_CC(128, 4); else EYOC_ST128_CC(128, 2); }
+  else { if (ctg == 128) EYOC_ST128_CC(64, 4); else EYOC_ST128_CC(64, 2); }
+#undef EYOC_ST128_CC
 #undef EYOC_ST128
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
