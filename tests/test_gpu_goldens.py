@@ -34,7 +34,7 @@ def test_loss_and_gradients_match_the_reference(golden_dir, i):
     np.testing.assert_allclose(float(neg.detach()), float(g[f"neg{i}"]), rtol=1e-5, equal_nan=True)
     for got, want in ((F0.grad.cpu().numpy(), g[f"gF0_{i}"]), (F1.grad.cpu().numpy(), g[f"gF1_{i}"])):
         np.testing.assert_allclose(got, want, rtol=0, atol=1e-4 * np.abs(want).max())
-    print(f"loss case {i}: pos {float(pos):.6f} neg {float(neg):.6f}; max grad err "
+    print(f"loss case {i}: pos {float(pos.detach()):.6f} neg {float(neg.detach()):.6f}; max grad err "
           f"{np.abs(F0.grad.cpu().numpy() - g[f'gF0_{i}']).max() / np.abs(g[f'gF0_{i}']).max():.2e}")
 
 
