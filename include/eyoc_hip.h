@@ -171,11 +171,11 @@ int eyoc_spconv_select_split16_kernel(int mode);
  * kernel in windowed pattern order, 18 GB less HBM traffic per 128-cloud forward), 0 off; other values only query.  Returns the previous
  * state.  Process-wide, read when maps are built; for tests and profiling. */
 int eyoc_spconv_select_up_kernel(int on);
-/* Strided 3^3 / stride-2 convolutions on Z-ordered maps through the staged kernel (spconv_st.hip with local rulebooks of the
- * strided table: a 256-row output tile's inputs - its rows' children plus a halo - are staged in LDS once per 32-channel
- * block): 1 on, 0 off (default: wave-private kernel in windowed pattern order - a strided tile's ~1000+ distinct input rows
- * overflow the two staging passes on LiDAR geometry, so the table falls back anyway); other values only query.  Returns the
- * previous state.  Process-wide, read when maps are built; for tests and profiling. */
+/* Strided 3^3 / stride-2 convolutions on Z-ordered maps through the small-tile staged kernel (spconv_st128.hip on 64-ROW output
+ * tiles: a tile's inputs - its rows' children plus the halo of the -1 offsets, 190-330 distinct fine rows - are staged in LDS once
+ * per 32-channel block, up to three passes of 319 rows): 1 on for the two fine tables (32 -> 64 and 64 -> 128 channels: -25 % /
+ * -16 % on those layers; the coarsest stays on the gathering kernel), 0 off (default: at the step level the records cost what the
+ * layers save); other values only query.  Returns the previous state.  Process-wide, read when maps are built. */
 int eyoc_spconv_select_down_kernel(int on);
 /* First convolution (C_in = 1, 32 output channels) of split16 forwards on Z-ordered maps: 1 (default) = conv1_st_kernel - the child
  * features of a 256-parent tile's neighbourhood staged in LDS through the level-1 tile rulebook; 0 = conv1_mfma_kernel, which probes

@@ -567,6 +567,37 @@ def test_fused_tail_matches_the_two_layer_tail_and_the_oracle(normalize):
     assert e_fused <= 2 * e_two + 1e-6
 
 
+def test_forward_on_small_tiles_matches_the_default_and_the_oracle():
+    """The whole network with the selectable tile shapes - stride-1 layers on 128-row tiles (eyoc_spconv_st_tile(128): the maps then
+    build 128-row records, plus 256-row ones of level 1 for the staged first convolution) and the strided layers on 64-row tiles
+    (eyoc_spconv_select_down_kernel(1)) - against the default kernels (same products; multi-pass tiles sum in another order) and
+    the oracle."""
+    import eyoc_amd
+    from eyoc_amd import synthetic as syn
+    from oracle import resunet as orr
+    L, lib = _lib()
+    p = syn.make_pair(4, beams=32, azimuths=1000, band=None)
+    coords = syn.batch_coords([p["coords0"], p["coords1"]])
+    feats = np.ones((len(coords), 1), np.float32)
+    sd = syn.make_weights(seed=3)
+    m = eyoc_amd.load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, conv1_kernel_size=5, normalize_feature=True)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m = m.cuda().eval()
+    m.spconv_math = "split16"
+    want = orr.resunet_forward(sd, coords, feats).numpy()
+    base = _forward(m, coords, feats)
+    prev_tile, prev_dn = lib.eyoc_spconv_st_tile(128), lib.eyoc_spconv_select_down_kernel(1)
+    try:
+        assert lib.eyoc_spconv_st_tile(-1) == 128
+        small = _forward(m, coords, feats)
+    finally:
+        lib.eyoc_spconv_st_tile(prev_tile)
+        lib.eyoc_spconv_select_down_kernel(prev_dn)
+    e, d = rel_err(small, want), rel_err(small, base)
+    print(f"forward on 128- / 64-row tiles ({len(coords)} rows): vs oracle {e:.2e}, vs the default kernels {d:.2e}")
+    assert m.last_spconv_math == "split16" and e < REL and d < 5e-6 and rel_err(base, want) < REL
+
+
 @pytest.mark.parametrize("ks", [5, 3])
 def test_staged_first_convolution_matches_the_probing_kernel_and_the_oracle(ks):
     """conv1_st_kernel (Z-ordered maps: child features of a 256-parent tile's neighbourhood staged in LDS) against
