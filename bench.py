@@ -83,6 +83,7 @@ def parse_args(argv=None):
     ap.add_argument("--st-variant", type=int, default=-1,
                     help="diagnostics: staged-kernel implementation (eyoc_spconv_select_st_kernel: 0 C++ loop, 1 assembly loop, 2 assembly without empty-block branches)")
     ap.add_argument("--down-staged", type=int, default=-1, help="diagnostics: eyoc_spconv_select_down_kernel (0 / 1)")
+    ap.add_argument("--st-group", type=int, default=-1, help="diagnostics: eyoc_spconv_st_group_rows (0 / 1): row grouping inside the staged kernel's tiles")
     ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
     return ap.parse_args(argv)
 
@@ -298,6 +299,9 @@ def worker(args):
         if args.down_staged >= 0:
             from eyoc_amd import _lib as _l
             _l.load().eyoc_spconv_select_down_kernel(args.down_staged)
+        if args.st_group >= 0:
+            from eyoc_amd import _lib as _l
+            _l.load().eyoc_spconv_st_group_rows(args.st_group)
         log("model packed")
         cfg = RegistrationConfig(ransac_max_iteration=args.ransac_iters)
         pipe, Batch = RegistrationPipeline(model, cfg), DeviceBatch

@@ -570,7 +570,7 @@ size_t eyoc_maps_workspace_bytes(int n_rows) {
   b += 4 * align_up(4 * n * 4) + align_up(sort_rows_tmp_bytes(4 * n_rows, UP_KEY_BITS + 4));   // tiling orders: keys, rows, result (<= 2 segments per level, levels sum to < 2 n)
   b += align_up(n * 8) * 2 + align_up(n * 4) * 2 + align_up(sort_rows64_tmp_bytes(n_rows));   // Z-order: keys in / out, rows in, permutation
   // local rulebooks of the stride-1 tables (levels sum to < 2 n rows; every level rounds up to a whole tile)
-  b += 2 * align_up(local_rulebook_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_bytes(1)) + 256);
+  b += 3 * align_up(local_rulebook_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_bytes(1)) + 256);   // stride-1 tables (+ level 1 in row order)
   b += 2 * align_up(local_rulebook128_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook128_bytes(1)) + 256);   // 128-row tile records (+ level 1 twice)
   b += 2 * align_up(local_rulebook_up_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_up_bytes(1)) + 256);
   b += align_up(local_rulebook64_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook64_bytes(1)) + 256);   // strided tables (coarse levels sum to < n rows), 64-row tiles
@@ -836,12 +836,12 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
         if (int rc = build_local_rulebook128(m->nbr_s1[l], 27, m->rows[l], m->local_s1[l], counters + 8, st)) { delete m; return rc; }
         if (l == 1) {   // the staged first convolution reads 256-parent tiles of this table
           m->local1_256 = cv.take<unsigned char>(local_rulebook_bytes(m->rows[l]));
-          if (int rc = build_local_rulebook(m->nbr_s1[l], 27, m->rows[l], m->local1_256, counters + 14, st)) { delete m; return rc; }
+          if (int rc = build_local_rulebook(m->nbr_s1[l], 27, m->rows[l], m->local1_256, counters + 14, st, 0)) { delete m; return rc; }
         }
       } else {
         m->local_s1[l] = cv.take<unsigned char>(local_rulebook_bytes(m->rows[l]));
         if (int rc = build_local_rulebook(m->nbr_s1[l], 27, m->rows[l], m->local_s1[l], counters + 8, st)) { delete m; return rc; }
-        if (l == 1) m->local1_256 = m->local_s1[l];
+        if (l == 1) m->local1_256 = m->local_s1[l];     // the staged first convolution finds a parent's slot through the record's inverse row map
       }
       if (l + 1 < EYOC_MAX_LEVELS && spconv_up_enabled()) {   // the transposed table whose outputs are this level's rows
         m->local_up[l] = cv.take<unsigned char>(local_rulebook_up_bytes(m->rows[l]));

@@ -833,10 +833,12 @@ __global__ __launch_bounds__(256, 2) void conv1_st_kernel(Conv1Args a) {
   __shared__ __attribute__((aligned(16))) _Float16 xt[4][2][16][KPS];                // [wave][hi / lo][row][window position], padded rows
   __shared__ __attribute__((aligned(8))) signed char ktab[8][216];                   // window position of (block kc, child cs) for parity class cls
   __shared__ unsigned char wmask[8][28];                                             // children of block kc inside the window, per class
+  __shared__ unsigned char inv[ST_TILE];                                             // tile slot of local parent row (the records group a tile's rows by neighbour pattern)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int K = a.ks * a.ks * a.ks, r = a.ks / 2;
   const int tile = blockIdx.x;
+  inv[threadIdx.x] = (a.local1 + (size_t)tile * ST_LR_BYTES)[ST_INV_OFF + threadIdx.x];
   for (int e = threadIdx.x; e < 8 * 27; e += 256) {
     const int cls = e / 27, kc = e % 27;
     unsigned int m = 0;
@@ -935,15 +937,18 @@ __global__ __launch_bounds__(256, 2) void conv1_st_kernel(Conv1Args a) {
   // round trips stand before a step's LDS work (row -> parent, parent -> rulebook entries) and 8 waves per CU hide nothing: they
   // are software-pipelined - coordinates / parent two steps ahead, entries one step ahead, all loads unconditional (clamped
   // rows; a load inside a branch is waited for on the spot)
-  auto load_row = [&](int base, int& cls, int& ew, int& ec) {
+  auto load_row = [&](int base, int& cls, int& pl) {
     int o = base + j;
     o = o < a.n ? o : a.n - 1;
     const int4 c = reinterpret_cast<const int4*>(a.coords)[o];
-    int pl = a.parent[o] - tile * ST_TILE;
+    pl = a.parent[o] - tile * ST_TILE;
     pl = pl < 0 ? 0 : pl > ST_TILE - 1 ? ST_TILE - 1 : pl;                              // rows of other tiles (past f1): any valid entry
     cls = (c.y & 1) | ((c.z & 1) << 1) | ((c.w & 1) << 2);
-    ew = (pl >> 6) * 16 + (pl & 15);                                                   // the parent's place in an entry: (16 w + j, c)
-    ec = (pl >> 4) & 3;
+  };
+  auto place = [&](int pl, int& ew, int& ec) {                                         // the parent's slot -> its place in an entry: (16 w + j, c)
+    const int sl = inv[pl];
+    ew = (sl >> 6) * 16 + (sl & 15);
+    ec = (sl >> 4) & 3;
   };
   auto load_entries = [&](int ew, int ec, int (&e)[7]) {
 #pragma unroll
@@ -953,9 +958,10 @@ __global__ __launch_bounds__(256, 2) void conv1_st_kernel(Conv1Args a) {
     }
   };
   const int base_first = f0 + 16 * wave;
-  int clsB, ewB, ecB, clsA, ewA, ecA, eB[7];
-  load_row(base_first, clsB, ewB, ecB);
-  load_row(base_first + 64, clsA, ewA, ecA);
+  int clsB, plB, ewB, ecB, clsA, plA, eB[7];
+  load_row(base_first, clsB, plB);
+  load_row(base_first + 64, clsA, plA);
+  place(plB, ewB, ecB);
   load_entries(ewB, ecB, eB);
   for (int base = base_first; base < f1; base += 64) {
     const int o = base + j;
@@ -964,9 +970,10 @@ __global__ __launch_bounds__(256, 2) void conv1_st_kernel(Conv1Args a) {
     int ecur[7];
 #pragma unroll
     for (int t = 0; t < 7; ++t) ecur[t] = eB[t];
-    clsB = clsA; ewB = ewA; ecB = ecA;
+    clsB = clsA;
+    place(plA, ewB, ecB);
     load_entries(ewB, ecB, eB);
-    load_row(base + 128, clsA, ewA, ecA);
+    load_row(base + 128, clsA, plA);
     {
       float4* z = reinterpret_cast<float4*>(&xt[wave][0][0][0]);
 #pragma unroll
@@ -1198,6 +1205,7 @@ int eyoc_spconv_staged(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* local_
 }
 
 int eyoc_spconv_st_tile(int rows) { return eyoc::select_st_tile(rows); }
+int eyoc_spconv_st_group_rows(int on) { return eyoc::select_st_group_rows(on); }
 
 size_t eyoc_spconv_local_rulebook_bytes_tile(int n_out, int tile) {
   return tile == 128 ? eyoc::local_rulebook128_bytes(n_out) : tile == 64 ? eyoc::local_rulebook64_bytes(n_out)

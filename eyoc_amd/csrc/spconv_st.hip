@@ -53,19 +53,32 @@ __host__ __device__ constexpr int slot_addr(int l) { return l * 64 + ((l >> 2) &
 // neighbour staged in the other pass).
 // Then, per pass, 27 (+1 pad) 16-bit occupancy masks: bit 4 w + c of mask (pass, k) = some row of rows 64 w + 16 c .. +15 has a
 // neighbour at offset k that is staged in this pass (the hand-scheduled loop skips the MFMAs of a chunk whose bit is clear).
+// Last, 256 bytes: the tile's ROW MAP.  The record describes 256 tile SLOTS; slot 64 w + 16 c + j holds local row
+// rowmap[(16 w + j) * 4 + c] of the tile (a permutation of 0 .. 255).  With row grouping on (round 4, the default) the builder
+// sorts the tile's rows by their neighbour pattern - 6 bits "any neighbour in the z+1 / z-1 / y+1 / y-1 / x+1 / x-1 layer", then the
+// 27-bit occupancy mask, z layers first - so that the 16 rows of an MFMA chunk miss the same offsets: non-empty (chunk, offset)
+// blocks 0.81 -> 0.68 at level 0, 0.93 -> 0.72 at levels 1 and 2, 0.66 -> 0.58 at level 3 on the bench geometry (the loop skips
+// the rest).  Only the ORDER of a tile's rows inside the workgroup changes: the stage, the products and their summation order per
+// output element are the same, results are bit-identical to the ungrouped records.
 constexpr int MASK_OFF = 16 + UCAP * 4 + NPASS * 27 * 64 * 8;   // 32784
 constexpr int MASK_PASS_BYTES = 56;
-constexpr int LR_BYTES = MASK_OFF + NPASS * MASK_PASS_BYTES;    // 32896
+constexpr int RM_OFF = MASK_OFF + NPASS * MASK_PASS_BYTES;      // 32896
+constexpr int INV_OFF = RM_OFF + TILE;                          // 33152: the inverse map, inv[local row] = slot (conv1_st_kernel finds a parent's entries with it)
+constexpr int LR_BYTES = INV_OFF + TILE;                        // 33408
+static_assert(INV_OFF == ST_INV_OFF, "spconv.h mirrors this layout");
 static_assert(TILE == ST_TILE && UMAX == ST_UMAX && UCAP == ST_UCAP && NPASS == ST_NPASS && LR_BYTES == ST_LR_BYTES, "spconv.h mirrors this layout");
+static_assert(LR_BYTES % 128 == 0, "records start on cache lines");
 // LDS hash of a tile's distinct input rows.  A usable tile has at most NPASS * UMAX = 1278 of them (31 % load); a tile with more
 // than HSLOTS (rows in no spatial order) gives up after a full round of probing and counts as overflowed.  (8192 slots - room
 // for all 256 * 27 possible rows - cost twice the clearing and numbering work and a third of the occupancy: 278 -> ~190 us at level 0.)
 constexpr int HSLOTS = 4096;
 
 __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restrict__ nbr, int K, int n_out, unsigned char* __restrict__ out,
-                                                        int* __restrict__ overflow) {
+                                                        int* __restrict__ overflow, int group) {
   __shared__ int hk[HSLOTS];
   __shared__ unsigned short hid[HSLOTS];
+  __shared__ unsigned short srow[27][TILE];                          // hash slot of (offset, local row), 0xFFFF = no neighbour
+  __shared__ unsigned long long key[TILE];
   __shared__ int wave_cnt[NW];
   __shared__ int too_many;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -94,6 +107,26 @@ __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restric
       }
     }
     slot[k] = (unsigned short)s;
+  }
+  // the tile's row order: sort key = (6 layer bits, occupancy mask with the z layers first, local row); ungrouped: the row itself
+  {
+    unsigned int mask = 0;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      srow[k][threadIdx.x] = slot[k];
+      if (slot[k] != 0xFFFFu) mask |= 1u << k;
+    }
+    // offsets enumerate x fastest: k = (dx + 1) + 3 (dy + 1) + 9 (dz + 1)
+    const unsigned int zp = (mask >> 18) & 0x1FFu, zm = mask & 0x1FFu, z0 = (mask >> 9) & 0x1FFu;
+    const unsigned int yp = mask & 0x70381C0u ? 1u : 0u;             // dy = +1: bits 6..8 of every z layer
+    const unsigned int ym = mask & 0x01C0E07u ? 1u : 0u;             // dy = -1: bits 0..2
+    const unsigned int xp = mask & 0x4924924u ? 1u : 0u;             // dx = +1: bits 2, 5, 8, ...
+    const unsigned int xm = mask & 0x1249249u ? 1u : 0u;             // dx = -1: bits 0, 3, 6, ...
+    unsigned int cb = (zp ? 32u : 0u) | (zm ? 16u : 0u) | (yp << 3) | (ym << 2) | (xp << 1) | xm;
+    cb ^= cb >> 1; cb ^= cb >> 2; cb ^= cb >> 4;                     // rank in the reflected Gray sequence: neighbouring buckets differ in one layer bit
+    const unsigned long long coarse = cb;
+    const unsigned long long pattern = ((unsigned long long)zp << 18) | ((unsigned long long)zm << 9) | z0;
+    key[threadIdx.x] = group ? (coarse << 35) | (pattern << 8) | threadIdx.x : (unsigned long long)threadIdx.x;
   }
   __syncthreads();
   if (too_many) {                                                      // workgroup-uniform
@@ -129,14 +162,36 @@ __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restric
     if (total > NPASS * UMAX) atomicAdd(overflow, 1);
   }
   __syncthreads();
-  // 3. LDS slot of every (offset, row): row r = 64 w + 16 c + j goes to 16-bit lane c of entry (k, 16 w + j)
+  if (group) {                                                         // 256-key bitonic sort (workgroup-uniform branch)
+    const int r_ = (int)threadIdx.x;
+    for (int kk = 2; kk <= TILE; kk <<= 1)
+      for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+        const int p = r_ ^ jj;
+        if (p > r_) {
+          const unsigned long long a_ = key[r_], b_ = key[p];
+          const bool up = (r_ & kk) == 0;
+          if ((a_ > b_) == up) { key[r_] = b_; key[p] = a_; }
+        }
+        __syncthreads();
+      }
+  }
+  // 3. LDS slot of every (offset, tile slot): thread s owns slot s = 64 w + 16 c + j, which holds local row src; the slot's
+  // entries go to 16-bit lane c of entry (k, 16 w + j)
   unsigned short* loc = reinterpret_cast<unsigned short*>(lr + 16 + UCAP * 4);
   unsigned char* msk = lr + MASK_OFF;
   __shared__ unsigned char nib[NPASS][27][NW];
   const int r = (int)threadIdx.x, w = r >> 6, c = (r >> 4) & 3, j = r & 15;
+  // sorted 16-row chunk i goes to slot chunk (w, c) = (i % 4, i / 4): dealt round-robin over the tile's four 64-slot quarters, so
+  // that every wave gets its share of the sparse and of the dense patterns (in sorted order the first quarter's waves would run
+  // out of non-empty blocks long before the last one's and wait at the tile's barriers)
+  // (snake order - 0 1 2 3 3 2 1 0 ... - so that the two row halves of a workgroup, quarters {0, 1} and {2, 3}, carry the same load)
+  const int src = (int)(key[group ? (c * 4 + ((c & 1) ? 3 - w : w)) * 16 + j : r] & 255u);
+  lr[RM_OFF + (w * 16 + j) * 4 + c] = (unsigned char)src;
+  lr[INV_OFF + src] = (unsigned char)r;
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
-    const int id = slot[k] != 0xFFFFu ? (int)hid[slot[k]] : -1;
+    const unsigned int hs = srow[k][src];
+    const int id = hs != 0xFFFFu ? (int)hid[hs] : -1;
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
       if (p > 0 && total <= p * UMAX) continue;                         // nobody reads the entries of a pass that does not happen
@@ -343,7 +398,7 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_kernel(SpconvArgs a, con
 #pragma unroll
   for (int hc = 0; hc < NH * NC; ++hc) {
     const int h = hc / NC, c = hc % NC;
-    const int o = tile * TILE + (w0 + h) * 64 + 16 * c + j;
+    const int o = tile * TILE + (int)lr[RM_OFF + ((w0 + h) * 16 + j) * 4 + c];       // the slot's row (record's row map)
     if (o >= a.n_out) continue;
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
@@ -557,11 +612,19 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
   // well) in front of every group, i.e. a store round trip AND a residual round trip per group, eight times in a row at the end of
   // every tile.  After the loop the 128 registers of the assembly blob are free: everything is in flight at once.
   constexpr int NG = NH * NC;
+  // output row of the lane's slot 64 (w0 + h) + 16 c + j: through the record's row map (a permutation of the tile's rows)
+  int orow[NG];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    const unsigned int rm = *reinterpret_cast<const unsigned int*>(lr + RM_OFF + ((w0 + h) * 16 + j) * 4);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) orow[h * NC + c] = tile * TILE + (int)((rm >> (8 * c)) & 255u);
+  }
   uint4 rh[NG], rl[NG];
   if (a.res) {
 #pragma unroll
     for (int hc = 0; hc < NG; ++hc) {
-      const int o = tile * TILE + (w0 + hc / NC) * 64 + 16 * (hc % NC) + j;
+      const int o = orow[hc];
       if (o < a.n_out) {
         const char* rp = reinterpret_cast<const char*>(a.res + (size_t)o * a.ld_res) + split16_off4(ch);
         rh[hc] = *reinterpret_cast<const uint4*>(rp);
@@ -572,7 +635,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
   float4 v[NG][NTW];
 #pragma unroll
   for (int hc = 0; hc < NG; ++hc) {
-    const int o = tile * TILE + (w0 + hc / NC) * 64 + 16 * (hc % NC) + j;
+    const int o = orow[hc];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
       const int ai = (hc * NTW + t) * 4;                                // register ACC(h, c, t) - 64 of the generator's map
@@ -594,7 +657,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
   }
 #pragma unroll
   for (int hc = 0; hc < NG; ++hc) {
-    const int o = tile * TILE + (w0 + hc / NC) * 64 + 16 * (hc % NC) + j;
+    const int o = orow[hc];
     if (o >= a.n_out) continue;
     if (SKIP == 7 && os != 12345.f) continue;                          // EYOC_ST_ABLATIONS: no epilogue (the accumulators stay live)
     if (a.out_split) {
@@ -643,9 +706,14 @@ size_t local_rulebook_bytes(int n_out) { return (size_t)cdiv(n_out, TILE) * LR_B
 
 // builds the per-tile local rulebooks of a stride-1 table; *overflow_dev (zeroed by the caller) counts tiles with more
 // than NPASS * UMAX distinct input rows (the staged kernel must not be used for the table then)
-int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st) {
+static std::atomic<int> g_st_group{1};
+int select_st_group_rows(int on) { return (on == 0 || on == 1) ? g_st_group.exchange(on) : g_st_group.load(); }
+
+// group: 1 = the tile's rows sorted by neighbour pattern, 0 = in their own order, -1 = the process-wide setting (select_st_group_rows)
+int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st, int group) {
   if (n_out <= 0) return EYOC_OK;
-  hipLaunchKernelGGL(k_local_rulebook, dim3(cdiv(n_out, TILE)), dim3(256), 0, st, nbr_dev, K, n_out, out_dev, overflow_dev);
+  if (group < 0) group = g_st_group.load();
+  hipLaunchKernelGGL(k_local_rulebook, dim3(cdiv(n_out, TILE)), dim3(256), 0, st, nbr_dev, K, n_out, out_dev, overflow_dev, group);
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
 }

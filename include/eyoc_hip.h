@@ -200,6 +200,11 @@ int eyoc_spconv_st_split_below(int workgroups);
  * previous value; process-wide, read by eyoc_maps_build).  The *_tile entry points take the shape explicitly (records of one
  * shape are not readable as the other). */
 int eyoc_spconv_st_tile(int rows);
+/* Row grouping inside the 256-row tile records (default on): the builder sorts a tile's rows by their neighbour pattern so that the 16
+ * rows of an MFMA chunk miss the same offsets - the staged loop skips (chunk, offset) blocks without a neighbour, and 0.81-0.93 of
+ * them are non-empty in row order, 0.68-0.72 grouped.  Results are bit-identical either way (only the order of a tile's rows inside
+ * its workgroup changes).  1 / 0 set, anything else only queries; returns the previous state; process-wide, read when records are built. */
+int eyoc_spconv_st_group_rows(int on);
 size_t eyoc_spconv_local_rulebook_bytes_tile(int n_out, int tile);
 int eyoc_spconv_build_local_rulebook_tile(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, int tile, void* out_dev,
                                           int32_t* overflow_dev, void* stream);

@@ -381,19 +381,36 @@ def test_staged_kernel_vs_fp64(morton_maps, cin, cout, level):
         lib.eyoc_spconv_st_split_below(prev_split)
     # the local rulebook: one record per 256-row tile - n_unique first, then the row list, the slot entries and, last, per pass
     # 28 16-bit occupancy masks (bit 4 w + c of mask k: some row of rows 64 w + 16 c .. + 15 has a neighbour at offset k)
-    REC, MASK_OFF = 32896, 32784
+    # ... and, last, the tile's row map: slot 64 w + 16 c + j holds local row rowmap[(16 w + j) * 4 + c] (the builder groups a tile's rows
+    # by neighbour pattern so that more (chunk, offset) blocks come out empty; in row order with eyoc_spconv_st_group_rows(0))
+    REC, MASK_OFF, RM_OFF = 33408, 32784, 32896
     n_tiles = (n + 255) // 256
     lr = local.cpu().numpy()[:n_tiles * REC].reshape(-1, REC)
     n_u = lr[:, :4].copy().view(np.int32)[:, 0]
     masks = lr[:, MASK_OFF:MASK_OFF + 56].copy().view(np.uint16)[:, :27]
+    rowmap = lr[:, RM_OFF:RM_OFF + 256].reshape(n_tiles, 4, 16, 4).transpose(0, 1, 3, 2).reshape(n_tiles, 256).astype(np.int64)   # [tile, slot]
+    assert (np.sort(rowmap, axis=1) == np.arange(256)).all()
     occ = np.zeros((n_tiles * 256, 27), bool)
     occ[:n] = (nbr >= 0).T
-    want_masks = (occ.reshape(n_tiles, 16, 16, 27).any(axis=2) * (1 << np.arange(16))[None, :, None]).sum(axis=1)
+    occ_rows = occ.reshape(n_tiles, 256, 27)
+    occ_slots = np.take_along_axis(occ_rows, rowmap[:, :, None], axis=1)
+    want_masks = (occ_slots.reshape(n_tiles, 16, 16, 27).any(axis=2) * (1 << np.arange(16))[None, :, None]).sum(axis=1)
+    f_rows, f_slots = occ_rows.reshape(n_tiles, 16, 16, 27).any(axis=2).mean(), occ_slots.reshape(n_tiles, 16, 16, 27).any(axis=2).mean()
+    assert f_slots < f_rows - 0.03, (f_rows, f_slots)
+    # grouping only re-orders a tile's rows inside its workgroup: bit-identical outputs
+    prev_g = lib.eyoc_spconv_st_group_rows(0)
+    try:
+        plain, local_plain = run_layer_staged(nbr, x, W, bias=b, scale=s, res=r, relu=True, out_split=False)
+    finally:
+        lib.eyoc_spconv_st_group_rows(prev_g)
+    np.testing.assert_array_equal(plain, got32)
+    rm_plain = local_plain.cpu().numpy()[:n_tiles * REC].reshape(-1, REC)[:, RM_OFF:RM_OFF + 256].reshape(n_tiles, 4, 16, 4).transpose(0, 1, 3, 2).reshape(n_tiles, 256)
+    assert (rm_plain == np.arange(256)).all()
     single = n_u <= 639                                    # tiles staged in one pass: the first-pass masks are the whole story
     np.testing.assert_array_equal(masks[single], want_masks[single].astype(np.uint16))
     pairs = int((nbr >= 0).sum())
     print(f"staged {cin}->{cout} level {level}: n {n} err {e:.2e} / {e32:.2e}  distinct rows per tile mean {n_u.mean():.0f} max {n_u.max()}"
-          f"  re-use {pairs / n_u.sum():.2f}x  empty (16-row chunk, offset) blocks {1 - (want_masks[:, :, None] >> np.arange(16) & 1).mean():.2f}")
+          f"  re-use {pairs / n_u.sum():.2f}x  non-empty (16-row chunk, offset) blocks {f_rows:.2f} in row order, {f_slots:.2f} grouped")
     assert e < 2e-6 and e32 < 2e-6 and n_u.max() <= 1278 and n_u.min() >= 1
 
 
@@ -481,7 +498,7 @@ def test_local_rulebook_counts_tiles_it_cannot_stage_instead_of_hanging():
     g = np.stack(np.meshgrid(np.arange(26), np.arange(26), np.arange(26), indexing="ij"), -1).reshape(-1, 3)
     coords = np.concatenate([np.zeros((len(g), 1), np.int64), g], 1).astype(np.int32)
     dev = torch.device("cuda")
-    REC = 32896
+    REC = 33408
     for order, expect_overflow in ((np.random.default_rng(0).permutation(len(coords)), True), (morton_order(coords), False)):
         nbr = oc.build_maps(coords[order])["s1"][0]
         n = nbr.shape[1]
