@@ -13,6 +13,9 @@ batch = DeviceBatch(pairs, list(range(P)), dev, descriptor=dict(inlier_ratio=0.3
 if os.environ.get("ST_TILE"):
     from eyoc_amd import _lib
     _lib.load().eyoc_spconv_st_tile(int(os.environ["ST_TILE"]))
+if os.environ.get("ST_GROUP"):
+    from eyoc_amd import _lib
+    _lib.load().eyoc_spconv_st_group_rows(int(os.environ["ST_GROUP"]))
 if os.environ.get("ZSPLIT"):
     from eyoc_amd import _lib
     _lib.load().eyoc_maps_internal_order(1)

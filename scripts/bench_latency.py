@@ -20,6 +20,9 @@ model = model.to(device).eval()
 if os.environ.get("ST_TILE"):                   # staged stride-1 kernel on 128- or 256-row tiles
     from eyoc_amd import _lib
     _lib.load().eyoc_spconv_st_tile(int(os.environ["ST_TILE"]))
+if os.environ.get("ST_GROUP"):
+    from eyoc_amd import _lib
+    _lib.load().eyoc_spconv_st_group_rows(int(os.environ["ST_GROUP"]))
 pipe = RegistrationPipeline(model, cfg)
 single = DeviceBatch([syn.make_pair(0)], [0], device, cfg.n_points)
 for _ in range(3):
