@@ -78,8 +78,11 @@ def parse_args(argv=None):
     ap.add_argument("--dry-run", action="store_true",
                     help="(tests) no GPU work: a stub step exercises launch / sharding / timing / gather on CPU over gloo")
     ap.add_argument("--overlap-maps", action="store_true",
-                    help="build the next step's coordinate maps on a side stream while the current step runs (measured: "
-                         "+0.5 % - the conv and RANSAC kernels fill the register files, the side stream only runs in their tails)")
+                    help="step s builds the maps of step s + 1 on a side stream while its own matching / RANSAC (fp64 VALU work, no "
+                         "LDS) runs on the main stream - harness.prepare_maps; every timed step still pays for exactly one map build, "
+                         "inside the timed bracket.  Measured round 4: 2584 -> 2625 pairs/s (+1.6 %) when it works - and in 3 of ~20 "
+                         "runs a one-off stall of 0.2-0.5 s somewhere in the timed region (cause not found: the side stream's "
+                         "allocator pool and queue are warmed in the warm-up steps), so it is NOT the default")
     ap.add_argument("--st-variant", type=int, default=-1,
                     help="diagnostics: staged-kernel implementation (eyoc_spconv_select_st_kernel: 0 C++ loop, 1 assembly loop, 2 assembly without empty-block branches)")
     ap.add_argument("--down-staged", type=int, default=-1, help="diagnostics: eyoc_spconv_select_down_kernel (0 / 1)")
@@ -315,9 +318,25 @@ def worker(args):
         torch.cuda.synchronize()
     log(f"inputs resident: {sum(b.voxels for _, b in batches)} voxels in {len(batches)} batch(es)")
 
+    warm_maps = None
     for i in range(args.warmup):
-        pipe.register(batches[i % len(batches)][1])
+        wb = batches[i % len(batches)][1]
+        if args.overlap_maps and not dry and cfg.use_RANSAC:
+            # the timed loop's own path: the side stream's allocator pool (the maps' workspace, a few GB) must be warm before
+            # the timed region - its first hipMallocs cost ~0.2 s
+            if warm_maps is None:
+                warm_maps = pipe.prepare_maps(wb)
+            wres = pipe.register(wb, return_device=True, maps=warm_maps)
+            nxt = pipe.prepare_maps(batches[(i + 1) % len(batches)][1])
+            wres.cpu()
+            model.check_range()
+            warm_maps = nxt
+        else:
+            pipe.register(wb)
         log(f"warmup {i} done")
+    if warm_maps is not None:              # prepared for a step that will not run: dropped (timed step 0 builds its own, inside the bracket)
+        torch.cuda.synchronize()
+        warm_maps = None
     if model is not None:
         model.set_timing(True)
         pipe.timing = True
@@ -369,10 +388,12 @@ def worker(args):
         if next_maps is None and overlap_maps:
             next_maps = pipe.prepare_maps(batch)                    # first step: nothing to hide behind
         res = pipe.register(batch, return_device=True, maps=next_maps)
+        log(f"step {s} enqueued")
         held, next_maps = next_maps, None
         if overlap_maps and s + 1 < steps_timed:
             # the next step's maps, on the side stream, while this step's matching / RANSAC runs on the main stream
             next_maps = pipe.prepare_maps(batches[(s + 1) % len(batches)][1])
+            log(f"step {s}: next maps built")
         if pending is not None:
             collect(pending)
         pending = (s, res, slot, held)
@@ -424,7 +445,9 @@ def worker(args):
                                  f"(mean {b0.voxels // (2 * b0.P)} voxels/cloud, ResUNetBN2C random-init, "
                                  f"5000-point NN, RANSAC {args.ransac_iters} hypotheses/pair, {plant}, spconv math {model.last_spconv_math})",
                      "pairs_per_step": args.pairs, "parallelism": f"pairs sharded over {world} GPU(s)",
-                     "inlier_ratio": args.inlier_ratio if descriptor else None}
+                     "inlier_ratio": args.inlier_ratio if descriptor else None,
+                     "map_build": ("maps of step s + 1 built on a side stream during step s's matching / RANSAC (one build per timed step)"
+                                   if overlap_maps and cfg.use_RANSAC else "in front of every forward, main stream")}
     if total_mode:
         out["config"]["total_pairs"] = args.total_pairs
         out["config"]["batches_per_rank"] = [len(ids) for ids, _ in batches]
