@@ -77,12 +77,13 @@ def parse_args(argv=None):
                     help="only the timed steps (profiling passes: keeps the kernel statistics to the timed region)")
     ap.add_argument("--dry-run", action="store_true",
                     help="(tests) no GPU work: a stub step exercises launch / sharding / timing / gather on CPU over gloo")
-    ap.add_argument("--overlap-maps", action="store_true",
+    ap.add_argument("--overlap-maps", action=argparse.BooleanOptionalAction, default=True,
                     help="step s builds the maps of step s + 1 on a side stream while its own matching / RANSAC (fp64 VALU work, no "
                          "LDS) runs on the main stream - harness.prepare_maps; every timed step still pays for exactly one map build, "
-                         "inside the timed bracket.  Measured round 4: 2584 -> 2625 pairs/s (+1.6 %) when it works - and in 3 of ~20 "
-                         "runs a one-off stall of 0.2-0.5 s somewhere in the timed region (cause not found: the side stream's "
-                         "allocator pool and queue are warmed in the warm-up steps), so it is NOT the default")
+                         "inside the timed bracket.  Round 4: +1.6-2 %% (2580 -> 2630 pairs/s).  The loop keeps three map sets alive, "
+                         "so after the W warm-up steps it runs untimed steps until the caching allocator has stopped growing "
+                         "(config.untimed_settle_steps) - a 9 GB hipMalloc inside the timed region costs 0.02-0.45 s on a fresh box; "
+                         "--no-overlap-maps builds the maps in front of every forward on the main stream")
     ap.add_argument("--st-variant", type=int, default=-1,
                     help="diagnostics: staged-kernel implementation (eyoc_spconv_select_st_kernel: 0 C++ loop, 1 assembly loop, 2 assembly without empty-block branches)")
     ap.add_argument("--down-staged", type=int, default=-1, help="diagnostics: eyoc_spconv_select_down_kernel (0 / 1)")
@@ -318,41 +319,13 @@ def worker(args):
         torch.cuda.synchronize()
     log(f"inputs resident: {sum(b.voxels for _, b in batches)} voxels in {len(batches)} batch(es)")
 
-    warm_maps = None
-    for i in range(args.warmup):
-        wb = batches[i % len(batches)][1]
-        if args.overlap_maps and not dry and cfg.use_RANSAC:
-            # the timed loop's own path: the side stream's allocator pool (the maps' workspace, a few GB) must be warm before
-            # the timed region - its first hipMallocs cost ~0.2 s
-            if warm_maps is None:
-                warm_maps = pipe.prepare_maps(wb)
-            wres = pipe.register(wb, return_device=True, maps=warm_maps)
-            nxt = pipe.prepare_maps(batches[(i + 1) % len(batches)][1])
-            wres.cpu()
-            model.check_range()
-            warm_maps = nxt
-        else:
-            pipe.register(wb)
-        log(f"warmup {i} done")
-    if warm_maps is not None:              # prepared for a step that will not run: dropped (timed step 0 builds its own, inside the bracket)
-        torch.cuda.synchronize()
-        warm_maps = None
     if model is not None:
         model.set_timing(True)
         pipe.timing = True
     layer_ms, stage_ms, n_fwd = None, {"feat": 0.0, "match": 0.0, "reg": 0.0}, 0
     passes = args.steps
     steps_timed = passes * len(batches) if total_mode else passes
-    edist.barrier()
-    if not dry:
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
     last = {}
-    # Software-pipelined over the steps: step s is ENQUEUED before the host reads step s-1's results and timers (two
-    # event sets, results left on the device until then), so the GPU never waits for the host's decode between steps.
-    # Everything - the last step's read-back included - is inside the timed bracket.
-    pending = None           # (step, device result, event slot, maps) of the step whose read-back is still due
-    next_maps = None
     overlap_maps = args.overlap_maps
 
     def collect(item):
@@ -371,38 +344,73 @@ def worker(args):
                 stage_ms[k] += v
             n_fwd += 1
 
-    for s in range(steps_timed):
-        ids, batch = batches[s % len(batches)]
-        if dry or not cfg.use_RANSAC:
-            last[s % len(batches)] = pipe.register(batch)
-            if model is not None and not dry:
-                ms = np.array(model.layer_ms())
-                layer_ms = ms if layer_ms is None else layer_ms + ms
-                for k, v in pipe.stage_ms().items():
-                    stage_ms[k] += v
-                n_fwd += 1
-            continue
-        slot = s & 1
-        model.timing_slot(slot)
-        pipe.slot = slot
-        if next_maps is None and overlap_maps:
-            next_maps = pipe.prepare_maps(batch)                    # first step: nothing to hide behind
-        res = pipe.register(batch, return_device=True, maps=next_maps)
-        log(f"step {s} enqueued")
-        held, next_maps = next_maps, None
-        if overlap_maps and s + 1 < steps_timed:
-            # the next step's maps, on the side stream, while this step's matching / RANSAC runs on the main stream
-            next_maps = pipe.prepare_maps(batches[(s + 1) % len(batches)][1])
-            log(f"step {s}: next maps built")
+    def run_steps(n_steps):
+        """Software-pipelined over the steps: step s is ENQUEUED before the host reads step s-1's results and timers (two
+        event sets, results left on the device until then), so the GPU never waits for the host's decode between steps.
+        Everything - the last step's read-back included - happens inside this call.  The warm-up runs the SAME code (same
+        streams, same number of live map sets and workspaces: their first hipMallocs cost ~0.25 s apiece on a fresh box)."""
+        nonlocal layer_ms, n_fwd
+        t_loop = time.perf_counter()
+        pending = None           # (step, device result, event slot, maps) of the step whose read-back is still due
+        next_maps = None
+        for s in range(n_steps):
+            ids, batch = batches[s % len(batches)]
+            if dry or not cfg.use_RANSAC:
+                last[s % len(batches)] = pipe.register(batch)
+                if model is not None and not dry:
+                    ms = np.array(model.layer_ms())
+                    layer_ms = ms if layer_ms is None else layer_ms + ms
+                    for k, v in pipe.stage_ms().items():
+                        stage_ms[k] += v
+                    n_fwd += 1
+                continue
+            slot = s & 1
+            model.timing_slot(slot)
+            pipe.slot = slot
+            if next_maps is None and overlap_maps:
+                next_maps = pipe.prepare_maps(batch)                    # first step: nothing to hide behind
+            res = pipe.register(batch, return_device=True, maps=next_maps)
+            held, next_maps = next_maps, None
+            if overlap_maps and s + 1 < n_steps:
+                # the next step's maps, on the side stream, while this step's matching / RANSAC runs on the main stream
+                next_maps = pipe.prepare_maps(batches[(s + 1) % len(batches)][1], after=pipe.matched)
+            if pending is not None:
+                collect(pending)
+            pending = (s, res, slot, held)
+            if args.verbose:
+                st = torch.cuda.memory_stats()
+                log(f"step {s}: enqueued at {time.perf_counter() - t_loop:.4f} s, reserved {st['reserved_bytes.all.current'] >> 20} MiB, "
+                    f"device allocs {st['num_device_alloc']}, frees {st['num_device_free']}")
         if pending is not None:
             collect(pending)
-        pending = (s, res, slot, held)
-    if pending is not None:
-        collect(pending)
+
+    run_steps(args.warmup)
+    log(f"{args.warmup} warm-up step(s) done")
+    settle = 0
+    if overlap_maps and not dry:
+        # the pipelined loop keeps three map sets alive from its third step on; a warm-up shorter than that leaves the third
+        # block's hipMalloc (0.02-0.45 s on a fresh box) inside the timed region.  Run untimed steps until the caching
+        # allocator has stopped growing (bounded), and report how many that took.
+        for _ in range(3):
+            a0 = torch.cuda.memory_stats()["num_device_alloc"]
+            run_steps(3)
+            settle += 3
+            if torch.cuda.memory_stats()["num_device_alloc"] == a0:
+                break
+        log(f"{settle} allocator-settling step(s) done")
+    layer_ms, stage_ms, n_fwd = None, {"feat": 0.0, "match": 0.0, "reg": 0.0}, 0
+    last.clear()
+    edist.barrier()
+    if not dry:
+        torch.cuda.synchronize()
+    allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0) if not dry else 0
+    t0 = time.perf_counter()
+    run_steps(steps_timed)
     edist.barrier()
     if not dry:
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    allocs_timed = (torch.cuda.memory_stats().get("num_device_alloc", 0) - allocs0) if not dry else 0
     elapsed = edist.max_over_ranks(elapsed, device)
     if model is not None:
         model.set_timing(False)
@@ -448,6 +456,10 @@ def worker(args):
                      "inlier_ratio": args.inlier_ratio if descriptor else None,
                      "map_build": ("maps of step s + 1 built on a side stream during step s's matching / RANSAC (one build per timed step)"
                                    if overlap_maps and cfg.use_RANSAC else "in front of every forward, main stream")}
+    if not dry:
+        out["config"]["device_allocs_in_timed_region"] = allocs_timed
+    if settle:
+        out["config"]["untimed_settle_steps"] = settle      # after the W warm-up steps, until the allocator stopped growing
     if total_mode:
         out["config"]["total_pairs"] = args.total_pairs
         out["config"]["batches_per_rank"] = [len(ids) for ids, _ in batches]

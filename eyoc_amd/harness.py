@@ -180,14 +180,19 @@ class RegistrationPipeline:
             return self.register(batch, seed, False, maps)
 
     @torch.no_grad()
-    def prepare_maps(self, batch: DeviceBatch):
+    def prepare_maps(self, batch: DeviceBatch, after=None):
         """Build the coordinate maps of ``batch`` NOW, on a side stream: they only depend on the coordinates, so a
         serving loop builds the next batch's maps (hash / sort / rulebook kernels, latency- and atomics-bound) while the
         previous batch is still in its RANSAC (VALU-bound) on the main stream.  Returns the handle ``register(...,
-        maps=)`` takes; keep it alive until that step's results were read."""
+        maps=)`` takes; keep it alive until that step's results were read.  ``after``: an event the side stream waits for
+        first - ``self.matched`` (recorded by ``register`` when its forward and matching are enqueued) puts the build
+        beside that step's RANSAC instead of beside whatever the main stream happens to run at enqueue time (the forward:
+        both want LDS and the atomics path, and the forward's kernels slow down by ~10 %)."""
         from .sparse_tensor import CoordinateManager
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=batch.coords.device)
+        if after is not None:
+            self._side.wait_event(after)
         with torch.cuda.stream(self._side):
             cm = CoordinateManager(batch.coords)
             cm.maps(-1)
@@ -209,6 +214,8 @@ class RegistrationPipeline:
             nn_idx = knn1_segmented(F0, F1, batch.seg, batch.seg, "SquareL2", return_distance=False)
             self.last_nn_idx = nn_idx
             self._mark(2)
+            self.matched = torch.cuda.Event()
+            self.matched.record()
             # all pairs in one batched call (pair p samples with seed + p, exactly like a per-pair loop would)
             res = reg.ransac_batched_from_correspondences(
                 batch.xyz0.reshape(-1, 3), batch.xyz1.reshape(-1, 3), nn_idx, batch.seg, batch.seg,
