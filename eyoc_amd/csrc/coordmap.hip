@@ -573,6 +573,7 @@ size_t eyoc_maps_workspace_bytes(int n_rows) {
   b += 3 * align_up(local_rulebook_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_bytes(1)) + 256);   // stride-1 tables (+ level 1 in row order)
   b += 2 * align_up(local_rulebook128_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook128_bytes(1)) + 256);   // 128-row tile records (+ level 1 twice)
   b += 2 * align_up(local_rulebook_up_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_up_bytes(1)) + 256);
+  b += 2 * (align_up(upc_kept_bytes(n_rows)) + align_up(upc_scratch_bytes(n_rows))) + EYOC_MAX_LEVELS * (align_up(upc_kept_bytes(1)) + align_up(upc_scratch_bytes(1)) + 512);   // class-major transposed records + their builder's scratch
   b += align_up(local_rulebook64_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook64_bytes(1)) + 256);   // strided tables (coarse levels sum to < n rows), 64-row tiles
   b += 4096;                                                         // counters
   return b + 96 * 256;
@@ -781,7 +782,7 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
     if (m->rows[l] < ORDER_MIN_ROWS) continue;
     // the transposed tables' order serves the gathering kernels only: Z-ordered maps with the staged transposed kernel (which sorts
     // inside its tiles) skip it - and with it the whole radix sort, nothing else being ordered there (0.3 ms per 128-cloud batch)
-    if (l + 1 < EYOC_MAX_LEVELS && !(zorder && spconv_up_enabled())) { seg_up[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l]; }
+    if (l + 1 < EYOC_MAX_LEVELS && !(zorder && (spconv_up_enabled() || spconv_upc_enabled()))) { seg_up[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l]; }
     if (s1_order && !zorder) { seg_s1[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l]; }
   }
   constexpr int TAG_SHIFT = UP_KEY_BITS, TAG_BITS = 4;   // pattern keys < 2^11, window number, segment tag above (at most 10 segments)
@@ -847,12 +848,22 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
         m->local_up[l] = cv.take<unsigned char>(local_rulebook_up_bytes(m->rows[l]));
         if (int rc = build_local_rulebook_up(m->nbr_up[l], 27, m->rows[l], m->local_up[l], counters + 9, st)) { delete m; return rc; }
       }
+      if (l + 1 < EYOC_MAX_LEVELS && spconv_upc_enabled()) {   // ... in class-major order (spconv_upc.hip)
+        m->local_upc[l] = cv.take<unsigned char>(upc_kept_bytes(m->rows[l]));
+        unsigned char* scratch = cv.take<unsigned char>(upc_scratch_bytes(m->rows[l]));
+        if (m->local_upc[l])
+          if (int rc = build_upc(m->nbr_up[l], m->rows[l], m->local_upc[l], scratch, st)) { delete m; return rc; }
+      }
       // the strided table level l -> l + 1: 64-row-tile records for the two fine ones (32 -> 64 and 64 -> 128 channels measured
       // -25 % / -16 % on them; the coarsest, 128 -> 256 on few rows, is level with the gathering kernel and keeps it)
       if (l + 1 < EYOC_MAX_LEVELS - 1 && m->nbr_down[l] && spconv_down_staged()) {
         m->local_down[l] = cv.take<unsigned char>(local_rulebook64_bytes(m->rows[l + 1]));     // 64-row output tiles (spconv_st128.hip)
         if (int rc = build_local_rulebook64(m->nbr_down[l], 27, m->rows[l + 1], m->local_down[l], counters + 10 + l, st)) { delete m; return rc; }
       }
+    }
+    for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
+      host[16 + l] = 0;
+      if (m->local_upc[l]) FAIL_HIP(hipMemcpyAsync(host + 16 + l, upc_overflow_ptr(m->local_upc[l]), sizeof(int), hipMemcpyDeviceToHost, st));
     }
     FAIL_HIP(hipMemcpyAsync(host, counters + 8, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
     FAIL_HIP(hipMemcpyAsync(host + 32, counters, 8 * sizeof(int), hipMemcpyDeviceToHost, st));   // errors + the scans' own totals
@@ -878,6 +889,8 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
     if (host[0] != 0 || host[6] != 0) m->local1_256 = nullptr;
     if (host[1] != 0)   // ... more than 639 distinct coarse rows under a 256-row tile
       for (int l = 0; l < EYOC_MAX_LEVELS; ++l) m->local_up[l] = nullptr;
+    for (int l = 0; l < EYOC_MAX_LEVELS; ++l)   // a class tile with more than 1278 distinct coarse rows: that table stays on the gathering kernels
+      if (host[16 + l] != 0) m->local_upc[l] = nullptr;
     for (int l = 0; l + 1 < EYOC_MAX_LEVELS; ++l)
       if (host[2 + l] != 0) m->local_down[l] = nullptr;
   }

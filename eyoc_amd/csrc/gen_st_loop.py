@@ -26,7 +26,12 @@ K, NC, NTW = 27, 4, 2
 LO_REGION = 640 * 64      # the LDS stage: 640 rows x 64 B of hi halves, then the same of lo halves (spconv_st.hip)
 
 
-def gen(NH, WD, LD=2, skip=True, abl=()):
+def gen(NH, WD, LD=2, skip=True, abl=(), K=K, koff=False, tag=""):
+    """``K``: offsets the blob walks (27 = a stride-1 table).  ``koff``: the weight fragments of offset i start at
+    ws0 + s[52 + i] instead of ws0 + i * ks - the class-major transposed kernel (spconv_upc.hip) walks the 1, 2, 4 or 8
+    offsets of ONE parity class, which are not equidistant in the packed weights (K <= 8 then)."""
+    assert not koff or K <= 8
+    WD, LD = min(WD, K), min(LD, K)
     NWS, NLS = WD + 1, LD + 1
     ACC = lambda h, c, t: 64 + ((h * NC + c) * NTW + t) * 4
     XS = lambda s, c, p: 128 + s * 32 + (c * 2 + p) * 4
@@ -70,11 +75,14 @@ def gen(NH, WD, LD=2, skip=True, abl=()):
         s = k % NWS
         if "now" in abl:
             return
+        if koff:
+            emit(f"s_add_u32 %[so], %[ws0], s{52 + k}")
         for t in range(NTW):
             for p in range(2):
                 emit(f"buffer_load_dwordx4 {vr(WS(s, t, p))}, {WL0}, %[wr], %[so] offen offset:{p * 1024 + t * 64}")
                 vmq.append(("W", k))
-        emit("s_add_u32 %[so], %[so], %[ks]")
+        if not koff:
+            emit("s_add_u32 %[so], %[so], %[ks]")
 
     def issue_l(k):
         if "nol" in abl:
@@ -161,7 +169,7 @@ def gen(NH, WD, LD=2, skip=True, abl=()):
                 t0, t1 = T[(c & 1) * 2], T[(c & 1) * 2 + 1]
                 if has_next:
                     addr(kn, hn, c, t0, t1)
-                lab = f"k{k}h{h}c{c}"
+                lab = f"{tag}k{k}h{h}c{c}"
                 if has_next:
                     read(hs + 1, c, 0, t0)
                     read(hs + 1, c, 1, t0)
@@ -317,6 +325,20 @@ def main(path):
         write_blob(f, "NH2", gen(2, WD2, LD2))
         write_blob(f, "NH1", gen(1, 2, 2))
         write_blob(f, "NH2_NOSKIP", gen(2, WD2, LD2, skip=False))
+        # spconv_upc.hip: the offsets of ONE parity class of a transposed (stride 2) table - 1, 2, 4 or 8 of them, %[nk] says how
+        # many.  One statement with a scalar dispatch in front (four statements in an if-chain made the compiler shuffle the
+        # pinned accumulators through scratch: 168 spilled VGPRs)
+        upc = []
+        for kc in (8, 4, 2):
+            upc += [f"s_cmp_eq_u32 %[nk], {kc}", f"s_cbranch_scc1 .Lst%=_upc{kc}"]
+        for kc in (1, 2, 4, 8):
+            if kc > 1:
+                upc.append(f".Lst%=_upc{kc}:")
+            upc += gen(2, WD2, LD2, K=kc, koff=True, tag=f"u{kc}")
+            if kc < 8:
+                upc.append("s_branch .Lst%=_upcend")
+        upc.append(".Lst%=_upcend:")
+        write_blob(f, "UPC", upc)
         f.write(f"#define EYOC_ST_LOOP_CLOBBERS {clobbers()}\n")
         # spconv_st128.hip: 128-row tiles, 64 rows x 32 channels per wave inside 128 VGPRs (four waves per SIMD, four workgroups per CU)
         write_blob(f, "T128", gen_w8(lo_region=320 * 64, lrows=32))

@@ -32,6 +32,7 @@ struct SpconvArgs {
   const unsigned char* local = nullptr;   // per-tile local rulebooks of `nbr` (build_local_rulebook / build_local_rulebook128) or NULL: enables the staged kernel
   int local_tile = 256;                   // rows per tile of `local`: 256 (spconv_st.hip), 128 or 64 (spconv_st128.hip)
   const unsigned char* local_up = nullptr;   // ... of a transposed table (build_local_rulebook_up): enables spconv_up.hip
+  const unsigned char* local_upc = nullptr;  // ... in class-major order (build_upc): enables spconv_upc.hip
   const float* out_scale = nullptr;  // device scalar multiplied into the accumulated sums (undoes the weight pre-scale); NULL = 1
   // optional: a permutation of the output rows; tiles take rows in this order (any order gives the same result,
   // a good one makes the rows of a tile share their occupied offsets).  NULL = natural order.
@@ -123,6 +124,13 @@ int launch_spconv_st(const SpconvArgs& a, const unsigned char* local_dev, hipStr
 int launch_spconv_up(const SpconvArgs& a, const unsigned char* local_dev, hipStream_t st);   // transposed 3^3 / stride 2 (spconv_up.hip)
 size_t local_rulebook_up_bytes(int n_out);
 int build_local_rulebook_up(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st);
+// class-major transposed kernel (spconv_upc.hip): `ws` = upc_kept_bytes of header + tile order + records, built by build_upc
+// (which also needs upc_scratch_bytes of scratch it does not keep)
+size_t upc_kept_bytes(int n_out);
+size_t upc_scratch_bytes(int n_out);
+int build_upc(const int32_t* nbr_dev, int n_out, unsigned char* ws, unsigned char* scratch, hipStream_t st);
+const int* upc_overflow_ptr(const unsigned char* ws);
+int launch_spconv_upc(const SpconvArgs& a, const unsigned char* ws, hipStream_t st);
 int select_st_variant(int v);   // spconv_st.hip: which staged kernel (returns the previous one)
 int select_st_split_below(int workgroups);   // layers with fewer 64-channel workgroups take 32-channel ones (returns the previous threshold)
 size_t local_rulebook_bytes(int n_out);
@@ -144,7 +152,8 @@ int launch_tail_fused(const float* in, int ld_in, int n, const float* w1, const 
                       const float* s2, const float* b2, int l2norm, float* out, int ld_out, const int32_t* out_perm, unsigned int* range,
                       hipStream_t st);
 bool spconv_rs_fits(const SpconvArgs& a);
-bool spconv_up_enabled();    // eyoc_spconv_select_up_kernel state
+bool spconv_up_enabled();    // eyoc_spconv_select_up_kernel state == 1 (spconv_up.hip)
+bool spconv_upc_enabled();   // ... == 2 (spconv_upc.hip)
 bool spconv_down_staged();   // eyoc_spconv_select_down_kernel state
 int spconv_forced_kernel();   // eyoc_spconv_select_kernel state: -1 automatic, 0 workgroup-tiled, 1 wave-private
 int launch_spconv_wave(const SpconvArgs& a, hipStream_t st);   // wave-private tiling (spconv_wave.hip)

@@ -724,7 +724,8 @@ int spconv_forced_kernel() { return g_kernel_mode; }
 // row-stationary kernel in windowed pattern order in time (0.68 / 1.06 / 1.44 vs 0.63 / 1.02 / 1.57 ms on the bench's three
 // layers, + 0.25 ms of rulebooks in the map build; the step is the same within noise) and 18 GB less HBM traffic per forward
 int g_up_kernel = 1;                      // eyoc_spconv_select_up_kernel
-bool spconv_up_enabled() { return g_up_kernel != 0; }
+bool spconv_up_enabled() { return g_up_kernel == 1; }
+bool spconv_upc_enabled() { return g_up_kernel == 2; }
 int g_conv1_staged = 1;   // eyoc_spconv_select_conv1_kernel: 1 the first convolution of Z-ordered split16 forwards on conv1_st_kernel, 0 on conv1_mfma_kernel, 2 on the exact-fp32 octree walker
 int g_down_staged = 0;   // strided convolutions on Z-ordered maps through the staged kernel (eyoc_spconv_select_down_kernel): off - their tiles overflow 2 passes
 bool spconv_down_staged() { return g_down_staged != 0; }
@@ -772,6 +773,11 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
       b.perm = nullptr;
       if (a.local_tile == 128 || a.local_tile == 64) return launch_spconv_st128(b, a.local, a.local_tile, select_st_variant(-1) != 2, st);
       return launch_spconv_st(b, a.local, st);
+    }
+    if (a.math == 1 && a.local_upc && use_rs != 0 && a.K == 27 && !a.l2norm && !a.res && !a.out_perm && a.cout % 64 == 0) {   // transposed table, class-major tiles
+      SpconvArgs b = a;
+      b.perm = nullptr;
+      return launch_spconv_upc(b, a.local_upc, st);
     }
     if (a.math == 1 && a.local_up && use_rs != 0 && a.K == 27 && !a.l2norm && a.cout % 64 == 0) {   // transposed table with tile rulebooks
       SpconvArgs b = a;
@@ -1235,8 +1241,33 @@ int eyoc_spconv_staged_tile(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* l
 
 int eyoc_spconv_select_up_kernel(int on) {
   const int prev = eyoc::g_up_kernel;
-  if (on == 0 || on == 1) eyoc::g_up_kernel = on;
+  if (on >= 0 && on <= 2) eyoc::g_up_kernel = on;
   return prev;
+}
+
+size_t eyoc_spconv_upc_bytes(int n_out) { return n_out < 0 ? 0 : eyoc::upc_kept_bytes(n_out) + eyoc::upc_scratch_bytes(n_out) + 512; }
+
+int eyoc_spconv_upc_build(eyoc_ctx* ctx, const int32_t* nbr_dev, int n_out, void* ws_dev, int32_t* info_host, void* stream) {
+  EYOC_REQUIRE(ctx && nbr_dev && ws_dev && n_out >= 0 && ((uintptr_t)ws_dev & 255) == 0, EYOC_ERR_INVALID, "eyoc_spconv_upc_build: bad argument");
+  unsigned char* ws = (unsigned char*)ws_dev;
+  if (int rc = eyoc::build_upc(nbr_dev, n_out, ws, ws + ((eyoc::upc_kept_bytes(n_out) + 255) & ~(size_t)255), (hipStream_t)stream)) return rc;
+  if (info_host) {   // {n_tiles, tile_start[9], count[8], overflow}: one synchronising copy (tests, diagnostics)
+    EYOC_CHECK_HIP(hipMemcpyAsync(info_host, ws, 19 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    EYOC_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  }
+  return EYOC_OK;
+}
+
+int eyoc_spconv_upc(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* ws_dev, int n_out, int n_in, const float* in_dev, int ld_in, int cin,
+                    const float* wpacked_dev, int cout, const float* bias_dev, int relu, float* out_dev, int ld_out, int out_split,
+                    const float* out_scale_dev, void* stream) {
+  EYOC_REQUIRE(ctx && nbr_dev && ws_dev, EYOC_ERR_INVALID, "eyoc_spconv_upc: NULL argument");
+  SpconvArgs a;
+  a.nbr = nbr_dev; a.K = 27; a.n_out = n_out; a.n_in = n_in; a.in = in_dev; a.ld_in = ld_in; a.cin = cin; a.w = wpacked_dev;
+  a.cout = cout; a.bias = bias_dev; a.res = nullptr; a.ld_res = 0; a.relu = relu; a.l2norm = 0;
+  a.out = out_dev; a.ld_out = ld_out; a.math = 1; a.out_split = out_split; a.out_scale = out_scale_dev;
+  a.local_upc = (const unsigned char*)ws_dev; a.ctx = ctx;
+  return launch_spconv(a, (hipStream_t)stream);
 }
 
 int eyoc_spconv_select_conv1_kernel(int on) {

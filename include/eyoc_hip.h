@@ -171,6 +171,18 @@ int eyoc_spconv_select_split16_kernel(int mode);
  * kernel in windowed pattern order, 18 GB less HBM traffic per 128-cloud forward), 0 off; other values only query.  Returns the previous
  * state.  Process-wide, read when maps are built; for tests and profiling. */
 int eyoc_spconv_select_up_kernel(int on);
+/* The same layers in CLASS-MAJOR order (spconv_upc.hip; eyoc_spconv_select_up_kernel(2)): the fine rows are partitioned by parity
+ * class (8 classes of 1-8 offsets), a tile is 256 rows of one class and runs the staged kernel's assembly loop over that class's
+ * offsets only.  Standalone entry points (the model uses the same kernels through its maps): workspace size for a table with
+ * n_out fine rows; build (ws_dev 256-byte aligned; info_host = NULL or 19 ints {tiles, first tile of class 0..8, rows of class
+ * 0..7, tiles with more distinct coarse rows than two stage passes hold - the kernel must not be used then}, which
+ * synchronises the stream); the layer (split16 rows in, split16 or fp32 rows out, no residual).
+ *   replaces: ME.MinkowskiConvolutionTranspose(kernel_size=3, stride=2) of model/resunet.py:83-116 */
+size_t eyoc_spconv_upc_bytes(int n_out);
+int eyoc_spconv_upc_build(eyoc_ctx* ctx, const int32_t* nbr_dev, int n_out, void* ws_dev, int32_t* info_host, void* stream);
+int eyoc_spconv_upc(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* ws_dev, int n_out, int n_in, const float* in_dev, int ld_in,
+                    int cin, const float* wpacked_dev, int cout, const float* bias_dev, int relu, float* out_dev, int ld_out,
+                    int out_split, const float* out_scale_dev, void* stream);
 /* Strided 3^3 / stride-2 convolutions on Z-ordered maps through the small-tile staged kernel (spconv_st128.hip on 64-ROW output
  * tiles: a tile's inputs - its rows' children plus the halo of the -1 offsets, 190-330 distinct fine rows - are staged in LDS once
  * per 32-channel block, up to three passes of 319 rows): 1 on for the two fine tables (32 -> 64 and 64 -> 128 channels: -25 % /

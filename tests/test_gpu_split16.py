@@ -247,7 +247,7 @@ def test_forward_on_z_ordered_rows_with_the_staged_kernel(request):
     prev = lib.eyoc_maps_internal_order(1) - 2
     prev_up = lib.eyoc_spconv_select_up_kernel(-1)
     try:
-        for mode, up in (("split16", 0), ("split16", 1), ("fp32", 0)):   # up = 1: transposed convolutions on spconv_up.hip
+        for mode, up in (("split16", 0), ("split16", 1), ("split16", 2), ("fp32", 0)):   # up = 1: transposed convolutions on spconv_up.hip, 2: spconv_upc.hip
             lib.eyoc_spconv_select_up_kernel(up)
             model.spconv_math = mode
             got = _forward(model, coords, feats)
