@@ -770,6 +770,11 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
   const bool s1_order = S1_ORDER != 0;
   int seg_up[EYOC_MAX_LEVELS], seg_s1[EYOC_MAX_LEVELS], seg_dn[EYOC_MAX_LEVELS], seg_base[3 * EYOC_MAX_LEVELS], n_seg = 0;
   size_t total = 0;
+  // transposed tables on Z-ordered maps: class-major tiles (spconv_upc.hip) for batches, Morton tiles (spconv_up.hip) below
+  // UPC_MIN_ROWS voxels - the partition's five small launches per level cost a single pair (60 k voxels) more than its kernel saves
+  // (eyoc_spconv_upc_min_rows, default 2^17)
+  const bool use_upc = spconv_upc_enabled() && n >= spconv_upc_min_rows();
+  const bool use_up = spconv_up_enabled() || (spconv_upc_enabled() && !use_upc);
   for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
     seg_up[l] = seg_s1[l] = seg_dn[l] = -1;
     // Z-ordered maps tile the strided convolutions in natural order: a tile's 64 coarse rows read their (adjacent)
@@ -782,7 +787,7 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
     if (m->rows[l] < ORDER_MIN_ROWS) continue;
     // the transposed tables' order serves the gathering kernels only: Z-ordered maps with the staged transposed kernel (which sorts
     // inside its tiles) skip it - and with it the whole radix sort, nothing else being ordered there (0.3 ms per 128-cloud batch)
-    if (l + 1 < EYOC_MAX_LEVELS && !(zorder && (spconv_up_enabled() || spconv_upc_enabled()))) { seg_up[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l]; }
+    if (l + 1 < EYOC_MAX_LEVELS && !(zorder && (use_up || use_upc))) { seg_up[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l]; }
     if (s1_order && !zorder) { seg_s1[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l]; }
   }
   constexpr int TAG_SHIFT = UP_KEY_BITS, TAG_BITS = 4;   // pattern keys < 2^11, window number, segment tag above (at most 10 segments)
@@ -844,15 +849,15 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
         if (int rc = build_local_rulebook(m->nbr_s1[l], 27, m->rows[l], m->local_s1[l], counters + 8, st)) { delete m; return rc; }
         if (l == 1) m->local1_256 = m->local_s1[l];     // the staged first convolution finds a parent's slot through the record's inverse row map
       }
-      if (l + 1 < EYOC_MAX_LEVELS && spconv_up_enabled()) {   // the transposed table whose outputs are this level's rows
+      if (l + 1 < EYOC_MAX_LEVELS && use_up) {   // the transposed table whose outputs are this level's rows
         m->local_up[l] = cv.take<unsigned char>(local_rulebook_up_bytes(m->rows[l]));
         if (int rc = build_local_rulebook_up(m->nbr_up[l], 27, m->rows[l], m->local_up[l], counters + 9, st)) { delete m; return rc; }
       }
-      if (l + 1 < EYOC_MAX_LEVELS && spconv_upc_enabled()) {   // ... in class-major order (spconv_upc.hip)
+      if (l + 1 < EYOC_MAX_LEVELS && use_upc) {   // ... in class-major order (spconv_upc.hip)
         m->local_upc[l] = cv.take<unsigned char>(upc_kept_bytes(m->rows[l]));
         unsigned char* scratch = cv.take<unsigned char>(upc_scratch_bytes(m->rows[l]));
         if (m->local_upc[l])
-          if (int rc = build_upc(m->nbr_up[l], m->rows[l], m->local_upc[l], scratch, st)) { delete m; return rc; }
+          if (int rc = build_upc(m->nbr_up[l], m->coords[l], 1 << l, m->rows[l], m->local_upc[l], scratch, st)) { delete m; return rc; }
       }
       // the strided table level l -> l + 1: 64-row-tile records for the two fine ones (32 -> 64 and 64 -> 128 channels measured
       // -25 % / -16 % on them; the coarsest, 128 -> 256 on few rows, is level with the gathering kernel and keeps it)

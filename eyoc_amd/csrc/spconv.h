@@ -118,6 +118,23 @@ __device__ inline bool split16_poisoned(const unsigned int* range) { return rang
 // later (gathers, weight pieces) into a blocking one: each stage then pays a full memory latency at its barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Tile builders hash a tile's distinct input rows into an LDS table (linear probing, atomicCAS) and number the occupied slots
+// in slot order.  Which key of a probe cluster landed in which of its slots depends on the order the CAS loops ran in; the SET
+// of occupied slots and the keys of a cluster (a maximal circular run of occupied slots) do not.  canonical_slot_id gives the
+// r-th smallest key of a cluster the number of the cluster's r-th slot: the numbering - and with it WHICH PASS stages a row, i.e.
+// the order in which a multi-pass tile's products are summed - is the same in every run (bit-reproducible outputs).
+// hk: the table (-1 = empty), hpos[s]: occupied slots in front of slot s (valid for occupied s), s: an occupied slot.
+template <int HS>
+__device__ inline int canonical_slot_id(const int* hk, const unsigned short* hpos, int s) {
+  const int kv = hk[s];
+  int start = s, len = 1;
+  while (len < HS && hk[(start - 1) & (HS - 1)] >= 0) { start = (start - 1) & (HS - 1); ++len; }
+  int rank = 0;
+  for (int q = start; q != s; q = (q + 1) & (HS - 1)) rank += hk[q] < kv;
+  for (int q = (s + 1) & (HS - 1); hk[q] >= 0 && q != start; q = (q + 1) & (HS - 1)) rank += hk[q] < kv;
+  return hpos[(start + rank) & (HS - 1)];
+}
+
 int launch_spconv(const SpconvArgs& a, hipStream_t st);
 int launch_permute_rows(const float* in, const int32_t* perm, int n, int c, float* out, hipStream_t st);
 int launch_spconv_st(const SpconvArgs& a, const unsigned char* local_dev, hipStream_t st);   // tile-local input stage (spconv_st.hip)
@@ -128,7 +145,8 @@ int build_local_rulebook_up(const int32_t* nbr_dev, int K, int n_out, unsigned c
 // (which also needs upc_scratch_bytes of scratch it does not keep)
 size_t upc_kept_bytes(int n_out);
 size_t upc_scratch_bytes(int n_out);
-int build_upc(const int32_t* nbr_dev, int n_out, unsigned char* ws, unsigned char* scratch, hipStream_t st);
+// coords_dev: the fine level's coordinates ([n_out][4], multiples of `stride`) or NULL (the class is then read off the table)
+int build_upc(const int32_t* nbr_dev, const int32_t* coords_dev, int stride, int n_out, unsigned char* ws, unsigned char* scratch, hipStream_t st);
 const int* upc_overflow_ptr(const unsigned char* ws);
 int launch_spconv_upc(const SpconvArgs& a, const unsigned char* ws, hipStream_t st);
 int select_st_variant(int v);   // spconv_st.hip: which staged kernel (returns the previous one)
@@ -154,6 +172,7 @@ int launch_tail_fused(const float* in, int ld_in, int n, const float* w1, const 
 bool spconv_rs_fits(const SpconvArgs& a);
 bool spconv_up_enabled();    // eyoc_spconv_select_up_kernel state == 1 (spconv_up.hip)
 bool spconv_upc_enabled();   // ... == 2 (spconv_upc.hip)
+int spconv_upc_min_rows();    // maps with fewer level-0 rows keep spconv_up.hip under mode 2
 bool spconv_down_staged();   // eyoc_spconv_select_down_kernel state
 int spconv_forced_kernel();   // eyoc_spconv_select_kernel state: -1 automatic, 0 workgroup-tiled, 1 wave-private
 int launch_spconv_wave(const SpconvArgs& a, hipStream_t st);   // wave-private tiling (spconv_wave.hip)

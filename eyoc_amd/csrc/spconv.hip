@@ -723,9 +723,11 @@ int spconv_forced_kernel() { return g_kernel_mode; }
 // staged kernel for the transposed convolutions (spconv_up.hip), on by default on Z-ordered maps: level with the
 // row-stationary kernel in windowed pattern order in time (0.68 / 1.06 / 1.44 vs 0.63 / 1.02 / 1.57 ms on the bench's three
 // layers, + 0.25 ms of rulebooks in the map build; the step is the same within noise) and 18 GB less HBM traffic per forward
-int g_up_kernel = 1;                      // eyoc_spconv_select_up_kernel
+int g_up_kernel = 2;                      // eyoc_spconv_select_up_kernel: 0 gathering kernels, 1 spconv_up.hip (Morton tiles), 2 spconv_upc.hip (class-major tiles)
 bool spconv_up_enabled() { return g_up_kernel == 1; }
 bool spconv_upc_enabled() { return g_up_kernel == 2; }
+int g_upc_min_rows = 1 << 17;            // eyoc_spconv_upc_min_rows
+int spconv_upc_min_rows() { return g_upc_min_rows; }
 int g_conv1_staged = 1;   // eyoc_spconv_select_conv1_kernel: 1 the first convolution of Z-ordered split16 forwards on conv1_st_kernel, 0 on conv1_mfma_kernel, 2 on the exact-fp32 octree walker
 int g_down_staged = 0;   // strided convolutions on Z-ordered maps through the staged kernel (eyoc_spconv_select_down_kernel): off - their tiles overflow 2 passes
 bool spconv_down_staged() { return g_down_staged != 0; }
@@ -1245,12 +1247,18 @@ int eyoc_spconv_select_up_kernel(int on) {
   return prev;
 }
 
+int eyoc_spconv_upc_min_rows(int rows) {
+  const int prev = eyoc::g_upc_min_rows;
+  if (rows >= 0) eyoc::g_upc_min_rows = rows;
+  return prev;
+}
+
 size_t eyoc_spconv_upc_bytes(int n_out) { return n_out < 0 ? 0 : eyoc::upc_kept_bytes(n_out) + eyoc::upc_scratch_bytes(n_out) + 512; }
 
 int eyoc_spconv_upc_build(eyoc_ctx* ctx, const int32_t* nbr_dev, int n_out, void* ws_dev, int32_t* info_host, void* stream) {
   EYOC_REQUIRE(ctx && nbr_dev && ws_dev && n_out >= 0 && ((uintptr_t)ws_dev & 255) == 0, EYOC_ERR_INVALID, "eyoc_spconv_upc_build: bad argument");
   unsigned char* ws = (unsigned char*)ws_dev;
-  if (int rc = eyoc::build_upc(nbr_dev, n_out, ws, ws + ((eyoc::upc_kept_bytes(n_out) + 255) & ~(size_t)255), (hipStream_t)stream)) return rc;
+  if (int rc = eyoc::build_upc(nbr_dev, nullptr, 1, n_out, ws, ws + ((eyoc::upc_kept_bytes(n_out) + 255) & ~(size_t)255), (hipStream_t)stream)) return rc;
   if (info_host) {   // {n_tiles, tile_start[9], count[8], overflow}: one synchronising copy (tests, diagnostics)
     EYOC_CHECK_HIP(hipMemcpyAsync(info_host, ws, 19 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     EYOC_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));

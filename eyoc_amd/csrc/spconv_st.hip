@@ -146,16 +146,44 @@ __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restric
   for (int w = 0; w < NW; ++w) { if (w < wave) base += wave_cnt[w]; total += wave_cnt[w]; }
   unsigned char* lr = out + (size_t)tile * LR_BYTES;
   int* U = reinterpret_cast<int*>(lr + 16);
-  for (int i0 = 0; i0 < PER_WAVE; i0 += 64) {
-    const int s = wave * PER_WAVE + i0 + lane;
-    const int key = hk[s];
-    const unsigned long long m = __ballot(key >= 0);
-    const int id = base + __popcll(m & ((1ull << lane) - 1ull));
-    if (key >= 0) {
-      hid[s] = (unsigned short)id;
-      if (id < NPASS * UMAX) U[id] = key;
+  if (total <= UMAX) {                                                 // one pass: any numbering gives the same sums - slot order
+    for (int i0 = 0; i0 < PER_WAVE; i0 += 64) {
+      const int s = wave * PER_WAVE + i0 + lane;
+      const int key = hk[s];
+      const unsigned long long m = __ballot(key >= 0);
+      const int id = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (key >= 0) {
+        hid[s] = (unsigned short)id;
+        U[id] = key;
+      }
+      base += __popcll(m);
     }
-    base += __popcll(m);
+  } else {                                                              // two passes: a numbering that does not depend on the order the CAS loops ran in (canonical_slot_id, spconv.h)
+    // (hid holds the slot-order positions first and the canonical numbers after - a second 8 KB array would cost the kernel its
+    // fourth workgroup per CU)
+    for (int i0 = 0; i0 < PER_WAVE; i0 += 64) {
+      const int s = wave * PER_WAVE + i0 + lane;
+      const unsigned long long m = __ballot(hk[s] >= 0);
+      if (hk[s] >= 0) hid[s] = (unsigned short)(base + __popcll(m & ((1ull << lane) - 1ull)));   // occupied slots in front of s
+      base += __popcll(m);
+    }
+    __syncthreads();
+    unsigned short ids[PER_WAVE / 64];
+#pragma unroll
+    for (int q = 0; q < PER_WAVE / 64; ++q) {
+      const int s = wave * PER_WAVE + q * 64 + lane;
+      ids[q] = hk[s] >= 0 ? (unsigned short)canonical_slot_id<HSLOTS>(hk, hid, s) : (unsigned short)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PER_WAVE / 64; ++q) {
+      const int s = wave * PER_WAVE + q * 64 + lane;
+      const int key = hk[s];
+      if (key >= 0) {
+        hid[s] = ids[q];
+        if (ids[q] < NPASS * UMAX) U[ids[q]] = key;
+      }
+    }
   }
   if (threadIdx.x == 0) {
     reinterpret_cast<int*>(lr)[0] = total <= NPASS * UMAX ? total : -1;

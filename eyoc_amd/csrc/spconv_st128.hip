@@ -62,7 +62,7 @@ __global__ __launch_bounds__(TILE) void k_local_rulebook_t(const int32_t* __rest
                                                            int* __restrict__ overflow) {
   constexpr int NWB = TILE / 64, LROWS = Rec<TILE>::LROWS, MASK_OFF = Rec<TILE>::MASK_OFF, LR_BYTES = Rec<TILE>::LR_BYTES, NPASS = Rec<TILE>::NPASS;
   __shared__ int hk[HSLOTS];
-  __shared__ unsigned short hid[HSLOTS];
+  __shared__ unsigned short hid[HSLOTS], hpos[HSLOTS];
   __shared__ int wave_cnt[NWB];
   __shared__ int too_many;
   __shared__ unsigned char nib[NPASS][27][NWB];
@@ -106,16 +106,35 @@ __global__ __launch_bounds__(TILE) void k_local_rulebook_t(const int32_t* __rest
   int base = 0, total = 0;
   for (int w = 0; w < NWB; ++w) { if (w < wave) base += wave_cnt[w]; total += wave_cnt[w]; }
   int* U = reinterpret_cast<int*>(lr + 16);
-  for (int i0 = 0; i0 < PER_WAVE; i0 += 64) {
-    const int s = wave * PER_WAVE + i0 + lane;
-    const int key = hk[s];
-    const unsigned long long m = __ballot(key >= 0);
-    const int id = base + __popcll(m & ((1ull << lane) - 1ull));
-    if (key >= 0) {
-      hid[s] = (unsigned short)id;
-      if (id < NPASS * UMAX) U[id] = key;
+  if (total <= UMAX) {                                                 // one pass: any numbering gives the same sums - slot order
+    for (int i0 = 0; i0 < PER_WAVE; i0 += 64) {
+      const int s = wave * PER_WAVE + i0 + lane;
+      const int key = hk[s];
+      const unsigned long long m = __ballot(key >= 0);
+      const int id = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (key >= 0) {
+        hid[s] = (unsigned short)id;
+        U[id] = key;
+      }
+      base += __popcll(m);
     }
-    base += __popcll(m);
+  } else {                                                              // several passes: a numbering that does not depend on the order the CAS loops ran in (canonical_slot_id, spconv.h)
+    for (int i0 = 0; i0 < PER_WAVE; i0 += 64) {
+      const int s = wave * PER_WAVE + i0 + lane;
+      const unsigned long long m = __ballot(hk[s] >= 0);
+      if (hk[s] >= 0) hpos[s] = (unsigned short)(base + __popcll(m & ((1ull << lane) - 1ull)));   // occupied slots in front of s
+      base += __popcll(m);
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < PER_WAVE; i0 += 64) {
+      const int s = wave * PER_WAVE + i0 + lane;
+      const int key = hk[s];
+      if (key >= 0) {
+        const int id = canonical_slot_id<HSLOTS>(hk, hpos, s);
+        hid[s] = (unsigned short)id;
+        if (id < NPASS * UMAX) U[id] = key;
+      }
+    }
   }
   if (threadIdx.x == 0) {
     reinterpret_cast<int*>(lr)[0] = total <= NPASS * UMAX ? total : -1;

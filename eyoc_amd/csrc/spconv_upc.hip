@@ -81,28 +81,37 @@ struct UpcHeader {
 };
 constexpr int HDR_BYTES = 256;
 
-// 1. class of every fine row (that of its first valid offset: each offset belongs to one class, and a row's own coarse cell
-// always exists) and the per-256-row-block class counts
-__global__ __launch_bounds__(256) void k_upc_class(const int32_t* __restrict__ nbr, int n, unsigned char* __restrict__ cls,
-                                                   int* __restrict__ blk_cnt) {
+// 1. class of every fine row and the class counts of every 1024-row block.  With the level's coordinates at hand the class is
+// the parity of (c / stride) per axis (an even axis admits offset 0 only, an odd one -1 and +1); without, that of the row's first
+// valid offset (each offset belongs to one class, and a row's own coarse cell always exists) - 27 table entries instead of 16 bytes.
+constexpr int PBLK = 1024;                                             // rows per partition block (4 per thread)
+__global__ __launch_bounds__(256) void k_upc_class(const int32_t* __restrict__ nbr, const int32_t* __restrict__ coords, int stride, int n,
+                                                   unsigned char* __restrict__ cls, int* __restrict__ blk_cnt) {
   __shared__ int cnt[NW][8];
-  const int row = blockIdx.x * 256 + (int)threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int c = 8;                                                          // 8 = no row
-  if (row < n) {
-    int idx[27];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < 27; ++k) idx[k] = nbr[(size_t)k * n + row];
-    c = 0;                                                            // (a row without any parent cannot exist; it would count as class 0)
+  for (int i = 0; i < PBLK / 256; ++i) {
+    const int row = blockIdx.x * PBLK + i * 256 + (int)threadIdx.x;
+    int c = 8;                                                        // 8 = no row
+    if (row < n) {
+      if (coords) {
+        const int4 q = reinterpret_cast<const int4*>(coords)[row];   // (batch, x, y, z), multiples of the level's stride
+        c = ((q.y / stride) & 1) | (((q.z / stride) & 1) << 1) | (((q.w / stride) & 1) << 2);
+      } else {
+        c = 0;
 #pragma unroll
-    for (int k = 26; k >= 0; --k)
-      if (idx[k] >= 0) c = class_of(k);
-    cls[row] = (unsigned char)c;
+        for (int k = 26; k >= 0; --k)
+          if (nbr[(size_t)k * n + row] >= 0) c = class_of(k);
+      }
+      cls[row] = (unsigned char)c;
+    }
+#pragma unroll
+    for (int b = 0; b < 8; ++b) mine[b] += __popcll(__ballot(c == b));
   }
+  if (lane == 0)
 #pragma unroll
-  for (int b = 0; b < 8; ++b) {
-    const int m = __popcll(__ballot(c == b));
-    if (lane == 0) cnt[wave][b] = m;
-  }
+    for (int b = 0; b < 8; ++b) cnt[wave][b] = mine[b];
   __syncthreads();
   if (threadIdx.x < 8) blk_cnt[blockIdx.x * 8 + threadIdx.x] = cnt[0][threadIdx.x] + cnt[1][threadIdx.x] + cnt[2][threadIdx.x] + cnt[3][threadIdx.x];
 }
@@ -114,9 +123,10 @@ __global__ __launch_bounds__(1024) void k_upc_scan(int* __restrict__ blk_cnt, in
   const int t = (int)threadIdx.x;
   const int per = (nblk + 1023) / 1024, b0 = t * per, b1 = min(nblk, b0 + per);
   int s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int b = b0; b < b1; ++b)
-#pragma unroll
-    for (int c = 0; c < 8; ++c) s[c] += blk_cnt[b * 8 + c];
+  for (int b = b0; b < b1; ++b) {
+    const int4 lo = reinterpret_cast<const int4*>(blk_cnt)[b * 2], hi = reinterpret_cast<const int4*>(blk_cnt)[b * 2 + 1];
+    s[0] += lo.x; s[1] += lo.y; s[2] += lo.z; s[3] += lo.w; s[4] += hi.x; s[5] += hi.y; s[6] += hi.z; s[7] += hi.w;
+  }
 #pragma unroll
   for (int c = 0; c < 8; ++c) part[t][c] = s[c];
   __syncthreads();
@@ -133,13 +143,12 @@ __global__ __launch_bounds__(1024) void k_upc_scan(int* __restrict__ blk_cnt, in
   int run[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) run[c] = part[t][c] - s[c];             // exclusive
-  for (int b = b0; b < b1; ++b)
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int v = blk_cnt[b * 8 + c];
-      blk_cnt[b * 8 + c] = run[c];
-      run[c] += v;
-    }
+  for (int b = b0; b < b1; ++b) {
+    const int4 lo = reinterpret_cast<const int4*>(blk_cnt)[b * 2], hi = reinterpret_cast<const int4*>(blk_cnt)[b * 2 + 1];
+    reinterpret_cast<int4*>(blk_cnt)[b * 2] = make_int4(run[0], run[1], run[2], run[3]);
+    reinterpret_cast<int4*>(blk_cnt)[b * 2 + 1] = make_int4(run[4], run[5], run[6], run[7]);
+    run[0] += lo.x; run[1] += lo.y; run[2] += lo.z; run[3] += lo.w; run[4] += hi.x; run[5] += hi.y; run[6] += hi.z; run[7] += hi.w;
+  }
   if (t == 0) {
     int tiles = 0;
     for (int c = 0; c < 8; ++c) {
@@ -158,20 +167,28 @@ __global__ __launch_bounds__(1024) void k_upc_scan(int* __restrict__ blk_cnt, in
 // padding slots of a class's last tile)
 __global__ __launch_bounds__(256) void k_upc_scatter(const unsigned char* __restrict__ cls, int n, const int* __restrict__ blk_base,
                                                      const UpcHeader* __restrict__ hdr, int* __restrict__ sorted) {
-  __shared__ int cnt[NW][8];
-  const int row = blockIdx.x * 256 + (int)threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = row < n ? (int)cls[row] : 8;
-  int rank = 0;
+  __shared__ int cnt[PBLK / 256][NW][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int c[PBLK / 256], rank[PBLK / 256];
 #pragma unroll
-  for (int b = 0; b < 8; ++b) {
-    const unsigned long long m = __ballot(c == b);
-    if (c == b) rank = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) cnt[wave][b] = __popcll(m);
+  for (int i = 0; i < PBLK / 256; ++i) {
+    const int row = blockIdx.x * PBLK + i * 256 + (int)threadIdx.x;
+    c[i] = row < n ? (int)cls[row] : 8;
+    rank[i] = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const unsigned long long m = __ballot(c[i] == b);
+      if (c[i] == b) rank[i] = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) cnt[i][wave][b] = __popcll(m);
+    }
   }
   __syncthreads();
-  if (c < 8) {
-    for (int w = 0; w < wave; ++w) rank += cnt[w][c];
-    sorted[(size_t)hdr->tile_start[c] * TILE + blk_base[blockIdx.x * 8 + c] + rank] = row;
+#pragma unroll
+  for (int i = 0; i < PBLK / 256; ++i) {
+    if (c[i] >= 8) continue;
+    int r = rank[i];
+    for (int q = 0; q < i * NW + wave; ++q) r += cnt[q / NW][q % NW][c[i]];       // the rows in front: earlier quarters, earlier waves
+    sorted[(size_t)hdr->tile_start[c[i]] * TILE + blk_base[blockIdx.x * 8 + c[i]] + r] = blockIdx.x * PBLK + i * 256 + (int)threadIdx.x;
   }
 }
 
@@ -203,7 +220,7 @@ constexpr int HSLOTS = 4096;                                          // LDS has
 __global__ __launch_bounds__(256) void k_upc_records(const int32_t* __restrict__ nbr, int n, const int* __restrict__ sorted,
                                                      UpcHeader* __restrict__ hdr, unsigned char* __restrict__ out) {
   __shared__ int hk[HSLOTS];
-  __shared__ unsigned short hid[HSLOTS];
+  __shared__ unsigned short hid[HSLOTS], hpos[HSLOTS];
   __shared__ unsigned short srow[KC][TILE];
   __shared__ unsigned int key[TILE];
   __shared__ int wave_cnt[NW];
@@ -248,16 +265,35 @@ __global__ __launch_bounds__(256) void k_upc_records(const int32_t* __restrict__
   for (int w = 0; w < NW; ++w) { if (w < wave) base += wave_cnt[w]; total += wave_cnt[w]; }
   unsigned char* lr = out + (size_t)tile * UPC_LR;
   int* U = reinterpret_cast<int*>(lr + U_OFF);
-  for (int i0 = 0; i0 < PER_WAVE; i0 += 64) {
-    const int s = wave * PER_WAVE + i0 + lane;
-    const int kv = hk[s];
-    const unsigned long long m = __ballot(kv >= 0);
-    const int id = base + __popcll(m & ((1ull << lane) - 1ull));
-    if (kv >= 0) {
-      hid[s] = (unsigned short)id;
-      if (id < NPASS * UMAX) U[id] = kv;
+  if (total <= UMAX) {                                                 // one pass: any numbering gives the same sums - slot order
+    for (int i0 = 0; i0 < PER_WAVE; i0 += 64) {
+      const int s = wave * PER_WAVE + i0 + lane;
+      const int kv = hk[s];
+      const unsigned long long m = __ballot(kv >= 0);
+      const int id = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (kv >= 0) {
+        hid[s] = (unsigned short)id;
+        U[id] = kv;
+      }
+      base += __popcll(m);
     }
-    base += __popcll(m);
+  } else {                                                              // several passes: a numbering that does not depend on the order the CAS loops ran in (canonical_slot_id, spconv.h)
+    for (int i0 = 0; i0 < PER_WAVE; i0 += 64) {
+      const int s = wave * PER_WAVE + i0 + lane;
+      const unsigned long long m = __ballot(hk[s] >= 0);
+      if (hk[s] >= 0) hpos[s] = (unsigned short)(base + __popcll(m & ((1ull << lane) - 1ull)));   // occupied slots in front of s
+      base += __popcll(m);
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < PER_WAVE; i0 += 64) {
+      const int s = wave * PER_WAVE + i0 + lane;
+      const int kv = hk[s];
+      if (kv >= 0) {
+        const int id = canonical_slot_id<HSLOTS>(hk, hpos, s);
+        hid[s] = (unsigned short)id;
+        if (id < NPASS * UMAX) U[id] = kv;
+      }
+    }
   }
   if (threadIdx.x == 0) {
     reinterpret_cast<int*>(lr)[0] = total <= NPASS * UMAX ? total : -1;
@@ -475,20 +511,20 @@ static inline size_t upc_records_off(int n_out) { return (size_t)HDR_BYTES + (((
 size_t upc_kept_bytes(int n_out) { return n_out <= 0 ? 0 : upc_records_off(n_out) + (size_t)upc_max_tiles(n_out) * UPC_LR; }
 size_t upc_scratch_bytes(int n_out) {
   if (n_out <= 0) return 0;
-  const size_t nblk = (size_t)cdiv(n_out, 256);
+  const size_t nblk = (size_t)cdiv(n_out, PBLK);
   return (((size_t)n_out + 255) & ~(size_t)255) + nblk * 8 * 4 + 256 + (size_t)upc_max_tiles(n_out) * TILE * 4;
 }
 
-int build_upc(const int32_t* nbr_dev, int n_out, unsigned char* ws, unsigned char* scratch, hipStream_t st) {
+int build_upc(const int32_t* nbr_dev, const int32_t* coords_dev, int stride, int n_out, unsigned char* ws, unsigned char* scratch, hipStream_t st) {
   if (n_out <= 0) return EYOC_OK;
-  const int nblk = cdiv(n_out, 256), max_tiles = upc_max_tiles(n_out);
+  const int nblk = cdiv(n_out, PBLK), max_tiles = upc_max_tiles(n_out);
   unsigned char* cls = scratch;
   int* blk = reinterpret_cast<int*>(scratch + (((size_t)n_out + 255) & ~(size_t)255));
   int* sorted = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(blk) + (size_t)nblk * 8 * 4 + 256);
   UpcHeader* hdr = reinterpret_cast<UpcHeader*>(ws);
   int* order = reinterpret_cast<int*>(ws + HDR_BYTES);
   EYOC_CHECK_HIP(hipMemsetAsync(sorted, 0xFF, (size_t)max_tiles * TILE * 4, st));
-  hipLaunchKernelGGL(k_upc_class, dim3(nblk), dim3(256), 0, st, nbr_dev, n_out, cls, blk);
+  hipLaunchKernelGGL(k_upc_class, dim3(nblk), dim3(256), 0, st, nbr_dev, coords_dev, stride, n_out, cls, blk);
   hipLaunchKernelGGL(k_upc_scan, dim3(1), dim3(1024), 0, st, blk, nblk, hdr);
   hipLaunchKernelGGL(k_upc_scatter, dim3(nblk), dim3(256), 0, st, cls, n_out, blk, hdr, sorted);
   hipLaunchKernelGGL(k_upc_order, dim3(cdiv(max_tiles, 256)), dim3(256), 0, st, hdr, order);

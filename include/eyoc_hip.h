@@ -168,8 +168,9 @@ int eyoc_spconv(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, const f
 int eyoc_spconv_select_split16_kernel(int mode);
 /* Staged kernel for the transposed 3^3 / stride-2 convolutions on Z-ordered maps (spconv_up.hip: tile rows sorted by
  * parity class, only occupied (16-row group, offset) blocks multiplied): 1 on (default: as fast as the row-stationary
- * kernel in windowed pattern order, 18 GB less HBM traffic per 128-cloud forward), 0 off; other values only query.  Returns the previous
- * state.  Process-wide, read when maps are built; for tests and profiling. */
+ * kernel in windowed pattern order, 18 GB less HBM traffic per 128-cloud forward), 0 off (gathering kernels), 2 (default since
+ * round 4) = the class-major kernel below for batches and this one for small inputs; other values only query.  Returns the
+ * previous state.  Process-wide, read when maps are built; for tests and profiling. */
 int eyoc_spconv_select_up_kernel(int on);
 /* The same layers in CLASS-MAJOR order (spconv_upc.hip; eyoc_spconv_select_up_kernel(2)): the fine rows are partitioned by parity
  * class (8 classes of 1-8 offsets), a tile is 256 rows of one class and runs the staged kernel's assembly loop over that class's
@@ -178,6 +179,10 @@ int eyoc_spconv_select_up_kernel(int on);
  * 0..7, tiles with more distinct coarse rows than two stage passes hold - the kernel must not be used then}, which
  * synchronises the stream); the layer (split16 rows in, split16 or fp32 rows out, no residual).
  *   replaces: ME.MinkowskiConvolutionTranspose(kernel_size=3, stride=2) of model/resunet.py:83-116 */
+/* eyoc_spconv_select_up_kernel(2) (the default) uses the class-major kernel for maps with at least this many level-0 rows (default
+ * 2^17; the partition's extra launches cost a single 60 k-voxel pair more than the kernel saves) and spconv_up.hip below; a
+ * negative argument only queries; returns the previous value.  Process-wide, read when maps are built. */
+int eyoc_spconv_upc_min_rows(int rows);
 size_t eyoc_spconv_upc_bytes(int n_out);
 int eyoc_spconv_upc_build(eyoc_ctx* ctx, const int32_t* nbr_dev, int n_out, void* ws_dev, int32_t* info_host, void* stream);
 int eyoc_spconv_upc(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* ws_dev, int n_out, int n_in, const float* in_dev, int ld_in,

@@ -100,8 +100,17 @@ def forward(model, cloud, feats=None):
 CASES = ["conv1", "block1.conv1", "conv2", "conv4_tr", "block2_tr.conv2", "conv1_tr"]
 
 
-@pytest.mark.parametrize("case", CASES)
-def test_overflow_in_one_layer_is_seen_reported_and_recovered_from(cloud, case):
+@pytest.fixture
+def class_major(request):
+    """True: the transposed convolutions run on spconv_upc.hip (class-major tiles) although the batch is small."""
+    L, lib = _lib()
+    prev = lib.eyoc_spconv_upc_min_rows(0 if request.param else 1 << 30)
+    yield request.param
+    lib.eyoc_spconv_upc_min_rows(prev)
+
+
+@pytest.mark.parametrize("case,class_major", [(c, False) for c in CASES] + [("conv4_tr", True)], indirect=["class_major"])
+def test_overflow_in_one_layer_is_seen_reported_and_recovered_from(cloud, case, class_major):
     from oracle import resunet as orr
     L, lib = _lib()
     sd, where = doctor(cloud["sd"], cloud["base"], case)

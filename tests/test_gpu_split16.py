@@ -249,12 +249,14 @@ def test_forward_on_z_ordered_rows_with_the_staged_kernel(request):
     try:
         for mode, up in (("split16", 0), ("split16", 1), ("split16", 2), ("fp32", 0)):   # up = 1: transposed convolutions on spconv_up.hip, 2: spconv_upc.hip
             lib.eyoc_spconv_select_up_kernel(up)
+            prev_min = lib.eyoc_spconv_upc_min_rows(0)        # class-major tiles whatever the size of the batch
             model.spconv_math = mode
             got = _forward(model, coords, feats)
             assert model.last_spconv_math == mode
             e = rel_err(got, want)
             cos = (got * want).sum(1)
             print(f"z-ordered forward, {mode}, staged transposed convolutions {up}: err {e:.2e}")
+            lib.eyoc_spconv_upc_min_rows(prev_min)
             assert e < REL and cos.min() > 1 - 1e-6, (mode, e, float(cos.min()))
         lib.eyoc_spconv_select_up_kernel(prev_up)
         # the permutation is invisible: permuting the caller's rows permutes the output
