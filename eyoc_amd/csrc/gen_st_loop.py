@@ -302,11 +302,26 @@ def gen_w8(D=2, WD=1, LD=2, skip=True, lo_region=LO_REGION, lrows=64):
     return out
 
 
+WD2, LD2 = 1, 2            # NH = 2 (measured: weights two offsets ahead and rulebook entries three, lane constants in v[56:61], gain nothing)
+
+
+def gen_upc(abl=()):
+    upc = []
+    for kc in (8, 4, 2):
+        upc += [f"s_cmp_eq_u32 %[nk], {kc}", f"s_cbranch_scc1 .Lst%=_upc{kc}"]
+    for kc in (1, 2, 4, 8):
+        if kc > 1:
+            upc.append(f".Lst%=_upc{kc}:")
+        upc += gen(2, WD2, LD2, True, abl, K=kc, koff=True, tag=f"u{kc}")
+        if kc < 8:
+            upc.append("s_branch .Lst%=_upcend")
+    upc.append(".Lst%=_upcend:")
+    return upc
+
+
 def clobbers(lo=128):
     return ", ".join(f'"v{i}"' for i in range(lo, 256))
 
-
-WD2, LD2 = 1, 2            # NH = 2 (measured: weights two offsets ahead and rulebook entries three, lane constants in v[56:61], gain nothing)
 
 
 def write_blob(f, name, lines):
@@ -328,17 +343,7 @@ def main(path):
         # spconv_upc.hip: the offsets of ONE parity class of a transposed (stride 2) table - 1, 2, 4 or 8 of them, %[nk] says how
         # many.  One statement with a scalar dispatch in front (four statements in an if-chain made the compiler shuffle the
         # pinned accumulators through scratch: 168 spilled VGPRs)
-        upc = []
-        for kc in (8, 4, 2):
-            upc += [f"s_cmp_eq_u32 %[nk], {kc}", f"s_cbranch_scc1 .Lst%=_upc{kc}"]
-        for kc in (1, 2, 4, 8):
-            if kc > 1:
-                upc.append(f".Lst%=_upc{kc}:")
-            upc += gen(2, WD2, LD2, K=kc, koff=True, tag=f"u{kc}")
-            if kc < 8:
-                upc.append("s_branch .Lst%=_upcend")
-        upc.append(".Lst%=_upcend:")
-        write_blob(f, "UPC", upc)
+        write_blob(f, "UPC", gen_upc())
         f.write(f"#define EYOC_ST_LOOP_CLOBBERS {clobbers()}\n")
         # spconv_st128.hip: 128-row tiles, 64 rows x 32 channels per wave inside 128 VGPRs (four waves per SIMD, four workgroups per CU)
         write_blob(f, "T128", gen_w8(lo_region=320 * 64, lrows=32))
@@ -352,6 +357,9 @@ def main(path):
                           ("NOL", ("nol",)), ("NOWL", ("now", "nol")), ("NOMWL", ("nom", "now", "nol")),
                           ("EMPTY", ("nom", "now", "nol", "nox", "nov")), ("TRACE", ("trace",))):
             write_blob(f, "NH2_" + name, gen(2, WD2, LD2, True, abl))
+        write_blob(f, "UPC_NOM", gen_upc(("nom",)))
+        write_blob(f, "UPC_NOW", gen_upc(("now",)))
+        write_blob(f, "UPC_EMPTY", gen_upc(("nom", "now", "nol", "nox", "nov")))
         write_blob(f, "NH2_W2L3", gen(2, 2, 3))       # weights two offsets ahead, rulebook entries three: no gain
         write_blob(f, "W8", gen_w8())                 # 8 waves of 64 rows x 32 channels in 128 VGPRs (four per SIMD): no gain
         f.write("#define EYOC_ST_LOOP_CLOBBERS_LOW EYOC_ST_LOOP_CLOBBERS, " + ", ".join(f'"v{i}"' for i in range(56, 62)) + "\n")

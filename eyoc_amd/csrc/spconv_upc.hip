@@ -346,6 +346,23 @@ __global__ __launch_bounds__(256) void k_upc_records(const int32_t* __restrict__
 }
 
 #include "spconv_st_loop.inc"
+// timing-only builds (results are garbage): -DEYOC_UPC_ABL=1 no MFMAs, 2 no weight loads, 3 nothing in the loop, 4 no stage DMA,
+// 5 no output stores (make ../lib/libeyoc_hip_upcabl<N>.so)
+#ifdef EYOC_UPC_ABL
+#include "spconv_st_loop_abl.inc"
+#if EYOC_UPC_ABL == 1
+#define EYOC_UPC_BLOB EYOC_ST_LOOP_UPC_NOM
+#elif EYOC_UPC_ABL == 2
+#define EYOC_UPC_BLOB EYOC_ST_LOOP_UPC_NOW
+#elif EYOC_UPC_ABL == 3
+#define EYOC_UPC_BLOB EYOC_ST_LOOP_UPC_EMPTY
+#else
+#define EYOC_UPC_BLOB EYOC_ST_LOOP_UPC
+#endif
+#else
+#define EYOC_UPC_ABL 0
+#define EYOC_UPC_BLOB EYOC_ST_LOOP_UPC
+#endif
 
 // One workgroup = one class tile x 64 output channels: 4 waves = 2 row halves x 2 channel halves (128 rows x 32 channels of
 // register accumulators per wave), two workgroups per CU - the shape of spconv_st_asm_kernel<CC, 2, 1>.
@@ -401,6 +418,7 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_upc_kernel(SpconvArgs a, co
     for (int it = 0; it < NITV; ++it) Ureg[it] = U[pass * UMAX + (it * NW + wave) * 16 + (lane >> 2)];
   };
   auto stage = [&](int qb) {
+    if (EYOC_UPC_ABL == 4) return;
 #pragma unroll
     for (int it = 0; it < NITV; ++it) {
       const int l0 = (it * NW + wave) * 16;
@@ -443,7 +461,7 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_upc_kernel(SpconvArgs a, co
       const int cc = (qb * 32) / CC, qp = ((qb * 32) % CC) / 32;
       const unsigned int ws0 = (unsigned)__builtin_amdgcn_readfirstlane(((slice * ncc + cc) * tile4 + (nt0 * JQ + 2 * qp) * 64) * 16);
       unsigned int so;
-      asm volatile(EYOC_ST_LOOP_UPC : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), "+{v[96:111]}"(A2), "+{v[112:127]}"(A3), [so] "=&s"(so)
+      asm volatile(EYOC_UPC_BLOB : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), "+{v[96:111]}"(A2), "+{v[112:127]}"(A3), [so] "=&s"(so)
                    : [wr] "s"(wr), [ws0] "s"(ws0), [lb] "s"(lb), [w1] "s"(w1off), [nk] "s"(nk), "{s[36:43]}"(M0), "{s[52:59]}"(KO)
                    : "memory", "scc", EYOC_ST_LOOP_CLOBBERS);
     }
@@ -483,6 +501,7 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_upc_kernel(SpconvArgs a, co
   for (int hc = 0; hc < NG; ++hc) {
     const int o = orow[hc];
     if (o < 0) continue;
+    if (EYOC_UPC_ABL == 5 && os != 12345.f) continue;
     if (a.out_split) {
       uint2 h0, l0, h1, l1;
       split16_encode4(v[hc][0], h0, l0);
