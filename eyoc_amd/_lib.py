@@ -129,6 +129,7 @@ PROTOTYPES = {
     "eyoc_knn_prefilter": (_i, [_i]),
     "eyoc_spconv_select_up_kernel": (_i, [_i]),
     "eyoc_spconv_upc_min_rows": (_i, [_i]),
+    "eyoc_spconv_upc_tile_rows": (_i, [_i, _i]),
     "eyoc_spconv_upc_bytes": (_sz, [_i]),
     "eyoc_spconv_upc_build": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "eyoc_spconv_upc": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp]),

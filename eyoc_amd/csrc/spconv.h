@@ -148,6 +148,7 @@ size_t upc_scratch_bytes(int n_out);
 // coords_dev: the fine level's coordinates ([n_out][4], multiples of `stride`) or NULL (the class is then read off the table)
 int build_upc(const int32_t* nbr_dev, const int32_t* coords_dev, int stride, int n_out, unsigned char* ws, unsigned char* scratch, hipStream_t st);
 const int* upc_overflow_ptr(const unsigned char* ws);
+int upc_set_tile_rows(int odd_axes, int rows);   // rows per tile (128 .. 256, multiple of 16) of the classes with that many odd axes; this device
 int launch_spconv_upc(const SpconvArgs& a, const unsigned char* ws, hipStream_t st);
 int select_st_variant(int v);   // spconv_st.hip: which staged kernel (returns the previous one)
 int select_st_split_below(int workgroups);   // layers with fewer 64-channel workgroups take 32-channel ones (returns the previous threshold)

@@ -1253,6 +1253,8 @@ int eyoc_spconv_upc_min_rows(int rows) {
   return prev;
 }
 
+int eyoc_spconv_upc_tile_rows(int odd_axes, int rows) { return eyoc::upc_set_tile_rows(odd_axes, rows); }
+
 size_t eyoc_spconv_upc_bytes(int n_out) { return n_out < 0 ? 0 : eyoc::upc_kept_bytes(n_out) + eyoc::upc_scratch_bytes(n_out) + 512; }
 
 int eyoc_spconv_upc_build(eyoc_ctx* ctx, const int32_t* nbr_dev, int n_out, void* ws_dev, int32_t* info_host, void* stream) {

@@ -14,7 +14,7 @@
 //   * no offset is walked in vain (the 27-offset loop on a transposed table spends 2/3 of its time on loop overhead:
 //     scripts/exp_up_staged.py), and inside a tile the rows are grouped by which of their parents exist, so that the loop's
 //     empty-block branches remove most of the products with missing parents (2.7-3.0 offsets per chunk against 2.5 useful);
-//   * the price: the 256 rows of a class tile spread over 8 x the volume, ~420 distinct coarse rows instead of ~145 (two stage
+//   * the price: the rows of a class tile (256; 192 for the class with 8 offsets) spread over 8 x the volume, ~420 distinct coarse rows instead of ~145 (two stage
 //     passes for 4-7 % of the tiles); the tiles of the 8 classes that cover the same stretch of the Morton curve run back to
 //     back on ONE XCD (tile_order), so that their common coarse rows are fetched from HBM once and from that XCD's L2 after.
 // Output rows are written through a per-slot row index (the tile's rows are not contiguous in the output).
@@ -45,7 +45,8 @@ __host__ __device__ constexpr int slot_addr(int l) { return l * 64 + ((l >> 2) &
 // pad[2]; int U[UCAP]; uint2 loc[NPASS][KC][64] (entry (pass, i, 16 w + j): the LDS slot addresses of the parents at the class's
 // i-th offset of tile slots 64 w + 16 c + j, c = 0..3, as four 16-bit values; slot UMAX = no parent / other pass);
 // unsigned short mask[NPASS][KC] (bit 4 w + c: some row of slot chunk (w, c) has a parent at offset i staged in this pass);
-// int orow[64][4]: output row of slot 64 w + 16 c + j at [(16 w + j)][c], -1 = a padding slot of the class's last tile.
+// int orow[64][4]: output row of slot 64 w + 16 c + j at [(16 w + j)][c], -1 = a padding slot (a class-7 tile holds 192 rows; the
+// last tile of a class what is left).
 constexpr int U_OFF = 16;
 constexpr int LOC_OFF = U_OFF + UCAP * 4;                          // 5136
 constexpr int MASK_OFF = LOC_OFF + NPASS * KC * 64 * 8;            // 13328
@@ -71,6 +72,13 @@ constexpr ClassTable make_classes() {
   return t;
 }
 __constant__ ClassTable c_classes = make_classes();
+// Rows per tile, by class.  The 256 rows of a class-7 tile (8 parents each) reach 650 distinct coarse rows at the median - more
+// than one stage pass holds (639) - and a second pass repeats most of the tile's products (the parents of a chunk are spread over
+// both passes): 192 rows (12 of the 16 chunks; ~520 distinct rows) keep 9 of 10 such tiles in one pass.
+// (eyoc_spconv_upc_tile_rows sets the rows per tile of the classes with 0 / 1 / 2 / 3 odd axes - for measurements)
+constexpr int MIN_TILE_ROWS = 128;
+__device__ int g_tile_rows[8] = {256, 256, 256, 256, 256, 256, 256, 192};
+__device__ inline int tile_rows(int b) { return g_tile_rows[b]; }
 
 // ---- per-level header (device): what the class partition came out as
 struct UpcHeader {
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(1024) void k_upc_scan(int* __restrict__ blk_cnt, in
       const int total = part[1023][c];
       hdr->count[c] = total;
       hdr->tile_start[c] = tiles;
-      tiles += (total + TILE - 1) / TILE;
+      tiles += (total + tile_rows(c) - 1) / tile_rows(c);
     }
     hdr->tile_start[8] = tiles;
     hdr->n_tiles = tiles;
@@ -188,7 +196,8 @@ __global__ __launch_bounds__(256) void k_upc_scatter(const unsigned char* __rest
     if (c[i] >= 8) continue;
     int r = rank[i];
     for (int q = 0; q < i * NW + wave; ++q) r += cnt[q / NW][q % NW][c[i]];       // the rows in front: earlier quarters, earlier waves
-    sorted[(size_t)hdr->tile_start[c[i]] * TILE + blk_base[blockIdx.x * 8 + c[i]] + r] = blockIdx.x * PBLK + i * 256 + (int)threadIdx.x;
+    const int pos = blk_base[blockIdx.x * 8 + c[i]] + r, R = tile_rows(c[i]);                 // position inside the class
+    sorted[(size_t)(hdr->tile_start[c[i]] + pos / R) * TILE + pos % R] = blockIdx.x * PBLK + i * 256 + (int)threadIdx.x;
   }
 }
 
@@ -522,7 +531,7 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_upc_kernel(SpconvArgs a, co
 
 namespace eyoc {
 
-static inline int upc_max_tiles(int n_out) { return cdiv(n_out, TILE) + 8; }
+static inline int upc_max_tiles(int n_out) { return cdiv(n_out, MIN_TILE_ROWS) + 8; }
 static inline size_t upc_records_off(int n_out) { return (size_t)HDR_BYTES + (((size_t)upc_max_tiles(n_out) * 4 + 255) & ~(size_t)255); }
 
 // workspace of one transposed table with n_out fine rows: header, tile order, records - kept while the maps live - followed
@@ -553,6 +562,16 @@ int build_upc(const int32_t* nbr_dev, const int32_t* coords_dev, int stride, int
 }
 
 // device address of the int that counts tiles whose distinct coarse rows exceed two stage passes (the kernel must not run then)
+int upc_set_tile_rows(int odd_axes, int rows) {
+  if (odd_axes < 0 || odd_axes > 3 || rows < MIN_TILE_ROWS || rows > TILE || rows % 16) return EYOC_ERR_INVALID;
+  int h[8];
+  EYOC_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tile_rows), sizeof(h)));
+  for (int b = 0; b < 8; ++b)
+    if (__builtin_popcount(b) == odd_axes) h[b] = rows;
+  EYOC_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tile_rows), h, sizeof(h)));
+  return EYOC_OK;
+}
+
 const int* upc_overflow_ptr(const unsigned char* ws) { return &reinterpret_cast<const UpcHeader*>(ws)->overflow; }
 
 int launch_spconv_upc(const SpconvArgs& a, const unsigned char* ws, hipStream_t st) {

@@ -183,6 +183,10 @@ int eyoc_spconv_select_up_kernel(int on);
  * 2^17; the partition's extra launches cost a single 60 k-voxel pair more than the kernel saves) and spconv_up.hip below; a
  * negative argument only queries; returns the previous value.  Process-wide, read when maps are built. */
 int eyoc_spconv_upc_min_rows(int rows);
+/* Rows per tile of the classes with `odd_axes` (0..3) odd axes: 128..256, a multiple of 16 (default 256, and 192 for the
+ * 8-offset class, whose 256-row tiles would need two stage passes).  Current device; read when records are built; for
+ * measurements (workspace sizes assume >= 128). */
+int eyoc_spconv_upc_tile_rows(int odd_axes, int rows);
 size_t eyoc_spconv_upc_bytes(int n_out);
 int eyoc_spconv_upc_build(eyoc_ctx* ctx, const int32_t* nbr_dev, int n_out, void* ws_dev, int32_t* info_host, void* stream);
 int eyoc_spconv_upc(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* ws_dev, int n_out, int n_in, const float* in_dev, int ld_in,

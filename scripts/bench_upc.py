@@ -13,6 +13,8 @@ for p in ps: clouds += [p["coords0"], p["coords1"]]
 coords = syn.batch_coords(clouds)
 coords = coords[morton_order(coords)]
 lib = _lib.load()
+for spec in os.environ.get("TILE_ROWS", "").split(","):
+    if spec: _lib.check(lib.eyoc_spconv_upc_tile_rows(int(spec.split(":")[0]), int(spec.split(":")[1])))
 def timeit(fn, reps=int(os.environ.get("REPS", "10"))):
     for _ in range(1 if os.environ.get("ONLY_UPC") else 3): fn()
     torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -55,7 +57,7 @@ for mode in ((2,) if os.environ.get("ONLY_UPC") else (1, 2)):
             hinfo = np.zeros(19, np.int32)
             _lib.check(lib.eyoc_spconv_upc_build(_lib.ctx(), tab, n, C.c_void_p(al), hinfo.ctypes.data, _lib.stream_ptr()))
             t_build = timeit(lambda: _lib.check(lib.eyoc_spconv_upc_build(_lib.ctx(), tab, n, C.c_void_p(al), None, _lib.stream_ptr())))
-            print(f"  lvl{lvl}: tiles {hinfo[0]} (of {(n + 255) // 256} + 8), class rows {hinfo[10:18].tolist()}, overflowed tiles {hinfo[18]}", flush=True)
+            print(f"  lvl{lvl}: tiles {hinfo[0]} (at most {(n + 127) // 128} + 8), class rows {hinfo[10:18].tolist()}, overflowed tiles {hinfo[18]}", flush=True)
             run = lambda: _lib.check(lib.eyoc_spconv_upc(_lib.ctx(), tab, C.c_void_p(al), n, n_in, _lib.ptr(xs), cin, cin, _lib.ptr(wd), cout, None, 0, _lib.ptr(out), cout, 0, _lib.ptr(osd), _lib.stream_ptr()))
         t = timeit(run)
         torch.cuda.synchronize()
