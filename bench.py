@@ -486,7 +486,7 @@ def worker(args):
     achieved_tf = flops / (conv_ms * 1e-3) / 1e12
     achieved_gbs = gather / (conv_ms * 1e-3) / 1e9
     math_mode = model.last_spconv_math
-    kernel = ("spconv_st_asm_kernel<64, 2, 1, 4> (12 of the launches; + spconv_st_asm_kernel<32, 1, 1, 4>, spconv_up_kernel, spconv_wave_kernel, "
+    kernel = ("spconv_st_asm_kernel<64, 2, 1, 4> (12 of the launches; + spconv_st_asm_kernel<32, 1, 1, 4>, spconv_upc_kernel, spconv_wave_kernel, "
               "tail_fused_kernel)" if math_mode == "split16" else "spconv_wave_kernel<...>") + " - the sparse-conv launches of one forward, summed"
     if math_mode == "split16":
         # split16: every algorithmic fp32 multiply-add is three fp16 MFMA multiply-adds.  What binds these kernels is the

@@ -24,7 +24,8 @@ def short(name):
 shutil.copy(os.path.join(g, f"{tag}_trace", f"{tag}_kernel_stats.csv"), os.path.join(out, f"{tag}_kernel_stats.csv"))
 bench = [l for l in open(os.path.join(g, f"{tag}_trace.log")) if l.startswith("{")][-1]
 open(os.path.join(out, f"{tag}_bench_under_rocprof.json"), "w").write(bench)
-steps = json.loads(bench)["steps"] + json.loads(bench)["warmup"]
+# forwards under the profiler: timed + warm-up + the untimed allocator-settling steps of the pipelined loop (bench.py --overlap-maps)
+steps = json.loads(bench)["steps"] + json.loads(bench)["warmup"] + json.loads(bench).get("config", {}).get("untimed_settle_steps", 0)
 
 rows = {}
 for kind, col in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
