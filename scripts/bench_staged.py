@@ -14,7 +14,7 @@ if os.environ.get("MORTON", "1") == "1": coords = coords[morton_order(coords)]
 cm = eyoc_amd.CoordinateManager(torch.from_numpy(coords).cuda())
 maps = cm.maps(); lib = _lib.load(); info = cm.info()
 print("rows", info["rows"], flush=True)
-LAYERS = ((0, 64, 64), (2, 128, 128)) if os.environ.get("ONLY_ST") else ((0, 64, 64), (0, 32, 32), (1, 64, 64), (2, 128, 128), (3, 256, 256))
+LAYERS = tuple(tuple(int(v) for v in s.split(":")) for s in os.environ["LAYERS"].split(",")) if os.environ.get("LAYERS") else ((0, 64, 64), (2, 128, 128)) if os.environ.get("ONLY_ST") else ((0, 64, 64), (0, 32, 32), (1, 64, 64), (2, 128, 128), (3, 256, 256))
 for lvl, cin, cout in LAYERS:
     n = info["rows"][lvl]; prs = info["pairs_s1"][lvl]
     tab = lib.eyoc_maps_table(maps, 0, lvl)
