@@ -84,6 +84,12 @@ def parse_args(argv=None):
                          "so after the W warm-up steps it runs untimed steps until the caching allocator has stopped growing "
                          "(config.untimed_settle_steps) - a 9 GB hipMalloc inside the timed region costs 0.02-0.45 s on a fresh box; "
                          "--no-overlap-maps builds the maps in front of every forward on the main stream")
+    ap.add_argument("--maps-after", choices=("start", "feat", "matched"), default="feat",
+                    help="what of step s the side stream waits for before it builds the maps of step s + 1: 'feat' (default) the forward - "
+                         "the build runs beside gather / NN / RANSAC; 'matched' also the NN (beside RANSAC only: the build then outlasts RANSAC "
+                         "by ~1.7 ms); 'start' nothing (beside the forward, whose kernels slow down by 6 %%: best pairs/s by 1 %%, "
+                         "worst kernel times).  Round 4, one box: 23.0 / 23.3 / 22.8 ms per step, 23.8 with --no-overlap-maps")
+    ap.add_argument("--main-priority", action="store_true", help="diagnostics: the step's own stream gets high priority (measured: +0.5 %% with --maps-after start)")
     ap.add_argument("--st-variant", type=int, default=-1,
                     help="diagnostics: staged-kernel implementation (eyoc_spconv_select_st_kernel: 0 C++ loop, 1 assembly loop, 2 assembly without empty-block branches)")
     ap.add_argument("--down-staged", type=int, default=-1, help="diagnostics: eyoc_spconv_select_down_kernel (0 / 1)")
@@ -336,10 +342,10 @@ def worker(args):
         nonlocal layer_ms, n_fwd
         s_, res_, slot_ = item[:3]
         batch_ = batches[s_ % len(batches)][1]
-        host = res_.cpu()
-        model.check_range()          # split16 range guard: raises if a forward since the last check overflowed
-        last[s_ % len(batches)] = [eyoc_amd.registration.decode_ransac_result(host[p], batch_.n_points) for p in range(batch_.P)] \
-            if cfg.use_RANSAC else res_
+        host, overflowed = res_.wait()      # this step's own read-back (enqueued with it): no queueing behind the step enqueued since
+        if overflowed:
+            model.check_range()             # split16 range guard: raises EYOC_ERR_RANGE with the library's message
+        last[s_ % len(batches)] = [eyoc_amd.registration.decode_ransac_result(host[p], batch_.n_points) for p in range(batch_.P)]
         if model is not None:
             model.timing_slot(slot_)
             ms = np.array(model.layer_ms())
@@ -349,8 +355,11 @@ def worker(args):
             n_fwd += 1
 
     def run_steps(n_steps):
-        """Software-pipelined over the steps: step s is ENQUEUED before the host reads step s-1's results and timers (two
-        event sets, results left on the device until then), so the GPU never waits for the host's decode between steps.
+        """Software-pipelined over the steps: step s is ENQUEUED - its read-back into pinned memory included (RegistrationPipeline.
+        enqueue) - before the host waits for step s-1's results and reads its timers (two event / buffer sets), so the GPU never
+        waits for the host's decode between steps.  (Until late in round 4 the read-back of step s-1 was ISSUED after step s had
+        been enqueued: on one stream that copy queues behind all of step s, the host never ran ahead, and the GPU idled ~2 ms per
+        step while the host decoded and launched - found in a kernel trace, bench.py's own stage timers could not see it.)
         Everything - the last step's read-back included - happens inside this call.  The warm-up runs the SAME code (same
         streams, same number of live map sets and workspaces: their first hipMallocs cost ~0.25 s apiece on a fresh box)."""
         nonlocal layer_ms, n_fwd
@@ -373,13 +382,17 @@ def worker(args):
             pipe.slot = slot
             if next_maps is None and overlap_maps:
                 next_maps = pipe.prepare_maps(batch)                    # first step: nothing to hide behind
-            res = pipe.register(batch, return_device=True, maps=next_maps)
+            res = pipe.enqueue(batch, maps=next_maps, slot=slot)
             held, next_maps = next_maps, None
-            if overlap_maps and s + 1 < n_steps:
-                # the next step's maps, on the side stream, while this step's matching / RANSAC runs on the main stream
-                next_maps = pipe.prepare_maps(batches[(s + 1) % len(batches)][1], after=pipe.matched)
+            # the previous step's read-back and timers FIRST: its results are long there, and the map build below blocks the host (two
+            # count read-backs behind the `matched` event) until ~1 ms before the GPU runs dry - decoding 64 results and reading 50
+            # timers after it left the GPU waiting for step s + 1's launches
             if pending is not None:
                 collect(pending)
+            if overlap_maps and s + 1 < n_steps:
+                # the next step's maps, on the side stream, while this step's matching / RANSAC runs on the main stream
+                after = {"matched": pipe.matched, "feat": pipe.featured, "start": None}[args.maps_after]
+                next_maps = pipe.prepare_maps(batches[(s + 1) % len(batches)][1], after=after)
             pending = (s, res, slot, held)
             if args.verbose:
                 st = torch.cuda.memory_stats()
@@ -388,6 +401,10 @@ def worker(args):
         if pending is not None:
             collect(pending)
 
+    hp = torch.cuda.Stream(priority=-1) if (not dry and args.main_priority) else None
+    if hp is not None:
+        hp.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hp)
     run_steps(args.warmup)
     log(f"{args.warmup} warm-up step(s) done")
     settle = 0
@@ -415,6 +432,8 @@ def worker(args):
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     allocs_timed = (torch.cuda.memory_stats().get("num_device_alloc", 0) - allocs0) if not dry else 0
+    if model is not None and not dry:
+        model.check_range()      # the sticky flag: every step's own verdict was read with its results; this is the belt to those braces
     elapsed = edist.max_over_ranks(elapsed, device)
     if model is not None:
         model.set_timing(False)
@@ -458,7 +477,7 @@ def worker(args):
                                  f"5000-point NN, RANSAC {args.ransac_iters} hypotheses/pair, {plant}, spconv math {model.last_spconv_math})",
                      "pairs_per_step": args.pairs, "parallelism": f"pairs sharded over {world} GPU(s)",
                      "inlier_ratio": args.inlier_ratio if descriptor else None,
-                     "map_build": ("maps of step s + 1 built on a side stream during step s's matching / RANSAC (one build per timed step)"
+                     "map_build": (f"maps of step s + 1 built on a side stream behind step s's {dict(start='enqueue', feat='forward', matched='matching')[args.maps_after]} (one build per timed step)"
                                    if overlap_maps and cfg.use_RANSAC else "in front of every forward, main stream")}
     if not dry:
         out["config"]["device_allocs_in_timed_region"] = allocs_timed

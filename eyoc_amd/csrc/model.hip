@@ -301,6 +301,12 @@ int eyoc_model_range_check(eyoc_model* m, void* stream, float* max_abs) {
   return EYOC_OK;
 }
 
+int eyoc_model_range_snapshot(eyoc_model* m, uint32_t* words_host, void* stream) {
+  EYOC_REQUIRE(m && words_host, EYOC_ERR_INVALID, "eyoc_model_range_snapshot: NULL argument");
+  EYOC_CHECK_HIP(hipMemcpyAsync(words_host, m->range, 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return EYOC_OK;
+}
+
 size_t eyoc_model_workspace_bytes(const eyoc_model* m, const eyoc_maps* maps) {
   if (!m || !maps) return 0;
   size_t b = 0;

@@ -294,6 +294,17 @@ class ResUNet2(nn.Module):
         _lib.check(rc, "eyoc_model_range_check")
         return self.last_max_activation
 
+    def range_snapshot(self, words: torch.Tensor):
+        """Enqueue a copy of the range guard's four device words into ``words`` (pinned ``int32[4]``) on the current stream, without
+        synchronising: called right behind a forward, ``words[0] != 0`` - once an event recorded behind it has fired - says that THIS
+        forward overflowed.  For callers that pipeline steps (``check_range`` reads behind everything enqueued since)."""
+        assert words.is_pinned() and words.dtype == torch.int32 and words.numel() >= 4
+        if self._handle is None:
+            words.zero_()
+            return
+        with torch.cuda.device(self._packed_device):
+            _lib.check(_lib.load().eyoc_model_range_snapshot(self._handle, words.data_ptr(), _lib.stream_ptr()), "eyoc_model_range_snapshot")
+
     def probe_activations(self, on=True):
         """Debug probe: keep the running maximum of |activation| over everything the split16 forwards store
         (``check_range()`` returns it) - tells how far a checkpoint is from the fp16 range before trusting split16."""

@@ -335,6 +335,11 @@ int eyoc_model_last_math(const eyoc_model* model);
  * k outputs as suspect (the ones that overflowed are the ones holding NaN rows); *max_abs (may be NULL) = largest |activation| stored since eyoc_model_set_probe(model, 1)
  * switched the debug probe on (-1 when the probe is off).  fp32 forwards never raise it. */
 int eyoc_model_range_check(eyoc_model* model, void* stream, float* max_abs);
+/* The guard's four device words {this forward's overflow flag, max |activation| bits (probe), probe switch, sticky flag} copied
+ * to `words_host` (16 bytes of pinned host memory) in stream order, WITHOUT synchronising: enqueued right behind a forward it
+ * captures that forward's own verdict (word 0), which a caller that pipelines steps reads once its own event behind the copy has
+ * fired - eyoc_model_range_check would queue its read behind everything enqueued since.  Nothing is cleared. */
+int eyoc_model_range_snapshot(eyoc_model* model, uint32_t* words_host, void* stream);
 int eyoc_model_set_probe(eyoc_model* model, int on);
 /* when `on`, eyoc_model_forward brackets every layer with hipEvents on `stream` and
  * eyoc_model_layer_ms returns the per-layer durations of the last forward (synchronises) */

@@ -223,3 +223,33 @@ def test_registration_pipeline_switches_to_fp32_for_good(cloud):
     for r0, r1 in zip(res["auto"], res["fp32"]):
         assert np.isfinite(r0.transformation).all()
         np.testing.assert_array_equal(r0.transformation, r1.transformation)
+
+
+def test_enqueued_steps_carry_their_own_verdict_and_results(cloud):
+    """``RegistrationPipeline.enqueue`` (what a caller that pipelines steps uses: bench.py): the read-back of the result records
+    and of the guard's verdict on THAT forward is enqueued with the step.  Three steps in flight - clean, overflowing, clean: each
+    ``wait()`` returns its own step's records (equal to ``register``'s) and only the middle one reports an overflow."""
+    from eyoc_amd import registration as reg, synthetic as syn
+    from eyoc_amd.harness import DeviceBatch, RegistrationConfig, RegistrationPipeline
+    L, lib = _lib()
+    pairs = [syn.make_pair(s, beams=32, azimuths=1000, band=None) for s in (3, 4)]
+    dev = torch.device("cuda")
+    cfg = RegistrationConfig(ransac_max_iteration=100000, n_points=2000)
+    batch = DeviceBatch(pairs, [3, 4], dev, n_points=cfg.n_points, descriptor=dict(inlier_ratio=0.3))
+    clean = make_model(cloud["sd"], "split16")
+    bad_sd, _ = doctor(cloud["sd"], cloud["base"], "block1.conv1")
+    bad = make_model(bad_sd, "split16")
+    p_clean, p_bad = RegistrationPipeline(clean, cfg), RegistrationPipeline(bad, cfg)
+    want = p_clean.register(batch, seed=7)
+    pend = [p_clean.enqueue(batch, seed=7, slot=0), p_bad.enqueue(batch, seed=7, slot=0), p_clean.enqueue(batch, seed=7, slot=1)]
+    out = [p.wait() for p in pend]
+    assert [o[1] for o in out] == [False, True, False]
+    for host, _ in (out[0], out[2]):
+        got = [reg.decode_ransac_result(host[i], batch.n_points) for i in range(batch.P)]
+        for g, w in zip(got, want):
+            np.testing.assert_array_equal(g.transformation, w.transformation)
+            assert g.inliers == w.inliers and g.survivors == w.survivors
+    with pytest.raises(L.EyocError) as ei:                  # the sticky flag of the model that overflowed is still there to be read
+        bad.check_range()
+    assert ei.value.code == L.ERR_RANGE
+    clean.check_range()
