@@ -89,6 +89,7 @@ def parse_args(argv=None):
                          "the build runs beside gather / NN / RANSAC; 'matched' also the NN (beside RANSAC only: the build then outlasts RANSAC "
                          "by ~1.7 ms); 'start' nothing (beside the forward, whose kernels slow down by 6 %%: best pairs/s by 1 %%, "
                          "worst kernel times).  Round 4, one box: 23.0 / 23.3 / 22.8 ms per step, 23.8 with --no-overlap-maps")
+    ap.add_argument("--side-priority", type=int, default=0, help="diagnostics: priority of the map-building side stream (-1 = high)")
     ap.add_argument("--main-priority", action="store_true", help="diagnostics: the step's own stream gets high priority (measured: +0.5 %% with --maps-after start)")
     ap.add_argument("--st-variant", type=int, default=-1,
                     help="diagnostics: staged-kernel implementation (eyoc_spconv_select_st_kernel: 0 C++ loop, 1 assembly loop, 2 assembly without empty-block branches)")
@@ -401,6 +402,8 @@ def worker(args):
         if pending is not None:
             collect(pending)
 
+    if pipe is not None:
+        pipe.side_priority = args.side_priority
     hp = torch.cuda.Stream(priority=-1) if (not dry and args.main_priority) else None
     if hp is not None:
         hp.wait_stream(torch.cuda.current_stream())

@@ -203,7 +203,7 @@ class RegistrationPipeline:
         both want LDS and the atomics path, and the forward's kernels slow down by ~10 %)."""
         from .sparse_tensor import CoordinateManager
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=batch.coords.device)
+            self._side = torch.cuda.Stream(device=batch.coords.device, priority=getattr(self, "side_priority", 0))
         if after is not None:
             self._side.wait_event(after)
         with torch.cuda.stream(self._side):
