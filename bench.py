@@ -84,11 +84,14 @@ def parse_args(argv=None):
                          "so after the W warm-up steps it runs untimed steps until the caching allocator has stopped growing "
                          "(config.untimed_settle_steps) - a 9 GB hipMalloc inside the timed region costs 0.02-0.45 s on a fresh box; "
                          "--no-overlap-maps builds the maps in front of every forward on the main stream")
-    ap.add_argument("--maps-after", choices=("start", "feat", "matched"), default="feat",
+    ap.add_argument("--maps-after", default="feat",
                     help="what of step s the side stream waits for before it builds the maps of step s + 1: 'feat' (default) the forward - "
                          "the build runs beside gather / NN / RANSAC; 'matched' also the NN (beside RANSAC only: the build then outlasts RANSAC "
                          "by ~1.7 ms); 'start' nothing (beside the forward, whose kernels slow down by 6 %%: best pairs/s by 1 %%, "
-                         "worst kernel times).  Round 4, one box: 23.0 / 23.3 / 22.8 ms per step, 23.8 with --no-overlap-maps")
+                         "worst kernel times); 'layer:-3' = when the forward reaches its third-to-last launch (eyoc_model_set_progress_event: "
+                         "the build then also runs beside the last two level-0 layers, which slow down by 3 %%, and ends with RANSAC).  "
+                         "Round 4, one box: feat 23.0 / matched 23.3 / start 22.8 ms per step, 23.8 with --no-overlap-maps; another box, "
+                         "alternating: feat 22.7 (forward 16.2 ms), layer:-3 22.4 (16.7 ms)")
     ap.add_argument("--side-priority", type=int, default=0, help="diagnostics: priority of the map-building side stream (-1 = high)")
     ap.add_argument("--main-priority", action="store_true", help="diagnostics: the step's own stream gets high priority (measured: +0.5 %% with --maps-after start)")
     ap.add_argument("--st-variant", type=int, default=-1,
@@ -392,7 +395,7 @@ def worker(args):
                 collect(pending)
             if overlap_maps and s + 1 < n_steps:
                 # the next step's maps, on the side stream, while this step's matching / RANSAC runs on the main stream
-                after = {"matched": pipe.matched, "feat": pipe.featured, "start": None}[args.maps_after]
+                after = {"matched": pipe.matched, "feat": pipe.featured, "start": None}.get(args.maps_after, progress)
                 next_maps = pipe.prepare_maps(batches[(s + 1) % len(batches)][1], after=after)
             pending = (s, res, slot, held)
             if args.verbose:
@@ -404,6 +407,8 @@ def worker(args):
 
     if pipe is not None:
         pipe.side_priority = args.side_priority
+    # --maps-after layer:-2 = in front of the forward's second-to-last launch (eyoc_model_set_progress_event)
+    progress = model.progress_event(int(args.maps_after.split(":")[1])) if (model is not None and not dry and args.maps_after.startswith("layer:")) else None
     hp = torch.cuda.Stream(priority=-1) if (not dry and args.main_priority) else None
     if hp is not None:
         hp.wait_stream(torch.cuda.current_stream())
@@ -480,7 +485,7 @@ def worker(args):
                                  f"5000-point NN, RANSAC {args.ransac_iters} hypotheses/pair, {plant}, spconv math {model.last_spconv_math})",
                      "pairs_per_step": args.pairs, "parallelism": f"pairs sharded over {world} GPU(s)",
                      "inlier_ratio": args.inlier_ratio if descriptor else None,
-                     "map_build": (f"maps of step s + 1 built on a side stream behind step s's {dict(start='enqueue', feat='forward', matched='matching')[args.maps_after]} (one build per timed step)"
+                     "map_build": (f"maps of step s + 1 built on a side stream behind step s's {dict(start='enqueue', feat='forward', matched='matching').get(args.maps_after, 'forward reaching ' + args.maps_after)} (one build per timed step)"
                                    if overlap_maps and cfg.use_RANSAC else "in front of every forward, main stream")}
     if not dry:
         out["config"]["device_allocs_in_timed_region"] = allocs_timed

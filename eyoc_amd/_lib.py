@@ -108,6 +108,7 @@ PROTOTYPES = {
     "eyoc_model_last_math": (_i, [_vp]),
     "eyoc_model_range_check": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
     "eyoc_model_range_snapshot": (_i, [_vp, _vp, _vp]),
+    "eyoc_model_set_progress_event": (_i, [_vp, _i, _vp]),
     "eyoc_model_set_probe": (_i, [_vp, _i]),
     "eyoc_spconv": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "eyoc_model_blob_floats": (_sz, [C.POINTER(ModelDesc)]),

@@ -51,6 +51,8 @@ struct eyoc_model {
   std::vector<hipEvent_t> events;     // two sets of layers + 1 events (eyoc_model_timing_slot)
   int slot = 0;
   int events_valid[2] = {0, 0};
+  hipEvent_t progress_event = nullptr;   // eyoc_model_set_progress_event: recorded in front of layer `progress_layer` of every forward
+  int progress_layer = -1;
   unsigned int* range = nullptr;      // device: {overflow flag of the forward in flight, max |activation| bits (probe), probe switch, sticky overflow flag} - split16_guard in spconv.h
   int probe = 0;
 };
@@ -377,10 +379,15 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
   if (split) EYOC_CHECK_HIP(hipMemsetAsync(m->range, 0, 4, st));       // the overflow flag of THIS forward (the sticky copy is word 3)
   hipEvent_t* ev = m->timing ? m->events.data() + (size_t)m->slot * (m->layers.size() + 1) : nullptr;
   if (m->timing) EYOC_CHECK_HIP(hipEventRecord(ev[0], st));
+  bool progress_recorded = m->progress_event == nullptr;
   for (size_t li = 0; li < m->layers.size(); ++li) {
     const LayerPlan& p = m->layers[li];
     const int n_out = maps->rows[p.out_level];
     int rc;
+    if (!progress_recorded && (int)li >= m->progress_layer) {            // (>=: a layer fused into its predecessor has no iteration of its own)
+      EYOC_CHECK_HIP(hipEventRecord(m->progress_event, st));
+      progress_recorded = true;
+    }
     if (p.map == M_CONV1) {
       Conv1Args a;
       a.coords = maps->coords[0]; a.n = n_out; a.table = maps->table[0]; a.ks = m->desc.conv1_kernel_size;
@@ -458,7 +465,18 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
     if (rc) return rc;
     if (m->timing) EYOC_CHECK_HIP(hipEventRecord(ev[li + 1], st));
   }
+  if (!progress_recorded) EYOC_CHECK_HIP(hipEventRecord(m->progress_event, st));
   if (m->timing) m->events_valid[m->slot] = 1;
+  return EYOC_OK;
+}
+
+int eyoc_model_set_progress_event(eyoc_model* m, int layer, void* hip_event) {
+  EYOC_REQUIRE(m, EYOC_ERR_INVALID, "eyoc_model_set_progress_event: NULL model");
+  const int n = (int)m->layers.size();
+  if (layer < 0) layer += n;                                             // -1 = in front of the last layer
+  EYOC_REQUIRE(!hip_event || (layer >= 0 && layer <= n), EYOC_ERR_INVALID, "eyoc_model_set_progress_event: layer %d of %d", layer, n);
+  m->progress_event = (hipEvent_t)hip_event;
+  m->progress_layer = layer;
   return EYOC_OK;
 }
 

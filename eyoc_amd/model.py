@@ -225,6 +225,7 @@ class ResUNet2(nn.Module):
             lib.eyoc_model_set_math(h, self._math)
         if self._probe:
             _lib.check(lib.eyoc_model_set_probe(h, 1), "eyoc_model_set_probe")
+        self._apply_progress()
         return blob
 
     @property
@@ -293,6 +294,24 @@ class ResUNet2(nn.Module):
         self.last_max_activation = float(mx.value) if mx.value >= 0 else None    # valid whether or not the check raises
         _lib.check(rc, "eyoc_model_range_check")
         return self.last_max_activation
+
+    def progress_event(self, layer: int):
+        """-> a ``torch.cuda.Event`` that every forward records in front of launch ``layer`` (negative: from the end; ``None`` switches
+        it off).  ``stream.wait_event(ev)`` issued AFTER a forward was enqueued waits for that forward to reach the layer."""
+        if layer is None:
+            self._progress = None
+        else:
+            ev = torch.cuda.Event()
+            ev.record()                       # creates the handle
+            self._progress = (ev, int(layer))
+        self._apply_progress()
+        return None if layer is None else self._progress[0]
+
+    def _apply_progress(self):
+        pr = getattr(self, "_progress", None)
+        if self._handle is not None:
+            _lib.check(_lib.load().eyoc_model_set_progress_event(self._handle, 0 if pr is None else pr[1], None if pr is None else C.c_void_p(pr[0].cuda_event)),
+                       "eyoc_model_set_progress_event")
 
     def range_snapshot(self, words: torch.Tensor):
         """Enqueue a copy of the range guard's four device words into ``words`` (pinned ``int32[4]``) on the current stream, without

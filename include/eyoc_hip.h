@@ -340,6 +340,11 @@ int eyoc_model_range_check(eyoc_model* model, void* stream, float* max_abs);
  * captures that forward's own verdict (word 0), which a caller that pipelines steps reads once its own event behind the copy has
  * fired - eyoc_model_range_check would queue its read behind everything enqueued since.  Nothing is cleared. */
 int eyoc_model_range_snapshot(eyoc_model* model, uint32_t* words_host, void* stream);
+/* Every forward records `hip_event` (a hipEvent_t the caller owns; NULL switches it off) on its stream in front of layer `layer`
+ * (0-based in launch order, negative counts from the end: -1 = in front of the last layer; == number of layers: behind it).  A
+ * caller that pipelines batches lets a side stream wait for it - bench.py starts the next batch's map build there, beside the
+ * last layers of the forward instead of behind it. */
+int eyoc_model_set_progress_event(eyoc_model* model, int layer, void* hip_event);
 int eyoc_model_set_probe(eyoc_model* model, int on);
 /* when `on`, eyoc_model_forward brackets every layer with hipEvents on `stream` and
  * eyoc_model_layer_ms returns the per-layer durations of the last forward (synchronises) */

@@ -253,3 +253,30 @@ def test_enqueued_steps_carry_their_own_verdict_and_results(cloud):
         bad.check_range()
     assert ei.value.code == L.ERR_RANGE
     clean.check_range()
+
+
+def test_progress_event_fires_inside_the_forward(cloud):
+    """``model.progress_event(layer)``: an event every forward records in front of launch ``layer`` - a side stream that waits for it
+    (bench.py --maps-after layer:-3) runs beside the rest of the forward.  It must lie between the forward's first and last event."""
+    m = make_model(cloud["sd"], "split16")
+    ev = m.progress_event(-3)
+    for _ in range(2):
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        forward(m, cloud)
+        t1.record()
+        torch.cuda.synchronize()
+        assert ev.query()
+    # a timing-enabled twin of the same event kind: where inside the forward does it fire?
+    evt = torch.cuda.Event(enable_timing=True)
+    evt.record()
+    from eyoc_amd import _lib as L
+    import ctypes as C
+    L.check(L.load().eyoc_model_set_progress_event(m._handle, -3, C.c_void_p(evt.cuda_event)))
+    t0.record()
+    forward(m, cloud)
+    t1.record()
+    torch.cuda.synchronize()
+    assert 0.3 * t0.elapsed_time(t1) < t0.elapsed_time(evt) < t0.elapsed_time(t1)
+    m.progress_event(None)
+    forward(m, cloud)
