@@ -260,6 +260,33 @@ def timed_rate(pipe, batch, reps, warm=1):
     return (time.perf_counter() - t0) / reps
 
 
+def pipelined_rate(pipe, batch, reps, warm=3):
+    """Seconds per call of a serving loop over batches of this size: every call is enqueued with its read-back (RegistrationPipeline.
+    enqueue), the next call's maps are built on the side stream behind this call's forward, and the host decodes call s - 1 while
+    call s runs - the pattern of the timed loop, for the small batches of configs[1] / configs[2]."""
+    import eyoc_amd
+    pend, maps, t0 = None, pipe.prepare_maps(batch), 0.0
+    for s in range(warm + reps):
+        if s == warm:
+            if pend is not None:
+                pend.wait()
+                pend = None
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        pipe.slot = s & 1
+        p = pipe.enqueue(batch, maps=maps, slot=s & 1)
+        if pend is not None:
+            host, over = pend.wait()
+            assert not over
+            [eyoc_amd.registration.decode_ransac_result(host[i], batch.n_points) for i in range(batch.P)]
+        maps = pipe.prepare_maps(batch, after=pipe.featured)
+        pend = p
+    host, over = pend.wait()
+    [eyoc_amd.registration.decode_ransac_result(host[i], batch.n_points) for i in range(batch.P)]
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
 def worker(args):
     t_start = time.perf_counter()
 
@@ -583,9 +610,13 @@ def worker(args):
         # configs[1] read literally: ONE pair through the same path (latency); configs[2]: batch = 8 pairs
         single = DeviceBatch(pairs0[:1], seeds0[:1], device, cfg.n_points, descriptor=descriptor)
         out["single_pair_latency_ms"] = timed_rate(pipe, single, 10, 3) * 1e3
+        if cfg.use_RANSAC:      # the same pairs one per call, calls pipelined like the timed loop (throughput, not latency)
+            out["single_pair_pipelined_pairs_per_s"] = 1 / pipelined_rate(pipe, single, 20)
         if len(pairs0) >= 8:
             b8 = DeviceBatch(pairs0[:8], seeds0[:8], device, cfg.n_points, descriptor=descriptor)
             out["batch8_pairs_per_s"] = 8 / timed_rate(pipe, b8, 10, 2)
+            if cfg.use_RANSAC:
+                out["batch8_pipelined_pairs_per_s"] = 8 / pipelined_rate(pipe, b8, 12)
         log("latency probes done")
         # the SAME step at the reference's own arithmetic (fp32 products on v_mfma_f32_16x16x4_f32), same process, same
         # batch: the figure to hold against a reference that multiplies in fp32 (model/resunet.py:31-140 -> sgemm)
