@@ -92,6 +92,11 @@ def parse_args(argv=None):
                          "the build then also runs beside the last two level-0 layers, which slow down by 3 %%, and ends with RANSAC).  "
                          "Round 4, one box: feat 23.0 / matched 23.3 / start 22.8 ms per step, 23.8 with --no-overlap-maps; another box, "
                          "alternating: feat 22.7 (forward 16.2 ms), layer:-3 22.4 (16.7 ms)")
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
+                    help="2 (default, round 5): two steps in flight - the forward of step s + 1 is enqueued on the main stream right "
+                         "behind the forward of step s, while step s's row gather / feature NN / RANSAC / read-back run on a second "
+                         "stream (RegistrationPipeline.enqueue(tail_stream=True)) and the maps of step s + 2 are built on a third; "
+                         "1: the round-4 loop (one stream per step, only the map build beside it).  Same kernels, same records")
     ap.add_argument("--side-priority", type=int, default=0, help="diagnostics: priority of the map-building side stream (-1 = high)")
     ap.add_argument("--main-priority", action="store_true", help="diagnostics: the step's own stream gets high priority (measured: +0.5 %% with --maps-after start)")
     ap.add_argument("--st-variant", type=int, default=-1,
@@ -368,6 +373,7 @@ def worker(args):
     steps_timed = passes * len(batches) if total_mode else passes
     last = {}
     overlap_maps = args.overlap_maps
+    two = args.in_flight == 2 and overlap_maps          # two steps in flight needs the maps off the main stream
 
     def collect(item):
         nonlocal layer_ms, n_fwd
@@ -413,14 +419,19 @@ def worker(args):
             pipe.slot = slot
             if next_maps is None and overlap_maps:
                 next_maps = pipe.prepare_maps(batch)                    # first step: nothing to hide behind
-            res = pipe.enqueue(batch, maps=next_maps, slot=slot)
+            res = pipe.enqueue(batch, maps=next_maps, slot=slot, tail_stream=two)
             held, next_maps = next_maps, None
+            if two and s + 1 < n_steps:
+                # two steps in flight: the main stream runs forward after forward, so the next step's maps must be there when THIS
+                # forward ends - built now, on the side stream, beside this forward (and the previous step's tail on its stream)
+                next_maps = pipe.prepare_maps(batches[(s + 1) % len(batches)][1],
+                                              after=progress if args.maps_after.startswith("layer:") else None)
             # the previous step's read-back and timers FIRST: its results are long there, and the map build below blocks the host (two
             # count read-backs behind the `matched` event) until ~1 ms before the GPU runs dry - decoding 64 results and reading 50
             # timers after it left the GPU waiting for step s + 1's launches
             if pending is not None:
                 collect(pending)
-            if overlap_maps and s + 1 < n_steps:
+            if overlap_maps and not two and s + 1 < n_steps:
                 # the next step's maps, on the side stream, while this step's matching / RANSAC runs on the main stream
                 after = {"matched": pipe.matched, "feat": pipe.featured, "start": None}.get(args.maps_after, progress)
                 next_maps = pipe.prepare_maps(batches[(s + 1) % len(batches)][1], after=after)
@@ -512,8 +523,13 @@ def worker(args):
                                  f"5000-point NN, RANSAC {args.ransac_iters} hypotheses/pair, {plant}, spconv math {model.last_spconv_math})",
                      "pairs_per_step": args.pairs, "parallelism": f"pairs sharded over {world} GPU(s)",
                      "inlier_ratio": args.inlier_ratio if descriptor else None,
-                     "map_build": (f"maps of step s + 1 built on a side stream behind step s's {dict(start='enqueue', feat='forward', matched='matching').get(args.maps_after, 'forward reaching ' + args.maps_after)} (one build per timed step)"
-                                   if overlap_maps and cfg.use_RANSAC else "in front of every forward, main stream")}
+                     "map_build": (("maps of step s + 1 built on a side stream beside step s's forward (one build per timed step)" if two else
+                                    f"maps of step s + 1 built on a side stream behind step s's {dict(start='enqueue', feat='forward', matched='matching').get(args.maps_after, 'forward reaching ' + args.maps_after)} (one build per timed step)")
+                                   if overlap_maps and cfg.use_RANSAC else "in front of every forward, main stream"),
+                     "steps_in_flight": 2 if (two and cfg.use_RANSAC) else 1,
+                     "schedule": ("forward of step s + 1 on the main stream beside row gather / NN / RANSAC / read-back of step s on a second "
+                                  "stream and the map build of step s + 2 on a third; every timed step pays for one of each inside the bracket"
+                                  if (two and cfg.use_RANSAC) else "one stream per step; only the next step's map build runs beside it")}
     if not dry:
         out["config"]["device_allocs_in_timed_region"] = allocs_timed
     if settle:

@@ -376,7 +376,10 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
   EYOC_REQUIRE(want != 1 || split, EYOC_ERR_INVALID,
                "eyoc_model_forward: split16 arithmetic is not available for this model / kernel selection");
   m->last_math = split ? 1 : 0;
-  if (split) EYOC_CHECK_HIP(hipMemsetAsync(m->range, 0, 4, st));       // the overflow flag of THIS forward (the sticky copy is word 3)
+  // the overflow flag of THIS forward (the sticky copy is word 3).  Cleared by every forward, fp32 ones included: after an
+  // overflow switched a model to fp32 MFMAs, eyoc_model_range_snapshot must not keep reporting the old verdict for forwards
+  // that cannot overflow
+  EYOC_CHECK_HIP(hipMemsetAsync(m->range, 0, 4, st));
   hipEvent_t* ev = m->timing ? m->events.data() + (size_t)m->slot * (m->layers.size() + 1) : nullptr;
   if (m->timing) EYOC_CHECK_HIP(hipEventRecord(ev[0], st));
   bool progress_recorded = m->progress_event == nullptr;

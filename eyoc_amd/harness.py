@@ -126,13 +126,15 @@ class DeviceBatch:
 class PendingStep:
     """A step whose read-back was enqueued with it (``RegistrationPipeline.enqueue``)."""
 
-    def __init__(self, host, words, done, device_result):
+    def __init__(self, host, words, done, device_result, keep=None):
         self.host, self.words, self.done, self.device_result = host, words, done, device_result
+        self.keep = keep          # tensors another stream still reads (the features under ``tail_stream``): released by ``wait``
 
     def wait(self):
         """-> (result records ``uint8 [P, 84]`` in pinned host memory - valid until the slot is enqueued again -, whether this
         step's split16 forward overflowed).  Waits for this step only."""
         self.done.synchronize()
+        self.keep = None
         return self.host, bool(int(self.words[0]) != 0)
 
 
@@ -213,24 +215,81 @@ class RegistrationPipeline:
             ready.record(self._side)
         return cm, ready
 
-    def enqueue(self, batch: DeviceBatch, seed: int = 0, maps=None, slot: int = 0) -> "PendingStep":
+    def enqueue(self, batch: DeviceBatch, seed: int = 0, maps=None, slot: int = 0, tail_stream: bool = False) -> "PendingStep":
         """``register`` for a caller that pipelines steps (RANSAC path): everything - the read-back of the ``[P, 84]`` result
         records into pinned host memory and of the split16 guard's verdict on THIS forward included - is enqueued now; the host
         waits on ``PendingStep.wait()`` later.  A read-back issued after the next step was enqueued (``register(...,
         return_device=True)`` + ``.cpu()``) queues behind that whole step on the stream: the host then never runs ahead of the GPU,
         and the GPU idles while the host decodes results and launches the next step (measured: 2 ms of a 24 ms step).
-        ``slot``: which of the two pinned buffer sets to use (a set is free again once its ``wait()`` returned)."""
-        res = self.register(batch, seed=seed, return_device=True, maps=maps)
+        ``slot``: which of the two pinned buffer sets to use (a set is free again once its ``wait()`` returned).
+
+        ``tail_stream=True`` (round 5, two steps in flight): only the forward (+ the guard's snapshot) goes on the caller's
+        stream; row gather, feature NN, RANSAC and the read-back of the records go on a second stream of the pipeline that waits
+        for the forward.  A caller that enqueues the next step right away gets that step's forward (matrix pipe, LDS) beside this
+        step's matching / RANSAC (fp64 VALU, no LDS) - same kernels, same inputs, bit-identical records."""
+        if not tail_stream or not self.cfg.use_RANSAC:
+            res = self.register(batch, seed=seed, return_device=True, maps=maps)
+            host, words = self._pinned_set(slot, res)
+            host.copy_(res, non_blocking=True)
+            self.model.range_snapshot(words)
+            done = torch.cuda.Event()
+            done.record()
+            return PendingStep(host, words, done, res)
+        main = torch.cuda.current_stream()
+        if getattr(self, "_tail", None) is None:
+            self._tail = torch.cuda.Stream(device=batch.coords.device)
+        self._mark(0)
+        F = self.features(batch, maps).F
+        self._mark(1)
+        # the guard's words are this forward's own only until the next forward starts: snapshot them on the forward's stream
+        words = self._pinned_words(slot)
+        self.model.range_snapshot(words)
+        self.featured = torch.cuda.Event()
+        self.featured.record(main)
+        self._tail.wait_event(self.featured)
+        with torch.cuda.stream(self._tail):
+            res = self._match_and_register(batch, F, seed)
+            host, _ = self._pinned_set(slot, res)
+            host.copy_(res, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self._tail)
+        # F was allocated on the caller's stream and is read on the tail stream: it stays referenced until wait()
+        return PendingStep(host, words, done, res, keep=(F,))
+
+    def _pinned_words(self, slot):
+        w = self.__dict__.setdefault("_pinned_w", {})
+        if slot not in w:
+            w[slot] = torch.zeros(4, dtype=torch.int32, pin_memory=True)
+        return w[slot]
+
+    def _pinned_set(self, slot, res):
         bufs = self.__dict__.setdefault("_pinned", {})
         key = (slot, tuple(res.shape), res.dtype)
         if key not in bufs:
-            bufs[key] = (torch.empty(res.shape, dtype=res.dtype, pin_memory=True), torch.zeros(4, dtype=torch.int32, pin_memory=True))
-        host, words = bufs[key]
-        host.copy_(res, non_blocking=True)
-        self.model.range_snapshot(words)
-        done = torch.cuda.Event()
-        done.record()
-        return PendingStep(host, words, done, res)
+            bufs[key] = torch.empty(res.shape, dtype=res.dtype, pin_memory=True)
+        return bufs[key], self._pinned_words(slot)
+
+    def _match_and_register(self, batch, F, seed):
+        """Row gather (+ descriptor blend), segmented feature NN and the batched RANSAC of all pairs on the CURRENT stream ->
+        ``[P, 84]`` result records on the device."""
+        F0 = gather_rows(F, batch.sel0, batch.G0, batch.beta)     # the sampled rows (+ descriptor blend, if any)
+        F1 = gather_rows(F, batch.sel1, batch.G1, batch.beta)
+        nn_idx = knn1_segmented(F0, F1, batch.seg, batch.seg, "SquareL2", return_distance=False)
+        self.last_nn_idx = nn_idx
+        self._mark(2)
+        self.matched = torch.cuda.Event()
+        self.matched.record()
+        # all pairs in one batched call (pair p samples with seed + p, exactly like a per-pair loop would)
+        # (the scratch budget - a quarter of the free memory, a driver round trip - is asked for once per pipeline: any launch-chunk
+        # size gives the same records)
+        if getattr(self, "_ransac_budget", None) is None:
+            self._ransac_budget = reg._ransac_budget(F.device)
+        res = reg.ransac_batched_from_correspondences(
+            batch.xyz0.reshape(-1, 3), batch.xyz1.reshape(-1, 3), nn_idx, batch.seg, batch.seg,
+            self.cfg.voxel_size * 1.0, self.cfg.ransac_max_iteration, seed=seed,
+            workspace_budget=self._ransac_budget)                                  # [P, 84] bytes on the device
+        self._mark(3)
+        return res
 
     @torch.no_grad()
     def register(self, batch: DeviceBatch, seed: int = 0, return_device=False, maps=None):
@@ -240,25 +299,15 @@ class RegistrationPipeline:
         self._mark(1)
         self.featured = torch.cuda.Event()       # the forward is enqueued: what `prepare_maps(after=)` of the NEXT batch may wait for
         self.featured.record()
-        F0 = gather_rows(F, batch.sel0, batch.G0, batch.beta)     # the sampled rows (+ descriptor blend, if any)
-        F1 = gather_rows(F, batch.sel1, batch.G1, batch.beta)
         n = batch.n_points
-        out = []
         if self.cfg.use_RANSAC:
-            nn_idx = knn1_segmented(F0, F1, batch.seg, batch.seg, "SquareL2", return_distance=False)
-            self.last_nn_idx = nn_idx
-            self._mark(2)
-            self.matched = torch.cuda.Event()
-            self.matched.record()
-            # all pairs in one batched call (pair p samples with seed + p, exactly like a per-pair loop would)
-            res = reg.ransac_batched_from_correspondences(
-                batch.xyz0.reshape(-1, 3), batch.xyz1.reshape(-1, 3), nn_idx, batch.seg, batch.seg,
-                self.cfg.voxel_size * 1.0, self.cfg.ransac_max_iteration, seed=seed)   # [P, 84] bytes on the device
-            self._mark(3)
+            res = self._match_and_register(batch, F, seed)
             if return_device:
                 return res                # the caller reads back later - and calls model.check_range() then
             host = res.cpu()
             return self._checked(batch, seed, maps) or [reg.decode_ransac_result(host[p], n) for p in range(batch.P)]
+        F0 = gather_rows(F, batch.sel0, batch.G0, batch.beta)
+        F1 = gather_rows(F, batch.sel1, batch.G1, batch.beta)
         # SC2-PCR path (scripts/test_kitti.py:179-181): Matcher.estimator re-samples both clouds to num_node with
         # replacement, matches them and registers the matched pairs.  Same draws (pair by pair from one seeded
         # RandomState, source before target) and the same arithmetic as a per-pair loop over ``matcher.estimator``,

@@ -255,6 +255,72 @@ def test_enqueued_steps_carry_their_own_verdict_and_results(cloud):
     clean.check_range()
 
 
+def test_two_steps_in_flight_give_the_serial_records(cloud):
+    """``enqueue(tail_stream=True)`` (bench.py's round-5 loop): only the forward runs on the caller's stream; gather / NN / RANSAC /
+    read-back run on the pipeline's second stream while the NEXT forward is already enqueued on the first.  Four steps back to
+    back, the maps of each built on the side stream: every step's records are those of the serial ``register`` - bit for bit -,
+    and the overflowing model in the middle is flagged on its own step only."""
+    from eyoc_amd import registration as reg, synthetic as syn
+    from eyoc_amd.harness import DeviceBatch, RegistrationConfig, RegistrationPipeline
+    L, lib = _lib()
+    dev = torch.device("cuda")
+    cfg = RegistrationConfig(ransac_max_iteration=100000, n_points=2000)
+    seeds = [(3, 4), (5, 6)]
+    batches = [DeviceBatch([syn.make_pair(s, beams=32, azimuths=1000, band=None) for s in ss], list(ss), dev, n_points=cfg.n_points,
+                           descriptor=dict(inlier_ratio=0.3)) for ss in seeds]
+    clean = make_model(cloud["sd"], "split16")
+    bad_sd, _ = doctor(cloud["sd"], cloud["base"], "block1.conv1")
+    bad = make_model(bad_sd, "split16")
+    p_clean, p_bad = RegistrationPipeline(clean, cfg), RegistrationPipeline(bad, cfg)
+    want = [p_clean.register(b, seed=7) for b in batches]
+    plan = [(p_clean, 0), (p_clean, 1), (p_bad, 0), (p_clean, 1), (p_clean, 0)]
+    pend = []
+    for k, (pipe, b) in enumerate(plan):
+        maps = pipe.prepare_maps(batches[b])
+        pend.append(pipe.enqueue(batches[b], seed=7, maps=maps, slot=k & 1, tail_stream=True))
+        if k >= 1:                      # two steps in flight: step k - 1 is read while step k runs
+            host, over = pend[k - 1].wait()
+            pipe_prev, b_prev = plan[k - 1]
+            assert over == (pipe_prev is p_bad)
+            if not over:
+                got = [reg.decode_ransac_result(host[i], batches[b_prev].n_points) for i in range(batches[b_prev].P)]
+                for g, w in zip(got, want[b_prev]):
+                    np.testing.assert_array_equal(g.transformation, w.transformation)
+                    assert g.inliers == w.inliers and g.survivors == w.survivors and g.best_hypothesis == w.best_hypothesis
+    host, over = pend[-1].wait()
+    assert not over
+    for g, w in zip([reg.decode_ransac_result(host[i], batches[0].n_points) for i in range(batches[0].P)], want[0]):
+        np.testing.assert_array_equal(g.transformation, w.transformation)
+    with pytest.raises(L.EyocError):
+        bad.check_range()
+    clean.check_range()
+
+
+def test_fp32_forwards_after_an_overflow_report_a_clean_verdict(cloud):
+    """word 0 of the guard (this forward's verdict) was cleared by split16 forwards only - after an overflow had switched
+    the model to fp32 MFMAs, every later ``enqueue`` kept reporting ``overflowed`` although fp32 forwards cannot overflow."""
+    from eyoc_amd import synthetic as syn
+    from eyoc_amd.harness import DeviceBatch, RegistrationConfig, RegistrationPipeline
+    L, lib = _lib()
+    dev = torch.device("cuda")
+    cfg = RegistrationConfig(ransac_max_iteration=50000, n_points=2000)
+    batch = DeviceBatch([syn.make_pair(3, beams=32, azimuths=1000, band=None)], [3], dev, n_points=cfg.n_points,
+                        descriptor=dict(inlier_ratio=0.3))
+    bad_sd, _ = doctor(cloud["sd"], cloud["base"], "block1.conv1")
+    m = make_model(bad_sd, "split16")
+    pipe = RegistrationPipeline(m, cfg)
+    _, over = pipe.enqueue(batch, seed=1, slot=0).wait()
+    assert over
+    with pytest.raises(L.EyocError):
+        m.check_range()                              # the sticky word, reported once
+    m.spconv_math = "fp32"                           # what harness._checked does in automatic mode
+    for tail in (False, True):
+        host, over = pipe.enqueue(batch, seed=1, slot=1, tail_stream=tail).wait()
+        assert not over and m.last_spconv_math == "fp32"
+        assert np.isfinite(np.frombuffer(host.numpy().tobytes(), np.float32)[:16]).all()
+    m.check_range()
+
+
 def test_progress_event_fires_inside_the_forward(cloud):
     """``model.progress_event(layer)``: an event every forward records in front of launch ``layer`` - a side stream that waits for it
     (bench.py --maps-after layer:-3) runs beside the rest of the forward.  It must lie between the forward's first and last event."""
