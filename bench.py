@@ -54,8 +54,8 @@ from eyoc_amd.metrics import registration_errors  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_16x16x4_f32 dense peak
-MFMA_F16_PEAK_TF = 2500
-MFMA_F16_SUSTAINED_TF = 1600.0     # scripts/micro/mfma_power.hip: dense v_mfma_f32_16x16x32_f16 stream, random fp16 operands, 2 waves per SIMD.0  # v_mfma_f32_16x16x32_f16 dense peak (MI355X_MICROARCH.md; never the 2:1-sparsity figure)
+MFMA_F16_PEAK_TF = 2500.0          # v_mfma_f32_16x16x32_f16 dense peak (MI355X_MICROARCH.md; never the 2:1-sparsity figure)
+MFMA_F16_SUSTAINED_TF = 1600.0     # scripts/micro/mfma_power.hip: a dense stream of that instruction on random fp16 operands, 2 waves per SIMD
 REC = 20                   # floats per result record: 16 pose + RTE + RRE + success + rank
 
 
@@ -321,7 +321,10 @@ def worker(args):
             T[0, 3] = s_
             gen[s_] = {"T_gt": T}
     else:
-        made = make_pairs(scenes, args.nuscenes)      # before any GPU call: forks
+        # before any GPU call: forks.  The host's cores are shared by the ranks of this node (8 ranks x 8 workers on a 16-core quota
+        # would be 64 processes)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        made = make_pairs(scenes, args.nuscenes, workers=max(1, min(8, usable_cores() // max(1, local_world), len(scenes))))
         gen = dict(zip(scenes, made))
         nus_pairs = None
         if world == 1 and not total_mode and not args.no_extras and not args.nuscenes:
@@ -368,30 +371,32 @@ def worker(args):
     if model is not None:
         model.set_timing(True)
         pipe.timing = True
-    layer_ms, stage_ms, n_fwd = None, {"feat": 0.0, "match": 0.0, "reg": 0.0}, 0
     passes = args.steps
     steps_timed = passes * len(batches) if total_mode else passes
-    last = {}
     overlap_maps = args.overlap_maps
     two = args.in_flight == 2 and overlap_maps          # two steps in flight needs the maps off the main stream
 
-    def collect(item):
-        nonlocal layer_ms, n_fwd
+    class Acc:
+        """What a leg of pipelined steps accumulates: per-layer / per-stage event times and the last results per batch."""
+        def __init__(self):
+            self.layer_ms, self.stage_ms, self.n_fwd, self.last = None, {"feat": 0.0, "match": 0.0, "reg": 0.0}, 0, {}
+
+    def collect(item, acc, batches_):
         s_, res_, slot_ = item[:3]
-        batch_ = batches[s_ % len(batches)][1]
+        batch_ = batches_[s_ % len(batches_)][1]
         host, overflowed = res_.wait()      # this step's own read-back (enqueued with it): no queueing behind the step enqueued since
         if overflowed:
             model.check_range()             # split16 range guard: raises EYOC_ERR_RANGE with the library's message
-        last[s_ % len(batches)] = [eyoc_amd.registration.decode_ransac_result(host[p], batch_.n_points) for p in range(batch_.P)]
+        acc.last[s_ % len(batches_)] = [eyoc_amd.registration.decode_ransac_result(host[p], batch_.n_points) for p in range(batch_.P)]
         if model is not None:
             model.timing_slot(slot_)
             ms = np.array(model.layer_ms())
-            layer_ms = ms if layer_ms is None else layer_ms + ms
+            acc.layer_ms = ms if acc.layer_ms is None else acc.layer_ms + ms
             for k, v in pipe.stage_ms(slot_).items():
-                stage_ms[k] += v
-            n_fwd += 1
+                acc.stage_ms[k] += v
+            acc.n_fwd += 1
 
-    def run_steps(n_steps):
+    def run_steps(n_steps, acc, batches_=None, two_=None, maps_after=None):
         """Software-pipelined over the steps: step s is ENQUEUED - its read-back into pinned memory included (RegistrationPipeline.
         enqueue) - before the host waits for step s-1's results and reads its timers (two event / buffer sets), so the GPU never
         waits for the host's decode between steps.  (Until late in round 4 the read-back of step s-1 was ISSUED after step s had
@@ -399,49 +404,51 @@ def worker(args):
         step while the host decoded and launched - found in a kernel trace, bench.py's own stage timers could not see it.)
         Everything - the last step's read-back included - happens inside this call.  The warm-up runs the SAME code (same
         streams, same number of live map sets and workspaces: their first hipMallocs cost ~0.25 s apiece on a fresh box)."""
-        nonlocal layer_ms, n_fwd
+        batches_ = batches if batches_ is None else batches_
+        two_ = two if two_ is None else two_
+        maps_after = args.maps_after if maps_after is None else maps_after
         t_loop = time.perf_counter()
         pending = None           # (step, device result, event slot, maps) of the step whose read-back is still due
         next_maps = None
         for s in range(n_steps):
-            ids, batch = batches[s % len(batches)]
+            ids, batch = batches_[s % len(batches_)]
             if dry or not cfg.use_RANSAC:
-                last[s % len(batches)] = pipe.register(batch)
+                acc.last[s % len(batches_)] = pipe.register(batch)
                 if model is not None and not dry:
                     ms = np.array(model.layer_ms())
-                    layer_ms = ms if layer_ms is None else layer_ms + ms
+                    acc.layer_ms = ms if acc.layer_ms is None else acc.layer_ms + ms
                     for k, v in pipe.stage_ms().items():
-                        stage_ms[k] += v
-                    n_fwd += 1
+                        acc.stage_ms[k] += v
+                    acc.n_fwd += 1
                 continue
             slot = s & 1
             model.timing_slot(slot)
             pipe.slot = slot
             if next_maps is None and overlap_maps:
                 next_maps = pipe.prepare_maps(batch)                    # first step: nothing to hide behind
-            res = pipe.enqueue(batch, maps=next_maps, slot=slot, tail_stream=two)
+            res = pipe.enqueue(batch, maps=next_maps, slot=slot, tail_stream=two_)
             held, next_maps = next_maps, None
-            if two and s + 1 < n_steps:
+            if two_ and s + 1 < n_steps:
                 # two steps in flight: the main stream runs forward after forward, so the next step's maps must be there when THIS
                 # forward ends - built now, on the side stream, beside this forward (and the previous step's tail on its stream)
-                next_maps = pipe.prepare_maps(batches[(s + 1) % len(batches)][1],
-                                              after=progress if args.maps_after.startswith("layer:") else None)
+                next_maps = pipe.prepare_maps(batches_[(s + 1) % len(batches_)][1],
+                                              after=progress if maps_after.startswith("layer:") else None)
             # the previous step's read-back and timers FIRST: its results are long there, and the map build below blocks the host (two
             # count read-backs behind the `matched` event) until ~1 ms before the GPU runs dry - decoding 64 results and reading 50
             # timers after it left the GPU waiting for step s + 1's launches
             if pending is not None:
-                collect(pending)
-            if overlap_maps and not two and s + 1 < n_steps:
+                collect(pending, acc, batches_)
+            if overlap_maps and not two_ and s + 1 < n_steps:
                 # the next step's maps, on the side stream, while this step's matching / RANSAC runs on the main stream
-                after = {"matched": pipe.matched, "feat": pipe.featured, "start": None}.get(args.maps_after, progress)
-                next_maps = pipe.prepare_maps(batches[(s + 1) % len(batches)][1], after=after)
+                after = {"matched": pipe.matched, "feat": pipe.featured, "start": None}.get(maps_after, progress)
+                next_maps = pipe.prepare_maps(batches_[(s + 1) % len(batches_)][1], after=after)
             pending = (s, res, slot, held)
             if args.verbose:
                 st = torch.cuda.memory_stats()
                 log(f"step {s}: enqueued at {time.perf_counter() - t_loop:.4f} s, reserved {st['reserved_bytes.all.current'] >> 20} MiB, "
                     f"device allocs {st['num_device_alloc']}, frees {st['num_device_free']}")
         if pending is not None:
-            collect(pending)
+            collect(pending, acc, batches_)
 
     if pipe is not None:
         pipe.side_priority = args.side_priority
@@ -451,7 +458,7 @@ def worker(args):
     if hp is not None:
         hp.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(hp)
-    run_steps(args.warmup)
+    run_steps(args.warmup, Acc())
     log(f"{args.warmup} warm-up step(s) done")
     settle = 0
     if overlap_maps and not dry:
@@ -460,19 +467,18 @@ def worker(args):
         # allocator has stopped growing (bounded), and report how many that took.
         for _ in range(3):
             a0 = torch.cuda.memory_stats()["num_device_alloc"]
-            run_steps(3)
+            run_steps(3, Acc())
             settle += 3
             if torch.cuda.memory_stats()["num_device_alloc"] == a0:
                 break
         log(f"{settle} allocator-settling step(s) done")
-    layer_ms, stage_ms, n_fwd = None, {"feat": 0.0, "match": 0.0, "reg": 0.0}, 0
-    last.clear()
+    acc = Acc()
     edist.barrier()
     if not dry:
         torch.cuda.synchronize()
     allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0) if not dry else 0
     t0 = time.perf_counter()
-    run_steps(steps_timed)
+    run_steps(steps_timed, acc)
     edist.barrier()
     if not dry:
         torch.cuda.synchronize()
@@ -481,6 +487,16 @@ def worker(args):
     if model is not None and not dry:
         model.check_range()      # the sticky flag: every step's own verdict was read with its results; this is the belt to those braces
     elapsed = edist.max_over_ranks(elapsed, device)
+    layer_ms, stage_ms, n_fwd, last = acc.layer_ms, acc.stage_ms, acc.n_fwd, acc.last
+    # the same kernels UNDISTURBED: with two steps in flight the forward shares the chip with the previous step's RANSAC and the next
+    # step's map build, and an event-bracketed layer time then holds whatever else ran in between.  A short one-stream pass (maps
+    # behind the forward, nothing beside the forward's kernels) gives the kernels' own durations for the roofline
+    alone = None
+    if model is not None and not dry and cfg.use_RANSAC and two:
+        alone = Acc()
+        run_steps(2, Acc(), two_=False, maps_after="feat")
+        run_steps(max(4, min(10, steps_timed)), alone, two_=False, maps_after="feat")
+        torch.cuda.synchronize()
     if model is not None:
         model.set_timing(False)
         pipe.timing = False
@@ -545,12 +561,17 @@ def worker(args):
     gather = sum(work[i]["gather_bytes"] for i in conv)
     compulsory = sum(work[i]["compulsory_bytes"] for i in conv)
     flops = sum(work[i]["flop"] for i in conv)
-    conv_ms = float(sum(layer_ms[i] for i in conv)) / n_fwd
+    conv_ms_timed = float(sum(layer_ms[i] for i in conv)) / n_fwd          # inside the timed region (shared chip when two steps are in flight)
+    if alone is not None:                                                    # the kernels' own durations: the one-stream pass behind the timed region
+        layer_ms_k, n_fwd_k = alone.layer_ms, alone.n_fwd
+    else:
+        layer_ms_k, n_fwd_k = layer_ms, n_fwd
+    conv_ms = float(sum(layer_ms_k[i] for i in conv)) / n_fwd_k
     out["config"]["voxels_per_level"] = x.coordinate_manager.info()["rows"]
     if args.verbose:
         print(f"{'layer':18s} {'ms':>8s} {'GFLOP':>8s} {'TFLOP/s':>8s} {'gatherGB/s':>10s} {'pairs':>10s}", file=sys.stderr)
         for i, w in enumerate(work):
-            ms_i = layer_ms[i] / n_fwd
+            ms_i = layer_ms_k[i] / n_fwd_k
             print(f"{w['name']:18s} {ms_i:8.3f} {w['flop'] / 1e9:8.2f} {w['flop'] / ms_i / 1e9:8.2f} "
                   f"{w['gather_bytes'] / ms_i / 1e6:10.1f} {w['pairs']:10d}", file=sys.stderr)
     achieved_tf = flops / (conv_ms * 1e-3) / 1e12
@@ -581,6 +602,18 @@ def worker(args):
                            "achieved": achieved_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                            "frac": achieved_tf / MFMA_F32_PEAK_TF, "traffic": None, "traffic_measured_in_run": False,
                            "kernel": kernel, "algorithmic_flop_per_forward": flops, "ms_per_forward": conv_ms, "math": math_mode}
+    out["roofline"]["measured"] = (f"hipEvents around every launch of the forward, on the launch stream, over {n_fwd_k} forwards of a one-stream pass run "
+                                   "right behind the timed region (nothing beside the forward's kernels); the timed region's own event times - "
+                                   "the forward sharing the chip with the previous step's RANSAC and the next step's map build - are in `in_timed_region`"
+                                   if alone is not None else f"hipEvents around every launch of the forward, on the launch stream, over the {n_fwd_k} forwards of the timed region")
+    if alone is not None:
+        k3 = 3 if math_mode == "split16" else 1
+        pk = MFMA_F16_PEAK_TF if math_mode == "split16" else MFMA_F32_PEAK_TF
+        out["roofline"]["in_timed_region"] = {"ms_per_forward": conv_ms_timed, "achieved": k3 * flops / (conv_ms_timed * 1e-3) / 1e12,
+                                              "frac": k3 * flops / (conv_ms_timed * 1e-3) / 1e12 / pk,
+                                              "note": "event-bracketed launches while two other streams share the chip: not the kernels' own durations"}
+        out["undisturbed_pass"] = {"steps": alone.n_fwd, "forward_ms_per_step": float(alone.layer_ms.sum()) / alone.n_fwd,
+                                   "stage_ms_per_step": {k: v / alone.n_fwd for k, v in alone.stage_ms.items()}}
     out["hbm_gather"] = {"achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_forward": gather, "compulsory_bytes_per_forward": compulsory,
                          "traffic_over_compulsory": None}
@@ -638,31 +671,66 @@ def worker(args):
         # batch: the figure to hold against a reference that multiplies in fp32 (model/resunet.py:31-140 -> sgemm)
         if math_mode == "split16":
             model.spconv_math = "fp32"
+            model.set_timing(True)
+            pipe.timing = True
             try:
-                pipe.register(b0)                                      # warm-up (maps in the caller's order, fp32 kernels)
-                model.set_timing(True)
-                model.timing_slot(0)
-                n32, ms32, lay32 = 5, 0.0, None
-                for _ in range(n32):
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    pipe.register(b0)
-                    torch.cuda.synchronize()
-                    ms32 += (time.perf_counter() - t1) * 1e3
-                    l_ = np.array(model.layer_ms())
-                    lay32 = l_ if lay32 is None else lay32 + l_
+                # like for like with the headline: the SAME pipelined loop (two steps in flight, maps on the side stream), >= 10 steps
+                run_steps(3, Acc())
+                torch.cuda.synchronize()
+                a32, n32 = Acc(), 10
+                t1 = time.perf_counter()
+                run_steps(n32, a32)
+                torch.cuda.synchronize()
+                ms32 = (time.perf_counter() - t1) * 1e3 / n32
                 assert model.last_spconv_math == "fp32"
-                conv32 = float(sum(lay32[i] for i in conv)) / n32
+                k32 = Acc()                                             # and its kernels alone, for the fp32 roofline
+                run_steps(1, Acc(), two_=False, maps_after="feat")
+                run_steps(4, k32, two_=False, maps_after="feat")
+                torch.cuda.synchronize()
+                conv32 = float(sum(k32.layer_ms[i] for i in conv)) / k32.n_fwd
                 tf32 = flops / (conv32 * 1e-3) / 1e12
-                out["fp32_math"] = {"value": b0.P / (ms32 / n32 * 1e-3), "unit": "pairs/s", "ms_per_step": ms32 / n32, "steps": n32,
-                                    "note": "un-pipelined steps (each one synchronised), otherwise the headline's workload",
+                out["fp32_math"] = {"value": b0.P / (ms32 * 1e-3), "unit": "pairs/s", "ms_per_step": ms32, "steps": n32,
+                                    "note": "the headline's workload and the headline's loop (bench.run_steps: same streams, same overlap), "
+                                            "sparse-conv products on v_mfma_f32_16x16x4_f32",
+                                    "success_rate": float(np.mean([e["success"] for e in pipe.evaluate(b0, a32.last[0])])),
                                     "roofline": {"bound": "mfma", "pipe": "fp32 matrix pipe (v_mfma_f32_16x16x4_f32)",
                                                  "achieved": tf32, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                                 "frac": tf32 / MFMA_F32_PEAK_TF, "ms_per_forward": conv32}}
+                                                 "frac": tf32 / MFMA_F32_PEAK_TF, "ms_per_forward": conv32,
+                                                 "measured": f"one-stream pass of {k32.n_fwd} forwards"}}
             finally:
                 model.set_timing(False)
+                pipe.timing = False
                 model.spconv_math = args.math
             log("fp32-math leg done")
+        # configs[3] at N = 1: the 545 pairs of the LoKITTI_50 split (config/file_LoKITTI_50.npy, scripts/test_kitti.sh:45-75) through the
+        # same loop on this one GPU - eight batches of 64 pairs and a ragged ninth of 33 (the 64 scenes of the timed batch repeat:
+        # the device work does not depend on which scene it is), every record read back and evaluated
+        if cfg.use_RANSAC and len(pairs0) >= 2:
+            n_split = 545
+            split = []
+            for b_ in range(0, n_split, args.pairs):
+                k_ = min(args.pairs, n_split - b_)
+                split.append((list(range(b_, b_ + k_)), b0 if k_ == len(pairs0) else
+                              DeviceBatch(pairs0[:k_], seeds0[:k_], device, cfg.n_points, descriptor=descriptor)))
+            model.set_timing(True)
+            pipe.timing = True
+            try:
+                run_steps(len(split), Acc(), batches_=split)          # one untimed pass: the ragged batch's maps / workspaces exist
+                torch.cuda.synchronize()
+                a5 = Acc()
+                t1 = time.perf_counter()
+                run_steps(len(split), a5, batches_=split)
+                torch.cuda.synchronize()
+                dt5 = time.perf_counter() - t1
+            finally:
+                model.set_timing(False)
+                pipe.timing = False
+            ok5 = [e["success"] for b_ in sorted(a5.last) for e in pipe.evaluate(split[b_][1], a5.last[b_])]
+            out["lokitti_545_1gpu"] = {"pairs_per_s": n_split / dt5, "seconds": dt5, "pairs": n_split, "records_gathered": len(ok5),
+                                       "batches": [len(ids_) for ids_, _ in split], "success_rate": float(np.mean(ok5)),
+                                       "note": "one pass over a 545-pair split on ONE GPU through the timed loop (ragged last batch); the 8-GPU "
+                                               "half of configs[3] is `--gpus 8 --total-pairs 545`, unmeasured on hardware"}
+            log("545-pair split done")
         # RANSAC cost against the inlier ratio (the number of surviving hypotheses grows like p^4)
         sweep = []
         for ratio in (0.0, 0.15, 0.3, 0.6):
