@@ -70,6 +70,9 @@ def parse_args(argv=None):
     ap.add_argument("--total-pairs", type=int, default=0, help="fixed split of this many pairs over all ranks (strong scaling)")
     ap.add_argument("--pool", type=int, default=0, help="distinct scenes per rank in --total-pairs mode (default: --pairs)")
     ap.add_argument("--nuscenes", action="store_true", help="nuScenes-shaped pairs: 32 beams, d in [5,50] m (configs[4])")
+    ap.add_argument("--sc2pcr", action="store_true",
+                    help="the SC2-PCR back-end instead of RANSAC in the timed steps (scripts/test_kitti.py:179-181; with --nuscenes --pairs 16 "
+                         "this is configs[4] on one GPU) - what profiles/r5_sc2pcr_* were taken on")
     ap.add_argument("--math", choices=["auto", "fp32", "split16"], default="auto",
                     help="arithmetic of the sparse convolutions (auto: split16 for batches that fill the chip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -104,6 +107,8 @@ def parse_args(argv=None):
     ap.add_argument("--down-staged", type=int, default=-1, help="diagnostics: eyoc_spconv_select_down_kernel (0 / 1)")
     ap.add_argument("--up-kernel", type=int, default=-1, help="diagnostics: eyoc_spconv_select_up_kernel (0 gathering, 1 Morton tiles, 2 class-major tiles)")
     ap.add_argument("--st-group", type=int, default=-1, help="diagnostics: eyoc_spconv_st_group_rows (0 / 1): row grouping inside the staged kernel's tiles")
+    ap.add_argument("--sc2-dense-x", type=int, default=None, help="diagnostics: eyoc_sc2pcr_set_dense_threshold (default 6; -1 = dense-block kernel off)")
+    ap.add_argument("--sc2-list-cap", type=int, default=None, help="diagnostics: eyoc_sc2pcr_set_shortlist_cap (default 1024; 0 = histogram selection)")
     ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
     return ap.parse_args(argv)
 
@@ -265,29 +270,38 @@ def timed_rate(pipe, batch, reps, warm=1):
     return (time.perf_counter() - t0) / reps
 
 
-def pipelined_rate(pipe, batch, reps, warm=3):
+def pipelined_rate(pipe, batch, reps, warm=3, tail=True):
     """Seconds per call of a serving loop over batches of this size: every call is enqueued with its read-back (RegistrationPipeline.
-    enqueue), the next call's maps are built on the side stream behind this call's forward, and the host decodes call s - 1 while
-    call s runs - the pattern of the timed loop, for the small batches of configs[1] / configs[2]."""
+    enqueue), two calls in flight (``tail``: matching / registration of call s on the pipeline's second stream beside the forward of
+    call s + 1, the maps of call s + 2 on the side stream), and the host decodes call s - 1 while call s runs - the pattern of the
+    timed loop, for the small batches of configs[1] / configs[2] and for the SC2-PCR back-end."""
     import eyoc_amd
+
+    def decode(pend):
+        host, over = pend.wait()
+        assert not over
+        if pipe.cfg.use_RANSAC:
+            return [eyoc_amd.registration.decode_ransac_result(host[i], batch.n_points) for i in range(batch.P)]
+        return host.numpy().astype(np.float64)
+
     pend, maps, t0 = None, pipe.prepare_maps(batch), 0.0
     for s in range(warm + reps):
         if s == warm:
             if pend is not None:
-                pend.wait()
+                decode(pend)
                 pend = None
             torch.cuda.synchronize()
             t0 = time.perf_counter()
         pipe.slot = s & 1
-        p = pipe.enqueue(batch, maps=maps, slot=s & 1)
+        p = pipe.enqueue(batch, maps=maps, slot=s & 1, tail_stream=tail)
+        if tail:
+            maps = pipe.prepare_maps(batch)
         if pend is not None:
-            host, over = pend.wait()
-            assert not over
-            [eyoc_amd.registration.decode_ransac_result(host[i], batch.n_points) for i in range(batch.P)]
-        maps = pipe.prepare_maps(batch, after=pipe.featured)
+            decode(pend)
+        if not tail:
+            maps = pipe.prepare_maps(batch, after=pipe.featured)
         pend = p
-    host, over = pend.wait()
-    [eyoc_amd.registration.decode_ransac_result(host[i], batch.n_points) for i in range(batch.P)]
+    decode(pend)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps
 
@@ -355,8 +369,14 @@ def worker(args):
         if args.st_group >= 0:
             from eyoc_amd import _lib as _l
             _l.load().eyoc_spconv_st_group_rows(args.st_group)
+        if args.sc2_dense_x is not None:
+            from eyoc_amd import _lib as _l
+            _l.load().eyoc_sc2pcr_set_dense_threshold(_l.ctx(device.index), args.sc2_dense_x)
+        if args.sc2_list_cap is not None:
+            from eyoc_amd import _lib as _l
+            _l.load().eyoc_sc2pcr_set_shortlist_cap(_l.ctx(device.index), args.sc2_list_cap)
         log("model packed")
-        cfg = RegistrationConfig(ransac_max_iteration=args.ransac_iters)
+        cfg = RegistrationConfig(ransac_max_iteration=args.ransac_iters, use_RANSAC=not args.sc2pcr)
         pipe, Batch = RegistrationPipeline(model, cfg), DeviceBatch
 
     batches = []
@@ -387,7 +407,11 @@ def worker(args):
         host, overflowed = res_.wait()      # this step's own read-back (enqueued with it): no queueing behind the step enqueued since
         if overflowed:
             model.check_range()             # split16 range guard: raises EYOC_ERR_RANGE with the library's message
-        acc.last[s_ % len(batches_)] = [eyoc_amd.registration.decode_ransac_result(host[p], batch_.n_points) for p in range(batch_.P)]
+        if cfg.use_RANSAC:
+            acc.last[s_ % len(batches_)] = [eyoc_amd.registration.decode_ransac_result(host[p], batch_.n_points) for p in range(batch_.P)]
+        else:                               # SC2-PCR path: the record is the pose
+            Th = host.numpy().astype(np.float64)
+            acc.last[s_ % len(batches_)] = [eyoc_amd.registration.RegistrationResult(Th[p], 0.0, 0.0) for p in range(batch_.P)]
         if model is not None:
             model.timing_slot(slot_)
             ms = np.array(model.layer_ms())
@@ -412,7 +436,7 @@ def worker(args):
         next_maps = None
         for s in range(n_steps):
             ids, batch = batches_[s % len(batches_)]
-            if dry or not cfg.use_RANSAC:
+            if dry:
                 acc.last[s % len(batches_)] = pipe.register(batch)
                 if model is not None and not dry:
                     ms = np.array(model.layer_ms())
@@ -492,7 +516,7 @@ def worker(args):
     # step's map build, and an event-bracketed layer time then holds whatever else ran in between.  A short one-stream pass (maps
     # behind the forward, nothing beside the forward's kernels) gives the kernels' own durations for the roofline
     alone = None
-    if model is not None and not dry and cfg.use_RANSAC and two:
+    if model is not None and not dry and two:
         alone = Acc()
         run_steps(2, Acc(), two_=False, maps_after="feat")
         run_steps(max(4, min(10, steps_timed)), alone, two_=False, maps_after="feat")
@@ -536,16 +560,16 @@ def worker(args):
         return
     out["config"] = {"workload": f"{args.pairs} synthetic {shape} pairs per step per GPU "
                                  f"(mean {b0.voxels // (2 * b0.P)} voxels/cloud, ResUNetBN2C random-init, "
-                                 f"5000-point NN, RANSAC {args.ransac_iters} hypotheses/pair, {plant}, spconv math {model.last_spconv_math})",
+                                 f"5000-point NN, {f'RANSAC {args.ransac_iters} hypotheses/pair' if cfg.use_RANSAC else 'SC2-PCR back-end (8000 resampled correspondences/pair)'}, {plant}, spconv math {model.last_spconv_math})",
                      "pairs_per_step": args.pairs, "parallelism": f"pairs sharded over {world} GPU(s)",
                      "inlier_ratio": args.inlier_ratio if descriptor else None,
                      "map_build": (("maps of step s + 1 built on a side stream beside step s's forward (one build per timed step)" if two else
                                     f"maps of step s + 1 built on a side stream behind step s's {dict(start='enqueue', feat='forward', matched='matching').get(args.maps_after, 'forward reaching ' + args.maps_after)} (one build per timed step)")
-                                   if overlap_maps and cfg.use_RANSAC else "in front of every forward, main stream"),
-                     "steps_in_flight": 2 if (two and cfg.use_RANSAC) else 1,
+                                   if overlap_maps else "in front of every forward, main stream"),
+                     "steps_in_flight": 2 if two else 1,
                      "schedule": ("forward of step s + 1 on the main stream beside row gather / NN / RANSAC / read-back of step s on a second "
                                   "stream and the map build of step s + 2 on a third; every timed step pays for one of each inside the bracket"
-                                  if (two and cfg.use_RANSAC) else "one stream per step; only the next step's map build runs beside it")}
+                                  if two else "one stream per step; only the next step's map build runs beside it")}
     if not dry:
         out["config"]["device_allocs_in_timed_region"] = allocs_timed
     if settle:
@@ -619,7 +643,7 @@ def worker(args):
                          "traffic_over_compulsory": None}
     out["forward_ms_per_step"] = float(layer_ms.sum()) / n_fwd
     out["stage_ms_per_step"] = {k: v / n_fwd for k, v in stage_ms.items()}
-    out["survivors_per_pair"] = float(np.mean([r.survivors for b in last.values() for r in b]))
+    out["survivors_per_pair"] = float(np.mean([r.survivors for b in last.values() for r in b])) if cfg.use_RANSAC else None
     # HBM traffic of the same kernels from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
     # WRITE_SIZE, separate passes; profiles/README.md) - quoted only when they were taken on this workload
     # AND on these kernel sources (the profile records a hash of eyoc_amd/csrc; a kernel change without a profile refresh must
@@ -652,7 +676,7 @@ def worker(args):
         except (OSError, KeyError, ValueError):
             pass
 
-    extras = world == 1 and not total_mode and not args.no_extras
+    extras = world == 1 and not total_mode and not args.no_extras and cfg.use_RANSAC
     if extras:
         pairs0 = [gen[scene_of(i)] for i in mine]
         seeds0 = [scene_of(i) for i in mine]
@@ -751,15 +775,19 @@ def worker(args):
         # the SC2-PCR back-end instead of RANSAC (scripts/test_kitti.py:179-181, configs[4]) on the same batch
         pipe2 = RegistrationPipeline(model, RegistrationConfig(use_RANSAC=False))
         t_sc2 = timed_rate(pipe2, b0, 3, 1)
+        t_sc2p = pipelined_rate(pipe2, b0, 4, 2)
         ev2 = pipe2.evaluate(b0, pipe2.register(b0))
-        out["sc2pcr_path"] = {"pairs_per_s": b0.P / t_sc2, "success_rate": float(np.mean([e["success"] for e in ev2]))}
+        out["sc2pcr_path"] = {"pairs_per_s": b0.P / t_sc2p, "synchronised_calls_pairs_per_s": b0.P / t_sc2,
+                              "success_rate": float(np.mean([e["success"] for e in ev2])),
+                              "note": "the headline's batch through the SC2-PCR back-end, calls pipelined like the timed loop"}
         # configs[4]: nuScenes-shaped input (32 beams, d in [5, 50] m) through the SC2-PCR back-end, 16 pairs per step
         if nus_pairs is not None:
             nseeds = list(range(5000, 5016))
             bn = DeviceBatch(nus_pairs, nseeds, device, cfg.n_points, descriptor=descriptor)
             t_n = timed_rate(pipe2, bn, 3, 1)
+            t_np = pipelined_rate(pipe2, bn, 10, 3)
             evn = pipe2.evaluate(bn, pipe2.register(bn))
-            out["nuscenes_sc2pcr_path"] = {"pairs_per_s": bn.P / t_n, "success_rate": float(np.mean([e["success"] for e in evn])),
+            out["nuscenes_sc2pcr_path"] = {"pairs_per_s": bn.P / t_np, "synchronised_calls_pairs_per_s": bn.P / t_n, "success_rate": float(np.mean([e["success"] for e in evn])),
                                            "pairs_per_step": bn.P, "mean_voxels_per_cloud": bn.voxels // (2 * bn.P),
                                            "planted_min": int(min(bn.planted)) if bn.planted else None}
         log("sc2pcr path done")

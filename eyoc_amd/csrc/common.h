@@ -81,6 +81,8 @@ struct eyoc_ctx {
   // (coordinates within +-2^zorder_kbits, batch index below 2^zorder_bbits); a build whose rows do not fit redoes its sort with
   // the full 18 + 10 bits.  The permutation is the same either way (the bias is order-preserving); only the number of radix passes differs.
   int zorder_kbits = 17, zorder_bbits = 10;
+  // SC2-PCR diagnostics (eyoc_sc2pcr_set_shortlist_cap / eyoc_sc2pcr_set_dense_threshold): per ctx, not per process
+  int sc2_list_cap = 1024, sc2_dense_x = 2;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -302,12 +302,20 @@ __device__ __forceinline__ void d_seeds(const int* __restrict__ rank, int n, int
 
 // ---- per seed: SC2 row = popcount(tight[seed] & tight[j]) * hard[seed][j]; stable top-k1 of it
 // (value descending, index ascending among equals).  One workgroup per seed; the row (n uint16
-// counts) lives in LDS.  Selection is exact and deterministic: coarse then fine histogram give the
-// k1-th largest value v*; everything above v* is taken, and of the values equal to v* the lowest
-// indices are taken through an ordered block scan.
+// counts) lives in LDS.  Selection is exact and deterministic.  Round 5: a SHORT LIST first - the k1-th largest of 64
+// group maxima (thread t scans entries t, t + 256, ...; four threads form a group) is a lower bound L of the k1-th
+// largest value, so the entries >= max(L, 1) (a few dozen) hold the whole answer: each counts the list entries in front of
+// it (value descending, index ascending = one comparison of packed keys) and stores itself at that position; a row with
+// fewer than k1 non-zero counts is completed with its lowest-index zeros.  Rows whose list does not fit (more than 1024
+// entries at or above the bound: many equal values) take the histogram path the kernel used for every seed before -
+// coarse then fine histogram give the k1-th largest value v*, everything above v* is taken, and of the values equal to
+// v* the lowest indices through an ordered scan.  (The histogram's LDS atomics - 2400 per inlier seed, clustered on a few
+// buckets - and thread 0's walk down the 1024 buckets were 2.6 of the kernel's 4.3 ms per 16-pair step.)
+// ``cnt_row`` != NULL: the seed sits in a DENSE block (d_seed_dense below) and its row of counts is already in memory.
 __device__ __forceinline__ void d_seed_topk(const unsigned long long* __restrict__ hard,
                                                    const unsigned long long* __restrict__ tight, int n, int words,
-                                                   const int* __restrict__ seeds, int k1, int* __restrict__ knn1) {
+                                                   const int* __restrict__ seeds, int k1, int* __restrict__ knn1,
+                                                   const unsigned short* __restrict__ cnt_row, int list_cap) {
   extern __shared__ unsigned char dyn[];
   unsigned short* row = reinterpret_cast<unsigned short*>(dyn);                                            // [n]
   unsigned long long* srow = reinterpret_cast<unsigned long long*>(dyn + ((size_t)n * 2 + 15) / 16 * 16);  // [words]
@@ -331,6 +339,9 @@ __device__ __forceinline__ void d_seed_topk(const unsigned long long* __restrict
   // The hard row is sparse (a few percent): compact its set bits into an LDS list, then ONE WAVE per candidate j
   // ANDs the two 1 KB tight rows with coalesced loads (a lane-per-j loop read them 8 bytes at a time, every lane a
   // different row, and idled on the unset bits).
+  if (cnt_row) {                                       // workgroup-uniform
+    for (int j = threadIdx.x; j < n; j += 256) row[j] = cnt_row[j];
+  } else {
   for (int j = threadIdx.x; j < n; j += 256) row[j] = 0;
   if (threadIdx.x == 0) cand_n = 0;
   __syncthreads();
@@ -365,23 +376,95 @@ __device__ __forceinline__ void d_seed_topk(const unsigned long long* __restrict
       if (lane == 0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          if (ci + u < nc) {
-            row[cand[ci + u]] = (unsigned short)c[u];
-            atomicAdd(&hist[c[u] >> 4], 1);
-          }
+          if (ci + u < nc) row[cand[ci + u]] = (unsigned short)c[u];
       }
     }
-    if (threadIdx.x == 0) atomicAdd(&hist[0], n - nc);   // every other column counts 0
+  }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {   // bucket of the k1-th largest value
-    int cum = 0, b = 1023;
-    for (; b > 0; --b) {
-      if (cum + hist[b] >= k1) break;
-      cum += hist[b];
+  {   // ---- short list
+    constexpr int CAP = 1024;
+    __shared__ unsigned int keys[CAP];
+    __shared__ unsigned short tmax[256];
+    __shared__ int keys_n, bound;
+    const int t = threadIdx.x, ln = t & 63;
+    unsigned int mx = 0;
+    for (int j = t; j < n; j += 256) mx = max(mx, (unsigned int)row[j]);
+    tmax[t] = (unsigned short)mx;
+    if (t == 0) keys_n = 0;
+    __syncthreads();
+    if (t < 64) {
+      const unsigned int g = max(max((unsigned int)tmax[4 * t], (unsigned int)tmax[4 * t + 1]), max((unsigned int)tmax[4 * t + 2], (unsigned int)tmax[4 * t + 3]));
+      int r = 0;
+      for (int u = 0; u < 64; ++u) {
+        const unsigned int o = (unsigned int)__shfl((int)g, u, 64);
+        r += (o > g) | ((o == g) & (u < ln));
+      }
+      if (r == k1 - 1) bound = (int)g;                 // k1 <= K1_MAX = 32 <= 64 groups: exactly one lane
     }
-    thr_bucket = b;
-    n_above = cum;
+    __syncthreads();
+    const unsigned int lc = (unsigned int)max(bound, 1);
+    for (int j = t; j < n; j += 256) {
+      const unsigned int c = row[j];
+      if (c >= lc) {
+        const int p = atomicAdd(&keys_n, 1);
+        if (p < CAP) keys[p] = (c << 14) | (unsigned int)(16383 - j);     // j < MAX_N = 2^14, c <= n: larger key = earlier in the order
+      }
+    }
+    __syncthreads();
+    const int m = keys_n;
+    if (m <= min(CAP, list_cap)) {                       // workgroup-uniform (list_cap: eyoc_sc2pcr_set_shortlist_cap, 0 = always the histogram)
+      for (int a = t; a < m; a += 256) {
+        const unsigned int key = keys[a];
+        int r = 0;
+        for (int q = 0; q < m; ++q) r += keys[q] > key;
+        if (r < k1) knn1[(size_t)s * k1 + r] = 16383 - (int)(key & 16383u);
+      }
+      if (m < k1 && t < 64) {                            // fewer than k1 non-zero counts: the lowest-index zeros complete the list
+        const int need = k1 - m;
+        int base = 0;
+        for (int j0 = 0; j0 < n && base < need; j0 += 64) {
+          const int j = j0 + ln;
+          const bool f = j < n && row[j] == 0;
+          const unsigned long long bm = __ballot(f);
+          const int pos = base + __popcll(bm & ((1ull << ln) - 1ull));
+          if (f && pos < need) knn1[(size_t)s * k1 + m + pos] = j;
+          base += __popcll(bm);
+        }
+      }
+      return;
+    }
+  }
+  // ---- histogram path (the list overflowed)
+  for (int j = threadIdx.x; j < n; j += 256) atomicAdd(&hist[row[j] >> 4], 1);
+  __syncthreads();
+  {   // bucket of the k1-th largest value.  (Round 5: thread 0 used to walk the 1024 buckets down from the top - ~30 us of
+      // dependent LDS reads per seed when most counts are small, 0.75 ms per 16-pair step.)  Thread t owns buckets 4 t .. 4 t + 3;
+      // a suffix scan over the threads gives every thread the number of entries above its buckets, and exactly one
+      // (thread, bucket) has  above < k1 <= above + own.
+    const int t = threadIdx.x, ln = t & 63, wv = t >> 6;
+    const int h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
+    const int mine = h0 + h1 + h2 + h3;
+    int suf = mine;                                   // inclusive suffix sum over the lanes of the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_down(suf, d, 64);
+      if (ln + d < 64) suf += o;
+    }
+    if (ln == 0) wave_cnt[wv] = suf;
+    __syncthreads();
+    for (int w = wv + 1; w < 4; ++w) suf += wave_cnt[w];
+    int cum = suf - mine;                             // entries in buckets above 4 t + 3
+    if (cum < k1 && suf >= k1) {                      // the threshold bucket is one of mine (t == 0: bucket 0 takes what is left)
+      int b = 3;
+      const int hh[4] = {h0, h1, h2, h3};
+      for (; b > 0; --b) {
+        if (cum + hh[b] >= k1) break;
+        cum += hh[b];
+      }
+      thr_bucket = 4 * t + b;
+      n_above = cum;
+    }
   }
   __syncthreads();
   for (int j = threadIdx.x; j < n; j += 256)
@@ -405,42 +488,138 @@ __device__ __forceinline__ void d_seed_topk(const unsigned long long* __restrict
       const int p = atomicAdd(&above_n, 1);
       if (p < K1_MAX) { above_idx[p] = j; above_val[p] = row[j]; }
     }
-  // equal entries: lowest indices first; thread t owns the contiguous index range [t*seg, (t+1)*seg)
-  const int seg = (n + 255) / 256;
-  const int j_lo = threadIdx.x * seg, j_hi = min(n, j_lo + seg);
-  int mine = 0;
-  for (int j = j_lo; j < j_hi; ++j) mine += row[j] == vstar;
-  int incl = mine;
+  // equal entries: lowest indices first.  Wave w owns the w-th quarter of the row and walks it 64 entries at a time (ballots give
+  // the order inside a step; consecutive lanes read consecutive entries - a thread per contiguous range of 32 entries had every
+  // wave access 16-way bank-conflicted)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int o = __shfl_up(incl, d, 64);
-    if (lane >= d) incl += o;
+  const int qlen = (n + 3) / 4, q_lo = wave * qlen, q_hi = min(n, q_lo + qlen);
+  int cnt_eq = 0;
+  for (int j0 = q_lo; j0 < q_hi; j0 += 64) {
+    const int j = j0 + lane;
+    cnt_eq += __popcll(__ballot(j < q_hi && row[j] == vstar));
   }
-  if (lane == 63) wave_cnt[wave] = incl;
+  if (lane == 0) wave_cnt[wave] = cnt_eq;
   __syncthreads();
-  int base = incl - mine;
+  int base = 0;
   for (int w = 0; w < wave; ++w) base += wave_cnt[w];
-  for (int j = j_lo; j < j_hi && base < need_eq; ++j)
-    if (row[j] == vstar) eq_idx[base++] = j;
+  for (int j0 = q_lo; j0 < q_hi && base < need_eq; j0 += 64) {      // wave-uniform
+    const int j = j0 + lane;
+    const bool f = j < q_hi && row[j] == vstar;
+    const unsigned long long m = __ballot(f);
+    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (f && pos < need_eq) eq_idx[pos] = j;
+    base += __popcll(m);
+  }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  {   // order: value descending, index ascending - every entry counts the entries in front of it (<= 31 of them)
     const int na = min(above_n, K1_MAX);
-    for (int a = 1; a < na; ++a) {   // insertion sort: value descending, index ascending
-      const int v = above_val[a], ix = above_idx[a];
-      int q = a - 1;
-      while (q >= 0 && (above_val[q] < v || (above_val[q] == v && above_idx[q] > ix))) {
-        above_val[q + 1] = above_val[q];
-        above_idx[q + 1] = above_idx[q];
-        --q;
-      }
-      above_val[q + 1] = v;
-      above_idx[q + 1] = ix;
+    if ((int)threadIdx.x < na) {
+      const int v = above_val[threadIdx.x], ix = above_idx[threadIdx.x];
+      int r = 0;
+      for (int q = 0; q < na; ++q) r += (above_val[q] > v) | ((above_val[q] == v) & (above_idx[q] < ix));
+      if (r < k1) knn1[(size_t)s * k1 + r] = ix;
     }
-    int m = 0;
-    for (int a = 0; a < na && m < k1; ++a) knn1[(size_t)s * k1 + m++] = above_idx[a];
-    for (int e = 0; e < need_eq && m < k1; ++e) knn1[(size_t)s * k1 + m++] = eq_idx[e];
-    for (; m < k1; ++m) knn1[(size_t)s * k1 + m] = seed;   // unreachable for n >= k1
+    const int ne = min(need_eq, k1 - min(na, k1));
+    if ((int)threadIdx.x < ne) knn1[(size_t)s * k1 + na + threadIdx.x] = eq_idx[threadIdx.x];
+    for (int m = na + max(ne, 0) + (int)threadIdx.x; m < k1; m += 256) knn1[(size_t)s * k1 + m] = seed;   // unreachable for n >= k1
+  }
+}
+
+// ---- dense seed blocks (round 5).  The seeds are the correspondences ranked by the leading eigenvector, so at a real inlier
+// ratio the first few hundred seeds are inliers, each compatible with ALL other inliers: 2400 candidates x 1 KB of tight-row
+// reads per seed at n = 8000, 30 % inliers - d_seed_topk's one-wave-per-(seed, candidate) loop spent 4 of the 18 ms of a
+// 16-pair step on them, bound by the latency of the row loads and its cross-lane reductions.  A block of 64 consecutive seeds
+// whose hard rows hold >= 2 n candidates together takes this path (measured on the bench's nuScenes-shaped pairs: x = 1-2 is the
+// minimum of the two kernels' sum, 2.14 ms against 2.35 at x = 6 and 2.95 without dense blocks) instead: LANE = SEED, the seeds' tight rows live in
+// REGISTERS (wave k of the workgroup keeps words [k W, (k+1) W) of all 64 rows), a candidate's row arrives through the scalar
+// cache (wave-uniform address), and a (seed, candidate) count costs 4 VALU instructions per word with no LDS read, no
+// reduction and no memory traffic beyond 1 KB per (block, candidate).  The four partial counts meet in LDS; wave k then
+// stores 16 candidates x 64 seeds as 32-byte pieces of the seeds' count rows.  Only candidates some seed of the block is
+// hard-compatible with are visited (the union of the 64 hard words).  d_seed_topk reads a dense block's rows instead of
+// computing them; the counts are integers, so the result is the same whichever path produced them.
+constexpr int DENSE_SPLITS = 16;     // workgroups per (pair, seed block): each takes 1/16 of the candidate words
+
+__device__ __forceinline__ void d_seed_blocks(const int* __restrict__ ptr_h, const int* __restrict__ seeds, int n, int n_seed,
+                                              const Sc2Ctl* __restrict__ ctl, unsigned char* __restrict__ blk_dense, int dense_x) {
+  const int lane = threadIdx.x & 63;
+  const int si = blockIdx.x * 64 + lane;
+  long long deg = 0;
+  if (si < n_seed) {
+    const int s = seeds[si];
+    deg = ctl->dense ? n : (long long)(ptr_h[s + 1] - ptr_h[s]);     // (the CSR offsets are clamped when the graph overflowed them)
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) deg += __shfl_down(deg, d, 64);
+  if (lane == 0) blk_dense[blockIdx.x] = (dense_x >= 0 && deg >= (long long)dense_x * n) ? 1 : 0;
+}
+
+template <int W>
+__device__ __forceinline__ void d_seed_dense(const unsigned long long* __restrict__ hard,
+                                             const unsigned long long* __restrict__ tight, int n, int words,
+                                             const int* __restrict__ seeds, int n_seed, unsigned short* __restrict__ cnt) {
+  __shared__ unsigned short part[4][64][64];          // [wave][candidate bit][seed]: conflict-free on both sides
+  __shared__ unsigned long long hws[64];
+  __shared__ unsigned long long uni;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int si = blockIdx.x * 64 + lane;
+  const bool valid = si < n_seed;
+  const int seed = seeds[valid ? si : blockIdx.x * 64];
+  const int w0 = wave * W;
+  const int wn = max(0, min(W, words - w0));            // this wave's words of a row (wave-uniform)
+  unsigned long long S[W];
+#pragma unroll
+  for (int t = 0; t < W; ++t) S[t] = t < wn ? tight[(size_t)seed * words + w0 + t] : 0ull;
+  const int per = (words + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int jw0 = (int)blockIdx.y * per, jw1 = min(words, jw0 + per);
+  const size_t pitch = (size_t)words * 64;
+  for (int jw = jw0; jw < jw1; ++jw) {
+    if (wave == 0) {
+      unsigned long long hw = valid ? hard[(size_t)seed * words + jw] : 0ull;
+      hws[lane] = hw;
+      unsigned int lo = (unsigned int)hw, hi = (unsigned int)(hw >> 32);
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { lo |= __shfl_xor(lo, d, 64); hi |= __shfl_xor(hi, d, 64); }
+      if (lane == 0) uni = ((unsigned long long)hi << 32) | lo;
+    }
+    __syncthreads();
+    const unsigned long long u_all = uni;
+    unsigned int ulo = __builtin_amdgcn_readfirstlane((unsigned int)u_all), uhi = __builtin_amdgcn_readfirstlane((unsigned int)(u_all >> 32));
+    unsigned long long u = ((unsigned long long)uhi << 32) | ulo;
+    while (u) {                                          // wave-uniform: the candidates some seed of the block needs
+      const int b = __builtin_ctzll(u);
+      u &= u - 1;
+      const unsigned long long* __restrict__ tj = tight + (size_t)(jw * 64 + b) * words + w0;   // uniform -> scalar loads
+      unsigned int acc = 0;
+#pragma unroll
+      for (int t = 0; t < W; ++t)
+        if (t < wn) {
+          const unsigned long long x = S[t] & tj[t];
+          acc += __popc((unsigned int)x) + __popc((unsigned int)(x >> 32));
+        }
+      part[wave][b][lane] = (unsigned short)acc;
+    }
+    __syncthreads();
+    {   // wave k: candidates 16 k .. 16 k + 15 of this word, 64 seeds: sum of the four partial counts, masked by the seed's hard bit
+      const unsigned long long hw = hws[lane];
+      unsigned int pk[8];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int b = 16 * wave + e;
+        unsigned int c = 0;
+        if ((u_all >> b) & 1ull) {                       // uniform
+          c = (unsigned int)part[0][b][lane] + part[1][b][lane] + part[2][b][lane] + part[3][b][lane];
+          c = ((hw >> b) & 1ull) ? c : 0u;
+        }
+        if (e & 1) pk[e >> 1] |= c << 16; else pk[e >> 1] = c;
+      }
+      if (valid) {
+        uint4* dst = reinterpret_cast<uint4*>(cnt + (size_t)si * pitch + (size_t)jw * 64 + 16 * wave);
+        dst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        dst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -672,8 +851,11 @@ struct Sc2Pair {
   int* knn; float* Ts; float* part; int* dom; int* rank; double* block_sq;
   int* ptr_h; unsigned short* col_h; float* val_h;   // CSR of the hard graph (support of the first-order matrix)
   long long csr_cap;
+  unsigned short* cnt;        // [n_seed][words * 64] second-order counts of the seeds of dense blocks (d_seed_dense)
+  unsigned char* blk_dense;   // [ceil(n_seed / 64)]
   int n, words, n_seed, k1, k2, n_part, col_chunk, num_iterations;
   float d, inlier_thr, nms_radius, refine_thr;
+  int list_cap, dense_x;      // per-ctx diagnostics (eyoc_sc2pcr_set_shortlist_cap / _set_dense_threshold)
 };
 struct Sc2Batch { Sc2Pair p[SC2_CHUNK]; };
 static_assert(sizeof(Sc2Batch) <= 4000, "the batch descriptor travels as a kernel argument (4 KB limit)");
@@ -740,10 +922,22 @@ __global__ __launch_bounds__(256) void k_masks(Sc2Batch B) {
   const Sc2Pair& q = B.p[blockIdx.z];
   d_masks(q.src, q.tgt, q.n, q.words, q.d, q.hard, q.tight);
 }
+__global__ __launch_bounds__(64) void k_seed_blocks(Sc2Batch B) {
+  const Sc2Pair& q = B.p[blockIdx.z];
+  if ((int)blockIdx.x * 64 >= q.n_seed) return;
+  d_seed_blocks(q.ptr_h, q.seeds, q.n, q.n_seed, q.ctl, q.blk_dense, q.dense_x);
+}
+template <int W>
+__global__ __launch_bounds__(256) void k_seed_dense(Sc2Batch B) {
+  const Sc2Pair& q = B.p[blockIdx.z];
+  if ((int)blockIdx.x * 64 >= q.n_seed || !q.blk_dense[blockIdx.x] || q.words > 4 * W || (W == 64 && q.words <= 128)) return;
+  d_seed_dense<W>(q.hard, q.tight, q.n, q.words, q.seeds, q.n_seed, q.cnt);
+}
 __global__ __launch_bounds__(256) void k_seed_topk(Sc2Batch B) {
   const Sc2Pair& q = B.p[blockIdx.z];
   if ((int)blockIdx.x >= q.n_seed) return;
-  d_seed_topk(q.hard, q.tight, q.n, q.words, q.seeds, q.k1, q.knn);
+  const unsigned short* row = q.blk_dense[blockIdx.x >> 6] ? q.cnt + (size_t)blockIdx.x * q.words * 64 : nullptr;
+  d_seed_topk(q.hard, q.tight, q.n, q.words, q.seeds, q.k1, q.knn, row, q.list_cap);
 }
 __global__ __launch_bounds__(256) void k_seed_solve(Sc2Batch B) {
   const Sc2Pair& q = B.p[blockIdx.z];
@@ -758,7 +952,7 @@ struct Plan {
   int n, words, n_seed, k1, k2;
   int n_part, col_chunk;   // column ranges of the lane-per-row sweeps (matvec, NMS, rank)
   size_t off_ctl, off_v, off_y, off_score, off_seeds, off_hard, off_tight, off_knn, off_Ts, off_part, off_int, off_sq, total;
-  size_t off_ptr_h, off_col_h, off_val_h;
+  size_t off_ptr_h, off_col_h, off_val_h, off_cnt, off_blk;
   long long csr_cap;   // entries each CSR list can hold: a quarter of the N^2 pairs (denser graphs sweep densely)
 };
 
@@ -795,6 +989,8 @@ Plan make_plan(int n, const eyoc_sc2pcr_params* p) {
   pl.off_ptr_h = take((size_t)(n + 1) * 4);
   pl.off_col_h = take((size_t)pl.csr_cap * 2);
   pl.off_val_h = take((size_t)pl.csr_cap * 4);
+  pl.off_cnt = take((size_t)(pl.n_seed + 1) * pl.words * 64 * 2);
+  pl.off_blk = take((size_t)(pl.n_seed + 64) / 64 + 1);
   pl.total = o + 256;
   return pl;
 }
@@ -802,6 +998,22 @@ Plan make_plan(int n, const eyoc_sc2pcr_params* p) {
 }  // namespace
 
 extern "C" {
+
+// Diagnostics, per ctx (tests run both paths of each and compare): the seed top-k's short list holds at most `cap` entries (0 = every
+// seed takes the histogram path, default and maximum 1024); a block of 64 seeds is "dense" when its hard rows hold >= x n candidates
+// (default 2; a negative x switches the dense-block kernel off).  Both return the previous value; neither changes any result.
+int eyoc_sc2pcr_set_shortlist_cap(eyoc_ctx* ctx, int cap) {
+  if (!ctx) return -1;
+  const int prev = ctx->sc2_list_cap;
+  if (cap >= 0) ctx->sc2_list_cap = cap > 1024 ? 1024 : cap;
+  return prev;
+}
+int eyoc_sc2pcr_set_dense_threshold(eyoc_ctx* ctx, int x) {
+  if (!ctx) return -1;
+  const int prev = ctx->sc2_dense_x;
+  ctx->sc2_dense_x = x;
+  return prev;
+}
 
 size_t eyoc_sc2pcr_workspace_bytes(int n, const eyoc_sc2pcr_params* params) {
   if (!params || n < 1 || n > MAX_N) return 0;
@@ -830,11 +1042,13 @@ static int sc2pcr_chunk(eyoc_ctx* ctx, const float* src_dev, const float* tgt_de
     q.dom = (int*)(w + pl.off_int); q.rank = q.dom + n; q.block_sq = (double*)(w + pl.off_sq);
     q.ptr_h = (int*)(w + pl.off_ptr_h); q.col_h = (unsigned short*)(w + pl.off_col_h);
     q.val_h = (float*)(w + pl.off_val_h); q.csr_cap = pl.csr_cap;
+    q.cnt = (unsigned short*)(w + pl.off_cnt); q.blk_dense = (unsigned char*)(w + pl.off_blk);
     q.n = n; q.words = pl.words; q.n_seed = pl.n_seed; q.k1 = pl.k1; q.k2 = pl.k2; q.n_part = pl.n_part;
     q.col_chunk = pl.col_chunk; q.num_iterations = p->num_iterations;
     q.d = p->d_thre; q.inlier_thr = p->inlier_threshold; q.nms_radius = p->nms_radius;
     // the reference refines with 0.10 m for its 3DMatch setting and 1.2 m otherwise (SC2_PCR.py:254-257)
     q.refine_thr = p->inlier_threshold == 0.10f ? 0.10f : 1.2f;
+    q.list_cap = ctx->sc2_list_cap; q.dense_x = ctx->sc2_dense_x;
     if (c < n_pairs) {
       n_max = n > n_max ? n : n_max; part_max = pl.n_part > part_max ? pl.n_part : part_max;
       seed_max = pl.n_seed > seed_max ? pl.n_seed : seed_max; words_max = pl.words > words_max ? pl.words : words_max;
@@ -870,6 +1084,12 @@ static int sc2pcr_chunk(eyoc_ctx* ctx, const float* src_dev, const float* tgt_de
   if (dyn > 48 * 1024 && !ctx->sc2_attr_set) {   // beyond the default dynamic-LDS allowance (n > ~12000)
     EYOC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seed_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     ctx->sc2_attr_set = true;
+  }
+  hipLaunchKernelGGL(k_seed_blocks, dim3(cdiv(seed_max, 64), 1, Z), dim3(64), 0, st, B);
+  if (words_max <= 128) hipLaunchKernelGGL(k_seed_dense<32>, dim3(cdiv(seed_max, 64), DENSE_SPLITS, Z), dim3(256), 0, st, B);
+  else {      // pairs of a chunk may fall on either side of 128 words: each kernel takes the pairs of its size class
+    hipLaunchKernelGGL(k_seed_dense<32>, dim3(cdiv(seed_max, 64), DENSE_SPLITS, Z), dim3(256), 0, st, B);
+    hipLaunchKernelGGL(k_seed_dense<64>, dim3(cdiv(seed_max, 64), DENSE_SPLITS, Z), dim3(256), 0, st, B);
   }
   hipLaunchKernelGGL(k_seed_topk, dim3(seed_max, 1, Z), dim3(256), dyn, st, B);
   hipLaunchKernelGGL(k_seed_solve, dim3(cdiv(seed_max, 4), 1, Z), dim3(256), 0, st, B);

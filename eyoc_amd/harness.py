@@ -216,8 +216,8 @@ class RegistrationPipeline:
         return cm, ready
 
     def enqueue(self, batch: DeviceBatch, seed: int = 0, maps=None, slot: int = 0, tail_stream: bool = False) -> "PendingStep":
-        """``register`` for a caller that pipelines steps (RANSAC path): everything - the read-back of the ``[P, 84]`` result
-        records into pinned host memory and of the split16 guard's verdict on THIS forward included - is enqueued now; the host
+        """``register`` for a caller that pipelines steps: everything - the read-back of the ``[P, 84]`` result records (RANSAC path;
+        ``T f32 [P, 4, 4]`` on the SC2-PCR path) into pinned host memory and of the split16 guard's verdict on THIS forward included - is enqueued now; the host
         waits on ``PendingStep.wait()`` later.  A read-back issued after the next step was enqueued (``register(...,
         return_device=True)`` + ``.cpu()``) queues behind that whole step on the stream: the host then never runs ahead of the GPU,
         and the GPU idles while the host decodes results and launches the next step (measured: 2 ms of a 24 ms step).
@@ -227,7 +227,8 @@ class RegistrationPipeline:
         stream; row gather, feature NN, RANSAC and the read-back of the records go on a second stream of the pipeline that waits
         for the forward.  A caller that enqueues the next step right away gets that step's forward (matrix pipe, LDS) beside this
         step's matching / RANSAC (fp64 VALU, no LDS) - same kernels, same inputs, bit-identical records."""
-        if not tail_stream or not self.cfg.use_RANSAC:
+        self.slot = slot
+        if not tail_stream:
             res = self.register(batch, seed=seed, return_device=True, maps=maps)
             host, words = self._pinned_set(slot, res)
             host.copy_(res, non_blocking=True)
@@ -248,13 +249,22 @@ class RegistrationPipeline:
         self.featured.record(main)
         self._tail.wait_event(self.featured)
         with torch.cuda.stream(self._tail):
-            res = self._match_and_register(batch, F, seed)
+            res = self._match_and_register(batch, F, seed) if self.cfg.use_RANSAC else self._match_and_register_sc2(batch, F, seed)
             host, _ = self._pinned_set(slot, res)
             host.copy_(res, non_blocking=True)
             done = torch.cuda.Event()
             done.record(self._tail)
         # F was allocated on the caller's stream and is read on the tail stream: it stays referenced until wait()
         return PendingStep(host, words, done, res, keep=(F,))
+
+    def _pinned_stage(self, count):
+        """Pinned int64 staging for the index upload of the SC2-PCR path; one buffer per event slot (``self.slot``: a slot's previous
+        upload was consumed by the time its step's results were read)."""
+        st = self.__dict__.setdefault("_stage", {})
+        buf = st.get(self.slot)
+        if buf is None or buf.numel() < count:
+            buf = st[self.slot] = torch.empty(max(count, 1), dtype=torch.int64, pin_memory=True)
+        return buf
 
     def _pinned_words(self, slot):
         w = self.__dict__.setdefault("_pinned_w", {})
@@ -306,46 +316,91 @@ class RegistrationPipeline:
                 return res                # the caller reads back later - and calls model.check_range() then
             host = res.cpu()
             return self._checked(batch, seed, maps) or [reg.decode_ransac_result(host[p], n) for p in range(batch.P)]
+        T = self._match_and_register_sc2(batch, F, seed)
+        if return_device:
+            return T
+        Th = T.cpu().numpy().astype(np.float64)
+        return self._checked(batch, seed, maps) or [reg.RegistrationResult(Th[p], 0.0, 0.0) for p in range(batch.P)]
+
+    def _match_and_register_sc2(self, batch, F, seed):
+        """SC2-PCR path (scripts/test_kitti.py:179-181) on the CURRENT stream -> ``T f32 [P,4,4]`` on the device.
+        Matcher.estimator re-samples both clouds to num_node with replacement, matches them and registers the matched pairs.
+        Same draws (pair by pair from one seeded RandomState, source before target) and the same arithmetic as a per-pair loop
+        over ``matcher.estimator``, but no per-pair device work: ONE index upload, row gathers, one segmented nearest-neighbour
+        launch and one batched SC2-PCR call for all pairs.  The host draws overlap the forward, which is still running.
+
+        Round 5: the 8000 draws of a pair hold only ~4000 distinct rows of either cloud, and a duplicated target ties with itself
+        exactly - such rows (60 %) fell through the MFMA pre-filter into the exact pass (2.3 of the step's 18 ms on 16 pairs).  The
+        neighbour search now runs on the DISTINCT rows: distinct targets in the order of their first draw - the reference's
+        arg-min returns the first of equal distances, so the winner among duplicates is the first draw, and the lowest first draw
+        among tied distinct rows is the lowest index overall -, every draw of a source row takes the result of its row.
+        Identical indices (``tests/test_gpu_sc2pcr.py`` compares with the per-pair estimator), a quarter of the products."""
+        n = batch.n_points
         F0 = gather_rows(F, batch.sel0, batch.G0, batch.beta)
         F1 = gather_rows(F, batch.sel1, batch.G1, batch.beta)
-        # SC2-PCR path (scripts/test_kitti.py:179-181): Matcher.estimator re-samples both clouds to num_node with
-        # replacement, matches them and registers the matched pairs.  Same draws (pair by pair from one seeded
-        # RandomState, source before target) and the same arithmetic as a per-pair loop over ``matcher.estimator``,
-        # but no per-pair device work: ONE index upload, two row gathers, one segmented nearest-neighbour launch and
-        # one batched SC2-PCR call for all pairs.  The host draws overlap the forward, which is still running.
         rng = np.random.RandomState(seed)
         m = self.matcher
         P = batch.P
+        dev = F.device
         if m.num_node == 'all':
             nn_pts = n
-            gsi = gti = np.arange(P * n, dtype=np.int64)
+            src_k, tgt_k = batch.xyz0.reshape(-1, 3), batch.xyz1.reshape(-1, 3)
+            seg = np.arange(P + 1) * nn_pts
+            nn = knn1_segmented(F0, F1, seg, seg, "GemmL2", return_distance=False)      # match_pair's own formula
+            self._mark(2)
+            self.matched = torch.cuda.Event()
+            self.matched.record()
         else:
             nn_pts = int(m.num_node)
-            draws = np.empty((P, 2, nn_pts), np.int64)
+            # RandomState.choice(n, k) IS randint(0, n, k) on the same stream, and one call for all pairs draws what the per-pair
+            # calls of Matcher.match_pair draw one after the other (source before target; tests/test_gpu_sc2pcr.py compares)
+            draws = rng.randint(0, n, (P, 2, nn_pts)).astype(np.int64, copy=False)
+            us, ut, inv, first, seg_a, seg_b = [], [], [], [], [0], [0]
+            pos = np.arange(nn_pts, dtype=np.int64)
             for p in range(P):
-                draws[p, 0] = rng.choice(n, nn_pts)
-                draws[p, 1] = rng.choice(n, nn_pts)
+                d0, d1 = draws[p, 0], draws[p, 1]
+                present = np.zeros(n, bool)
+                present[d0] = True
+                u0 = np.flatnonzero(present)                                   # distinct source rows
+                i0 = (np.cumsum(present) - 1)[d0]                               # draw -> its distinct row
+                fst = np.full(n, nn_pts, np.int64)
+                np.minimum.at(fst, d1, pos)                                     # first draw of every target row
+                f1 = np.flatnonzero(fst[d1] == pos)                             # the first draws, ascending: distinct targets in that order
+                u1 = d1[f1]
+                us.append(u0 + p * n); inv.append(i0 + seg_a[-1])
+                ut.append(u1 + p * n); first.append(f1 + p * nn_pts)
+                seg_a.append(seg_a[-1] + len(u0)); seg_b.append(seg_b[-1] + len(u1))
             draws += (np.arange(P, dtype=np.int64) * n)[:, None, None]
             gsi, gti = draws[:, 0].reshape(-1), draws[:, 1].reshape(-1)
-        idx = torch.from_numpy(np.stack([gsi, gti])).to(F.device, non_blocking=True)
-        src_d, tgt_d = gather_rows(F0, idx[0]), gather_rows(F1, idx[1])
-        src_k = batch.xyz0.reshape(-1, 3).index_select(0, idx[0])
-        tgt_k = batch.xyz1.reshape(-1, 3).index_select(0, idx[1])
-        seg = np.arange(P + 1) * nn_pts
-        nn = knn1_segmented(src_d, tgt_d, seg, seg, "GemmL2", return_distance=False)      # match_pair's own formula
-        self._mark(2)
-        base = torch.arange(P, device=F.device).repeat_interleave(nn_pts) * nn_pts     # local -> packed target row
+            base_u = np.repeat(np.asarray(seg_b[:-1], np.int64), np.diff(seg_a))     # distinct source row -> first distinct target of its pair
+            parts = [gsi, gti, np.concatenate(inv), np.concatenate(us), np.concatenate(ut), np.concatenate(first), base_u]
+            cuts = np.cumsum([0] + [len(a) for a in parts])
+            # ONE upload, from pinned memory: a copy from pageable memory blocks the host until everything enqueued on this stream
+            # before it is done - with two steps in flight that is the previous step's whole SC2-PCR (the steps then run one after
+            # the other however they were enqueued)
+            stage = self._pinned_stage(int(cuts[-1]))
+            np.concatenate(parts, out=stage.numpy()[:cuts[-1]])
+            packed = stage[:cuts[-1]].to(dev, non_blocking=True)
+            gsi_d, gti_d, inv_d, us_d, ut_d, first_d, base_d = (packed[cuts[k]:cuts[k + 1]] for k in range(7))
+            src_k = batch.xyz0.reshape(-1, 3).index_select(0, gsi_d)
+            tgt_k = batch.xyz1.reshape(-1, 3).index_select(0, gti_d)
+            nn_u = knn1_segmented(gather_rows(F0, us_d), gather_rows(F1, ut_d), seg_a, seg_b, "GemmL2", return_distance=False)
+            self._mark(2)
+            self.matched = torch.cuda.Event()
+            self.matched.record()
+            # distinct source row -> first draw (packed row of tgt_k) of its nearest distinct target; then every draw of that row
+            nn = first_d.index_select(0, nn_u + base_d).index_select(0, inv_d)
         keep = min(nn_pts, int(m.max_points))                                            # SC2_PCR.py:318-319 truncation
-        tgt_m = tgt_k.index_select(0, nn + base)
+        if m.num_node == 'all':
+            base = torch.arange(P, device=dev).repeat_interleave(nn_pts) * nn_pts       # local -> packed target row
+            nn = nn + base
+        tgt_m = tgt_k.index_select(0, nn)
         if keep < nn_pts:
             src_k = src_k.reshape(P, nn_pts, 3)[:, :keep].reshape(-1, 3)
             tgt_m = tgt_m.reshape(P, nn_pts, 3)[:, :keep].reshape(-1, 3)
         T, _, _ = m.SC2_PCR_packed(src_k.contiguous(), tgt_m.contiguous(), np.arange(P + 1) * keep)
         self._mark(3)
-        if return_device:
-            return T
-        Th = T.cpu().numpy().astype(np.float64)
-        return self._checked(batch, seed, maps) or [reg.RegistrationResult(Th[p], 0.0, 0.0) for p in range(P)]
+        return T
 
     def correspondence_inlier_ratio(self, batch: DeviceBatch, nn_idx=None, thresh=None):
         """Diagnostic (outside the timed path): per pair, the fraction of the feature correspondences of the last

@@ -540,6 +540,13 @@ size_t eyoc_sc2pcr_batched_workspace_bytes_n(int max_n, int n_pairs, const eyoc_
 int eyoc_sc2pcr_batched(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int32_t* seg_host,
                         int n_pairs, const eyoc_sc2pcr_params* params, float* T_dev, float* fitness_dev,
                         int fitness_stride, void* workspace_dev, size_t workspace_bytes, void* stream);
+/* Diagnostics of the per-seed stage (second-order counts + top-k1, sc2pcr.hip), per ctx; neither changes any result - tests run
+ * both sides of each and compare bit for bit.  Both return the previous value.
+ * _set_shortlist_cap: the top-k1 short list holds at most `cap` <= 1024 entries (default 1024; 0 = every seed takes the histogram
+ * selection); _set_dense_threshold: a block of 64 consecutive seeds counts as dense - lane = seed kernel, rows in registers - when
+ * its hard rows hold >= x * n candidates together (default 2; negative = that kernel off). */
+int eyoc_sc2pcr_set_shortlist_cap(eyoc_ctx* ctx, int cap);
+int eyoc_sc2pcr_set_dense_threshold(eyoc_ctx* ctx, int x);
 
 #ifdef __cplusplus
 }

@@ -109,6 +109,43 @@ def test_sc2pcr_batched_equals_per_pair():
     assert tb < tl * 1.1
 
 
+def test_seed_stage_paths_agree_bit_for_bit():
+    """The per-seed stage has two ways to get a seed's second-order counts (one wave per candidate; dense blocks of 64 seeds with
+    the rows in registers) and two ways to pick the top-k1 (short list; histogram): every combination must give the same poses and
+    the same seed-wise fitness, bit for bit - on noisy pairs at three inlier ratios, on a pair whose inliers are EXACT (thousands
+    of equal counts: the short list overflows by itself) and on ragged sizes.  Ref: SC2_PCR.py:61-108 (cal_seed_trans)."""
+    import eyoc_amd
+    from eyoc_amd import _lib as L
+    m = eyoc_amd.Matcher(inlier_threshold=0.6, d_thre=0.1, ratio=0.2, nms_radius=0.6, max_points=8000, k1=30, k2=20, num_iterations=20)
+    T = gi.rigid(0.02, -0.01, 0.1, 4.0, 0.3, -0.2)
+    cases = [(700, 3000, 0.1, 0.03), (701, 5000, 0.3, 0.03), (702, 8000, 0.6, 0.05), (703, 4000, 0.6, 0.0), (704, 2500, 1.0, 0.0),
+             (705, 777, 0.4, 0.02)]
+    src, tgt = [], []
+    for seed, n, frac, noise in cases:
+        p0, p1, _ = gi.corr_case(seed, n, T, frac, noise=noise)
+        src.append(torch.from_numpy(p0).cuda()); tgt.append(torch.from_numpy(p1).cuda())
+    lib, ctx = L.load(), L.ctx(0)
+    out = {}
+    try:
+        for cap in (1024, 0, 40):
+            for x in (2, 0, 6, -1):
+                lib.eyoc_sc2pcr_set_shortlist_cap(ctx, cap)
+                lib.eyoc_sc2pcr_set_dense_threshold(ctx, x)
+                out[cap, x] = [(Tb.cpu().numpy(), fb.cpu().numpy()) for Tb, fb in m.SC2_PCR_batch(src, tgt)]
+    finally:
+        lib.eyoc_sc2pcr_set_shortlist_cap(ctx, 1024)
+        lib.eyoc_sc2pcr_set_dense_threshold(ctx, 2)
+    ref = out[0, -1]                        # histogram selection, no dense blocks: the round-4 algorithm
+    for b, (seed, n, frac, noise) in enumerate(cases):
+        assert np.isfinite(ref[b][0]).all()
+        if frac >= 0.3:
+            np.testing.assert_allclose(ref[b][0], T, atol=0.05)
+    for key, res in out.items():
+        for b in range(len(cases)):
+            np.testing.assert_array_equal(res[b][0], ref[b][0], err_msg=f"pose, case {b}, (cap, x) = {key}")
+            np.testing.assert_array_equal(res[b][1], ref[b][1], err_msg=f"fitness, case {b}, (cap, x) = {key}")
+
+
 def test_harness_sc2pcr_path_equals_per_pair_estimator():
     """RegistrationPipeline with use_RANSAC=False (scripts/test_kitti.py:179-181) batches the matching and the
     SC2-PCR of all pairs; the poses are bit-identical to looping ``Matcher.estimator`` with the same draws."""
