@@ -26,8 +26,15 @@ K, NC, NTW = 27, 4, 2
 LO_REGION = 640 * 64      # the LDS stage: 640 rows x 64 B of hi halves, then the same of lo halves (spconv_st.hip)
 
 
-def gen(NH, WD, LD=2, skip=True, abl=(), K=K, koff=False, tag=""):
-    """``K``: offsets the blob walks (27 = a stride-1 table).  ``koff``: the weight fragments of offset i start at
+def gen(NH, WD, LD=2, skip=True, abl=(), K=K, koff=False, tag="", lazy=False):
+    """``lazy`` (round 5): the operand reads of a half-step are issued only for its NON-EMPTY blocks.  The eager schedule reads
+    every block's two operand pieces whether or not the block is multiplied - a third of the LDS traffic of a loop whose LDS
+    array is as busy as its matrix pipe.  A skipped read makes the number of reads in flight data-dependent, so the exact
+    in-order ``lgkmcnt`` counts of the eager schedule are gone: a half-step waits for ALL reads (its own: issued one half-step
+    earlier), then issues the next half-step's reads in one burst, then multiplies.  Measured level with the eager schedule on all
+    five layer shapes (0.392 vs 0.395, 0.146 vs 0.144, 0.181 vs 0.177, 0.239 vs 0.236, 0.316 vs 0.315 ms; bit-identical outputs):
+    a third fewer LDS reads buy nothing - diagnostics builds only (variant 3 of -DEYOC_ST_ABLATIONS).
+    ``K``: offsets the blob walks (27 = a stride-1 table).  ``koff``: the weight fragments of offset i start at
     ws0 + s[52 + i] instead of ws0 + i * ks - the class-major transposed kernel (spconv_upc.hip) walks the 1, 2, 4 or 8
     offsets of ONE parity class, which are not equidistant in the packed weights (K <= 8 then)."""
     assert not koff or K <= 8
@@ -165,6 +172,27 @@ def gen(NH, WD, LD=2, skip=True, abl=(), K=K, koff=False, tag=""):
                 wait_vm(("W", k))
             if has_next:
                 wait_vm(("L", kn))
+            if lazy:
+                emit("s_waitcnt lgkmcnt(0)")
+                if has_next:
+                    for c in range(NC):
+                        t0 = T[(c & 1) * 2]
+                        lab = f"{tag}r{kn}h{hn}c{c}"
+                        emit(f"s_bitcmp1_b32 s{36 + (kn >> 1)}, {(kn & 1) * 16 + hn * 4 + c}")
+                        emit(f"s_cbranch_scc0 .Lst%=_{lab}")
+                        addr(kn, hn, c, t0, None)
+                        read(hs + 1, c, 0, t0)
+                        read(hs + 1, c, 1, t0)
+                        emit(f".Lst%=_{lab}:")
+                for c in range(NC):
+                    lab = f"{tag}k{k}h{h}c{c}"
+                    emit(f"s_bitcmp1_b32 s{36 + (k >> 1)}, {(k & 1) * 16 + h * 4 + c}")
+                    emit(f"s_cbranch_scc0 .Lst%=_{lab}")
+                    for term in range(3):
+                        mfma(h, c, 0, term, k, hs)
+                        mfma(h, c, 1, term, k, hs)
+                    emit(f".Lst%=_{lab}:")
+                continue
             for c in range(NC):
                 t0, t1 = T[(c & 1) * 2], T[(c & 1) * 2 + 1]
                 if has_next:
@@ -305,14 +333,14 @@ def gen_w8(D=2, WD=1, LD=2, skip=True, lo_region=LO_REGION, lrows=64):
 WD2, LD2 = 1, 2            # NH = 2 (measured: weights two offsets ahead and rulebook entries three, lane constants in v[56:61], gain nothing)
 
 
-def gen_upc(abl=()):
+def gen_upc(abl=(), lazy=False):
     upc = []
     for kc in (8, 4, 2):
         upc += [f"s_cmp_eq_u32 %[nk], {kc}", f"s_cbranch_scc1 .Lst%=_upc{kc}"]
     for kc in (1, 2, 4, 8):
         if kc > 1:
             upc.append(f".Lst%=_upc{kc}:")
-        upc += gen(2, WD2, LD2, True, abl, K=kc, koff=True, tag=f"u{kc}")
+        upc += gen(2, WD2, LD2, True, abl, K=kc, koff=True, tag=f"u{kc}", lazy=lazy)
         if kc < 8:
             upc.append("s_branch .Lst%=_upcend")
     upc.append(".Lst%=_upcend:")
@@ -361,6 +389,7 @@ def main(path):
         write_blob(f, "UPC_NOW", gen_upc(("now",)))
         write_blob(f, "UPC_EMPTY", gen_upc(("nom", "now", "nol", "nox", "nov")))
         write_blob(f, "NH2_W2L3", gen(2, 2, 3))       # weights two offsets ahead, rulebook entries three: no gain
+        write_blob(f, "NH2_LAZY", gen(2, WD2, LD2, lazy=True))   # operand reads only for non-empty blocks (round 5): level on every layer
         write_blob(f, "W8", gen_w8())                 # 8 waves of 64 rows x 32 channels in 128 VGPRs (four per SIMD): no gain
         f.write("#define EYOC_ST_LOOP_CLOBBERS_LOW EYOC_ST_LOOP_CLOBBERS, " + ", ".join(f'"v{i}"' for i in range(56, 62)) + "\n")
         f.write("#define EYOC_ST_LOOP_CLOBBERS_W8 " + ", ".join(f'"v{i}"' for i in range(28, 96)) + "\n")

@@ -595,7 +595,8 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
 #endif
       if constexpr (NH == 2 && (SKIP == 1 || SKIP == 6 || SKIP == 7 || SKIP == 15)) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2);
       else if constexpr (NH == 2 && SKIP == 0) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOSKIP);
-#ifdef EYOC_ST_ABLATIONS       // timing-only builds of the loop (results are garbage): no weight loads / no operand reads / no address VALU
+#ifdef EYOC_ST_ABLATIONS       // timing-only
+      else if constexpr (NH == 2 && SKIP == 2) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_LAZY);   // (not timing-only: operand reads for non-empty blocks only - bit-identical, level) builds of the loop (results are garbage): no weight loads / no operand reads / no address VALU
       else if constexpr (NH == 2 && SKIP == 3) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOW);
       else if constexpr (NH == 2 && SKIP == 4) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOX);
       else if constexpr (NH == 2 && SKIP == 5) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOV);
@@ -747,8 +748,8 @@ int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char
 }
 
 // which staged kernel runs: 0 = the C++ offset loop (spconv_st_kernel), 1 = the assembly loop (default), 2 = the assembly loop
-// without the empty-block branches (diagnostics); -DEYOC_ST_ABLATIONS builds add 3 = 8 waves of 64 rows x 32 channels (four per
-// SIMD, 128 VGPRs) and 13 ... = timing-only ablations
+// without the empty-block branches (diagnostics); -DEYOC_ST_ABLATIONS builds add 3 = operand reads only for non-empty blocks
+// (round 5: level), 4 = 8 waves of 64 rows x 32 channels (four per SIMD, 128 VGPRs) and 13 ... = timing-only ablations
 static std::atomic<int> g_st_variant{1};
 #ifdef EYOC_ST_ABLATIONS
 constexpr int ST_VARIANTS = 28;
@@ -794,7 +795,8 @@ int launch_spconv_st(const SpconvArgs& a_in, const unsigned char* local_dev, hip
     if (ctg == 64) {
       if (variant == 2) { if (wide) EYOC_STA(64, 2, 0); else EYOC_STA(32, 2, 0); }
 #ifdef EYOC_ST_ABLATIONS
-      else if (variant == 3) {                                         // 8 waves of 64 rows x 32 channels, four per SIMD
+      else if (variant == 3) { if (wide) EYOC_STA(64, 2, 2); else EYOC_STA(32, 2, 2); }
+      else if (variant == 4) {                                         // 8 waves of 64 rows x 32 channels, four per SIMD
         if (wide) hipLaunchKernelGGL((spconv_st_asm_kernel<64, 1, 1, 2 * NW>), grid, dim3(2 * NW * 64), 0, st, a, local_dev, n_tiles);
         else hipLaunchKernelGGL((spconv_st_asm_kernel<32, 1, 1, 2 * NW>), grid, dim3(2 * NW * 64), 0, st, a, local_dev, n_tiles);
       }
