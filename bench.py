@@ -107,6 +107,7 @@ def parse_args(argv=None):
     ap.add_argument("--down-staged", type=int, default=-1, help="diagnostics: eyoc_spconv_select_down_kernel (0 / 1)")
     ap.add_argument("--up-kernel", type=int, default=-1, help="diagnostics: eyoc_spconv_select_up_kernel (0 gathering, 1 Morton tiles, 2 class-major tiles)")
     ap.add_argument("--st-group", type=int, default=-1, help="diagnostics: eyoc_spconv_st_group_rows (0 / 1): row grouping inside the staged kernel's tiles")
+    ap.add_argument("--conv1-kernel", type=int, default=-1, help="diagnostics: eyoc_spconv_select_conv1_kernel (1 staged block vectors, 0 probing, 2 fp32 walker)")
     ap.add_argument("--sc2-dense-x", type=int, default=None, help="diagnostics: eyoc_sc2pcr_set_dense_threshold (default 6; -1 = dense-block kernel off)")
     ap.add_argument("--sc2-list-cap", type=int, default=None, help="diagnostics: eyoc_sc2pcr_set_shortlist_cap (default 1024; 0 = histogram selection)")
     ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
@@ -369,6 +370,9 @@ def worker(args):
         if args.st_group >= 0:
             from eyoc_amd import _lib as _l
             _l.load().eyoc_spconv_st_group_rows(args.st_group)
+        if args.conv1_kernel >= 0:
+            from eyoc_amd import _lib as _l
+            _l.load().eyoc_spconv_select_conv1_kernel(args.conv1_kernel)
         if args.sc2_dense_x is not None:
             from eyoc_amd import _lib as _l
             _l.load().eyoc_sc2pcr_set_dense_threshold(_l.ctx(device.index), args.sc2_dense_x)

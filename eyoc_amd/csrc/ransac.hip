@@ -179,27 +179,21 @@ __global__ __launch_bounds__(GEN_THREADS) void k_generate(PairArgs a) {
     rec = lrec;
   }
   const unsigned long long base = pair_base(a.seed, b);
-  int* cnt = a.n_surv + c * CNT_STRIDE;
-  int* surv = a.surv + (size_t)c * a.H;
+  int* ncand = a.n_surv + c * CNT_STRIDE + 2;              // the pair's candidate counter ([0] survivors, [1] largest count)
+  int* cand = a.cnts + (size_t)c * a.H;                    // candidates wait in the pair's count array (k_count writes it after k_fit)
   const int lane = threadIdx.x & 63;
   int* wq = queue[threadIdx.x >> 6];
   int queued = 0;   // wave-uniform
-  const double edge_sim = (double)a.edge_sim, max_dist = (double)a.max_dist;
-  auto fit = [&](int h) {   // h < 0: idle lane
-    double s[4][3], q[4][3], R[3][3], t[3];
-    if (h < 0) return;
-    sample_and_check_edges(rec, (unsigned)n, base, (unsigned)h, edge_sim, s, q);   // re-draws the sample (cheaper than queueing 24 doubles)
-    if (!fit_and_check_distance(s, q, max_dist, R, t)) return;
-    const int slot = atomicAdd(cnt, 1);
-    surv[slot] = h;
-    if (slot < a.cap_t) {
-      double* x = a.xf + ((size_t)c * a.cap_t + slot) * 12;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        x[3 * i] = R[i][0]; x[3 * i + 1] = R[i][1]; x[3 * i + 2] = R[i][2];
-        x[9 + i] = t[i];
-      }
-    }
+  const double edge_sim = (double)a.edge_sim;
+  // Round 5: the hypotheses that pass all six edge checks (~1 %) are handed to k_fit - 64 at a time, one atomic per wave and
+  // one coalesced store - instead of being fitted here: the 4-point Kabsch (a Jacobi eigen-solver in fp64) needs more registers
+  // than the 128 a 1024-thread workgroup leaves a lane (400 bytes of scratch per lane, also paid by the sampling loop around it)
+  auto flush = [&](int h) {   // h < 0: idle lane
+    const unsigned long long m = __ballot(h >= 0);
+    int pos = 0;
+    if (lane == 0) pos = atomicAdd(ncand, __popcll(m));
+    pos = __shfl(pos, 0, 64);
+    if (h >= 0) cand[pos + __popcll(m & ((1ull << lane) - 1ull))] = h;
   };
   // Two queues per wave: every hypothesis takes the FIRST edge check only (one hash, two records: most fail it); the ones that
   // pass are queued and take the full six-edge check 64 at a time; the ones that pass that are queued for the fit.
@@ -232,11 +226,42 @@ __global__ __launch_bounds__(GEN_THREADS) void k_generate(PairArgs a) {
       queued += __popcll(m);
       if (queued >= 64) {
         queued -= 64;
-        fit(wq[queued + lane]);
+        flush(wq[queued + lane]);
       }
     }
   }
-  fit(lane < queued ? wq[lane] : -1);
+  flush(lane < queued ? wq[lane] : -1);
+}
+
+// 4-point fit + distance checker of the queued candidates: one lane per candidate, 256-thread workgroups (the whole register
+// file: no scratch), records from global memory (a pair's 120 KB stay in L2).  Survivors append their hypothesis number and
+// transform exactly as the fused kernel did; which slot a survivor gets depends on atomics, the results do not.
+__global__ __launch_bounds__(256) void k_fit(PairArgs a) {
+  const int c = blockIdx.y;
+  const float* __restrict__ rec = a.rec + (size_t)a.s0[c] * 6;
+  const int n = a.n[c];
+  const unsigned long long base = pair_base(a.seed, a.pair0 + c);
+  int* cnt = a.n_surv + c * CNT_STRIDE;
+  const int ncand = cnt[2];
+  const int* __restrict__ cand = a.cnts + (size_t)c * a.H;
+  int* surv = a.surv + (size_t)c * a.H;
+  const double edge_sim = (double)a.edge_sim, max_dist = (double)a.max_dist;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < ncand; i += gridDim.x * 256) {
+    const int h = cand[i];
+    double s[4][3], q[4][3], R[3][3], t[3];
+    sample_and_check_edges(rec, (unsigned)n, base, (unsigned)h, edge_sim, s, q);   // re-draws the sample (cheaper than queueing 24 doubles)
+    if (!fit_and_check_distance(s, q, max_dist, R, t)) continue;
+    const int slot = atomicAdd(cnt, 1);
+    surv[slot] = h;
+    if (slot < a.cap_t) {
+      double* x = a.xf + ((size_t)c * a.cap_t + slot) * 12;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        x[3 * k] = R[k][0]; x[3 * k + 1] = R[k][1]; x[3 * k + 2] = R[k][2];
+        x[9 + k] = t[k];
+      }
+    }
+  }
 }
 
 // squared form of Open3D's `dist < max_correspondence_distance` (no fp64 square root per residual)
@@ -606,6 +631,7 @@ int ransac_run(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const 
     const int gen_blocks = GEN_BLOCKS_TOTAL / nc > GEN_BLOCKS_MIN ? GEN_BLOCKS_TOTAL / nc : GEN_BLOCKS_MIN;
     if (in_lds) hipLaunchKernelGGL(k_generate<true>, dim3(gen_blocks, nc), dim3(GEN_THREADS), lds_bytes, st, a);
     else hipLaunchKernelGGL(k_generate<false>, dim3(gen_blocks, nc), dim3(GEN_THREADS), 0, st, a);
+    hipLaunchKernelGGL(k_fit, dim3(2048 / nc > 8 ? 2048 / nc : 8, nc), dim3(256), 0, st, a);
     if (pruned) hipLaunchKernelGGL(k_bucket, dim3(nc), dim3(256), 0, st, a);
     constexpr int KC_BLOCKS = 4096;   // workgroups of the count over the pairs of a launch (2048: 1.6 rounds of the 1280 the chip holds - measured 3.5 vs 3.3 ms)
     hipLaunchKernelGGL(k_count, dim3(KC_BLOCKS / nc, nc), dim3(256), 0, st, a, (const double*)a.xf, pruned);

@@ -161,7 +161,7 @@ size_t local_rulebook64_bytes(int n_out);     // 64-row tiles: the strided table
 int build_local_rulebook64(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st);
 int launch_spconv_st128(const SpconvArgs& a, const unsigned char* local_dev, int tile, int skip_empty_blocks, hipStream_t st);
 // group: 1 = the rows of a tile sorted by neighbour pattern (fewer non-empty MFMA blocks), 0 = in their own order (what
-// conv1_st_kernel needs: it finds a parent's entries by its local row), -1 = the process-wide setting of select_st_group_rows
+// conv1_bf_kernel needs: it finds a parent's entries by its local row), -1 = the process-wide setting of select_st_group_rows
 int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st, int group = -1);
 int select_st_group_rows(int on);
 int launch_spconv_rs(const SpconvArgs& a, hipStream_t st);     // row-stationary, SPLIT16 only (spconv_rs.hip)
@@ -202,10 +202,10 @@ struct Conv1Args {
   const int32_t* s1c;       // [27][nc]
   int nc;
   // tile-local rulebooks of the level-1 stride-1 table (build_local_rulebook; Z-ordered maps) or NULL: with them the first
-  // convolution stages the child features of a 256-parent tile's neighbourhood in LDS once (conv1_st_kernel)
+  // convolution stages the child features of a 256-parent tile's neighbourhood in LDS once (conv1_bf_kernel)
   const unsigned char* local1 = nullptr;
 };
-// layout of a local rulebook record (spconv_st.hip owns it; conv1_st_kernel in spconv.hip reads the row list and the entries)
+// layout of a local rulebook record (spconv_st.hip owns it; conv1_bf_kernel in spconv.hip reads the row list and the entries)
 constexpr int ST_TILE = 256, ST_UMAX = 639, ST_UCAP = 1280, ST_NPASS = 2, ST_LOC_OFF = 16 + ST_UCAP * 4, ST_INV_OFF = 33152, ST_LR_BYTES = 33408;
 int launch_conv1(const Conv1Args& a, hipStream_t st);
 bool conv1_walks_octree(const Conv1Args& a);   // false: launch_conv1 will probe a.table (it must be built)

@@ -728,7 +728,7 @@ bool spconv_up_enabled() { return g_up_kernel == 1; }
 bool spconv_upc_enabled() { return g_up_kernel == 2; }
 int g_upc_min_rows = 1 << 17;            // eyoc_spconv_upc_min_rows
 int spconv_upc_min_rows() { return g_upc_min_rows; }
-int g_conv1_staged = 1;   // eyoc_spconv_select_conv1_kernel: 1 the first convolution of Z-ordered split16 forwards on conv1_st_kernel, 0 on conv1_mfma_kernel, 2 on the exact-fp32 octree walker
+int g_conv1_staged = 1;   // eyoc_spconv_select_conv1_kernel: 1 the first convolution of Z-ordered split16 forwards on conv1_bf_kernel (block feature vectors of a staged level-1 tile), 0 on conv1_mfma_kernel, 2 on the exact-fp32 octree walker
 int g_down_staged = 0;   // strided convolutions on Z-ordered maps through the staged kernel (eyoc_spconv_select_down_kernel): off - their tiles overflow 2 passes
 bool spconv_down_staged() { return g_down_staged != 0; }
 
@@ -820,54 +820,79 @@ int launch_permute_rows(const float* in, const int32_t* perm, int n, int c, floa
   return EYOC_OK;
 }
 
-// ---- first convolution with a tile-local stage (round 3; Z-ordered maps, C_in = 1, 32 output channels, split16 downstream).
-// conv1_mfma_kernel above probes, for EVERY fine row, the 27 coarse blocks around its parent and their 8 children each: ~60
-// dependent loads per lane and 16-row tile although the ~2.4 children of a parent share all of them and neighbouring parents most.
-// Here a workgroup takes one 256-row tile of LEVEL 1 (the parents) and its local rulebook (the one the staged convolution of level
-// 1 uses: the distinct level-1 rows U its 27-neighbourhoods touch, and per (offset, parent) the slot of the neighbour):
-//   1. for every slot of U: the block's 8 child links and their input features -> cf[slot][8] in LDS (0 for a missing child):
-//      ~6 loads per fine row instead of ~216;
-//   2. the tile's fine rows are a contiguous row range (Z-order: children of consecutive parents are consecutive); a wave takes 16 of
-//      them; lane (g, j) walks a quarter of the 27 offsets of row j's parent: slot from the rulebook entry (one 2-byte load), the 8
-//      child features from LDS, the window position of (offset, child) for the row's parity class from a table, and writes the
-//      hi / lo halves into the row's line of the [16 x 128] operand tile;
-//   3. the same 24 MFMAs ([16 x 128] x [128 x 32], split16) and epilogue as conv1_mfma_kernel.
-__global__ __launch_bounds__(256, 2) void conv1_st_kernel(Conv1Args a) {
-  constexpr int COUT = 32, KP = 128, KPS = KP + 8, NT = COUT / 16, NQ = KP / 32;
-  constexpr int NSLOT = ST_NPASS * ST_UMAX + 1;                                        // + one block without children: "no neighbour"
-  constexpr int ZSLOT = NSLOT - 1;
-  __shared__ __attribute__((aligned(16))) _Float16 cfh[NSLOT][8], cfl[NSLOT][8];     // hi / lo halves of the 8 child features of a staged block
-  __shared__ unsigned char cval[NSLOT];                                              // which children carry a non-zero feature
-  __shared__ __attribute__((aligned(16))) _Float16 xt[4][2][16][KPS];                // [wave][hi / lo][row][window position], padded rows
-  __shared__ __attribute__((aligned(8))) signed char ktab[8][216];                   // window position of (block kc, child cs) for parity class cls
-  __shared__ unsigned char wmask[8][28];                                             // children of block kc inside the window, per class
-  __shared__ unsigned char inv[ST_TILE];                                             // tile slot of local parent row (the records group a tile's rows by neighbour pattern)
+// ---- first convolution as a K = 27 sparse convolution over level-1 BLOCK FEATURE VECTORS (round 5; Z-ordered maps, C_in = 1,
+// 32 output channels, split16 downstream).  conv1_mfma_kernel above probes, for EVERY fine row, the 27 coarse blocks around its
+// parent and their 8 children each (~60 dependent loads per lane and 16-row tile) although the ~2.4 children of a parent share
+// all of them and neighbouring parents most.  Round 3's conv1_st_kernel staged the child features of a 256-parent level-1 tile's
+// neighbourhood in LDS once (the tile record the staged stride-1 kernel of level 1 uses) but still assembled, per fine row, a
+// [128]-entry line of window positions in LDS (zero the tile, then one conditional 2-byte write per child in the window) before
+// it could multiply: 0.8 ms per 128 clouds for 0.5 GB of compulsory traffic, bound by that assembly and its dependent loads.
+// Here nothing is assembled (0.49 ms; the old kernel is gone).  The 8 child features of a level-1 block - one 16-byte
+// line of fp16 hi halves, one of lo halves - ARE an MFMA operand piece: for the fine row in column j, k-slot group g of k-step t
+// is the block vector of neighbour block 4 t + g of the row's parent, read straight from the staged vectors (the slot comes
+// from the level-1 tile record, as in the staged stride-1 kernel).  The weights are what depends on the row: which of the 216
+// (block, child) pairs lies where in the row's 5^3 window is a function of the row's PARITY CLASS (its child slot in its
+// parent), so the tile's fine rows are grouped by class - the class is the child slot, the rows of class q are `children[p][q]`
+// of the tile's 256 parents: eight ballot compactions, no sort - and a wave multiplies all 16-row chunks of one class against
+// that class's [216 x 32] weight matrix, gathered once per (tile, class) from an LDS copy of the [125 x 32] kernel into 112
+// registers.  42 MFMAs per 16 rows instead of 24 (the matrix pipe idles in this layer either way), no operand tile, no
+// per-row dependent global loads: the tile's rulebook entries are staged in LDS with the block vectors.
+// Same products as conv1_mfma_kernel, summed in another order (blocks, not window positions): equal to fp32 rounding
+// (tests/test_gpu_split16.py).  Timing-only ablations (make ../lib/libeyoc_hip_c1abl<N>.so): the class-weight gathers 0.07 ms, the
+// LDS copy of the kernel 0.04 ms of the 0.49; the rest is the tile's dependent stage rounds and its stores.
+#ifndef CONV1_BF_ABL
+#define CONV1_BF_ABL 0
+#endif
+__global__ __launch_bounds__(256, 2) void conv1_bf_kernel(Conv1Args a) {
+  constexpr int COUT = 32, NT = COUT / 16, NS7 = 7;
+  constexpr int NSLOT = ST_NPASS * ST_UMAX + 1, ZSLOT = NSLOT - 1;
+  __shared__ __attribute__((aligned(16))) _Float16 cfh[NSLOT][8], cfl[NSLOT][8];     // block vectors of the staged level-1 rows
+  __shared__ __attribute__((aligned(16))) _Float16 w5h[128][COUT], w5l[128][COUT];   // the kernel, scaled and split; row 127 = zeros
+  __shared__ __attribute__((aligned(16))) unsigned short ent[27 * 64 * 4];           // pass-0 rulebook entries of the tile
+  __shared__ unsigned short lrow[8][ST_TILE];                                        // fine rows of class q (minus the tile's first fine row)
+  __shared__ unsigned char lpar[8][ST_TILE];                                         // ... and their parents (local index)
+  __shared__ signed char ktab[8][216];
+  __shared__ unsigned char inv[ST_TILE];
+  __shared__ int ccnt[8][4], ctot[8];
+  __shared__ int f0s;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int K = a.ks * a.ks * a.ks, r = a.ks / 2;
   const int tile = blockIdx.x;
-  inv[threadIdx.x] = (a.local1 + (size_t)tile * ST_LR_BYTES)[ST_INV_OFF + threadIdx.x];
-  for (int e = threadIdx.x; e < 8 * 27; e += 256) {
-    const int cls = e / 27, kc = e % 27;
-    unsigned int m = 0;
-    for (int cs = 0; cs < 8; ++cs) {
-      const int dx = 2 * (kc % 3 - 1) + (cs & 1) - (cls & 1), dy = 2 * ((kc / 3) % 3 - 1) + ((cs >> 1) & 1) - ((cls >> 1) & 1),
-                dz = 2 * (kc / 9 - 1) + (cs >> 2) - (cls >> 2);
-      const bool in = dx >= -r && dx <= r && dy >= -r && dy <= r && dz >= -r && dz <= r;
-      ktab[cls][kc * 8 + cs] = (signed char)(in ? (dx + r) + a.ks * (dy + r) + a.ks * a.ks * (dz + r) : -1);
-      m |= (in ? 1u : 0u) << cs;
-    }
-    wmask[cls][kc] = (unsigned char)m;
-  }
-  // ---- 1. stage: child features of the tile's distinct level-1 rows, already split into fp16 hi / lo halves
   const unsigned char* lr = a.local1 + (size_t)tile * ST_LR_BYTES;
+  inv[threadIdx.x] = lr[ST_INV_OFF + threadIdx.x];
+  for (int e = threadIdx.x; e < 8 * 216; e += 256) {
+    const int cls = e / 216, kc = (e % 216) / 8, cs = e % 8;
+    const int dx = 2 * (kc % 3 - 1) + (cs & 1) - (cls & 1), dy = 2 * ((kc / 3) % 3 - 1) + ((cs >> 1) & 1) - ((cls >> 1) & 1),
+              dz = 2 * (kc / 9 - 1) + (cs >> 2) - (cls >> 2);
+    const bool in = dx >= -r && dx <= r && dy >= -r && dy <= r && dz >= -r && dz <= r;
+    ktab[cls][kc * 8 + cs] = (signed char)(in ? (dx + r) + a.ks * (dy + r) + a.ks * a.ks * (dz + r) : 127);
+  }
+  {   // the kernel: W * 2^sh split into fp16 halves (2^sh lifts the layer's largest weight into [256, 512))
+    const float wsc = a.wscale ? a.wscale[0] : 256.0f;
+    for (int e = threadIdx.x; e < 128 * COUT; e += 256) {
+      const int k = e / COUT;
+#if CONV1_BF_ABL == 1
+      const float w = 1.0f * wsc;
+#else
+      const float w = k < K ? a.w[e] * wsc : 0.0f;
+#endif
+      const _Float16 h = (_Float16)w;
+      (&w5h[0][0])[e] = h;
+      (&w5l[0][0])[e] = (_Float16)(w - (float)h);
+    }
+  }
+  {   // the tile's pass-0 entries: 13.5 KB, 16 bytes per load
+    const uint4* src = reinterpret_cast<const uint4*>(lr + ST_LOC_OFF);
+    uint4* dst = reinterpret_cast<uint4*>(ent);
+    for (int e = threadIdx.x; e < 27 * 64 * 4 * 2 / 16; e += 256) dst[e] = src[e];
+  }
+  // ---- stage: block vectors of the tile's distinct level-1 rows (three rounds of independent loads: row numbers, child links, child features)
   const int n_u = *reinterpret_cast<const int*>(lr);
   const int* __restrict__ U = reinterpret_cast<const int*>(lr + 16);
   const float* __restrict__ fin = a.in;
   {
-    // three rounds of independent loads (row numbers, child links, child features): a dependent chain per slot would cost
-    // three memory round trips for each of a thread's (up to 5) slots in turn
-    constexpr int NS = (NSLOT + 255) / 256;                                            // 5
+    constexpr int NS = (NSLOT + 255) / 256;
     int u[NS];
     int4 c0[NS], c1[NS];
 #pragma unroll
@@ -895,162 +920,137 @@ __global__ __launch_bounds__(256, 2) void conv1_st_kernel(Conv1Args a) {
       const int s = (int)threadIdx.x + 256 * i;
       if (s < n_u || s == ZSLOT) {
         half8_t h8, l8;
-        unsigned int m = 0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const float x = s < n_u ? f[i][q] : 0.f;
           h8[q] = (_Float16)x;
           l8[q] = (_Float16)(x - (float)h8[q]);
-          m |= (x != 0.f ? 1u : 0u) << q;
         }
         *reinterpret_cast<half8_t*>(&cfh[s][0]) = h8;
         *reinterpret_cast<half8_t*>(&cfl[s][0]) = l8;
-        cval[s] = (unsigned char)m;
       }
     }
   }
-  // the tile's fine rows: from the first child of its first parent to the first child of the next tile's first parent
-  auto first_child = [&](int prow) {
-    if (prow >= a.nc) return a.n;
-    const int4 c0 = reinterpret_cast<const int4*>(a.children)[2 * (size_t)prow], c1 = reinterpret_cast<const int4*>(a.children)[2 * (size_t)prow + 1];
-    const int v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-    int m = a.n;
-    for (int i = 0; i < 8; ++i) if (v[i] >= 0 && v[i] < m) m = v[i];
-    return m;
-  };
-  const int f0 = first_child(tile * ST_TILE), f1 = first_child((tile + 1) * ST_TILE);
-  // weight fragments (A operand): lane (g, j): W[k = 32 q + 8 g + i][cout = 16 t + j] * 2^sh, split (2^sh lifts the layer's
-  // largest weight into [256, 512): the lo halves stay normal and no hi half leaves the fp16 range; 2^8 without a.wscale)
-  const float wsc = a.wscale ? a.wscale[0] : 256.0f, iwsc = a.wscale ? a.wscale[1] : 1.0f / 256.0f;
-  half8_t wh[NQ][NT], wl[NQ][NT];
+  // ---- the tile's fine rows by class: thread p holds parent p's child links
+  {
+    const int prow = tile * ST_TILE + (int)threadIdx.x;
+    int v[8];
+    if (prow < a.nc) {
+      const int4 c0 = reinterpret_cast<const int4*>(a.children)[2 * (size_t)prow], c1 = reinterpret_cast<const int4*>(a.children)[2 * (size_t)prow + 1];
+      v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+    } else {
 #pragma unroll
-  for (int q = 0; q < NQ; ++q)
+      for (int q = 0; q < 8; ++q) v[q] = -1;
+    }
+    if (threadIdx.x == 0) {                              // the tile's first fine row: the first child of its first parent (Z-order)
+      int m = a.n;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+      for (int q = 0; q < 8; ++q) if (v[q] >= 0 && v[q] < m) m = v[q];
+      f0s = m;
+    }
+    unsigned long long bm[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int k = 32 * q + 8 * g + i;
-        const float w = k < K ? a.w[(size_t)k * COUT + 16 * t + j] * wsc : 0.0f;
-        const _Float16 h = (_Float16)w;
-        wh[q][t][i] = h;
-        wl[q][t][i] = (_Float16)(w - (float)h);
+    for (int q = 0; q < 8; ++q) {
+      bm[q] = __ballot(v[q] >= 0);
+      if (lane == 0) ccnt[q][wave] = __popcll(bm[q]);
+    }
+    __syncthreads();
+    const int f0 = f0s;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      int base = 0;
+      for (int w = 0; w < wave; ++w) base += ccnt[q][w];
+      if (v[q] >= 0) {
+        const int pos = base + __popcll(bm[q] & ((1ull << lane) - 1ull));
+        lrow[q][pos] = (unsigned short)(v[q] - f0);
+        lpar[q][pos] = (unsigned char)threadIdx.x;
       }
+      if (threadIdx.x == 0) ctot[q] = ccnt[q][0] + ccnt[q][1] + ccnt[q][2] + ccnt[q][3];
+    }
+  }
   __syncthreads();
-  _Float16 (*xh)[KPS] = xt[wave][0];
-  _Float16 (*xl)[KPS] = xt[wave][1];
+  const int f0 = f0s;
   const int n_pass = n_u > ST_UMAX ? 2 : 1;
   const unsigned short* __restrict__ loc = reinterpret_cast<const unsigned short*>(lr + ST_LOC_OFF);
+  const float iwsc = a.wscale ? a.wscale[1] : 1.0f / 256.0f;
+  float4 bias4[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bias4[t] = *reinterpret_cast<const float4*>(a.bias + 16 * t + 4 * g);
   float mx = 0.f;
-  // ---- 2. + 3. 16 fine rows per wave and step; lane (g, j) walks offsets g, g + 4, ... of row j's parent.  Two dependent global
-  // round trips stand before a step's LDS work (row -> parent, parent -> rulebook entries) and 8 waves per CU hide nothing: they
-  // are software-pipelined - coordinates / parent two steps ahead, entries one step ahead, all loads unconditional (clamped
-  // rows; a load inside a branch is waited for on the spot)
-  auto load_row = [&](int base, int& cls, int& pl) {
-    int o = base + j;
-    o = o < a.n ? o : a.n - 1;
-    const int4 c = reinterpret_cast<const int4*>(a.coords)[o];
-    pl = a.parent[o] - tile * ST_TILE;
-    pl = pl < 0 ? 0 : pl > ST_TILE - 1 ? ST_TILE - 1 : pl;                              // rows of other tiles (past f1): any valid entry
-    cls = (c.y & 1) | ((c.z & 1) << 1) | ((c.w & 1) << 2);
-  };
-  auto place = [&](int pl, int& ew, int& ec) {                                         // the parent's slot -> its place in an entry: (16 w + j, c)
-    const int sl = inv[pl];
-    ew = (sl >> 6) * 16 + (sl & 15);
-    ec = (sl >> 4) & 3;
-  };
-  auto load_entries = [&](int ew, int ec, int (&e)[7]) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  for (int qi = 0; qi < 2; ++qi) {
+    const int q = wave + 4 * qi;                         // this wave's class
+    const int nq = ctot[q];
+    if (nq == 0) continue;                               // wave-uniform
+    // the class's weights: lane (g, j) of k-step t holds W[window position of (block 4 t + g, child i)][channel 16 tt + j], i = 0..7
+    half8_t wh[NS7][NT], wl[NS7][NT];
 #pragma unroll
-    for (int t = 0; t < 7; ++t) {
-      const int kc = g + 4 * t < 27 ? g + 4 * t : 26;
-      e[t] = loc[((size_t)kc * 64 + ew) * 4 + ec];
+    for (int t = 0; t < NS7; ++t) {
+      const int kc = 4 * t + g;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#if CONV1_BF_ABL == 2
+        const int kp = (kc + i) & 127;
+#elif CONV1_BF_ABL == 3
+        const int kp = i;
+#else
+        const int kp = kc < 27 ? (int)ktab[q][kc * 8 + i] : 127;
+#endif
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          wh[t][tt][i] = w5h[kp][16 * tt + j];
+          wl[t][tt][i] = w5l[kp][16 * tt + j];
+        }
+      }
     }
-  };
-  const int base_first = f0 + 16 * wave;
-  int clsB, plB, ewB, ecB, clsA, plA, eB[7];
-  load_row(base_first, clsB, plB);
-  load_row(base_first + 64, clsA, plA);
-  place(plB, ewB, ecB);
-  load_entries(ewB, ecB, eB);
-  for (int base = base_first; base < f1; base += 64) {
-    const int o = base + j;
-    // this step's data (loaded a step ago), then the requests of the next two steps
-    const int cls = clsB, ew = ewB, ec = ecB;
-    int ecur[7];
+#if CONV1_BF_ABL == 4
+    for (int c0 = 0; c0 < min(nq, 16); c0 += 16) {
+#else
+    for (int c0 = 0; c0 < nq; c0 += 16) {
+#endif
+      const int idx = c0 + j;
+      const bool ok = idx < nq;
+      const int pl = lpar[q][ok ? idx : 0];
+      const int o = f0 + (int)lrow[q][ok ? idx : 0];
+      const int sl = inv[pl];
+      const int ew = (sl >> 6) * 16 + (sl & 15), ec = (sl >> 4) & 3;
+      f32x4 acc[NT];
 #pragma unroll
-    for (int t = 0; t < 7; ++t) ecur[t] = eB[t];
-    clsB = clsA;
-    place(plA, ewB, ecB);
-    load_entries(ewB, ecB, eB);
-    load_row(base + 128, clsA, plA);
-    {
-      float4* z = reinterpret_cast<float4*>(&xt[wave][0][0][0]);
+      for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < (2 * 16 * KPS * 2 / 16 + 63) / 64; ++q)
-        if (q * 64 + lane < 2 * 16 * KPS * 2 / 16) z[q * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (o < f1) {
-      int slot[7];
-#pragma unroll
-      for (int t = 0; t < 7; ++t) {
-        const int kc = g + 4 * t;
-        int sl = ZSLOT;
+      for (int t = 0; t < NS7; ++t) {
+        const int kc = 4 * t + g;
+        int slot = ZSLOT;
         if (kc < 27) {
-          const int e0 = ecur[t] >> 6;                                                   // entry = 64 l + swizzle
-          if (e0 != ST_UMAX) sl = e0;
+          const int e0 = ent[(kc * 64 + ew) * 4 + ec] >> 6;                            // entry = 64 l + swizzle
+          if (e0 != ST_UMAX) slot = e0;
           else if (n_pass > 1) {                                                        // rare: the neighbour sits in the second pass
             const int e1 = loc[((size_t)(27 + kc) * 64 + ew) * 4 + ec] >> 6;
-            if (e1 != ST_UMAX) sl = ST_UMAX + e1;
+            if (e1 != ST_UMAX) slot = ST_UMAX + e1;
           }
         }
-        slot[t] = sl;
-      }
-      // only the children that exist, carry a feature and fall inside the window are visited (~1 of 8 per block)
+        const half8_t vh = *reinterpret_cast<const half8_t*>(&cfh[slot][0]);
+        const half8_t vl = *reinterpret_cast<const half8_t*>(&cfl[slot][0]);
 #pragma unroll
-      for (int t = 0; t < 7; ++t) {
-        const int kc = g + 4 * t;
-        unsigned int m = kc < 27 ? (unsigned)cval[slot[t]] & (unsigned)wmask[cls][kc] : 0u;
-        while (m) {
-          const int cs = __builtin_ctz(m);
-          m &= m - 1;
-          const int kpos = ktab[cls][kc * 8 + cs];
-          xh[j][kpos] = cfh[slot[t]][cs];
-          xl[j][kpos] = cfl[slot[t]][cs];
+        for (int tt = 0; tt < NT; ++tt) {
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t][tt], vh, acc[tt], 0, 0, 0);
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t][tt], vl, acc[tt], 0, 0, 0);
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t][tt], vh, acc[tt], 0, 0, 0);
+        }
+      }
+      if (ok) {
+        float* dst = a.out + (size_t)o * a.ld_out;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int ch0 = 16 * t + 4 * g;
+          const float4 v = make_float4(acc[t][0] * iwsc + bias4[t].x, acc[t][1] * iwsc + bias4[t].y,
+                                       acc[t][2] * iwsc + bias4[t].z, acc[t][3] * iwsc + bias4[t].w);
+          split16_track(mx, v);
+          if (a.out_split) split16_store4(dst, ch0, v);
+          else *reinterpret_cast<float4*>(dst + ch0) = v;
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    f32x4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const half8_t vh = *reinterpret_cast<const half8_t*>(&xh[j][32 * q + 8 * g]);
-      const half8_t vl = *reinterpret_cast<const half8_t*>(&xl[j][32 * q + 8 * g]);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q][t], vh, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[q][t], vl, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[q][t], vh, acc[t], 0, 0, 0);
-      }
-    }
-    if (o < f1) {
-      float* dst = a.out + (size_t)o * a.ld_out;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int ch0 = 16 * t + 4 * g;
-        const float4 b = *reinterpret_cast<const float4*>(a.bias + ch0);
-        const float4 v = make_float4(acc[t][0] * iwsc + b.x, acc[t][1] * iwsc + b.y,
-                                     acc[t][2] * iwsc + b.z, acc[t][3] * iwsc + b.w);
-        split16_track(mx, v);
-        if (a.out_split) split16_store4(dst, ch0, v);
-        else *reinterpret_cast<float4*>(dst + ch0) = v;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
   }
   if (a.out_split) split16_report(a.range, mx);
 }
@@ -1066,8 +1066,8 @@ int launch_conv1(const Conv1Args& a, hipStream_t st) {
     // C_in = 1, 32 output channels, split16 activations downstream (the large-batch path): the MFMA formulation.  Its
     // products carry 22-bit significands like every split16 layer; fp32 consumers keep the exact-fp32 walker
     if (g_conv1_staged != 2 && a.cin == 1 && a.cout == 32 && a.out_split && a.ks * a.ks * a.ks < 128 && !a.in_perm) {
-      if (a.local1 && g_conv1_staged == 1) {                               // Z-ordered maps: child features staged per 256-parent tile
-        hipLaunchKernelGGL(conv1_st_kernel, dim3(cdiv(a.nc, ST_TILE)), dim3(256), 0, st, a);
+      if (a.local1 && g_conv1_staged == 1) {                               // Z-ordered maps: block vectors staged per 256-parent tile
+        hipLaunchKernelGGL(conv1_bf_kernel, dim3(cdiv(a.nc, ST_TILE)), dim3(256), 0, st, a);
         EYOC_CHECK_HIP(hipGetLastError());
         return EYOC_OK;
       }

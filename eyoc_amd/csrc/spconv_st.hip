@@ -63,7 +63,7 @@ __host__ __device__ constexpr int slot_addr(int l) { return l * 64 + ((l >> 2) &
 constexpr int MASK_OFF = 16 + UCAP * 4 + NPASS * 27 * 64 * 8;   // 32784
 constexpr int MASK_PASS_BYTES = 56;
 constexpr int RM_OFF = MASK_OFF + NPASS * MASK_PASS_BYTES;      // 32896
-constexpr int INV_OFF = RM_OFF + TILE;                          // 33152: the inverse map, inv[local row] = slot (conv1_st_kernel finds a parent's entries with it)
+constexpr int INV_OFF = RM_OFF + TILE;                          // 33152: the inverse map, inv[local row] = slot (conv1_bf_kernel finds a parent's entries with it)
 constexpr int LR_BYTES = INV_OFF + TILE;                        // 33408
 static_assert(INV_OFF == ST_INV_OFF, "spconv.h mirrors this layout");
 static_assert(TILE == ST_TILE && UMAX == ST_UMAX && UCAP == ST_UCAP && NPASS == ST_NPASS && LR_BYTES == ST_LR_BYTES, "spconv.h mirrors this layout");

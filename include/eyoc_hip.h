@@ -198,8 +198,9 @@ int eyoc_spconv_upc(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* ws_dev, i
  * -16 % on those layers; the coarsest stays on the gathering kernel), 0 off (default: at the step level the records cost what the
  * layers save); other values only query.  Returns the previous state.  Process-wide, read when maps are built. */
 int eyoc_spconv_select_down_kernel(int on);
-/* First convolution (C_in = 1, 32 output channels) of split16 forwards on Z-ordered maps: 1 (default) = conv1_st_kernel - the child
- * features of a 256-parent tile's neighbourhood staged in LDS through the level-1 tile rulebook; 0 = conv1_mfma_kernel, which probes
+/* First convolution (C_in = 1, 32 output channels) of split16 forwards on Z-ordered maps: 1 (default) = conv1_bf_kernel - the block
+ * feature vectors (8 child features per level-1 row) of a 256-parent tile's neighbourhood staged in LDS through the level-1 tile
+ * rulebook, the tile's fine rows grouped by parity class, a K = 27 product over blocks; 0 = conv1_mfma_kernel, which probes
  * the octree per fine row; 2 = the exact-fp32 octree walker (conv1_tree_kernel) even in front of split16 consumers.  Other values only query.  Returns the previous state; process-wide, for tests and profiling. */
 int eyoc_spconv_select_conv1_kernel(int on);
 /* Stride-1 (3^3) split16 layers with a tile-local input stage (spconv_st.hip): per 256-row tile the distinct input rows are

@@ -619,9 +619,9 @@ def test_forward_on_small_tiles_matches_the_default_and_the_oracle():
 
 @pytest.mark.parametrize("ks", [5, 3])
 def test_staged_first_convolution_matches_the_probing_kernel_and_the_oracle(ks):
-    """conv1_st_kernel (Z-ordered maps: child features of a 256-parent tile's neighbourhood staged in LDS) against
-    conv1_mfma_kernel (octree probing per fine row) - same products in the same order per window position, so the features
-    agree to fp32 rounding - and against the oracle; two clouds in a batch, non-unit features with planted zeros, both
+    """conv1_bf_kernel (Z-ordered maps: the block feature vectors of a 256-parent tile's neighbourhood staged in LDS, the fine rows
+    grouped by parity class, a K = 27 product over level-1 blocks) against conv1_mfma_kernel (octree probing per fine row, products
+    per window position) - the same products in another order, so the features agree to fp32 rounding - and against the oracle; two clouds in a batch, non-unit features with planted zeros, both
     window sizes; the strided convolutions through the staged kernel ride along (eyoc_spconv_select_down_kernel)."""
     import eyoc_amd
     from eyoc_amd import synthetic as syn
