@@ -133,6 +133,10 @@ __device__ __forceinline__ void d_masks(const float* __restrict__ src, const flo
   const long long n_tiles = (long long)words * words;
   if (tile >= n_tiles) return;   // wave-uniform; no barrier below
   const int ti = (int)(tile / words), w = (int)(tile % words);
+  // Round 5: the cross length is symmetric, so only the tiles on and above the diagonal are computed (each cross length costs ~28
+  // VALU issue slots, two square roots among them); the wave of tile (ti, w) also writes tile (w, ti) - the 64 x 64 bit transpose
+  // of what its lanes hold, six exchange steps per matrix
+  if (ti > w) return;
   const int j = w * 64 + lane, i_mine = ti * 64 + lane;
   float* R = rows[wave];
   {
@@ -154,6 +158,29 @@ __device__ __forceinline__ void d_masks(const float* __restrict__ src, const flo
   if (lane < rows_here) {
     hard[(size_t)i_mine * words + w] = my_h;
     tight[(size_t)i_mine * words + w] = my_t;
+  }
+  if (ti == w) return;
+  // transpose: lane l holds row l (bit c = column c); afterwards lane c holds column c (bit l = row l).  Step s exchanges, between
+  // lanes l and l ^ s, the off-diagonal s x s blocks of every 2s x 2s block
+  auto step = [&](unsigned long long x, int sft, unsigned long long lo_mask) {
+    const unsigned int ylo = (unsigned int)__shfl_xor((int)(unsigned int)x, sft, 64);
+    const unsigned int yhi = (unsigned int)__shfl_xor((int)(unsigned int)(x >> 32), sft, 64);
+    const unsigned long long y = ((unsigned long long)yhi << 32) | ylo;
+    // a lane with bit `sft` clear keeps its low-position blocks and takes the partner's low-position blocks into its high positions
+    return (lane & sft) ? ((x & ~lo_mask) | ((y & ~lo_mask) >> sft)) : ((x & lo_mask) | ((y & lo_mask) << sft));
+  };
+  auto transpose64 = [&](unsigned long long x) {
+    x = step(x, 32, 0x00000000FFFFFFFFull);
+    x = step(x, 16, 0x0000FFFF0000FFFFull);
+    x = step(x, 8, 0x00FF00FF00FF00FFull);
+    x = step(x, 4, 0x0F0F0F0F0F0F0F0Full);
+    x = step(x, 2, 0x3333333333333333ull);
+    return step(x, 1, 0x5555555555555555ull);
+  };
+  const unsigned long long th = transpose64(my_h), tt = transpose64(my_t);
+  if (j < n) {                                   // row j = w * 64 + lane of the mirrored tile; its columns ti * 64 ..
+    hard[(size_t)j * words + ti] = th;
+    tight[(size_t)j * words + ti] = tt;
   }
 }
 
