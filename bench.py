@@ -104,7 +104,6 @@ def parse_args(argv=None):
     ap.add_argument("--main-priority", action="store_true", help="diagnostics: the step's own stream gets high priority (measured: +0.5 %% with --maps-after start)")
     ap.add_argument("--st-variant", type=int, default=-1,
                     help="diagnostics: staged-kernel implementation (eyoc_spconv_select_st_kernel: 0 C++ loop, 1 assembly loop, 2 assembly without empty-block branches)")
-    ap.add_argument("--down-staged", type=int, default=-1, help="diagnostics: eyoc_spconv_select_down_kernel (0 / 1)")
     ap.add_argument("--up-kernel", type=int, default=-1, help="diagnostics: eyoc_spconv_select_up_kernel (0 gathering, 1 Morton tiles, 2 class-major tiles)")
     ap.add_argument("--st-group", type=int, default=-1, help="diagnostics: eyoc_spconv_st_group_rows (0 / 1): row grouping inside the staged kernel's tiles")
     ap.add_argument("--conv1-kernel", type=int, default=-1, help="diagnostics: eyoc_spconv_select_conv1_kernel (1 staged block vectors, 0 probing, 2 fp32 walker)")
@@ -364,9 +363,6 @@ def worker(args):
         if args.up_kernel >= 0:
             from eyoc_amd import _lib as _l
             _l.load().eyoc_spconv_select_up_kernel(args.up_kernel)
-        if args.down_staged >= 0:
-            from eyoc_amd import _lib as _l
-            _l.load().eyoc_spconv_select_down_kernel(args.down_staged)
         if args.st_group >= 0:
             from eyoc_amd import _lib as _l
             _l.load().eyoc_spconv_st_group_rows(args.st_group)

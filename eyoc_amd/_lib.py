@@ -94,11 +94,7 @@ PROTOTYPES = {
     "eyoc_spconv_select_split16_kernel": (_i, [_i]),
     "eyoc_spconv_select_st_kernel": (_i, [_i]),
     "eyoc_spconv_st_split_below": (_i, [_i]),
-    "eyoc_spconv_st_tile": (_i, [_i]),
     "eyoc_spconv_st_group_rows": (_i, [_i]),
-    "eyoc_spconv_local_rulebook_bytes_tile": (_sz, [_i, _i]),
-    "eyoc_spconv_build_local_rulebook_tile": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
-    "eyoc_spconv_staged_tile": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "eyoc_spconv_local_rulebook_bytes": (_sz, [_i]),
     "eyoc_spconv_build_local_rulebook": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "eyoc_spconv_staged": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
@@ -126,6 +122,7 @@ PROTOTYPES = {
     "eyoc_model_timing_slot": (_i, [_vp, _i]),
     "eyoc_bn_workspace_bytes": (_sz, [_i, _i]),
     "eyoc_bn_train_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, C.c_float, _i, _vp, _i, _vp, _vp, _sz, _vp]),
+    "eyoc_bn_train_forward_running": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, C.c_float, _i, _vp, _i, _vp, _vp, _vp, C.c_float, _vp, _sz, _vp]),
     "eyoc_bn_train_backward": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, C.c_float, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "eyoc_maps_gather_window": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "eyoc_knn_prefilter": (_i, [_i]),
@@ -135,7 +132,6 @@ PROTOTYPES = {
     "eyoc_spconv_upc_bytes": (_sz, [_i]),
     "eyoc_spconv_upc_build": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "eyoc_spconv_upc": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp]),
-    "eyoc_spconv_select_down_kernel": (_i, [_i]),
     "eyoc_spconv_select_conv1_kernel": (_i, [_i]),
     "eyoc_knn1": (_i, [_vp, _vp, _vp, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i, _i, _vp, _vp, _vp]),
     "eyoc_pdist": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),

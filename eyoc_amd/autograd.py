@@ -29,15 +29,21 @@ def _pack_perm(K, cin, cout, transposed, mirror, device) -> torch.Tensor:
     if key not in _PERM_CACHE:
         lib = _lib.load()
         n = K * cin * cout
-        assert n < (1 << 24)                               # the sequence must be exact in fp32
-        w = np.arange(1, n + 1, dtype=np.float32)
-        packed = np.zeros(n, np.float32)
-        if transposed:
-            rc = lib.eyoc_spconv_pack_weights_transposed(w.ctypes.data, K, cin, cout, 1 if mirror else 0, packed.ctypes.data)
-        else:
-            rc = lib.eyoc_spconv_pack_weights(w.ctypes.data, None, K, cin, cout, packed.ctypes.data)
-        _lib.check(rc, "eyoc_spconv_pack_weights")
-        _PERM_CACHE[key] = torch.from_numpy(packed.astype(np.int64)).to(device)    # 0 = padding slot, i + 1 = element i
+
+        def run(w):
+            packed = np.zeros(n, np.float32)
+            if transposed:
+                rc = lib.eyoc_spconv_pack_weights_transposed(w.ctypes.data, K, cin, cout, 1 if mirror else 0, packed.ctypes.data)
+            else:
+                rc = lib.eyoc_spconv_pack_weights(w.ctypes.data, None, K, cin, cout, packed.ctypes.data)
+            _lib.check(rc, "eyoc_spconv_pack_weights")
+            return packed.astype(np.int64)
+
+        # fp32 holds integers exactly up to 2^24: the element number travels as two sequences (i // 4096 + 1, 0 = padding; i % 4096)
+        idx = np.arange(n, dtype=np.int64)
+        hi, lo = run((idx // 4096 + 1).astype(np.float32)), run((idx % 4096).astype(np.float32))
+        packed = np.where(hi > 0, (hi - 1) * 4096 + lo + 1, 0)
+        _PERM_CACHE[key] = torch.from_numpy(packed).to(device)    # 0 = padding slot, i + 1 = element i
     return _PERM_CACHE[key]
 
 

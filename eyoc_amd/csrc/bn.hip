@@ -51,21 +51,46 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
 }
 
 // MODE 0: out[ch] = mean, out[c + ch] = biased variance.  MODE 1: out[ch] = sum a (dbeta), out[c + ch] = sum b (dgamma).
+// One workgroup per TWO channels: thread t adds the partial sums of column (t & 3) = (channel, a / b) over the blocks t >> 2,
+// t >> 2 + 64, ... in ascending order, then the 64 per-thread sums meet in a fixed tree - bit-reproducible whatever the timing.
+// (Round 5: one thread per channel walked all <= 1024 partial blocks alone, 49 us of dependent loads per call and 42 calls per
+// training iteration - 2 of its 12 ms.)
+// MODE 0 with `running` != NULL also moves the running statistics like nn.BatchNorm1d: running = (1 - m) running + m batch, the
+// variance unbiased (n / (n - 1)) - one launch instead of five element-wise ones per norm.
 template <int MODE>
-__global__ void k_bn_final(const double* __restrict__ partial, int blocks, int n, int c, float* __restrict__ out0, float* __restrict__ out1) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
-  double a = 0.0, b = 0.0;
-  for (int k = 0; k < blocks; ++k) { a += partial[(size_t)k * 2 * c + ch]; b += partial[(size_t)k * 2 * c + c + ch]; }
-  if (MODE == 0) {
-    const double m = a / n;
-    double v = b / n - m * m;
-    if (v < 0.0) v = 0.0;
-    out0[ch] = (float)m;
-    out1[ch] = (float)v;
-  } else {
-    out0[ch] = (float)a;
-    out1[ch] = (float)b;
+__global__ __launch_bounds__(256) void k_bn_final(const double* __restrict__ partial, int blocks, int n, int c, float* __restrict__ out0,
+                                                  float* __restrict__ out1, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                  float momentum) {
+  __shared__ double red[256];
+  const int col = threadIdx.x & 3, sub = threadIdx.x >> 2;
+  const int ch = blockIdx.x * 2 + (col >> 1), ab = col & 1;
+  double s = 0.0;
+  if (ch < c)
+    for (int k = sub; k < blocks; k += 64) s += partial[(size_t)k * 2 * c + ab * c + ch];
+  red[threadIdx.x] = s;
+  __syncthreads();
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) {
+    if (sub < w) red[threadIdx.x] += red[threadIdx.x + 4 * w];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4 && ab == 0 && ch < c) {            // threads 0 and 2: one per channel
+    const double a = red[threadIdx.x], b = red[threadIdx.x + 1];
+    if (MODE == 0) {
+      const double m = a / n;
+      double v = b / n - m * m;
+      if (v < 0.0) v = 0.0;
+      out0[ch] = (float)m;
+      out1[ch] = (float)v;
+      if (run_mean) {
+        const float mf = (float)m, vf = (float)v * ((float)n / (float)(n > 1 ? n - 1 : 1));
+        run_mean[ch] = run_mean[ch] * (1.0f - momentum) + momentum * mf;
+        run_var[ch] = run_var[ch] * (1.0f - momentum) + momentum * vf;
+      }
+    } else {
+      out0[ch] = (float)a;
+      out1[ch] = (float)b;
+    }
   }
 }
 
@@ -128,8 +153,9 @@ extern "C" {
 
 size_t eyoc_bn_workspace_bytes(int n, int c) { return bn_shape_ok(n, c) ? align_up((size_t)bn_blocks(n) * 2 * c * sizeof(double)) : 0; }
 
-int eyoc_bn_train_forward(eyoc_ctx* ctx, const float* x_dev, int n, int c, int ld_x, const float* gamma_dev, const float* beta_dev, float eps,
-                          int relu, float* y_dev, int ld_y, float* mean_var_dev, void* ws_dev, size_t ws_bytes, void* stream) {
+static int bn_train_forward(eyoc_ctx* ctx, const float* x_dev, int n, int c, int ld_x, const float* gamma_dev, const float* beta_dev, float eps,
+                            int relu, float* y_dev, int ld_y, float* mean_var_dev, float* run_mean_dev, float* run_var_dev, float momentum,
+                            void* ws_dev, size_t ws_bytes, void* stream) {
   EYOC_REQUIRE(ctx && x_dev && gamma_dev && beta_dev && y_dev && mean_var_dev && ws_dev, EYOC_ERR_INVALID, "eyoc_bn_train_forward: NULL argument");
   EYOC_REQUIRE(bn_shape_ok(n, c) && ld_x % 4 == 0 && ld_y % 4 == 0 && ld_x >= c && ld_y >= c, EYOC_ERR_INVALID,
                "eyoc_bn_train_forward: n %d, c %d (a divisor of 256, >= 4), leading dimensions %d / %d (multiples of 4)", n, c, ld_x, ld_y);
@@ -139,11 +165,26 @@ int eyoc_bn_train_forward(eyoc_ctx* ctx, const float* x_dev, int n, int c, int l
   const int nb = bn_blocks(n);
   hipLaunchKernelGGL(k_bn_partial<0>, dim3(nb), dim3(256), 0, st, x_dev, ld_x, (const float*)nullptr, 0, (const float*)nullptr, 0, n, c,
                      (const float*)nullptr, eps, (double*)ws_dev);
-  hipLaunchKernelGGL(k_bn_final<0>, dim3(cdiv(c, 64)), dim3(64), 0, st, (const double*)ws_dev, nb, n, c, mean_var_dev, mean_var_dev + c);
+  hipLaunchKernelGGL(k_bn_final<0>, dim3(cdiv(c, 2)), dim3(256), 0, st, (const double*)ws_dev, nb, n, c, mean_var_dev, mean_var_dev + c,
+                     run_mean_dev, run_var_dev, momentum);
   hipLaunchKernelGGL(k_bn_apply, dim3(cdiv((long long)n * (c / 4), 256)), dim3(256), 0, st, x_dev, ld_x, n, c, mean_var_dev, gamma_dev, beta_dev, eps,
                      relu, y_dev, ld_y);
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
+}
+
+int eyoc_bn_train_forward(eyoc_ctx* ctx, const float* x_dev, int n, int c, int ld_x, const float* gamma_dev, const float* beta_dev, float eps,
+                          int relu, float* y_dev, int ld_y, float* mean_var_dev, void* ws_dev, size_t ws_bytes, void* stream) {
+  return bn_train_forward(ctx, x_dev, n, c, ld_x, gamma_dev, beta_dev, eps, relu, y_dev, ld_y, mean_var_dev, nullptr, nullptr, 0.0f, ws_dev, ws_bytes,
+                          stream);
+}
+
+int eyoc_bn_train_forward_running(eyoc_ctx* ctx, const float* x_dev, int n, int c, int ld_x, const float* gamma_dev, const float* beta_dev,
+                                  float eps, int relu, float* y_dev, int ld_y, float* mean_var_dev, float* running_mean_dev,
+                                  float* running_var_dev, float momentum, void* ws_dev, size_t ws_bytes, void* stream) {
+  EYOC_REQUIRE(running_mean_dev && running_var_dev, EYOC_ERR_INVALID, "eyoc_bn_train_forward_running: NULL running statistics");
+  return bn_train_forward(ctx, x_dev, n, c, ld_x, gamma_dev, beta_dev, eps, relu, y_dev, ld_y, mean_var_dev, running_mean_dev, running_var_dev,
+                          momentum, ws_dev, ws_bytes, stream);
 }
 
 int eyoc_bn_train_backward(eyoc_ctx* ctx, const float* x_dev, int ld_x, const float* y_dev, int ld_y, const float* dy_dev, int ld_dy, int n, int c,
@@ -158,7 +199,8 @@ int eyoc_bn_train_backward(eyoc_ctx* ctx, const float* x_dev, int ld_x, const fl
   hipStream_t st = (hipStream_t)stream;
   const int nb = bn_blocks(n);
   hipLaunchKernelGGL(k_bn_partial<1>, dim3(nb), dim3(256), 0, st, x_dev, ld_x, y_dev, ld_y, dy_dev, ld_dy, n, c, mean_var_dev, eps, (double*)ws_dev);
-  hipLaunchKernelGGL(k_bn_final<1>, dim3(cdiv(c, 64)), dim3(64), 0, st, (const double*)ws_dev, nb, n, c, dbeta_dev, dgamma_dev);
+  hipLaunchKernelGGL(k_bn_final<1>, dim3(cdiv(c, 2)), dim3(256), 0, st, (const double*)ws_dev, nb, n, c, dbeta_dev, dgamma_dev, (float*)nullptr,
+                     (float*)nullptr, 0.0f);
   hipLaunchKernelGGL(k_bn_backward_apply, dim3(cdiv((long long)n * c, 256)), dim3(256), 0, st, x_dev, ld_x, y_dev, ld_y, dy_dev, ld_dy, n, c,
                      mean_var_dev, gamma_dev, eps, dbeta_dev, dgamma_dev, dx_dev, ld_dx);
   EYOC_CHECK_HIP(hipGetLastError());

@@ -159,13 +159,8 @@ struct eyoc_maps {
   int32_t* row_perm = nullptr;
   // per-tile local rulebooks of the stride-1 tables (spconv_st.hip), built when the rows are in Z-order; NULL otherwise
   unsigned char* local_s1[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
-  int local_tile = 256;                    // rows per tile of the local_s1 records: 256 (spconv_st.hip) or 128 (spconv_st128.hip)
-  unsigned char* local1_256 = nullptr;     // 256-row records of the level-1 stride-1 table for the staged first convolution when local_s1 holds 128-row ones
   unsigned char* local_up[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};   // transposed tables (outputs at level l)
   unsigned char* local_upc[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};  // ... partitioned by parity class (spconv_upc.hip: header, tile order, records)
-  // strided tables (inputs at level l, outputs at level l + 1): 64-row-tile records (spconv_st128.hip) - a 64-row output tile's
-  // inputs are its rows' children plus a halo, 190-330 distinct fine rows; NULL when a tile overflows or the kernel is off
-  unsigned char* local_down[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
   bool table0_built = false;   // table[0] has its memory reserved but is only filled on demand (maps_build_table0)
 };
 

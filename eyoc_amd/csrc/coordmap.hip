@@ -570,11 +570,9 @@ size_t eyoc_maps_workspace_bytes(int n_rows) {
   b += 4 * align_up(4 * n * 4) + align_up(sort_rows_tmp_bytes(4 * n_rows, UP_KEY_BITS + 4));   // tiling orders: keys, rows, result (<= 2 segments per level, levels sum to < 2 n)
   b += align_up(n * 8) * 2 + align_up(n * 4) * 2 + align_up(sort_rows64_tmp_bytes(n_rows));   // Z-order: keys in / out, rows in, permutation
   // local rulebooks of the stride-1 tables (levels sum to < 2 n rows; every level rounds up to a whole tile)
-  b += 3 * align_up(local_rulebook_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_bytes(1)) + 256);   // stride-1 tables (+ level 1 in row order)
-  b += 2 * align_up(local_rulebook128_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook128_bytes(1)) + 256);   // 128-row tile records (+ level 1 twice)
+  b += 2 * align_up(local_rulebook_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_bytes(1)) + 256);   // stride-1 tables
   b += 2 * align_up(local_rulebook_up_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_up_bytes(1)) + 256);
   b += 2 * (align_up(upc_kept_bytes(n_rows)) + align_up(upc_scratch_bytes(n_rows))) + EYOC_MAX_LEVELS * (align_up(upc_kept_bytes(1)) + align_up(upc_scratch_bytes(1)) + 512);   // class-major transposed records + their builder's scratch
-  b += align_up(local_rulebook64_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook64_bytes(1)) + 256);   // strided tables (coarse levels sum to < n rows), 64-row tiles
   b += 4096;                                                         // counters
   return b + 96 * 256;
 }
@@ -835,20 +833,9 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
   // ---- local rulebooks of the stride-1 tables (tile-local input stage of the sparse convolution): only for Z-ordered rows
   if (zorder) {
     FAIL_HIP(hipMemsetAsync(counters + 8, 0, 8 * sizeof(int), st));    // [8] stride-1, [9] transposed, [10 + l] strided table l
-    m->local_tile = select_st_tile(-1);
     for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
-      if (m->local_tile == 128) {
-        m->local_s1[l] = cv.take<unsigned char>(local_rulebook128_bytes(m->rows[l]));
-        if (int rc = build_local_rulebook128(m->nbr_s1[l], 27, m->rows[l], m->local_s1[l], counters + 8, st)) { delete m; return rc; }
-        if (l == 1) {   // the staged first convolution reads 256-parent tiles of this table
-          m->local1_256 = cv.take<unsigned char>(local_rulebook_bytes(m->rows[l]));
-          if (int rc = build_local_rulebook(m->nbr_s1[l], 27, m->rows[l], m->local1_256, counters + 14, st, 0)) { delete m; return rc; }
-        }
-      } else {
-        m->local_s1[l] = cv.take<unsigned char>(local_rulebook_bytes(m->rows[l]));
-        if (int rc = build_local_rulebook(m->nbr_s1[l], 27, m->rows[l], m->local_s1[l], counters + 8, st)) { delete m; return rc; }
-        if (l == 1) m->local1_256 = m->local_s1[l];     // the staged first convolution finds a parent's slot through the record's inverse row map
-      }
+      m->local_s1[l] = cv.take<unsigned char>(local_rulebook_bytes(m->rows[l]));
+      if (int rc = build_local_rulebook(m->nbr_s1[l], 27, m->rows[l], m->local_s1[l], counters + 8, st)) { delete m; return rc; }
       if (l + 1 < EYOC_MAX_LEVELS && use_up) {   // the transposed table whose outputs are this level's rows
         m->local_up[l] = cv.take<unsigned char>(local_rulebook_up_bytes(m->rows[l]));
         if (int rc = build_local_rulebook_up(m->nbr_up[l], 27, m->rows[l], m->local_up[l], counters + 9, st)) { delete m; return rc; }
@@ -858,12 +845,6 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
         unsigned char* scratch = cv.take<unsigned char>(upc_scratch_bytes(m->rows[l]));
         if (m->local_upc[l])
           if (int rc = build_upc(m->nbr_up[l], m->coords[l], 1 << l, m->rows[l], m->local_upc[l], scratch, st)) { delete m; return rc; }
-      }
-      // the strided table level l -> l + 1: 64-row-tile records for the two fine ones (32 -> 64 and 64 -> 128 channels measured
-      // -25 % / -16 % on them; the coarsest, 128 -> 256 on few rows, is level with the gathering kernel and keeps it)
-      if (l + 1 < EYOC_MAX_LEVELS - 1 && m->nbr_down[l] && spconv_down_staged()) {
-        m->local_down[l] = cv.take<unsigned char>(local_rulebook64_bytes(m->rows[l + 1]));     // 64-row output tiles (spconv_st128.hip)
-        if (int rc = build_local_rulebook64(m->nbr_down[l], 27, m->rows[l + 1], m->local_down[l], counters + 10 + l, st)) { delete m; return rc; }
       }
     }
     for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
@@ -891,13 +872,10 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
       }
     if (host[0] != 0)   // a tile with more distinct input rows than two passes stage (does not happen for Z-ordered rows): no staged kernel
       for (int l = 0; l < EYOC_MAX_LEVELS; ++l) m->local_s1[l] = nullptr;
-    if (host[0] != 0 || host[6] != 0) m->local1_256 = nullptr;
     if (host[1] != 0)   // ... more than 639 distinct coarse rows under a 256-row tile
       for (int l = 0; l < EYOC_MAX_LEVELS; ++l) m->local_up[l] = nullptr;
     for (int l = 0; l < EYOC_MAX_LEVELS; ++l)   // a class tile with more than 1278 distinct coarse rows: that table stays on the gathering kernels
       if (host[16 + l] != 0) m->local_upc[l] = nullptr;
-    for (int l = 0; l + 1 < EYOC_MAX_LEVELS; ++l)
-      if (host[2 + l] != 0) m->local_down[l] = nullptr;
   }
   FAIL_HIP(hipGetLastError());
 #undef FAIL_HIP

@@ -217,119 +217,6 @@ def gen(NH, WD, LD=2, skip=True, abl=(), K=K, koff=False, tag="", lazy=False):
     return out
 
 
-def gen_w8(D=2, WD=1, LD=2, skip=True, lo_region=LO_REGION, lrows=64):
-    """``lo_region``: byte distance between the hi and the lo halves of a staged row; ``lrows``: rulebook entries per offset
-    (64 for the 256-row tile records; the 128-row tiles of spconv_st128.hip hold 32 and a 320-row stage).
-    The 8-wave workgroup's loop (4 row quarters x 2 channel halves: 64 rows x 32 channels per wave) inside 128 VGPRs, so
-    that FOUR waves share a SIMD (two workgroups per CU as before - the LDS stage is unchanged): a workgroup that waits for
-    its stage or stores its tile leaves two waves per SIMD on the matrix pipe instead of one (one wave alone reaches ~60 % of
-    the pipe in this loop).  Operand reads run D chunk groups ahead in a ring of D + 1 register slots.
-      v[0:27]   the compiler's      v[28:51] operand ring X(slot, p) = 28 + slot*8 + p*4      v[52:83] weight sets (2)
-      v[84:89]  rulebook sets (3)   v[90:95] lane constants / address temporaries                v[96:127] accumulators"""
-    NXS, NWS, NLS = D + 1, WD + 1, LD + 1
-    assert NXS * 8 <= 24 and NWS * 16 <= 32 and NLS * 2 <= 6
-    ACC = lambda c, t: 96 + (c * NTW + t) * 4
-    XS = lambda slot, p: 28 + slot * 8 + p * 4
-    WS = lambda s, t, p: 52 + s * 16 + (t * 2 + p) * 4
-    LS = lambda s: 84 + s * 2
-    GH, WL0, LV, C4 = (f"v{90 + i}" for i in range(4))
-    T = [94, 95]
-    vr = lambda n, w=4: f"v[{n}:{n + w - 1}]"
-    out, vmq, lgq, done = [], [], [], [-1]
-    emit = out.append
-
-    def wait_vm(tag):
-        if tag not in vmq:
-            return
-        idx = len(vmq) - 1 - vmq[::-1].index(tag)
-        if idx <= done[0]:
-            return
-        emit(f"s_waitcnt vmcnt({min(len(vmq) - 1 - idx, 63)})")
-        done[0] = idx
-
-    def lg_count(tag):
-        idx = len(lgq) - 1 - lgq[::-1].index(tag)
-        return min(len(lgq) - 1 - idx, 15)
-
-    def issue_w(k):
-        for t in range(NTW):
-            for p in range(2):
-                emit(f"buffer_load_dwordx4 {vr(WS(k % NWS, t, p))}, {WL0}, %[wr], %[so] offen offset:{p * 1024 + t * 64}")
-                vmq.append(("W", k))
-        emit("s_add_u32 %[so], %[so], %[ks]")
-
-    kper = 4096 // (lrows * 8)          # offsets per 4 KB of rulebook entries (the instruction's offset field ends at 4095)
-
-    def issue_l(k):
-        if k % kper == 0 and k > 0:
-            emit(f"v_add_u32 {LV}, 0x1000, {LV}")
-        emit(f"global_load_dwordx2 {vr(LS(k % NLS), 2)}, {LV}, %[lb] offset:{(k % kper) * lrows * 8}")
-        vmq.append(("L", k))
-
-    def fetch(q):
-        """address + the two operand reads of chunk group q = 4 k + c into ring slot q % NXS"""
-        k, c = divmod(q, NC)
-        if c == 0:
-            wait_vm(("L", k))
-        t = T[q & 1]
-        emit(f"v_xor_b32_sdwa v{t}, {GH}, v{LS(k % NLS) + (c >> 1)} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_{c & 1}")
-        for p in range(2):
-            emit(f"ds_read_b128 {vr(XS(q % NXS, p))}, v{t}" + (f" offset:{lo_region}" if p else ""))
-            lgq.append(("X", q))
-
-    emit("s_mov_b32 %[so], %[ws0]")
-    emit(f"v_mbcnt_lo_u32_b32 {LV}, -1, 0")
-    emit(f"v_mbcnt_hi_u32_b32 {LV}, -1, {LV}")
-    emit(f"v_and_b32 {GH}, 48, {LV}")
-    emit(f"v_and_b32 {LV}, 15, {LV}")
-    emit(f"v_lshrrev_b32 {WL0}, 2, {LV}")
-    emit(f"v_lshlrev_b32 {WL0}, 3, {WL0}")
-    emit(f"v_and_b32 {C4}, 3, {LV}")
-    emit(f"v_add_u32 {WL0}, {WL0}, {C4}")
-    emit(f"v_lshrrev_b32 {C4}, 4, {WL0}")
-    emit(f"v_and_b32 {WL0}, 15, {WL0}")
-    emit(f"v_add_u32 {WL0}, {WL0}, {GH}")
-    emit(f"v_lshlrev_b32 {WL0}, 4, {WL0}")
-    emit(f"v_mul_lo_u32 {C4}, {C4}, %[w1]")
-    emit(f"v_add_u32 {WL0}, {WL0}, {C4}")
-    emit(f"v_lshlrev_b32 {LV}, 3, {LV}")
-    for k in range(WD):
-        issue_w(k)
-    for k in range(LD):
-        issue_l(k)
-    emit("s_waitcnt vmcnt(0)")
-    done[0] = len(vmq) - 1
-    emit("s_barrier")
-    for q in range(D):
-        fetch(q)
-    for q in range(K * NC):
-        k, c = divmod(q, NC)
-        if c == 0:
-            if k + WD < K:
-                issue_w(k + WD)
-            if k + LD < K:
-                issue_l(k + LD)
-            wait_vm(("W", k))
-        if q + D < K * NC:
-            fetch(q + D)
-        if skip:
-            emit(f"s_bitcmp1_b32 s{36 + (k >> 1)}, {(k & 1) * 16 + c}")
-            emit(f"s_cbranch_scc0 .Lst%=_q{q}")
-        emit(f"s_waitcnt lgkmcnt({lg_count(('X', q))})")
-        for term in range(3):
-            for t in range(NTW):
-                a = WS(k % NWS, t, 1 if term == 2 else 0)
-                b = XS(q % NXS, 1 if term == 1 else 0)
-                emit(f"v_mfma_f32_16x16x32_f16 {vr(ACC(c, t))}, {vr(a)}, {vr(b)}, {vr(ACC(c, t))}")
-        if skip:
-            emit(f".Lst%=_q{q}:")
-    emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    emit("s_nop 7")
-    emit("s_nop 7")
-    emit("s_nop 7")
-    return out
-
-
 WD2, LD2 = 1, 2            # NH = 2 (measured: weights two offsets ahead and rulebook entries three, lane constants in v[56:61], gain nothing)
 
 
@@ -373,12 +260,6 @@ def main(path):
         # pinned accumulators through scratch: 168 spilled VGPRs)
         write_blob(f, "UPC", gen_upc())
         f.write(f"#define EYOC_ST_LOOP_CLOBBERS {clobbers()}\n")
-        # spconv_st128.hip: 128-row tiles, 64 rows x 32 channels per wave inside 128 VGPRs (four waves per SIMD, four workgroups per CU)
-        write_blob(f, "T128", gen_w8(lo_region=320 * 64, lrows=32))
-        write_blob(f, "T128_NOSKIP", gen_w8(skip=False, lo_region=320 * 64, lrows=32))
-        write_blob(f, "T64", gen_w8(lo_region=320 * 64, lrows=16))          # 64-row tiles (strided tables): one row group per tile
-        write_blob(f, "T64_NOSKIP", gen_w8(skip=False, lo_region=320 * 64, lrows=16))
-        f.write("#define EYOC_ST_LOOP_CLOBBERS_T128 " + ", ".join(f'"v{i}"' for i in range(28, 96)) + "\n")
     with open(path.replace(".inc", "_abl.inc"), "w") as f:
         f.write("// GENERATED by gen_st_loop.py - diagnostics builds only (EYOC_ST_ABLATIONS / EYOC_ST_TRACE); results are garbage\n")
         for name, abl in (("NOW", ("now",)), ("NOX", ("nox", "nov")), ("NOV", ("nov",)), ("NOM", ("nom",)), ("NOMW", ("nom", "now")),
@@ -390,9 +271,7 @@ def main(path):
         write_blob(f, "UPC_EMPTY", gen_upc(("nom", "now", "nol", "nox", "nov")))
         write_blob(f, "NH2_W2L3", gen(2, 2, 3))       # weights two offsets ahead, rulebook entries three: no gain
         write_blob(f, "NH2_LAZY", gen(2, WD2, LD2, lazy=True))   # operand reads only for non-empty blocks (round 5): level on every layer
-        write_blob(f, "W8", gen_w8())                 # 8 waves of 64 rows x 32 channels in 128 VGPRs (four per SIMD): no gain
         f.write("#define EYOC_ST_LOOP_CLOBBERS_LOW EYOC_ST_LOOP_CLOBBERS, " + ", ".join(f'"v{i}"' for i in range(56, 62)) + "\n")
-        f.write("#define EYOC_ST_LOOP_CLOBBERS_W8 " + ", ".join(f'"v{i}"' for i in range(28, 96)) + "\n")
 
 
 if __name__ == "__main__":

@@ -417,7 +417,7 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
         }
       }
       a.parent = maps->parent[0]; a.children = maps->children[0]; a.s1c = maps->nbr_s1[1]; a.nc = maps->rows[1];
-      a.local1 = maps->row_perm ? maps->local1_256 : nullptr;           // Z-ordered maps: the level-1 tile rulebooks (256-parent tiles)
+      a.local1 = maps->row_perm ? maps->local_s1[1] : nullptr;          // Z-ordered maps: the level-1 tile rulebooks (256-parent tiles)
       rc = conv1_walks_octree(a) ? EYOC_OK : maps_build_table0(const_cast<eyoc_maps*>(maps), st);
       if (!rc) rc = launch_conv1(a, st);
     } else if (split && g_fuse_tail && li + 2 == m->layers.size() && p.map == M_IDENT && p.K == 1 && p.res_buf < 0 &&
@@ -455,10 +455,9 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
         a.out_split = p.out_buf != B_OUT;
         a.range = m->range;
         // stride-1 layers on Z-ordered rows: tile-local input stage (spconv_st.hip)
-        if (p.map == M_S1 && p.cin >= 32 && p.cin % 32 == 0) { a.local = maps->local_s1[p.level]; a.local_tile = maps->local_tile; }
+        if (p.map == M_S1 && p.cin >= 32 && p.cin % 32 == 0) a.local = maps->local_s1[p.level];
         if (p.map == M_UP && p.cin % 32 == 0 && p.cout % 64 == 0) a.local_up = maps->local_up[p.level];   // spconv_up.hip
         if (p.map == M_UP && p.cin % 32 == 0 && p.cout % 64 == 0) a.local_upc = maps->local_upc[p.level]; // spconv_upc.hip (class-major tiles)
-        if (p.map == M_DOWN && p.cin % 32 == 0 && p.cout >= 64) { a.local = maps->local_down[p.level]; a.local_tile = 64; }   // strided: staged on 64-row tiles
       }
       if (p.out_buf == B_OUT) a.out_perm = maps->row_perm;   // the network output goes back to the caller's row order
       a.perm = p.map == M_UP ? maps->perm_up[p.level] : p.map == M_S1 ? maps->perm_s1[p.level]

@@ -30,7 +30,6 @@ struct SpconvArgs {
   int out_split = 0;               // write SPLIT16 rows (internal activations) instead of fp32 rows
   const int32_t* out_perm = nullptr;      // output row o is written to row out_perm[o] of `out` (the network output in the caller's order); res is not permuted
   const unsigned char* local = nullptr;   // per-tile local rulebooks of `nbr` (build_local_rulebook / build_local_rulebook128) or NULL: enables the staged kernel
-  int local_tile = 256;                   // rows per tile of `local`: 256 (spconv_st.hip), 128 or 64 (spconv_st128.hip)
   const unsigned char* local_up = nullptr;   // ... of a transposed table (build_local_rulebook_up): enables spconv_up.hip
   const unsigned char* local_upc = nullptr;  // ... in class-major order (build_upc): enables spconv_upc.hip
   const float* out_scale = nullptr;  // device scalar multiplied into the accumulated sums (undoes the weight pre-scale); NULL = 1
@@ -153,13 +152,6 @@ int launch_spconv_upc(const SpconvArgs& a, const unsigned char* ws, hipStream_t 
 int select_st_variant(int v);   // spconv_st.hip: which staged kernel (returns the previous one)
 int select_st_split_below(int workgroups);   // layers with fewer 64-channel workgroups take 32-channel ones (returns the previous threshold)
 size_t local_rulebook_bytes(int n_out);
-// 128-row tiles (spconv_st128.hip): four workgroups per CU, four waves per SIMD
-int select_st_tile(int rows);   // 128 / 256 set the tile shape new maps build their stride-1 records for; anything else only queries
-size_t local_rulebook128_bytes(int n_out);
-int build_local_rulebook128(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st);
-size_t local_rulebook64_bytes(int n_out);     // 64-row tiles: the strided tables (a 64-row coarse tile reads 190-330 distinct fine rows)
-int build_local_rulebook64(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st);
-int launch_spconv_st128(const SpconvArgs& a, const unsigned char* local_dev, int tile, int skip_empty_blocks, hipStream_t st);
 // group: 1 = the rows of a tile sorted by neighbour pattern (fewer non-empty MFMA blocks), 0 = in their own order (what
 // conv1_bf_kernel needs: it finds a parent's entries by its local row), -1 = the process-wide setting of select_st_group_rows
 int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st, int group = -1);
@@ -174,7 +166,6 @@ bool spconv_rs_fits(const SpconvArgs& a);
 bool spconv_up_enabled();    // eyoc_spconv_select_up_kernel state == 1 (spconv_up.hip)
 bool spconv_upc_enabled();   // ... == 2 (spconv_upc.hip)
 int spconv_upc_min_rows();    // maps with fewer level-0 rows keep spconv_up.hip under mode 2
-bool spconv_down_staged();   // eyoc_spconv_select_down_kernel state
 int spconv_forced_kernel();   // eyoc_spconv_select_kernel state: -1 automatic, 0 workgroup-tiled, 1 wave-private
 int launch_spconv_wave(const SpconvArgs& a, hipStream_t st);   // wave-private tiling (spconv_wave.hip)
 

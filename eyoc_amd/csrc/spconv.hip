@@ -729,8 +729,6 @@ bool spconv_upc_enabled() { return g_up_kernel == 2; }
 int g_upc_min_rows = 1 << 17;            // eyoc_spconv_upc_min_rows
 int spconv_upc_min_rows() { return g_upc_min_rows; }
 int g_conv1_staged = 1;   // eyoc_spconv_select_conv1_kernel: 1 the first convolution of Z-ordered split16 forwards on conv1_bf_kernel (block feature vectors of a staged level-1 tile), 0 on conv1_mfma_kernel, 2 on the exact-fp32 octree walker
-int g_down_staged = 0;   // strided convolutions on Z-ordered maps through the staged kernel (eyoc_spconv_select_down_kernel): off - their tiles overflow 2 passes
-bool spconv_down_staged() { return g_down_staged != 0; }
 
 int launch_spconv(const SpconvArgs& a, hipStream_t st) {
   EYOC_REQUIRE(a.in && a.w && a.out, EYOC_ERR_INVALID, "spconv: NULL tensor");
@@ -773,7 +771,6 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
     if (a.math == 1 && a.local && use_rs != 0 && a.K == 27 && !a.l2norm && st_ok) {
       SpconvArgs b = a;
       b.perm = nullptr;
-      if (a.local_tile == 128 || a.local_tile == 64) return launch_spconv_st128(b, a.local, a.local_tile, select_st_variant(-1) != 2, st);
       return launch_spconv_st(b, a.local, st);
     }
     if (a.math == 1 && a.local_upc && use_rs != 0 && a.K == 27 && !a.l2norm && !a.res && !a.out_perm && a.cout % 64 == 0) {   // transposed table, class-major tiles
@@ -1212,34 +1209,7 @@ int eyoc_spconv_staged(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* local_
   return launch_spconv(a, (hipStream_t)stream);
 }
 
-int eyoc_spconv_st_tile(int rows) { return eyoc::select_st_tile(rows); }
 int eyoc_spconv_st_group_rows(int on) { return eyoc::select_st_group_rows(on); }
-
-size_t eyoc_spconv_local_rulebook_bytes_tile(int n_out, int tile) {
-  return tile == 128 ? eyoc::local_rulebook128_bytes(n_out) : tile == 64 ? eyoc::local_rulebook64_bytes(n_out)
-                                                              : tile == 256 ? eyoc::local_rulebook_bytes(n_out) : 0;
-}
-
-int eyoc_spconv_build_local_rulebook_tile(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, int tile, void* out_dev, int32_t* overflow_dev,
-                                          void* stream) {
-  EYOC_REQUIRE(ctx && nbr_dev && out_dev && overflow_dev && K == 27 && (tile == 64 || tile == 128 || tile == 256), EYOC_ERR_INVALID,
-               "eyoc_spconv_build_local_rulebook_tile: bad argument (K %d, tile %d)", K, tile);
-  if (tile == 64) return build_local_rulebook64(nbr_dev, K, n_out, (unsigned char*)out_dev, overflow_dev, (hipStream_t)stream);
-  if (tile == 128) return build_local_rulebook128(nbr_dev, K, n_out, (unsigned char*)out_dev, overflow_dev, (hipStream_t)stream);
-  return build_local_rulebook(nbr_dev, K, n_out, (unsigned char*)out_dev, overflow_dev, (hipStream_t)stream);
-}
-
-int eyoc_spconv_staged_tile(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* local_dev, int tile, int n_out, int n_in, const float* in_dev,
-                            int ld_in, int cin, const float* wpacked_dev, int cout, const float* bias_dev, const float* res_dev, int ld_res,
-                            int relu, float* out_dev, int ld_out, int out_split, const float* out_scale_dev, void* stream) {
-  EYOC_REQUIRE(ctx && nbr_dev && local_dev && (tile == 64 || tile == 128 || tile == 256), EYOC_ERR_INVALID, "eyoc_spconv_staged_tile: bad argument");
-  SpconvArgs a;
-  a.nbr = nbr_dev; a.K = 27; a.n_out = n_out; a.n_in = n_in; a.in = in_dev; a.ld_in = ld_in; a.cin = cin; a.w = wpacked_dev;
-  a.cout = cout; a.bias = bias_dev; a.res = res_dev; a.ld_res = ld_res; a.relu = relu; a.l2norm = 0;
-  a.out = out_dev; a.ld_out = ld_out; a.math = 1; a.out_split = out_split; a.out_scale = out_scale_dev;
-  a.local = (const unsigned char*)local_dev; a.local_tile = tile; a.ctx = ctx;
-  return launch_spconv(a, (hipStream_t)stream);
-}
 
 int eyoc_spconv_select_up_kernel(int on) {
   const int prev = eyoc::g_up_kernel;
@@ -1286,11 +1256,6 @@ int eyoc_spconv_select_conv1_kernel(int on) {
   return prev;
 }
 
-int eyoc_spconv_select_down_kernel(int on) {
-  const int prev = eyoc::g_down_staged;
-  if (on == 0 || on == 1) eyoc::g_down_staged = on;
-  return prev;
-}
 
 int eyoc_spconv_select_st_kernel(int variant) {
   return eyoc::select_st_variant(variant);

@@ -612,11 +612,6 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
       else if constexpr (NH == 2 && SKIP == 16) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOWL);
       else if constexpr (NH == 2 && SKIP == 17) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_EMPTY);
 #endif
-#ifdef EYOC_ST_ABLATIONS
-      else if constexpr (NWV == 2 * NW)
-        asm volatile(EYOC_ST_LOOP_W8 : "+{v[96:111]}"(A0), "+{v[112:127]}"(A1), [so] "=&s"(so)
-                     : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS_W8);
-#endif
       else
         asm volatile(EYOC_ST_LOOP_NH1 : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), [so] "=&s"(so)
                      : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS);
@@ -749,7 +744,7 @@ int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char
 
 // which staged kernel runs: 0 = the C++ offset loop (spconv_st_kernel), 1 = the assembly loop (default), 2 = the assembly loop
 // without the empty-block branches (diagnostics); -DEYOC_ST_ABLATIONS builds add 3 = operand reads only for non-empty blocks
-// (round 5: level), 4 = 8 waves of 64 rows x 32 channels (four per SIMD, 128 VGPRs) and 13 ... = timing-only ablations
+// (round 5: level) and 13 ... = timing-only ablations
 static std::atomic<int> g_st_variant{1};
 #ifdef EYOC_ST_ABLATIONS
 constexpr int ST_VARIANTS = 28;
@@ -796,10 +791,6 @@ int launch_spconv_st(const SpconvArgs& a_in, const unsigned char* local_dev, hip
       if (variant == 2) { if (wide) EYOC_STA(64, 2, 0); else EYOC_STA(32, 2, 0); }
 #ifdef EYOC_ST_ABLATIONS
       else if (variant == 3) { if (wide) EYOC_STA(64, 2, 2); else EYOC_STA(32, 2, 2); }
-      else if (variant == 4) {                                         // 8 waves of 64 rows x 32 channels, four per SIMD
-        if (wide) hipLaunchKernelGGL((spconv_st_asm_kernel<64, 1, 1, 2 * NW>), grid, dim3(2 * NW * 64), 0, st, a, local_dev, n_tiles);
-        else hipLaunchKernelGGL((spconv_st_asm_kernel<32, 1, 1, 2 * NW>), grid, dim3(2 * NW * 64), 0, st, a, local_dev, n_tiles);
-      }
       else if (variant == 13) EYOC_STA(64, 2, 3);
       else if (variant == 14) EYOC_STA(64, 2, 4);
       else if (variant == 15) EYOC_STA(64, 2, 5);

@@ -182,9 +182,16 @@ class ResUNet2(nn.Module):
         changed; it is MANDATORY after edits that fingerprint cannot see (``p.data`` edits, writes through views)."""
         return self.pack(self._packed_device)
 
+    def _no_blob_for_expanded(self, what):
+        if self.EXPANDED:
+            raise NotImplementedError(f"{type(self).__name__}.{what}: the packed blob holds the ResUNet2 layer plan only - the Expanded "
+                                      "variants (norm<i>_2 / block<i>_2) run layer by layer from their parameters; ship their "
+                                      "state_dict between ranks (eyoc_amd.dist.broadcast_model does)")
+
     def pack_host(self) -> torch.Tensor:
         """The packed blob as a CPU tensor (``eyoc_model_pack_host``: batch norms folded, fp32 fragment order + split16
         packing) - byte for byte what ``pack()`` uploads.  Needs the shared library but no GPU."""
+        self._no_blob_for_expanded("pack_host")
         lib = _lib.load()
         blob = torch.zeros(self.blob_floats(), dtype=torch.float32)
         d = self._desc()
@@ -196,6 +203,7 @@ class ResUNet2(nn.Module):
     def pack(self, device=None, blob: torch.Tensor | None = None, from_blob=False):
         """(Re)create the device-side model.  ``from_blob=True`` adopts an already packed blob (the
         receiving side of the weight broadcast) instead of packing this module's parameters."""
+        self._no_blob_for_expanded("pack")
         lib = _lib.load()
         device = torch.device(device) if device is not None else self.final.kernel.device
         if device.type != "cuda":

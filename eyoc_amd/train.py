@@ -31,7 +31,9 @@ MAP_S1, MAP_DOWN, MAP_UP = 0, 1, 2
 
 class _BatchNormTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu):
+    def forward(ctx, x, gamma, beta, eps, relu, running=None):
+        """``running = (running_mean, running_var, momentum)``: moved inside the same library call (one launch instead of five
+        element-wise ones per norm); ``None``: statistics only."""
         x = x.contiguous()
         n, c = x.shape
         lib = _lib.load()
@@ -39,9 +41,15 @@ class _BatchNormTrain(torch.autograd.Function):
         stats = torch.empty(2 * c, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             ws = _lib.workspace(lib.eyoc_bn_workspace_bytes(n, c), x.device)
-            _lib.check(lib.eyoc_bn_train_forward(_lib.ctx(x.device.index), _lib.ptr(x), n, c, x.stride(0), _lib.ptr(gamma.contiguous()),
-                                                 _lib.ptr(beta.contiguous()), float(eps), 1 if relu else 0, _lib.ptr(y), y.stride(0),
-                                                 _lib.ptr(stats), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "eyoc_bn_train_forward")
+            if running is not None:
+                _lib.check(lib.eyoc_bn_train_forward_running(_lib.ctx(x.device.index), _lib.ptr(x), n, c, x.stride(0), _lib.ptr(gamma.contiguous()),
+                                                             _lib.ptr(beta.contiguous()), float(eps), 1 if relu else 0, _lib.ptr(y), y.stride(0),
+                                                             _lib.ptr(stats), _lib.ptr(running[0]), _lib.ptr(running[1]), float(running[2]),
+                                                             _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "eyoc_bn_train_forward_running")
+            else:
+                _lib.check(lib.eyoc_bn_train_forward(_lib.ctx(x.device.index), _lib.ptr(x), n, c, x.stride(0), _lib.ptr(gamma.contiguous()),
+                                                     _lib.ptr(beta.contiguous()), float(eps), 1 if relu else 0, _lib.ptr(y), y.stride(0),
+                                                     _lib.ptr(stats), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "eyoc_bn_train_forward")
         ctx.save_for_backward(x, y if relu else None, gamma, stats)
         ctx.eps, ctx.relu = float(eps), bool(relu)
         ctx.mark_non_differentiable(stats)
@@ -62,14 +70,21 @@ class _BatchNormTrain(torch.autograd.Function):
                                                   _lib.ptr(dy), dy.stride(0), n, c, _lib.ptr(gamma.contiguous()), _lib.ptr(stats), ctx.eps,
                                                   _lib.ptr(dx), dx.stride(0), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), ws.numel(),
                                                   _lib.stream_ptr()), "eyoc_bn_train_backward")
-        return dx, dgamma, dbeta, None, None
+        return dx, dgamma, dbeta, None, None, None
 
 
 def batch_norm_train(x: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool = False) -> torch.Tensor:
     """``MinkowskiBatchNorm`` in training mode (model/common.py:4-6): normalise with the batch's own statistics and move
     the running statistics by ``momentum`` (unbiased variance, ``num_batches_tracked + 1``) exactly like ``nn.BatchNorm1d``."""
+    track = bn.track_running_stats and bn.running_mean is not None
+    if track and bn.momentum is not None and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous() \
+            and bn.running_mean.dtype == torch.float32:
+        y, _ = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps, relu, (bn.running_mean, bn.running_var, bn.momentum))
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        return y
     y, stats = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps, relu)
-    if bn.track_running_stats and bn.running_mean is not None:
+    if track:
         n, c = x.shape
         with torch.no_grad():
             bn.num_batches_tracked += 1
@@ -101,6 +116,16 @@ def forward_layers(model, x: SparseTensor, taps: dict | None = None) -> SparseTe
     """The network layer by layer through the autograd Functions above - ``ResUNet2`` (model/resunet.py:142-193) and
     ``ResUNetExpanded`` (:254-484: every stage runs a second norm + block, ``norm<i>_2`` / ``block<i>_2``).  In training mode
     every norm uses batch statistics; in eval mode its running statistics (a per-channel affine, element-wise)."""
+    if model.training or torch.is_grad_enabled():
+        # the gradient w.r.t. a convolution's INPUT runs the forward kernel with the channel roles swapped, so its C_in must be one
+        # of the kernel's output widths; the concatenated decoder inputs of some tables (BN2B / BN2D / FatBN: 128 + 64 = 192,
+        # 256 + 128 = 384) are not - say so here instead of failing inside loss.backward()
+        Cn, T = model.CHANNELS, model.TR_CHANNELS
+        for name, cin in (("conv3_tr", Cn[3] + T[4]), ("conv2_tr", Cn[2] + T[3])):
+            if model.training and cin not in (32, 64, 128, 256):
+                raise NotImplementedError(f"{type(model).__name__}: training is not implemented for this channel table - {name} has "
+                                          f"{cin} input channels, and the input gradient of a sparse convolution needs 32, 64, 128 or 256 "
+                                          "(ResUNetBN2C-shaped tables train; every table runs in eval mode)")
     cm = x.coordinate_manager
     s1 = [cm.table(MAP_S1, l) for l in range(4)]
     down = [cm.table(MAP_DOWN, l) for l in range(3)]

@@ -192,12 +192,6 @@ int eyoc_spconv_upc_build(eyoc_ctx* ctx, const int32_t* nbr_dev, int n_out, void
 int eyoc_spconv_upc(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* ws_dev, int n_out, int n_in, const float* in_dev, int ld_in,
                     int cin, const float* wpacked_dev, int cout, const float* bias_dev, int relu, float* out_dev, int ld_out,
                     int out_split, const float* out_scale_dev, void* stream);
-/* Strided 3^3 / stride-2 convolutions on Z-ordered maps through the small-tile staged kernel (spconv_st128.hip on 64-ROW output
- * tiles: a tile's inputs - its rows' children plus the halo of the -1 offsets, 190-330 distinct fine rows - are staged in LDS once
- * per 32-channel block, up to three passes of 319 rows): 1 on for the two fine tables (32 -> 64 and 64 -> 128 channels: -25 % /
- * -16 % on those layers; the coarsest stays on the gathering kernel), 0 off (default: at the step level the records cost what the
- * layers save); other values only query.  Returns the previous state.  Process-wide, read when maps are built. */
-int eyoc_spconv_select_down_kernel(int on);
 /* First convolution (C_in = 1, 32 output channels) of split16 forwards on Z-ordered maps: 1 (default) = conv1_bf_kernel - the block
  * feature vectors (8 child features per level-1 row) of a 256-parent tile's neighbourhood staged in LDS through the level-1 tile
  * rulebook, the tile's fine rows grouped by parity class, a K = 27 product over blocks; 0 = conv1_mfma_kernel, which probes
@@ -216,24 +210,11 @@ int eyoc_spconv_select_st_kernel(int variant);
  * in 32-channel workgroups instead (twice as many, each half as long: single pairs and small batches).  0 = never (tests force
  * the wide kernels onto small clouds with it); negative only queries.  Returns the previous threshold; process-wide. */
 int eyoc_spconv_st_split_below(int workgroups);
-/* The same on 128-ROW tiles (spconv_st128.hip: a 40 KB stage and 128 VGPRs per wave, so four workgroups share a CU and four
- * waves a SIMD - a tile's stage / loop / store phases overlap with three other tiles' instead of one).  eyoc_spconv_st_tile(128 |
- * 256) selects the tile shape NEW maps build their stride-1 records for (default 256 - the 128-row kernel measured level or slightly behind; other values only query; returns the
- * previous value; process-wide, read by eyoc_maps_build).  The *_tile entry points take the shape explicitly (records of one
- * shape are not readable as the other). */
-int eyoc_spconv_st_tile(int rows);
 /* Row grouping inside the 256-row tile records (default on): the builder sorts a tile's rows by their neighbour pattern so that the 16
  * rows of an MFMA chunk miss the same offsets - the staged loop skips (chunk, offset) blocks without a neighbour, and 0.81-0.93 of
  * them are non-empty in row order, 0.68-0.72 grouped.  Results are bit-identical either way (only the order of a tile's rows inside
  * its workgroup changes).  1 / 0 set, anything else only queries; returns the previous state; process-wide, read when records are built. */
 int eyoc_spconv_st_group_rows(int on);
-size_t eyoc_spconv_local_rulebook_bytes_tile(int n_out, int tile);
-int eyoc_spconv_build_local_rulebook_tile(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, int tile, void* out_dev,
-                                          int32_t* overflow_dev, void* stream);
-int eyoc_spconv_staged_tile(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* local_dev, int tile, int n_out, int n_in,
-                            const float* in_dev, int ld_in, int cin, const float* wpacked_dev, int cout, const float* bias_dev,
-                            const float* res_dev, int ld_res, int relu, float* out_dev, int ld_out, int out_split,
-                            const float* out_scale_dev, void* stream);
 size_t eyoc_spconv_local_rulebook_bytes(int n_out);
 int eyoc_spconv_build_local_rulebook(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, void* out_dev,
                                      int32_t* overflow_dev, void* stream);
@@ -453,6 +434,12 @@ size_t eyoc_bn_workspace_bytes(int n, int c);
 int eyoc_bn_train_forward(eyoc_ctx* ctx, const float* x_dev, int n, int c, int ld_x, const float* gamma_dev, const float* beta_dev,
                           float eps, int relu, float* y_dev, int ld_y, float* mean_var_dev, void* workspace_dev, size_t workspace_bytes,
                           void* stream);
+/* ... and the running statistics moved in the same call, like nn.BatchNorm1d in training mode: running_mean = (1 - momentum)
+ * running_mean + momentum * mean, running_var likewise with the UNBIASED batch variance (n / (n - 1)).  (num_batches_tracked and a
+ * momentum of None - the cumulative average - stay with the caller.) */
+int eyoc_bn_train_forward_running(eyoc_ctx* ctx, const float* x_dev, int n, int c, int ld_x, const float* gamma_dev, const float* beta_dev,
+                                  float eps, int relu, float* y_dev, int ld_y, float* mean_var_dev, float* running_mean_dev,
+                                  float* running_var_dev, float momentum, void* workspace_dev, size_t workspace_bytes, void* stream);
 /* Its backward: dy' = dy where y > 0 (y_dev = the forward's output when a ReLU was fused, else NULL);
  * dbeta = sum dy', dgamma = sum dy' xhat, dx = gamma / sigma (dy' - dbeta / n - xhat dgamma / n). */
 int eyoc_bn_train_backward(eyoc_ctx* ctx, const float* x_dev, int ld_x, const float* y_dev, int ld_y, const float* dy_dev, int ld_dy, int n,

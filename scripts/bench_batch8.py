@@ -10,9 +10,6 @@ model, _sd = bench.build_model(dev, 0)
 cfg = RegistrationConfig(ransac_max_iteration=4000000)
 pipe = RegistrationPipeline(model, cfg)
 batch = DeviceBatch(pairs, list(range(P)), dev, descriptor=dict(inlier_ratio=0.3))
-if os.environ.get("ST_TILE"):
-    from eyoc_amd import _lib
-    _lib.load().eyoc_spconv_st_tile(int(os.environ["ST_TILE"]))
 if os.environ.get("ST_GROUP"):
     from eyoc_amd import _lib
     _lib.load().eyoc_spconv_st_group_rows(int(os.environ["ST_GROUP"]))

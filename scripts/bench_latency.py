@@ -17,9 +17,6 @@ model = eyoc_amd.load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, conv1_kernel
 import numpy as np  # noqa: E402
 model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.make_weights().items()})
 model = model.to(device).eval()
-if os.environ.get("ST_TILE"):                   # staged stride-1 kernel on 128- or 256-row tiles
-    from eyoc_amd import _lib
-    _lib.load().eyoc_spconv_st_tile(int(os.environ["ST_TILE"]))
 if os.environ.get("ST_GROUP"):
     from eyoc_amd import _lib
     _lib.load().eyoc_spconv_st_group_rows(int(os.environ["ST_GROUP"]))

@@ -40,7 +40,7 @@ for lvl, cin, cout in LAYERS:
         res_t[name] = timeit(lambda: _lib.check(lib.eyoc_spconv_ex(_lib.ctx(), tab, 27, n, n, _lib.ptr(xs), cin, cin, _lib.ptr(wd), cout, None, None, 0, 0, _lib.ptr(out), cout, 1, 1, _lib.ptr(osd), _lib.stream_ptr())))
     lib.eyoc_spconv_select_split16_kernel(1)
     ref_out = None
-    variants = [int(v) for v in os.environ.get("ST_VARIANTS", "1,100,128").split(",")]       # 100: variant 1 on records WITHOUT row grouping
+    variants = [int(v) for v in os.environ.get("ST_VARIANTS", "1,100").split(",")]       # 100: variant 1 on records WITHOUT row grouping
     lib.eyoc_spconv_st_group_rows(0)
     local_plain = torch.zeros_like(local)
     t_lr_plain = timeit(lambda: lib.eyoc_spconv_build_local_rulebook(_lib.ctx(), tab, 27, n, _lib.ptr(local_plain), _lib.ptr(ovf), _lib.stream_ptr()))
@@ -51,11 +51,6 @@ for lvl, cin, cout in LAYERS:
         res = torch.empty_like(x)
         lib.eyoc_split16_encode(_lib.ctx(), _lib.ptr(torch.randn(n, cout, device="cuda")), n, cout, cout, _lib.ptr(res), cout, _lib.stream_ptr())
     run_st = lambda: _lib.check(lib.eyoc_spconv_staged(_lib.ctx(), tab, _lib.ptr(local), n, n, _lib.ptr(xs), cin, cin, _lib.ptr(wd), cout, None, _lib.ptr(res), 0 if res is None else cout, 0, _lib.ptr(out), cout, 1, _lib.ptr(osd), _lib.stream_ptr()))
-    # the 128-row-tile kernel (spconv_st128.hip) on its own records: variant 128
-    local128 = torch.zeros(int(lib.eyoc_spconv_local_rulebook_bytes_tile(n, 128)), dtype=torch.uint8, device="cuda")
-    ovf128 = torch.zeros(1, dtype=torch.int32, device="cuda")
-    t_lr128 = timeit(lambda: lib.eyoc_spconv_build_local_rulebook_tile(_lib.ctx(), tab, 27, n, 128, _lib.ptr(local128), _lib.ptr(ovf128), _lib.stream_ptr()))
-    run_st128 = lambda: _lib.check(lib.eyoc_spconv_staged_tile(_lib.ctx(), tab, _lib.ptr(local128), 128, n, n, _lib.ptr(xs), cin, cin, _lib.ptr(wd), cout, None, _lib.ptr(res), 0 if res is None else cout, 0, _lib.ptr(out), cout, 1, _lib.ptr(osd), _lib.stream_ptr()))
     best = {v: [] for v in variants}
     for rnd in range(int(os.environ.get("ROUNDS", "5"))):      # variants interleaved over several rounds: clocks drift with load
         for variant in variants:
@@ -63,11 +58,6 @@ for lvl, cin, cout in LAYERS:
                 lib.eyoc_spconv_select_st_kernel(1)
                 best[variant].append(timeit(run_plain, reps=5))
                 if rnd == 0 and ref_out is not None and not torch.equal(ref_out, out): best[variant].append(-1e6)
-                continue
-            if variant == 128:
-                lib.eyoc_spconv_select_st_kernel(1)
-                best[variant].append(timeit(run_st128, reps=5))
-                if rnd == 0 and ref_out is not None and float((ref_out - out).abs().max()) > 1e-3 * float(ref_out.abs().max()): best[variant].append(-1e6)
                 continue
             lib.eyoc_spconv_select_st_kernel(variant)
             best[variant].append(timeit(run_st, reps=5))
@@ -77,4 +67,4 @@ for lvl, cin, cout in LAYERS:
                 elif not torch.equal(ref_out, out): best[variant].append(-1e6)   # a mismatch shows as an absurd time
     for v in variants: res_t[f"st{v}"] = float(np.median(best[v])); res_t[f"st{v}min"] = min(best[v])
     lib.eyoc_spconv_select_st_kernel(1)
-    print(f"lvl{lvl} {cin}->{cout} n={n} pairs={prs} overflow={int(ovf.item())} local-rulebook {t_lr:.3f} (in row order {t_lr_plain:.3f}) / 128-row {t_lr128:.3f} ms (overflow {int(ovf128.item())}) | " + "  ".join(f"{k} {v:.3f} ms ({2*prs*cin*cout/v/1e9:.0f} TF)" for k, v in res_t.items()), flush=True)
+    print(f"lvl{lvl} {cin}->{cout} n={n} pairs={prs} overflow={int(ovf.item())} local-rulebook {t_lr:.3f} (in row order {t_lr_plain:.3f}) | " + "  ".join(f"{k} {v:.3f} ms ({2*prs*cin*cout/v/1e9:.0f} TF)" for k, v in res_t.items()), flush=True)

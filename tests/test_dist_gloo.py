@@ -95,3 +95,40 @@ def test_broadcast_model_ships_the_real_packed_blob(tmp_path):
     assert a.size > 8_000_000                                       # BN2C: fp32 + split16 packing of every layer
     np.testing.assert_array_equal(a, b)                             # bit-identical on both ranks
     assert np.count_nonzero(a) > a.size // 2
+
+
+def _expanded_worker(rank, world, port, out_dir):
+    """``ResUNetExpBN2C`` has parameters the packed blob does not hold (``norm<i>_2`` / ``block<i>_2``) -
+    ``broadcast_model`` ships its state as it is, and ``pack`` / ``pack_host`` refuse instead of silently dropping them."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import eyoc_amd
+    edist.init(backend="gloo")
+    torch.manual_seed(100 + rank)                               # different random parameters per rank
+    model = eyoc_amd.load_model("ResUNetExpBN2C")(1, 32, bn_momentum=0.05, conv1_kernel_size=5, normalize_feature=True)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_()
+            m.running_var.uniform_(0.5, 1.5)
+    with pytest.raises(NotImplementedError):
+        model.pack_host()
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    edist.broadcast_model(model, torch.device("cpu"), src=0)
+    after = model.state_dict()
+    if rank == 0:
+        assert all(torch.equal(before[k], after[k]) for k in before)
+    else:
+        assert any(not torch.equal(before[k], after[k]) for k in before)
+    torch.save({k: v.clone() for k, v in after.items()}, os.path.join(out_dir, f"sd{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_broadcast_model_ships_the_state_of_an_expanded_model(tmp_path):
+    from eyoc_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libeyoc_hip.so not built")
+    mp.spawn(_expanded_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "sd0.pt"), torch.load(tmp_path / "sd1.pt")
+    assert any(k.startswith("block3_2.") for k in a) and any(k.startswith("norm4_tr_2.") for k in a)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k

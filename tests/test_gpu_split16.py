@@ -304,7 +304,7 @@ def morton_order(coords):
     return np.argsort((b << 54) | spread(x) | (spread(y) << 1) | (spread(z) << 2), kind="stable")
 
 
-def run_layer_staged(nbr, x, W, bias=None, scale=None, res=None, relu=False, out_split=True, tile=256):
+def run_layer_staged(nbr, x, W, bias=None, scale=None, res=None, relu=False, out_split=True):
     L, lib = _lib()
     K, cin, cout = W.shape
     packed = np.zeros(K * cin * cout, np.float32)
@@ -315,26 +315,18 @@ def run_layer_staged(nbr, x, W, bias=None, scale=None, res=None, relu=False, out
     dev = torch.device("cuda")
     n_out = nbr.shape[1]
     nd = torch.from_numpy(np.ascontiguousarray(nbr, np.int32)).to(dev)
-    local = torch.zeros(int(lib.eyoc_spconv_local_rulebook_bytes_tile(n_out, tile)), dtype=torch.uint8, device=dev)
+    local = torch.zeros(int(lib.eyoc_spconv_local_rulebook_bytes(n_out)), dtype=torch.uint8, device=dev)
     ovf = torch.zeros(1, dtype=torch.int32, device=dev)
-    if tile == 256:
-        L.check(lib.eyoc_spconv_build_local_rulebook(L.ctx(), L.ptr(nd), K, n_out, L.ptr(local), L.ptr(ovf), L.stream_ptr()))
-    else:
-        L.check(lib.eyoc_spconv_build_local_rulebook_tile(L.ctx(), L.ptr(nd), K, n_out, tile, L.ptr(local), L.ptr(ovf), L.stream_ptr()))
+    L.check(lib.eyoc_spconv_build_local_rulebook(L.ctx(), L.ptr(nd), K, n_out, L.ptr(local), L.ptr(ovf), L.stream_ptr()))
     assert int(ovf.item()) == 0, "a tile has more distinct input rows than two passes stage"
     xin = encode(torch.from_numpy(x).to(dev))
     rin = None if res is None else encode(torch.from_numpy(res).to(dev))
     out = torch.full((n_out, cout), -555.0, device=dev)
     wd, osd = torch.from_numpy(packed).to(dev), torch.from_numpy(os_).to(dev)
     bd = None if bias is None else torch.from_numpy(np.ascontiguousarray(bias, np.float32)).to(dev)
-    if tile == 256:
-        L.check(lib.eyoc_spconv_staged(L.ctx(), L.ptr(nd), L.ptr(local), n_out, x.shape[0], L.ptr(xin), xin.stride(0), cin, L.ptr(wd), cout,
-                                       L.ptr(bd), L.ptr(rin), 0 if rin is None else rin.stride(0), 1 if relu else 0, L.ptr(out),
-                                       out.stride(0), 1 if out_split else 0, L.ptr(osd), L.stream_ptr()), "eyoc_spconv_staged")
-    else:
-        L.check(lib.eyoc_spconv_staged_tile(L.ctx(), L.ptr(nd), L.ptr(local), tile, n_out, x.shape[0], L.ptr(xin), xin.stride(0), cin, L.ptr(wd),
-                                            cout, L.ptr(bd), L.ptr(rin), 0 if rin is None else rin.stride(0), 1 if relu else 0, L.ptr(out),
-                                            out.stride(0), 1 if out_split else 0, L.ptr(osd), L.stream_ptr()), "eyoc_spconv_staged_tile")
+    L.check(lib.eyoc_spconv_staged(L.ctx(), L.ptr(nd), L.ptr(local), n_out, x.shape[0], L.ptr(xin), xin.stride(0), cin, L.ptr(wd), cout,
+                                   L.ptr(bd), L.ptr(rin), 0 if rin is None else rin.stride(0), 1 if relu else 0, L.ptr(out),
+                                   out.stride(0), 1 if out_split else 0, L.ptr(osd), L.stream_ptr()), "eyoc_spconv_staged")
     if out_split:
         out = decode(out)
     torch.cuda.synchronize()
@@ -414,81 +406,6 @@ def test_staged_kernel_vs_fp64(morton_maps, cin, cout, level):
     print(f"staged {cin}->{cout} level {level}: n {n} err {e:.2e} / {e32:.2e}  distinct rows per tile mean {n_u.mean():.0f} max {n_u.max()}"
           f"  re-use {pairs / n_u.sum():.2f}x  non-empty (16-row chunk, offset) blocks {f_rows:.2f} in row order, {f_slots:.2f} grouped")
     assert e < 2e-6 and e32 < 2e-6 and n_u.max() <= 1278 and n_u.min() >= 1
-
-
-@pytest.mark.parametrize("cin,cout,level", [(64, 64, 0), (32, 32, 0), (128, 128, 1), (256, 256, 2), (96, 64, 1), (64, 128, 3)])
-def test_staged_kernel_on_128_row_tiles_vs_fp64(morton_maps, cin, cout, level):
-    """spconv_st128.hip (128-row tiles, 40 KB stage, 128 VGPRs: four workgroups per CU) against the fp64 restatement at the
-    split16 bar and against the 256-row kernel (same products; tiles that take a second pass sum in another order, so equal to
-    fp32 rounding, not bitwise); with and without the empty-block branches bit-identical; the records: distinct rows per tile
-    and the 8-bit occupancy masks."""
-    nbr = morton_maps["s1"][level]
-    n = nbr.shape[1]
-    rng = np.random.default_rng(1000 + cin + cout + level)
-    x = np.abs(rng.normal(size=(n, cin))).astype(np.float32)
-    W = (rng.normal(size=(27, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
-    s = rng.uniform(0.5, 1.5, cout).astype(np.float32)
-    b = rng.normal(size=cout).astype(np.float32)
-    r = rng.normal(size=(n, cout)).astype(np.float32)
-    want = layer_f64(nbr, x, W, bias=b, scale=s, res=r, relu=True)
-    got, local = run_layer_staged(nbr, x, W, bias=b, scale=s, res=r, relu=True, tile=128)
-    got32, _ = run_layer_staged(nbr, x, W, bias=b, scale=s, res=r, relu=True, out_split=False, tile=128)
-    big, _ = run_layer_staged(nbr, x, W, bias=b, scale=s, res=r, relu=True, out_split=False, tile=256)
-    L, lib = _lib()
-    prev = lib.eyoc_spconv_select_st_kernel(2)                       # no empty-block branches
-    try:
-        noskip, _ = run_layer_staged(nbr, x, W, bias=b, scale=s, res=r, relu=True, out_split=False, tile=128)
-    finally:
-        lib.eyoc_spconv_select_st_kernel(prev)
-    np.testing.assert_array_equal(noskip, got32)
-    e, e32, d = rel_err(got, want), rel_err(got32, want), rel_err(got32, big)
-    REC, MASK_OFF, UOFF = 17792, 17680, 16
-    n_tiles = (n + 127) // 128
-    lr = local.cpu().numpy()[:n_tiles * REC].reshape(-1, REC)
-    n_u = lr[:, :4].copy().view(np.int32)[:, 0]
-    distinct = np.array([len(np.unique(t[t >= 0])) for t in np.array_split(nbr, np.arange(128, n, 128), axis=1)])
-    np.testing.assert_array_equal(n_u, distinct)
-    U = lr[:, UOFF:UOFF + 4 * 638].copy().view(np.int32)
-    for t in (0, n_tiles // 2, n_tiles - 1):                         # the row list is the set of distinct rows
-        cols = nbr[:, t * 128:(t + 1) * 128]
-        assert sorted(U[t, :n_u[t]].tolist()) == sorted(np.unique(cols[cols >= 0]).tolist())
-    masks = lr[:, MASK_OFF:MASK_OFF + 56].copy().view(np.uint16)[:, :27]
-    occ = np.zeros((n_tiles * 128, 27), bool)
-    occ[:n] = (nbr >= 0).T
-    want_masks = (occ.reshape(n_tiles, 8, 16, 27).any(axis=2) * (1 << np.arange(8))[None, :, None]).sum(axis=1)
-    single = n_u <= 319
-    np.testing.assert_array_equal(masks[single], want_masks[single].astype(np.uint16))
-    print(f"staged/128 {cin}->{cout} level {level}: n {n} err {e:.2e} / {e32:.2e}, vs 256-row kernel {d:.2e}; distinct rows per tile mean "
-          f"{n_u.mean():.0f} max {n_u.max()}, two-pass tiles {(n_u > 319).mean():.3f}")
-    assert e < 2e-6 and e32 < 2e-6 and d < 2e-6 and n_u.max() <= 638
-
-
-@pytest.mark.parametrize("cin,cout,level", [(32, 64, 0), (64, 128, 1), (128, 256, 2)])
-def test_strided_convolution_staged_on_64_row_tiles_vs_fp64(morton_maps, cin, cout, level):
-    """The strided 3^3 / stride-2 convolutions (model/resunet.py:44-77) through spconv_st128.hip on 64-ROW output tiles: a tile's
-    inputs (its rows' children plus the halo of the -1 offsets) are 190-330 distinct fine rows, staged in LDS once per 32-channel
-    block.  Against the fp64 restatement at the split16 bar, against the gathering kernel, and the records against numpy."""
-    nbr = morton_maps["down"][level]
-    n_out, n_in = nbr.shape[1], len(morton_maps["cm"][level])
-    rng = np.random.default_rng(2000 + cin + level)
-    x = np.abs(rng.normal(size=(n_in, cin))).astype(np.float32)
-    W = (rng.normal(size=(27, cin, cout)) / np.sqrt(7 * cin)).astype(np.float32)
-    s = rng.uniform(0.5, 1.5, cout).astype(np.float32)
-    b = rng.normal(size=cout).astype(np.float32)
-    want = layer_f64(nbr, x, W, bias=b, scale=s)
-    got, local = run_layer_staged(nbr, x, W, bias=b, scale=s, tile=64)
-    got32, _ = run_layer_staged(nbr, x, W, bias=b, scale=s, out_split=False, tile=64)
-    ref = run_layer_split(nbr, x, W, bias=b, scale=s)
-    e, e32, d = rel_err(got, want), rel_err(got32, want), rel_err(got32, ref)
-    REC = 14464
-    n_tiles = (n_out + 63) // 64
-    lr = local.cpu().numpy()[:n_tiles * REC].reshape(-1, REC)
-    n_u = lr[:, :4].copy().view(np.int32)[:, 0]
-    distinct = np.array([len(np.unique(t[t >= 0])) for t in np.array_split(nbr, np.arange(64, n_out, 64), axis=1)])
-    np.testing.assert_array_equal(n_u, distinct)
-    print(f"strided/64 {cin}->{cout} level {level}: {n_in} -> {n_out} rows, err {e:.2e} / {e32:.2e}, vs gathering kernel {d:.2e}; distinct rows per "
-          f"tile mean {n_u.mean():.0f} max {n_u.max()}, two-pass tiles {(n_u > 319).mean():.3f}")
-    assert e < 2e-6 and e32 < 2e-6 and d < 2e-6 and n_u.max() <= 957
 
 
 def test_local_rulebook_counts_tiles_it_cannot_stage_instead_of_hanging():
@@ -586,43 +503,12 @@ def test_fused_tail_matches_the_two_layer_tail_and_the_oracle(normalize):
     assert e_fused <= 2 * e_two + 1e-6
 
 
-def test_forward_on_small_tiles_matches_the_default_and_the_oracle():
-    """The whole network with the selectable tile shapes - stride-1 layers on 128-row tiles (eyoc_spconv_st_tile(128): the maps then
-    build 128-row records, plus 256-row ones of level 1 for the staged first convolution) and the strided layers on 64-row tiles
-    (eyoc_spconv_select_down_kernel(1)) - against the default kernels (same products; multi-pass tiles sum in another order) and
-    the oracle."""
-    import eyoc_amd
-    from eyoc_amd import synthetic as syn
-    from oracle import resunet as orr
-    L, lib = _lib()
-    p = syn.make_pair(4, beams=32, azimuths=1000, band=None)
-    coords = syn.batch_coords([p["coords0"], p["coords1"]])
-    feats = np.ones((len(coords), 1), np.float32)
-    sd = syn.make_weights(seed=3)
-    m = eyoc_amd.load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, conv1_kernel_size=5, normalize_feature=True)
-    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
-    m = m.cuda().eval()
-    m.spconv_math = "split16"
-    want = orr.resunet_forward(sd, coords, feats).numpy()
-    base = _forward(m, coords, feats)
-    prev_tile, prev_dn = lib.eyoc_spconv_st_tile(128), lib.eyoc_spconv_select_down_kernel(1)
-    try:
-        assert lib.eyoc_spconv_st_tile(-1) == 128
-        small = _forward(m, coords, feats)
-    finally:
-        lib.eyoc_spconv_st_tile(prev_tile)
-        lib.eyoc_spconv_select_down_kernel(prev_dn)
-    e, d = rel_err(small, want), rel_err(small, base)
-    print(f"forward on 128- / 64-row tiles ({len(coords)} rows): vs oracle {e:.2e}, vs the default kernels {d:.2e}")
-    assert m.last_spconv_math == "split16" and e < REL and d < 5e-6 and rel_err(base, want) < REL
-
-
 @pytest.mark.parametrize("ks", [5, 3])
 def test_staged_first_convolution_matches_the_probing_kernel_and_the_oracle(ks):
     """conv1_bf_kernel (Z-ordered maps: the block feature vectors of a 256-parent tile's neighbourhood staged in LDS, the fine rows
     grouped by parity class, a K = 27 product over level-1 blocks) against conv1_mfma_kernel (octree probing per fine row, products
     per window position) - the same products in another order, so the features agree to fp32 rounding - and against the oracle; two clouds in a batch, non-unit features with planted zeros, both
-    window sizes; the strided convolutions through the staged kernel ride along (eyoc_spconv_select_down_kernel)."""
+    window sizes."""
     import eyoc_amd
     from eyoc_amd import synthetic as syn
     from oracle import resunet as orr
@@ -639,17 +525,15 @@ def test_staged_first_convolution_matches_the_probing_kernel_and_the_oracle(ks):
     m.spconv_math = "split16"
     want = orr.resunet_forward(sd, coords, feats, conv1_kernel_size=ks).numpy()
     prev_order = lib.eyoc_maps_internal_order(1) - 2                   # Z-ordered maps whatever the size
-    prev_c1, prev_dn = lib.eyoc_spconv_select_conv1_kernel(-1), lib.eyoc_spconv_select_down_kernel(-1)
+    prev_c1 = lib.eyoc_spconv_select_conv1_kernel(-1)
     outs = {}
     try:
         for staged in (0, 1):
             lib.eyoc_spconv_select_conv1_kernel(staged)
-            lib.eyoc_spconv_select_down_kernel(staged)
             outs[staged] = _forward(m, coords, feats)
             assert m.last_spconv_math == "split16"
     finally:
         lib.eyoc_spconv_select_conv1_kernel(prev_c1)
-        lib.eyoc_spconv_select_down_kernel(prev_dn)
         lib.eyoc_maps_internal_order(prev_order)
     e1, e0 = rel_err(outs[1], want), rel_err(outs[0], want)
     d = rel_err(outs[1], outs[0])
