@@ -584,7 +584,7 @@ static int knn_run(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c,
     bm_floats += (long long)eyoc::cdiv(seg_b[s + 1] - seg_b[s], 16) * 3 * 64 * 4;   // 3 x 64 float4 per tile of 16 targets
   }
   const bool prefilter = prefilter_env != 0 && !dot && !second_dev && !dist_dev && dist_type != 1 && c == 32 && max_nb > 0 &&
-                         (waves >= 512 || prefilter_env == 2);
+                         (waves >= 512 || prefilter_env == 2);   // (round 5: a single pair - 79 waves, each walking all 5000 targets - takes 0.15 ms here against 0.10 in the exact kernel)
   const size_t off_bt = eyoc::align_up((size_t)n_total * sizeof(unsigned long long));
   const size_t off_bm = eyoc::align_up(off_bt + (size_t)bt_floats * sizeof(float) + 64);
   const size_t off_an = eyoc::align_up(off_bm + (prefilter ? (size_t)bm_floats * sizeof(float) : 0));

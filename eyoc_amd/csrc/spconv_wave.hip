@@ -448,11 +448,11 @@ int launch_spconv_wave(const SpconvArgs& a_in, hipStream_t st) {
     // per unit (256 MFMAs), the whole 512-register file for one wave (no spills), the item's bookkeeping shared by
     // its slices.  Measured +10..20 % on the 128/256-channel layers, -5 % on the 64-channel ones (which keep 64-row
     // tiles at two waves per SIMD).
-    if (wide && a.cin >= 128) {
-      const long long waves128 = (long long)cdiv(a.n_out, 128) * (a.cout / 64);
+    const long long waves128 = (long long)cdiv(a.n_out, 128) * (a.cout / 64);
+    if (wide && a.cin >= 128 && waves128 >= 512) {
       a.small_rows = waves128 < 3000 ? a.n_out / 4 / 128 * 128 : 0;
       launch_wave_cfg<64, 128, 64, 4, 1>(a, st);
-    } else if (wide) {
+    } else if (wide) {      // (also the 128-channel-input layers of a single pair: 72 waves of 128 rows on 1024 SIMDs last twice as long as 144 of 64)
       launch_wave_cfg<64, 64, 64, 2>(a, st);
     } else {
       launch_wave_cfg<64, 64, 32, 2>(a, st);

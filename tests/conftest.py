@@ -29,3 +29,47 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _memoised_oracle_forward():
+    """The CPU oracle's plain eval forward is the slowest thing the GPU tests do (10-20 s for a 31k-voxel cloud), and several tests -
+    and every parametrisation of a test - ask it for the same cloud and weights again.  Within a session identical calls (same
+    weight VALUES, coordinates, features and options; no intermediates, no training mode, no supplied maps) return a copy of the
+    first answer.  The oracle itself is untouched."""
+    import hashlib
+
+    import numpy as np
+    try:
+        from oracle import resunet as orr
+    except Exception:                                   # noqa: BLE001 - no oracle, nothing to memoise
+        yield
+        return
+    real, cache = orr.resunet_forward, {}
+
+    def digest(*arrays):
+        h = hashlib.sha1()
+        for a in arrays:
+            a = np.ascontiguousarray(a.detach().cpu().numpy() if hasattr(a, "detach") else a)
+            h.update(str((a.dtype, a.shape)).encode())
+            h.update(a.tobytes())
+        return h.hexdigest()
+
+    def cached(sd, coords, feats, normalize_feature=True, conv1_kernel_size=5, maps=None, return_intermediate=False, dtype=None, **kw):
+        import torch
+        dtype = torch.float32 if dtype is None else dtype
+        if maps is not None or return_intermediate or kw:
+            return real(sd, coords, feats, normalize_feature=normalize_feature, conv1_kernel_size=conv1_kernel_size, maps=maps,
+                        return_intermediate=return_intermediate, dtype=dtype, **kw)
+        try:
+            key = (digest(*[sd[k] for k in sorted(sd)]), tuple(sorted(sd)), digest(coords, feats), bool(normalize_feature),
+                   int(conv1_kernel_size), str(dtype))
+        except Exception:                               # noqa: BLE001 - anything unhashable: just run it
+            return real(sd, coords, feats, normalize_feature=normalize_feature, conv1_kernel_size=conv1_kernel_size, dtype=dtype)
+        if key not in cache:
+            cache[key] = real(sd, coords, feats, normalize_feature=normalize_feature, conv1_kernel_size=conv1_kernel_size, dtype=dtype)
+        return cache[key].clone()
+
+    orr.resunet_forward = cached
+    yield
+    orr.resunet_forward = real
