@@ -90,3 +90,26 @@ def match_pair_case(kind, seed, n0, n1, c=32):
         s1 = (0.5 + 1.1 * _u(seed + 6, n1)).astype(np.float32)
         return F0 * s0[:, None], F1 * s1[:, None]
     raise ValueError(kind)
+
+
+def label_batch_case(seed, sizes=((1500, 1300), (800, 2000), (1000, 1000))):
+    """A batch of cloud pairs for ``match_and_filter_corr`` (G10): coordinates around two sensors (norms on both sides of the 20 m
+    spherical radius and across the cells of the similarity tables), unit features of which half are shared with noise."""
+    C0s, F0s, C1s, F1s = [], [], [], []
+    for k, (n0, n1) in enumerate(sizes):
+        C0s.append(((_u(seed + 10 * k, n0, 3) - 0.5) * 120).astype(np.float32))
+        C1s.append(((_u(seed + 10 * k + 1, n1, 3) - 0.5) * 120).astype(np.float32))
+        F0, F1 = nn_case(seed + 10 * k + 2, n0, n1, noise=0.15)
+        F0s.append(F0); F1s.append(F1)
+    return C0s, F0s, C1s, F1s
+
+
+def dist_sim_table(seed=0):
+    """A similarity table of the reference's shape family (config/dist_sim_plot/*.npz: six float64 slices [gap cells, distance
+    cells]) - synthetic data; the reference's own tables stay with the reference."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for i, shape in enumerate([(12, 16), (18, 16), (20, 18), (20, 18), (20, 18), (20, 18)]):
+        gy, gx = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), indexing="ij")
+        out[i] = np.clip(0.85 * np.exp(-0.12 * gy - 0.05 * gx) + 0.05 * rng.normal(size=shape), 0.0, 1.0)
+    return out

@@ -16,6 +16,7 @@ reference's numeric outputs only.
   g7_loss.npz    lib.trainer.CorrespondenceExtensionTrainer.contrastive_hardest_negative_loss (lib/trainer.py:935-991): both
                  loss terms AND d(pos + neg)/dF0, /dF1, global ``np.random`` seeded per case
   g8_labels.npz  lib.trainer.CorrespondenceExtensionTrainer.calculate_ratio_test / get_topk_matches (lib/trainer.py:993-1016)
+  g10_match_filter.npz  lib.trainer.CorrespondenceExtensionTrainer.match_and_filter_corr (lib/trainer.py:1025-1151) with STORED K = 2 neighbours
   g9_eval.npz    scripts.test_kitti.find_corr / random_sample / apply_transform / evaluate_nn_dist (scripts/test_kitti.py:28-73)
 ``lib.trainer`` and ``scripts.test_kitti`` import through ``_refimport.install()`` (codec alias + EMPTY stand-ins for the
 absent libraries; no arithmetic is stubbed).
@@ -260,7 +261,80 @@ def g9():
     np.savez_compressed(os.path.join(HERE, "g9_eval.npz"), **out)
 
 
+G10_CASES = [("Lowe", "Spherical", None), ("Lowe", "Similarity", [3, 17, 40]), ("Lowe", "None", None), ("None", "Spherical", None)]
+
+
+def g10():
+    """The reference's own ``match_and_filter_corr`` (lib/trainer.py:1025-1151) - re-collation with the collate biases, top-k in both
+    directions, spherical and similarity filters - run unmodified on a batch of three pairs.  Two pytorch3d names it calls are absent
+    here and are given bodies FOR THIS FIXTURE ONLY, neither of them the code under test:
+      * ``pytorch3d.structures.Pointclouds``: a list -> zero-padded tensor holder (``features_padded``, ``num_points_per_cloud``);
+      * ``knn_points(K = 2)``: returns STORED neighbours - the two smallest squared distances and the nearest index of every row,
+        computed by the numpy restatement ``oracle.labels.knn2`` (the neighbour search itself is pinned elsewhere: G1 / G8 inputs) and
+        padded with zeros like pytorch3d pads rows beyond a cloud's length.
+    The similarity table is synthetic (``_inputs.dist_sim_table``; set on the trainer so that it does not read the reference's file)."""
+    from types import SimpleNamespace
+    import lib.trainer as lt
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle.labels import knn2
+
+    class Pointclouds:
+        def __init__(self, points, features=None):
+            self.f = [torch.as_tensor(f) for f in features]
+
+        def features_padded(self):
+            n = max(len(f) for f in self.f)
+            out = torch.zeros((len(self.f), n, self.f[0].shape[1]), dtype=self.f[0].dtype)
+            for i, f in enumerate(self.f):
+                out[i, :len(f)] = f
+            return out
+
+        def num_points_per_cloud(self):
+            return torch.tensor([len(f) for f in self.f])
+
+    C0s, F0s, C1s, F1s = gi.label_batch_case(101)
+    stored = []
+    for A, B in ((F0s, F1s), (F1s, F0s)):
+        n = max(len(a) for a in A)
+        d = np.zeros((len(A), n, 2), np.float32)
+        ix = np.zeros((len(A), n, 2), np.int64)
+        for i, (a, b) in enumerate(zip(A, B)):
+            idx, d1, d2 = knn2(a, b)
+            d[i, :len(a), 0], d[i, :len(a), 1], ix[i, :len(a), 0] = d1, d2, idx
+        stored.append((torch.from_numpy(d), torch.from_numpy(ix)))
+    out = {"cases": np.array(json.dumps(G10_CASES))}
+    table = gi.dist_sim_table()
+    real_pc, real_knn = lt.pytorch3d.structures.Pointclouds, getattr(lt, "knn_points", None)
+    try:
+        lt.pytorch3d.structures.Pointclouds = Pointclouds
+        for i, (ff, sf, fd) in enumerate(G10_CASES):
+            calls = []
+
+            def knn_points(p1, p2, n1, n2, K=1):
+                calls.append(K)
+                d, ix = stored[len(calls) - 1]
+                return d[:, :, :K].clone(), ix[:, :, :K].clone(), None
+
+            lt.knn_points = knn_points
+            me = SimpleNamespace(config=SimpleNamespace(similarity_thresh=0.3, pretraining_dataset="kitti"),
+                                 dist_sim_map={k: torch.tensor(v) for k, v in table.items()})
+            me.calculate_ratio_test = lambda d: lt.CorrespondenceExtensionTrainer.calculate_ratio_test(me, d)
+            me.get_topk_matches = lambda d, ix, k: lt.CorrespondenceExtensionTrainer.get_topk_matches(me, d, ix, k)
+            matches, unc = lt.CorrespondenceExtensionTrainer.match_and_filter_corr(
+                me, [torch.from_numpy(c) for c in C0s], [torch.from_numpy(f) for f in F0s], [torch.from_numpy(c) for c in C1s],
+                [torch.from_numpy(f) for f in F1s], radius=20, feature_filter=ff, spatial_filter=sf, frame_distance=fd)
+            assert len(calls) == 2
+            out[f"matches{i}"] = matches.numpy().astype(np.int64)
+            for p, u in enumerate(unc):
+                out[f"unc{i}_{p}"] = u.numpy().astype(np.int64)
+    finally:
+        lt.pytorch3d.structures.Pointclouds = real_pc
+        if real_knn is not None:
+            lt.knn_points = real_knn
+    np.savez_compressed(os.path.join(HERE, "g10_match_filter.npz"), **out)
+
+
 if __name__ == "__main__":
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10):
         fn()
         print("wrote", fn.__name__)

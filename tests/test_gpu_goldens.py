@@ -62,6 +62,24 @@ def test_ratio_test_and_topk_match_the_reference(golden_dir, i):
     np.testing.assert_array_equal(idx.cpu().numpy()[src][uniq], g[f"tgt{i}"][uniq])
 
 
+@pytest.mark.parametrize("i", [0, 1, 2, 3])
+def test_match_and_filter_corr_matches_the_reference(golden_dir, i):
+    """eyoc_amd.labels.match_and_filter_corr (eyoc_knn2, eyoc_lowe_topk, eyoc_pair_filter / _similarity and the re-collation) against
+    the reference's own method (G10, lib/trainer.py:1025-1151 run unmodified on three pairs with stored K = 2 neighbours): collated
+    matches and per-pair filtered survivors, up to the order ``torch.topk`` leaves open between equal weights."""
+    from eyoc_amd import labels
+    from test_oracle_golden import same_rows_up_to_topk_ties
+    g = _load(golden_dir, "g10_match_filter.npz")
+    ff, sf, fd = json.loads(str(g["cases"]))[i]
+    C0s, F0s, C1s, F1s = gi.label_batch_case(101)
+    t = lambda xs: [torch.from_numpy(x) for x in xs]
+    m, unc = labels.match_and_filter_corr(t(C0s), t(F0s), t(C1s), t(F1s), radius=20, feature_filter=ff, spatial_filter=sf, frame_distance=fd,
+                                          dist_sim_map=gi.dist_sim_table(), similarity_thresh=0.3)
+    same_rows_up_to_topk_ties(m.numpy(), g[f"matches{i}"], "matches")
+    for p, u in enumerate(unc):
+        same_rows_up_to_topk_ties(u.cpu().numpy(), g[f"unc{i}_{p}"], f"pair {p}")
+
+
 @pytest.mark.parametrize("i", [0, 1, 2])
 def test_find_corr_matches_the_reference(golden_dir, i):
     """scripts/test_kitti.py:28-42: drawn rows exact, neighbours exact up to fp32 near-ties of the distance."""
