@@ -306,6 +306,41 @@ def pipelined_rate(pipe, batch, reps, warm=3, tail=True):
     return (time.perf_counter() - t0) / reps
 
 
+def train_step_ms(pair, sd, device, iters=10):
+    """Wall time of a training iteration on one pair (its own model instance: the timed eval model is not touched)."""
+    from scipy.spatial import cKDTree
+    from eyoc_amd.autograd import contrastive_hardest_negative_loss
+    T = np.asarray(pair["T_gt"], np.float64)
+    d, j = cKDTree(pair["xyz1"].astype(np.float64)).query(pair["xyz0"].astype(np.float64) @ T[:3, :3].T + T[:3, 3])
+    i = np.nonzero(d < 0.3)[0]
+    pos = torch.from_numpy(np.stack([i, j[i]], 1))
+    model = eyoc_amd.load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, conv1_kernel_size=5, normalize_feature=True)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model = model.to(device).train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.8, weight_decay=1e-4)
+    coords = torch.from_numpy(syn.batch_coords([pair["coords0"], pair["coords1"]])).to(device)
+    feats = torch.ones((coords.shape[0], 1), device=device)
+    n0 = len(pair["coords0"])
+    rng = np.random.RandomState(0)
+
+    def step():
+        f = model(eyoc_amd.SparseTensor(feats, coordinates=coords)).F
+        lp, ln = contrastive_hardest_negative_loss(f[:n0], f[n0:], pos, num_pos=1024, num_hn_samples=2048, rng=rng)
+        opt.zero_grad()
+        (lp + ln).backward()
+        opt.step()
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    return {"value": (time.perf_counter() - t0) / iters * 1e3, "unit": "ms per iteration", "voxels": int(coords.shape[0]), "positives": int(len(pos)),
+            "note": "maps + model.train()(x) (batch-statistics norms, autograd through libeyoc_hip.so) + hardest-contrastive loss + backward + SGD step"}
+
+
 def worker(args):
     t_start = time.perf_counter()
 
@@ -755,6 +790,13 @@ def worker(args):
                                        "note": "one pass over a 545-pair split on ONE GPU through the timed loop (ragged last batch); the 8-GPU "
                                                "half of configs[3] is `--gpus 8 --total-pairs 545`, unmeasured on hardware"}
             log("545-pair split done")
+        # one training iteration (lib/trainer.py:1655-1676): maps + train-mode forward (batch statistics) + hardest-
+        # contrastive loss + backward + SGD step on the first pair's two ~30k-voxel clouds, through model.train()(x)
+        try:
+            out["train_step_ms"] = train_step_ms(pairs0[0], sd, device)
+        except Exception as e:      # noqa: BLE001 - an extra must not cost the headline
+            out["train_step_ms"] = {"error": repr(e)[:200]}
+        log("training step done")
         # RANSAC cost against the inlier ratio (the number of surviving hypotheses grows like p^4)
         sweep = []
         for ratio in (0.0, 0.15, 0.3, 0.6):

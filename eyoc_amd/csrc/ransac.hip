@@ -15,6 +15,8 @@
 //      The largest count of each pair is kept with an atomicMax.
 //   3. rmse: only the survivors that reach the largest count (almost always one) get their inlier RMSE.
 //   4. select: single workgroup arg-max with the total order (more inliers, lower RMSE, lower h).
+#include <atomic>
+
 #include "pose_math.h"
 
 using namespace eyoc;
@@ -569,11 +571,14 @@ namespace {
 struct RansacLayout {
   size_t off_cnt, off_rec, off_surv, off_cnts, off_rmse, off_xf, off_rs, off_be, off_pm, bytes;
 };
-int g_ransac_cap_t = 1 << 20;   // eyoc_ransac_transform_store
-inline int ransac_cap_t(int H) { return H < g_ransac_cap_t ? H : g_ransac_cap_t; }
-RansacLayout ransac_layout(int chunk, int total, int H) {
+// eyoc_ransac_transform_store / eyoc_ransac_select_pruning: process-wide test knobs.  Every entry point reads each ONCE (a snapshot
+// that its layout, its chunk size and its kernels all use), so a setter racing a call cannot make the sizes of one call disagree
+std::atomic<int> g_ransac_cap_t{1 << 20};
+std::atomic<int> g_ransac_prune{1};
+inline int ransac_cap_t(int H, int store) { return H < store ? H : store; }
+RansacLayout ransac_layout(int chunk, int total, int H, int store) {
   RansacLayout l;
-  const int cap_t = ransac_cap_t(H);
+  const int cap_t = ransac_cap_t(H, store);
   l.off_cnt = 0;
   l.off_rec = align_up((size_t)chunk * CNT_STRIDE * 4);
   l.off_surv = align_up(l.off_rec + (size_t)total * 24);
@@ -587,26 +592,25 @@ RansacLayout ransac_layout(int chunk, int total, int H) {
   return l;
 }
 // the largest chunk (n_pairs capped at CHUNK, then halved) whose layout stays within `budget` bytes; never below one pair
-int ransac_pick_chunk(int n_pairs, int total, int H, size_t budget) {
+int ransac_pick_chunk(int n_pairs, int total, int H, size_t budget, int store) {
   int chunk = n_pairs < CHUNK ? n_pairs : CHUNK;
-  while (chunk > 1 && ransac_layout(chunk, total, H).bytes > budget) chunk >>= 1;
+  while (chunk > 1 && ransac_layout(chunk, total, H, store).bytes > budget) chunk >>= 1;
   return chunk;
 }
-int g_ransac_prune = 1;       // eyoc_ransac_select_pruning
 
 int ransac_run(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int64_t* corr_tgt_dev, const int32_t* seg_src_host,
                const int32_t* seg_tgt_host, int n_pairs, const eyoc_ransac_params* p, eyoc_ransac_result* results_dev, char* sc,
-               int chunk, int max_n, hipStream_t st) {
+               int chunk, int max_n, int store, hipStream_t st) {
   const int H = p->max_iteration;
   const int total = seg_src_host[n_pairs];
-  const int cap_t = ransac_cap_t(H);
-  const RansacLayout l = ransac_layout(chunk, total, H);
+  const int cap_t = ransac_cap_t(H, store);
+  const RansacLayout l = ransac_layout(chunk, total, H, store);
   PairArgs a;
   a.rec = (float*)(sc + l.off_rec); a.seed = p->seed; a.H = H; a.edge_sim = p->edge_similarity; a.max_dist = p->max_distance;
   a.n_surv = (int*)(sc + l.off_cnt); a.surv = (int*)(sc + l.off_surv); a.cnts = (int*)(sc + l.off_cnts);
   a.rmse = (unsigned int*)(sc + l.off_rmse); a.xf = (double*)(sc + l.off_xf); a.cap_t = cap_t;
   a.rec_sorted = (float*)(sc + l.off_rs); a.bucket_end = (int*)(sc + l.off_be); a.pmax = (double*)(sc + l.off_pm);
-  const int pruned = g_ransac_prune && max_n <= 8192 ? 1 : 0;
+  const int pruned = g_ransac_prune.load() && max_n <= 8192 ? 1 : 0;
   const bool in_lds = max_n <= LDS_RECORDS;
   const size_t lds_bytes = in_lds ? (size_t)max_n * 24 : 0;
   if (in_lds) {
@@ -661,21 +665,18 @@ int ransac_validate(const float* src_dev, const float* tgt_dev, const int64_t* c
 }  // namespace
 
 extern "C" int eyoc_ransac_transform_store(int survivors) {
-  const int prev = g_ransac_cap_t;
-  if (survivors >= 1) g_ransac_cap_t = survivors;
-  return prev;
+  return survivors >= 1 ? g_ransac_cap_t.exchange(survivors) : g_ransac_cap_t.load();
 }
 
 extern "C" int eyoc_ransac_select_pruning(int on) {
-  const int prev = g_ransac_prune;
-  if (on == 0 || on == 1) g_ransac_prune = on;
-  return prev;
+  return (on == 0 || on == 1) ? g_ransac_prune.exchange(on) : g_ransac_prune.load();
 }
 
 extern "C" size_t eyoc_ransac_workspace_bytes(int n_pairs, int total_corr, int max_iteration, size_t budget_bytes) {
   if (n_pairs < 1 || total_corr < 0 || max_iteration < 1) return 0;
-  const int chunk = ransac_pick_chunk(n_pairs, total_corr, max_iteration, budget_bytes ? budget_bytes : ~(size_t)0);
-  return ransac_layout(chunk, total_corr, max_iteration).bytes;
+  const int store = g_ransac_cap_t.load();
+  const int chunk = ransac_pick_chunk(n_pairs, total_corr, max_iteration, budget_bytes ? budget_bytes : ~(size_t)0, store);
+  return ransac_layout(chunk, total_corr, max_iteration, store).bytes;
 }
 
 extern "C" int eyoc_ransac_batched_ws(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int64_t* corr_tgt_dev,
@@ -688,12 +689,13 @@ extern "C" int eyoc_ransac_batched_ws(eyoc_ctx* ctx, const float* src_dev, const
   int rc = ransac_validate(src_dev, tgt_dev, corr_tgt_dev, seg_src_host, seg_tgt_host, n_pairs, p, results_dev, &max_n);
   if (rc) return rc;
   const int total = seg_src_host[n_pairs];
-  const int chunk = ransac_pick_chunk(n_pairs, total, p->max_iteration, workspace_bytes);
-  const size_t need = ransac_layout(chunk, total, p->max_iteration).bytes;
+  const int store = g_ransac_cap_t.load();
+  const int chunk = ransac_pick_chunk(n_pairs, total, p->max_iteration, workspace_bytes, store);
+  const size_t need = ransac_layout(chunk, total, p->max_iteration, store).bytes;
   EYOC_REQUIRE(need <= workspace_bytes, EYOC_ERR_WORKSPACE,
                "eyoc_ransac_batched_ws: workspace %zu < %zu bytes (one pair per launch; eyoc_ransac_workspace_bytes)", workspace_bytes, need);
   return ransac_run(ctx, src_dev, tgt_dev, corr_tgt_dev, seg_src_host, seg_tgt_host, n_pairs, p, results_dev, (char*)workspace_dev, chunk,
-                    max_n, (hipStream_t)stream);
+                    max_n, store, (hipStream_t)stream);
 }
 
 // the same with scratch the context owns (grow-only): the chunk is sized from the device's FREE memory - at most a quarter
@@ -708,21 +710,28 @@ extern "C" int eyoc_ransac_batched(eyoc_ctx* ctx, const float* src_dev, const fl
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   const int total = seg_src_host[n_pairs];
-  size_t free_b = 0, total_b = 0;
-  EYOC_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
-  size_t budget = (free_b + ctx->scratch_bytes) / 4;
-  if (budget > ((size_t)16 << 30)) budget = (size_t)16 << 30;
-  if (budget < ctx->scratch_bytes) budget = ctx->scratch_bytes;          // what is already there is free to use
-  int chunk = ransac_pick_chunk(n_pairs, total, p->max_iteration, budget);
+  const int store = g_ransac_cap_t.load();
+  // the scratch already there is free to use: the device is only asked how much memory it has left (a driver round trip) when the
+  // largest chunk does not fit into it - i.e. on the first call of a batch shape, not on the hot path
+  int chunk = ransac_pick_chunk(n_pairs, total, p->max_iteration, ctx->scratch_bytes, store);
+  const int want = n_pairs < CHUNK ? n_pairs : CHUNK;
+  if (chunk < want || ransac_layout(chunk, total, p->max_iteration, store).bytes > ctx->scratch_bytes) {
+    size_t free_b = 0, total_b = 0;
+    EYOC_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
+    size_t budget = (free_b + ctx->scratch_bytes) / 4;
+    if (budget > ((size_t)16 << 30)) budget = (size_t)16 << 30;
+    if (budget < ctx->scratch_bytes) budget = ctx->scratch_bytes;
+    chunk = ransac_pick_chunk(n_pairs, total, p->max_iteration, budget, store);
+  }
   for (;;) {
-    rc = ctx->ensure_scratch(ransac_layout(chunk, total, p->max_iteration).bytes, st);
+    rc = ctx->ensure_scratch(ransac_layout(chunk, total, p->max_iteration, store).bytes, st);
     if (rc == EYOC_OK) break;
     if (chunk == 1) return rc;
     (void)hipGetLastError();                                             // the failed hipMalloc's sticky error
     chunk >>= 1;
   }
   return ransac_run(ctx, src_dev, tgt_dev, corr_tgt_dev, seg_src_host, seg_tgt_host, n_pairs, p, results_dev, (char*)ctx->scratch, chunk,
-                    max_n, st);
+                    max_n, store, st);
 }
 
 extern "C" int eyoc_ransac(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int64_t* corr_tgt_dev, int n,
