@@ -617,14 +617,19 @@ __device__ __forceinline__ void d_seed_dense(const unsigned long long* __restric
       const int b = __builtin_ctzll(u);
       u &= u - 1;
       const unsigned long long* __restrict__ tj = tight + (size_t)(jw * 64 + b) * words + w0;   // uniform -> scalar loads
-      unsigned int acc = 0;
+      // every word unconditionally: the S words past the row's end are zero, so what the candidate's pointer reads there (the next
+      // row, or the workspace arrays behind the matrix) does not count - and without a guard per word the compiler merges the
+      // uniform loads into s_load_dwordx16 (with the guards it issued one s_load_dwordx2 + s_waitcnt per word: 0.33 of the VALU rate)
+      unsigned int a0 = 0, a1 = 0, a2 = 0, a3 = 0;          // four chains: v_bcnt accumulates into its own result
 #pragma unroll
-      for (int t = 0; t < W; ++t)
-        if (t < wn) {
-          const unsigned long long x = S[t] & tj[t];
-          acc += __popc((unsigned int)x) + __popc((unsigned int)(x >> 32));
-        }
-      part[wave][b][lane] = (unsigned short)acc;
+      for (int t = 0; t < W; t += 2) {
+        const unsigned long long x = S[t] & tj[t], y = S[t + 1] & tj[t + 1];
+        a0 += __popc((unsigned int)x);
+        a1 += __popc((unsigned int)(x >> 32));
+        a2 += __popc((unsigned int)y);
+        a3 += __popc((unsigned int)(y >> 32));
+      }
+      part[wave][b][lane] = (unsigned short)((a0 + a1) + (a2 + a3));
     }
     __syncthreads();
     {   // wave k: candidates 16 k .. 16 k + 15 of this word, 64 seeds: sum of the four partial counts, masked by the seed's hard bit

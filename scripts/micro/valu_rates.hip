@@ -19,6 +19,17 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
         if (MODE == 4) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[i].x) : "v"(c2.x));
       }
   }
+  if (MODE == 5) {                                          // v_fma_f64 (RANSAC's k_count: 15-16 of them per residual)
+    double d[8];
+    for (int i = 0; i < 8; ++i) d[i] = threadIdx.x * 0.01 + i;
+    const double a = 1.0001, b = 0.5;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[i]) : "v"(a), "v"(b));
+    for (int i = 0; i < 8; ++i) v[i].x += (float)d[i];
+  }
   float s = 0;
   for (int i = 0; i < 8; ++i) s += v[i].x + v[i].y;
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
@@ -41,7 +52,7 @@ void run(const char* name, int blocks) {
 int main() {
   for (int blocks : {256, 1024}) {
     run<0>("v_fma_f32", blocks); run<1>("v_pk_fma_f32", blocks); run<2>("v_pk_add_f32", blocks); run<3>("v_pk_mul_f32", blocks);
-    run<4>("v_add_f32", blocks);
+    run<4>("v_add_f32", blocks); run<5>("v_fma_f64", blocks);
   }
   return 0;
 }
