@@ -683,7 +683,7 @@ def worker(args):
     # WRITE_SIZE, separate passes; profiles/README.md) - quoted only when they were taken on this workload
     # AND on these kernel sources (the profile records a hash of eyoc_amd/csrc; a kernel change without a profile refresh must
     # not keep quoting the old counters)
-    for tag in ("r4", "r3", "r2", "r1"):
+    for tag in ("r5", "r4", "r3", "r2", "r1"):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_spconv_traffic.json")))
             if prof["workload"] == out["config"]["workload"] and prof.get("csrc_sha16") != csrc_sha16():
@@ -711,6 +711,31 @@ def worker(args):
         except (OSError, KeyError, ValueError):
             pass
 
+    # the registration back-end's own roofline (RANSAC's scorer, SC2-PCR's kernels): VALU wave-instructions per launch from
+    # the committed counter pass (rocprofv3 --pmc SQ_INSTS_VALU: profiles/r5_valu.json, quoted only for these kernel sources) over the
+    # kernel's duration in the committed trace, against the issue rate scripts/micro/valu_rates.hip measures for the instruction that
+    # dominates it (v_fma_f64 for the residual sweep)
+    sc2_roof = None
+    try:
+        vp = json.load(open(os.path.join(ROOT, "profiles", "r5_valu.json")))
+        if vp.get("csrc_sha16") == csrc_sha16():
+            rates = vp["valu_issue_rates_G_wave_inst_per_s"]
+            if cfg.use_RANSAC:
+                kc = vp["ransac"]["k_count"]
+                out["ransac_roofline"] = {"bound": "valu (fp64)", "kernel": "k_count (the residual sweep: 15 v_fma_f64-class instructions per residual)",
+                                          "achieved": kc["G_wave_inst_per_s"], "peak": rates["v_fma_f64"], "unit": "G wave-instructions/s",
+                                          "frac": kc["G_wave_inst_per_s"] / rates["v_fma_f64"], "ms_per_launch": kc["ms_per_launch"],
+                                          "measured_in_run": False, "source": "profiles/r5_valu.json, profiles/r5_kernel_stats.csv, profiles/r5_valu_rates.txt",
+                                          "other_kernels": {k: v for k, v in vp["ransac"].items() if k != "k_count"}}
+            km = vp["sc2pcr"]["k_masks"]
+            sc2_roof = {"bound": "valu", "kernel": "k_masks (symmetric cross-length tiles) - the back-end's kernels are VALU / latency work, none touches HBM twice",
+                        "achieved": km["G_wave_inst_per_s"], "peak": rates["v_add_f32"], "unit": "G wave-instructions/s",
+                        "frac": km["G_wave_inst_per_s"] / rates["v_add_f32"], "measured_in_run": False,
+                        "kernels": vp["sc2pcr"], "source": "profiles/r5_valu.json, profiles/r5_sc2pcr_kernel_stats.csv"}
+            if not cfg.use_RANSAC:
+                out["sc2pcr_roofline"] = sc2_roof
+    except (OSError, KeyError, ValueError):
+        sc2_roof = None
     extras = world == 1 and not total_mode and not args.no_extras and cfg.use_RANSAC
     if extras:
         pairs0 = [gen[scene_of(i)] for i in mine]
@@ -830,6 +855,7 @@ def worker(args):
             t_np = pipelined_rate(pipe2, bn, 10, 3)
             evn = pipe2.evaluate(bn, pipe2.register(bn))
             out["nuscenes_sc2pcr_path"] = {"pairs_per_s": bn.P / t_np, "synchronised_calls_pairs_per_s": bn.P / t_n, "success_rate": float(np.mean([e["success"] for e in evn])),
+                                           "sc2pcr_roofline": sc2_roof,
                                            "pairs_per_step": bn.P, "mean_voxels_per_cloud": bn.voxels // (2 * bn.P),
                                            "planted_min": int(min(bn.planted)) if bn.planted else None}
         log("sc2pcr path done")
