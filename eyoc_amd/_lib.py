@@ -95,6 +95,7 @@ PROTOTYPES = {
     "eyoc_spconv_select_st_kernel": (_i, [_i]),
     "eyoc_spconv_st_split_below": (_i, [_i]),
     "eyoc_spconv_st_group_rows": (_i, [_i]),
+    "eyoc_spconv_st_ksplit": (_i, [_i]),
     "eyoc_spconv_local_rulebook_bytes": (_sz, [_i]),
     "eyoc_spconv_build_local_rulebook": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "eyoc_spconv_staged": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),

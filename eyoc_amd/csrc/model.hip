@@ -313,6 +313,7 @@ size_t eyoc_model_workspace_bytes(const eyoc_model* m, const eyoc_maps* maps) {
   if (!m || !maps) return 0;
   size_t b = 0;
   for (int i = B_X1; i < B_OUT; ++i) b += align_up((size_t)maps->rows[m->bufs[i].level] * m->bufs[i].width * sizeof(float));
+  b += align_up(KS_PART_BYTES);                                        // split-K scratch of the staged kernel on small inputs
   return b + 256;
 }
 
@@ -366,6 +367,7 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
   buf[B_IN] = const_cast<float*>(feats_dev);
   buf[B_OUT] = out_dev;
   for (int i = B_X1; i < B_OUT; ++i) buf[i] = cv.take<float>((size_t)maps->rows[m->bufs[i].level] * m->bufs[i].width);
+  float* ks_part = cv.take<float>(KS_PART_BYTES / 4);
   // arithmetic of the sparse convolutions: SPLIT16 needs the wave-private kernel for EVERY layer (only it reads and
   // writes the format), which round 1 measured to pay off once the finest level alone fills the chip (>= 4096 wave tiles ~ 4 KITTI
   // pairs); small batches stay on fp32, where the launcher picks the workgroup-tiled kernel per layer
@@ -455,7 +457,7 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
         a.out_split = p.out_buf != B_OUT;
         a.range = m->range;
         // stride-1 layers on Z-ordered rows: tile-local input stage (spconv_st.hip)
-        if (p.map == M_S1 && p.cin >= 32 && p.cin % 32 == 0) a.local = maps->local_s1[p.level];
+        if (p.map == M_S1 && p.cin >= 32 && p.cin % 32 == 0) { a.local = maps->local_s1[p.level]; a.ks_part = ks_part; }
         if (p.map == M_UP && p.cin % 32 == 0 && p.cout % 64 == 0) a.local_up = maps->local_up[p.level];   // spconv_up.hip
         if (p.map == M_UP && p.cin % 32 == 0 && p.cout % 64 == 0) a.local_upc = maps->local_upc[p.level]; // spconv_upc.hip (class-major tiles)
       }

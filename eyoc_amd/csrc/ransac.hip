@@ -154,7 +154,7 @@ __device__ inline bool hypothesis(const float* __restrict__ rec, unsigned int n,
 
 constexpr int CNT_STRIDE = 64;
 constexpr int GEN_THREADS = 1024;
-constexpr int GEN_BLOCKS_MIN = 8, GEN_BLOCKS_TOTAL = 512;   // workgroups per pair: 512 over the pairs of a launch (every workgroup copies its pair's records to LDS first: 64 per pair at 64 pairs per launch was 4096 copies of 120 KB), at least 8
+constexpr int GEN_BLOCKS_MIN = 8, GEN_BLOCKS_TOTAL = 256;   // workgroups per pair: 256 over the pairs of a launch - one per CU (512 = two rounds of workgroups, each copying the records again: a single pair took 104 us instead of 59) - (every workgroup copies its pair's records to LDS first: 64 per pair at 64 pairs per launch was 4096 copies of 120 KB), at least 8
 constexpr int LDS_RECORDS = 6016;                    // 6016 * 24 B = 141 KB of the 160 KB LDS (+ 16 KB of queues)
 
 __device__ inline unsigned long long pair_base(unsigned int seed, int b) {

@@ -42,7 +42,13 @@ struct SpconvArgs {
   // SPLIT16 range guard (see split16_guard below): device words {overflow flag, max |x| bits, probe switch} or NULL
   unsigned int* range = nullptr;
   eyoc_ctx* ctx = nullptr;         // the caller's context (per-device launch state, e.g. function attributes already set) or NULL
+  // staged stride-1 kernel on SMALL inputs (spconv_st.hip, round 5): scratch for splitting a tile's 32-channel input blocks over
+  // several workgroups - partial accumulators [KS_MAX_SLOTS][32 floats x 256 threads].  NULL: no split.
+  float* ks_part = nullptr;
 };
+constexpr int KS_MAX_SLOTS = 1024;                        // (workgroups x splits) a split launch may use: 32 KB of partial sums each
+constexpr size_t KS_PART_BYTES = (size_t)KS_MAX_SLOTS * 256 * 32 * 4;
+int select_st_ksplit(int on);                             // 1 (default) / 0: eyoc_spconv_st_ksplit
 
 // ---- SPLIT16 row format: every block of 32 channels takes 128 bytes (one cache line), the 32 fp16 "hi" halves (x rounded
 // to fp16) followed by the 32 fp16 "lo" halves (x - hi rounded to fp16): the same 4 bytes per channel as fp32, 22

@@ -1210,6 +1210,7 @@ int eyoc_spconv_staged(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* local_
 }
 
 int eyoc_spconv_st_group_rows(int on) { return eyoc::select_st_group_rows(on); }
+int eyoc_spconv_st_ksplit(int on) { return eyoc::select_st_ksplit(on); }
 
 int eyoc_spconv_select_up_kernel(int on) {
   const int prev = eyoc::g_up_kernel;

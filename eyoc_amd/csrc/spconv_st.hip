@@ -470,8 +470,14 @@ typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
 #include "spconv_st_loop_abl.inc"
 #endif
 
+// ksplit > 1 (small inputs, NH = 1 only; round 5): blockIdx.y = which share of the tile's (pass, 32-channel block) list this
+// workgroup multiplies.  A single pair's level-3 layer is 72 workgroups, each walking 8 blocks x 27 offsets one after the other -
+// 104 us for 8 GFLOP; split eight ways it is 576 workgroups of one block each.  Two launches: phase 0 stores every share's raw
+// accumulators, phase 1 (one workgroup per (tile, channel group), no stage, no loop) adds the shares in share order and runs the
+// epilogue.  (One launch with an arrival counter and the last workgroup summing was built first: its agent-scope fences - an L2
+// write-back and invalidate per workgroup on gfx950 - made a single pair 1 ms SLOWER.)
 template <int CC, int NH, int SKIP, int NWV = NW>
-__global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(SpconvArgs a, const unsigned char* __restrict__ local, int n_tiles) {
+__global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(SpconvArgs a, const unsigned char* __restrict__ local, int n_tiles, int ksplit, int phase) {
   constexpr int NTW = 2, CTW = NTW * 16, NC = 4;
   constexpr int CTG = CTW * NH * (NWV / NW);                            // NWV = 8: 4 row quarters x 2 channel halves, NH = 1
   constexpr int NITV = XROWS / (16 * NWV);
@@ -543,15 +549,20 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
     }
   };
 
-  load_rows(0);
+  if (!phase) load_rows(0);
   // pull the tile's rulebook entries (13.8 KB, last touched by the builder: HBM by now) into L2 while the stage is in flight: the
   // loop requests them only two offsets (~2000 cycles) ahead, less than an HBM round trip under load - one dword per 128-byte line
   int warm = 0;
-  if (threadIdx.x < 27 * 64 * 8 / 128) warm = *reinterpret_cast<const int*>(lr + 16 + UCAP * 4 + threadIdx.x * 128);
+  if (!phase && threadIdx.x < 27 * 64 * 8 / 128) warm = *reinterpret_cast<const int*>(lr + 16 + UCAP * 4 + threadIdx.x * 128);
   const int n_u = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(lr)[0]);
   const int n_pass = n_u > UMAX ? 2 : 1;
+  // this workgroup's share [i0, i1) of the (pass, block) list (everything without a split)
+  const int ks = __builtin_amdgcn_readfirstlane((int)blockIdx.y);
+  const int i0 = ks * (n_pass * nqb) / ksplit, i1 = phase ? 0 : (ks + 1) * (n_pass * nqb) / ksplit;     // phase 1: no block at all
   bool first = true;
   for (int pass = 0; pass < n_pass; ++pass) {
+    const int q_lo = max(i0 - pass * nqb, 0), q_hi = min(i1 - pass * nqb, nqb);
+    if (q_lo >= q_hi) continue;                                          // workgroup-uniform
     n_up = min(n_u - pass * UMAX, UMAX);
     if (pass > 0) load_rows(pass);
     // this wave's occupancy masks of the pass: 14 dwords through the scalar cache, shifted so that bit (k & 1) * 16 + 4 h + c
@@ -565,7 +576,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
     }
     // rulebook entries of (pass, k, h): 8 bytes at lb + lv + (k * 64 + h * 16) * 8
     const unsigned char* lb = lr + 16 + UCAP * 4 + ((size_t)pass * 27 * 64 + w0 * 16) * 8;
-    for (int qb = 0; qb < nqb; ++qb) {
+    for (int qb = q_lo; qb < q_hi; ++qb) {
       if (!first) __syncthreads();                                     // every wave is done with the previous block's rows
       first = false;
       stage(pass, qb);
@@ -621,6 +632,32 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
   }
 
   asm volatile("" :: "v"(warm));
+  if constexpr (NH == 1 && NWV == NW) {
+    if (ksplit > 1) {                                                    // launch-uniform
+      constexpr int NR4 = 8;                                             // 32 accumulator registers per thread = 8 float4
+      float4* P = reinterpret_cast<float4*>(a.ks_part) + (size_t)((tile * n_cg + cg) * ksplit) * NR4 * 256;
+      if (phase == 0) {
+        float4* mine = P + (size_t)ks * NR4 * 256 + threadIdx.x;
+#pragma unroll
+        for (int r = 0; r < NR4; ++r) {
+          const f32x16& A = r < 4 ? A0 : A1;
+          mine[r * 256] = make_float4(A[(r & 3) * 4], A[(r & 3) * 4 + 1], A[(r & 3) * 4 + 2], A[(r & 3) * 4 + 3]);
+        }
+        return;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { A0[i] = 0.f; A1[i] = 0.f; }
+      for (int k = 0; k < ksplit; ++k) {                                 // share order
+        const float4* src = P + (size_t)k * NR4 * 256 + threadIdx.x;
+#pragma unroll
+        for (int r = 0; r < NR4; ++r) {
+          const float4 v = src[r * 256];
+          f32x16& A = r < 4 ? A0 : A1;
+          A[(r & 3) * 4] += v.x; A[(r & 3) * 4 + 1] += v.y; A[(r & 3) * 4 + 2] += v.z; A[(r & 3) * 4 + 3] += v.w;
+        }
+      }
+    }
+  }
   // ---- epilogue straight from the registers.  The loop loads the weight rows permuted (gen_st_loop.py) so that lane (g, j)
   // holds, for row 64 h + 16 c + j, channels 8 g .. 8 g + 3 in tuple t = 0 and 8 g + 4 .. 8 g + 7 in tuple t = 1: 8 consecutive
   // channels = one 16-byte access per half of a SPLIT16 row (half as many memory instructions as 4-channel tuples)
@@ -752,6 +789,8 @@ constexpr int ST_VARIANTS = 28;
 constexpr int ST_VARIANTS = 3;
 #endif
 static std::atomic<int> g_st_split_below{1024};
+static std::atomic<int> g_st_ksplit{1};
+int select_st_ksplit(int on) { return (on == 0 || on == 1) ? g_st_ksplit.exchange(on) : g_st_ksplit.load(); }
 int select_st_split_below(int workgroups) { return workgroups >= 0 ? g_st_split_below.exchange(workgroups) : g_st_split_below.load(); }
 int select_st_variant(int v) { return (v >= 0 && v < ST_VARIANTS) ? g_st_variant.exchange(v) : g_st_variant.load(); }
 
@@ -772,8 +811,18 @@ int launch_spconv_st(const SpconvArgs& a_in, const unsigned char* local_dev, hip
   const int n_cg = a.cout / ctg;
   EYOC_REQUIRE(a.cout % ctg == 0 && n_cg >= 1 && n_cg <= 8 && 8 % n_cg == 0 && a.cin % 32 == 0, EYOC_ERR_INVALID,
                "spconv_st: %d -> %d channels", a.cin, a.cout);
-  const dim3 grid((unsigned)(cdiv(n_tiles, 8 / n_cg) * 8)), block(NW * 64);
+  dim3 grid((unsigned)(cdiv(n_tiles, 8 / n_cg) * 8)), block(NW * 64);
   const int variant = g_st_variant.load();
+  // small inputs (32-channel workgroups that do not fill the chip's 512 slots): the 32-channel input blocks of a tile split over
+  // ksplit workgroups, as many as keep workgroups x splits within the scratch (and never more than there are blocks)
+  int ksplit = 1;
+  if (variant == 1 && ctg == 32 && a.ks_part && g_st_ksplit.load() && a.cin >= 128) {   // (two blocks: the second launch costs what the split saves)
+    const int wgs = (int)grid.x, nqb = a.cin / 32;
+    ksplit = KS_MAX_SLOTS / (wgs > 0 ? wgs : 1);
+    if (ksplit > nqb) ksplit = nqb;
+    if (ksplit < 4 || (long long)n_tiles * n_cg > KS_MAX_SLOTS) ksplit = 1;
+    grid.y = (unsigned)ksplit;
+  }
   if (variant == 0) {
     // the dynamic-LDS attribute is per (function, device): set on every launch of this diagnostics path (no process-wide cache)
 #define EYOC_ST(NTW_, CC_, NH_)                                                                                             \
@@ -786,7 +835,12 @@ int launch_spconv_st(const SpconvArgs& a_in, const unsigned char* local_dev, hip
     else { if (wide) EYOC_ST(2, 64, 1); else EYOC_ST(2, 32, 1); }
 #undef EYOC_ST
   } else {
-#define EYOC_STA(CC_, NH_, SK_) hipLaunchKernelGGL((spconv_st_asm_kernel<CC_, NH_, SK_>), grid, block, 0, st, a, local_dev, n_tiles)
+#define EYOC_STA(CC_, NH_, SK_)                                                                                          \
+  do {                                                                                                                  \
+    hipLaunchKernelGGL((spconv_st_asm_kernel<CC_, NH_, SK_>), grid, block, 0, st, a, local_dev, n_tiles, ksplit, 0);    \
+    if (ksplit > 1)                                                                                                     \
+      hipLaunchKernelGGL((spconv_st_asm_kernel<CC_, NH_, SK_>), dim3(grid.x), block, 0, st, a, local_dev, n_tiles, ksplit, 1); \
+  } while (0)
     if (ctg == 64) {
       if (variant == 2) { if (wide) EYOC_STA(64, 2, 0); else EYOC_STA(32, 2, 0); }
 #ifdef EYOC_ST_ABLATIONS

@@ -215,6 +215,12 @@ int eyoc_spconv_st_split_below(int workgroups);
  * them are non-empty in row order, 0.68-0.72 grouped.  Results are bit-identical either way (only the order of a tile's rows inside
  * its workgroup changes).  1 / 0 set, anything else only queries; returns the previous state; process-wide, read when records are built. */
 int eyoc_spconv_st_group_rows(int on);
+/* Small inputs (a single pair: the level-3 layer is 72 workgroups walking 8 input blocks x 27 offsets each): eyoc_model_forward lets
+ * the staged kernel split a tile's 32-channel input blocks over several workgroups (partial sums in the forward's workspace, added in
+ * share order by a second launch: bit-reproducible).  1 on (default) / 0 off, anything else only queries; returns the
+ * previous state; process-wide, for tests and profiling.  Results differ from the unsplit kernel by fp32 rounding (another
+ * summation order). */
+int eyoc_spconv_st_ksplit(int on);
 size_t eyoc_spconv_local_rulebook_bytes(int n_out);
 int eyoc_spconv_build_local_rulebook(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, void* out_dev,
                                      int32_t* overflow_dev, void* stream);

@@ -539,3 +539,35 @@ def test_staged_first_convolution_matches_the_probing_kernel_and_the_oracle(ks):
     d = rel_err(outs[1], outs[0])
     print(f"first convolution {ks}^3, {len(coords)} rows: staged vs oracle {e1:.2e}, probing vs oracle {e0:.2e}, staged vs probing {d:.2e}")
     assert e1 < REL and e0 < REL and d < 2e-6
+
+
+def test_small_input_split_over_input_blocks_matches_the_unsplit_forward():
+    """A single ~30k-voxel cloud through the Z-ordered split16 forward: the deep levels' stride-1 layers are a few dozen workgroups,
+    so eyoc_model_forward splits every tile's 32-channel input blocks over several workgroups (eyoc_spconv_st_ksplit; partial sums
+    added in share order by a second launch).  Same features as the unsplit kernel to fp32 rounding, both at the oracle's bar, and
+    bit-identical from run to run."""
+    from eyoc_amd import synthetic as syn
+    from oracle import resunet as orr
+    from test_gpu_round2 import _model
+    L, lib = _lib()
+    p = syn.make_pair(1)
+    coords = syn.batch_coords([p["coords0"]])
+    model, sd = _model()
+    model.spconv_math = "split16"
+    want = orr.resunet_forward(sd, coords, p["feats0"]).numpy()
+    prev = lib.eyoc_spconv_st_ksplit(-1)
+    prev_k = lib.eyoc_spconv_select_split16_kernel(1)          # the default selection (the file's fixture forces the gathering kernels)
+    outs = {}
+    try:
+        for on in (0, 1):
+            lib.eyoc_spconv_st_ksplit(on)
+            outs[on] = [_forward(model, coords, p["feats0"]) for _ in range(3 if on else 1)]
+    finally:
+        lib.eyoc_spconv_st_ksplit(prev)
+        lib.eyoc_spconv_select_split16_kernel(prev_k)
+    assert prev == 1
+    for o in outs[1][1:]:
+        np.testing.assert_array_equal(o, outs[1][0])
+    e0, e1, d = rel_err(outs[0][0], want), rel_err(outs[1][0], want), rel_err(outs[1][0], outs[0][0])
+    print(f"split over input blocks: vs oracle {e1:.2e} (unsplit {e0:.2e}), split vs unsplit {d:.2e}")
+    assert e0 < REL and e1 < REL and 0 < d < 2e-6
