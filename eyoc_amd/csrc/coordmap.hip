@@ -672,6 +672,22 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
     m->table[0].mask = cap - 1;
     m->table0_built = false;
   }
+  // Z-ordered rows: every level's row count is known by now, so the links' and the coarsest table's fills go out up front - between the
+  // short dependent kernels of a level each costs a launch gap (a single pair: five fills, ~8 us apiece on the critical path)
+  unsigned int top_cap = 0;
+  if (zorder) {
+    for (int l = 1; l < EYOC_MAX_LEVELS; ++l) {
+      m->children[l - 1] = cv.take<int32_t>((size_t)pre_rows[l] * 8);
+      FAIL_HIP(hipMemsetAsync(m->children[l - 1], 0xFF, (size_t)pre_rows[l] * 32, st));
+    }
+    HashTable& tt = m->table[EYOC_MAX_LEVELS - 1];
+    top_cap = table_capacity(pre_rows[EYOC_MAX_LEVELS - 2]);
+    tt.keys = cv.take<unsigned long long>(top_cap);
+    tt.vals = cv.take<int>(top_cap);
+    tt.mask = top_cap - 1;
+    FAIL_HIP(hipMemsetAsync(tt.keys, 0xFF, (size_t)top_cap * 8, st));
+    FAIL_HIP(hipMemsetAsync(tt.vals, 0x7F, (size_t)top_cap * 4, st));
+  }
   for (int l = 1; l < EYOC_MAX_LEVELS; ++l) {
     // table of THIS level is built from the previous level's rows
     const int n_src = m->rows[l - 1];
@@ -715,20 +731,17 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
     }
     m->coords[l] = cv.take<int32_t>((size_t)m->rows[l] * 4);
     m->parent[l - 1] = cv.take<int32_t>((size_t)n_src);
-    m->children[l - 1] = cv.take<int32_t>((size_t)m->rows[l] * 8);
-    FAIL_HIP(hipMemsetAsync(m->children[l - 1], 0xFF, (size_t)m->rows[l] * 32, st));
+    if (!zorder) {
+      m->children[l - 1] = cv.take<int32_t>((size_t)m->rows[l] * 8);
+      FAIL_HIP(hipMemsetAsync(m->children[l - 1], 0xFF, (size_t)m->rows[l] * 32, st));
+    }
     if (sorted_level) {
       hipLaunchKernelGGL(k_compact_sorted, dim3(nb), dim3(SCAN_BLOCK), 0, st, flag, partial, src, n_src, ts2, l - 1,
                          m->coords[l], m->parent[l - 1], m->children[l - 1]);
       if (l + 1 == EYOC_MAX_LEVELS) {
         // the coarsest level's table (k_neighbours probes it): its UNIQUE rows are inserted - one uncontended CAS per voxel
         // instead of one per finer row, four neighbouring lanes fighting over every slot (118 -> ~20 us on the bench batch)
-        const unsigned int cap = table_capacity(n_src);
-        t.keys = cv.take<unsigned long long>(cap);
-        t.vals = cv.take<int>(cap);
-        t.mask = cap - 1;
-        FAIL_HIP(hipMemsetAsync(t.keys, 0xFF, (size_t)cap * 8, st));
-        FAIL_HIP(hipMemsetAsync(t.vals, 0x7F, (size_t)cap * 4, st));
+        // (table allocated and filled up front, above)
         hipLaunchKernelGGL(k_insert, dim3(cdiv(m->rows[l], 256)), dim3(256), 0, st, m->coords[l], m->rows[l], ts2, t, (int*)nullptr, counters);
       }
       continue;
