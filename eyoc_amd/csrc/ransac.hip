@@ -51,6 +51,7 @@ struct PairArgs {          // a chunk of pairs; segment bounds travel as kernel 
   double* xf;              // [chunk][cap_t][12] transforms (R row-major, t) of the first cap_t survivors of a pair
   int cap_t;
   float* rec_sorted;       // [total, 6] the records of every pair bucketed by their residual under the pair's reference transform
+  float* rr_sorted;        // [total, 4] fp32( that residual vector ), same order (what the packed fp32 sweep of k_count adds the deltas to)
   int* bucket_end;         // [chunk][NBUCKET + 1] records in buckets 0 .. b (prefix lengths); [NBUCKET] = n
   double* pmax;            // [chunk] largest |source point| of the pair
 };
@@ -342,12 +343,18 @@ __global__ __launch_bounds__(256) void k_bucket(PairArgs a) {
       const int pos = atomicAdd(&start[bkt[u]], 1);
       const float2* r = reinterpret_cast<const float2*>(rec + (size_t)i * 6);
       float2* w = reinterpret_cast<float2*>(out + (size_t)pos * 6);
-      w[0] = r[0]; w[1] = r[1]; w[2] = r[2];
+      const float2 p0 = r[0], p1 = r[1], p2 = r[2];
+      w[0] = p0; w[1] = p1; w[2] = p2;
+      const double x = p0.x, y = p0.y, z = p1.x;                          // the residual under the reference transform once more (pass 1's expression)
+      const double dx = fma(R[0], x, fma(R[1], y, fma(R[2], z, t[0] - (double)p1.y)));
+      const double dy = fma(R[3], x, fma(R[4], y, fma(R[5], z, t[1] - (double)p2.x)));
+      const double dz = fma(R[6], x, fma(R[7], y, fma(R[8], z, t[2] - (double)p2.y)));
+      reinterpret_cast<float4*>(a.rr_sorted)[(size_t)s0 + pos] = make_float4((float)dx, (float)dy, (float)dz, 0.f);
     }
   }
 }
 
-// ---- count.  A wave takes a group of G <= 64 survivors and sweeps the (bucketed) correspondences in blocks of 64 * PPL
+// ---- count in fp64 (records that are not bucketed: more than 8192 correspondences, or pruning switched off).  A wave takes a group of G <= 64 survivors and sweeps the (bucketed) correspondences in blocks of 64 * PPL
 // held in registers as doubles.  For one survivor of the group its transform arrives in SGPRs (scalar loads: the address
 // is wave-uniform), the residual test of the block is 16 VALU instructions per correspondence, and the inlier count
 // of the block is s_bcnt1 of the compare masks - scalar work.  Lane s of one VGPR accumulates survivor s's count, so
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(256) void k_bucket(PairArgs a) {
 // the blocks past its prefix (reference pruning above).
 constexpr int PPL = 4;
 
-__global__ __launch_bounds__(256) void k_count(PairArgs a, const double* __restrict__ xf_all, int pruned) {
+__global__ __launch_bounds__(256) void k_count_fp64(PairArgs a, const double* __restrict__ xf_all, int pruned) {
   const int c = blockIdx.y;
   const int s0 = a.s0[c], n = a.n[c];
   const float* __restrict__ rec = (pruned ? a.rec_sorted : a.rec) + (size_t)s0 * 6;
@@ -426,6 +433,196 @@ __global__ __launch_bounds__(256) void k_count(PairArgs a, const double* __restr
         }
         mycnt += lane == s ? csum : 0;
       }
+    }
+    if (lane < gs) cnts[sbase + lane] = mycnt;
+    best = mycnt > best ? mycnt : best;   // lanes >= gs hold 0
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) best = max(best, __shfl_xor(best, d, 64));
+  if (lane == 0 && best > 0) atomicMax(a.n_surv + c * CNT_STRIDE + 1, best);
+}
+
+// ---- count on bucketed records (the production path).  Same organisation as k_count_fp64 - a wave per group of G survivors,
+// blocks of records in registers, the survivor's numbers through scalar loads, lane s accumulating survivor s's count - but the
+// residual test runs in PACKED fp32 (two residuals per v_pk_fma_f32: 16 packed instructions + 4 compares per two residuals
+// against 16 v_*_f64 per residual; round 4's sweep sat at 0.84-0.91 of the fp64 issue rate, profiles/r5_valu.json) and stays exact:
+//
+//   R p + t - q = r_ref + dR p + dt,     r_ref = R_ref p + t_ref - q (k_bucket: fp64, rounded to fp32 once),  dR = R - R_ref, dt = t - t_ref
+//
+// With the pair's survivors near-duplicates of the reference, every term on the right is small (|r_ref| <= a few max_distance
+// inside the pruned prefix, |dR| |p| and |dt| a fraction of a metre), so fp32 rounding moves a component by ~1e-6 m where the
+// plain fp32 expression (terms of ~100 m cancelling) moves it by ~1e-3 m - inside the inlier residuals' own spread: the first
+// version of this kernel did that, sent most blocks to the fp64 recount and was slower than fp64 throughout.  Bound used:
+// every intermediate of a component is at most A = |r_ref|_max + |dt|_inf + 3 |dR|_max |p|_max (maxima over the block's records);
+// rounding r_ref, dt and dR to fp32 plus the four roundings of the chain put the fp32 component within 8 u A (u = 2^-24) of the
+// real-number value; the fp64 values involved (the oracle's own chain, r_ref, dR, dt) are within ~2^-50 A_full of theirs,
+// A_full = the magnitudes before cancellation (2^-40 A_full is added): delta = 10 u A + 2^-40 A_full.  For |r| <= thr + 2 delta
+// the squared norms then differ by at most 2 sqrt(3) delta |r| + 3 delta^2 + 3 u d2; `band` is 1.5 x that.  fp32 d2 below
+// thr2 - band: the fp64 d2 is below thr2; above thr2 + band: it is not; in between (about one residual in 10^5) the lane
+// evaluates the oracle's fp64 expression on the original record.  A survivor whose band is not small against thr2 (far from the
+// reference, huge coordinates, non-finite numbers) sweeps the block in fp64.  The counts are the oracle's, bit for bit
+// (tests/test_gpu_pose.py, tests/test_gpu_ransac_scale.py, tests/test_gpu_round2.py).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int PKP = 4;                       // packed pairs of records per lane
+constexpr int KC_RECORDS = 64 * 2 * PKP;     // records of a block
+
+// the oracle's test of record i under transform T (12 doubles)
+__device__ inline bool inlier_fp64(const float* __restrict__ rec, int i, const double* __restrict__ T, double thr2) {
+  const float2* r = reinterpret_cast<const float2*>(rec + (size_t)i * 6);
+  const float2 p0 = r[0], p1 = r[1], p2 = r[2];
+  const double x = p0.x, y = p0.y, z = p1.x;
+  const double dx = fma(T[0], x, fma(T[1], y, fma(T[2], z, T[9] - (double)p1.y)));
+  const double dy = fma(T[3], x, fma(T[4], y, fma(T[5], z, T[10] - (double)p2.x)));
+  const double dz = fma(T[6], x, fma(T[7], y, fma(T[8], z, T[11] - (double)p2.y)));
+  return fma(dx, dx, fma(dy, dy, dz * dz)) < thr2;
+}
+
+// five waves per SIMD (96 VGPRs; the spills this costs are in the block prologue and the fp64 recount, not in the sweep): 1.92 -> 1.72 ms
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_count(PairArgs a, const double* __restrict__ xf_all) {
+  __shared__ float4 deltas[4][64][3];    // per wave: fp32( T_s - T_ref ) of its group's survivors - dR row-major, dt
+  const int c = blockIdx.y;
+  const int s0 = a.s0[c], n = a.n[c];
+  const float* __restrict__ rec = a.rec_sorted + (size_t)s0 * 6;
+  const float4* __restrict__ rr = reinterpret_cast<const float4*>(a.rr_sorted) + s0;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int ns_all = a.n_surv[c * CNT_STRIDE];
+  const int ns = ns_all < a.cap_t ? ns_all : a.cap_t;
+  const double thr = (double)a.max_dist, thr2 = thr2_of(a.max_dist);
+  const double* __restrict__ xf = xf_all + (size_t)c * a.cap_t * 12;
+  const int* __restrict__ bend = a.bucket_end + c * (NBUCKET + 1);
+  int* cnts = a.cnts + (size_t)c * a.H;
+  int G = 64;   // fewer survivors: smaller groups, so that a pair still gives every wave of its grid slice a group
+  while (G > 8 && (ns + G - 1) / G < (int)gridDim.x * 4) G >>= 1;
+  const int n_groups = (ns + G - 1) / G;
+  int best = 0;
+  for (int grp = blockIdx.x * 4 + wave; grp < n_groups; grp += gridDim.x * 4) {
+    const int sbase = grp * G;
+    const int gs = min(G, ns - sbase);
+    // lane s: how many bucketed records survivor s has to look at, and the magnitudes its error band is made of
+    int hi = 0;
+    double m_dt = 0.0, m_dr = 0.0, m_t = 0.0, m_r = 1.0;   // |dt|_inf, |dR|_max, |t|_inf and |R|_max over {survivor, reference}
+    if (lane < gs) {
+      const double* __restrict__ T = xf + (size_t)(sbase + lane) * 12;
+      double fr = 0.0, dt = 0.0;
+      bool finite = true;
+      float ef[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const double v = T[i], r = xf[i], e = v - r;
+        ef[i] = (float)e;
+        finite = finite && fabs(v) < 1e300 && fabs(r) < 1e300;             // false for a NaN as well
+        if (i < 9) { fr = fma(e, e, fr); m_dr = fmax(m_dr, fabs(e)); m_r = fmax(m_r, fmax(fabs(v), fabs(r))); }
+        else { dt = fma(e, e, dt); m_dt = fmax(m_dt, fabs(e)); m_t = fmax(m_t, fmax(fabs(v), fabs(r))); }
+      }
+      if (!finite) m_t = 1e300;                                            // no band: this survivor counts in fp64
+#pragma unroll
+      for (int k = 0; k < 3; ++k) deltas[wave][lane][k] = make_float4(ef[4 * k], ef[4 * k + 1], ef[4 * k + 2], ef[4 * k + 3]);
+      const double delta = (sqrt(fr) * a.pmax[c] + sqrt(dt)) * (1.0 + 1e-9) + 1e-9;
+      const double q = ((double)a.max_dist + delta) / (double)a.max_dist;
+      const int b = q < (double)(NBUCKET - 2) ? (int)q + 1 : NBUCKET;   // one bucket of margin; NaN / huge: everything
+      hi = bend[b < NBUCKET ? b : NBUCKET];
+    }
+    int hi_max = hi;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) hi_max = max(hi_max, __shfl_xor(hi_max, d, 64));
+    hi_max = __builtin_amdgcn_readfirstlane(hi_max);
+    int mycnt = 0;
+    for (int i0 = 0; i0 < hi_max; i0 += KC_RECORDS) {
+      f32x2 x[PKP], y[PKP], z[PKP], rx[PKP], ry[PKP], rz[PKP];
+      float mp = 0.f, mr = 0.f;            // largest |source coordinate| and |reference residual component| of the block's records
+#pragma unroll
+      for (int u = 0; u < PKP; ++u) {
+        float v[2][6];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int i = i0 + (2 * u + h) * 64 + lane;
+          if (i < n) {
+            const float2* r = reinterpret_cast<const float2*>(rec + (size_t)i * 6);
+            const float2 p0 = r[0], p1 = r[1];
+            const float4 e = rr[i];
+            v[h][0] = p0.x; v[h][1] = p0.y; v[h][2] = p1.x; v[h][3] = e.x; v[h][4] = e.y; v[h][5] = e.z;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+              const float m = fabsf(v[h][k]) <= 3e38f ? fabsf(v[h][k]) : 3e38f;   // NaN / inf -> no band
+              if (k < 3) mp = fmaxf(mp, m); else mr = fmaxf(mr, m);
+            }
+          } else {   // past the end: a correspondence nothing brings within reach (d2 = 3e36 in fp32: no overflow)
+            v[h][0] = v[h][1] = v[h][2] = 0.f; v[h][3] = v[h][4] = v[h][5] = 1e18f;
+          }
+        }
+        x[u] = f32x2{v[0][0], v[1][0]}; y[u] = f32x2{v[0][1], v[1][1]}; z[u] = f32x2{v[0][2], v[1][2]};
+        rx[u] = f32x2{v[0][3], v[1][3]}; ry[u] = f32x2{v[0][4], v[1][4]}; rz[u] = f32x2{v[0][5], v[1][5]};
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) { mp = fmaxf(mp, __shfl_xor(mp, d, 64)); mr = fmaxf(mr, __shfl_xor(mr, d, 64)); }
+      // lane s: the two fp32 thresholds of (survivor s, this block); flo < 0 = "no usable band: count the block in fp64"
+      float flo = -1.f, fhi = -1.f;
+      {
+        const double A = (double)mr + m_dt + 3.0 * m_dr * (double)mp;
+        const double A_full = 4.0 * (m_t + (double)mr) + 8.0 * m_r * (double)mp;
+        const double delta = 10.0 * 0x1p-24 * A + 0x1p-40 * A_full;
+        const double band = 1.5 * (4.0 * delta * (thr + 2.0 * delta) + 3.0 * delta * delta + 8.0 * 0x1p-24 * thr2);
+        if (band < 0.25 * thr2 && A_full < 1e15 && thr2 < 1e30 && thr2 > 1e-30) {
+          flo = __double2float_rd(thr2 - band);
+          fhi = __double2float_ru(thr2 + band);
+        }
+      }
+      int blkcnt = 0;                                                    // lane s: survivor s's count in this block (v_writelane)
+#pragma unroll 1
+      for (int s = 0; s < gs; ++s) {
+        if (i0 >= __builtin_amdgcn_readlane(hi, s)) continue;          // wave-uniform: this survivor's prefix ends before the block
+        const float lo_s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, flo), s));
+        const float hi_s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fhi), s));
+        int csum = 0;
+        unsigned long long amb[PKP][2];
+        unsigned long long amb_any = 0;
+        if (lo_s >= 0.f) {
+          // the survivor's deltas: one LDS address for the whole wave (a broadcast read).  They came through scalar loads from a
+          // global fp32 copy at first: 3 KB per wave and block sweep, ~16 waves behind one 16 KB scalar cache - every load missed,
+          // and the halved arithmetic bought nothing (2.08 against 2.17 ms)
+          const float4 D0 = deltas[wave][s][0], D1 = deltas[wave][s][1], D2 = deltas[wave][s][2];
+          const float r00 = D0.x, r01 = D0.y, r02 = D0.z, r10 = D0.w, r11 = D1.x, r12 = D1.y, r20 = D1.z, r21 = D1.w, r22 = D2.x;
+          const float t0 = D2.y, t1 = D2.z, t2 = D2.w;
+#pragma unroll
+          for (int u = 0; u < PKP; ++u) {
+            const f32x2 dx = __builtin_elementwise_fma(f32x2{r00, r00}, x[u], __builtin_elementwise_fma(f32x2{r01, r01}, y[u],
+                             __builtin_elementwise_fma(f32x2{r02, r02}, z[u], f32x2{t0, t0} + rx[u])));
+            const f32x2 dy = __builtin_elementwise_fma(f32x2{r10, r10}, x[u], __builtin_elementwise_fma(f32x2{r11, r11}, y[u],
+                             __builtin_elementwise_fma(f32x2{r12, r12}, z[u], f32x2{t1, t1} + ry[u])));
+            const f32x2 dz = __builtin_elementwise_fma(f32x2{r20, r20}, x[u], __builtin_elementwise_fma(f32x2{r21, r21}, y[u],
+                             __builtin_elementwise_fma(f32x2{r22, r22}, z[u], f32x2{t2, t2} + rz[u])));
+            const f32x2 d2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
+            const unsigned long long sure0 = __ballot(d2.x < lo_s), sure1 = __ballot(d2.y < lo_s);
+            amb[u][0] = __ballot(d2.x < hi_s) ^ sure0;                  // "sure" is a subset of "maybe" (lo_s < hi_s)
+            amb[u][1] = __ballot(d2.y < hi_s) ^ sure1;
+            csum += __popcll(sure0) + __popcll(sure1);
+            amb_any |= amb[u][0] | amb[u][1];
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < PKP; ++u) amb[u][0] = amb[u][1] = ~0ull;
+          amb_any = ~0ull;
+        }
+        if (amb_any) {                                                   // wave-uniform, rare: the undecided residuals in fp64
+          const double* __restrict__ T = xf + (size_t)(sbase + s) * 12;
+#pragma unroll
+          for (int u = 0; u < PKP; ++u)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              if (!amb[u][h]) continue;
+              const int i = i0 + (2 * u + h) * 64 + lane;
+              const bool in = ((amb[u][h] >> lane) & 1) && i < n && inlier_fp64(rec, i, T, thr2);
+              csum += __popcll(__ballot(in));
+            }
+        }
+        // csum and s are wave-uniform (SGPRs); gfx9 allows one SGPR per VOP3, so the lane select travels in m0 (saved and restored:
+        // the compiler does not track m0 through inline assembly)
+        int m0_keep;
+        asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                     : "+v"(blkcnt), "=&s"(m0_keep) : "s"(csum), "s"(s));
+      }
+      mycnt += blkcnt;
     }
     if (lane < gs) cnts[sbase + lane] = mycnt;
     best = mycnt > best ? mycnt : best;   // lanes >= gs hold 0
@@ -569,7 +766,7 @@ namespace {
 // transforms are stored for the first cap_t survivors of a pair (96 B each; 2^20 = the survivors of an inlier ratio of 0.7);
 // the rest - only ever reached by degenerate inputs - are re-derived by k_count_overflow
 struct RansacLayout {
-  size_t off_cnt, off_rec, off_surv, off_cnts, off_rmse, off_xf, off_rs, off_be, off_pm, bytes;
+  size_t off_cnt, off_rec, off_surv, off_cnts, off_rmse, off_xf, off_rs, off_rr, off_be, off_pm, bytes;
 };
 // eyoc_ransac_transform_store / eyoc_ransac_select_pruning: process-wide test knobs.  Every entry point reads each ONCE (a snapshot
 // that its layout, its chunk size and its kernels all use), so a setter racing a call cannot make the sizes of one call disagree
@@ -586,7 +783,8 @@ RansacLayout ransac_layout(int chunk, int total, int H, int store) {
   l.off_rmse = align_up(l.off_cnts + (size_t)chunk * H * 4);
   l.off_xf = align_up(l.off_rmse + (size_t)chunk * H * 4);
   l.off_rs = align_up(l.off_xf + (size_t)chunk * cap_t * 96);
-  l.off_be = align_up(l.off_rs + (size_t)total * 24);
+  l.off_rr = align_up(l.off_rs + (size_t)total * 24);
+  l.off_be = align_up(l.off_rr + (size_t)total * 16);
   l.off_pm = align_up(l.off_be + (size_t)chunk * (NBUCKET + 1) * 4);
   l.bytes = align_up(l.off_pm + (size_t)chunk * 8);
   return l;
@@ -609,7 +807,7 @@ int ransac_run(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const 
   a.rec = (float*)(sc + l.off_rec); a.seed = p->seed; a.H = H; a.edge_sim = p->edge_similarity; a.max_dist = p->max_distance;
   a.n_surv = (int*)(sc + l.off_cnt); a.surv = (int*)(sc + l.off_surv); a.cnts = (int*)(sc + l.off_cnts);
   a.rmse = (unsigned int*)(sc + l.off_rmse); a.xf = (double*)(sc + l.off_xf); a.cap_t = cap_t;
-  a.rec_sorted = (float*)(sc + l.off_rs); a.bucket_end = (int*)(sc + l.off_be); a.pmax = (double*)(sc + l.off_pm);
+  a.rec_sorted = (float*)(sc + l.off_rs); a.rr_sorted = (float*)(sc + l.off_rr); a.bucket_end = (int*)(sc + l.off_be); a.pmax = (double*)(sc + l.off_pm);
   const int pruned = g_ransac_prune.load() && max_n <= 8192 ? 1 : 0;
   const bool in_lds = max_n <= LDS_RECORDS;
   const size_t lds_bytes = in_lds ? (size_t)max_n * 24 : 0;
@@ -638,7 +836,8 @@ int ransac_run(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const 
     hipLaunchKernelGGL(k_fit, dim3(2048 / nc > 8 ? 2048 / nc : 8, nc), dim3(256), 0, st, a);
     if (pruned) hipLaunchKernelGGL(k_bucket, dim3(nc), dim3(256), 0, st, a);
     constexpr int KC_BLOCKS = 4096;   // workgroups of the count over the pairs of a launch (2048: 1.6 rounds of the 1280 the chip holds - measured 3.5 vs 3.3 ms)
-    hipLaunchKernelGGL(k_count, dim3(KC_BLOCKS / nc, nc), dim3(256), 0, st, a, (const double*)a.xf, pruned);
+    if (pruned) hipLaunchKernelGGL(k_count, dim3(KC_BLOCKS / nc, nc), dim3(256), 0, st, a, (const double*)a.xf);
+    else hipLaunchKernelGGL(k_count_fp64, dim3(KC_BLOCKS / nc, nc), dim3(256), 0, st, a, (const double*)a.xf, pruned);
     if (H > cap_t) hipLaunchKernelGGL(k_count_overflow, dim3(256, nc), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_rmse, dim3(64, nc), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_select, dim3(nc), dim3(1024), 0, st, a, results_dev);
