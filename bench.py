@@ -394,16 +394,16 @@ def worker(args):
         model.spconv_math = args.math
         if args.st_variant >= 0:
             from eyoc_amd import _lib as _l
-            _l.load().eyoc_spconv_select_st_kernel(args.st_variant)
+            _l.knob("eyoc_spconv_select_st_kernel", args.st_variant)
         if args.up_kernel >= 0:
             from eyoc_amd import _lib as _l
-            _l.load().eyoc_spconv_select_up_kernel(args.up_kernel)
+            _l.knob("eyoc_spconv_select_up_kernel", args.up_kernel)
         if args.st_group >= 0:
             from eyoc_amd import _lib as _l
-            _l.load().eyoc_spconv_st_group_rows(args.st_group)
+            _l.knob("eyoc_spconv_st_group_rows", args.st_group)
         if args.conv1_kernel >= 0:
             from eyoc_amd import _lib as _l
-            _l.load().eyoc_spconv_select_conv1_kernel(args.conv1_kernel)
+            _l.knob("eyoc_spconv_select_conv1_kernel", args.conv1_kernel)
         if args.sc2_dense_x is not None:
             from eyoc_amd import _lib as _l
             _l.load().eyoc_sc2pcr_set_dense_threshold(_l.ctx(device.index), args.sc2_dense_x)

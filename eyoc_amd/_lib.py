@@ -62,8 +62,8 @@ PROTOTYPES = {
     "eyoc_maps_build": (_i, [_vp, _vp, _i, _vp, _sz, _vp, C.POINTER(_vp)]),
     "eyoc_maps_build_ordered": (_i, [_vp, _vp, _i, _vp, _sz, _vp, _i, C.POINTER(_vp)]),
     "eyoc_maps_free": (_i, [_vp]),
-    "eyoc_maps_internal_order": (_i, [_i]),
-    "eyoc_maps_order_window_shift": (_i, [_i]),
+    "eyoc_maps_internal_order": (_i, [_vp, _i]),
+    "eyoc_maps_order_window_shift": (_i, [_vp, _i]),
     "eyoc_maps_row_order": (_vp, [_vp]),
     "eyoc_maps_copy_row_order": (_i, [_vp, _vp, _vp]),
     "eyoc_maps_rows": (_i, [_vp, _i]),
@@ -72,7 +72,7 @@ PROTOTYPES = {
     "eyoc_maps_copy_coords": (_i, [_vp, _i, _vp, _vp]),
     "eyoc_maps_copy_table": (_i, [_vp, _i, _i, _vp, _vp]),
     "eyoc_maps_copy_up_order": (_i, [_vp, _i, _vp, _vp]),
-    "eyoc_maps_order_min_rows": (_i, [_i]),
+    "eyoc_maps_order_min_rows": (_i, [_vp, _i]),
     "eyoc_maps_info": (_i, [_vp, _vp, _i, _vp, C.POINTER(MapsInfo)]),
     "eyoc_voxelize_workspace_bytes": (_sz, [_i]),
     "eyoc_voxelize": (_i, [_vp, _vp, _i, _i, C.c_float, _i, _vp, _vp, C.POINTER(C.c_int), _vp, _sz, _vp]),
@@ -85,17 +85,17 @@ PROTOTYPES = {
                                          _vp]),
     "eyoc_spconv_packed_floats": (_sz, [_i, _i, _i]),
     "eyoc_spconv_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
-    "eyoc_spconv_select_kernel": (_i, [_i]),
+    "eyoc_spconv_select_kernel": (_i, [_vp, _i]),
     "eyoc_spconv_pack_weights_transposed": (_i, [_vp, _i, _i, _i, _i, _vp]),
     "eyoc_spconv_grad_weight_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "eyoc_spconv_grad_weight": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "eyoc_spconv_pack_weights_split16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "eyoc_spconv_ex": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
-    "eyoc_spconv_select_split16_kernel": (_i, [_i]),
-    "eyoc_spconv_select_st_kernel": (_i, [_i]),
-    "eyoc_spconv_st_split_below": (_i, [_i]),
-    "eyoc_spconv_st_group_rows": (_i, [_i]),
-    "eyoc_spconv_st_ksplit": (_i, [_i]),
+    "eyoc_spconv_select_split16_kernel": (_i, [_vp, _i]),
+    "eyoc_spconv_select_st_kernel": (_i, [_vp, _i]),
+    "eyoc_spconv_st_split_below": (_i, [_vp, _i]),
+    "eyoc_spconv_st_group_rows": (_i, [_vp, _i]),
+    "eyoc_spconv_st_ksplit": (_i, [_vp, _i]),
     "eyoc_spconv_local_rulebook_bytes": (_sz, [_i]),
     "eyoc_spconv_build_local_rulebook": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "eyoc_spconv_staged": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
@@ -112,7 +112,7 @@ PROTOTYPES = {
     "eyoc_model_pack_host": (_i, [C.POINTER(ModelDesc), C.POINTER(LayerParams), _i, _vp, _sz]),
     "eyoc_model_create": (_i, [_vp, C.POINTER(ModelDesc), C.POINTER(LayerParams), _i, _vp, _sz, C.POINTER(_vp)]),
     "eyoc_model_destroy": (_i, [_vp]),
-    "eyoc_model_fuse_tail": (_i, [_i]),
+    "eyoc_model_fuse_tail": (_i, [_vp, _i]),
     "eyoc_model_workspace_bytes": (_sz, [_vp, _vp]),
     "eyoc_model_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "eyoc_model_num_layers": (_i, [_vp]),
@@ -126,23 +126,23 @@ PROTOTYPES = {
     "eyoc_bn_train_forward_running": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, C.c_float, _i, _vp, _i, _vp, _vp, _vp, C.c_float, _vp, _sz, _vp]),
     "eyoc_bn_train_backward": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, C.c_float, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "eyoc_maps_gather_window": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
-    "eyoc_knn_prefilter": (_i, [_i]),
-    "eyoc_spconv_select_up_kernel": (_i, [_i]),
-    "eyoc_spconv_upc_min_rows": (_i, [_i]),
+    "eyoc_knn_prefilter": (_i, [_vp, _i]),
+    "eyoc_spconv_select_up_kernel": (_i, [_vp, _i]),
+    "eyoc_spconv_upc_min_rows": (_i, [_vp, _i]),
     "eyoc_spconv_upc_tile_rows": (_i, [_i, _i]),
     "eyoc_spconv_upc_bytes": (_sz, [_i]),
     "eyoc_spconv_upc_build": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "eyoc_spconv_upc": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp]),
-    "eyoc_spconv_select_conv1_kernel": (_i, [_i]),
+    "eyoc_spconv_select_conv1_kernel": (_i, [_vp, _i]),
     "eyoc_knn1": (_i, [_vp, _vp, _vp, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i, _i, _vp, _vp, _vp]),
     "eyoc_pdist": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "eyoc_kabsch_batched": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "eyoc_irls_quad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "eyoc_ransac": (_i, [_vp, _vp, _vp, _vp, _i, C.POINTER(RansacParams), _vp, _vp]),
-    "eyoc_maps_select_orders": (_i, [_i, _i]),
-    "eyoc_ransac_select_pruning": (_i, [_i]),
-    "eyoc_ransac_transform_store": (_i, [_i]),
-    "eyoc_ransac_workspace_bytes": (_sz, [_i, _i, _i, _sz]),
+    "eyoc_maps_select_orders": (_i, [_vp, _i, _i]),
+    "eyoc_ransac_select_pruning": (_i, [_vp, _i]),
+    "eyoc_ransac_transform_store": (_i, [_vp, _i]),
+    "eyoc_ransac_workspace_bytes": (_sz, [_vp, _i, _i, _i, _sz]),
     "eyoc_ransac_batched_ws": (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i,
                                     C.POINTER(RansacParams), _vp, _vp, _sz, _vp]),
     "eyoc_ransac_batched": (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i,
@@ -212,6 +212,15 @@ def ctx(device_index: int | None = None):
         check(lib.eyoc_create(int(device_index), C.byref(h)), "eyoc_create")
         _ctx[device_index] = h
     return _ctx[device_index]
+
+
+def knob(name: str, *values, device=None) -> int:
+    """A kernel-selection / tiling switch of the device's ctx (``eyoc_spconv_select_*``, ``eyoc_maps_*``, ``eyoc_ransac_*`` ...; tests and
+    diagnostics): ``knob("eyoc_spconv_select_kernel", 1)`` sets it and returns the previous value, an out-of-range value only queries."""
+    import torch
+    if isinstance(device, torch.device):
+        device = device.index
+    return getattr(load(), name)(ctx(device), *values)
 
 
 def stream_ptr():

@@ -83,7 +83,34 @@ struct eyoc_ctx {
   int zorder_kbits = 17, zorder_bbits = 10;
   // SC2-PCR diagnostics (eyoc_sc2pcr_set_shortlist_cap / eyoc_sc2pcr_set_dense_threshold): per ctx, not per process
   int sc2_list_cap = 1024, sc2_dense_x = 2;
+  // kernel-selection and tiling switches (tests, diagnostics, bench flags).  Per ctx since round 5: they were file-scope statics, so two
+  // models in one process - or a test that forgot to restore one - shared kernel selection.  Every entry point reads them from the
+  // ctx it was given; the setters (eyoc_spconv_select_*, eyoc_maps_*, eyoc_knn_prefilter, eyoc_ransac_*, eyoc_model_fuse_tail) take the ctx
+  struct Knobs {
+    int maps_order_min_rows = 65536;   // eyoc_maps_order_min_rows
+    int maps_window_shift = 18;        // eyoc_maps_order_window_shift: window of the tiling orders, log2 rows (measured: 2^17-2^18; 2^12, 2^14 lose)
+    int maps_s1_order = 1, maps_down_order = 0;   // eyoc_maps_select_orders: tiling orders of the stride-1 / strided tables
+    int maps_internal_order = -1;      // eyoc_maps_internal_order: -1 automatic (Z-order from 8192 rows), 0 caller's order, 1 Z-order
+    int knn_prefilter = 1;             // eyoc_knn_prefilter
+    int fuse_tail = 1;                 // eyoc_model_fuse_tail: the two 1x1 layers at the end of a split16 forward in one kernel (spconv_tail.hip)
+    int spconv_kernel = -1;            // eyoc_spconv_select_kernel: -1 automatic, 0 workgroup-tiled, 1 wave-private
+    int split16_kernel = 1;            // eyoc_spconv_select_split16_kernel: 1 per layer, 0 always the wave-private kernel, 2 always the row-stationary one
+    int up_kernel = 2;                 // eyoc_spconv_select_up_kernel: 0 gathering kernels, 1 spconv_up.hip (Morton tiles), 2 spconv_upc.hip (class-major tiles)
+    int upc_min_rows = 1 << 17;        // eyoc_spconv_upc_min_rows: maps with fewer level-0 rows keep spconv_up.hip under mode 2
+    int conv1_kernel = 1;              // eyoc_spconv_select_conv1_kernel: 1 conv1_bf_kernel (block feature vectors), 0 conv1_mfma_kernel, 2 the exact-fp32 octree walker
+    int st_group = 1;                  // eyoc_spconv_st_group_rows: the staged kernel's tiles sorted by neighbour pattern
+    int st_variant = 1;                // eyoc_spconv_select_st_kernel
+    int st_split_below = 1024;         // eyoc_spconv_st_split_below
+    int st_ksplit = 1;                 // eyoc_spconv_st_ksplit
+    int ransac_store = 1 << 20;        // eyoc_ransac_transform_store
+    int ransac_prune = 1;              // eyoc_ransac_select_pruning
+  } knobs;
 };
+// the switches of a call: the ctx's, or the defaults where an internal launcher was handed no ctx
+inline const eyoc_ctx::Knobs& knobs_of(const eyoc_ctx* ctx) {
+  static const eyoc_ctx::Knobs defaults;
+  return ctx ? ctx->knobs : defaults;
+}
 
 // ---------------------------------------------------------------------------------------------
 // coordinate keys and the open-addressing hash shared by coordmap.hip and spconv.hip (conv1)

@@ -536,12 +536,8 @@ __global__ void k_count_region(const int32_t* __restrict__ coords, int n, HashTa
 }
 
 constexpr int UP_KEY_BITS = KEY_PATTERN_BITS + KEY_WINDOW_BITS;
-static int ORDER_MIN_ROWS = 65536;
-// Z-ordered levels: window of the tiling orders, log2 rows.  Measured on the 64-pair bench: 2^17-2^18 rows (2^12, 2^14
-// lose - too many short pattern runs; no windows: +23 % on the 1 -> 0 transposed convolution)
-static int ORDER_WINDOW_SHIFT = 18;      // eyoc_maps_order_window_shift
-static int S1_ORDER = 1, DOWN_ORDER = 0;   // eyoc_maps_select_orders: tiling orders of the stride-1 / strided tables
-static int INTERNAL_ORDER = -1;          // eyoc_maps_internal_order: -1 automatic (Z-order from 8192 rows), 0 caller's order, 1 Z-order
+// Z-ordered levels: window of the tiling orders, log2 rows (eyoc_ctx::Knobs::maps_window_shift).  Measured on the 64-pair bench:
+// 2^17-2^18 rows (2^12, 2^14 lose - too many short pattern runs; no windows: +23 % on the 1 -> 0 transposed convolution)
 // Z-order (and with it the staged split16 kernels, model.hip) from 8192 rows: measured faster than the fp32 kernels on
 // the caller's row order at every size tried - maps + forward of a 15 k-row half cloud 2.30 -> 1.78 ms, one 31 k-row
 // cloud 2.45 -> 2.02, a pair 2.86 -> 2.17 (scripts/bench_small_forward.py).  Smaller inputs keep the caller's order.
@@ -613,7 +609,8 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
   // ---- level 0: the caller's rows, in the caller's order
   m->rows[0] = n;
   m->coords[0] = cv.take<int32_t>((size_t)n * 4);
-  const int order_mode = INTERNAL_ORDER >= 0 ? INTERNAL_ORDER : order;   // the process-wide switch (tests) beats the call's wish
+  const eyoc_ctx::Knobs& kn = ctx->knobs;
+  const int order_mode = kn.maps_internal_order >= 0 ? kn.maps_internal_order : order;   // the ctx's switch (tests) beats the call's wish
   const bool zorder = order_mode > 0 || (order_mode < 0 && n >= ZORDER_MIN_ROWS);
   int pre_rows[EYOC_MAX_LEVELS] = {n, 0, 0, 0};                          // Z-order: known before the levels are built
   if (zorder) {
@@ -778,31 +775,31 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
   // its segment number in the high key bits, and ONE stable radix sort orders all segments at once (seven separate
   // rocPRIM sorts cost 38 small launches, 0.7 ms per 64-cloud batch).  The orders only serve the wave-private
   // convolution kernel, which takes over above ~4000 row tiles: small levels (single-pair latency path) skip them.
-  const bool s1_order = S1_ORDER != 0;
+  const bool s1_order = kn.maps_s1_order != 0;
   int seg_up[EYOC_MAX_LEVELS], seg_s1[EYOC_MAX_LEVELS], seg_dn[EYOC_MAX_LEVELS], seg_base[3 * EYOC_MAX_LEVELS], n_seg = 0;
   size_t total = 0;
   // transposed tables on Z-ordered maps: class-major tiles (spconv_upc.hip) for batches, Morton tiles (spconv_up.hip) below
   // UPC_MIN_ROWS voxels - the partition's five small launches per level cost a single pair (60 k voxels) more than its kernel saves
   // (eyoc_spconv_upc_min_rows, default 2^17)
-  const bool use_upc = spconv_upc_enabled() && n >= spconv_upc_min_rows();
-  const bool use_up = spconv_up_enabled() || (spconv_upc_enabled() && !use_upc);
+  const bool use_upc = kn.up_kernel == 2 && n >= kn.upc_min_rows;
+  const bool use_up = kn.up_kernel == 1 || (kn.up_kernel == 2 && !use_upc);
   for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
     seg_up[l] = seg_s1[l] = seg_dn[l] = -1;
     // Z-ordered maps tile the strided convolutions in natural order: a tile's 64 coarse rows read their (adjacent)
     // children, which beats the pattern order's fuller chunks (2.38 -> 2.25 ms for the three layers;
     // eyoc_maps_select_orders(-1, 1) restores the sort)
-    const bool dn_order = DOWN_ORDER == 1;
-    if (l + 1 < EYOC_MAX_LEVELS && m->rows[l + 1] >= ORDER_MIN_ROWS && (dn_order || !zorder)) {   // outputs of the strided conv l -> l+1
+    const bool dn_order = kn.maps_down_order == 1;
+    if (l + 1 < EYOC_MAX_LEVELS && m->rows[l + 1] >= kn.maps_order_min_rows && (dn_order || !zorder)) {   // outputs of the strided conv l -> l+1
       seg_dn[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l + 1];
     }
-    if (m->rows[l] < ORDER_MIN_ROWS) continue;
+    if (m->rows[l] < kn.maps_order_min_rows) continue;
     // the transposed tables' order serves the gathering kernels only: Z-ordered maps with the staged transposed kernel (which sorts
     // inside its tiles) skip it - and with it the whole radix sort, nothing else being ordered there (0.3 ms per 128-cloud batch)
     if (l + 1 < EYOC_MAX_LEVELS && !(zorder && (use_up || use_upc))) { seg_up[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l]; }
     if (s1_order && !zorder) { seg_s1[l] = n_seg; seg_base[n_seg++] = (int)total; total += m->rows[l]; }
   }
   constexpr int TAG_SHIFT = UP_KEY_BITS, TAG_BITS = 4;   // pattern keys < 2^11, window number, segment tag above (at most 10 segments)
-  const int wshift = zorder ? ORDER_WINDOW_SHIFT : -1;
+  const int wshift = zorder ? kn.maps_window_shift : -1;
   unsigned int* key_in = cv.take<unsigned int>(total);
   unsigned int* key_out = cv.take<unsigned int>(total);
   int* row_in = cv.take<int>(total);
@@ -848,7 +845,7 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
     FAIL_HIP(hipMemsetAsync(counters + 8, 0, 8 * sizeof(int), st));    // [8] stride-1, [9] transposed, [10 + l] strided table l
     for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
       m->local_s1[l] = cv.take<unsigned char>(local_rulebook_bytes(m->rows[l]));
-      if (int rc = build_local_rulebook(m->nbr_s1[l], 27, m->rows[l], m->local_s1[l], counters + 8, st)) { delete m; return rc; }
+      if (int rc = build_local_rulebook(m->nbr_s1[l], 27, m->rows[l], m->local_s1[l], counters + 8, st, kn.st_group)) { delete m; return rc; }
       if (l + 1 < EYOC_MAX_LEVELS && use_up) {   // the transposed table whose outputs are this level's rows
         m->local_up[l] = cv.take<unsigned char>(local_rulebook_up_bytes(m->rows[l]));
         if (int rc = build_local_rulebook_up(m->nbr_up[l], 27, m->rows[l], m->local_up[l], counters + 9, st)) { delete m; return rc; }
@@ -1007,30 +1004,35 @@ int eyoc::maps_build_table0(eyoc_maps* m, hipStream_t st) {
 
 extern "C" {
 
-int eyoc_maps_internal_order(int mode) {
-  const int prev = INTERNAL_ORDER;
-  if (mode >= -1 && mode <= 1) INTERNAL_ORDER = mode;
+int eyoc_maps_internal_order(eyoc_ctx* ctx, int mode) {
+  if (!ctx) return -1;
+  const int prev = ctx->knobs.maps_internal_order;
+  if (mode >= -1 && mode <= 1) ctx->knobs.maps_internal_order = mode;
   return prev + 2;
 }
 
 const int32_t* eyoc_maps_row_order(const eyoc_maps* maps) { return maps ? maps->row_perm : nullptr; }
 
-int eyoc_maps_select_orders(int s1, int down) {
-  const int prev = S1_ORDER | DOWN_ORDER << 1;
-  if (s1 == 0 || s1 == 1) S1_ORDER = s1;
-  if (down == 0 || down == 1) DOWN_ORDER = down;
+int eyoc_maps_select_orders(eyoc_ctx* ctx, int s1, int down) {
+  if (!ctx) return -1;
+  eyoc_ctx::Knobs& kn = ctx->knobs;
+  const int prev = kn.maps_s1_order | kn.maps_down_order << 1;
+  if (s1 == 0 || s1 == 1) kn.maps_s1_order = s1;
+  if (down == 0 || down == 1) kn.maps_down_order = down;
   return prev;
 }
 
-int eyoc_maps_order_window_shift(int shift) {
-  const int prev = ORDER_WINDOW_SHIFT;
-  if (shift >= 0) ORDER_WINDOW_SHIFT = shift;
+int eyoc_maps_order_window_shift(eyoc_ctx* ctx, int shift) {
+  if (!ctx) return -1;
+  const int prev = ctx->knobs.maps_window_shift;
+  if (shift >= 0) ctx->knobs.maps_window_shift = shift;
   return prev;
 }
 
-int eyoc_maps_order_min_rows(int min_rows) {
-  const int prev = ORDER_MIN_ROWS;
-  if (min_rows >= 0) ORDER_MIN_ROWS = min_rows;
+int eyoc_maps_order_min_rows(eyoc_ctx* ctx, int min_rows) {
+  if (!ctx) return -1;
+  const int prev = ctx->knobs.maps_order_min_rows;
+  if (min_rows >= 0) ctx->knobs.maps_order_min_rows = min_rows;
   return prev;
 }
 

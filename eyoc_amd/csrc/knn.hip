@@ -536,10 +536,10 @@ void launch_knn(const float* A, const float* Bt, const SegArgs& seg, int nseg, i
 
 }  // namespace
 
-static int g_knn_prefilter = 1;
-extern "C" int eyoc_knn_prefilter(int mode) {
-  const int prev = g_knn_prefilter;
-  if (mode >= 0 && mode <= 2) g_knn_prefilter = mode;
+extern "C" int eyoc_knn_prefilter(eyoc_ctx* ctx, int mode) {
+  if (!ctx) return -1;
+  const int prev = ctx->knobs.knn_prefilter;
+  if (mode >= 0 && mode <= 2) ctx->knobs.knn_prefilter = mode;
   return prev;
 }
 
@@ -575,7 +575,7 @@ static int knn_run(eyoc_ctx* ctx, const float* A_dev, const float* B_dev, int c,
     max_ld = seg.ld[s] > max_ld ? seg.ld[s] : max_ld;
   }
   // MFMA pre-filter (see knn_mfma_kernel): plain index queries that fill the chip
-  const int prefilter_env = g_knn_prefilter;
+  const int prefilter_env = ctx->knobs.knn_prefilter;
   long long waves = 0, bm_floats = 0;
   SegMfma sm;
   for (int s = 0; s < nseg; ++s) {

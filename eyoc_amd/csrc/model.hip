@@ -35,8 +35,6 @@ struct BufPlan { int level, width; };
 
 size_t pad64(size_t v) { return (v + 63) / 64 * 64; }
 
-int g_fuse_tail = 1;     // eyoc_model_fuse_tail: the two 1x1 layers at the end of a split16 forward in one kernel (spconv_tail.hip)
-
 }  // namespace
 
 struct eyoc_model {
@@ -271,9 +269,10 @@ int eyoc_model_destroy(eyoc_model* m) {
   return EYOC_OK;
 }
 
-int eyoc_model_fuse_tail(int on) {
-  const int prev = g_fuse_tail;
-  if (on == 0 || on == 1) g_fuse_tail = on;
+int eyoc_model_fuse_tail(eyoc_ctx* ctx, int on) {
+  if (!ctx) return -1;
+  const int prev = ctx->knobs.fuse_tail;
+  if (on == 0 || on == 1) ctx->knobs.fuse_tail = on;
   return prev;
 }
 
@@ -372,7 +371,7 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
   // writes the format), which round 1 measured to pay off once the finest level alone fills the chip (>= 4096 wave tiles ~ 4 KITTI
   // pairs); small batches stay on fp32, where the launcher picks the workgroup-tiled kernel per layer
   const int want = m->math;
-  const bool split_ok = spconv_forced_kernel() != 0 && !(m->desc.normalize_feature && m->desc.out_channels > 64) &&
+  const bool split_ok = ctx->knobs.spconv_kernel != 0 && !(m->desc.normalize_feature && m->desc.out_channels > 64) &&
                         m->desc.channels[1] % 32 == 0;
   const bool split = split_ok && (want == 1 || (want < 0 && maps->rows[0] >= 8192));   // = the Z-order threshold of eyoc_maps_build
   EYOC_REQUIRE(want != 1 || split, EYOC_ERR_INVALID,
@@ -399,6 +398,7 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
       a.in = buf[p.in_buf]; a.cin = p.cin; a.w = m->blob + p.w_off; a.bias = m->blob + p.b_off; a.cout = p.cout;
       a.out = buf[p.out_buf] + p.out_col; a.ld_out = m->bufs[p.out_buf].width;
       a.out_split = split ? 1 : 0;
+      a.ctx = ctx;
       a.range = split ? m->range : nullptr;
       a.wscale = m->blob + p.s_off;
       a.in_perm = maps->row_perm;                        // Z-ordered maps: the caller's features are read through the permutation
@@ -422,7 +422,7 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
       a.local1 = maps->row_perm ? maps->local_s1[1] : nullptr;          // Z-ordered maps: the level-1 tile rulebooks (256-parent tiles)
       rc = conv1_walks_octree(a) ? EYOC_OK : maps_build_table0(const_cast<eyoc_maps*>(maps), st);
       if (!rc) rc = launch_conv1(a, st);
-    } else if (split && g_fuse_tail && li + 2 == m->layers.size() && p.map == M_IDENT && p.K == 1 && p.res_buf < 0 &&
+    } else if (split && ctx->knobs.fuse_tail && li + 2 == m->layers.size() && p.map == M_IDENT && p.K == 1 && p.res_buf < 0 &&
                m->layers[li + 1].map == M_IDENT && m->layers[li + 1].K == 1 && m->layers[li + 1].in_buf == p.out_buf &&
                m->layers[li + 1].res_buf < 0 && !m->layers[li + 1].relu && m->layers[li + 1].out_buf == B_OUT && p.out_col == 0 &&
                tail_fusable(p.cin, p.cout, m->layers[li + 1].cout)) {

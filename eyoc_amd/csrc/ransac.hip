@@ -15,8 +15,6 @@
 //      The largest count of each pair is kept with an atomicMax.
 //   3. rmse: only the survivors that reach the largest count (almost always one) get their inlier RMSE.
 //   4. select: single workgroup arg-max with the total order (more inliers, lower RMSE, lower h).
-#include <atomic>
-
 #include "pose_math.h"
 
 using namespace eyoc;
@@ -768,10 +766,8 @@ namespace {
 struct RansacLayout {
   size_t off_cnt, off_rec, off_surv, off_cnts, off_rmse, off_xf, off_rs, off_rr, off_be, off_pm, bytes;
 };
-// eyoc_ransac_transform_store / eyoc_ransac_select_pruning: process-wide test knobs.  Every entry point reads each ONCE (a snapshot
-// that its layout, its chunk size and its kernels all use), so a setter racing a call cannot make the sizes of one call disagree
-std::atomic<int> g_ransac_cap_t{1 << 20};
-std::atomic<int> g_ransac_prune{1};
+// eyoc_ransac_transform_store / eyoc_ransac_select_pruning: test switches of the ctx (eyoc_ctx::Knobs).  Every entry point reads each
+// ONCE (a snapshot that its layout, its chunk size and its kernels all use)
 inline int ransac_cap_t(int H, int store) { return H < store ? H : store; }
 RansacLayout ransac_layout(int chunk, int total, int H, int store) {
   RansacLayout l;
@@ -808,7 +804,7 @@ int ransac_run(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const 
   a.n_surv = (int*)(sc + l.off_cnt); a.surv = (int*)(sc + l.off_surv); a.cnts = (int*)(sc + l.off_cnts);
   a.rmse = (unsigned int*)(sc + l.off_rmse); a.xf = (double*)(sc + l.off_xf); a.cap_t = cap_t;
   a.rec_sorted = (float*)(sc + l.off_rs); a.rr_sorted = (float*)(sc + l.off_rr); a.bucket_end = (int*)(sc + l.off_be); a.pmax = (double*)(sc + l.off_pm);
-  const int pruned = g_ransac_prune.load() && max_n <= 8192 ? 1 : 0;
+  const int pruned = ctx->knobs.ransac_prune && max_n <= 8192 ? 1 : 0;
   const bool in_lds = max_n <= LDS_RECORDS;
   const size_t lds_bytes = in_lds ? (size_t)max_n * 24 : 0;
   if (in_lds) {
@@ -863,17 +859,23 @@ int ransac_validate(const float* src_dev, const float* tgt_dev, const int64_t* c
 
 }  // namespace
 
-extern "C" int eyoc_ransac_transform_store(int survivors) {
-  return survivors >= 1 ? g_ransac_cap_t.exchange(survivors) : g_ransac_cap_t.load();
+extern "C" int eyoc_ransac_transform_store(eyoc_ctx* ctx, int survivors) {
+  if (!ctx) return -1;
+  const int prev = ctx->knobs.ransac_store;
+  if (survivors >= 1) ctx->knobs.ransac_store = survivors;
+  return prev;
 }
 
-extern "C" int eyoc_ransac_select_pruning(int on) {
-  return (on == 0 || on == 1) ? g_ransac_prune.exchange(on) : g_ransac_prune.load();
+extern "C" int eyoc_ransac_select_pruning(eyoc_ctx* ctx, int on) {
+  if (!ctx) return -1;
+  const int prev = ctx->knobs.ransac_prune;
+  if (on == 0 || on == 1) ctx->knobs.ransac_prune = on;
+  return prev;
 }
 
-extern "C" size_t eyoc_ransac_workspace_bytes(int n_pairs, int total_corr, int max_iteration, size_t budget_bytes) {
+extern "C" size_t eyoc_ransac_workspace_bytes(const eyoc_ctx* ctx, int n_pairs, int total_corr, int max_iteration, size_t budget_bytes) {
   if (n_pairs < 1 || total_corr < 0 || max_iteration < 1) return 0;
-  const int store = g_ransac_cap_t.load();
+  const int store = knobs_of(ctx).ransac_store;
   const int chunk = ransac_pick_chunk(n_pairs, total_corr, max_iteration, budget_bytes ? budget_bytes : ~(size_t)0, store);
   return ransac_layout(chunk, total_corr, max_iteration, store).bytes;
 }
@@ -888,7 +890,7 @@ extern "C" int eyoc_ransac_batched_ws(eyoc_ctx* ctx, const float* src_dev, const
   int rc = ransac_validate(src_dev, tgt_dev, corr_tgt_dev, seg_src_host, seg_tgt_host, n_pairs, p, results_dev, &max_n);
   if (rc) return rc;
   const int total = seg_src_host[n_pairs];
-  const int store = g_ransac_cap_t.load();
+  const int store = ctx->knobs.ransac_store;
   const int chunk = ransac_pick_chunk(n_pairs, total, p->max_iteration, workspace_bytes, store);
   const size_t need = ransac_layout(chunk, total, p->max_iteration, store).bytes;
   EYOC_REQUIRE(need <= workspace_bytes, EYOC_ERR_WORKSPACE,
@@ -909,7 +911,7 @@ extern "C" int eyoc_ransac_batched(eyoc_ctx* ctx, const float* src_dev, const fl
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   const int total = seg_src_host[n_pairs];
-  const int store = g_ransac_cap_t.load();
+  const int store = ctx->knobs.ransac_store;
   // the scratch already there is free to use: the device is only asked how much memory it has left (a driver round trip) when the
   // largest chunk does not fit into it - i.e. on the first call of a batch shape, not on the hot path
   int chunk = ransac_pick_chunk(n_pairs, total, p->max_iteration, ctx->scratch_bytes, store);

@@ -48,7 +48,6 @@ struct SpconvArgs {
 };
 constexpr int KS_MAX_SLOTS = 1024;                        // (workgroups x splits) a split launch may use: 32 KB of partial sums each
 constexpr size_t KS_PART_BYTES = (size_t)KS_MAX_SLOTS * 256 * 32 * 4;
-int select_st_ksplit(int on);                             // 1 (default) / 0: eyoc_spconv_st_ksplit
 
 // ---- SPLIT16 row format: every block of 32 channels takes 128 bytes (one cache line), the 32 fp16 "hi" halves (x rounded
 // to fp16) followed by the 32 fp16 "lo" halves (x - hi rounded to fp16): the same 4 bytes per channel as fp32, 22
@@ -155,13 +154,11 @@ int build_upc(const int32_t* nbr_dev, const int32_t* coords_dev, int stride, int
 const int* upc_overflow_ptr(const unsigned char* ws);
 int upc_set_tile_rows(int odd_axes, int rows);   // rows per tile (128 .. 256, multiple of 16) of the classes with that many odd axes; this device
 int launch_spconv_upc(const SpconvArgs& a, const unsigned char* ws, hipStream_t st);
-int select_st_variant(int v);   // spconv_st.hip: which staged kernel (returns the previous one)
-int select_st_split_below(int workgroups);   // layers with fewer 64-channel workgroups take 32-channel ones (returns the previous threshold)
+int st_variants();   // spconv_st.hip: how many staged-kernel variants this build has (eyoc_spconv_select_st_kernel's range)
 size_t local_rulebook_bytes(int n_out);
 // group: 1 = the rows of a tile sorted by neighbour pattern (fewer non-empty MFMA blocks), 0 = in their own order (what
-// conv1_bf_kernel needs: it finds a parent's entries by its local row), -1 = the process-wide setting of select_st_group_rows
-int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st, int group = -1);
-int select_st_group_rows(int on);
+// conv1_bf_kernel needs: it finds a parent's entries by its local row); eyoc_maps_build passes its ctx's eyoc_spconv_st_group_rows switch
+int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st, int group = 1);
 int launch_spconv_rs(const SpconvArgs& a, hipStream_t st);     // row-stationary, SPLIT16 only (spconv_rs.hip)
 // the network's 1x1 tail in one kernel (spconv_tail.hip): conv1_tr (96 -> 64, ReLU) -> final (64 -> 32, bias) -> row normalisation
 bool tail_fusable(int cin1, int cmid, int cout);
@@ -169,10 +166,6 @@ int launch_tail_fused(const float* in, int ld_in, int n, const float* w1, const 
                       const float* s2, const float* b2, int l2norm, float* out, int ld_out, const int32_t* out_perm, unsigned int* range,
                       hipStream_t st);
 bool spconv_rs_fits(const SpconvArgs& a);
-bool spconv_up_enabled();    // eyoc_spconv_select_up_kernel state == 1 (spconv_up.hip)
-bool spconv_upc_enabled();   // ... == 2 (spconv_upc.hip)
-int spconv_upc_min_rows();    // maps with fewer level-0 rows keep spconv_up.hip under mode 2
-int spconv_forced_kernel();   // eyoc_spconv_select_kernel state: -1 automatic, 0 workgroup-tiled, 1 wave-private
 int launch_spconv_wave(const SpconvArgs& a, hipStream_t st);   // wave-private tiling (spconv_wave.hip)
 
 // first convolution: K = ks^3 offsets probed straight from the level-0 hash table (C_in is tiny)
@@ -201,6 +194,7 @@ struct Conv1Args {
   // tile-local rulebooks of the level-1 stride-1 table (build_local_rulebook; Z-ordered maps) or NULL: with them the first
   // convolution stages the child features of a 256-parent tile's neighbourhood in LDS once (conv1_bf_kernel)
   const unsigned char* local1 = nullptr;
+  const eyoc_ctx* ctx = nullptr;      // whose switches decide the kernel (eyoc_spconv_select_conv1_kernel); NULL: the defaults
 };
 // layout of a local rulebook record (spconv_st.hip owns it; conv1_bf_kernel in spconv.hip reads the row list and the entries)
 constexpr int ST_TILE = 256, ST_UMAX = 639, ST_UCAP = 1280, ST_NPASS = 2, ST_LOC_OFF = 16 + ST_UCAP * 4, ST_INV_OFF = 33152, ST_LR_BYTES = 33408;

@@ -714,21 +714,10 @@ __global__ void k_split16_decode(const float* __restrict__ in, int n, int c, int
 
 namespace eyoc {
 
-static int g_kernel_mode = -1;            // eyoc_spconv_select_kernel
-
-// split16 layers: 1 = choose per layer (default), 0 = always the wave-private kernel, 2 = always the row-stationary one
-static int g_split16_kernel = 1;          // eyoc_spconv_select_split16_kernel
-
-int spconv_forced_kernel() { return g_kernel_mode; }
-// staged kernel for the transposed convolutions (spconv_up.hip), on by default on Z-ordered maps: level with the
-// row-stationary kernel in windowed pattern order in time (0.68 / 1.06 / 1.44 vs 0.63 / 1.02 / 1.57 ms on the bench's three
-// layers, + 0.25 ms of rulebooks in the map build; the step is the same within noise) and 18 GB less HBM traffic per forward
-int g_up_kernel = 2;                      // eyoc_spconv_select_up_kernel: 0 gathering kernels, 1 spconv_up.hip (Morton tiles), 2 spconv_upc.hip (class-major tiles)
-bool spconv_up_enabled() { return g_up_kernel == 1; }
-bool spconv_upc_enabled() { return g_up_kernel == 2; }
-int g_upc_min_rows = 1 << 17;            // eyoc_spconv_upc_min_rows
-int spconv_upc_min_rows() { return g_upc_min_rows; }
-int g_conv1_staged = 1;   // eyoc_spconv_select_conv1_kernel: 1 the first convolution of Z-ordered split16 forwards on conv1_bf_kernel (block feature vectors of a staged level-1 tile), 0 on conv1_mfma_kernel, 2 on the exact-fp32 octree walker
+// which kernels run is decided per ctx (eyoc_ctx::Knobs, common.h): automatic by default, forced by the eyoc_spconv_select_* setters.
+// The staged kernel for the transposed convolutions is on by default on Z-ordered maps: level with the row-stationary kernel in
+// windowed pattern order in time (0.68 / 1.06 / 1.44 vs 0.63 / 1.02 / 1.57 ms on the bench's three layers, + 0.25 ms of rulebooks in
+// the map build; the step is the same within noise) and 18 GB less HBM traffic per forward
 
 int launch_spconv(const SpconvArgs& a, hipStream_t st) {
   EYOC_REQUIRE(a.in && a.w && a.out, EYOC_ERR_INVALID, "spconv: NULL tensor");
@@ -750,7 +739,8 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
   // Two decompositions: the wave-private kernel (spconv_wave.hip) wins once its 64-row tiles give every SIMD
   // a few waves' worth of work (measured cross-over ~4000 tiles on MI355X); below that the workgroup-tiled
   // kernel here balances better.  eyoc_spconv_select_kernel forces one of them.
-  const int force = g_kernel_mode;
+  const eyoc_ctx::Knobs& kn = knobs_of(a.ctx);
+  const int force = kn.spconv_kernel;
   const long long wave_tiles = (long long)cdiv(a.n_out, 64) * (a.cout >= 64 ? a.cout / 64 : 1);
   // row normalisation needs the whole output row in one tile: the wave-private kernel's tiles are at most 64
   // channels wide, so a normalised 128-channel layer always takes the workgroup-tiled kernel (CT = 128)
@@ -760,7 +750,7 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
     EYOC_REQUIRE(a.math == 0 || (a.cin % 32 == 0 && a.ld_in % 32 == 0), EYOC_ERR_INVALID, "spconv: split16 rows come in blocks of 32 channels");
     EYOC_REQUIRE(!a.out_split || a.ld_out % 32 == 0, EYOC_ERR_INVALID, "spconv: split16 output rows come in blocks of 32 channels");
     // split16 layers: the row-stationary kernel (spconv_rs.hip) unless eyoc_spconv_select_split16_kernel(0) asks for the wave-private one
-    const int use_rs = g_split16_kernel;
+    const int use_rs = kn.split16_kernel;
     // measured per layer of the 64-pair bench: the row-stationary kernel wins on the stride-1, transposed and 1x1 layers
     // with C_in >= 64 (-5 .. -15 %); the 32-channel layers and the strided convolutions (few, scattered pairs per
     // output row: 2.9x more zero MFMAs buy nothing there) stay on the wave-private kernel
@@ -1062,8 +1052,8 @@ int launch_conv1(const Conv1Args& a, hipStream_t st) {
   if (conv1_walks_octree(a)) {
     // C_in = 1, 32 output channels, split16 activations downstream (the large-batch path): the MFMA formulation.  Its
     // products carry 22-bit significands like every split16 layer; fp32 consumers keep the exact-fp32 walker
-    if (g_conv1_staged != 2 && a.cin == 1 && a.cout == 32 && a.out_split && a.ks * a.ks * a.ks < 128 && !a.in_perm) {
-      if (a.local1 && g_conv1_staged == 1) {                               // Z-ordered maps: block vectors staged per 256-parent tile
+    if (knobs_of(a.ctx).conv1_kernel != 2 && a.cin == 1 && a.cout == 32 && a.out_split && a.ks * a.ks * a.ks < 128 && !a.in_perm) {
+      if (a.local1 && knobs_of(a.ctx).conv1_kernel == 1) {                               // Z-ordered maps: block vectors staged per 256-parent tile
         hipLaunchKernelGGL(conv1_bf_kernel, dim3(cdiv(a.nc, ST_TILE)), dim3(256), 0, st, a);
         EYOC_CHECK_HIP(hipGetLastError());
         return EYOC_OK;
@@ -1108,9 +1098,10 @@ extern "C" {
 
 size_t eyoc_spconv_packed_floats(int K, int cin, int cout) { return (size_t)K * cin * cout; }
 
-int eyoc_spconv_select_kernel(int mode) {
-  const int prev = eyoc::g_kernel_mode;
-  eyoc::g_kernel_mode = mode;
+int eyoc_spconv_select_kernel(eyoc_ctx* ctx, int mode) {
+  if (!ctx) return -2;
+  const int prev = ctx->knobs.spconv_kernel;
+  ctx->knobs.spconv_kernel = mode;
   return prev;
 }
 
@@ -1194,7 +1185,7 @@ int eyoc_spconv_build_local_rulebook(eyoc_ctx* ctx, const int32_t* nbr_dev, int 
   EYOC_REQUIRE(ctx && nbr_dev && out_dev && overflow_dev && K >= 1 && K <= 27 && n_out >= 0, EYOC_ERR_INVALID,
                "eyoc_spconv_build_local_rulebook: bad argument");
   EYOC_CHECK_HIP(hipMemsetAsync(overflow_dev, 0, 4, (hipStream_t)stream));
-  return build_local_rulebook(nbr_dev, K, n_out, (unsigned char*)out_dev, overflow_dev, (hipStream_t)stream);
+  return build_local_rulebook(nbr_dev, K, n_out, (unsigned char*)out_dev, overflow_dev, (hipStream_t)stream, ctx->knobs.st_group);
 }
 
 int eyoc_spconv_staged(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* local_dev, int n_out, int n_in, const float* in_dev, int ld_in,
@@ -1205,22 +1196,36 @@ int eyoc_spconv_staged(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* local_
   a.nbr = nbr_dev; a.K = 27; a.n_out = n_out; a.n_in = n_in; a.in = in_dev; a.ld_in = ld_in; a.cin = cin; a.w = wpacked_dev;
   a.cout = cout; a.bias = bias_dev; a.res = res_dev; a.ld_res = ld_res; a.relu = relu; a.l2norm = 0;
   a.out = out_dev; a.ld_out = ld_out; a.math = 1; a.out_split = out_split; a.out_scale = out_scale_dev;
-  a.local = (const unsigned char*)local_dev;
+  a.local = (const unsigned char*)local_dev; a.ctx = ctx;
   return launch_spconv(a, (hipStream_t)stream);
 }
 
-int eyoc_spconv_st_group_rows(int on) { return eyoc::select_st_group_rows(on); }
-int eyoc_spconv_st_ksplit(int on) { return eyoc::select_st_ksplit(on); }
-
-int eyoc_spconv_select_up_kernel(int on) {
-  const int prev = eyoc::g_up_kernel;
-  if (on >= 0 && on <= 2) eyoc::g_up_kernel = on;
+// the setters below return the previous value (-1: NULL ctx) and leave the switch alone for an out-of-range argument, so
+// f(ctx, -1) reads it
+int eyoc_spconv_st_group_rows(eyoc_ctx* ctx, int on) {
+  if (!ctx) return -1;
+  const int prev = ctx->knobs.st_group;
+  if (on == 0 || on == 1) ctx->knobs.st_group = on;
+  return prev;
+}
+int eyoc_spconv_st_ksplit(eyoc_ctx* ctx, int on) {
+  if (!ctx) return -1;
+  const int prev = ctx->knobs.st_ksplit;
+  if (on == 0 || on == 1) ctx->knobs.st_ksplit = on;
   return prev;
 }
 
-int eyoc_spconv_upc_min_rows(int rows) {
-  const int prev = eyoc::g_upc_min_rows;
-  if (rows >= 0) eyoc::g_upc_min_rows = rows;
+int eyoc_spconv_select_up_kernel(eyoc_ctx* ctx, int on) {
+  if (!ctx) return -1;
+  const int prev = ctx->knobs.up_kernel;
+  if (on >= 0 && on <= 2) ctx->knobs.up_kernel = on;
+  return prev;
+}
+
+int eyoc_spconv_upc_min_rows(eyoc_ctx* ctx, int rows) {
+  if (!ctx) return -1;
+  const int prev = ctx->knobs.upc_min_rows;
+  if (rows >= 0) ctx->knobs.upc_min_rows = rows;
   return prev;
 }
 
@@ -1251,24 +1256,31 @@ int eyoc_spconv_upc(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* ws_dev, i
   return launch_spconv(a, (hipStream_t)stream);
 }
 
-int eyoc_spconv_select_conv1_kernel(int on) {
-  const int prev = eyoc::g_conv1_staged;
-  if (on >= 0 && on <= 2) eyoc::g_conv1_staged = on;
+int eyoc_spconv_select_conv1_kernel(eyoc_ctx* ctx, int on) {
+  if (!ctx) return -1;
+  const int prev = ctx->knobs.conv1_kernel;
+  if (on >= 0 && on <= 2) ctx->knobs.conv1_kernel = on;
   return prev;
 }
 
-
-int eyoc_spconv_select_st_kernel(int variant) {
-  return eyoc::select_st_variant(variant);
+int eyoc_spconv_select_st_kernel(eyoc_ctx* ctx, int variant) {
+  if (!ctx) return -1;
+  const int prev = ctx->knobs.st_variant;
+  if (variant >= 0 && variant < eyoc::st_variants()) ctx->knobs.st_variant = variant;
+  return prev;
 }
 
-int eyoc_spconv_st_split_below(int workgroups) {
-  return eyoc::select_st_split_below(workgroups);
+int eyoc_spconv_st_split_below(eyoc_ctx* ctx, int workgroups) {
+  if (!ctx) return -1;
+  const int prev = ctx->knobs.st_split_below;
+  if (workgroups >= 0) ctx->knobs.st_split_below = workgroups;
+  return prev;
 }
 
-int eyoc_spconv_select_split16_kernel(int mode) {
-  const int prev = eyoc::g_split16_kernel;
-  if (mode >= 0 && mode <= 2) eyoc::g_split16_kernel = mode;
+int eyoc_spconv_select_split16_kernel(eyoc_ctx* ctx, int mode) {
+  if (!ctx) return -1;
+  const int prev = ctx->knobs.split16_kernel;
+  if (mode >= 0 && mode <= 2) ctx->knobs.split16_kernel = mode;
   return prev;
 }
 
@@ -1280,7 +1292,7 @@ int eyoc_spconv_ex(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, int 
   SpconvArgs a;
   a.nbr = nbr_dev; a.K = K; a.n_out = n_out; a.n_in = n_in; a.in = in_dev; a.ld_in = ld_in; a.cin = cin; a.w = wpacked_dev;
   a.cout = cout; a.bias = bias_dev; a.res = res_dev; a.ld_res = ld_res; a.relu = relu; a.l2norm = 0;
-  a.out = out_dev; a.ld_out = ld_out; a.math = math; a.out_split = out_split; a.out_scale = out_scale_dev;
+  a.out = out_dev; a.ld_out = ld_out; a.math = math; a.out_split = out_split; a.out_scale = out_scale_dev; a.ctx = ctx;
   return launch_spconv(a, (hipStream_t)stream);
 }
 
@@ -1307,7 +1319,7 @@ int eyoc_spconv(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, const f
   SpconvArgs a;
   a.nbr = nbr_dev; a.K = K; a.n_out = n_out; a.in = in_dev; a.ld_in = ld_in; a.cin = cin; a.w = wpacked_dev;
   a.cout = cout; a.bias = bias_dev; a.res = res_dev; a.ld_res = ld_res; a.relu = relu; a.l2norm = 0;
-  a.out = out_dev; a.ld_out = ld_out;
+  a.out = out_dev; a.ld_out = ld_out; a.ctx = ctx;
   return launch_spconv(a, (hipStream_t)stream);
 }
 

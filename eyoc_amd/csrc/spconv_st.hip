@@ -767,13 +767,9 @@ size_t local_rulebook_bytes(int n_out) { return (size_t)cdiv(n_out, TILE) * LR_B
 
 // builds the per-tile local rulebooks of a stride-1 table; *overflow_dev (zeroed by the caller) counts tiles with more
 // than NPASS * UMAX distinct input rows (the staged kernel must not be used for the table then)
-static std::atomic<int> g_st_group{1};
-int select_st_group_rows(int on) { return (on == 0 || on == 1) ? g_st_group.exchange(on) : g_st_group.load(); }
-
-// group: 1 = the tile's rows sorted by neighbour pattern, 0 = in their own order, -1 = the process-wide setting (select_st_group_rows)
+// group: 1 = the tile's rows sorted by neighbour pattern (eyoc_ctx::Knobs::st_group, the default), 0 = in their own order
 int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st, int group) {
   if (n_out <= 0) return EYOC_OK;
-  if (group < 0) group = g_st_group.load();
   hipLaunchKernelGGL(k_local_rulebook, dim3(cdiv(n_out, TILE)), dim3(256), 0, st, nbr_dev, K, n_out, out_dev, overflow_dev, group);
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
@@ -782,17 +778,12 @@ int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char
 // which staged kernel runs: 0 = the C++ offset loop (spconv_st_kernel), 1 = the assembly loop (default), 2 = the assembly loop
 // without the empty-block branches (diagnostics); -DEYOC_ST_ABLATIONS builds add 3 = operand reads only for non-empty blocks
 // (round 5: level) and 13 ... = timing-only ablations
-static std::atomic<int> g_st_variant{1};
 #ifdef EYOC_ST_ABLATIONS
 constexpr int ST_VARIANTS = 28;
 #else
 constexpr int ST_VARIANTS = 3;
 #endif
-static std::atomic<int> g_st_split_below{1024};
-static std::atomic<int> g_st_ksplit{1};
-int select_st_ksplit(int on) { return (on == 0 || on == 1) ? g_st_ksplit.exchange(on) : g_st_ksplit.load(); }
-int select_st_split_below(int workgroups) { return workgroups >= 0 ? g_st_split_below.exchange(workgroups) : g_st_split_below.load(); }
-int select_st_variant(int v) { return (v >= 0 && v < ST_VARIANTS) ? g_st_variant.exchange(v) : g_st_variant.load(); }
+int st_variants() { return ST_VARIANTS; }
 
 // stride-1 SPLIT16 layers whose table has a local rulebook (rows in natural = Morton order, no tiling permutation)
 int launch_spconv_st(const SpconvArgs& a_in, const unsigned char* local_dev, hipStream_t st) {
@@ -803,8 +794,9 @@ int launch_spconv_st(const SpconvArgs& a_in, const unsigned char* local_dev, hip
   // rounds of work; small problems (a batch of 8 pairs: 70 tiles at the coarsest level) take 32 (waves of 64 rows x 32 channels,
   // twice the workgroups, each half as long) - below ~2 rounds a layer lasts as long as ONE workgroup does
   // (measured: single pair 2.08 -> 1.84 ms with the threshold at 1024 workgroups; a batch of 8 pairs does not care)
-  const int split_below = g_st_split_below.load();
-  const int variant0 = g_st_variant.load();
+  const eyoc_ctx::Knobs& kn = knobs_of(a.ctx);
+  const int split_below = kn.st_split_below;
+  const int variant0 = kn.st_variant;
   const bool small = variant0 != 0 && a.cout >= 64 && a.cout <= 256 && (long long)n_tiles * (a.cout / 64) < split_below;
   const int ctg = a.cout >= 64 && !small ? 64 : 32;                  // output channels per workgroup
   const bool wide = spconv_cc(a.cin, a.cout) == 64;
@@ -812,11 +804,11 @@ int launch_spconv_st(const SpconvArgs& a_in, const unsigned char* local_dev, hip
   EYOC_REQUIRE(a.cout % ctg == 0 && n_cg >= 1 && n_cg <= 8 && 8 % n_cg == 0 && a.cin % 32 == 0, EYOC_ERR_INVALID,
                "spconv_st: %d -> %d channels", a.cin, a.cout);
   dim3 grid((unsigned)(cdiv(n_tiles, 8 / n_cg) * 8)), block(NW * 64);
-  const int variant = g_st_variant.load();
+  const int variant = kn.st_variant;
   // small inputs (32-channel workgroups that do not fill the chip's 512 slots): the 32-channel input blocks of a tile split over
   // ksplit workgroups, as many as keep workgroups x splits within the scratch (and never more than there are blocks)
   int ksplit = 1;
-  if (variant == 1 && ctg == 32 && a.ks_part && g_st_ksplit.load() && a.cin >= 128) {   // (two blocks: the second launch costs what the split saves)
+  if (variant == 1 && ctg == 32 && a.ks_part && kn.st_ksplit && a.cin >= 128) {   // (two blocks: the second launch costs what the split saves)
     const int wgs = (int)grid.x, nqb = a.cin / 32;
     ksplit = KS_MAX_SLOTS / (wgs > 0 ? wgs : 1);
     if (ksplit > nqb) ksplit = nqb;

@@ -67,7 +67,7 @@ def ransac_batched_from_correspondences(src, tgt, corr_tgt, seg_src, seg_tgt, ma
         # the largest launch chunk that fits ``workspace_budget`` bytes (default: a quarter of what the device and the
         # allocator's cache have free, at most 16 GB); any chunk size gives the same results
         budget = int(workspace_budget) if workspace_budget else _ransac_budget(s.device)
-        ws = _lib.workspace(lib.eyoc_ransac_workspace_bytes(P, int(seg_src[-1]), int(max_iteration), budget), s.device)
+        ws = _lib.workspace(lib.eyoc_ransac_workspace_bytes(_lib.ctx(s.device.index), P, int(seg_src[-1]), int(max_iteration), budget), s.device)
         _lib.check(lib.eyoc_ransac_batched_ws(_lib.ctx(s.device.index), _lib.ptr(s), _lib.ptr(t), _lib.ptr(c), ss, st, P,
                                               C.byref(p), _lib.ptr(res), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
                    "eyoc_ransac_batched_ws")

@@ -50,6 +50,11 @@ int eyoc_version(void);
 const char* eyoc_last_error(void);
 int eyoc_create(int device, eyoc_ctx** out);
 int eyoc_destroy(eyoc_ctx* ctx);
+/* The kernel-selection and tiling switches declared further down (eyoc_maps_order_*, eyoc_maps_select_orders, eyoc_maps_internal_order,
+ * eyoc_spconv_select_*, eyoc_spconv_st_*, eyoc_spconv_upc_min_rows, eyoc_model_fuse_tail, eyoc_knn_prefilter, eyoc_ransac_select_pruning,
+ * eyoc_ransac_transform_store) are state of the ctx they are given: every entry point reads them from ITS ctx (file-scope statics until
+ * round 4).  They exist for parity tests and profiling; production code never calls them.  Each returns the previous value (-1 for a
+ * NULL ctx) and only queries when the argument is out of range. */
 
 /* ------------------------------------------------------------------------------------------------
  * coordinate maps + rulebooks
@@ -83,7 +88,7 @@ int eyoc_maps_build(eyoc_ctx* ctx, const int32_t* coords_dev, int n_rows, void* 
 /* eyoc_maps_build keeps the CALLER's row order (the accessors below return level coordinates and tables in the caller's
  * rows).  The same with the internal row order chosen by the caller: -1 automatic (Z-order from 8192 rows: what
  * eyoc_model_forward is fastest on), 0 the caller's order (the level coordinates and tables the accessors below return
- * are then in the caller's rows), 1 Z-order.  eyoc_maps_internal_order(0 / 1) overrides it process-wide. */
+ * are then in the caller's rows), 1 Z-order.  eyoc_maps_internal_order(ctx, 0 / 1) overrides it for every build of that ctx. */
 int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n_rows, void* workspace_dev,
                             size_t workspace_bytes, void* stream, int order, eyoc_maps** out);
 int eyoc_maps_free(eyoc_maps* maps);
@@ -93,24 +98,24 @@ int eyoc_maps_free(eyoc_maps* maps);
  * out_dev: int32 [rows[level]]. */
 int eyoc_maps_copy_up_order(const eyoc_maps* maps, int level, int32_t* out_dev, void* stream);
 /* Levels with fewer rows than this keep the natural order (the sorts only pay off for the large-batch kernel;
- * default 65536).  Process-wide; min_rows < 0 only queries.  Returns the previous value.  For tests / profiling. */
-int eyoc_maps_order_min_rows(int min_rows);
+ * default 65536).  Per ctx; min_rows < 0 only queries.  Returns the previous value.  For tests / profiling. */
+int eyoc_maps_order_min_rows(eyoc_ctx* ctx, int min_rows);
 /* Z-ordered maps sort their tiling orders inside windows of 2^shift consecutive rows (default 18; the window's rows and
- * their neighbours stay cache-resident while its pattern runs are walked).  Process-wide; shift < 0 only queries.
+ * their neighbours stay cache-resident while its pattern runs are walked).  Per ctx; shift < 0 only queries.
  * Returns the previous value.  For tests / profiling. */
-int eyoc_maps_order_window_shift(int shift);
+int eyoc_maps_order_window_shift(eyoc_ctx* ctx, int shift);
 /* Which tables get a pattern-sorted tiling order at all: s1 = the stride-1 tables (default 1), down = the strided tables of
  * Z-ordered maps (default 0: natural order wins there).  0 / 1 set, anything else leaves the switch alone.  Returns the
- * previous state (s1 | down << 1).  Process-wide, read when maps are built; for tests / profiling. */
-int eyoc_maps_select_orders(int s1, int down);
+ * previous state (s1 | down << 1).  Per ctx, read when maps are built; for tests / profiling. */
+int eyoc_maps_select_orders(eyoc_ctx* ctx, int s1, int down);
 /* Internal row order.  From 8192 rows on (mode -1, the default) the maps store level 0 in Z-order (Morton order of
  * (batch, x, y, z)) instead of the caller's order, so that 64 consecutive rows are a compact blob of voxels - what
  * the tile-local input stage of the sparse convolution needs.  eyoc_maps_coords / _table then describe the INTERNAL
  * rows; eyoc_maps_row_order returns the device array perm[i] = caller's row of internal row i (NULL: the caller's order
  * was kept).  eyoc_model_forward reads its input and writes its output in the caller's order either way.
  * eyoc_maps_internal_order(mode): -1 automatic, 0 always the caller's order, 1 always Z-order; returns the previous
- * mode + 2; process-wide, for tests. */
-int eyoc_maps_internal_order(int mode);
+ * mode + 2; per ctx, for tests. */
+int eyoc_maps_internal_order(eyoc_ctx* ctx, int mode);
 const int32_t* eyoc_maps_row_order(const eyoc_maps* maps);
 /* stream-ordered copy of the same array (the identity when the caller's order was kept); out_dev: int32 [rows[0]] */
 int eyoc_maps_copy_row_order(const eyoc_maps* maps, int32_t* out_dev, void* stream);
@@ -164,14 +169,14 @@ int eyoc_spconv(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, const f
  * implement split16 layers - wave-private (spconv_wave.hip, pair compaction + LDS accumulators) and row-stationary
  * (spconv_rs.hip, register accumulators + zero operands, weights shared through LDS); the launcher picks per layer,
  * eyoc_spconv_select_split16_kernel forces one (0 wave-private, 2 row-stationary, 1 automatic; returns the previous
- * mode; process-wide, for tests and profiling). */
-int eyoc_spconv_select_split16_kernel(int mode);
+ * mode; per ctx, for tests and profiling). */
+int eyoc_spconv_select_split16_kernel(eyoc_ctx* ctx, int mode);
 /* Staged kernel for the transposed 3^3 / stride-2 convolutions on Z-ordered maps (spconv_up.hip: tile rows sorted by
  * parity class, only occupied (16-row group, offset) blocks multiplied): 1 on (default: as fast as the row-stationary
  * kernel in windowed pattern order, 18 GB less HBM traffic per 128-cloud forward), 0 off (gathering kernels), 2 (default since
  * round 4) = the class-major kernel below for batches and this one for small inputs; other values only query.  Returns the
- * previous state.  Process-wide, read when maps are built; for tests and profiling. */
-int eyoc_spconv_select_up_kernel(int on);
+ * previous state.  Per ctx, read when maps are built; for tests and profiling. */
+int eyoc_spconv_select_up_kernel(eyoc_ctx* ctx, int on);
 /* The same layers in CLASS-MAJOR order (spconv_upc.hip; eyoc_spconv_select_up_kernel(2)): the fine rows are partitioned by parity
  * class (8 classes of 1-8 offsets), a tile is 256 rows of one class and runs the staged kernel's assembly loop over that class's
  * offsets only.  Standalone entry points (the model uses the same kernels through its maps): workspace size for a table with
@@ -181,8 +186,8 @@ int eyoc_spconv_select_up_kernel(int on);
  *   replaces: ME.MinkowskiConvolutionTranspose(kernel_size=3, stride=2) of model/resunet.py:83-116 */
 /* eyoc_spconv_select_up_kernel(2) (the default) uses the class-major kernel for maps with at least this many level-0 rows (default
  * 2^17; the partition's extra launches cost a single 60 k-voxel pair more than the kernel saves) and spconv_up.hip below; a
- * negative argument only queries; returns the previous value.  Process-wide, read when maps are built. */
-int eyoc_spconv_upc_min_rows(int rows);
+ * negative argument only queries; returns the previous value.  Per ctx, read when maps are built. */
+int eyoc_spconv_upc_min_rows(eyoc_ctx* ctx, int rows);
 /* Rows per tile of the classes with `odd_axes` (0..3) odd axes: 128..256, a multiple of 16 (default 256, and 192 for the
  * 8-offset class, whose 256-row tiles would need two stage passes).  Current device; read when records are built; for
  * measurements (workspace sizes assume >= 128). */
@@ -195,8 +200,8 @@ int eyoc_spconv_upc(eyoc_ctx* ctx, const int32_t* nbr_dev, const void* ws_dev, i
 /* First convolution (C_in = 1, 32 output channels) of split16 forwards on Z-ordered maps: 1 (default) = conv1_bf_kernel - the block
  * feature vectors (8 child features per level-1 row) of a 256-parent tile's neighbourhood staged in LDS through the level-1 tile
  * rulebook, the tile's fine rows grouped by parity class, a K = 27 product over blocks; 0 = conv1_mfma_kernel, which probes
- * the octree per fine row; 2 = the exact-fp32 octree walker (conv1_tree_kernel) even in front of split16 consumers.  Other values only query.  Returns the previous state; process-wide, for tests and profiling. */
-int eyoc_spconv_select_conv1_kernel(int on);
+ * the octree per fine row; 2 = the exact-fp32 octree walker (conv1_tree_kernel) even in front of split16 consumers.  Other values only query.  Returns the previous state; per ctx, for tests and profiling. */
+int eyoc_spconv_select_conv1_kernel(eyoc_ctx* ctx, int on);
 /* Stride-1 (3^3) split16 layers with a tile-local input stage (spconv_st.hip): per 256-row tile the distinct input rows are
  * copied to LDS once per 32-channel block and all 27 offsets run from there.  Needs the table's per-tile "local
  * rulebooks" (built once per table; *overflow_dev counts 256-row tiles with more than 1278 distinct input rows - the staged
@@ -204,23 +209,23 @@ int eyoc_spconv_select_conv1_kernel(int on);
  * uses them itself; these entry points exist for tests and profiling.
  * eyoc_spconv_select_st_kernel picks the implementation of the offset loop: 1 (default) = hand-scheduled gfx950 assembly
  * with scalar branches around the MFMAs of empty (16-row chunk, offset) blocks; 2 = the same without the branches;
- * 0 = the compiler-scheduled C++ loop.  Any other value only queries.  Returns the previous variant; process-wide, for tests and profiling. */
-int eyoc_spconv_select_st_kernel(int variant);
+ * 0 = the compiler-scheduled C++ loop.  Any other value only queries.  Returns the previous variant; per ctx, for tests and profiling. */
+int eyoc_spconv_select_st_kernel(eyoc_ctx* ctx, int variant);
 /* A layer with fewer than `workgroups` 64-output-channel workgroups (default 1024 = two rounds of the chip's 512 slots) runs
  * in 32-channel workgroups instead (twice as many, each half as long: single pairs and small batches).  0 = never (tests force
- * the wide kernels onto small clouds with it); negative only queries.  Returns the previous threshold; process-wide. */
-int eyoc_spconv_st_split_below(int workgroups);
+ * the wide kernels onto small clouds with it); negative only queries.  Returns the previous threshold; per ctx. */
+int eyoc_spconv_st_split_below(eyoc_ctx* ctx, int workgroups);
 /* Row grouping inside the 256-row tile records (default on): the builder sorts a tile's rows by their neighbour pattern so that the 16
  * rows of an MFMA chunk miss the same offsets - the staged loop skips (chunk, offset) blocks without a neighbour, and 0.81-0.93 of
  * them are non-empty in row order, 0.68-0.72 grouped.  Results are bit-identical either way (only the order of a tile's rows inside
- * its workgroup changes).  1 / 0 set, anything else only queries; returns the previous state; process-wide, read when records are built. */
-int eyoc_spconv_st_group_rows(int on);
+ * its workgroup changes).  1 / 0 set, anything else only queries; returns the previous state; per ctx, read when records are built. */
+int eyoc_spconv_st_group_rows(eyoc_ctx* ctx, int on);
 /* Small inputs (a single pair: the level-3 layer is 72 workgroups walking 8 input blocks x 27 offsets each): eyoc_model_forward lets
  * the staged kernel split a tile's 32-channel input blocks over several workgroups (partial sums in the forward's workspace, added in
  * share order by a second launch: bit-reproducible).  1 on (default) / 0 off, anything else only queries; returns the
- * previous state; process-wide, for tests and profiling.  Results differ from the unsplit kernel by fp32 rounding (another
+ * previous state; per ctx, for tests and profiling.  Results differ from the unsplit kernel by fp32 rounding (another
  * summation order). */
-int eyoc_spconv_st_ksplit(int on);
+int eyoc_spconv_st_ksplit(eyoc_ctx* ctx, int on);
 size_t eyoc_spconv_local_rulebook_bytes(int n_out);
 int eyoc_spconv_build_local_rulebook(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, void* out_dev,
                                      int32_t* overflow_dev, void* stream);
@@ -249,8 +254,8 @@ int eyoc_spconv_grad_weight(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_
                             size_t workspace_bytes, void* stream);
 /* Two decompositions implement the operator (workgroup-tiled: spconv.hip, wave-private: spconv_wave.hip);
  * by default the launcher picks by problem size.  mode -1 = automatic (default), 0 = workgroup-tiled,
- * 1 = wave-private.  Process-wide; meant for parity tests and profiling.  Returns the previous mode. */
-int eyoc_spconv_select_kernel(int mode);
+ * 1 = wave-private.  Per ctx; meant for parity tests and profiling.  Returns the previous mode. */
+int eyoc_spconv_select_kernel(eyoc_ctx* ctx, int mode);
 
 /* ------------------------------------------------------------------------------------------------
  * ResUNet2 family (ResUNetBN2C in production)
@@ -293,8 +298,8 @@ int eyoc_model_create(eyoc_ctx* ctx, const eyoc_model_desc* desc, const eyoc_lay
 int eyoc_model_destroy(eyoc_model* model);
 /* split16 forwards run the network's 1x1 tail (conv1_tr -> ReLU -> final + bias -> row normalisation, model/resunet.py:183-191)
  * as ONE kernel whose 64-channel intermediate never leaves the registers (spconv_tail.hip; BN2C's 96 -> 64 -> 32 widths):
- * 1 on (default), 0 = two launches; other values only query.  Returns the previous state; process-wide, for tests. */
-int eyoc_model_fuse_tail(int on);
+ * 1 on (default), 0 = two launches; other values only query.  Returns the previous state; per ctx, for tests. */
+int eyoc_model_fuse_tail(eyoc_ctx* ctx, int on);
 size_t eyoc_model_workspace_bytes(const eyoc_model* model, const eyoc_maps* maps);
 /* feats_dev f32 [N1, in_channels] -> out_dev f32 [N1, out_channels], rows in input order */
 int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* model, const eyoc_maps* maps,
@@ -345,8 +350,8 @@ int eyoc_model_timing_slot(eyoc_model* model, int slot);
 /* MFMA pre-filter of eyoc_knn1's plain index query (dist_type 0 or 2, idx only, C = 32): an fp32-MFMA score decides every row
  * whose runner-up is out of rounding reach, the exact kernel recomputes the rest - the indices are identical either way.
  * mode 0: never, 1 (default): when the query fills the chip (>= 512 waves of 64 rows), 2: always; < 0 only queries.
- * Returns the previous mode.  Process-wide; for tests and profiling. */
-int eyoc_knn_prefilter(int mode);
+ * Returns the previous mode.  Per ctx; for tests and profiling. */
+int eyoc_knn_prefilter(eyoc_ctx* ctx, int mode);
 /* ------------------------------------------------------------------------------------------------
  * feature matching
  *   replaces: lib.eval.find_nn_gpu + lib.metrics.pdist (lib/eval.py:18-48, lib/metrics.py:22-29)
@@ -490,14 +495,14 @@ int eyoc_ransac(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const
  * do not depend on the chunk size.
  *
  * eyoc_ransac_batched_ws: CALLER-OWNED scratch (256-byte aligned device memory; nothing is allocated inside the call).
- * eyoc_ransac_workspace_bytes(n_pairs, total_corr = seg_src[n_pairs], max_iteration, budget) = the bytes of the largest
+ * eyoc_ransac_workspace_bytes(ctx, n_pairs, total_corr = seg_src[n_pairs], max_iteration, budget) = the bytes of the largest
  * chunk (n_pairs capped at 64, then halved) that stays within `budget` bytes (0 = no limit), never less than a one-pair
  * chunk; the call derives its chunk from workspace_bytes the same way and returns EYOC_ERR_WORKSPACE if not even one pair
  * fits.
  * eyoc_ransac_batched (and eyoc_ransac): the same on the ctx's grow-only scratch, for callers without an allocator - the
  * chunk is sized so that the scratch takes at most a quarter of the device's free memory (hipMemGetInfo) and at most
  * 16 GB, and is halved again (down to one pair) if the allocation fails all the same. */
-size_t eyoc_ransac_workspace_bytes(int n_pairs, int total_corr, int max_iteration, size_t budget_bytes);
+size_t eyoc_ransac_workspace_bytes(const eyoc_ctx* ctx, int n_pairs, int total_corr, int max_iteration, size_t budget_bytes);
 int eyoc_ransac_batched_ws(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const int64_t* corr_tgt_dev,
                            const int32_t* seg_src_host, const int32_t* seg_tgt_host, int n_pairs,
                            const eyoc_ransac_params* params, eyoc_ransac_result* results_dev, void* workspace_dev,
@@ -507,12 +512,12 @@ int eyoc_ransac_batched(eyoc_ctx* ctx, const float* src_dev, const float* tgt_de
                         const eyoc_ransac_params* params, eyoc_ransac_result* results_dev, void* stream);
 /* Reference pruning of the scorer (k_bucket: a survivor only evaluates the correspondences that can be inliers given its
  * distance to the pair's first survivor; counts are exactly those of the full sweep): 1 on (default), 0 off, other values
- * only query.  Returns the previous state.  Process-wide; for tests / profiling. */
-int eyoc_ransac_select_pruning(int on);
+ * only query.  Returns the previous state.  Per ctx; for tests / profiling. */
+int eyoc_ransac_select_pruning(eyoc_ctx* ctx, int on);
 /* How many survivor transforms per pair are stored for the scorer (default 2^20 = 96 MB per pair; survivors beyond it are
  * re-derived from their hypothesis number by k_count_overflow - same counts, more work).  survivors >= 1 sets, anything else
- * only queries; returns the previous value.  Process-wide; tests set it tiny to drive every survivor through the overflow path. */
-int eyoc_ransac_transform_store(int survivors);
+ * only queries; returns the previous value.  Per ctx; tests set it tiny to drive every survivor through the overflow path. */
+int eyoc_ransac_transform_store(eyoc_ctx* ctx, int survivors);
 
 /* replaces: Matcher.SC2_PCR (scripts/SC2_PCR/SC2_PCR.py:307-384) for bs == 1.
  * src,tgt f32 [n,3] matched correspondences -> T f32 [4,4], seedwise_fitness f32 [int(ratio*n)]. */

@@ -12,10 +12,10 @@ pipe = RegistrationPipeline(model, cfg)
 batch = DeviceBatch(pairs, list(range(P)), dev, descriptor=dict(inlier_ratio=0.3))
 if os.environ.get("ST_GROUP"):
     from eyoc_amd import _lib
-    _lib.load().eyoc_spconv_st_group_rows(int(os.environ["ST_GROUP"]))
+    _lib.knob("eyoc_spconv_st_group_rows", int(os.environ["ST_GROUP"]))
 if os.environ.get("ZSPLIT"):
     from eyoc_amd import _lib
-    _lib.load().eyoc_maps_internal_order(1)
+    _lib.knob("eyoc_maps_internal_order", 1)
     model.spconv_math = "split16"
 for _ in range(3): pipe.register(batch)
 pipe.timing = True; model.set_timing(True)

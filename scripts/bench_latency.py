@@ -19,7 +19,7 @@ model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.make_w
 model = model.to(device).eval()
 if os.environ.get("ST_GROUP"):
     from eyoc_amd import _lib
-    _lib.load().eyoc_spconv_st_group_rows(int(os.environ["ST_GROUP"]))
+    _lib.knob("eyoc_spconv_st_group_rows", int(os.environ["ST_GROUP"]))
 pipe = RegistrationPipeline(model, cfg)
 single = DeviceBatch([syn.make_pair(0)], [0], device, cfg.n_points)
 for _ in range(3):

@@ -11,7 +11,7 @@ for name, clouds in (("half cloud", [p["coords0"][:15000]]), ("1 cloud", [p["coo
     coords = torch.from_numpy(syn.batch_coords(clouds)).to(dev)
     feats = torch.ones((coords.shape[0], 1), device=dev)
     for mode in ("old", "new"):
-        lib.eyoc_maps_internal_order(1 if mode == "new" else 0)
+        _lib.knob("eyoc_maps_internal_order", 1 if mode == "new" else 0)
         model.spconv_math = "split16" if mode == "new" else "fp32"
         def run():
             return model(eyoc_amd.SparseTensor(feats, coordinates=coords)).F

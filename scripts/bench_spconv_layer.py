@@ -23,9 +23,9 @@ lib = _lib.load()
 # kernel selection through the library's setters (it reads no environment variables): WAVE=0/1 forces the workgroup-tiled /
 # wave-private kernel, RS=0/2 the wave-private / row-stationary split16 kernel
 if os.environ.get("WAVE"):
-    lib.eyoc_spconv_select_kernel(int(os.environ["WAVE"]))
+    _lib.knob("eyoc_spconv_select_kernel", int(os.environ["WAVE"]))
 if os.environ.get("RS"):
-    lib.eyoc_spconv_select_split16_kernel(int(os.environ["RS"]))
+    _lib.knob("eyoc_spconv_select_split16_kernel", int(os.environ["RS"]))
 info = cm.info()
 print("rows", info["rows"], "pairs_s1", info["pairs_s1"], flush=True)
 MATH = int(os.environ.get("MATH", "1"))

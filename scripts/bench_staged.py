@@ -36,15 +36,15 @@ for lvl, cin, cout in LAYERS:
     t_lr = timeit(lambda: lib.eyoc_spconv_build_local_rulebook(_lib.ctx(), tab, 27, n, _lib.ptr(local), _lib.ptr(ovf), _lib.stream_ptr()))
     res_t = {}
     for name, mode in (() if os.environ.get("ONLY_ST") else (("wave", 0), ("rs", 2))):
-        lib.eyoc_spconv_select_split16_kernel(mode)
+        _lib.knob("eyoc_spconv_select_split16_kernel", mode)
         res_t[name] = timeit(lambda: _lib.check(lib.eyoc_spconv_ex(_lib.ctx(), tab, 27, n, n, _lib.ptr(xs), cin, cin, _lib.ptr(wd), cout, None, None, 0, 0, _lib.ptr(out), cout, 1, 1, _lib.ptr(osd), _lib.stream_ptr())))
-    lib.eyoc_spconv_select_split16_kernel(1)
+    _lib.knob("eyoc_spconv_select_split16_kernel", 1)
     ref_out = None
     variants = [int(v) for v in os.environ.get("ST_VARIANTS", "1,100").split(",")]       # 100: variant 1 on records WITHOUT row grouping
-    lib.eyoc_spconv_st_group_rows(0)
+    _lib.knob("eyoc_spconv_st_group_rows", 0)
     local_plain = torch.zeros_like(local)
     t_lr_plain = timeit(lambda: lib.eyoc_spconv_build_local_rulebook(_lib.ctx(), tab, 27, n, _lib.ptr(local_plain), _lib.ptr(ovf), _lib.stream_ptr()))
-    lib.eyoc_spconv_st_group_rows(1)
+    _lib.knob("eyoc_spconv_st_group_rows", 1)
     run_plain = lambda: _lib.check(lib.eyoc_spconv_staged(_lib.ctx(), tab, _lib.ptr(local_plain), n, n, _lib.ptr(xs), cin, cin, _lib.ptr(wd), cout, None, _lib.ptr(res), 0 if res is None else cout, 0, _lib.ptr(out), cout, 1, _lib.ptr(osd), _lib.stream_ptr()))
     res = None
     if os.environ.get("RES") and cin == cout:      # residual layers (the second convolution of a block): RES=1
@@ -55,16 +55,16 @@ for lvl, cin, cout in LAYERS:
     for rnd in range(int(os.environ.get("ROUNDS", "5"))):      # variants interleaved over several rounds: clocks drift with load
         for variant in variants:
             if variant == 100:
-                lib.eyoc_spconv_select_st_kernel(1)
+                _lib.knob("eyoc_spconv_select_st_kernel", 1)
                 best[variant].append(timeit(run_plain, reps=5))
                 if rnd == 0 and ref_out is not None and not torch.equal(ref_out, out): best[variant].append(-1e6)
                 continue
-            lib.eyoc_spconv_select_st_kernel(variant)
+            _lib.knob("eyoc_spconv_select_st_kernel", variant)
             best[variant].append(timeit(run_st, reps=5))
             if rnd == 0:
                 torch.cuda.synchronize()
                 if ref_out is None: ref_out = out.clone()
                 elif not torch.equal(ref_out, out): best[variant].append(-1e6)   # a mismatch shows as an absurd time
     for v in variants: res_t[f"st{v}"] = float(np.median(best[v])); res_t[f"st{v}min"] = min(best[v])
-    lib.eyoc_spconv_select_st_kernel(1)
+    _lib.knob("eyoc_spconv_select_st_kernel", 1)
     print(f"lvl{lvl} {cin}->{cout} n={n} pairs={prs} overflow={int(ovf.item())} local-rulebook {t_lr:.3f} (in row order {t_lr_plain:.3f}) | " + "  ".join(f"{k} {v:.3f} ms ({2*prs*cin*cout/v/1e9:.0f} TF)" for k, v in res_t.items()), flush=True)

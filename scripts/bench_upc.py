@@ -30,7 +30,7 @@ def layer_ref(T, x, W, rows):
     return out
 res = {}
 for mode in ((2,) if os.environ.get("ONLY_UPC") else (1, 2)):
-    lib.eyoc_spconv_select_up_kernel(1)        # maps with spconv_up.hip's records (mode 2 builds its own workspace below)
+    _lib.knob("eyoc_spconv_select_up_kernel", 1)        # maps with spconv_up.hip's records (mode 2 builds its own workspace below)
     cm = eyoc_amd.CoordinateManager(torch.from_numpy(coords).cuda())
     maps = cm.maps(); info = cm.info()
     for lvl, cin, cout in ((0, 128, 64), (1, 256, 64), (2, 256, 128)):

@@ -38,8 +38,8 @@ for lvl, cin, cout in ((0, 128, 64), (1, 256, 64), (2, 256, 128)):
     res = {}
     variants = [int(v) for v in os.environ.get("ST_VARIANTS", "1").split(",")]
     for grp in [0, 1] + [100 + v for v in variants if v != 1]:
-        lib.eyoc_spconv_st_group_rows(1 if grp >= 100 else grp)
-        lib.eyoc_spconv_select_st_kernel(grp - 100 if grp >= 100 else 1)
+        _lib.knob("eyoc_spconv_st_group_rows", 1 if grp >= 100 else grp)
+        _lib.knob("eyoc_spconv_select_st_kernel", grp - 100 if grp >= 100 else 1)
         t_lr = timeit(lambda: lib.eyoc_spconv_build_local_rulebook(_lib.ctx(), tab, 27, n, _lib.ptr(local), _lib.ptr(ovf), _lib.stream_ptr()))
         run_st = lambda: _lib.check(lib.eyoc_spconv_staged(_lib.ctx(), tab, _lib.ptr(local), n, n_in, _lib.ptr(xs), cin, cin, _lib.ptr(wd), cout, None, None, 0, 0, _lib.ptr(out), cout, 1, _lib.ptr(osd), _lib.stream_ptr()))
         t = timeit(run_st)
@@ -50,7 +50,7 @@ for lvl, cin, cout in ((0, 128, 64), (1, 256, 64), (2, 256, 128)):
         msk = rec[:, 32784:32784 + 54].copy().view(np.uint16)[:, :27]
         nonempty = np.unpackbits(msk.view(np.uint8), axis=1).mean()
         res[grp] = (t, t_lr, err, nonempty, nu.mean(), nu.max())
-    lib.eyoc_spconv_st_group_rows(1); lib.eyoc_spconv_select_st_kernel(1)
+    _lib.knob("eyoc_spconv_st_group_rows", 1); _lib.knob("eyoc_spconv_select_st_kernel", 1)
     print(f"lvl{lvl} {cin}->{cout} n={n} n_in={n_in} pairs={prs} ({prs / n:.2f}/row) overflow={int(ovf.item())} | gather kernel {t_ref:.3f} ms | " +
           "  ".join(f"staged group={g}: {v[0]:.3f} ms (records {v[1]:.3f} ms, rel err {v[2]:.1e}, non-empty blocks {v[3]:.3f}, distinct rows mean {v[4]:.0f} max {v[5]})" for g, v in res.items()), flush=True)
 
@@ -80,13 +80,13 @@ for lvl, cin, cout in ((0, 128, 64), (1, 256, 64), (2, 256, 128)):
     out = torch.empty(n, cout, device="cuda")
     local = torch.zeros(int(lib.eyoc_spconv_local_rulebook_bytes(n)), dtype=torch.uint8, device="cuda")
     ovf = torch.zeros(1, dtype=torch.int32, device="cuda")
-    lib.eyoc_spconv_st_group_rows(1)
+    _lib.knob("eyoc_spconv_st_group_rows", 1)
     lib.eyoc_spconv_build_local_rulebook(_lib.ctx(), _lib.ptr(Tp), 27, n, _lib.ptr(local), _lib.ptr(ovf), _lib.stream_ptr())
     res = {}
     for v in [1] + [v for v in variants if v != 1]:
-        lib.eyoc_spconv_select_st_kernel(v)
+        _lib.knob("eyoc_spconv_select_st_kernel", v)
         res[v] = timeit(lambda: _lib.check(lib.eyoc_spconv_staged(_lib.ctx(), _lib.ptr(Tp), _lib.ptr(local), n, n_in, _lib.ptr(xs), cin, cin, _lib.ptr(wd), cout, None, None, 0, 0, _lib.ptr(out), cout, 1, _lib.ptr(osd), _lib.stream_ptr())))
-    lib.eyoc_spconv_select_st_kernel(1)
+    _lib.knob("eyoc_spconv_select_st_kernel", 1)
     rec = local[: (n + 255) // 256 * 33408].view(-1, 33408).cpu().numpy()
     nu = rec[:, :4].copy().view(np.int32)[:, 0]
     msk = rec[:, 32784:32784 + 54].copy().view(np.uint16)[:, :27]

@@ -46,18 +46,18 @@ def test_forward_same_features_from_both_kernels_and_any_tiling_order(big_batch)
     model = _model()
     auto = _forward(model, coords)                       # automatic choice: wave-private where it pays, sorted tiles
     np.testing.assert_allclose(torch.linalg.norm(auto, dim=1).cpu().numpy(), 1.0, atol=1e-5)
-    prev = lib.eyoc_spconv_select_kernel(0)
+    prev = _lib.knob("eyoc_spconv_select_kernel", 0)
     try:
         tiled = _forward(model, coords)                  # workgroup-tiled kernel everywhere
     finally:
-        lib.eyoc_spconv_select_kernel(prev)
+        _lib.knob("eyoc_spconv_select_kernel", prev)
     assert float((auto - tiled).abs().max()) < 2e-5      # different summation grouping inside the MFMA chains only
     assert float((auto * tiled).sum(1).min()) > 1 - 1e-6
-    prev_rows = lib.eyoc_maps_order_min_rows(1 << 30)    # no tiling orders at all
+    prev_rows = _lib.knob("eyoc_maps_order_min_rows", 1 << 30)    # no tiling orders at all
     try:
         unordered = _forward(model, coords)
     finally:
-        lib.eyoc_maps_order_min_rows(prev_rows)
+        _lib.knob("eyoc_maps_order_min_rows", prev_rows)
     assert torch.equal(auto, unordered), "the tiling order must not change any bit of the result"
     assert torch.equal(auto, _forward(model, coords)), "run-to-run reproducibility"
 
@@ -69,14 +69,14 @@ def test_cloud_alone_equals_its_rows_in_the_batch(big_batch):
     lib = _lib.load()
     clouds, coords = big_batch
     model = _model()
-    prev = lib.eyoc_spconv_select_kernel(0)
+    prev = _lib.knob("eyoc_spconv_select_kernel", 0)
     try:
         full = _forward(model, coords)
         n0 = len(clouds[0])
         alone = _forward(model, syn.batch_coords([clouds[0]]))
         last = _forward(model, syn.batch_coords([clouds[-1]]))
     finally:
-        lib.eyoc_spconv_select_kernel(prev)
+        _lib.knob("eyoc_spconv_select_kernel", prev)
     assert torch.equal(full[:n0], alone)
     assert torch.equal(full[-len(clouds[-1]):], last)
 

@@ -23,9 +23,9 @@ def order_small_levels():
     """The tiling orders are only built for large levels in production; build them for the small test clouds too."""
     from eyoc_amd import _lib
     lib = _lib.load()
-    prev = lib.eyoc_maps_order_min_rows(0)
+    prev = _lib.knob("eyoc_maps_order_min_rows", 0)
     yield
-    lib.eyoc_maps_order_min_rows(prev)
+    _lib.knob("eyoc_maps_order_min_rows", prev)
 
 
 def check_up_order(order, up, window_shift=None):
@@ -90,15 +90,15 @@ def test_maps_synthetic_kitti_cloud():
 def zorder_rows():
     from eyoc_amd import _lib
     lib = _lib.load()
-    prev = lib.eyoc_maps_internal_order(1) - 2
-    prev_w = lib.eyoc_maps_order_window_shift(12)   # several windows in a 62k-row cloud
+    prev = _lib.knob("eyoc_maps_internal_order", 1) - 2
+    prev_w = _lib.knob("eyoc_maps_order_window_shift", 12)   # several windows in a 62k-row cloud
     # the windowed tiling order of the transposed tables is only built when the staged transposed kernel (which sorts inside its
     # tiles instead) is off: switch it off for these builds so that the order is still checked
-    prev_up = lib.eyoc_spconv_select_up_kernel(0)
+    prev_up = _lib.knob("eyoc_spconv_select_up_kernel", 0)
     yield
-    lib.eyoc_maps_internal_order(prev)
-    lib.eyoc_maps_order_window_shift(prev_w)
-    lib.eyoc_spconv_select_up_kernel(prev_up)
+    _lib.knob("eyoc_maps_internal_order", prev)
+    _lib.knob("eyoc_maps_order_window_shift", prev_w)
+    _lib.knob("eyoc_spconv_select_up_kernel", prev_up)
 
 
 @pytest.mark.parametrize("case", ["random3", "kitti", "tiny"])

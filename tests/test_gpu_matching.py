@@ -165,9 +165,9 @@ def test_many_segments_in_one_call():
 def prefilter_always():
     from eyoc_amd import _lib
     lib = _lib.load()
-    prev = lib.eyoc_knn_prefilter(2)
+    prev = _lib.knob("eyoc_knn_prefilter", 2)
     yield lib
-    lib.eyoc_knn_prefilter(prev)
+    _lib.knob("eyoc_knn_prefilter", prev)
 
 
 def test_mfma_prefilter_gives_the_contract_indices(prefilter_always):
@@ -176,6 +176,7 @@ def test_mfma_prefilter_gives_the_contract_indices(prefilter_always):
     on exact ties (duplicated targets, lowest index wins), on near-ties one ulp apart, with NaN rows and with
     features of very different norms."""
     import eyoc_amd
+    from eyoc_amd import _lib
     from oracle import matching as om
     lib = prefilter_always
     rng = np.random.default_rng(5)
@@ -187,10 +188,10 @@ def test_mfma_prefilter_gives_the_contract_indices(prefilter_always):
                                       return_distance=False).cpu().numpy()
         for s in range(len(seg_a) - 1 if oracle else 0):
             np.testing.assert_array_equal(got[seg_a[s]:seg_a[s + 1]], om.find_nn(A[seg_a[s]:seg_a[s + 1]], B[seg_b[s]:seg_b[s + 1]]))
-        lib.eyoc_knn_prefilter(0)
+        _lib.knob("eyoc_knn_prefilter", 0)
         ref = eyoc_amd.knn1_segmented(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(), seg_a, seg_b,
                                       return_distance=False).cpu().numpy()
-        lib.eyoc_knn_prefilter(2)
+        _lib.knob("eyoc_knn_prefilter", 2)
         np.testing.assert_array_equal(got, ref)
 
     # ordinary unit features, ragged segments (tiles of 16 targets / 64 queries with tails)
@@ -291,7 +292,7 @@ def test_match_pair_nn_bit_exact_vs_oracle(prefilter):
     from eyoc_amd import _lib
     from oracle import matching as om
     lib = _lib.load()
-    prev = lib.eyoc_knn_prefilter(prefilter)
+    prev = _lib.knob("eyoc_knn_prefilter", prefilter)
     try:
         saw_nan = False
         for name, A, B in _match_cases():
@@ -311,7 +312,7 @@ def test_match_pair_nn_bit_exact_vs_oracle(prefilter):
             saw_nan |= bool(np.isnan(wd).any())
         assert saw_nan
     finally:
-        lib.eyoc_knn_prefilter(prev)
+        _lib.knob("eyoc_knn_prefilter", prev)
 
 
 def test_match_pair_segments_and_l2_difference():

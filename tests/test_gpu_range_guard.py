@@ -104,9 +104,9 @@ CASES = ["conv1", "block1.conv1", "conv2", "conv4_tr", "block2_tr.conv2", "conv1
 def class_major(request):
     """True: the transposed convolutions run on spconv_upc.hip (class-major tiles) although the batch is small."""
     L, lib = _lib()
-    prev = lib.eyoc_spconv_upc_min_rows(0 if request.param else 1 << 30)
+    prev = L.knob("eyoc_spconv_upc_min_rows", 0 if request.param else 1 << 30)
     yield request.param
-    lib.eyoc_spconv_upc_min_rows(prev)
+    L.knob("eyoc_spconv_upc_min_rows", prev)
 
 
 @pytest.mark.parametrize("case,class_major", [(c, False) for c in CASES] + [("conv4_tr", True)], indirect=["class_major"])

@@ -67,12 +67,12 @@ def test_overflow_scorer_produces_the_winning_count(n, frac, H, seed):
     p1 = (p1 + np.random.default_rng(n).normal(0, 0.03, p1.shape)).astype(np.float32)
     args = (torch.from_numpy(p0), torch.from_numpy(p1), torch.arange(n), 0.3, H)
     full = eyoc_amd.ransac_from_correspondences(*args, seed=seed)
-    prev = lib.eyoc_ransac_transform_store(8)
+    prev = L.knob("eyoc_ransac_transform_store", 8)
     try:
-        assert lib.eyoc_ransac_transform_store(-1) == 8
+        assert L.knob("eyoc_ransac_transform_store", -1) == 8
         res = eyoc_amd.ransac_from_correspondences(*args, seed=seed)
     finally:
-        lib.eyoc_ransac_transform_store(prev)
+        L.knob("eyoc_ransac_transform_store", prev)
     ref = orn.ransac(p0, p1, np.arange(n), 0.3, H, seed=seed)
     assert res.survivors > 1000
     _same(res, ref)
@@ -103,10 +103,10 @@ def test_results_do_not_depend_on_the_launch_chunk_or_on_who_owns_the_scratch():
     s, t, c, seg_s, seg_t = _ragged_batch()
     P, H = len(seg_s) - 1, 60000
     want = reg.ransac_batched_from_correspondences(s, t, c, seg_s, seg_t, 0.3, H, seed=40).cpu().numpy()
-    sizes = {k: int(lib.eyoc_ransac_workspace_bytes(k, seg_s[-1], H, 0)) for k in (1, 2, 5, P)}
+    sizes = {k: int(lib.eyoc_ransac_workspace_bytes(L.ctx(0), k, seg_s[-1], H, 0)) for k in (1, 2, 5, P)}
     assert sizes[1] < sizes[2] < sizes[5] < sizes[P]
     for k in (5, 2, 1):
-        assert int(lib.eyoc_ransac_workspace_bytes(P, seg_s[-1], H, sizes[k])) == sizes[k]       # the largest chunk within the budget
+        assert int(lib.eyoc_ransac_workspace_bytes(L.ctx(0), P, seg_s[-1], H, sizes[k])) == sizes[k]       # the largest chunk within the budget
         got = reg.ransac_batched_from_correspondences(s, t, c, seg_s, seg_t, 0.3, H, seed=40, workspace_budget=sizes[k]).cpu().numpy()
         np.testing.assert_array_equal(got, want, err_msg=f"chunk of {k} pairs")
     # context-owned scratch

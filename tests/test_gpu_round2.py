@@ -97,11 +97,11 @@ def test_wave_kernel_variants_vs_oracle_on_kitti_cloud(kitti_maps, cin, cout, ki
     rng = np.random.default_rng(cin + cout)
     x = rng.normal(size=(n_in, cin)).astype(np.float32)
     W = (rng.normal(size=(27, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
-    prev = lib.eyoc_spconv_select_kernel(1)
+    prev = _lib.knob("eyoc_spconv_select_kernel", 1)
     try:
         got = run_layer(nbr, x, W, relu=True)
     finally:
-        lib.eyoc_spconv_select_kernel(prev)
+        _lib.knob("eyoc_spconv_select_kernel", prev)
     want = oracle_layer(nbr, x, W, relu=True)
     e = rel_err(got, want)
     print(f"wave {cin}->{cout} {kind} level {level}: n_out {nbr.shape[1]} rel err {e:.2e}")
@@ -122,11 +122,11 @@ def test_normalised_128_channel_output(mode):
     feats = np.ones((len(coords), 1), np.float32)
     sd = syn.make_weights(seed=9, out_channels=128)
     model, _ = _model(sd, out_channels=128)
-    prev = lib.eyoc_spconv_select_kernel(mode)
+    prev = _lib.knob("eyoc_spconv_select_kernel", mode)
     try:
         got = model(eyoc_amd.SparseTensor(torch.from_numpy(feats).cuda(), coordinates=torch.from_numpy(coords).cuda())).F.cpu().numpy()
     finally:
-        lib.eyoc_spconv_select_kernel(prev)
+        _lib.knob("eyoc_spconv_select_kernel", prev)
     want = orr.resunet_forward(sd, coords, feats).numpy()
     np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
     assert rel_err(got, want) < REL

@@ -18,11 +18,11 @@ def spconv_kernel(request):
     production picks between them by problem size."""
     from eyoc_amd import _lib
     lib = _lib.load()
-    prev = lib.eyoc_spconv_select_kernel(request.param)
-    prev_rows = lib.eyoc_maps_order_min_rows(0)   # build the tiling orders for the small test clouds as well
+    prev = _lib.knob("eyoc_spconv_select_kernel", request.param)
+    prev_rows = _lib.knob("eyoc_maps_order_min_rows", 0)   # build the tiling orders for the small test clouds as well
     yield request.param
-    lib.eyoc_spconv_select_kernel(prev)
-    lib.eyoc_maps_order_min_rows(prev_rows)
+    _lib.knob("eyoc_spconv_select_kernel", prev)
+    _lib.knob("eyoc_maps_order_min_rows", prev_rows)
 
 
 def rel_err(a, b):

@@ -25,9 +25,9 @@ def _lib():
 def split16_kernel(request):
     """Every test runs on both split16 kernels (spconv_wave.hip MATH = 1 / spconv_rs.hip); production picks per layer."""
     L, lib = _lib()
-    prev = lib.eyoc_spconv_select_split16_kernel(request.param)
+    prev = L.knob("eyoc_spconv_select_split16_kernel", request.param)
     yield request.param
-    lib.eyoc_spconv_select_split16_kernel(prev)
+    L.knob("eyoc_spconv_select_split16_kernel", prev)
 
 
 def encode(x):
@@ -127,11 +127,11 @@ def test_split16_layer_is_as_accurate_as_fp32_mfma(maps, cin, cout, split16_kern
     r = rng.normal(size=(nbr.shape[1], cout)).astype(np.float32)
     want = layer_f64(nbr, x, W, bias=b, scale=s, res=r, relu=True)
     lib = L.load()
-    prev = lib.eyoc_spconv_select_kernel(1)
+    prev = L.knob("eyoc_spconv_select_kernel", 1)
     try:
         got32 = run_layer(nbr, x, W, bias=b, scale=s, res=r, relu=True)
     finally:
-        lib.eyoc_spconv_select_kernel(prev)
+        L.knob("eyoc_spconv_select_kernel", prev)
     got16 = run_layer_split(nbr, x, W, bias=b, scale=s, res=r, relu=True)
     got16s = run_layer_split(nbr, x, W, bias=b, scale=s, res=r, relu=True, out_split=True)
     e32, e16, e16s = rel_err(got32, want), rel_err(got16, want), rel_err(got16s, want)
@@ -244,21 +244,21 @@ def test_forward_on_z_ordered_rows_with_the_staged_kernel(request):
     feats = np.concatenate([p["feats0"], p["feats1"]])
     model, sd = _model()
     want = orr.resunet_forward(sd, coords, feats).numpy()
-    prev = lib.eyoc_maps_internal_order(1) - 2
-    prev_up = lib.eyoc_spconv_select_up_kernel(-1)
+    prev = L.knob("eyoc_maps_internal_order", 1) - 2
+    prev_up = L.knob("eyoc_spconv_select_up_kernel", -1)
     try:
         for mode, up in (("split16", 0), ("split16", 1), ("split16", 2), ("fp32", 0)):   # up = 1: transposed convolutions on spconv_up.hip, 2: spconv_upc.hip
-            lib.eyoc_spconv_select_up_kernel(up)
-            prev_min = lib.eyoc_spconv_upc_min_rows(0)        # class-major tiles whatever the size of the batch
+            L.knob("eyoc_spconv_select_up_kernel", up)
+            prev_min = L.knob("eyoc_spconv_upc_min_rows", 0)        # class-major tiles whatever the size of the batch
             model.spconv_math = mode
             got = _forward(model, coords, feats)
             assert model.last_spconv_math == mode
             e = rel_err(got, want)
             cos = (got * want).sum(1)
             print(f"z-ordered forward, {mode}, staged transposed convolutions {up}: err {e:.2e}")
-            lib.eyoc_spconv_upc_min_rows(prev_min)
+            L.knob("eyoc_spconv_upc_min_rows", prev_min)
             assert e < REL and cos.min() > 1 - 1e-6, (mode, e, float(cos.min()))
-        lib.eyoc_spconv_select_up_kernel(prev_up)
+        L.knob("eyoc_spconv_select_up_kernel", prev_up)
         # the permutation is invisible: permuting the caller's rows permutes the output
         rng = np.random.default_rng(3)
         perm = rng.permutation(len(coords))
@@ -266,8 +266,8 @@ def test_forward_on_z_ordered_rows_with_the_staged_kernel(request):
         a = _forward(model, coords, feats)
         assert rel_err(_forward(model, coords[perm], feats[perm]), a[perm]) < 1e-5
     finally:
-        lib.eyoc_maps_internal_order(prev)
-        lib.eyoc_spconv_select_up_kernel(prev_up)
+        L.knob("eyoc_maps_internal_order", prev)
+        L.knob("eyoc_spconv_select_up_kernel", prev_up)
         model.spconv_math = "auto"
 
 
@@ -362,17 +362,17 @@ def test_staged_kernel_vs_fp64(morton_maps, cin, cout, level):
     # compiler-scheduled C++), in 64- and in 32-channel workgroups,
     # multiply the same products in the same order: bit-identical outputs
     L, lib = _lib()
-    prev, prev_split = lib.eyoc_spconv_select_st_kernel(-1), lib.eyoc_spconv_st_split_below(-1)
+    prev, prev_split = L.knob("eyoc_spconv_select_st_kernel", -1), L.knob("eyoc_spconv_st_split_below", -1)
     try:
         for split in (prev_split, 0):                      # a cloud this small takes 32-channel workgroups; 0: the wide kernels
-            lib.eyoc_spconv_st_split_below(split)
+            L.knob("eyoc_spconv_st_split_below", split)
             for variant in (0, 1, 2):
-                lib.eyoc_spconv_select_st_kernel(variant)
+                L.knob("eyoc_spconv_select_st_kernel", variant)
                 alt, _ = run_layer_staged(nbr, x, W, bias=b, scale=s, res=r, relu=True, out_split=False)
                 np.testing.assert_array_equal(alt, got32, err_msg=f"staged kernel variant {variant}, split below {split}")
     finally:
-        lib.eyoc_spconv_select_st_kernel(prev)
-        lib.eyoc_spconv_st_split_below(prev_split)
+        L.knob("eyoc_spconv_select_st_kernel", prev)
+        L.knob("eyoc_spconv_st_split_below", prev_split)
     # the local rulebook: one record per 256-row tile - n_unique first, then the row list, the slot entries and, last, per pass
     # 28 16-bit occupancy masks (bit 4 w + c of mask k: some row of rows 64 w + 16 c .. + 15 has a neighbour at offset k)
     # ... and, last, the tile's row map: slot 64 w + 16 c + j holds local row rowmap[(16 w + j) * 4 + c] (the builder groups a tile's rows
@@ -392,11 +392,11 @@ def test_staged_kernel_vs_fp64(morton_maps, cin, cout, level):
     f_rows, f_slots = occ_rows.reshape(n_tiles, 16, 16, 27).any(axis=2).mean(), occ_slots.reshape(n_tiles, 16, 16, 27).any(axis=2).mean()
     assert f_slots < f_rows - 0.03, (f_rows, f_slots)
     # grouping only re-orders a tile's rows inside its workgroup: bit-identical outputs
-    prev_g = lib.eyoc_spconv_st_group_rows(0)
+    prev_g = L.knob("eyoc_spconv_st_group_rows", 0)
     try:
         plain, local_plain = run_layer_staged(nbr, x, W, bias=b, scale=s, res=r, relu=True, out_split=False)
     finally:
-        lib.eyoc_spconv_st_group_rows(prev_g)
+        L.knob("eyoc_spconv_st_group_rows", prev_g)
     np.testing.assert_array_equal(plain, got32)
     rm_plain = local_plain.cpu().numpy()[:n_tiles * REC].reshape(-1, REC)[:, RM_OFF:RM_OFF + 256].reshape(n_tiles, 4, 16, 4).transpose(0, 1, 3, 2).reshape(n_tiles, 256)
     assert (rm_plain == np.arange(256)).all()
@@ -487,14 +487,14 @@ def test_fused_tail_matches_the_two_layer_tail_and_the_oracle(normalize):
     model.spconv_math = "split16"
     want = orr.resunet_forward(sd, coords, p["feats0"], normalize_feature=normalize).numpy()
     outs = {}
-    prev = lib.eyoc_model_fuse_tail(-1)
+    prev = L.knob("eyoc_model_fuse_tail", -1)
     try:
         for fuse in (0, 1):
-            lib.eyoc_model_fuse_tail(fuse)
+            L.knob("eyoc_model_fuse_tail", fuse)
             outs[fuse] = _forward(model, coords, p["feats0"])
             assert model.last_spconv_math == "split16"
     finally:
-        lib.eyoc_model_fuse_tail(prev)
+        L.knob("eyoc_model_fuse_tail", prev)
     scale = np.abs(want).max()
     e_fused, e_two = np.abs(outs[1] - want).max() / scale, np.abs(outs[0] - want).max() / scale
     d = np.abs(outs[1] - outs[0]).max() / scale
@@ -524,17 +524,17 @@ def test_staged_first_convolution_matches_the_probing_kernel_and_the_oracle(ks):
     m = m.cuda().eval()
     m.spconv_math = "split16"
     want = orr.resunet_forward(sd, coords, feats, conv1_kernel_size=ks).numpy()
-    prev_order = lib.eyoc_maps_internal_order(1) - 2                   # Z-ordered maps whatever the size
-    prev_c1 = lib.eyoc_spconv_select_conv1_kernel(-1)
+    prev_order = L.knob("eyoc_maps_internal_order", 1) - 2                   # Z-ordered maps whatever the size
+    prev_c1 = L.knob("eyoc_spconv_select_conv1_kernel", -1)
     outs = {}
     try:
         for staged in (0, 1):
-            lib.eyoc_spconv_select_conv1_kernel(staged)
+            L.knob("eyoc_spconv_select_conv1_kernel", staged)
             outs[staged] = _forward(m, coords, feats)
             assert m.last_spconv_math == "split16"
     finally:
-        lib.eyoc_spconv_select_conv1_kernel(prev_c1)
-        lib.eyoc_maps_internal_order(prev_order)
+        L.knob("eyoc_spconv_select_conv1_kernel", prev_c1)
+        L.knob("eyoc_maps_internal_order", prev_order)
     e1, e0 = rel_err(outs[1], want), rel_err(outs[0], want)
     d = rel_err(outs[1], outs[0])
     print(f"first convolution {ks}^3, {len(coords)} rows: staged vs oracle {e1:.2e}, probing vs oracle {e0:.2e}, staged vs probing {d:.2e}")
@@ -555,16 +555,16 @@ def test_small_input_split_over_input_blocks_matches_the_unsplit_forward():
     model, sd = _model()
     model.spconv_math = "split16"
     want = orr.resunet_forward(sd, coords, p["feats0"]).numpy()
-    prev = lib.eyoc_spconv_st_ksplit(-1)
-    prev_k = lib.eyoc_spconv_select_split16_kernel(1)          # the default selection (the file's fixture forces the gathering kernels)
+    prev = L.knob("eyoc_spconv_st_ksplit", -1)
+    prev_k = L.knob("eyoc_spconv_select_split16_kernel", 1)          # the default selection (the file's fixture forces the gathering kernels)
     outs = {}
     try:
         for on in (0, 1):
-            lib.eyoc_spconv_st_ksplit(on)
+            L.knob("eyoc_spconv_st_ksplit", on)
             outs[on] = [_forward(model, coords, p["feats0"]) for _ in range(3 if on else 1)]
     finally:
-        lib.eyoc_spconv_st_ksplit(prev)
-        lib.eyoc_spconv_select_split16_kernel(prev_k)
+        L.knob("eyoc_spconv_st_ksplit", prev)
+        L.knob("eyoc_spconv_select_split16_kernel", prev_k)
     assert prev == 1
     for o in outs[1][1:]:
         np.testing.assert_array_equal(o, outs[1][0])
