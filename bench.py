@@ -722,9 +722,13 @@ def worker(args):
             rates = vp["valu_issue_rates_G_wave_inst_per_s"]
             if cfg.use_RANSAC:
                 kc = vp["ransac"]["k_count"]
-                out["ransac_roofline"] = {"bound": "valu (fp64)", "kernel": "k_count (the residual sweep: 15 v_fma_f64-class instructions per residual)",
-                                          "achieved": kc["G_wave_inst_per_s"], "peak": rates["v_fma_f64"], "unit": "G wave-instructions/s",
-                                          "frac": kc["G_wave_inst_per_s"] / rates["v_fma_f64"], "ms_per_launch": kc["ms_per_launch"],
+                # the sweep is packed fp32 since round 5 (two residuals per v_pk_fma_f32; the one-in-10^5 undecided residual recounted in
+                # fp64): its roof is the packed-fp32 issue rate.  fp64 throughout (round 4) ran at 0.84-0.91 of the v_fma_f64 rate
+                peak = rates.get("v_pk_fma_f32", rates["v_fma_f32"])
+                out["ransac_roofline"] = {"bound": "valu (packed fp32)",
+                                          "kernel": "k_count (the residual sweep: 16 v_pk_*_f32 + 4 compares per TWO residuals; 16 v_*_f64 per residual before)",
+                                          "achieved": kc["G_wave_inst_per_s"], "peak": peak, "unit": "G wave-instructions/s",
+                                          "frac": kc["G_wave_inst_per_s"] / peak, "ms_per_launch": kc["ms_per_launch"],
                                           "measured_in_run": False, "source": "profiles/r5_valu.json, profiles/r5_kernel_stats.csv, profiles/r5_valu_rates.txt",
                                           "other_kernels": {k: v for k, v in vp["ransac"].items() if k != "k_count"}}
             km = vp["sc2pcr"]["k_masks"]

@@ -28,7 +28,7 @@ for line in open(os.path.join(ROOT, "profiles", "r5_valu_rates.txt")):
     if m:
         rates[m.group(1)] = float(m.group(2))
 res = {"csrc_sha16": bench.csrc_sha16(),
-       "valu_issue_rates_G_wave_inst_per_s": {**{k: rates[k] for k in ("v_fma_f64", "v_fma_f32", "v_add_f32")},
+       "valu_issue_rates_G_wave_inst_per_s": {**{k: rates[k] for k in ("v_fma_f64", "v_fma_f32", "v_pk_fma_f32", "v_add_f32")},
                                               "source": "profiles/r5_valu_rates.txt (scripts/micro/valu_rates.hip, four waves per SIMD)"}}
 for tag, key, names in (("r5", "ransac", ["k_count", "k_generate<true>", "k_fit"]),
                         ("r5_sc2pcr", "sc2pcr", ["k_masks", "k_csr_fill", "k_nms", "k_seed_dense<32>", "k_seed_solve", "k_sc_spmv", "k_seed_topk", "k_rank"])):
