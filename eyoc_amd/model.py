@@ -121,13 +121,31 @@ class ResUNet2(nn.Module):
         see edits made through ``p.data`` (``p.data.mul_()`` leaves ``p._version`` alone) nor writes through another
         view of the storage: after those call ``repack()`` - the forward would silently run the old packed weights.
         Inference-mode tensors have no version counter; they contribute their storage address only."""
+        # walked by hand: ``self.parameters()`` / ``self.buffers()`` go through torch's generic named-member generators - 0.3 ms per
+        # forward for the 73 modules of ResUNetBN2C, a fifth of a single pair's 1.6 ms.  The module list is cached together with every
+        # module's children, which are re-checked here (a replaced sub-module anywhere in the tree rebuilds the list); parameters and
+        # buffers are read from the modules' own dicts every time, so rebinding one (``.to()``, ``register_buffer``) is seen.
+        cache = self.__dict__.get("_eyoc_module_list")
+        stale = cache is None
+        if not stale:
+            for m, kids in cache:
+                if tuple(m._modules.values()) != kids:                     # (modules compare by identity)
+                    stale = True
+                    break
+        if stale:
+            cache = [(m, tuple(m._modules.values())) for m in self.modules()]
+            self.__dict__["_eyoc_module_list"] = cache
         v = []
-        for t in list(self.parameters()) + list(self.buffers()):
-            try:
-                ver = t._version
-            except RuntimeError:
-                ver = -1
-            v.append((t.data_ptr(), ver))
+        for m, _ in cache:
+            for d in (m._parameters, m._buffers):
+                for t in d.values():
+                    if t is None:
+                        continue
+                    try:
+                        ver = t._version
+                    except RuntimeError:
+                        ver = -1
+                    v.append((t.data_ptr(), ver))
         return hash(tuple(v))
 
     def _invalidate(self):

@@ -214,3 +214,27 @@ def test_accessors_answer_in_the_callers_rows_after_a_z_ordered_forward():
     assert x2.coordinate_manager.row_order() is None and t.shape == (27, len(coords))
     f2 = model(x2).F
     assert float((f1 - f2).abs().max()) < 1e-5
+
+
+def test_kernel_selection_switches_belong_to_the_ctx_they_are_set_on():
+    """The `eyoc_*_select_*` / `eyoc_maps_*` / `eyoc_ransac_*` switches were file-scope statics until round 4 (two models in one process
+    shared kernel selection).  A second ctx on the same device: what is set on it stays on it, the process's own ctx keeps its values, and a
+    NULL ctx is refused (-1)."""
+    import ctypes as C
+    from eyoc_amd import _lib
+    lib = _lib.load()
+    other = C.c_void_p()
+    _lib.check(lib.eyoc_create(0, C.byref(other)), "eyoc_create")
+    try:
+        cases = [("eyoc_spconv_select_split16_kernel", 2, 1), ("eyoc_spconv_select_up_kernel", 0, 2), ("eyoc_maps_order_window_shift", 12, 18),
+                 ("eyoc_ransac_transform_store", 8, 1 << 20), ("eyoc_knn_prefilter", 0, 1), ("eyoc_spconv_st_ksplit", 0, 1)]
+        for name, value, default in cases:
+            mine = _lib.knob(name, -7)                                   # out of range: a query
+            f = getattr(lib, name)
+            assert f(other, value) == default, name                      # a fresh ctx starts from the defaults
+            assert f(other, -7) == value, name
+            assert _lib.knob(name, -7) == mine, name                     # ... and the process's ctx did not notice
+            assert f(None, value) == -1, name
+        assert lib.eyoc_maps_select_orders(other, 0, 1) == 1 and lib.eyoc_maps_select_orders(other, -1, -1) == 2
+    finally:
+        lib.eyoc_destroy(other)
