@@ -128,3 +128,36 @@ def test_results_do_not_depend_on_the_launch_chunk_or_on_who_owns_the_scratch():
     assert rc == -3 and b"workspace" in lib.eyoc_last_error()
     torch.cuda.synchronize()
     assert int(res.min()) == 7
+
+
+@pytest.mark.parametrize("shift,scale,noise", [(0.0, 1.0, 0.1), (3.0e4, 1.0, 0.1), (0.0, 1.0e5, 0.0), (0.0, 1.0, 0.29)])
+def test_packed_fp32_count_decides_like_the_fp64_count(shift, scale, noise):
+    """k_count sweeps `r_ref + dR p + dt` in packed fp32 against `thr^2 -+ band` and recounts what falls inside the band in fp64 (round
+    5).  Its counts must be the fp64 sweep's (k_count_fp64: pruning off) and the oracle's where the band is (a) narrow (the bench's
+    regime), (b) wide because the clouds sit 30 km from the origin (fp32 coordinates resolve 2 mm there: many residuals undecided),
+    (c) unusable - coordinates of 1e7, the band exceeds thr^2, every block counts in fp64 - and (d) with the inliers' residuals spread
+    right up to the threshold (noise ~ max_distance: the densest band)."""
+    import eyoc_amd
+    from oracle import ransac as orn
+    L, lib = _lib()
+    n, H, thr = 3000, 200000, 0.3
+    T = gi.rigid(0.02, -0.01, 0.1, 2.0, -1.0, 0.3)
+    p0, p1, _ = gi.corr_case(500 + int(noise * 100), n, T, 0.5, noise=noise)
+    if scale != 1.0:
+        p0, p1, thr = (p0 * scale).astype(np.float32), (p1 * scale).astype(np.float32), thr * scale
+    if shift:
+        p0, p1 = (p0 + np.float32(shift)).astype(np.float32), (p1 + np.float32(shift)).astype(np.float32)
+    args = (torch.from_numpy(p0), torch.from_numpy(p1), torch.arange(n), thr, H)
+    packed = eyoc_amd.ransac_from_correspondences(*args, seed=5)
+    prev = L.knob("eyoc_ransac_select_pruning", 0)
+    try:
+        plain = eyoc_amd.ransac_from_correspondences(*args, seed=5)
+    finally:
+        L.knob("eyoc_ransac_select_pruning", prev)
+    ref = orn.ransac(p0, p1, np.arange(n), thr, H, seed=5)
+    print(f"shift {shift} scale {scale} noise {noise}: survivors {packed.survivors}, inliers {packed.inliers} (oracle {ref['inliers']})")
+    assert packed.survivors > 50
+    assert (packed.survivors, packed.best_hypothesis, packed.inliers, packed.inlier_rmse) == \
+           (plain.survivors, plain.best_hypothesis, plain.inliers, plain.inlier_rmse)
+    np.testing.assert_array_equal(packed.transformation, plain.transformation)
+    assert (packed.survivors, packed.best_hypothesis, packed.inliers) == (ref["survivors"], ref["best_h"], ref["inliers"])
