@@ -57,9 +57,11 @@ def _pack(weight: torch.Tensor, transposed: bool, mirror: bool) -> torch.Tensor:
         return src[perm]
 
 
-def _run(table, n_out, x, packed, cin, cout):
+def _run(table, n_out, x, packed, cin, cout, out=None):
+    """``out``: a ``[n_out, cout]`` view to write into (rows ``out.stride(0)`` floats apart: a column block of a wider tensor)."""
     lib = _lib.load()
-    out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
     K = 1 if table is None else table.shape[0]
     with torch.cuda.device(x.device):
         _lib.check(lib.eyoc_spconv(_lib.ctx(x.device.index), _lib.ptr(table), K, n_out, _lib.ptr(x), x.stride(0), cin, _lib.ptr(packed),
@@ -84,8 +86,20 @@ class _SparseConv(torch.autograd.Function):
         lib = _lib.load()
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            # the same operator over the transposed rulebook with W[k]^T (mirrored offsets for a self-transposed table)
-            dx = _run(ctx.table_t, ctx.n_in, dy, _pack(weight, True, ctx.mirror), cout, cin)
+            # the same operator over the transposed rulebook with W[k]^T (mirrored offsets for a self-transposed table).  Its output
+            # width is this layer's C_in, which the kernels take as 32 / 64 / 128 / 256: the concatenated decoder inputs of some channel
+            # tables (ResUNetBN2B / BN2D / FatBN: 128 + 64 = 192, 256 + 128 = 384) go through in column blocks of those widths
+            if cin in (32, 64, 128, 256):
+                dx = _run(ctx.table_t, ctx.n_in, dy, _pack(weight, True, ctx.mirror), cout, cin)
+            else:
+                if cin % 32:
+                    raise _lib.EyocError(f"sparse_conv: the input gradient needs C_in % 32 == 0, got {cin}", _lib.ERR_INVALID)
+                dx = torch.empty((ctx.n_in, cin), dtype=torch.float32, device=dy.device)
+                a = 0
+                while a < cin:
+                    w = next(b for b in (256, 128, 64, 32) if b <= cin - a)
+                    _run(ctx.table_t, ctx.n_in, dy, _pack(weight[:, a:a + w, :], True, ctx.mirror), cout, w, out=dx[:, a:a + w])
+                    a += w
         if ctx.needs_input_grad[1]:
             n_out = dy.shape[0]
             dw = torch.empty(weight.shape, dtype=torch.float32, device=weight.device)   # dense [K, C_in, C_out], whatever the strides of `weight`

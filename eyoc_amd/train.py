@@ -116,16 +116,6 @@ def forward_layers(model, x: SparseTensor, taps: dict | None = None) -> SparseTe
     """The network layer by layer through the autograd Functions above - ``ResUNet2`` (model/resunet.py:142-193) and
     ``ResUNetExpanded`` (:254-484: every stage runs a second norm + block, ``norm<i>_2`` / ``block<i>_2``).  In training mode
     every norm uses batch statistics; in eval mode its running statistics (a per-channel affine, element-wise)."""
-    if model.training or torch.is_grad_enabled():
-        # the gradient w.r.t. a convolution's INPUT runs the forward kernel with the channel roles swapped, so its C_in must be one
-        # of the kernel's output widths; the concatenated decoder inputs of some tables (BN2B / BN2D / FatBN: 128 + 64 = 192,
-        # 256 + 128 = 384) are not - say so here instead of failing inside loss.backward()
-        Cn, T = model.CHANNELS, model.TR_CHANNELS
-        for name, cin in (("conv3_tr", Cn[3] + T[4]), ("conv2_tr", Cn[2] + T[3])):
-            if model.training and cin not in (32, 64, 128, 256):
-                raise NotImplementedError(f"{type(model).__name__}: training is not implemented for this channel table - {name} has "
-                                          f"{cin} input channels, and the input gradient of a sparse convolution needs 32, 64, 128 or 256 "
-                                          "(ResUNetBN2C-shaped tables train; every table runs in eval mode)")
     cm = x.coordinate_manager
     s1 = [cm.table(MAP_S1, l) for l in range(4)]
     down = [cm.table(MAP_DOWN, l) for l in range(3)]

@@ -10,6 +10,9 @@ from eyoc_amd.autograd import contrastive_hardest_negative_loss
 BEAMS, AZ = int(os.environ.get("BEAMS", "32")), int(os.environ.get("AZ", "1000"))
 ITERS = int(os.environ.get("ITERS", "30"))
 dev = torch.device("cuda:0")
+if os.environ.get("SPCONV_KERNEL"):      # eyoc_spconv_select_kernel: 0 workgroup-tiled, 1 wave-private (default: by size)
+    from eyoc_amd import _lib
+    _lib.knob("eyoc_spconv_select_kernel", int(os.environ["SPCONV_KERNEL"]))
 p = syn.make_pair(1000, beams=BEAMS, azimuths=AZ, band=None)
 from scipy.spatial import cKDTree
 T = np.asarray(p["T_gt"], np.float64)

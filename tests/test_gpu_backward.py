@@ -37,7 +37,9 @@ def _oracle_grads(nbr, x, W, dy):
 
 @pytest.mark.parametrize("kind,level,cin,cout", [("s1", 0, 32, 32), ("s1", 0, 64, 64), ("s1", 1, 64, 64), ("s1", 2, 128, 128),
                                                  ("down", 0, 32, 64), ("down", 1, 64, 128), ("up", 0, 128, 64), ("up", 1, 256, 64),
-                                                 ("down", 2, 128, 256), ("up", 2, 256, 128), ("s1", 3, 256, 256), ("s1", 2, 128, 128)])
+                                                 ("down", 2, 128, 256), ("up", 2, 256, 128), ("s1", 3, 256, 256), ("s1", 2, 128, 128),
+                                                 # concatenated decoder inputs of ResUNetBN2B / FatBN: the input gradient in column blocks
+                                                 ("up", 1, 192, 64), ("up", 2, 384, 128)])
 def test_layer_gradients_vs_oracle_autograd(cloud, kind, level, cin, cout):
     """grad-input = the forward kernel over the transposed rulebook with W[k]^T; grad-weight = eyoc_spconv_grad_weight."""
     from eyoc_amd.autograd import sparse_conv

@@ -169,3 +169,40 @@ def test_expanded_variant_eval_and_train_match_the_oracle():
     assert all(q.grad is not None for q in model.parameters())
     print(f"ResUNetExpBN2C on {len(coords)} voxels: eval {e_eval:.2e}, train {e_train:.2e}")
     assert e_eval < REL and e_train < REL
+
+
+def test_other_channel_tables_train_too():
+    """``ResUNetBN2B`` (model/resunet.py:201-204): ``conv3_tr`` reads 128 + 64 = 192 channels - not a width the kernels write, so
+    its input gradient runs in column blocks (128 + 64).  Training-mode features against the oracle's, and a gradient for every
+    parameter that matches the oracle's autograd (the product's ReLU decisions handed to the oracle, as in the BN2C test above)."""
+    import eyoc_amd
+    from eyoc_amd import synthetic as syn
+    from eyoc_amd.train import forward_train
+    from oracle import resunet as orr
+    p = syn.make_pair(9, beams=16, azimuths=500, band=None)
+    coords = syn.batch_coords([p["coords0"]])
+    feats = np.ones((len(coords), 1), np.float32)
+    sd = syn.make_weights(seed=8, tr_channels=(None, 64, 64, 64, 64))
+    model = eyoc_amd.load_model("ResUNetBN2B")(1, 32, bn_momentum=0.05, conv1_kernel_size=5, normalize_feature=True)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    assert tuple(model.state_dict()["conv3_tr.kernel"].shape) == (27, 192, 64)
+    model = model.cuda().train()
+    x = eyoc_amd.SparseTensor(torch.from_numpy(feats).cuda(), coordinates=torch.from_numpy(coords).cuda())
+    taps = {}
+    out = forward_train(model, x, taps).F
+    dF = torch.from_numpy(np.random.default_rng(3).normal(size=tuple(out.shape)).astype(np.float32))
+    (out * dF.cuda()).sum().backward()
+    masks = {k: (v.detach() > 0).float().cpu() for k, v in taps.items()}
+    sdt = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in sd.items()}
+    params = [k for k in sdt if k.endswith(".kernel") or k.endswith("bn.weight") or k.endswith("bn.bias") or k == "final.bias"]
+    for k in params:
+        sdt[k].requires_grad_(True)
+    want = orr.resunet_forward(sdt, coords, feats, train=True, bn_momentum=0.05, relu_masks=masks)
+    (want * dF).sum().backward()
+    e_f = rel_err(out.detach().cpu().numpy(), want.detach().numpy())
+    named = dict(model.named_parameters())
+    assert set(named) == set(params)
+    errs = {k: rel_err(named[k].grad.cpu().numpy().reshape(-1), sdt[k].grad.numpy().reshape(-1)) for k in params}
+    worst = max(errs, key=errs.get)
+    print(f"ResUNetBN2B on {len(coords)} voxels: train features {e_f:.2e}, worst parameter gradient {worst} {errs[worst]:.2e}")
+    assert e_f < REL and errs[worst] < REL, (worst, errs[worst])
