@@ -210,7 +210,7 @@ int eyoc_bn_train_backward(eyoc_ctx* ctx, const float* x_dev, int ld_x, const fl
 int eyoc_maps_gather_window(eyoc_ctx* ctx, eyoc_maps* maps, int ks, const float* feats_dev, int cin, float* out_dev, void* stream) {
   EYOC_REQUIRE(ctx && maps && feats_dev && out_dev, EYOC_ERR_INVALID, "eyoc_maps_gather_window: NULL argument");
   EYOC_REQUIRE((ks == 1 || ks == 3 || ks == 5 || ks == 7) && cin >= 1 && cin <= 64, EYOC_ERR_INVALID, "eyoc_maps_gather_window: ks %d, cin %d", ks, cin);
-  EYOC_REQUIRE(!maps->row_perm, EYOC_ERR_INVALID, "eyoc_maps_gather_window: the maps must keep the caller's row order (eyoc_maps_build_ordered, order 0)");
+  // feats and the result are in the maps' INTERNAL rows (the caller's unless eyoc_maps_row_order says otherwise)
   hipStream_t st = (hipStream_t)stream;
   int rc = maps_build_table0(maps, st);
   if (rc) return rc;

@@ -95,14 +95,25 @@ def batch_norm_train(x: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool = Fal
     return y
 
 
-def gather_window(cm, feats: torch.Tensor, ks: int) -> torch.Tensor:
-    """``[N, ks^3 * C_in]``: every row's ``ks^3`` window of input features (zeros where no voxel is), caller's row order."""
+def gather_window(cm, feats: torch.Tensor, ks: int, internal: bool = False) -> torch.Tensor:
+    """``[N, ks^3 * C_in]``: every row's ``ks^3`` window of input features (zeros where no voxel is), caller's row order
+    (``internal=True``: ``feats`` and the result in the rows of the forward's own - possibly Z-ordered - maps)."""
     n, cin = feats.shape
     out = torch.empty((n, ks ** 3 * cin), dtype=torch.float32, device=feats.device)
     with torch.cuda.device(feats.device):
-        _lib.check(_lib.load().eyoc_maps_gather_window(_lib.ctx(feats.device.index), cm._caller_maps(), int(ks), _lib.ptr(feats.contiguous()),
+        _lib.check(_lib.load().eyoc_maps_gather_window(_lib.ctx(feats.device.index), cm.maps() if internal else cm._caller_maps(), int(ks), _lib.ptr(feats.contiguous()),
                                                        cin, _lib.ptr(out), _lib.stream_ptr()), "eyoc_maps_gather_window")
     return out
+
+
+def _match_rows(want: torch.Tensor, have: torch.Tensor) -> torch.Tensor:
+    """For two orderings of the same unique coordinate rows ``[n, 4]``: ``idx`` with ``have[idx] == want`` (diagnostics only)."""
+    def key(c):
+        c = c.long()
+        return ((c[:, 0] * (1 << 18) + (c[:, 1] + (1 << 17))) * (1 << 18) + (c[:, 2] + (1 << 17))) * (1 << 18) + (c[:, 3] + (1 << 17))
+    kw, kh = key(want), key(have)
+    sh = torch.argsort(kh)
+    return sh[torch.searchsorted(kh[sh], kw)]
 
 
 def forward_train(model, x: SparseTensor, taps: dict | None = None) -> SparseTensor:
@@ -117,14 +128,35 @@ def forward_layers(model, x: SparseTensor, taps: dict | None = None) -> SparseTe
     ``ResUNetExpanded`` (:254-484: every stage runs a second norm + block, ``norm<i>_2`` / ``block<i>_2``).  In training mode
     every norm uses batch statistics; in eval mode its running statistics (a per-channel affine, element-wise)."""
     cm = x.coordinate_manager
-    s1 = [cm.table(MAP_S1, l) for l in range(4)]
-    down = [cm.table(MAP_DOWN, l) for l in range(3)]
-    up = [cm.table(MAP_UP, l) for l in range(3)]
+    # The layers run in the rows of the forward's own maps: from 8192 rows on those are Z-ordered (eyoc_maps_build_ordered(-1): one
+    # sort + top-down derivation, two host synchronisations) - a second set of maps in the caller's order is the hash-table build with a
+    # host round trip per level, 2.1 ms of a 11 ms training iteration on two 11 k-voxel clouds.  Input rows are permuted on the way in,
+    # output rows (and the tapped tensors) on the way out; both are differentiable row gathers.
+    cm.maps(-1)
+    order = cm.row_order()                                   # int32 [N]: caller's row of internal row i; None = the caller's order was kept
+    internal = order is not None
+    s1 = [cm.table(MAP_S1, l, internal=internal) for l in range(4)]
+    down = [cm.table(MAP_DOWN, l, internal=internal) for l in range(3)]
+    up = [cm.table(MAP_UP, l, internal=internal) for l in range(3)]
     expanded = bool(getattr(model, "EXPANDED", False))
+    back = None
+    if internal:
+        order = order.long()
+        back = torch.empty_like(order)
+        back[order] = torch.arange(order.numel(), device=order.device)      # internal row of every caller's row
+    level_back = {}
 
     def tap(name, t):
         if taps is not None:
-            taps[name] = t
+            if internal:                                     # diagnostics see the caller's rows at every level
+                n = t.shape[0]
+                if n not in level_back:
+                    lvl = next(l for l in range(4) if cm.rows(l) == n)
+                    zc, cc = cm.level_coordinates(lvl, internal=True), cm.level_coordinates(lvl)
+                    level_back[n] = _match_rows(cc, zc)
+                taps[name] = t.index_select(0, level_back[n])
+            else:
+                taps[name] = t
         return t
 
     def norm(t, n, relu=False):
@@ -149,7 +181,8 @@ def forward_layers(model, x: SparseTensor, taps: dict | None = None) -> SparseTe
         return out
 
     # encoder.  conv1: window gather + one dense product (C_in is tiny)
-    G = gather_window(cm, x.F, model.conv1_kernel_size)
+    F_in = x.F.index_select(0, order) if internal else x.F
+    G = gather_window(cm, F_in, model.conv1_kernel_size, internal=internal)
     out_s1 = stage(G @ model.conv1.kernel.reshape(-1, model.conv1.cout), "1", s1[0])
     out_s2 = stage(sparse_conv(out_s1, model.conv2.kernel, down[0], up[0]), "2", s1[1])
     out_s4 = stage(sparse_conv(out_s2, model.conv3.kernel, down[1], up[1]), "3", s1[2])
@@ -166,4 +199,6 @@ def forward_layers(model, x: SparseTensor, taps: dict | None = None) -> SparseTe
     out = out @ model.final.kernel + model.final.bias
     if model.normalize_feature:
         out = out / torch.norm(out, p=2, dim=1, keepdim=True)          # no epsilon (model/resunet.py:187-191)
+    if internal:
+        out = out.index_select(0, back)
     return SparseTensor(out, coordinate_map_key=x.coordinate_map_key, coordinate_manager=cm)

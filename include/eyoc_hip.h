@@ -458,8 +458,8 @@ int eyoc_bn_train_backward(eyoc_ctx* ctx, const float* x_dev, int ld_x, const fl
                            float* dgamma_dev, float* dbeta_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 /* The first convolution's window as a dense matrix (model/resunet.py:31-38, C_in = 1 in production, K = ks^3):
  * out f32 [n, ks^3 * cin], out[row][k * cin + c] = feats[voxel at window offset k of row][c] or 0 (offsets x fastest, like every
- * rulebook) - the convolution and its weight gradient are then plain [n, K cin] x [K cin, C_out] products.  The maps must keep the
- * caller's row order (eyoc_maps_build_ordered with order 0); builds the level-0 hash table on first use. */
+ * rulebook) - the convolution and its weight gradient are then plain [n, K cin] x [K cin, C_out] products.  feats and out are in
+ * the maps' INTERNAL rows (the caller's unless eyoc_maps_row_order returns a permutation); builds the level-0 hash table on first use. */
 int eyoc_maps_gather_window(eyoc_ctx* ctx, eyoc_maps* maps, int ks, const float* feats_dev, int cin, float* out_dev, void* stream);
 
 /* replaces: o3d.pipelines.registration.registration_ransac_based_on_feature_matching(..., 4,
