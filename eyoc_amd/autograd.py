@@ -141,14 +141,21 @@ def _hardest_negative_term(anchor, cand_feats, cand_ids, anchor_key, cand_key_sc
     """One direction of the negative term (lib/trainer.py:962-987): for every anchor row the nearest row of
     ``cand_feats`` (``eyoc_knn1`` in "L2" mode, ties to the lowest index), dropped when (anchor, candidate) is itself a
     known positive, penalised by ``relu(neg_thresh - d)^2``.  The distance is re-evaluated with torch ops on the two
-    gathered rows so the gradient reaches both ends, exactly where ``D.min(1)`` sends it."""
+    gathered rows so the gradient reaches both ends, exactly where ``D.min(1)`` sends it.
+
+    Everything stays on the device (``cand_ids``, ``anchor_key``, ``known_positive_keys``: int64 device tensors): reading the
+    neighbour indices back to filter the positives on the host put two synchronisations between the forward and the backward of
+    every iteration; the mean over the kept rows is a masked sum over all of them.  An empty selection gives the reference's NaN
+    mean with the reference's gradient (none: a NaN constant is added to a zero sum, instead of dividing by zero)."""
     n = anchor.shape[0]
     with torch.no_grad():
         nearest = knn1_segmented(anchor.detach(), cand_feats.detach(), [0, n], [0, cand_feats.shape[0]], "L2", return_distance=False)
+        keys = anchor_key + cand_ids[nearest] * cand_key_scale
+        keep = (~torch.isin(keys, known_positive_keys)).to(anchor.dtype)
     dist = torch.sqrt((anchor - cand_feats[nearest]).pow(2).sum(1) + 1e-7)
-    keys = anchor_key + cand_ids[nearest.cpu().numpy()] * cand_key_scale
-    is_negative = torch.from_numpy(~np.isin(keys, known_positive_keys)).to(anchor.device)
-    return torch.relu(neg_thresh - dist[is_negative]).pow(2).mean()
+    count = keep.sum()
+    empty = torch.where(count > 0, torch.zeros_like(count), torch.full_like(count, float("nan")))
+    return (torch.relu(neg_thresh - dist).pow(2) * keep).sum() / count.clamp(min=1.0) + empty
 
 
 def contrastive_hardest_negative_loss(F0, F1, positive_pairs, num_pos=5192, num_hn_samples=2048, pos_thresh=0.1, neg_thresh=1.4,
@@ -161,11 +168,13 @@ def contrastive_hardest_negative_loss(F0, F1, positive_pairs, num_pos=5192, num_
     cand0, cand1, keep = _draw_loss_samples(np.random if rng is None else rng, len(F0), len(F1), len(pairs), num_hn_samples, num_pos)
     used = pairs if keep is None else pairs[torch.as_tensor(keep)]
     dev = F0.device
-    i0, i1 = used[:, 0].numpy(), used[:, 1].numpy()
-    a0, a1 = F0[used[:, 0].to(dev)], F1[used[:, 1].to(dev)]
-    all_keys = pairs[:, 0].numpy() + pairs[:, 1].numpy() * scale
+    # one upload of every index array the loss needs (pinned staging would only matter for much larger draws)
+    used_d, pairs_d = used.to(dev), pairs.to(dev)
+    cand0_d, cand1_d = torch.as_tensor(cand0).to(dev), torch.as_tensor(cand1).to(dev)
+    a0, a1 = F0[used_d[:, 0]], F1[used_d[:, 1]]
+    all_keys = pairs_d[:, 0] + pairs_d[:, 1] * scale
     # keys: (row of cloud 0) + (row of cloud 1) * scale in both directions
-    neg01 = _hardest_negative_term(a0, F1[torch.as_tensor(cand1).to(dev)], cand1, i0, scale, all_keys, neg_thresh)
-    neg10 = _hardest_negative_term(a1, F0[torch.as_tensor(cand0).to(dev)], cand0, i1 * scale, 1, all_keys, neg_thresh)
+    neg01 = _hardest_negative_term(a0, F1[cand1_d], cand1_d, used_d[:, 0], scale, all_keys, neg_thresh)
+    neg10 = _hardest_negative_term(a1, F0[cand0_d], cand0_d, used_d[:, 1] * scale, 1, all_keys, neg_thresh)
     pos = torch.relu((a0 - a1).pow(2).sum(1) - pos_thresh).mean()
     return pos, (neg01 + neg10) / 2

@@ -135,9 +135,9 @@ def forward_layers(model, x: SparseTensor, taps: dict | None = None) -> SparseTe
     cm.maps(-1)
     order = cm.row_order()                                   # int32 [N]: caller's row of internal row i; None = the caller's order was kept
     internal = order is not None
-    s1 = [cm.table(MAP_S1, l, internal=internal) for l in range(4)]
-    down = [cm.table(MAP_DOWN, l, internal=internal) for l in range(3)]
-    up = [cm.table(MAP_UP, l, internal=internal) for l in range(3)]
+    s1 = [cm.table_view(MAP_S1, l, internal=internal) for l in range(4)]
+    down = [cm.table_view(MAP_DOWN, l, internal=internal) for l in range(3)]
+    up = [cm.table_view(MAP_UP, l, internal=internal) for l in range(3)]
     expanded = bool(getattr(model, "EXPANDED", False))
     back = None
     if internal:
