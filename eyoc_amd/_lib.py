@@ -108,6 +108,7 @@ PROTOTYPES = {
     "eyoc_model_set_progress_event": (_i, [_vp, _i, _vp]),
     "eyoc_model_set_probe": (_i, [_vp, _i]),
     "eyoc_spconv": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp]),
+    "eyoc_spconv_sum": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp]),
     "eyoc_model_blob_floats": (_sz, [C.POINTER(ModelDesc)]),
     "eyoc_model_pack_host": (_i, [C.POINTER(ModelDesc), C.POINTER(LayerParams), _i, _vp, _sz]),
     "eyoc_model_create": (_i, [_vp, C.POINTER(ModelDesc), C.POINTER(LayerParams), _i, _vp, _sz, C.POINTER(_vp)]),
@@ -231,6 +232,44 @@ def stream_ptr():
 def ptr(t):
     """Device pointer of a torch tensor (or None)."""
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def on_device(device):
+    """``torch.cuda.device(device)`` when the current device is another one, a no-op context otherwise (the context manager's own
+    enter / exit is ~5 us - a tenth of one autograd layer's host time, paid twice per layer per direction)."""
+    import torch
+    idx = device.index if isinstance(device, torch.device) else device
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_SWITCH
+    return torch.cuda.device(idx)
+
+
+_SCRATCH: dict = {}
+
+
+def scratch(nbytes: int, device):
+    """A grow-only 256-byte aligned device buffer per (device, current stream) for kernels that need their workspace only until they
+    finish (batch-norm partial sums, gradient partials): consecutive calls on a stream reuse it in stream order - no allocation, no
+    slicing per call (``workspace`` = a fresh tensor every time: three torch ops, ~8 us of a ~45 us layer call)."""
+    import torch
+    idx = device.index if isinstance(device, torch.device) else int(device)
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < nbytes:
+        t = workspace(max(int(nbytes) * 2, 1 << 20), torch.device("cuda", idx))
+        _SCRATCH[key] = t
+    return t
 
 
 def workspace(nbytes: int, device):

@@ -22,7 +22,7 @@ from .eval import knn1_segmented
 _PERM_CACHE: dict = {}      # (K, cin, cout, transposed, mirror, device) -> int64 gather indices; one entry per layer SHAPE, never stale
 
 
-def _pack_perm(K, cin, cout, transposed, mirror, device) -> torch.Tensor:
+def _pack_perm(K, cin, cout, transposed, mirror, device):
     """The library's host packers only MOVE values (fragment order of the MFMA kernels, zeros in padding slots): packing
     the sequence 1, 2, 3 ... once per layer shape yields the permutation, and every later pack is one gather on the device."""
     key = (K, cin, cout, bool(transposed), bool(mirror), str(device))
@@ -43,7 +43,12 @@ def _pack_perm(K, cin, cout, transposed, mirror, device) -> torch.Tensor:
         idx = np.arange(n, dtype=np.int64)
         hi, lo = run((idx // 4096 + 1).astype(np.float32)), run((idx % 4096).astype(np.float32))
         packed = np.where(hi > 0, (hi - 1) * 4096 + lo + 1, 0)
-        _PERM_CACHE[key] = torch.from_numpy(packed).to(device)    # 0 = padding slot, i + 1 = element i
+        # 0 = padding slot, i + 1 = element i.  Layouts without padding slots (every shape of the ResUNet tables) are kept as plain
+        # indices: the pack is then ONE gather instead of zeros + cat + gather
+        if (packed > 0).all():
+            _PERM_CACHE[key] = (torch.from_numpy(packed - 1).to(device), False)
+        else:
+            _PERM_CACHE[key] = (torch.from_numpy(packed).to(device), True)
     return _PERM_CACHE[key]
 
 
@@ -51,10 +56,12 @@ def _pack(weight: torch.Tensor, transposed: bool, mirror: bool) -> torch.Tensor:
     """Weights in the MFMA fragment order the kernels consume: a device-side gather through the shape's permutation - no
     host round trip, no synchronisation, nothing cached that depends on the parameter's contents."""
     K, cin, cout = weight.shape
-    perm = _pack_perm(K, cin, cout, transposed, mirror, weight.device)
+    perm, padded = _pack_perm(K, cin, cout, transposed, mirror, weight.device)
     with torch.no_grad():
-        src = torch.cat([weight.new_zeros(1), weight.detach().reshape(-1).float()])
-        return src[perm]
+        flat = weight.detach().reshape(-1).float()
+        if not padded:
+            return flat[perm]
+        return torch.cat([flat.new_zeros(1), flat])[perm]
 
 
 def _run(table, n_out, x, packed, cin, cout, out=None):
@@ -63,10 +70,43 @@ def _run(table, n_out, x, packed, cin, cout, out=None):
     if out is None:
         out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
     K = 1 if table is None else table.shape[0]
-    with torch.cuda.device(x.device):
-        _lib.check(lib.eyoc_spconv(_lib.ctx(x.device.index), _lib.ptr(table), K, n_out, _lib.ptr(x), x.stride(0), cin, _lib.ptr(packed),
-                                   cout, None, None, 0, 0, _lib.ptr(out), out.stride(0), _lib.stream_ptr()), "eyoc_spconv")
+    with _lib.on_device(x.device):
+        _lib.check(lib.eyoc_spconv_sum(_lib.ctx(x.device.index), _lib.ptr(table), K, n_out, _lib.ptr(x), x.stride(0), cin, _lib.ptr(packed),
+                                       cout, _lib.ptr(out), out.stride(0), _lib.stream_ptr()), "eyoc_spconv_sum")
     return out
+
+
+def input_gradient(dy: torch.Tensor, weight: torch.Tensor, table_t, mirror: bool, n_in: int) -> torch.Tensor:
+    """d(loss)/d(input) of one layer: the same operator over the transposed rulebook with W[k]^T (mirrored offsets for a self-transposed
+    table).  Its output width is the layer's C_in, which the kernels take as 32 / 64 / 128 / 256: the concatenated decoder inputs of some
+    channel tables (ResUNetBN2B / BN2D / FatBN: 128 + 64 = 192, 256 + 128 = 384) go through in column blocks of those widths."""
+    K, cin, cout = weight.shape
+    if cin in (32, 64, 128, 256):
+        return _run(table_t, n_in, dy, _pack(weight, True, mirror), cout, cin)
+    if cin % 32:
+        raise _lib.EyocError(f"sparse_conv: the input gradient needs C_in % 32 == 0, got {cin}", _lib.ERR_INVALID)
+    dx = torch.empty((n_in, cin), dtype=torch.float32, device=dy.device)
+    a = 0
+    while a < cin:
+        w = next(b for b in (256, 128, 64, 32) if b <= cin - a)
+        _run(table_t, n_in, dy, _pack(weight[:, a:a + w, :], True, mirror), cout, w, out=dx[:, a:a + w])
+        a += w
+    return dx
+
+
+def weight_gradient(x: torch.Tensor, dy: torch.Tensor, weight: torch.Tensor, table) -> torch.Tensor:
+    """d(loss)/d(kernel), dense ``[K, C_in, C_out]`` whatever the strides of ``weight`` (``eyoc_spconv_grad_weight``: fp32 MFMA over the
+    gathered pair lists, fixed reduction order)."""
+    K, cin, cout = weight.shape
+    lib = _lib.load()
+    n_out = dy.shape[0]
+    dw = torch.empty(weight.shape, dtype=torch.float32, device=weight.device)
+    with _lib.on_device(x.device):
+        ws = _lib.scratch(lib.eyoc_spconv_grad_weight_workspace_bytes(K, n_out, cin, cout), x.device)
+        _lib.check(lib.eyoc_spconv_grad_weight(_lib.ctx(x.device.index), _lib.ptr(table), K, n_out, _lib.ptr(x), x.stride(0),
+                                               cin, _lib.ptr(dy), dy.stride(0), cout, _lib.ptr(dw), _lib.ptr(ws), ws.numel(),
+                                               _lib.stream_ptr()), "eyoc_spconv_grad_weight")
+    return dw
 
 
 class _SparseConv(torch.autograd.Function):
@@ -82,32 +122,8 @@ class _SparseConv(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        K, cin, cout = weight.shape
-        lib = _lib.load()
-        dx = dw = None
-        if ctx.needs_input_grad[0]:
-            # the same operator over the transposed rulebook with W[k]^T (mirrored offsets for a self-transposed table).  Its output
-            # width is this layer's C_in, which the kernels take as 32 / 64 / 128 / 256: the concatenated decoder inputs of some channel
-            # tables (ResUNetBN2B / BN2D / FatBN: 128 + 64 = 192, 256 + 128 = 384) go through in column blocks of those widths
-            if cin in (32, 64, 128, 256):
-                dx = _run(ctx.table_t, ctx.n_in, dy, _pack(weight, True, ctx.mirror), cout, cin)
-            else:
-                if cin % 32:
-                    raise _lib.EyocError(f"sparse_conv: the input gradient needs C_in % 32 == 0, got {cin}", _lib.ERR_INVALID)
-                dx = torch.empty((ctx.n_in, cin), dtype=torch.float32, device=dy.device)
-                a = 0
-                while a < cin:
-                    w = next(b for b in (256, 128, 64, 32) if b <= cin - a)
-                    _run(ctx.table_t, ctx.n_in, dy, _pack(weight[:, a:a + w, :], True, ctx.mirror), cout, w, out=dx[:, a:a + w])
-                    a += w
-        if ctx.needs_input_grad[1]:
-            n_out = dy.shape[0]
-            dw = torch.empty(weight.shape, dtype=torch.float32, device=weight.device)   # dense [K, C_in, C_out], whatever the strides of `weight`
-            with torch.cuda.device(x.device):
-                ws = _lib.workspace(lib.eyoc_spconv_grad_weight_workspace_bytes(K, n_out, cin, cout), x.device)
-                _lib.check(lib.eyoc_spconv_grad_weight(_lib.ctx(x.device.index), _lib.ptr(ctx.table), K, n_out, _lib.ptr(x), x.stride(0),
-                                                       cin, _lib.ptr(dy), dy.stride(0), cout, _lib.ptr(dw), _lib.ptr(ws), ws.numel(),
-                                                       _lib.stream_ptr()), "eyoc_spconv_grad_weight")
+        dx = input_gradient(dy, weight, ctx.table_t, ctx.mirror, ctx.n_in) if ctx.needs_input_grad[0] else None
+        dw = weight_gradient(x, dy, weight, ctx.table) if ctx.needs_input_grad[1] else None
         return dx, dw, None, None, None, None
 
 

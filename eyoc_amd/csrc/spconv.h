@@ -45,6 +45,12 @@ struct SpconvArgs {
   // staged stride-1 kernel on SMALL inputs (spconv_st.hip, round 5): scratch for splitting a tile's 32-channel input blocks over
   // several workgroups - partial accumulators [KS_MAX_SLOTS][32 floats x 256 threads].  NULL: no split.
   float* ks_part = nullptr;
+  // fp32 workgroup-tiled kernel (spconv.hip), small inputs: `offset_split` > 1 workgroups share a row tile, each walking a contiguous
+  // range of the K offsets and storing its raw sums in `offset_part` [offset_split][n_out][cout]; a second launch adds the shares in
+  // order and applies the epilogue.  Set by launch_spconv itself when the caller allows it (`allow_offset_split`: the summation order
+  // then depends on the problem size - training layers, where no other kernel has to give the same bits)
+  int allow_offset_split = 0, offset_split = 1;
+  float* offset_part = nullptr;
 };
 constexpr int KS_MAX_SLOTS = 1024;                        // (workgroups x splits) a split launch may use: 32 KB of partial sums each
 constexpr size_t KS_PART_BYTES = (size_t)KS_MAX_SLOTS * 256 * 32 * 4;

@@ -159,7 +159,9 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 4 : 2)) void spconv_kernel(Spco
   __syncthreads();
   if (tid == 0) {
     int n = 0;
-    for (int k = 0; k < a.K; ++k)
+    // (offset split: workgroup z of gridDim.z walks the offsets [K z / Z, K (z + 1) / Z) only)
+    const int k_lo = a.K * (int)blockIdx.z / (int)gridDim.z, k_hi = a.K * ((int)blockIdx.z + 1) / (int)gridDim.z;
+    for (int k = k_lo; k < k_hi; ++k)
       for (int s0 = 0; s0 < cnt[k]; s0 += C::SUB)
         items[n++] = (unsigned)k | ((unsigned)(s0 / C::SUB) << 8) | ((unsigned)min(C::SUB, cnt[k] - s0) << 16);
     items[n] = items[n + 1] = n ? items[n - 1] : 0u;   // padding: the pipeline decodes two items ahead
@@ -360,6 +362,15 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 4 : 2)) void spconv_kernel(Spco
 
   // ---- epilogue
   constexpr int C4 = CT / 4;
+  if (gridDim.z > 1) {      // offset split: the raw sums of this share; k_offset_reduce adds the shares and applies the epilogue
+    float* part = a.offset_part + (size_t)blockIdx.z * a.n_out * a.cout;
+    for (int i = tid; i < BM * C4; i += C::THREADS) {
+      const int r = i / C4, c4 = i % C4;
+      if (r >= rows_here) continue;
+      *reinterpret_cast<float4*>(part + (size_t)(row0 + r) * a.cout + ct0 + c4 * 4) = *reinterpret_cast<const float4*>(acc + acc_off(r, c4));
+    }
+    return;
+  }
   if (a.l2norm) {
     for (int i = tid; i < BM * C4; i += C::THREADS) {
       const int r = i / C4, c4 = i % C4;
@@ -408,10 +419,36 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 4 : 2)) void spconv_kernel(Spco
   TR();
 }
 
+// out = sum of the offset shares (in share order: deterministic) + bias + residual, ReLU
+__global__ __launch_bounds__(256) void k_offset_reduce(SpconvArgs a) {
+  const int c4n = a.cout / 4;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)a.n_out * c4n) return;
+  const size_t o = (size_t)(i / c4n);
+  const int c = (int)(i % c4n) * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < a.offset_split; ++z) {
+    const float4 q = *reinterpret_cast<const float4*>(a.offset_part + ((size_t)z * a.n_out + o) * a.cout + c);
+    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+  }
+  if (a.bias) {
+    const float4 b = *reinterpret_cast<const float4*>(a.bias + c);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+  }
+  if (a.res) {
+    const float4 q = *reinterpret_cast<const float4*>(a.res + o * a.ld_res + c);
+    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+  }
+  if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  *reinterpret_cast<float4*>(a.out + (a.out_perm ? (size_t)a.out_perm[o] : o) * a.ld_out + c) = v;
+}
+
 template <int CT, int BM, int NW, int CC>
 void launch_cfg(const SpconvArgs& a, hipStream_t st) {
-  dim3 grid(cdiv(a.n_out, BM), a.cout / CT);
+  dim3 grid(cdiv(a.n_out, BM), a.cout / CT, a.offset_split > 1 ? a.offset_split : 1);
   hipLaunchKernelGGL((spconv_kernel<CT, BM, NW, CC>), grid, dim3(NW * 64), 0, st, a);
+  if (a.offset_split > 1)
+    hipLaunchKernelGGL(k_offset_reduce, dim3(cdiv((long long)a.n_out * (a.cout / 4), 256)), dim3(256), 0, st, a);
 }
 
 template <int CT, int CC>
@@ -779,10 +816,24 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
   }
   if (wave_ok && (force > 0 || (force < 0 && wave_tiles >= 4096))) return launch_spconv_wave(a, st);
   const bool wide = spconv_cc(a.cin, a.cout) == 64;
+  // Small inputs leave most of the chip idle while every workgroup walks its 27 offsets x C_in slices one after the other, each item
+  // a weight fetch from L2 (a level-2 / level-3 layer of two 11 k-voxel clouds: 88-176 workgroups of 32 rows, 54-108 items of ~3 us:
+  // 180 us for 10 MFLOP).  Where the caller allows it the offsets are split over 2-4 workgroups per row tile (scratch of the ctx).
+  SpconvArgs b = a;
+  if (a.allow_offset_split && a.ctx && a.K == 27 && !a.l2norm && a.math == 0 && !a.out_split) {
+    const long long wgs = (long long)cdiv(a.n_out, 32) * (a.cout / spconv_ct(a.cout));
+    const int z = wgs * 4 <= 512 ? 4 : wgs * 3 <= 512 ? 3 : wgs * 2 <= 512 ? 2 : 1;
+    if (z > 1) {
+      const size_t bytes = (size_t)z * a.n_out * a.cout * sizeof(float);
+      if (int rc = a.ctx->ensure_scratch(bytes, st)) return rc;
+      b.offset_split = z;
+      b.offset_part = (float*)a.ctx->scratch;
+    }
+  }
   switch (spconv_ct(a.cout)) {
-    case 32: wide ? launch_ct<32, 64>(a, st) : launch_ct<32, 32>(a, st); break;
-    case 64: wide ? launch_ct<64, 64>(a, st) : launch_ct<64, 32>(a, st); break;
-    default: wide ? launch_ct<128, 64>(a, st) : launch_ct<128, 32>(a, st); break;
+    case 32: wide ? launch_ct<32, 64>(b, st) : launch_ct<32, 32>(b, st); break;
+    case 64: wide ? launch_ct<64, 64>(b, st) : launch_ct<64, 32>(b, st); break;
+    default: wide ? launch_ct<128, 64>(b, st) : launch_ct<128, 32>(b, st); break;
   }
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
@@ -1320,6 +1371,19 @@ int eyoc_spconv(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, const f
   a.nbr = nbr_dev; a.K = K; a.n_out = n_out; a.in = in_dev; a.ld_in = ld_in; a.cin = cin; a.w = wpacked_dev;
   a.cout = cout; a.bias = bias_dev; a.res = res_dev; a.ld_res = ld_res; a.relu = relu; a.l2norm = 0;
   a.out = out_dev; a.ld_out = ld_out; a.ctx = ctx;
+  return launch_spconv(a, (hipStream_t)stream);
+}
+
+// The bare operator for the training path (autograd.sparse_conv: forward and input gradient): no epilogue, and the launcher may split
+// the offsets of a small input over several workgroups per row tile - the summation order, and with it the last bits of the result,
+// then depend on the problem size (deterministic for a given input; eyoc_spconv keeps ONE order for every size).
+int eyoc_spconv_sum(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, const float* in_dev, int ld_in, int cin,
+                    const float* wpacked_dev, int cout, float* out_dev, int ld_out, void* stream) {
+  EYOC_REQUIRE(ctx, EYOC_ERR_INVALID, "eyoc_spconv_sum: NULL ctx");
+  SpconvArgs a;
+  a.nbr = nbr_dev; a.K = K; a.n_out = n_out; a.in = in_dev; a.ld_in = ld_in; a.cin = cin; a.w = wpacked_dev;
+  a.cout = cout; a.bias = nullptr; a.res = nullptr; a.ld_res = 0; a.relu = 0; a.l2norm = 0;
+  a.out = out_dev; a.ld_out = ld_out; a.ctx = ctx; a.allow_offset_split = 1;
   return launch_spconv(a, (hipStream_t)stream);
 }
 

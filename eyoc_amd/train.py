@@ -23,6 +23,7 @@ import ctypes as C
 import torch
 
 from . import _lib
+from . import autograd as _ag
 from .autograd import sparse_conv
 from .sparse_tensor import SparseTensor
 
@@ -39,8 +40,8 @@ class _BatchNormTrain(torch.autograd.Function):
         lib = _lib.load()
         y = torch.empty_like(x)
         stats = torch.empty(2 * c, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
-            ws = _lib.workspace(lib.eyoc_bn_workspace_bytes(n, c), x.device)
+        with _lib.on_device(x.device):
+            ws = _lib.scratch(lib.eyoc_bn_workspace_bytes(n, c), x.device)
             if running is not None:
                 _lib.check(lib.eyoc_bn_train_forward_running(_lib.ctx(x.device.index), _lib.ptr(x), n, c, x.stride(0), _lib.ptr(gamma.contiguous()),
                                                              _lib.ptr(beta.contiguous()), float(eps), 1 if relu else 0, _lib.ptr(y), y.stride(0),
@@ -64,13 +65,72 @@ class _BatchNormTrain(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
-            ws = _lib.workspace(lib.eyoc_bn_workspace_bytes(n, c), x.device)
+        with _lib.on_device(x.device):
+            ws = _lib.scratch(lib.eyoc_bn_workspace_bytes(n, c), x.device)
             _lib.check(lib.eyoc_bn_train_backward(_lib.ctx(x.device.index), _lib.ptr(x), x.stride(0), _lib.ptr(y), 0 if y is None else y.stride(0),
                                                   _lib.ptr(dy), dy.stride(0), n, c, _lib.ptr(gamma.contiguous()), _lib.ptr(stats), ctx.eps,
                                                   _lib.ptr(dx), dx.stride(0), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), ws.numel(),
                                                   _lib.stream_ptr()), "eyoc_bn_train_backward")
         return dx, dgamma, dbeta, None, None, None
+
+
+class _ConvNormTrain(torch.autograd.Function):
+    """One sparse convolution and the batch norm (+ ReLU) behind it as ONE autograd node: the two library calls of ``sparse_conv`` and
+    ``_BatchNormTrain`` back to back, forward and backward - every convolution of the network is followed by a norm, and a training
+    iteration on two 11 k-voxel clouds is bound by the ~20 us of host time an autograd node costs per direction."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, table, table_t, mirror, n_out, eps, relu, running):
+        x = x.contiguous()
+        K, cin, cout = weight.shape
+        z = _ag._run(table, n_out, x, _ag._pack(weight, False, False), cin, cout)
+        lib = _lib.load()
+        y = torch.empty_like(z)
+        stats = torch.empty(2 * cout, dtype=torch.float32, device=x.device)
+        with _lib.on_device(x.device):
+            ws = _lib.scratch(lib.eyoc_bn_workspace_bytes(n_out, cout), x.device)
+            _lib.check(lib.eyoc_bn_train_forward_running(_lib.ctx(x.device.index), _lib.ptr(z), n_out, cout, z.stride(0), _lib.ptr(gamma),
+                                                         _lib.ptr(beta), float(eps), 1 if relu else 0, _lib.ptr(y), y.stride(0),
+                                                         _lib.ptr(stats), _lib.ptr(running[0]), _lib.ptr(running[1]), float(running[2]),
+                                                         _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "eyoc_bn_train_forward_running")
+        ctx.save_for_backward(x, weight, z, y if relu else None, gamma, stats)
+        ctx.table, ctx.table_t, ctx.mirror, ctx.n_in, ctx.eps = table, table_t, mirror, x.shape[0], float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, z, y, gamma, stats = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, c = z.shape
+        lib = _lib.load()
+        dz = torch.empty_like(z)
+        dgamma = torch.empty(c, dtype=torch.float32, device=z.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=z.device)
+        with _lib.on_device(z.device):
+            ws = _lib.scratch(lib.eyoc_bn_workspace_bytes(n, c), z.device)
+            _lib.check(lib.eyoc_bn_train_backward(_lib.ctx(z.device.index), _lib.ptr(z), z.stride(0), _lib.ptr(y), 0 if y is None else y.stride(0),
+                                                  _lib.ptr(dy), dy.stride(0), n, c, _lib.ptr(gamma), _lib.ptr(stats), ctx.eps,
+                                                  _lib.ptr(dz), dz.stride(0), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), ws.numel(),
+                                                  _lib.stream_ptr()), "eyoc_bn_train_backward")
+        dx = _ag.input_gradient(dz, weight, ctx.table_t, ctx.mirror, ctx.n_in) if ctx.needs_input_grad[0] else None
+        dw = _ag.weight_gradient(x, dz, weight, ctx.table) if ctx.needs_input_grad[1] else None
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def conv_norm_train(x: torch.Tensor, weight: torch.Tensor, bn: torch.nn.BatchNorm1d, table, table_t=None, relu: bool = False) -> torch.Tensor:
+    """``norm(conv(x))`` in training mode; the fused node when the norm is an ordinary tracking fp32 ``BatchNorm1d``, the two separate
+    ones otherwise (same arithmetic either way: the same two library calls)."""
+    fused = bn.track_running_stats and bn.running_mean is not None and bn.momentum is not None and bn.weight is not None \
+        and bn.running_mean.dtype == torch.float32 and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous() \
+        and bn.weight.is_contiguous() and bn.bias.is_contiguous() and table is not None
+    if not fused:
+        return batch_norm_train(sparse_conv(x, weight, table, table_t), bn, relu)
+    mirror = table_t is None
+    y = _ConvNormTrain.apply(x, weight, bn.weight, bn.bias, table, table if mirror else table_t, mirror, table.shape[1], bn.eps, relu,
+                             (bn.running_mean, bn.running_var, bn.momentum))
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return y
 
 
 def batch_norm_train(x: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool = False) -> torch.Tensor:
@@ -100,7 +160,7 @@ def gather_window(cm, feats: torch.Tensor, ks: int, internal: bool = False) -> t
     (``internal=True``: ``feats`` and the result in the rows of the forward's own - possibly Z-ordered - maps)."""
     n, cin = feats.shape
     out = torch.empty((n, ks ** 3 * cin), dtype=torch.float32, device=feats.device)
-    with torch.cuda.device(feats.device):
+    with _lib.on_device(feats.device):
         _lib.check(_lib.load().eyoc_maps_gather_window(_lib.ctx(feats.device.index), cm.maps() if internal else cm._caller_maps(), int(ks), _lib.ptr(feats.contiguous()),
                                                        cin, _lib.ptr(out), _lib.stream_ptr()), "eyoc_maps_gather_window")
     return out
@@ -167,15 +227,23 @@ def forward_layers(model, x: SparseTensor, taps: dict | None = None) -> SparseTe
         y = t * scale + (bn.bias - bn.running_mean * scale)
         return torch.relu(y) if relu else y
 
+    def conv_norm(t, kernel, n, table, table_t=None, relu=False):
+        """a convolution and the norm behind it (one autograd node in training mode)"""
+        if model.training:
+            return conv_norm_train(t, kernel, n.bn, table, table_t, relu)
+        return norm(sparse_conv(t, kernel, table, table_t), n, relu)
+
     def block(t, blk, table, name):
         """BasicBlockBN (model/residual_block.py:37-53): relu(bn2(conv2(relu(bn1(conv1(x))))) + x)"""
-        out = tap(name + ".conv1", norm(sparse_conv(t, blk.conv1.kernel, table), blk.norm1, relu=True))
-        out = norm(sparse_conv(out, blk.conv2.kernel, table), blk.norm2)
+        out = tap(name + ".conv1", conv_norm(t, blk.conv1.kernel, blk.norm1, table, relu=True))
+        out = conv_norm(out, blk.conv2.kernel, blk.norm2, table)
         return tap(name + ".conv2", torch.relu(out + t))
 
-    def stage(t, name, table):
-        """``norm -> block (-> relu, already rectified) [-> norm_2 -> block_2]`` on the output of the stage's convolution"""
-        out = block(norm(t, getattr(model, "norm" + name)), getattr(model, "block" + name), table, "block" + name)
+    def stage(t, name, table, conv=None):
+        """``[conv ->] norm -> block (-> relu, already rectified) [-> norm_2 -> block_2]``; ``conv = (input, kernel, table, table_t)`` is
+        the stage's own convolution (fused with the stage's norm), ``t`` its output when the caller ran it already"""
+        first = conv_norm(conv[0], conv[1], getattr(model, "norm" + name), conv[2], conv[3]) if conv else norm(t, getattr(model, "norm" + name))
+        out = block(first, getattr(model, "block" + name), table, "block" + name)
         if expanded:
             out = block(norm(out, getattr(model, f"norm{name}_2")), getattr(model, f"block{name}_2"), table, f"block{name}_2")
         return out
@@ -184,15 +252,15 @@ def forward_layers(model, x: SparseTensor, taps: dict | None = None) -> SparseTe
     F_in = x.F.index_select(0, order) if internal else x.F
     G = gather_window(cm, F_in, model.conv1_kernel_size, internal=internal)
     out_s1 = stage(G @ model.conv1.kernel.reshape(-1, model.conv1.cout), "1", s1[0])
-    out_s2 = stage(sparse_conv(out_s1, model.conv2.kernel, down[0], up[0]), "2", s1[1])
-    out_s4 = stage(sparse_conv(out_s2, model.conv3.kernel, down[1], up[1]), "3", s1[2])
-    out_s8 = stage(sparse_conv(out_s4, model.conv4.kernel, down[2], up[2]), "4", s1[3])
+    out_s2 = stage(None, "2", s1[1], (out_s1, model.conv2.kernel, down[0], up[0]))
+    out_s4 = stage(None, "3", s1[2], (out_s2, model.conv3.kernel, down[1], up[1]))
+    out_s8 = stage(None, "4", s1[3], (out_s4, model.conv4.kernel, down[2], up[2]))
     # decoder; ME.cat order is [decoder | skip]
-    out = stage(sparse_conv(out_s8, model.conv4_tr.kernel, up[2], down[2]), "4_tr", s1[2])
+    out = stage(None, "4_tr", s1[2], (out_s8, model.conv4_tr.kernel, up[2], down[2]))
     out = torch.cat([out, out_s4], 1)
-    out = stage(sparse_conv(out, model.conv3_tr.kernel, up[1], down[1]), "3_tr", s1[1])
+    out = stage(None, "3_tr", s1[1], (out, model.conv3_tr.kernel, up[1], down[1]))
     out = torch.cat([out, out_s2], 1)
-    out = stage(sparse_conv(out, model.conv2_tr.kernel, up[0], down[0]), "2_tr", s1[0])
+    out = stage(None, "2_tr", s1[0], (out, model.conv2_tr.kernel, up[0], down[0]))
     out = torch.cat([out, out_s1], 1)
     # the two 1x1 layers are plain dense products (96 -> 64 -> 32): library GEMMs, forward and backward
     out = tap("conv1_tr", torch.relu(out @ model.conv1_tr.kernel))

@@ -239,6 +239,12 @@ int eyoc_spconv_ex(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, int 
                    float* out_dev, int ld_out, int math, int out_split, const float* out_scale_dev, void* stream);
 int eyoc_split16_encode(eyoc_ctx* ctx, const float* in_dev, int n, int c, int ld_in, float* out_dev, int ld_out, void* stream);
 int eyoc_split16_decode(eyoc_ctx* ctx, const float* in_dev, int n, int c, int ld_in, float* out_dev, int ld_out, void* stream);
+/* The bare operator out[o] = sum_k in[nbr[k][o]] W[k] for the training path (forward and input gradient of autograd.sparse_conv;
+ * lib/trainer.py:1655-1676 runs them through MinkowskiEngine): no epilogue, fp32 MFMAs, and for small inputs the launcher may split
+ * the K offsets over 2-4 workgroups per row tile (scratch of the ctx; shares added in a fixed order) - the summation order then depends
+ * on n_out, which eyoc_spconv never lets happen.  Same argument meaning as eyoc_spconv. */
+int eyoc_spconv_sum(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, const float* in_dev, int ld_in, int cin,
+                    const float* wpacked_dev, int cout, float* out_dev, int ld_out, void* stream);
 /* Backward of one layer (the reference back-propagates through MinkowskiEngine, lib/trainer.py:1667).
  *   grad-input: dIn[i] = sum_k dOut[o] W[k]^T over the pairs (i -> o, k) is a sparse convolution over the TRANSPOSED
  *     rulebook - for a stride-1 table the same table with mirrored offsets (mirror = 1), for the strided (EYOC_MAP_DOWN)
