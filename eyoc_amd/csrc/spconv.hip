@@ -822,7 +822,8 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
   SpconvArgs b = a;
   if (a.allow_offset_split && a.ctx && a.K == 27 && !a.l2norm && a.math == 0 && !a.out_split) {
     const long long wgs = (long long)cdiv(a.n_out, 32) * (a.cout / spconv_ct(a.cout));
-    const int z = wgs * 4 <= 512 ? 4 : wgs * 3 <= 512 ? 3 : wgs * 2 <= 512 ? 2 : 1;
+    // (up to 2048 workgroups: 20 KB of LDS and 2-4 waves each - eight fit a CU, and what bounds a workgroup is its chain of items, not the CU)
+    const int z = wgs * 4 <= 2048 ? 4 : wgs * 3 <= 2048 ? 3 : wgs * 2 <= 2048 ? 2 : 1;
     if (z > 1) {
       const size_t bytes = (size_t)z * a.n_out * a.cout * sizeof(float);
       if (int rc = a.ctx->ensure_scratch(bytes, st)) return rc;

@@ -96,9 +96,15 @@ __global__ void k_reduce_partials(const float* __restrict__ partial, int n_block
   out[e] = s;
 }
 
-int grad_weight_blocks(int n_out) {
-  int nb = cdiv(n_out, 4096);
-  return nb < 1 ? 1 : (nb > 64 ? 64 : nb);
+// row blocks of a gradient launch: 1024 rows each (4096 until round 5: a level-0 layer of two 11 k-voxel clouds was 6 x 27 workgroups of
+// 16 sequential steps on 256 CUs - 147 us), fewer where 27 offsets x the channel tiles already give the chip a few thousand workgroups
+int grad_weight_blocks(int n_out, int K, int cin, int cout) {
+  const int ti = cin % 64 == 0 ? 4 : (cin % 32 == 0 ? 2 : 1), tj = cout % 64 == 0 ? 4 : (cout % 32 == 0 ? 2 : 1);
+  const long long per = (long long)K * (cin / (16 * ti)) * (cout / (16 * tj));
+  int nb = cdiv(n_out, 1024);
+  if (nb > 64) nb = 64;
+  while (nb > 1 && nb * per > 4096) nb >>= 1;
+  return nb < 1 ? 1 : nb;
 }
 
 }  // namespace
@@ -121,7 +127,7 @@ int eyoc_spconv_pack_weights_transposed(const float* w, int K, int cin, int cout
 
 size_t eyoc_spconv_grad_weight_workspace_bytes(int K, int n_out, int cin, int cout) {
   if (K < 1 || n_out < 0 || cin < 1 || cout < 1) return 0;
-  return align_up((size_t)grad_weight_blocks(n_out) * K * cin * cout * sizeof(float)) + 256;
+  return align_up((size_t)grad_weight_blocks(n_out, K, cin, cout) * K * cin * cout * sizeof(float)) + 256;
 }
 
 // dW[k][ci][co] = sum over o with nbr[k][o] >= 0 of in[nbr[k][o]][ci] * dout[o][co]   (plain [K, cin, cout] layout)
@@ -135,7 +141,7 @@ int eyoc_spconv_grad_weight(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_
                EYOC_ERR_WORKSPACE, "eyoc_spconv_grad_weight: workspace %zu < required %zu bytes (256-byte aligned)", ws_bytes,
                eyoc_spconv_grad_weight_workspace_bytes(K, n_out, cin, cout));
   hipStream_t st = (hipStream_t)stream;
-  const int nb = grad_weight_blocks(n_out);
+  const int nb = grad_weight_blocks(n_out, K, cin, cout);
   const int rows_per_block = cdiv(cdiv(n_out, nb), 64) * 64;
   float* partial = (float*)ws;
   const int ti = cin % 64 == 0 ? 4 : (cin % 32 == 0 ? 2 : 1), tj = cout % 64 == 0 ? 4 : (cout % 32 == 0 ? 2 : 1);
