@@ -80,10 +80,11 @@ class _ConvNormTrain(torch.autograd.Function):
     iteration on two 11 k-voxel clouds is bound by the ~20 us of host time an autograd node costs per direction."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, table, table_t, mirror, n_out, eps, relu, running):
+    def forward(ctx, x, weight, gamma, beta, table, table_t, mirror, n_out, eps, relu, running, packed):
         x = x.contiguous()
         K, cin, cout = weight.shape
-        z = _ag._run(table, n_out, x, _ag._pack(weight, False, False), cin, cout)
+        z = _ag._run(table, n_out, x, _ag._pack(weight, False, False) if packed is None else packed[0], cin, cout)
+        ctx.packed_t = None if packed is None else packed[1]
         lib = _lib.load()
         y = torch.empty_like(z)
         stats = torch.empty(2 * cout, dtype=torch.float32, device=x.device)
@@ -112,12 +113,13 @@ class _ConvNormTrain(torch.autograd.Function):
                                                   _lib.ptr(dy), dy.stride(0), n, c, _lib.ptr(gamma), _lib.ptr(stats), ctx.eps,
                                                   _lib.ptr(dz), dz.stride(0), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), ws.numel(),
                                                   _lib.stream_ptr()), "eyoc_bn_train_backward")
-        dx = _ag.input_gradient(dz, weight, ctx.table_t, ctx.mirror, ctx.n_in) if ctx.needs_input_grad[0] else None
+        dx = _ag.input_gradient(dz, weight, ctx.table_t, ctx.mirror, ctx.n_in, ctx.packed_t) if ctx.needs_input_grad[0] else None
         dw = _ag.weight_gradient(x, dz, weight, ctx.table) if ctx.needs_input_grad[1] else None
-        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
-def conv_norm_train(x: torch.Tensor, weight: torch.Tensor, bn: torch.nn.BatchNorm1d, table, table_t=None, relu: bool = False) -> torch.Tensor:
+def conv_norm_train(x: torch.Tensor, weight: torch.Tensor, bn: torch.nn.BatchNorm1d, table, table_t=None, relu: bool = False,
+                    packed=None) -> torch.Tensor:
     """``norm(conv(x))`` in training mode; the fused node when the norm is an ordinary tracking fp32 ``BatchNorm1d``, the two separate
     ones otherwise (same arithmetic either way: the same two library calls)."""
     fused = bn.track_running_stats and bn.running_mean is not None and bn.momentum is not None and bn.weight is not None \
@@ -127,7 +129,7 @@ def conv_norm_train(x: torch.Tensor, weight: torch.Tensor, bn: torch.nn.BatchNor
         return batch_norm_train(sparse_conv(x, weight, table, table_t), bn, relu)
     mirror = table_t is None
     y = _ConvNormTrain.apply(x, weight, bn.weight, bn.bias, table, table if mirror else table_t, mirror, table.shape[1], bn.eps, relu,
-                             (bn.running_mean, bn.running_var, bn.momentum))
+                             (bn.running_mean, bn.running_var, bn.momentum), packed)
     if bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     return y
@@ -227,10 +229,21 @@ def forward_layers(model, x: SparseTensor, taps: dict | None = None) -> SparseTe
         y = t * scale + (bn.bias - bn.running_mean * scale)
         return torch.relu(y) if relu else y
 
+    # every kernel of the fused nodes packed (forward + transposed) by one gather
+    packs = {}
+    if model.training:
+        stages = ("1", "2", "3", "4", "4_tr", "3_tr", "2_tr")
+        blocks = [getattr(model, "block" + n) for n in stages] + ([getattr(model, f"block{n}_2") for n in stages] if expanded else [])
+        kernels = [(getattr(model, "conv" + n).kernel, False) for n in stages[1:]]
+        kernels += [(c.kernel, True) for b in blocks for c in (b.conv1, b.conv2)]
+        bulk = _ag.bulk_pack(kernels)
+        if bulk is not None:
+            packs = {id(w): pk for (w, _), pk in zip(kernels, bulk)}
+
     def conv_norm(t, kernel, n, table, table_t=None, relu=False):
         """a convolution and the norm behind it (one autograd node in training mode)"""
         if model.training:
-            return conv_norm_train(t, kernel, n.bn, table, table_t, relu)
+            return conv_norm_train(t, kernel, n.bn, table, table_t, relu, packs.get(id(kernel)))
         return norm(sparse_conv(t, kernel, table, table_t), n, relu)
 
     def block(t, blk, table, name):
