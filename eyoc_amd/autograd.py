@@ -202,7 +202,7 @@ def _hardest_negative_term(anchor, cand_feats, cand_ids, anchor_key, cand_key_sc
     known positive, penalised by ``relu(neg_thresh - d)^2``.  The distance is re-evaluated with torch ops on the two
     gathered rows so the gradient reaches both ends, exactly where ``D.min(1)`` sends it.
 
-    Everything stays on the device (``cand_ids``, ``anchor_key``, ``known_positive_keys``: int64 device tensors): reading the
+    Everything stays on the device (``cand_ids``, ``anchor_key``, ``known_positive_keys`` - sorted -: int64 device tensors): reading the
     neighbour indices back to filter the positives on the host put two synchronisations between the forward and the backward of
     every iteration; the mean over the kept rows is a masked sum over all of them.  An empty selection gives the reference's NaN
     mean with the reference's gradient (none: a NaN constant is added to a zero sum, instead of dividing by zero)."""
@@ -210,7 +210,12 @@ def _hardest_negative_term(anchor, cand_feats, cand_ids, anchor_key, cand_key_sc
     with torch.no_grad():
         nearest = knn1_segmented(anchor.detach(), cand_feats.detach(), [0, n], [0, cand_feats.shape[0]], "L2", return_distance=False)
         keys = anchor_key + cand_ids[nearest] * cand_key_scale
-        keep = (~torch.isin(keys, known_positive_keys)).to(anchor.dtype)
+        # membership in the SORTED positive keys: one binary search (torch.isin sorts both sides on every call)
+        if known_positive_keys.numel():
+            at = torch.searchsorted(known_positive_keys, keys).clamp_(max=known_positive_keys.numel() - 1)
+            keep = (known_positive_keys[at] != keys).to(anchor.dtype)
+        else:
+            keep = torch.ones(n, dtype=anchor.dtype, device=anchor.device)
     dist = torch.sqrt((anchor - cand_feats[nearest]).pow(2).sum(1) + 1e-7)
     count = keep.sum()
     empty = torch.where(count > 0, torch.zeros_like(count), torch.full_like(count, float("nan")))
@@ -227,11 +232,16 @@ def contrastive_hardest_negative_loss(F0, F1, positive_pairs, num_pos=5192, num_
     cand0, cand1, keep = _draw_loss_samples(np.random if rng is None else rng, len(F0), len(F1), len(pairs), num_hn_samples, num_pos)
     used = pairs if keep is None else pairs[torch.as_tensor(keep)]
     dev = F0.device
-    # one upload of every index array the loss needs (pinned staging would only matter for much larger draws)
-    used_d, pairs_d = used.to(dev), pairs.to(dev)
-    cand0_d, cand1_d = torch.as_tensor(cand0).to(dev), torch.as_tensor(cand1).to(dev)
+    # ONE upload of every index array the loss needs (four small synchronous copies from pageable memory otherwise)
+    n_used, n_pairs = len(used), len(pairs)
+    host = torch.cat([used.reshape(-1), pairs.reshape(-1), torch.as_tensor(cand0, dtype=torch.int64), torch.as_tensor(cand1, dtype=torch.int64)])
+    devbuf = host.to(dev)
+    used_d = devbuf[:2 * n_used].view(n_used, 2)
+    pairs_d = devbuf[2 * n_used:2 * (n_used + n_pairs)].view(n_pairs, 2)
+    cand0_d = devbuf[2 * (n_used + n_pairs):2 * (n_used + n_pairs) + len(cand0)]
+    cand1_d = devbuf[2 * (n_used + n_pairs) + len(cand0):]
     a0, a1 = F0[used_d[:, 0]], F1[used_d[:, 1]]
-    all_keys = pairs_d[:, 0] + pairs_d[:, 1] * scale
+    all_keys = (pairs_d[:, 0] + pairs_d[:, 1] * scale).sort().values
     # keys: (row of cloud 0) + (row of cloud 1) * scale in both directions
     neg01 = _hardest_negative_term(a0, F1[cand1_d], cand1_d, used_d[:, 0], scale, all_keys, neg_thresh)
     neg10 = _hardest_negative_term(a1, F0[cand0_d], cand0_d, used_d[:, 1] * scale, 1, all_keys, neg_thresh)
