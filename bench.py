@@ -350,6 +350,9 @@ def worker(args):
 
     rank, local_rank, world = edist.env_rank()
     assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    # host-side torch ops above 32 k elements run on the intra-op pool: sized for the cores this rank may really use, not for the 256 the
+    # box reports (one such call in the training loss took 13 ms on 16 granted cores and slowed the rest of its iteration three times)
+    torch.set_num_threads(max(1, usable_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
     dry = args.dry_run
     descriptor = dict(inlier_ratio=args.inlier_ratio) if args.inlier_ratio > 0 else None
 
