@@ -133,6 +133,11 @@ def _make_pair(job):
     return syn.make_pair(seed)
 
 
+def scene_workers(local_world, n_scenes):
+    """Scene-generator processes of ONE rank: the node's usable cores divided by the ranks that share them (at least 1, at most 8)."""
+    return max(1, min(8, usable_cores() // max(1, local_world), n_scenes))
+
+
 def make_pairs(seeds, nuscenes=False, workers=None):
     """Synthetic pairs, generated in parallel (numpy ray casting, ~1.3 s each).  Must run BEFORE this process touches
     the GPU: the workers are forked."""
@@ -376,7 +381,7 @@ def worker(args):
         # before any GPU call: forks.  The host's cores are shared by the ranks of this node (8 ranks x 8 workers on a 16-core quota
         # would be 64 processes)
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-        made = make_pairs(scenes, args.nuscenes, workers=max(1, min(8, usable_cores() // max(1, local_world), len(scenes))))
+        made = make_pairs(scenes, args.nuscenes, workers=scene_workers(local_world, len(scenes)))
         gen = dict(zip(scenes, made))
         nus_pairs = None
         if world == 1 and not total_mode and not args.no_extras and not args.nuscenes:

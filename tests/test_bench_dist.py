@@ -52,3 +52,31 @@ def test_single_rank_and_torchrun_environment():
     out = _run("--gpus", "1", "--steps", "1", "--warmup", "0", "--pairs", "2",
                env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
     assert out["n_gpus"] == 1 and out["records_gathered"] == 2
+
+
+def test_eight_ranks_lokitti_545_split():
+    """configs[3] at its real shape: 545 pairs over 8 ranks in batches of 64, one process per rank as
+    `scripts/test_kitti.sh:45-75` runs one process per GPU.  Pair i lives on rank i % 8 (ranks 0 holds 69 pairs, the others
+    68), every rank's ragged last batch is walked, and rank 0 gets all 545 records back in global order."""
+    out = _run("--gpus", "8", "--steps", "1", "--warmup", "0", "--pairs", "64", "--total-pairs", "545")
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == list(range(8)) and out["scaling"] == "strong"
+    assert out["records_gathered"] == 545 and out["success_rate"] == 1.0
+    rr = out["record_rank"]
+    assert rr == [float(i % 8) for i in range(545)]
+    counts = [rr.count(float(r)) for r in range(8)]
+    assert counts == [69] + [68] * 7
+    assert out["steps"] == 2                                    # rank 0: one batch of 64 and a ragged one of 5
+    # whole-job throughput = all 545 pairs over the slowest rank's time
+    assert out["value"] > 0 and out["config"]["pairs_per_step"] == 64
+
+
+def test_scene_workers_are_divided_by_the_ranks_of_the_node():
+    """8 ranks on a node share its cores: each rank's scene-generator pool is cores // 8 (at least 1, at most 8)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cores = bench.usable_cores()
+    assert bench.scene_workers(8, 64) == max(1, min(8, cores // 8, 64))
+    assert bench.scene_workers(1, 64) == max(1, min(8, cores, 64))
+    assert bench.scene_workers(8, 1) == 1

@@ -132,3 +132,44 @@ def test_broadcast_model_ships_the_state_of_an_expanded_model(tmp_path):
     assert any(k.startswith("block3_2.") for k in a) and any(k.startswith("norm4_tr_2.") for k in a)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def _model_worker8(rank, world, port, out_dir):
+    """W = 8: the start-up broadcast of the real 70 MB blob to seven other ranks over gloo."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import eyoc_amd
+    from eyoc_amd import synthetic as syn
+    edist.init(backend="gloo")
+    Model = eyoc_amd.load_model("ResUNetBN2C")
+    model = Model(1, 32, bn_momentum=0.05, conv1_kernel_size=5, normalize_feature=True)
+    if rank == 0:
+        sd = syn.make_weights()
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    blob = edist.broadcast_model(model, torch.device("cpu"), src=0)
+    assert blob.numel() == model.blob_floats()
+    # a 64-bit checksum of the bytes per rank (the blobs themselves would be 8 x 70 MB on disk)
+    words = blob.numpy().view(np.uint32).astype(np.uint64)
+    chk = np.array([int(words.sum()), int((words * (np.arange(words.size, dtype=np.uint64) % 65521 + 1)).sum() & 0xFFFFFFFFFFFF),
+                    words.size], dtype=np.uint64)
+    np.save(os.path.join(out_dir, f"chk{rank}.npy"), chk)
+    mine = edist.shard(545, rank, world)
+    np.save(os.path.join(out_dir, f"mine{rank}.npy"), np.asarray(mine))
+    edist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_broadcast_of_the_real_blob_and_545_pair_shards(tmp_path):
+    from eyoc_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libeyoc_hip.so not built")
+    world = 8
+    mp.spawn(_model_worker8, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    chks = [np.load(tmp_path / f"chk{r}.npy") for r in range(world)]
+    assert int(chks[0][2]) > 8_000_000 and int(chks[0][0]) > 0
+    for r in range(1, world):
+        np.testing.assert_array_equal(chks[0], chks[r])           # every rank holds rank 0's bytes
+    shards = [np.load(tmp_path / f"mine{r}.npy") for r in range(world)]
+    assert [len(s) for s in shards] == [69] + [68] * 7             # LoKITTI_50: 545 pairs, pair i on rank i % 8
+    assert sorted(np.concatenate(shards).tolist()) == list(range(545))
