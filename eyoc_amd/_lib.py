@@ -63,6 +63,7 @@ PROTOTYPES = {
     "eyoc_maps_build_ordered": (_i, [_vp, _vp, _i, _vp, _sz, _vp, _i, C.POINTER(_vp)]),
     "eyoc_maps_free": (_i, [_vp]),
     "eyoc_maps_internal_order": (_i, [_vp, _i]),
+    "eyoc_maps_lazy_tables": (_i, [_vp, _i]),
     "eyoc_maps_order_window_shift": (_i, [_vp, _i]),
     "eyoc_maps_row_order": (_vp, [_vp]),
     "eyoc_maps_copy_row_order": (_i, [_vp, _vp, _vp]),
@@ -127,6 +128,7 @@ PROTOTYPES = {
     "eyoc_bn_train_forward_running": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, C.c_float, _i, _vp, _i, _vp, _vp, _vp, C.c_float, _vp, _sz, _vp]),
     "eyoc_bn_train_backward": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, C.c_float, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "eyoc_maps_gather_window": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "eyoc_maps_gather_window_internal": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "eyoc_knn_prefilter": (_i, [_vp, _i]),
     "eyoc_spconv_select_up_kernel": (_i, [_vp, _i]),
     "eyoc_spconv_upc_min_rows": (_i, [_vp, _i]),
@@ -256,20 +258,35 @@ def on_device(device):
 
 
 _SCRATCH: dict = {}
+_SCRATCH_MAX_STREAMS = 8
 
 
 def scratch(nbytes: int, device):
     """A grow-only 256-byte aligned device buffer per (device, current stream) for kernels that need their workspace only until they
     finish (batch-norm partial sums, gradient partials): consecutive calls on a stream reuse it in stream order - no allocation, no
-    slicing per call (``workspace`` = a fresh tensor every time: three torch ops, ~8 us of a ~45 us layer call)."""
+    slicing per call (``workspace`` = a fresh tensor every time: three torch ops, ~8 us of a ~45 us layer call).
+
+    Keyed by the raw stream handle, which the runtime may hand to a NEW stream after the old one was destroyed: a buffer is therefore
+    tied to its torch stream with ``record_stream`` (the caching allocator then orders its reuse on that stream whoever holds the
+    handle), grows by a quarter over the request (not 2 x), and the cache keeps the ``_SCRATCH_MAX_STREAMS`` most recently used streams
+    (``scratch_clear()`` drops everything, e.g. between training and serving phases)."""
     import torch
     idx = device.index if isinstance(device, torch.device) else int(device)
-    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
-    t = _SCRATCH.get(key)
+    stream = torch.cuda.current_stream(idx)
+    key = (idx, stream.cuda_stream)
+    t = _SCRATCH.pop(key, None)
     if t is None or t.numel() < nbytes:
-        t = workspace(max(int(nbytes) * 2, 1 << 20), torch.device("cuda", idx))
-        _SCRATCH[key] = t
+        t = workspace(max(int(nbytes) + int(nbytes) // 4, 1 << 20), torch.device("cuda", idx))
+        t.record_stream(stream)
+    _SCRATCH[key] = t                                             # re-inserted: dict order = least recently used first
+    while len(_SCRATCH) > _SCRATCH_MAX_STREAMS:
+        _SCRATCH.pop(next(iter(_SCRATCH)))
     return t
+
+
+def scratch_clear():
+    """Drops every cached scratch buffer (they go back to torch's caching allocator once the kernels using them have finished)."""
+    _SCRATCH.clear()
 
 
 def workspace(nbytes: int, device):

@@ -207,10 +207,9 @@ int eyoc_bn_train_backward(eyoc_ctx* ctx, const float* x_dev, int ld_x, const fl
   return EYOC_OK;
 }
 
-int eyoc_maps_gather_window(eyoc_ctx* ctx, eyoc_maps* maps, int ks, const float* feats_dev, int cin, float* out_dev, void* stream) {
-  EYOC_REQUIRE(ctx && maps && feats_dev && out_dev, EYOC_ERR_INVALID, "eyoc_maps_gather_window: NULL argument");
-  EYOC_REQUIRE((ks == 1 || ks == 3 || ks == 5 || ks == 7) && cin >= 1 && cin <= 64, EYOC_ERR_INVALID, "eyoc_maps_gather_window: ks %d, cin %d", ks, cin);
-  // feats and the result are in the maps' INTERNAL rows (the caller's unless eyoc_maps_row_order says otherwise)
+static int gather_window_rows(eyoc_ctx* ctx, eyoc_maps* maps, int ks, const float* feats_dev, int cin, float* out_dev, void* stream, const char* who) {
+  EYOC_REQUIRE(ctx && maps && feats_dev && out_dev, EYOC_ERR_INVALID, "%s: NULL argument", who);
+  EYOC_REQUIRE((ks == 1 || ks == 3 || ks == 5 || ks == 7) && cin >= 1 && cin <= 64, EYOC_ERR_INVALID, "%s: ks %d, cin %d", who, ks, cin);
   hipStream_t st = (hipStream_t)stream;
   int rc = maps_build_table0(maps, st);
   if (rc) return rc;
@@ -220,6 +219,20 @@ int eyoc_maps_gather_window(eyoc_ctx* ctx, eyoc_maps* maps, int ks, const float*
   hipLaunchKernelGGL(k_gather_window, dim3(cdiv(total, 256)), dim3(256), 0, st, maps->coords[0], n, maps->table[0], ks, feats_dev, cin, out_dev);
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
+}
+
+// feats and the result in the CALLER's rows: maps whose internal order differs (eyoc_maps_row_order != NULL) are refused - a caller that
+// holds Z-ordered maps and caller-ordered features would otherwise get silently permuted rows
+int eyoc_maps_gather_window(eyoc_ctx* ctx, eyoc_maps* maps, int ks, const float* feats_dev, int cin, float* out_dev, void* stream) {
+  EYOC_REQUIRE(!maps || !maps->row_perm, EYOC_ERR_INVALID,
+               "eyoc_maps_gather_window: the maps are in Z-order internally - permute the features with eyoc_maps_row_order and call "
+               "eyoc_maps_gather_window_internal, or build the maps in the caller's order");
+  return gather_window_rows(ctx, maps, ks, feats_dev, cin, out_dev, stream, "eyoc_maps_gather_window");
+}
+
+// feats and the result in the maps' INTERNAL rows (row i = the caller's row eyoc_maps_row_order()[i]; the caller's rows when that is NULL)
+int eyoc_maps_gather_window_internal(eyoc_ctx* ctx, eyoc_maps* maps, int ks, const float* feats_dev, int cin, float* out_dev, void* stream) {
+  return gather_window_rows(ctx, maps, ks, feats_dev, cin, out_dev, stream, "eyoc_maps_gather_window_internal");
 }
 
 }  // extern "C"

@@ -91,6 +91,7 @@ struct eyoc_ctx {
     int maps_window_shift = 18;        // eyoc_maps_order_window_shift: window of the tiling orders, log2 rows (measured: 2^17-2^18; 2^12, 2^14 lose)
     int maps_s1_order = 1, maps_down_order = 0;   // eyoc_maps_select_orders: tiling orders of the stride-1 / strided tables
     int maps_internal_order = -1;      // eyoc_maps_internal_order: -1 automatic (Z-order from 8192 rows), 0 caller's order, 1 Z-order
+    int maps_lazy_tables = 1;          // eyoc_maps_lazy_tables: big Z-ordered batches skip the tables only their record builders read (coordmap.hip)
     int knn_prefilter = 1;             // eyoc_knn_prefilter
     int fuse_tail = 1;                 // eyoc_model_fuse_tail: the two 1x1 layers at the end of a split16 forward in one kernel (spconv_tail.hip)
     int spconv_kernel = -1;            // eyoc_spconv_select_kernel: -1 automatic, 0 workgroup-tiled, 1 wave-private
@@ -189,10 +190,21 @@ struct eyoc_maps {
   unsigned char* local_up[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};   // transposed tables (outputs at level l)
   unsigned char* local_upc[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};  // ... partitioned by parity class (spconv_upc.hip: header, tile order, records)
   bool table0_built = false;   // table[0] has its memory reserved but is only filled on demand (maps_build_table0)
+  // Lazy tables (round 6; Z-ordered batches with class-major transposed records, eyoc_ctx::Knobs::maps_lazy_tables): the finest level's
+  // stride-1 table and every transposed table are read by their tile-record builders only, so the build derives the records straight
+  // from the octree (spconv_st.hip build_local_rulebook_derived) / from the compact [8][n] table up8[l] (derive.h) and leaves the
+  // [27][n] tables UNWRITTEN (their memory stays reserved).  eyoc::maps_ensure_table fills one on first use: the accessors
+  // (eyoc_maps_table, _copy_table, _info), a forward whose layer falls back to a gathering kernel, a build whose records overflowed.
+  bool s1_ready[EYOC_MAX_LEVELS] = {true, true, true, true};
+  bool up_ready[EYOC_MAX_LEVELS] = {true, true, true, true};
+  int32_t* up8[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t build_stream = nullptr;   // the stream eyoc_maps_build ran on (eyoc_maps_table has no stream argument)
 };
 
 namespace eyoc {
 int maps_build_table0(eyoc_maps* maps, hipStream_t st);
+// fills a lazily skipped [27][n] table (kind: EYOC_MAP_S1 / EYOC_MAP_UP; anything else is always there) on `st`; no-op when ready
+int maps_ensure_table(eyoc_maps* maps, int kind, int level, hipStream_t st);
 size_t sort_rows64_tmp_bytes(int n);
 int sort_rows_by_key64(void* tmp, size_t tmp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out, const int* vals_in,
                        int* vals_out, int n, int bits, hipStream_t st);

@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "spconv.h"
+#include "derive.h"
 
 using namespace eyoc;
 
@@ -373,9 +374,10 @@ __global__ void k_children(const int* __restrict__ slot, const int* __restrict__
   }
 }
 
-// stride-1 table and transposed (2ts -> ts) table of level l from the stride-1 table of level l+1.
-// For fine row o with parity bits b and parent p, offset `off` on an axis reaches position b + off:
-//   -1 -> coarse block at -1, child bit 1;  0 / 1 -> own block, bit 0 / 1;  2 -> coarse block at +1, bit 0.
+// stride-1 table and transposed (2ts -> ts) table of level l from the stride-1 table of level l+1 (derive.h has the geometry).
+// S1: write the stride-1 table.  UP: 0 = no transposed table, 1 = the full [27][n] one (+ the tiling-order keys when asked for),
+// 2 = the compact [8][n] one (derive.h: up8) - all a class-major record builder reads (spconv_upc.hip), 32 instead of 108 bytes per row.
+template <bool S1, int UP>
 __global__ void k_derive_fine(const int32_t* __restrict__ coords, int n, int sh, const int32_t* __restrict__ parent,
                               const int32_t* __restrict__ children, const int32_t* __restrict__ s1c, int nc,
                               int32_t* __restrict__ s1, int32_t* __restrict__ up, unsigned int* __restrict__ up_key,
@@ -386,89 +388,42 @@ __global__ void k_derive_fine(const int32_t* __restrict__ coords, int n, int sh,
   const int b[3] = {(c.y >> sh) & 1, (c.z >> sh) & 1, (c.w >> sh) & 1};
   const int p = parent[o];
   int blk[8];   // a bit per axis: 0 = own coarse block, 1 = the neighbouring block on the side this voxel leans to
+  derive_blocks(b, p, s1c, nc, blk);
+  if constexpr (S1) {
+    int v[27];
+    derive_window(b, blk, children, v);
 #pragma unroll
-  for (int a = 0; a < 8; ++a) {
-    const int ox = (a & 1) ? (b[0] ? 1 : -1) : 0, oy = (a & 2) ? (b[1] ? 1 : -1) : 0, oz = (a & 4) ? (b[2] ? 1 : -1) : 0;
-    const int kc = (ox + 1) + 3 * (oy + 1) + 9 * (oz + 1);
-    blk[a] = a == 0 ? p : s1c[(size_t)kc * nc + p];
+    for (int k = 0; k < 27; ++k) s1[(size_t)k * n + o] = v[k];
   }
-  // The 27 neighbours of a fine voxel are a 3 x 3 x 3 window of the 4 x 4 x 4 cube of children of its 8 reachable coarse blocks;
-  // which window is decided by the voxel's parity (per axis: positions -1..1 or 0..2 of the cube).  The 8 child RECORDS are
-  // loaded whole (32 bytes each: 16 wide loads instead of 27 four-byte loads that each pull a 32-byte sector) and the window is
-  // cut out with per-axis selects; nothing is indexed by a run-time value.
-  int rec[8][8];
-#pragma unroll
-  for (int a = 0; a < 8; ++a) {
-    int4 lo = make_int4(-1, -1, -1, -1), hi = lo;
-    if (blk[a] >= 0) {
-      lo = reinterpret_cast<const int4*>(children)[2 * (size_t)blk[a]];
-      hi = reinterpret_cast<const int4*>(children)[2 * (size_t)blk[a] + 1];
-    }
-    rec[a][0] = lo.x; rec[a][1] = lo.y; rec[a][2] = lo.z; rec[a][3] = lo.w; rec[a][4] = hi.x; rec[a][5] = hi.y; rec[a][6] = hi.z; rec[a][7] = hi.w;
-  }
-  // cube position u per axis: 0 / 1 = own block, child bit 0 / 1; 2 / 3 = the neighbouring block, child bit 0 / 1.
-  // Window position k (offset k - 1) of an axis with parity bit p: p = 0 -> u = 3, 0, 1 (the block at -1 ends with its bit-1
-  // child); p = 1 -> u = 0, 1, 2 (the block at +1 starts with its bit-0 child).
-  int wx[4][4][3];                                                     // [uz][uy][kx]
-#pragma unroll
-  for (int uz = 0; uz < 4; ++uz)
-#pragma unroll
-    for (int uy = 0; uy < 4; ++uy) {
-      int in[4];
-#pragma unroll
-      for (int ux = 0; ux < 4; ++ux) in[ux] = rec[(ux >> 1) | ((uy >> 1) << 1) | ((uz >> 1) << 2)][(ux & 1) | ((uy & 1) << 1) | ((uz & 1) << 2)];
-      wx[uz][uy][0] = b[0] ? in[0] : in[3];
-      wx[uz][uy][1] = b[0] ? in[1] : in[0];
-      wx[uz][uy][2] = b[0] ? in[2] : in[1];
-    }
-  int wy[4][3][3];                                                     // [uz][ky][kx]
-#pragma unroll
-  for (int uz = 0; uz < 4; ++uz)
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      wy[uz][0][kx] = b[1] ? wx[uz][0][kx] : wx[uz][3][kx];
-      wy[uz][1][kx] = b[1] ? wx[uz][1][kx] : wx[uz][0][kx];
-      wy[uz][2][kx] = b[1] ? wx[uz][2][kx] : wx[uz][1][kx];
-    }
-  // blocks of the transposed map: per axis the own block (offset 0 on an even position, +1 on an odd one) or, for offset -1
-  // on an odd position, the neighbouring one: bl[m] = blk[m & parity class]
-  int bl[8];
-#pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    int sx[2][2];
-#pragma unroll
-    for (int az = 0; az < 2; ++az)
-#pragma unroll
-      for (int ay = 0; ay < 2; ++ay) sx[az][ay] = ((m & 1) && b[0]) ? blk[1 | (ay << 1) | (az << 2)] : blk[(ay << 1) | (az << 2)];
-    const int sy0 = ((m & 2) && b[1]) ? sx[0][1] : sx[0][0], sy1 = ((m & 2) && b[1]) ? sx[1][1] : sx[1][0];
-    bl[m] = ((m & 4) && b[2]) ? sy1 : sy0;
-  }
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    const int kx = k % 3, ky = (k / 3) % 3, kz = k / 9;
-    const int v = kz == 0 ? (b[2] ? wy[0][ky][kx] : wy[3][ky][kx]) : kz == 1 ? (b[2] ? wy[1][ky][kx] : wy[0][ky][kx]) : (b[2] ? wy[2][ky][kx] : wy[1][ky][kx]);
-    s1[(size_t)k * n + o] = v;
-    if (up) {
-      const int off[3] = {kx - 1, ky - 1, kz - 1};
-      // transposed map: c_u - off*ts must be a coarse coordinate: even position needs off == 0,
-      // odd position needs off == +1 (the parent) or off == -1 (the next block)
-      bool up_ok = true;
-#pragma unroll
-      for (int ax = 0; ax < 3; ++ax) up_ok = up_ok && (b[ax] ? off[ax] != 0 : off[ax] == 0);
-      const int m = (off[0] < 0 ? 1 : 0) | (off[1] < 0 ? 2 : 0) | (off[2] < 0 ? 4 : 0);
-      up[(size_t)k * n + o] = up_ok ? bl[m] : -1;
-    }
-  }
-  if (up_key) {
-    // pattern of the transposed map: parity class (which axes sit on an odd position) and which of the coarse
-    // blocks that class can reach exist -> 11-bit sort key (UP_KEY_BITS)
+  if constexpr (UP != 0) {
+    int bl[8];
+    derive_up_blocks(b, blk, bl);
     const int cls = b[0] | (b[1] << 1) | (b[2] << 2);
-    unsigned int present = 0;
+    if constexpr (UP == 1) {
 #pragma unroll
-    for (int a = 0; a < 8; ++a)
-      if ((a & cls) == a && blk[a] >= 0) present |= 1u << a;
-    up_key[o] = key_tag | window_bits(o, wshift) | ((unsigned)cls << 8) | present;
-    up_row[o] = o;
+      for (int k = 0; k < 27; ++k) {
+        const int off[3] = {k % 3 - 1, (k / 3) % 3 - 1, k / 9 - 1};
+        // transposed map: c_u - off*ts must be a coarse coordinate: even position needs off == 0,
+        // odd position needs off == +1 (the parent) or off == -1 (the next block)
+        bool up_ok = true;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) up_ok = up_ok && (b[ax] ? off[ax] != 0 : off[ax] == 0);
+        up[(size_t)k * n + o] = up_ok ? bl[up8_slot_of_offset(k)] : -1;
+      }
+      if (up_key) {
+        // pattern of the transposed map: parity class (which axes sit on an odd position) and which of the coarse
+        // blocks that class can reach exist -> 11-bit sort key (UP_KEY_BITS)
+        unsigned int present = 0;
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+          if ((a & cls) == a && blk[a] >= 0) present |= 1u << a;
+        up_key[o] = key_tag | window_bits(o, wshift) | ((unsigned)cls << 8) | present;
+        up_row[o] = o;
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) up[(size_t)m * n + o] = (m & ~cls) == 0 ? bl[m] : -1;
+    }
   }
 }
 
@@ -561,6 +516,7 @@ size_t eyoc_maps_workspace_bytes(int n_rows) {
   b += EYOC_MAX_LEVELS * (align_up(cap * 8) + align_up(cap * 4));   // hash tables
   b += EYOC_MAX_LEVELS * align_up(n * 16);                           // coordinates
   b += 10 * align_up(n * 27 * 4);                                    // 4 s1 + 3 down + 3 up tables
+  b += 3 * align_up(n * 8 * 4);                                      // compact transposed tables (lazy tables: derive.h up8)
   b += 3 * align_up(n * 4) + align_up((n / SCAN_TILE + 2) * 4);      // slot, flag, partial sums
   b += 3 * (align_up(n * 4) + align_up(n * 32));                     // parent / children links
   b += 4 * align_up(4 * n * 4) + align_up(sort_rows_tmp_bytes(4 * n_rows, UP_KEY_BITS + 4));   // tiling orders: keys, rows, result (<= 2 segments per level, levels sum to < 2 n)
@@ -759,13 +715,26 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
     }
   }
   // ---- rulebooks: hash probes at the coarsest level only, everything else derived top-down
+  // transposed tables on Z-ordered maps: class-major tiles (spconv_upc.hip) for batches, Morton tiles (spconv_up.hip) below
+  // UPC_MIN_ROWS voxels - the partition's five small launches per level cost a single pair (60 k voxels) more than its kernel saves
+  // (eyoc_spconv_upc_min_rows, default 2^17)
+  const bool use_upc = kn.up_kernel == 2 && n >= kn.upc_min_rows;
+  const bool use_up = kn.up_kernel == 1 || (kn.up_kernel == 2 && !use_upc);
+  // lazy tables (common.h eyoc_maps): the level-0 stride-1 table and the transposed tables are read by their record builders only
+  const bool lazy = zorder && use_upc && kn.maps_lazy_tables != 0;
+  m->build_stream = st;
   for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
     m->nbr_s1[l] = cv.take<int32_t>((size_t)27 * m->rows[l]);
     if (l + 1 < EYOC_MAX_LEVELS) {
       m->nbr_down[l] = cv.take<int32_t>((size_t)27 * m->rows[l + 1]);
       m->nbr_up[l] = cv.take<int32_t>((size_t)27 * m->rows[l]);
+      if (lazy) {
+        m->up8[l] = cv.take<int32_t>((size_t)8 * m->rows[l]);
+        m->up_ready[l] = false;
+      }
     }
   }
+  if (lazy) m->s1_ready[0] = false;
   {
     const int top = EYOC_MAX_LEVELS - 1;
     hipLaunchKernelGGL(k_neighbours, dim3(cdiv(m->rows[top], 256)), dim3(256), 0, st, m->coords[top], m->rows[top],
@@ -778,11 +747,6 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
   const bool s1_order = kn.maps_s1_order != 0;
   int seg_up[EYOC_MAX_LEVELS], seg_s1[EYOC_MAX_LEVELS], seg_dn[EYOC_MAX_LEVELS], seg_base[3 * EYOC_MAX_LEVELS], n_seg = 0;
   size_t total = 0;
-  // transposed tables on Z-ordered maps: class-major tiles (spconv_upc.hip) for batches, Morton tiles (spconv_up.hip) below
-  // UPC_MIN_ROWS voxels - the partition's five small launches per level cost a single pair (60 k voxels) more than its kernel saves
-  // (eyoc_spconv_upc_min_rows, default 2^17)
-  const bool use_upc = kn.up_kernel == 2 && n >= kn.upc_min_rows;
-  const bool use_up = kn.up_kernel == 1 || (kn.up_kernel == 2 && !use_upc);
   for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
     seg_up[l] = seg_s1[l] = seg_dn[l] = -1;
     // Z-ordered maps tile the strided convolutions in natural order: a tile's 64 coarse rows read their (adjacent)
@@ -809,10 +773,18 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
   for (int l = EYOC_MAX_LEVELS - 2; l >= 0; --l) {
     const int nl = m->rows[l], nc = m->rows[l + 1];
     const int su = seg_up[l];
-    hipLaunchKernelGGL(k_derive_fine, dim3(cdiv(nl, 256)), dim3(256), 0, st, m->coords[l], nl, l, m->parent[l],
-                       m->children[l], m->nbr_s1[l + 1], nc, m->nbr_s1[l], m->nbr_up[l],
-                       su >= 0 ? key_in + seg_base[su] : (unsigned int*)nullptr, su >= 0 ? row_in + seg_base[su] : (int*)nullptr,
-                       (unsigned int)(su >= 0 ? su : 0) << TAG_SHIFT, wshift);
+    if (lazy) {
+      // levels >= 1: the stride-1 table (the next finer level derives from it) + the compact transposed table; level 0: nothing here -
+      // its tile-record builder derives the windows itself and writes up8[0] on the way (build_local_rulebook_derived, below)
+      if (l > 0)
+        hipLaunchKernelGGL((k_derive_fine<true, 2>), dim3(cdiv(nl, 256)), dim3(256), 0, st, m->coords[l], nl, l, m->parent[l], m->children[l],
+                           m->nbr_s1[l + 1], nc, m->nbr_s1[l], m->up8[l], (unsigned int*)nullptr, (int*)nullptr, 0u, wshift);
+    } else {
+      hipLaunchKernelGGL((k_derive_fine<true, 1>), dim3(cdiv(nl, 256)), dim3(256), 0, st, m->coords[l], nl, l, m->parent[l],
+                         m->children[l], m->nbr_s1[l + 1], nc, m->nbr_s1[l], m->nbr_up[l],
+                         su >= 0 ? key_in + seg_base[su] : (unsigned int*)nullptr, su >= 0 ? row_in + seg_base[su] : (int*)nullptr,
+                         (unsigned int)(su >= 0 ? su : 0) << TAG_SHIFT, wshift);
+    }
     hipLaunchKernelGGL(k_derive_down, dim3(cdiv(nc, 256)), dim3(256), 0, st, nc, m->children[l], m->nbr_s1[l + 1],
                        m->nbr_down[l]);
   }
@@ -845,7 +817,12 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
     FAIL_HIP(hipMemsetAsync(counters + 8, 0, 8 * sizeof(int), st));    // [8] stride-1, [9] transposed, [10 + l] strided table l
     for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
       m->local_s1[l] = cv.take<unsigned char>(local_rulebook_bytes(m->rows[l]));
-      if (int rc = build_local_rulebook(m->nbr_s1[l], 27, m->rows[l], m->local_s1[l], counters + 8, st, kn.st_group)) { delete m; return rc; }
+      if (lazy && l == 0) {
+        DeriveSrc src;
+        src.coords = m->coords[0]; src.parent = m->parent[0]; src.children = m->children[0]; src.s1c = m->nbr_s1[1];
+        src.nc = m->rows[1]; src.sh = 0; src.up8 = m->up8[0];
+        if (int rc = build_local_rulebook_derived(src, m->rows[0], m->local_s1[0], counters + 8, st, kn.st_group)) { delete m; return rc; }
+      } else if (int rc = build_local_rulebook(m->nbr_s1[l], 27, m->rows[l], m->local_s1[l], counters + 8, st, kn.st_group)) { delete m; return rc; }
       if (l + 1 < EYOC_MAX_LEVELS && use_up) {   // the transposed table whose outputs are this level's rows
         m->local_up[l] = cv.take<unsigned char>(local_rulebook_up_bytes(m->rows[l]));
         if (int rc = build_local_rulebook_up(m->nbr_up[l], 27, m->rows[l], m->local_up[l], counters + 9, st)) { delete m; return rc; }
@@ -853,8 +830,9 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
       if (l + 1 < EYOC_MAX_LEVELS && use_upc) {   // ... in class-major order (spconv_upc.hip)
         m->local_upc[l] = cv.take<unsigned char>(upc_kept_bytes(m->rows[l]));
         unsigned char* scratch = cv.take<unsigned char>(upc_scratch_bytes(m->rows[l]));
-        if (m->local_upc[l])
-          if (int rc = build_upc(m->nbr_up[l], m->coords[l], 1 << l, m->rows[l], m->local_upc[l], scratch, st)) { delete m; return rc; }
+        if (m->local_upc[l]) {
+          if (int rc = build_upc(lazy ? m->up8[l] : m->nbr_up[l], m->coords[l], 1 << l, m->rows[l], m->local_upc[l], scratch, st, lazy)) { delete m; return rc; }
+        } else if (int rc = maps_ensure_table(m, EYOC_MAP_UP, l, st)) { delete m; return rc; }
       }
     }
     for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
@@ -880,12 +858,17 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
         delete m;
         return EYOC_ERR_INVALID;
       }
-    if (host[0] != 0)   // a tile with more distinct input rows than two passes stage (does not happen for Z-ordered rows): no staged kernel
+    if (host[0] != 0) {   // a tile with more distinct input rows than two passes stage (does not happen for Z-ordered rows): no staged kernel
       for (int l = 0; l < EYOC_MAX_LEVELS; ++l) m->local_s1[l] = nullptr;
+      if (int rc = maps_ensure_table(m, EYOC_MAP_S1, 0, st)) { delete m; return rc; }   // the gathering kernels read the table
+    }
     if (host[1] != 0)   // ... more than 639 distinct coarse rows under a 256-row tile
       for (int l = 0; l < EYOC_MAX_LEVELS; ++l) m->local_up[l] = nullptr;
     for (int l = 0; l < EYOC_MAX_LEVELS; ++l)   // a class tile with more than 1278 distinct coarse rows: that table stays on the gathering kernels
-      if (host[16 + l] != 0) m->local_upc[l] = nullptr;
+      if (host[16 + l] != 0) {
+        m->local_upc[l] = nullptr;
+        if (int rc = maps_ensure_table(m, EYOC_MAP_UP, l, st)) { delete m; return rc; }
+      }
   }
   FAIL_HIP(hipGetLastError());
 #undef FAIL_HIP
@@ -963,6 +946,12 @@ const int32_t* eyoc_maps_coords(const eyoc_maps* maps, int level) {
 
 const int32_t* eyoc_maps_table(const eyoc_maps* maps, int kind, int level) {
   if (!maps || level < 0 || level >= maps->n_levels) return nullptr;
+  // a table the build skipped (lazy tables) is filled now, on the build's stream, and waited for: the pointer is valid for any stream
+  if ((kind == EYOC_MAP_S1 && !maps->s1_ready[level]) || (kind == EYOC_MAP_UP && level + 1 < maps->n_levels && !maps->up_ready[level])) {
+    eyoc_maps* mm = const_cast<eyoc_maps*>(maps);
+    if (maps_ensure_table(mm, kind, level, mm->build_stream) != EYOC_OK) return nullptr;
+    if (hipStreamSynchronize(mm->build_stream) != hipSuccess) return nullptr;
+  }
   switch (kind) {
     case EYOC_MAP_S1: return maps->nbr_s1[level];
     case EYOC_MAP_DOWN: return level + 1 < maps->n_levels ? maps->nbr_down[level] : nullptr;
@@ -988,6 +977,26 @@ int eyoc_maps_copy_table(const eyoc_maps* maps, int kind, int level, int32_t* ou
 
 }  // extern "C"
 
+int eyoc::maps_ensure_table(eyoc_maps* m, int kind, int level, hipStream_t st) {
+  if (!m || level < 0 || level + 1 >= m->n_levels) return EYOC_OK;      // the coarsest level's table is always built
+  const bool s1 = kind == EYOC_MAP_S1 && !m->s1_ready[level], up = kind == EYOC_MAP_UP && !m->up_ready[level];
+  if (!s1 && !up) return EYOC_OK;
+  const int nl = m->rows[level], nc = m->rows[level + 1];
+  if (nl > 0) {
+    if (s1)
+      hipLaunchKernelGGL((k_derive_fine<true, 0>), dim3(cdiv(nl, 256)), dim3(256), 0, st, m->coords[level], nl, level, m->parent[level],
+                         m->children[level], m->nbr_s1[level + 1], nc, m->nbr_s1[level], (int32_t*)nullptr, (unsigned int*)nullptr,
+                         (int*)nullptr, 0u, -1);
+    else
+      hipLaunchKernelGGL((k_derive_fine<false, 1>), dim3(cdiv(nl, 256)), dim3(256), 0, st, m->coords[level], nl, level, m->parent[level],
+                         m->children[level], m->nbr_s1[level + 1], nc, (int32_t*)nullptr, m->nbr_up[level], (unsigned int*)nullptr,
+                         (int*)nullptr, 0u, -1);
+    EYOC_CHECK_HIP(hipGetLastError());
+  }
+  (s1 ? m->s1_ready : m->up_ready)[level] = true;
+  return EYOC_OK;
+}
+
 // level-0 hash table on demand (only the hash-probing first-convolution fallback reads it)
 int eyoc::maps_build_table0(eyoc_maps* m, hipStream_t st) {
   if (m->table0_built) return EYOC_OK;
@@ -1012,6 +1021,13 @@ int eyoc_maps_internal_order(eyoc_ctx* ctx, int mode) {
 }
 
 const int32_t* eyoc_maps_row_order(const eyoc_maps* maps) { return maps ? maps->row_perm : nullptr; }
+
+int eyoc_maps_lazy_tables(eyoc_ctx* ctx, int on) {
+  EYOC_REQUIRE(ctx, EYOC_ERR_INVALID, "eyoc_maps_lazy_tables: NULL ctx");
+  const int prev = ctx->knobs.maps_lazy_tables;
+  if (on == 0 || on == 1) ctx->knobs.maps_lazy_tables = on;            // anything else: a query
+  return prev;
+}
 
 int eyoc_maps_select_orders(eyoc_ctx* ctx, int s1, int down) {
   if (!ctx) return -1;
@@ -1078,6 +1094,8 @@ int eyoc_maps_info(eyoc_ctx* ctx, const eyoc_maps* m, int conv1_ks, void* stream
   };
   for (int l = 0; l < m->n_levels; ++l) {
     info->rows[l] = m->rows[l];
+    if ((rc = maps_ensure_table(const_cast<eyoc_maps*>(m), EYOC_MAP_S1, l, st))) return rc;
+    if (l + 1 < m->n_levels && (rc = maps_ensure_table(const_cast<eyoc_maps*>(m), EYOC_MAP_UP, l, st))) return rc;
     count(m->nbr_s1[l], 27ll * m->rows[l], l);
     if (l + 1 < m->n_levels) {
       count(m->nbr_down[l], 27ll * m->rows[l + 1], 8 + l);

@@ -308,11 +308,23 @@ int eyoc_model_range_snapshot(eyoc_model* m, uint32_t* words_host, void* stream)
   return EYOC_OK;
 }
 
+// split-K scratch of the staged kernel (spconv_st.hip, launch_spconv_st): only stride-1 layers with >= 4 input blocks whose
+// 32-channel workgroups fit KS_MAX_SLOTS partial-sum slots can split - a batch whose smallest such layer is larger (the bench: 571
+// tiles x 8 channel groups at level 3) and a model that is pinned to fp32 products need none of the 32 MiB
+static size_t ks_part_bytes(const eyoc_model* m, const eyoc_maps* maps) {
+  if (m->math == 0) return 0;
+  for (const LayerPlan& p : m->layers)
+    if (p.map == M_S1 && p.cin >= 128 && p.cout >= 64 && p.cout <= 256 &&
+        (long long)cdiv(maps->rows[p.level], ST_TILE) * (p.cout / 32) <= KS_MAX_SLOTS)
+      return KS_PART_BYTES;
+  return 0;
+}
+
 size_t eyoc_model_workspace_bytes(const eyoc_model* m, const eyoc_maps* maps) {
   if (!m || !maps) return 0;
   size_t b = 0;
   for (int i = B_X1; i < B_OUT; ++i) b += align_up((size_t)maps->rows[m->bufs[i].level] * m->bufs[i].width * sizeof(float));
-  b += align_up(KS_PART_BYTES);                                        // split-K scratch of the staged kernel on small inputs
+  b += align_up(ks_part_bytes(m, maps));
   return b + 256;
 }
 
@@ -366,7 +378,8 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
   buf[B_IN] = const_cast<float*>(feats_dev);
   buf[B_OUT] = out_dev;
   for (int i = B_X1; i < B_OUT; ++i) buf[i] = cv.take<float>((size_t)maps->rows[m->bufs[i].level] * m->bufs[i].width);
-  float* ks_part = cv.take<float>(KS_PART_BYTES / 4);
+  const size_t ks_bytes = ks_part_bytes(m, maps);
+  float* ks_part = ks_bytes ? cv.take<float>(ks_bytes / 4) : nullptr;
   // arithmetic of the sparse convolutions: SPLIT16 needs the wave-private kernel for EVERY layer (only it reads and
   // writes the format), which round 1 measured to pay off once the finest level alone fills the chip (>= 4096 wave tiles ~ 4 KITTI
   // pairs); small batches stay on fp32, where the launcher picks the workgroup-tiled kernel per layer
@@ -462,6 +475,9 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
         if (p.map == M_UP && p.cin % 32 == 0 && p.cout % 64 == 0) a.local_upc = maps->local_upc[p.level]; // spconv_upc.hip (class-major tiles)
       }
       if (p.out_buf == B_OUT) a.out_perm = maps->row_perm;   // the network output goes back to the caller's row order
+      // lazy tables (common.h eyoc_maps): a layer that no tile-record kernel takes reads its [27][n] table - filled here on first use
+      if ((p.map == M_S1 || p.map == M_UP) && spconv_record_path(a) == 0)
+        if ((rc = maps_ensure_table(const_cast<eyoc_maps*>(maps), p.map == M_S1 ? EYOC_MAP_S1 : EYOC_MAP_UP, p.level, st))) return rc;
       a.perm = p.map == M_UP ? maps->perm_up[p.level] : p.map == M_S1 ? maps->perm_s1[p.level]
                : p.map == M_DOWN ? maps->perm_down[p.level] : nullptr;
       rc = launch_spconv(a, st);

@@ -150,13 +150,14 @@ int launch_permute_rows(const float* in, const int32_t* perm, int n, int c, floa
 int launch_spconv_st(const SpconvArgs& a, const unsigned char* local_dev, hipStream_t st);   // tile-local input stage (spconv_st.hip)
 int launch_spconv_up(const SpconvArgs& a, const unsigned char* local_dev, hipStream_t st);   // transposed 3^3 / stride 2 (spconv_up.hip)
 size_t local_rulebook_up_bytes(int n_out);
+int spconv_record_path(const SpconvArgs& a);   // spconv.hip: 1 / 2 / 3 = a tile-record kernel takes the layer (a.nbr is not read), 0 = a gathering kernel
 int build_local_rulebook_up(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st);
 // class-major transposed kernel (spconv_upc.hip): `ws` = upc_kept_bytes of header + tile order + records, built by build_upc
 // (which also needs upc_scratch_bytes of scratch it does not keep)
 size_t upc_kept_bytes(int n_out);
 size_t upc_scratch_bytes(int n_out);
 // coords_dev: the fine level's coordinates ([n_out][4], multiples of `stride`) or NULL (the class is then read off the table)
-int build_upc(const int32_t* nbr_dev, const int32_t* coords_dev, int stride, int n_out, unsigned char* ws, unsigned char* scratch, hipStream_t st);
+int build_upc(const int32_t* nbr_dev, const int32_t* coords_dev, int stride, int n_out, unsigned char* ws, unsigned char* scratch, hipStream_t st, bool compact = false);
 const int* upc_overflow_ptr(const unsigned char* ws);
 int upc_set_tile_rows(int odd_axes, int rows);   // rows per tile (128 .. 256, multiple of 16) of the classes with that many odd axes; this device
 int launch_spconv_upc(const SpconvArgs& a, const unsigned char* ws, hipStream_t st);
@@ -165,6 +166,18 @@ size_t local_rulebook_bytes(int n_out);
 // group: 1 = the rows of a tile sorted by neighbour pattern (fewer non-empty MFMA blocks), 0 = in their own order (what
 // conv1_bf_kernel needs: it finds a parent's entries by its local row); eyoc_maps_build passes its ctx's eyoc_spconv_st_group_rows switch
 int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st, int group = 1);
+// The same records WITHOUT a stride-1 table in memory (round 6): every thread derives its row's 27 neighbours from the octree links
+// and the coarser level's table (derive.h) inside the builder - the finest level's [27][n] table (413 MB on the 128-cloud bench batch)
+// is then neither written nor read back.  up8 (optional): the compact transposed table [8][n_out] of the level, written on the way.
+struct DeriveSrc {
+  const int32_t* coords = nullptr;     // [n_out, 4] level coordinates
+  const int32_t* parent = nullptr;     // [n_out] row of the coarser level
+  const int32_t* children = nullptr;   // [nc, 8] rows of this level
+  const int32_t* s1c = nullptr;        // [27][nc] stride-1 table of the coarser level
+  int nc = 0, sh = 0;                  // coarser level's rows; log2 of this level's stride
+  int32_t* up8 = nullptr;
+};
+int build_local_rulebook_derived(const DeriveSrc& src, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st, int group = 1);
 int launch_spconv_rs(const SpconvArgs& a, hipStream_t st);     // row-stationary, SPLIT16 only (spconv_rs.hip)
 // the network's 1x1 tail in one kernel (spconv_tail.hip): conv1_tr (96 -> 64, ReLU) -> final (64 -> 32, bias) -> row normalisation
 bool tail_fusable(int cin1, int cmid, int cout);

@@ -756,6 +756,23 @@ namespace eyoc {
 // windowed pattern order in time (0.68 / 1.06 / 1.44 vs 0.63 / 1.02 / 1.57 ms on the bench's three layers, + 0.25 ms of rulebooks in
 // the map build; the step is the same within noise) and 18 GB less HBM traffic per forward
 
+// Which tile-record kernel takes a split16 layer: 1 the staged stride-1 kernel (spconv_st.hip), 2 class-major transposed tiles
+// (spconv_upc.hip), 3 Morton transposed tiles (spconv_up.hip), 0 none - a gathering kernel, which reads a.nbr.  ONE predicate for the
+// launcher below and for eyoc_model_forward, which fills a lazily skipped table only when a layer really reads it (common.h eyoc_maps).
+int spconv_record_path(const SpconvArgs& a) {
+  if (a.math != 1 || a.K != 27 || a.l2norm) return 0;
+  const int use_rs = knobs_of(a.ctx).split16_kernel;
+  if (use_rs == 0) return 0;
+  // stride-1 table with local rulebooks: staged kernel (its workgroups cover 64 - or 32 - output channels each and
+  // 1, 2, 4 or 8 of them share a tile; other widths stay on the gathering kernels)
+  const int st_ctg = a.cout >= 64 ? 64 : 32;
+  const bool st_ok = a.cout % st_ctg == 0 && a.cout / st_ctg <= 8 && 8 % (a.cout / st_ctg) == 0 && a.cin % 32 == 0;
+  if (a.local && st_ok) return 1;
+  if (a.local_upc && !a.res && !a.out_perm && a.cout % 64 == 0) return 2;
+  if (a.local_up && a.cout % 64 == 0) return 3;
+  return 0;
+}
+
 int launch_spconv(const SpconvArgs& a, hipStream_t st) {
   EYOC_REQUIRE(a.in && a.w && a.out, EYOC_ERR_INVALID, "spconv: NULL tensor");
   EYOC_REQUIRE(a.n_out >= 0, EYOC_ERR_INVALID, "spconv: n_out %d", a.n_out);
@@ -793,22 +810,11 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
     // output row: 2.9x more zero MFMAs buy nothing there) stay on the wave-private kernel
     // stride-1 table with local rulebooks: staged kernel (its workgroups cover 64 - or 32 - output channels each and
     // 1, 2, 4 or 8 of them share a tile; other widths stay on the gathering kernels)
-    const int st_ctg = a.cout >= 64 ? 64 : 32;
-    const bool st_ok = a.cout % st_ctg == 0 && a.cout / st_ctg <= 8 && 8 % (a.cout / st_ctg) == 0 && a.cin % 32 == 0;
-    if (a.math == 1 && a.local && use_rs != 0 && a.K == 27 && !a.l2norm && st_ok) {
-      SpconvArgs b = a;
-      b.perm = nullptr;
-      return launch_spconv_st(b, a.local, st);
-    }
-    if (a.math == 1 && a.local_upc && use_rs != 0 && a.K == 27 && !a.l2norm && !a.res && !a.out_perm && a.cout % 64 == 0) {   // transposed table, class-major tiles
-      SpconvArgs b = a;
-      b.perm = nullptr;
-      return launch_spconv_upc(b, a.local_upc, st);
-    }
-    if (a.math == 1 && a.local_up && use_rs != 0 && a.K == 27 && !a.l2norm && a.cout % 64 == 0) {   // transposed table with tile rulebooks
-      SpconvArgs b = a;
-      b.perm = nullptr;
-      return launch_spconv_up(b, a.local_up, st);
+    switch (spconv_record_path(a)) {
+      case 1: { SpconvArgs b = a; b.perm = nullptr; return launch_spconv_st(b, a.local, st); }
+      case 2: { SpconvArgs b = a; b.perm = nullptr; return launch_spconv_upc(b, a.local_upc, st); }     // transposed table, class-major tiles
+      case 3: { SpconvArgs b = a; b.perm = nullptr; return launch_spconv_up(b, a.local_up, st); }       // transposed table with tile rulebooks
+      default: break;
     }
     const bool rs_layer = a.cin >= 64 && !(a.n_in > a.n_out);
     if (a.math == 1 && spconv_rs_fits(a) && (use_rs == 2 || (use_rs == 1 && rs_layer))) return launch_spconv_rs(a, st);

@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "spconv.h"
+#include "derive.h"
 
 using namespace eyoc;
 
@@ -73,8 +74,9 @@ static_assert(LR_BYTES % 128 == 0, "records start on cache lines");
 // for all 256 * 27 possible rows - cost twice the clearing and numbering work and a third of the occupancy: 278 -> ~190 us at level 0.)
 constexpr int HSLOTS = 4096;
 
+template <bool DERIVE>
 __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restrict__ nbr, int K, int n_out, unsigned char* __restrict__ out,
-                                                        int* __restrict__ overflow, int group) {
+                                                        int* __restrict__ overflow, int group, DeriveSrc d) {
   __shared__ int hk[HSLOTS];
   __shared__ unsigned short hid[HSLOTS];
   __shared__ unsigned short srow[27][TILE];                          // hash slot of (offset, local row), 0xFFFF = no neighbour
@@ -90,8 +92,27 @@ __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restric
   // 1. insert every valid entry (linear probing; duplicates meet their own key); the slot found stays in a register
   unsigned short slot[27];
   int idxs[27];                                                      // all 27 loads first: behind the CAS loops each would wait alone
+  if constexpr (DERIVE) {                                            // no table in memory: the row's window through the octree (derive.h)
 #pragma unroll
-  for (int k = 0; k < 27; ++k) idxs[k] = (k < K && row < n_out) ? nbr[(size_t)k * n_out + row] : -1;
+    for (int k = 0; k < 27; ++k) idxs[k] = -1;
+    if (row < n_out) {
+      const int4 c = reinterpret_cast<const int4*>(d.coords)[row];
+      const int b[3] = {(c.y >> d.sh) & 1, (c.z >> d.sh) & 1, (c.w >> d.sh) & 1};
+      int blk[8];
+      derive_blocks(b, d.parent[row], d.s1c, d.nc, blk);
+      derive_window(b, blk, d.children, idxs);
+      if (d.up8) {
+        int bl[8];
+        derive_up_blocks(b, blk, bl);
+        const int cls = b[0] | (b[1] << 1) | (b[2] << 2);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) d.up8[(size_t)m * n_out + row] = (m & ~cls) == 0 ? bl[m] : -1;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 27; ++k) idxs[k] = (k < K && row < n_out) ? nbr[(size_t)k * n_out + row] : -1;
+  }
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
     const int idx = idxs[k];
@@ -770,7 +791,15 @@ size_t local_rulebook_bytes(int n_out) { return (size_t)cdiv(n_out, TILE) * LR_B
 // group: 1 = the tile's rows sorted by neighbour pattern (eyoc_ctx::Knobs::st_group, the default), 0 = in their own order
 int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st, int group) {
   if (n_out <= 0) return EYOC_OK;
-  hipLaunchKernelGGL(k_local_rulebook, dim3(cdiv(n_out, TILE)), dim3(256), 0, st, nbr_dev, K, n_out, out_dev, overflow_dev, group);
+  hipLaunchKernelGGL(k_local_rulebook<false>, dim3(cdiv(n_out, TILE)), dim3(256), 0, st, nbr_dev, K, n_out, out_dev, overflow_dev, group, DeriveSrc());
+  EYOC_CHECK_HIP(hipGetLastError());
+  return EYOC_OK;
+}
+
+int build_local_rulebook_derived(const DeriveSrc& src, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st, int group) {
+  if (n_out <= 0) return EYOC_OK;
+  EYOC_REQUIRE(src.coords && src.parent && src.children && src.s1c && src.nc > 0, EYOC_ERR_INVALID, "build_local_rulebook_derived: incomplete octree");
+  hipLaunchKernelGGL(k_local_rulebook<true>, dim3(cdiv(n_out, TILE)), dim3(256), 0, st, (const int32_t*)nullptr, 27, n_out, out_dev, overflow_dev, group, src);
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
 }

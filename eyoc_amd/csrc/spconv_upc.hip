@@ -21,6 +21,7 @@
 #include <atomic>
 
 #include "spconv.h"
+#include "derive.h"
 
 using namespace eyoc;
 
@@ -226,8 +227,9 @@ __global__ __launch_bounds__(256) void k_upc_order(const UpcHeader* __restrict__
 
 // 5. the records
 constexpr int HSLOTS = 4096;                                          // LDS hash of a tile's distinct coarse rows (at most 256 * 8)
+// compact: `nbr` is the [8][n] table of derive.h (up8: slot = bit per axis "offset -1") instead of the full [27][n] one
 __global__ __launch_bounds__(256) void k_upc_records(const int32_t* __restrict__ nbr, int n, const int* __restrict__ sorted,
-                                                     UpcHeader* __restrict__ hdr, unsigned char* __restrict__ out) {
+                                                     UpcHeader* __restrict__ hdr, unsigned char* __restrict__ out, int compact) {
   __shared__ int hk[HSLOTS];
   __shared__ unsigned short hid[HSLOTS], hpos[HSLOTS];
   __shared__ unsigned short srow[KC][TILE];
@@ -245,7 +247,10 @@ __global__ __launch_bounds__(256) void k_upc_records(const int32_t* __restrict__
   __syncthreads();
   int idxs[KC];
 #pragma unroll
-  for (int i = 0; i < KC; ++i) idxs[i] = (i < nk && row >= 0) ? nbr[(size_t)c_classes.order[k0 + (i < nk ? i : 0)] * n + row] : -1;
+  for (int i = 0; i < KC; ++i) {
+    const int k = c_classes.order[k0 + (i < nk ? i : 0)];
+    idxs[i] = (i < nk && row >= 0) ? nbr[(size_t)(compact ? up8_slot_of_offset(k) : k) * n + row] : -1;
+  }
   unsigned int pattern = 0;
 #pragma unroll
   for (int i = 0; i < KC; ++i) {
@@ -543,7 +548,9 @@ size_t upc_scratch_bytes(int n_out) {
   return (((size_t)n_out + 255) & ~(size_t)255) + nblk * 8 * 4 + 256 + (size_t)upc_max_tiles(n_out) * TILE * 4;
 }
 
-int build_upc(const int32_t* nbr_dev, const int32_t* coords_dev, int stride, int n_out, unsigned char* ws, unsigned char* scratch, hipStream_t st) {
+int build_upc(const int32_t* nbr_dev, const int32_t* coords_dev, int stride, int n_out, unsigned char* ws, unsigned char* scratch, hipStream_t st,
+              bool compact) {
+  EYOC_REQUIRE(!compact || coords_dev, EYOC_ERR_INVALID, "build_upc: the compact table needs the level's coordinates for the classes");
   if (n_out <= 0) return EYOC_OK;
   const int nblk = cdiv(n_out, PBLK), max_tiles = upc_max_tiles(n_out);
   unsigned char* cls = scratch;
@@ -556,7 +563,7 @@ int build_upc(const int32_t* nbr_dev, const int32_t* coords_dev, int stride, int
   hipLaunchKernelGGL(k_upc_scan, dim3(1), dim3(1024), 0, st, blk, nblk, hdr);
   hipLaunchKernelGGL(k_upc_scatter, dim3(nblk), dim3(256), 0, st, cls, n_out, blk, hdr, sorted);
   hipLaunchKernelGGL(k_upc_order, dim3(cdiv(max_tiles, 256)), dim3(256), 0, st, hdr, order);
-  hipLaunchKernelGGL(k_upc_records, dim3(max_tiles), dim3(256), 0, st, nbr_dev, n_out, sorted, hdr, ws + upc_records_off(n_out));
+  hipLaunchKernelGGL(k_upc_records, dim3(max_tiles), dim3(256), 0, st, nbr_dev, n_out, sorted, hdr, ws + upc_records_off(n_out), compact ? 1 : 0);
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
 }

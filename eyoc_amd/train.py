@@ -123,16 +123,23 @@ def conv_norm_train(x: torch.Tensor, weight: torch.Tensor, bn: torch.nn.BatchNor
     """``norm(conv(x))`` in training mode; the fused node when the norm is an ordinary tracking fp32 ``BatchNorm1d``, the two separate
     ones otherwise (same arithmetic either way: the same two library calls)."""
     fused = bn.track_running_stats and bn.running_mean is not None and bn.momentum is not None and bn.weight is not None \
-        and bn.running_mean.dtype == torch.float32 and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous() \
-        and bn.weight.is_contiguous() and bn.bias.is_contiguous() and table is not None
+        and bn.bias is not None and all(t.dtype == torch.float32 and t.is_contiguous() and t.device == x.device
+                                        for t in (bn.running_mean, bn.running_var, bn.weight, bn.bias)) and table is not None
     if not fused:
         return batch_norm_train(sparse_conv(x, weight, table, table_t), bn, relu)
     mirror = table_t is None
     y = _ConvNormTrain.apply(x, weight, bn.weight, bn.bias, table, table if mirror else table_t, mirror, table.shape[1], bn.eps, relu,
                              (bn.running_mean, bn.running_var, bn.momentum), packed)
+    _touch_running(bn)
+    return y
+
+
+def _touch_running(bn):
+    """The library moved ``running_mean`` / ``running_var`` through raw pointers: tell torch (``_version`` is what autograd's saved-tensor
+    check and ``model._weights_version()`` look at) and count the batch like ``nn.BatchNorm1d``."""
+    torch.autograd.graph.increment_version((bn.running_mean, bn.running_var))
     if bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
-    return y
 
 
 def batch_norm_train(x: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool = False) -> torch.Tensor:
@@ -142,8 +149,7 @@ def batch_norm_train(x: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool = Fal
     if track and bn.momentum is not None and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous() \
             and bn.running_mean.dtype == torch.float32:
         y, _ = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps, relu, (bn.running_mean, bn.running_var, bn.momentum))
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+        _touch_running(bn)
         return y
     y, stats = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps, relu)
     if track:
@@ -162,9 +168,14 @@ def gather_window(cm, feats: torch.Tensor, ks: int, internal: bool = False) -> t
     (``internal=True``: ``feats`` and the result in the rows of the forward's own - possibly Z-ordered - maps)."""
     n, cin = feats.shape
     out = torch.empty((n, ks ** 3 * cin), dtype=torch.float32, device=feats.device)
+    lib = _lib.load()
     with _lib.on_device(feats.device):
-        _lib.check(_lib.load().eyoc_maps_gather_window(_lib.ctx(feats.device.index), cm.maps() if internal else cm._caller_maps(), int(ks), _lib.ptr(feats.contiguous()),
-                                                       cin, _lib.ptr(out), _lib.stream_ptr()), "eyoc_maps_gather_window")
+        if internal:
+            _lib.check(lib.eyoc_maps_gather_window_internal(_lib.ctx(feats.device.index), cm.maps(), int(ks), _lib.ptr(feats.contiguous()), cin,
+                                                            _lib.ptr(out), _lib.stream_ptr()), "eyoc_maps_gather_window_internal")
+        else:
+            _lib.check(lib.eyoc_maps_gather_window(_lib.ctx(feats.device.index), cm._caller_maps(), int(ks), _lib.ptr(feats.contiguous()), cin,
+                                                   _lib.ptr(out), _lib.stream_ptr()), "eyoc_maps_gather_window")
     return out
 
 
@@ -208,15 +219,16 @@ def forward_layers(model, x: SparseTensor, taps: dict | None = None) -> SparseTe
         back[order] = torch.arange(order.numel(), device=order.device)      # internal row of every caller's row
     level_back = {}
 
-    def tap(name, t):
+    def tap(name, t, lvl):
+        """``lvl``: the tensor's level, from the call site (two levels can have the same number of rows - isolated voxels that a
+        strided convolution does not merge - so the row count does not identify it)"""
         if taps is not None:
             if internal:                                     # diagnostics see the caller's rows at every level
-                n = t.shape[0]
-                if n not in level_back:
-                    lvl = next(l for l in range(4) if cm.rows(l) == n)
+                assert t.shape[0] == cm.rows(lvl), (name, t.shape[0], lvl, cm.rows(lvl))
+                if lvl not in level_back:
                     zc, cc = cm.level_coordinates(lvl, internal=True), cm.level_coordinates(lvl)
-                    level_back[n] = _match_rows(cc, zc)
-                taps[name] = t.index_select(0, level_back[n])
+                    level_back[lvl] = _match_rows(cc, zc)
+                taps[name] = t.index_select(0, level_back[lvl])
             else:
                 taps[name] = t
         return t
@@ -246,37 +258,38 @@ def forward_layers(model, x: SparseTensor, taps: dict | None = None) -> SparseTe
             return conv_norm_train(t, kernel, n.bn, table, table_t, relu, packs.get(id(kernel)))
         return norm(sparse_conv(t, kernel, table, table_t), n, relu)
 
-    def block(t, blk, table, name):
+    def block(t, blk, table, name, lvl):
         """BasicBlockBN (model/residual_block.py:37-53): relu(bn2(conv2(relu(bn1(conv1(x))))) + x)"""
-        out = tap(name + ".conv1", conv_norm(t, blk.conv1.kernel, blk.norm1, table, relu=True))
+        out = tap(name + ".conv1", conv_norm(t, blk.conv1.kernel, blk.norm1, table, relu=True), lvl)
         out = conv_norm(out, blk.conv2.kernel, blk.norm2, table)
-        return tap(name + ".conv2", torch.relu(out + t))
+        return tap(name + ".conv2", torch.relu(out + t), lvl)
 
-    def stage(t, name, table, conv=None):
+    def stage(t, name, lvl, conv=None):
         """``[conv ->] norm -> block (-> relu, already rectified) [-> norm_2 -> block_2]``; ``conv = (input, kernel, table, table_t)`` is
         the stage's own convolution (fused with the stage's norm), ``t`` its output when the caller ran it already"""
+        table = s1[lvl]
         first = conv_norm(conv[0], conv[1], getattr(model, "norm" + name), conv[2], conv[3]) if conv else norm(t, getattr(model, "norm" + name))
-        out = block(first, getattr(model, "block" + name), table, "block" + name)
+        out = block(first, getattr(model, "block" + name), table, "block" + name, lvl)
         if expanded:
-            out = block(norm(out, getattr(model, f"norm{name}_2")), getattr(model, f"block{name}_2"), table, f"block{name}_2")
+            out = block(norm(out, getattr(model, f"norm{name}_2")), getattr(model, f"block{name}_2"), table, f"block{name}_2", lvl)
         return out
 
     # encoder.  conv1: window gather + one dense product (C_in is tiny)
     F_in = x.F.index_select(0, order) if internal else x.F
     G = gather_window(cm, F_in, model.conv1_kernel_size, internal=internal)
-    out_s1 = stage(G @ model.conv1.kernel.reshape(-1, model.conv1.cout), "1", s1[0])
-    out_s2 = stage(None, "2", s1[1], (out_s1, model.conv2.kernel, down[0], up[0]))
-    out_s4 = stage(None, "3", s1[2], (out_s2, model.conv3.kernel, down[1], up[1]))
-    out_s8 = stage(None, "4", s1[3], (out_s4, model.conv4.kernel, down[2], up[2]))
+    out_s1 = stage(G @ model.conv1.kernel.reshape(-1, model.conv1.cout), "1", 0)
+    out_s2 = stage(None, "2", 1, (out_s1, model.conv2.kernel, down[0], up[0]))
+    out_s4 = stage(None, "3", 2, (out_s2, model.conv3.kernel, down[1], up[1]))
+    out_s8 = stage(None, "4", 3, (out_s4, model.conv4.kernel, down[2], up[2]))
     # decoder; ME.cat order is [decoder | skip]
-    out = stage(None, "4_tr", s1[2], (out_s8, model.conv4_tr.kernel, up[2], down[2]))
+    out = stage(None, "4_tr", 2, (out_s8, model.conv4_tr.kernel, up[2], down[2]))
     out = torch.cat([out, out_s4], 1)
-    out = stage(None, "3_tr", s1[1], (out, model.conv3_tr.kernel, up[1], down[1]))
+    out = stage(None, "3_tr", 1, (out, model.conv3_tr.kernel, up[1], down[1]))
     out = torch.cat([out, out_s2], 1)
-    out = stage(None, "2_tr", s1[0], (out, model.conv2_tr.kernel, up[0], down[0]))
+    out = stage(None, "2_tr", 0, (out, model.conv2_tr.kernel, up[0], down[0]))
     out = torch.cat([out, out_s1], 1)
     # the two 1x1 layers are plain dense products (96 -> 64 -> 32): library GEMMs, forward and backward
-    out = tap("conv1_tr", torch.relu(out @ model.conv1_tr.kernel))
+    out = tap("conv1_tr", torch.relu(out @ model.conv1_tr.kernel), 0)
     out = out @ model.final.kernel + model.final.bias
     if model.normalize_feature:
         out = out / torch.norm(out, p=2, dim=1, keepdim=True)          # no epsilon (model/resunet.py:187-191)

@@ -41,7 +41,9 @@ typedef enum {
 } eyoc_status;
 
 #define EYOC_MAX_LEVELS 4
-#define EYOC_VERSION 100
+/* 110 (round 6): the kernel-selection setters and eyoc_ransac_workspace_bytes take the ctx first (round 5), eyoc_maps_gather_window
+ * refuses Z-ordered maps again and eyoc_maps_gather_window_internal exists, eyoc_model_workspace_bytes depends on the maps' size class */
+#define EYOC_VERSION 110
 
 /* ------------------------------------------------------------------------------------------------
  * context
@@ -116,13 +118,19 @@ int eyoc_maps_select_orders(eyoc_ctx* ctx, int s1, int down);
  * eyoc_maps_internal_order(mode): -1 automatic, 0 always the caller's order, 1 always Z-order; returns the previous
  * mode + 2; per ctx, for tests. */
 int eyoc_maps_internal_order(eyoc_ctx* ctx, int mode);
+/* Lazy tables (round 6, default on): a Z-ordered build of >= eyoc_spconv_upc_min_rows rows derives the tile records of the finest
+ * level's stride-1 table and of the transposed tables straight from the octree links and leaves those [27][n] tables unwritten (their
+ * only readers on the hot path were the record builders: 0.8 GB per 128-cloud batch).  They are filled on first use - by
+ * eyoc_maps_table / _copy_table / _info, by a forward whose layer runs a gathering kernel, by a build whose records overflowed - so
+ * nothing a caller can observe changes.  eyoc_maps_lazy_tables(ctx, 0) builds every table eagerly again; returns the previous setting. */
+int eyoc_maps_lazy_tables(eyoc_ctx* ctx, int on);
 const int32_t* eyoc_maps_row_order(const eyoc_maps* maps);
 /* stream-ordered copy of the same array (the identity when the caller's order was kept); out_dev: int32 [rows[0]] */
 int eyoc_maps_copy_row_order(const eyoc_maps* maps, int32_t* out_dev, void* stream);
 int eyoc_maps_rows(const eyoc_maps* maps, int level);
 /* device pointers into the workspace; valid while the maps object lives */
 const int32_t* eyoc_maps_coords(const eyoc_maps* maps, int level);             /* [rows,4]        */
-const int32_t* eyoc_maps_table(const eyoc_maps* maps, int kind, int level);    /* [27][n_out]     */
+const int32_t* eyoc_maps_table(const eyoc_maps* maps, int kind, int level);    /* [27][n_out]; a lazily skipped table is filled on the build's stream and waited for */
 /* stream-ordered device-to-device copies of the same arrays into caller-owned buffers */
 int eyoc_maps_copy_coords(const eyoc_maps* maps, int level, int32_t* out_dev, void* stream);
 int eyoc_maps_copy_table(const eyoc_maps* maps, int kind, int level, int32_t* out_dev, void* stream);
@@ -242,7 +250,10 @@ int eyoc_split16_decode(eyoc_ctx* ctx, const float* in_dev, int n, int c, int ld
 /* The bare operator out[o] = sum_k in[nbr[k][o]] W[k] for the training path (forward and input gradient of autograd.sparse_conv;
  * lib/trainer.py:1655-1676 runs them through MinkowskiEngine): no epilogue, fp32 MFMAs, and for small inputs the launcher may split
  * the K offsets over 2-4 workgroups per row tile (scratch of the ctx; shares added in a fixed order) - the summation order then depends
- * on n_out, which eyoc_spconv never lets happen.  Same argument meaning as eyoc_spconv. */
+ * on n_out, which eyoc_spconv never lets happen.  Same argument meaning as eyoc_spconv.  The split's shares live in the ctx's ONE
+ * grow-only scratch, which kNN / label kernels / RANSAC of the same ctx use too: a call on another stream first waits (event) for
+ * the previous user's stream, i.e. offset-split training layers and matching on a second stream of the same ctx serialise there -
+ * give concurrent phases their own eyoc_ctx. */
 int eyoc_spconv_sum(eyoc_ctx* ctx, const int32_t* nbr_dev, int K, int n_out, const float* in_dev, int ld_in, int cin,
                     const float* wpacked_dev, int cout, float* out_dev, int ld_out, void* stream);
 /* Backward of one layer (the reference back-propagates through MinkowskiEngine, lib/trainer.py:1667).
@@ -464,9 +475,12 @@ int eyoc_bn_train_backward(eyoc_ctx* ctx, const float* x_dev, int ld_x, const fl
                            float* dgamma_dev, float* dbeta_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 /* The first convolution's window as a dense matrix (model/resunet.py:31-38, C_in = 1 in production, K = ks^3):
  * out f32 [n, ks^3 * cin], out[row][k * cin + c] = feats[voxel at window offset k of row][c] or 0 (offsets x fastest, like every
- * rulebook) - the convolution and its weight gradient are then plain [n, K cin] x [K cin, C_out] products.  feats and out are in
- * the maps' INTERNAL rows (the caller's unless eyoc_maps_row_order returns a permutation); builds the level-0 hash table on first use. */
+ * rulebook) - the convolution and its weight gradient are then plain [n, K cin] x [K cin, C_out] products.  Builds the level-0 hash
+ * table on first use.  eyoc_maps_gather_window: feats and out in the CALLER's rows - maps that are Z-ordered internally
+ * (eyoc_maps_row_order != NULL) are refused with EYOC_ERR_INVALID; eyoc_maps_gather_window_internal (EYOC_VERSION >= 110): feats and
+ * out in the maps' INTERNAL rows (row i = the caller's row eyoc_maps_row_order()[i]). */
 int eyoc_maps_gather_window(eyoc_ctx* ctx, eyoc_maps* maps, int ks, const float* feats_dev, int cin, float* out_dev, void* stream);
+int eyoc_maps_gather_window_internal(eyoc_ctx* ctx, eyoc_maps* maps, int ks, const float* feats_dev, int cin, float* out_dev, void* stream);
 
 /* replaces: o3d.pipelines.registration.registration_ransac_based_on_feature_matching(..., 4,
  * [EdgeLength(0.9), Distance(d)], RANSACConvergenceCriteria(4000000, 10000))

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(lib, s), f"{s} declared in eyoc_hip.h but not exported"
         assert s in _lib.PROTOTYPES, f"{s} has no ctypes prototype"
     assert set(_lib.PROTOTYPES) <= set(syms)
-    assert lib.eyoc_version() == 100
+    assert lib.eyoc_version() == 110
 
 
 def test_struct_sizes_match_header():

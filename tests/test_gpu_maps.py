@@ -238,3 +238,51 @@ def test_kernel_selection_switches_belong_to_the_ctx_they_are_set_on():
         assert lib.eyoc_maps_select_orders(other, 0, 1) == 1 and lib.eyoc_maps_select_orders(other, -1, -1) == 2
     finally:
         lib.eyoc_destroy(other)
+
+
+def test_lazy_tables_change_nothing_a_caller_can_observe():
+    """Round 6: a Z-ordered build with class-major transposed records derives the tile records of the finest stride-1 table and of the
+    transposed tables straight from the octree links (derive.h; compact [8][n] transposed tables) and leaves those [27][n] tables
+    unwritten.  The forward must be bit-identical to the eager build's, and the accessors - which fill a skipped table on first use -
+    must still return the oracle's tables."""
+    import eyoc_amd
+    from eyoc_amd import _lib, synthetic as syn
+    from oracle import coords as oc
+    from test_gpu_round2 import _model
+    p = syn.make_pair(2)
+    coords = syn.batch_coords([p["coords0"], p["coords1"]])
+    feats = np.random.default_rng(3).uniform(0.5, 1.5, size=(len(coords), 1)).astype(np.float32)
+    model, _sd = _model()
+    prev_min = _lib.knob("eyoc_spconv_upc_min_rows", 8192)               # class-major records (and with them lazy tables) for a 2-cloud batch
+    assert _lib.knob("eyoc_maps_lazy_tables", -7) == 1                   # the default
+    try:
+        outs, cms = [], []
+        for lazy in (1, 0):
+            _lib.knob("eyoc_maps_lazy_tables", lazy)
+            x = eyoc_amd.SparseTensor(torch.from_numpy(feats).cuda(), coordinates=torch.from_numpy(coords).cuda())
+            outs.append(model(x).F.clone())
+            cms.append(x.coordinate_manager)
+        assert torch.equal(outs[0], outs[1])
+        cm = cms[0]
+        perm = cm.row_order().cpu().numpy()
+        want = oc.build_maps(coords[perm])
+        for l in range(4):
+            np.testing.assert_array_equal(cm.table(_lib.MAP_S1, l, internal=True).cpu().numpy(), want["s1"][l])
+            if l < 3:
+                np.testing.assert_array_equal(cm.table(_lib.MAP_UP, l, internal=True).cpu().numpy(), want["up"][l])
+                np.testing.assert_array_equal(cm.table(_lib.MAP_DOWN, l, internal=True).cpu().numpy(), want["down"][l])
+        info = cm.info(conv1_kernel_size=5)
+        st = oc.map_stats(want)
+        assert info["pairs_s1"] == st["pairs_s1"] and info["pairs_up"] == st["pairs_up"] and info["pairs_down"] == st["pairs_down"]
+        # a forward that needs the skipped tables (every split16 layer on the gathering kernels) fills them itself
+        _lib.knob("eyoc_maps_lazy_tables", 1)
+        x = eyoc_amd.SparseTensor(torch.from_numpy(feats).cuda(), coordinates=torch.from_numpy(coords).cuda())
+        prev_k = _lib.knob("eyoc_spconv_select_split16_kernel", 0)
+        try:
+            f_gather = model(x).F
+        finally:
+            _lib.knob("eyoc_spconv_select_split16_kernel", prev_k)
+        assert float((f_gather - outs[0]).abs().max()) < 2e-5
+    finally:
+        _lib.knob("eyoc_spconv_upc_min_rows", prev_min)
+        _lib.knob("eyoc_maps_lazy_tables", 1)

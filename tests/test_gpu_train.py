@@ -206,3 +206,39 @@ def test_other_channel_tables_train_too():
     worst = max(errs, key=errs.get)
     print(f"ResUNetBN2B on {len(coords)} voxels: train features {e_f:.2e}, worst parameter gradient {worst} {errs[worst]:.2e}")
     assert e_f < REL and errs[worst] < REL, (worst, errs[worst])
+
+
+def test_advice_r5_gather_window_rows_and_running_statistics_versions(setup):
+    """(1) ``eyoc_maps_gather_window`` takes the CALLER's rows and refuses maps that are Z-ordered internally (a caller
+    with caller-ordered features would get silently permuted rows); ``eyoc_maps_gather_window_internal`` is the internal-rows entry.
+    (2) a train-mode forward moves the running statistics through raw pointers: torch must see the write (``_version``)."""
+    import eyoc_amd
+    from eyoc_amd import _lib
+    from eyoc_amd.train import forward_train, gather_window
+    model, sd, coords, feats = setup
+    x = eyoc_amd.SparseTensor(torch.from_numpy(feats).cuda(), coordinates=torch.from_numpy(coords).cuda())
+    cm = x.coordinate_manager
+    lib = _lib.load()
+    F = torch.from_numpy(feats).cuda()
+    Gc = gather_window(cm, F, 3)                                       # the caller's rows (this small cloud's maps keep them)
+    prev = lib.eyoc_maps_internal_order(_lib.ctx(0), 1)                # Z-order forced for the second set
+    try:
+        cmz = eyoc_amd.SparseTensor(torch.from_numpy(feats).cuda(), coordinates=torch.from_numpy(coords).cuda()).coordinate_manager
+        mz = cmz.maps()
+        assert lib.eyoc_maps_row_order(mz)
+        out = torch.empty((len(coords), 27), dtype=torch.float32, device="cuda")
+        rc = lib.eyoc_maps_gather_window(_lib.ctx(0), mz, 3, _lib.ptr(F), 1, _lib.ptr(out), _lib.stream_ptr())
+        assert rc == -1 and b"Z-order" in lib.eyoc_last_error()
+        order = cmz.row_order().long()
+        Gi = gather_window(cmz, F.index_select(0, order), 3, internal=True)    # internal rows in, internal rows out
+        back = torch.empty_like(order)
+        back[order] = torch.arange(order.numel(), device="cuda")
+        assert torch.equal(Gi.index_select(0, back), Gc)
+    finally:
+        lib.eyoc_maps_internal_order(_lib.ctx(0), prev)
+    model.train()
+    bn = model.norm1.bn
+    v0 = (bn.running_mean._version, bn.running_var._version, int(bn.num_batches_tracked))
+    forward_train(model, x, None)
+    assert bn.running_mean._version > v0[0] and bn.running_var._version > v0[1] and int(bn.num_batches_tracked) == v0[2] + 1
+    model.eval()
