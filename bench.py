@@ -104,6 +104,8 @@ def parse_args(argv=None):
     ap.add_argument("--main-priority", action="store_true", help="diagnostics: the step's own stream gets high priority (measured: +0.5 %% with --maps-after start)")
     ap.add_argument("--st-variant", type=int, default=-1,
                     help="diagnostics: staged-kernel implementation (eyoc_spconv_select_st_kernel: 0 C++ loop, 1 assembly loop, 2 assembly without empty-block branches)")
+    ap.add_argument("--down-kernel", type=int, default=-1, help="diagnostics: eyoc_spconv_select_down_kernel (1 staged on 128-row tiles, 0 gathering)")
+    ap.add_argument("--lazy-tables", type=int, default=-1, help="diagnostics: eyoc_maps_lazy_tables (1 / 0)")
     ap.add_argument("--up-kernel", type=int, default=-1, help="diagnostics: eyoc_spconv_select_up_kernel (0 gathering, 1 Morton tiles, 2 class-major tiles)")
     ap.add_argument("--st-group", type=int, default=-1, help="diagnostics: eyoc_spconv_st_group_rows (0 / 1): row grouping inside the staged kernel's tiles")
     ap.add_argument("--conv1-kernel", type=int, default=-1, help="diagnostics: eyoc_spconv_select_conv1_kernel (1 staged block vectors, 0 probing, 2 fp32 walker)")
@@ -403,6 +405,12 @@ def worker(args):
         if args.st_variant >= 0:
             from eyoc_amd import _lib as _l
             _l.knob("eyoc_spconv_select_st_kernel", args.st_variant)
+        if args.down_kernel >= 0:
+            from eyoc_amd import _lib as _l
+            _l.knob("eyoc_spconv_select_down_kernel", args.down_kernel)
+        if args.lazy_tables >= 0:
+            from eyoc_amd import _lib as _l
+            _l.knob("eyoc_maps_lazy_tables", args.lazy_tables)
         if args.up_kernel >= 0:
             from eyoc_amd import _lib as _l
             _l.knob("eyoc_spconv_select_up_kernel", args.up_kernel)

@@ -64,6 +64,7 @@ PROTOTYPES = {
     "eyoc_maps_free": (_i, [_vp]),
     "eyoc_maps_internal_order": (_i, [_vp, _i]),
     "eyoc_maps_lazy_tables": (_i, [_vp, _i]),
+    "eyoc_spconv_select_down_kernel": (_i, [_vp, _i]),
     "eyoc_maps_order_window_shift": (_i, [_vp, _i]),
     "eyoc_maps_row_order": (_vp, [_vp]),
     "eyoc_maps_copy_row_order": (_i, [_vp, _vp, _vp]),

@@ -525,6 +525,7 @@ size_t eyoc_maps_workspace_bytes(int n_rows) {
   b += 2 * align_up(local_rulebook_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_bytes(1)) + 256);   // stride-1 tables
   b += 2 * align_up(local_rulebook_up_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_up_bytes(1)) + 256);
   b += 2 * (align_up(upc_kept_bytes(n_rows)) + align_up(upc_scratch_bytes(n_rows))) + EYOC_MAX_LEVELS * (align_up(upc_kept_bytes(1)) + align_up(upc_scratch_bytes(1)) + 512);   // class-major transposed records + their builder's scratch
+  b += 3 * (align_up(local_rulebook128_bytes(n_rows)) + 256);        // strided tables in 128-row tiles (a level has at most n rows)
   b += 4096;                                                         // counters
   return b + 96 * 256;
 }
@@ -835,6 +836,13 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
         } else if (int rc = maps_ensure_table(m, EYOC_MAP_UP, l, st)) { delete m; return rc; }
       }
     }
+    // strided tables (outputs = the rows of level l + 1) in 128-row tiles: batches only - a single pair's 97 level-1 tiles do not fill the chip
+    const bool use_down = kn.down_kernel == 1 && n >= kn.upc_min_rows;
+    for (int l = 0; l + 1 < EYOC_MAX_LEVELS && use_down; ++l) {
+      m->local_down[l] = cv.take<unsigned char>(local_rulebook128_bytes(m->rows[l + 1]));
+      if (m->local_down[l])
+        if (int rc = build_local_rulebook128(m->nbr_down[l], 27, m->rows[l + 1], m->local_down[l], counters + 10 + l, st, kn.st_group)) { delete m; return rc; }
+    }
     for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
       host[16 + l] = 0;
       if (m->local_upc[l]) FAIL_HIP(hipMemcpyAsync(host + 16 + l, upc_overflow_ptr(m->local_upc[l]), sizeof(int), hipMemcpyDeviceToHost, st));
@@ -864,6 +872,8 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
     }
     if (host[1] != 0)   // ... more than 639 distinct coarse rows under a 256-row tile
       for (int l = 0; l < EYOC_MAX_LEVELS; ++l) m->local_up[l] = nullptr;
+    for (int l = 0; l + 1 < EYOC_MAX_LEVELS; ++l)   // a 128-row coarse tile with more than 1278 distinct fine rows: that strided table stays on the gathering kernel
+      if (host[2 + l] != 0) m->local_down[l] = nullptr;
     for (int l = 0; l < EYOC_MAX_LEVELS; ++l)   // a class tile with more than 1278 distinct coarse rows: that table stays on the gathering kernels
       if (host[16 + l] != 0) {
         m->local_upc[l] = nullptr;
@@ -1021,6 +1031,14 @@ int eyoc_maps_internal_order(eyoc_ctx* ctx, int mode) {
 }
 
 const int32_t* eyoc_maps_row_order(const eyoc_maps* maps) { return maps ? maps->row_perm : nullptr; }
+
+int eyoc_spconv_select_down_kernel(eyoc_ctx* ctx, int mode) {
+  EYOC_REQUIRE(ctx, EYOC_ERR_INVALID, "eyoc_spconv_select_down_kernel: NULL ctx");
+  const int prev = ctx->knobs.down_kernel;
+  if (mode == 0 || mode == 1) ctx->knobs.down_kernel = mode;           // anything else: a query ...
+  if (mode == 2 || mode == 3) ctx->knobs.st128_wide = mode - 2;        // ... or (diagnostics) 2 / 3: 64- / 128-channel workgroups for >= 128-channel layers
+  return prev;
+}
 
 int eyoc_maps_lazy_tables(eyoc_ctx* ctx, int on) {
   EYOC_REQUIRE(ctx, EYOC_ERR_INVALID, "eyoc_maps_lazy_tables: NULL ctx");

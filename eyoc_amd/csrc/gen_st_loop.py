@@ -26,7 +26,7 @@ K, NC, NTW = 27, 4, 2
 LO_REGION = 640 * 64      # the LDS stage: 640 rows x 64 B of hi halves, then the same of lo halves (spconv_st.hip)
 
 
-def gen(NH, WD, LD=2, skip=True, abl=(), K=K, koff=False, tag="", lazy=False):
+def gen(NH, WD, LD=2, skip=True, abl=(), K=K, koff=False, tag="", lazy=False, lowl=False):
     """``lazy`` (round 5): the operand reads of a half-step are issued only for its NON-EMPTY blocks.  The eager schedule reads
     every block's two operand pieces whether or not the block is multiplied - a third of the LDS traffic of a loop whose LDS
     array is as busy as its matrix pipe.  A skipped read makes the number of reads in flight data-dependent, so the exact
@@ -38,19 +38,24 @@ def gen(NH, WD, LD=2, skip=True, abl=(), K=K, koff=False, tag="", lazy=False):
     ws0 + s[52 + i] instead of ws0 + i * ks - the class-major transposed kernel (spconv_upc.hip) walks the 1, 2, 4 or 8
     offsets of ONE parity class, which are not equidistant in the packed weights (K <= 8 then)."""
     assert not koff or K <= 8
+    assert not lowl or NH == 1
     WD, LD = min(WD, K), min(LD, K)
     NWS, NLS = WD + 1, LD + 1
     ACC = lambda h, c, t: 64 + ((h * NC + c) * NTW + t) * 4
     XS = lambda s, c, p: 128 + s * 32 + (c * 2 + p) * 4
     WS = lambda s, t, p: 192 + s * 16 + (t * 2 + p) * 4
-    LB = 192 + NWS * 16
+    # ``lowl`` (NH = 1 only, round 6): the rulebook sets and lane constants live in v[96..127] (the second half of the accumulator
+    # range, which a 64-row wave does not use), so that v[192:255] holds FOUR weight sets: with 4 chunks per offset an offset lasts
+    # ~300 cycles and "two offsets ahead" is less than an L2 round trip - weights run 3 offsets ahead, rulebook entries LD (<= 12)
+    LB = 96 if lowl else 192 + NWS * 16
+    assert not lowl or (NWS <= 4 and 96 + NLS * NH * 2 + 6 <= 128)
     LS = lambda s, h: LB + (s * NH + h) * 2
     # lane constants, computed in the prologue (no VGPR operands: nothing for the compiler to spill around the blob):
     # GH = (lane >> 4) << 4 (XOR term of the hi piece), WL0 = byte offset of the lane's weight fragments of channel tile 0
     # (tile 1: + 64, in the offset field), LV = (lane & 15) * 8 (+ 4096 per 8 offsets) = offset of the lane's rulebook
     # entries, C4 = a prologue temporary; T = the two address temporaries.  They sit behind the rulebook sets when v[..255]
     # has room, else in v[96..] (NH = 1: half the accumulators) or v[56:63] (clobbered on top; the compiler keeps no value there)
-    free = 256 - (LB + NLS * NH * 2)
+    free = (128 if lowl else 256) - (LB + NLS * NH * 2)
     CR = LB + NLS * NH * 2 if free >= 6 else (96 if NH == 1 else 56)
     GH, WL0, LV, C4 = (f"v{CR + i}" for i in range(4))
     T = [CR + 4, None, CR + 5, None]
@@ -254,12 +259,14 @@ def main(path):
         f.write("// (register map, schedule and wait counts: see the generator).\n")
         write_blob(f, "NH2", gen(2, WD2, LD2))
         write_blob(f, "NH1", gen(1, 2, 2))
+        write_blob(f, "NH1_DEEP", gen(1, 3, 5, lowl=True))      # clobbers v[96:127] on top (EYOC_ST_LOOP_CLOBBERS_NH1)
         write_blob(f, "NH2_NOSKIP", gen(2, WD2, LD2, skip=False))
         # spconv_upc.hip: the offsets of ONE parity class of a transposed (stride 2) table - 1, 2, 4 or 8 of them, %[nk] says how
         # many.  One statement with a scalar dispatch in front (four statements in an if-chain made the compiler shuffle the
         # pinned accumulators through scratch: 168 spilled VGPRs)
         write_blob(f, "UPC", gen_upc())
         f.write(f"#define EYOC_ST_LOOP_CLOBBERS {clobbers()}\n")
+        f.write("#define EYOC_ST_LOOP_CLOBBERS_NH1 EYOC_ST_LOOP_CLOBBERS, " + ", ".join(f'"v{i}"' for i in range(96, 128)) + "\n")
     with open(path.replace(".inc", "_abl.inc"), "w") as f:
         f.write("// GENERATED by gen_st_loop.py - diagnostics builds only (EYOC_ST_ABLATIONS / EYOC_ST_TRACE); results are garbage\n")
         for name, abl in (("NOW", ("now",)), ("NOX", ("nox", "nov")), ("NOV", ("nov",)), ("NOM", ("nom",)), ("NOMW", ("nom", "now")),
@@ -269,6 +276,8 @@ def main(path):
         write_blob(f, "UPC_NOM", gen_upc(("nom",)))
         write_blob(f, "UPC_NOW", gen_upc(("now",)))
         write_blob(f, "UPC_EMPTY", gen_upc(("nom", "now", "nol", "nox", "nov")))
+        write_blob(f, "NH1_EMPTY", gen(1, 2, 2, True, ("nom", "now", "nol", "nox", "nov")))   # round 6: what a 128-row strided tile costs around its loop
+        write_blob(f, "NH1_NOM", gen(1, 2, 2, True, ("nom",)))
         write_blob(f, "NH2_W2L3", gen(2, 2, 3))       # weights two offsets ahead, rulebook entries three: no gain
         write_blob(f, "NH2_LAZY", gen(2, WD2, LD2, lazy=True))   # operand reads only for non-empty blocks (round 5): level on every layer
         f.write("#define EYOC_ST_LOOP_CLOBBERS_LOW EYOC_ST_LOOP_CLOBBERS, " + ", ".join(f'"v{i}"' for i in range(56, 62)) + "\n")

@@ -30,6 +30,7 @@ struct SpconvArgs {
   int out_split = 0;               // write SPLIT16 rows (internal activations) instead of fp32 rows
   const int32_t* out_perm = nullptr;      // output row o is written to row out_perm[o] of `out` (the network output in the caller's order); res is not permuted
   const unsigned char* local = nullptr;   // per-tile local rulebooks of `nbr` (build_local_rulebook / build_local_rulebook128) or NULL: enables the staged kernel
+  const unsigned char* local_down = nullptr;   // ... of a strided table in 128-row tiles (build_local_rulebook128): enables launch_spconv_st128
   const unsigned char* local_up = nullptr;   // ... of a transposed table (build_local_rulebook_up): enables spconv_up.hip
   const unsigned char* local_upc = nullptr;  // ... in class-major order (build_upc): enables spconv_upc.hip
   const float* out_scale = nullptr;  // device scalar multiplied into the accumulated sums (undoes the weight pre-scale); NULL = 1
@@ -177,6 +178,10 @@ struct DeriveSrc {
   int nc = 0, sh = 0;                  // coarser level's rows; log2 of this level's stride
   int32_t* up8 = nullptr;
 };
+// 128-row tiles (strided tables; the record layout of the 256-row tiles, quarters 0 and 1 only)
+size_t local_rulebook128_bytes(int n_out);
+int build_local_rulebook128(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st, int group = 1);
+int launch_spconv_st128(const SpconvArgs& a, const unsigned char* local_dev, hipStream_t st);
 int build_local_rulebook_derived(const DeriveSrc& src, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st, int group = 1);
 int launch_spconv_rs(const SpconvArgs& a, hipStream_t st);     // row-stationary, SPLIT16 only (spconv_rs.hip)
 // the network's 1x1 tail in one kernel (spconv_tail.hip): conv1_tr (96 -> 64, ReLU) -> final (64 -> 32, bias) -> row normalisation

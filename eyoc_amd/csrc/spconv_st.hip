@@ -74,19 +74,26 @@ static_assert(LR_BYTES % 128 == 0, "records start on cache lines");
 // for all 256 * 27 possible rows - cost twice the clearing and numbering work and a third of the occupancy: 278 -> ~190 us at level 0.)
 constexpr int HSLOTS = 4096;
 
-template <bool DERIVE>
-__global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restrict__ nbr, int K, int n_out, unsigned char* __restrict__ out,
-                                                        int* __restrict__ overflow, int group, DeriveSrc d) {
-  __shared__ int hk[HSLOTS];
-  __shared__ unsigned short hid[HSLOTS];
-  __shared__ unsigned short srow[27][TILE];                          // hash slot of (offset, local row), 0xFFFF = no neighbour
-  __shared__ unsigned long long key[TILE];
-  __shared__ int wave_cnt[NW];
+// NWB = waves of the builder = 64-row quarters of the tile it describes: 4 (256-row tiles: the stride-1 tables) or 2 (128-row tiles:
+// the strided tables, round 6 - a 128-row coarse tile reads 370-620 distinct fine rows, a 256-row one 700-1250).  Same record layout
+// either way (a 128-row tile leaves the entries of quarters 2 and 3 unwritten: nobody reads them).
+template <bool DERIVE, int NWB>
+__global__ __launch_bounds__(NWB * 64) void k_local_rulebook(const int32_t* __restrict__ nbr, int K, int n_out, unsigned char* __restrict__ out,
+                                                             int* __restrict__ overflow, int group, DeriveSrc d) {
+  constexpr int TR = NWB * 64;                                       // rows per tile
+  // 128-row tiles: half the table (at most 1278 usable rows = 62 % load; 370-620 typical) - clearing and numbering the table is a
+  // fixed cost per tile, and 20 KB of LDS instead of 32 lets eight workgroups share a CU
+  constexpr int HS = NWB == 4 ? HSLOTS : HSLOTS / 2, HSHIFT = NWB == 4 ? 20 : 21;
+  __shared__ int hk[HS];
+  __shared__ unsigned short hid[HS];
+  __shared__ unsigned short srow[27][TR];                            // hash slot of (offset, local row), 0xFFFF = no neighbour
+  __shared__ unsigned long long key[TR];
+  __shared__ int wave_cnt[NWB];
   __shared__ int too_many;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = blockIdx.x;
-  const int row = tile * TILE + (int)threadIdx.x;
-  for (int i = threadIdx.x; i < HSLOTS; i += 256) hk[i] = -1;
+  const int row = tile * TR + (int)threadIdx.x;
+  for (int i = threadIdx.x; i < HS; i += TR) hk[i] = -1;
   if (threadIdx.x == 0) too_many = 0;
   __syncthreads();
   // 1. insert every valid entry (linear probing; duplicates meet their own key); the slot found stays in a register
@@ -118,13 +125,13 @@ __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restric
     const int idx = idxs[k];
     unsigned int s = 0xFFFFu;
     if (idx >= 0) {
-      s = ((unsigned)idx * 2654435761u) >> 20;
+      s = ((unsigned)idx * 2654435761u) >> HSHIFT;
       int probes = 0;
       while (true) {
         const int prev = atomicCAS(&hk[s], -1, idx);
         if (prev == -1 || prev == idx) break;
-        s = (s + 1) & (HSLOTS - 1);
-        if (++probes >= HSLOTS) { too_many = 1; s = 0xFFFFu; break; }   // the table is full: more than HSLOTS distinct rows
+        s = (s + 1) & (HS - 1);
+        if (++probes >= HS) { too_many = 1; s = 0xFFFFu; break; }   // the table is full: more than HSLOTS distinct rows
       }
     }
     slot[k] = (unsigned short)s;
@@ -158,13 +165,13 @@ __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restric
     return;
   }
   // 2. number the occupied slots in slot order (deterministic): every wave owns a quarter of the table
-  constexpr int PER_WAVE = HSLOTS / NW;
+  constexpr int PER_WAVE = HS / NWB;
   int cnt = 0;
   for (int i0 = 0; i0 < PER_WAVE; i0 += 64) cnt += __popcll(__ballot(hk[wave * PER_WAVE + i0 + lane] >= 0));
   if (lane == 0) wave_cnt[wave] = cnt;
   __syncthreads();
   int base = 0, total = 0;
-  for (int w = 0; w < NW; ++w) { if (w < wave) base += wave_cnt[w]; total += wave_cnt[w]; }
+  for (int w = 0; w < NWB; ++w) { if (w < wave) base += wave_cnt[w]; total += wave_cnt[w]; }
   unsigned char* lr = out + (size_t)tile * LR_BYTES;
   int* U = reinterpret_cast<int*>(lr + 16);
   if (total <= UMAX) {                                                 // one pass: any numbering gives the same sums - slot order
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restric
 #pragma unroll
     for (int q = 0; q < PER_WAVE / 64; ++q) {
       const int s = wave * PER_WAVE + q * 64 + lane;
-      ids[q] = hk[s] >= 0 ? (unsigned short)canonical_slot_id<HSLOTS>(hk, hid, s) : (unsigned short)0;
+      ids[q] = hk[s] >= 0 ? (unsigned short)canonical_slot_id<HS>(hk, hid, s) : (unsigned short)0;
     }
     __syncthreads();
 #pragma unroll
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restric
   __syncthreads();
   if (group) {                                                         // 256-key bitonic sort (workgroup-uniform branch)
     const int r_ = (int)threadIdx.x;
-    for (int kk = 2; kk <= TILE; kk <<= 1)
+    for (int kk = 2; kk <= TR; kk <<= 1)
       for (int jj = kk >> 1; jj > 0; jj >>= 1) {
         const int p = r_ ^ jj;
         if (p > r_) {
@@ -228,13 +235,13 @@ __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restric
   // entries go to 16-bit lane c of entry (k, 16 w + j)
   unsigned short* loc = reinterpret_cast<unsigned short*>(lr + 16 + UCAP * 4);
   unsigned char* msk = lr + MASK_OFF;
-  __shared__ unsigned char nib[NPASS][27][NW];
+  __shared__ unsigned char nib[NPASS][27][4];
   const int r = (int)threadIdx.x, w = r >> 6, c = (r >> 4) & 3, j = r & 15;
   // sorted 16-row chunk i goes to slot chunk (w, c) = (i % 4, i / 4): dealt round-robin over the tile's four 64-slot quarters, so
   // that every wave gets its share of the sparse and of the dense patterns (in sorted order the first quarter's waves would run
   // out of non-empty blocks long before the last one's and wait at the tile's barriers)
   // (snake order - 0 1 2 3 3 2 1 0 ... - so that the two row halves of a workgroup, quarters {0, 1} and {2, 3}, carry the same load)
-  const int src = (int)(key[group ? (c * 4 + ((c & 1) ? 3 - w : w)) * 16 + j : r] & 255u);
+  const int src = (int)(key[group ? (c * NWB + ((c & 1) ? NWB - 1 - w : w)) * 16 + j : r] & 255u);
   lr[RM_OFF + (w * 16 + j) * 4 + c] = (unsigned char)src;
   lr[INV_OFF + src] = (unsigned char)r;
 #pragma unroll
@@ -256,7 +263,10 @@ __global__ __launch_bounds__(256) void k_local_rulebook(const int32_t* __restric
   if (threadIdx.x < NPASS * 28) {
     const int p = (int)threadIdx.x / 28, k = (int)threadIdx.x % 28;
     unsigned short m = 0;
-    if (k < 27 && !(p > 0 && total <= p * UMAX)) m = (unsigned short)(nib[p][k][0] | nib[p][k][1] << 4 | nib[p][k][2] << 8 | nib[p][k][3] << 12);
+    if (k < 27 && !(p > 0 && total <= p * UMAX)) {
+      m = (unsigned short)(nib[p][k][0] | nib[p][k][1] << 4);
+      if (NWB == 4) m |= (unsigned short)(nib[p][k][2] << 8 | nib[p][k][3] << 12);
+    }
     reinterpret_cast<unsigned short*>(msk)[p * 28 + k] = m;
   }
 }
@@ -497,12 +507,18 @@ typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
 // accumulators, phase 1 (one workgroup per (tile, channel group), no stage, no loop) adds the shares in share order and runs the
 // epilogue.  (One launch with an arrival counter and the last workgroup summing was built first: its agent-scope fences - an L2
 // write-back and invalidate per workgroup on gfx950 - made a single pair 1 ms SLOWER.)
-template <int CC, int NH, int SKIP, int NWV = NW>
+// TR = 128 (round 6, the strided tables; NH = 1, 4 waves): the tile is 128 output rows x 64 channels - waves = 2 row quarters x 2 channel
+// halves of 64 rows x 32 channels, records from k_local_rulebook<.., 2> (same layout; quarters 2 and 3 do not exist).
+template <int CC, int NH, int SKIP, int NWV = NW, int TR = TILE>
 __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(SpconvArgs a, const unsigned char* __restrict__ local, int n_tiles, int ksplit, int phase) {
   constexpr int NTW = 2, CTW = NTW * 16, NC = 4;
-  constexpr int CTG = CTW * NH * (NWV / NW);                            // NWV = 8: 4 row quarters x 2 channel halves, NH = 1
+  constexpr bool T128 = TR == 128;
+  constexpr int CTG = T128 ? (NH == 2 ? 4 * CTW : 2 * CTW) : CTW * NH * (NWV / NW);   // NWV = 8: 4 row quarters x 2 channel halves, NH = 1
   constexpr int NITV = XROWS / (16 * NWV);
   static_assert(NWV == NW || (NWV == 2 * NW && NH == 1), "8 waves: 64 rows x 32 channels each");
+  // 128-row tiles: four waves of 64 rows x 32 channels (2 row quarters x 2 channel halves: 64 channels per workgroup) or, NH = 2, of
+  // 128 rows x 32 channels (4 channel quarters: 128 channels per workgroup - half the stages and tiles of a >= 128-channel layer)
+  static_assert(TR == TILE || (T128 && NWV == NW), "128-row tiles: four waves");
   // (EYOC_ST_ABLATIONS 15-17: a padded stage = ONE workgroup per CU, to time a workgroup that has its CU to itself)
   __shared__ __attribute__((aligned(128))) unsigned char xs[X_BYTES + (SKIP >= 15 && SKIP <= 17 ? 8192 : 0)];
   const int lane = threadIdx.x & 63;
@@ -512,8 +528,8 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
   const int xcd = (int)blockIdx.x & 7, per = 8 / n_cg;
   const int cg = xcd % n_cg, tile = ((int)blockIdx.x >> 3) * per + xcd / n_cg;
   if (tile >= n_tiles) return;
-  const int w0 = NH == 1 ? (wave & 3) : 2 * (wave >> 1);
-  const int ct0 = cg * CTG + (NH == 2 ? (wave & 1) * CTW : (wave >> 2) * CTW);
+  const int w0 = T128 ? (NH == 2 ? 0 : (wave >> 1)) : NH == 1 ? (wave & 3) : 2 * (wave >> 1);
+  const int ct0 = cg * CTG + (T128 && NH == 2 ? wave * CTW : T128 || NH == 2 ? (wave & 1) * CTW : (wave >> 2) * CTW);
   const int CT = a.cout >= 128 ? 128 : a.cout;
   const int n_slices = a.cout / CT, slice = ct0 / CT, nt0 = (ct0 - slice * CT) / 16;
   constexpr int JQ = CC / 16;
@@ -644,6 +660,15 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
       else if constexpr (NH == 2 && SKIP == 16) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_NOWL);
       else if constexpr (NH == 2 && SKIP == 17) EYOC_ST_ASM_NH2(EYOC_ST_LOOP_NH2_EMPTY);
 #endif
+#ifdef EYOC_ST_ABLATIONS
+      else if constexpr (NH == 1 && SKIP == 13)
+        asm volatile(EYOC_ST_LOOP_NH1_EMPTY : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), [so] "=&s"(so) : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS);
+      else if constexpr (NH == 1 && SKIP == 8)
+        asm volatile(EYOC_ST_LOOP_NH1_NOM : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), [so] "=&s"(so) : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS);
+#endif
+      else if constexpr (SKIP == 18)       // NH = 1 with weights three offsets ahead and rulebook entries five (round 6)
+        asm volatile(EYOC_ST_LOOP_NH1_DEEP : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), [so] "=&s"(so)
+                     : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS_NH1);
       else
         asm volatile(EYOC_ST_LOOP_NH1 : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), [so] "=&s"(so)
                      : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS);
@@ -653,7 +678,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
   }
 
   asm volatile("" :: "v"(warm));
-  if constexpr (NH == 1 && NWV == NW) {
+  if constexpr (NH == 1 && NWV == NW && !T128) {
     if (ksplit > 1) {                                                    // launch-uniform
       constexpr int NR4 = 8;                                             // 32 accumulator registers per thread = 8 float4
       float4* P = reinterpret_cast<float4*>(a.ks_part) + (size_t)((tile * n_cg + cg) * ksplit) * NR4 * 256;
@@ -700,7 +725,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
   for (int h = 0; h < NH; ++h) {
     const unsigned int rm = *reinterpret_cast<const unsigned int*>(lr + RM_OFF + ((w0 + h) * 16 + j) * 4);
 #pragma unroll
-    for (int c = 0; c < NC; ++c) orow[h * NC + c] = tile * TILE + (int)((rm >> (8 * c)) & 255u);
+    for (int c = 0; c < NC; ++c) orow[h * NC + c] = tile * TR + (int)((rm >> (8 * c)) & 255u);
   }
   uint4 rh[NG], rl[NG];
   if (a.res) {
@@ -791,7 +816,7 @@ size_t local_rulebook_bytes(int n_out) { return (size_t)cdiv(n_out, TILE) * LR_B
 // group: 1 = the tile's rows sorted by neighbour pattern (eyoc_ctx::Knobs::st_group, the default), 0 = in their own order
 int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st, int group) {
   if (n_out <= 0) return EYOC_OK;
-  hipLaunchKernelGGL(k_local_rulebook<false>, dim3(cdiv(n_out, TILE)), dim3(256), 0, st, nbr_dev, K, n_out, out_dev, overflow_dev, group, DeriveSrc());
+  hipLaunchKernelGGL((k_local_rulebook<false, 4>), dim3(cdiv(n_out, TILE)), dim3(256), 0, st, nbr_dev, K, n_out, out_dev, overflow_dev, group, DeriveSrc());
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
 }
@@ -799,7 +824,7 @@ int build_local_rulebook(const int32_t* nbr_dev, int K, int n_out, unsigned char
 int build_local_rulebook_derived(const DeriveSrc& src, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st, int group) {
   if (n_out <= 0) return EYOC_OK;
   EYOC_REQUIRE(src.coords && src.parent && src.children && src.s1c && src.nc > 0, EYOC_ERR_INVALID, "build_local_rulebook_derived: incomplete octree");
-  hipLaunchKernelGGL(k_local_rulebook<true>, dim3(cdiv(n_out, TILE)), dim3(256), 0, st, (const int32_t*)nullptr, 27, n_out, out_dev, overflow_dev, group, src);
+  hipLaunchKernelGGL((k_local_rulebook<true, 4>), dim3(cdiv(n_out, TILE)), dim3(256), 0, st, (const int32_t*)nullptr, 27, n_out, out_dev, overflow_dev, group, src);
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
 }
@@ -810,7 +835,7 @@ int build_local_rulebook_derived(const DeriveSrc& src, int n_out, unsigned char*
 #ifdef EYOC_ST_ABLATIONS
 constexpr int ST_VARIANTS = 28;
 #else
-constexpr int ST_VARIANTS = 3;
+constexpr int ST_VARIANTS = 5;      // 4 = variant 1 with the deep-prefetch loop in the NH = 1 kernels (32-channel layers, 128-row strided tiles)
 #endif
 int st_variants() { return ST_VARIANTS; }
 
@@ -883,9 +908,64 @@ int launch_spconv_st(const SpconvArgs& a_in, const unsigned char* local_dev, hip
       else if (variant == 27) EYOC_STA(64, 2, 17);
 #endif
       else { if (wide) EYOC_STA(64, 2, 1); else EYOC_STA(32, 2, 1); }
-    } else { if (wide) EYOC_STA(64, 1, 1); else EYOC_STA(32, 1, 1); }
+    } else if (variant == 4) { if (wide) EYOC_STA(64, 1, 18); else EYOC_STA(32, 1, 18); }
+    else { if (wide) EYOC_STA(64, 1, 1); else EYOC_STA(32, 1, 1); }
 #undef EYOC_STA
   }
+  EYOC_CHECK_HIP(hipGetLastError());
+  return EYOC_OK;
+}
+
+// strided (2ts <- ts) SPLIT16 layers whose table has 128-row tile records (build_local_rulebook128): 128 output rows x 64 channels per
+// workgroup, the NH = 1 assembly loop
+int launch_spconv_st128(const SpconvArgs& a, const unsigned char* local_dev, hipStream_t st) {
+  EYOC_REQUIRE(a.math == 1 && local_dev && !a.l2norm && a.K == 27 && !a.perm, EYOC_ERR_INVALID, "spconv_st128: unsupported layer");
+  const eyoc_ctx::Knobs& kn128 = knobs_of(a.ctx);
+  // >= 128 output channels: workgroups of 128 rows x 128 channels (waves of 128 rows x 32 channels, the NH = 2 loop) - the tile's rows
+  // are staged once per 128 channels and every weight fragment serves 8 chunks
+  const bool wide_wg = a.cout % 128 == 0 && kn128.st128_wide != 0;
+  const int n_tiles = cdiv(a.n_out, 128), n_cg = a.cout / (wide_wg ? 128 : 64);
+  EYOC_REQUIRE(a.cout % 64 == 0 && n_cg >= 1 && n_cg <= 8 && 8 % n_cg == 0 && a.cin % 32 == 0, EYOC_ERR_INVALID, "spconv_st128: %d -> %d channels",
+               a.cin, a.cout);
+  const dim3 grid((unsigned)(cdiv(n_tiles, 8 / n_cg) * 8)), block(NW * 64);
+  if (wide_wg) {
+    if (spconv_cc(a.cin, a.cout) == 64) hipLaunchKernelGGL((spconv_st_asm_kernel<64, 2, 1, NW, 128>), grid, block, 0, st, a, local_dev, n_tiles, 1, 0);
+    else hipLaunchKernelGGL((spconv_st_asm_kernel<32, 2, 1, NW, 128>), grid, block, 0, st, a, local_dev, n_tiles, 1, 0);
+    EYOC_CHECK_HIP(hipGetLastError());
+    return EYOC_OK;
+  }
+  const bool deep = knobs_of(a.ctx).st_variant == 4;
+#ifdef EYOC_ST_ABLATIONS       // timing-only (results are garbage): 16 no stage, 17 no epilogue, 23 nothing in the loop, 18 no MFMAs
+  const int v_ = knobs_of(a.ctx).st_variant;
+#define EYOC_ST128_ABL(SK_)                                                                                                         \
+  do {                                                                                                                              \
+    if (spconv_cc(a.cin, a.cout) == 64) hipLaunchKernelGGL((spconv_st_asm_kernel<64, 1, SK_, NW, 128>), grid, block, 0, st, a, local_dev, n_tiles, 1, 0); \
+    else hipLaunchKernelGGL((spconv_st_asm_kernel<32, 1, SK_, NW, 128>), grid, block, 0, st, a, local_dev, n_tiles, 1, 0);          \
+    EYOC_CHECK_HIP(hipGetLastError());                                                                                              \
+    return EYOC_OK;                                                                                                                 \
+  } while (0)
+  if (v_ == 16) EYOC_ST128_ABL(6);
+  if (v_ == 17) EYOC_ST128_ABL(7);
+  if (v_ == 23) EYOC_ST128_ABL(13);
+  if (v_ == 18) EYOC_ST128_ABL(8);
+#undef EYOC_ST128_ABL
+#endif
+  if (spconv_cc(a.cin, a.cout) == 64) {
+    if (deep) hipLaunchKernelGGL((spconv_st_asm_kernel<64, 1, 18, NW, 128>), grid, block, 0, st, a, local_dev, n_tiles, 1, 0);
+    else hipLaunchKernelGGL((spconv_st_asm_kernel<64, 1, 1, NW, 128>), grid, block, 0, st, a, local_dev, n_tiles, 1, 0);
+  } else {
+    if (deep) hipLaunchKernelGGL((spconv_st_asm_kernel<32, 1, 18, NW, 128>), grid, block, 0, st, a, local_dev, n_tiles, 1, 0);
+    else hipLaunchKernelGGL((spconv_st_asm_kernel<32, 1, 1, NW, 128>), grid, block, 0, st, a, local_dev, n_tiles, 1, 0);
+  }
+  EYOC_CHECK_HIP(hipGetLastError());
+  return EYOC_OK;
+}
+
+size_t local_rulebook128_bytes(int n_out) { return (size_t)cdiv(n_out, 128) * LR_BYTES; }
+
+int build_local_rulebook128(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st, int group) {
+  if (n_out <= 0) return EYOC_OK;
+  hipLaunchKernelGGL((k_local_rulebook<false, 2>), dim3(cdiv(n_out, 128)), dim3(128), 0, st, nbr_dev, K, n_out, out_dev, overflow_dev, group, DeriveSrc());
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;
 }

@@ -124,6 +124,9 @@ int eyoc_maps_internal_order(eyoc_ctx* ctx, int mode);
  * eyoc_maps_table / _copy_table / _info, by a forward whose layer runs a gathering kernel, by a build whose records overflowed - so
  * nothing a caller can observe changes.  eyoc_maps_lazy_tables(ctx, 0) builds every table eagerly again; returns the previous setting. */
 int eyoc_maps_lazy_tables(eyoc_ctx* ctx, int on);
+/* Strided convolutions of a split16 forward on Z-ordered maps of >= eyoc_spconv_upc_min_rows rows: 1 (default, round 6) the staged kernel
+ * on 128-row output tiles (tile records built by eyoc_maps_build), 0 the gathering kernel; returns the previous setting. */
+int eyoc_spconv_select_down_kernel(eyoc_ctx* ctx, int mode);
 const int32_t* eyoc_maps_row_order(const eyoc_maps* maps);
 /* stream-ordered copy of the same array (the identity when the caller's order was kept); out_dev: int32 [rows[0]] */
 int eyoc_maps_copy_row_order(const eyoc_maps* maps, int32_t* out_dev, void* stream);

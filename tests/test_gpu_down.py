@@ -1,0 +1,64 @@
+"""Strided convolutions (model/resunet.py:44-77: conv2 / conv3 / conv4, kernel 3, stride 2) through the staged kernel on 128-row output
+tiles (round 6; spconv_st.hip ``launch_spconv_st128``, records from ``k_local_rulebook<.., 2>`` on the strided tables) against the
+gathering kernel they replace and, through the whole forward, against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def batches_take_the_batch_kernels():
+    """class-major transposed records, lazy tables and the staged strided kernel start at 2^17 rows in production: lowered so that a
+    two-cloud batch (62 k rows) runs them"""
+    from eyoc_amd import _lib
+    prev = _lib.knob("eyoc_spconv_upc_min_rows", 8192)
+    yield
+    _lib.knob("eyoc_spconv_upc_min_rows", prev)
+    _lib.knob("eyoc_spconv_select_down_kernel", 1)
+
+
+def _forward(model, coords, feats):
+    import eyoc_amd
+    x = eyoc_amd.SparseTensor(torch.from_numpy(feats).cuda(), coordinates=torch.from_numpy(coords).cuda())
+    return model(x).F.clone()
+
+
+@pytest.mark.parametrize("seed", [2, 7])
+def test_staged_strided_layers_equal_the_gathering_kernel_and_the_oracle(batches_take_the_batch_kernels, seed):
+    from eyoc_amd import _lib, synthetic as syn
+    from test_gpu_round2 import _model
+    p = syn.make_pair(seed)
+    coords = syn.batch_coords([p["coords0"], p["coords1"]])
+    feats = np.random.default_rng(seed).uniform(0.5, 1.5, size=(len(coords), 1)).astype(np.float32)
+    model, sd = _model()
+    assert _lib.knob("eyoc_spconv_select_down_kernel", -7) == 1          # the default
+    f_staged = _forward(model, coords, feats)
+    _lib.knob("eyoc_spconv_select_down_kernel", 0)
+    f_gather = _forward(model, coords, feats)
+    _lib.knob("eyoc_spconv_select_down_kernel", 1)
+    assert not torch.equal(f_staged, f_gather), "both runs took the same kernel - the switch did nothing"
+    # same products, another summation order (32-channel blocks outside the offsets instead of inside): fp32 rounding only
+    assert float((f_staged - f_gather).abs().max()) < 2e-5
+    assert torch.equal(f_staged, _forward(model, coords, feats))        # reproducible
+    from oracle import resunet as orr
+    want = np.asarray(orr.resunet_forward(sd, coords, feats))
+    err = np.abs(f_staged.cpu().numpy() - want).max()
+    assert err <= 1e-4 * np.abs(want).max(), err
+
+
+def test_a_cloud_in_no_spatial_order_falls_back(batches_take_the_batch_kernels):
+    """Rows in random positions: a 128-row coarse tile then reads more distinct fine rows than two stage passes hold (or its hash
+    fills up) - the table keeps the gathering kernel, and the forward still matches the oracle."""
+    from test_gpu_round2 import _model
+    from oracle import resunet as orr
+    rng = np.random.default_rng(0)
+    c = np.unique(rng.integers(0, 30, size=(24000, 3)), axis=0).astype(np.int32)       # a dense 30^3 box: every coarse row has ~27 fine neighbours
+    from eyoc_amd import synthetic as syn
+    coords = syn.batch_coords([c])
+    feats = rng.uniform(0.5, 1.5, size=(len(coords), 1)).astype(np.float32)
+    model, sd = _model()
+    f = _forward(model, coords, feats).cpu().numpy()
+    want = np.asarray(orr.resunet_forward(sd, coords, feats))
+    assert np.abs(f - want).max() <= 1e-4 * np.abs(want).max()
