@@ -93,7 +93,7 @@ struct eyoc_ctx {
     int maps_internal_order = -1;      // eyoc_maps_internal_order: -1 automatic (Z-order from 8192 rows), 0 caller's order, 1 Z-order
     int maps_lazy_tables = 1;          // eyoc_maps_lazy_tables: big Z-ordered batches skip the tables only their record builders read (coordmap.hip)
     int knn_prefilter = 1;             // eyoc_knn_prefilter
-    int fuse_tail = 1;                 // eyoc_model_fuse_tail: the two 1x1 layers at the end of a split16 forward in one kernel (spconv_tail.hip)
+    int fuse_tail = 2;                 // eyoc_model_fuse_tail: 2 the 1x1 tail in the epilogue of the last staged layer where that layer allows it (spconv_st.hip TAILF), 1 in one kernel of its own (spconv_tail.hip), 0 two launches
     int spconv_kernel = -1;            // eyoc_spconv_select_kernel: -1 automatic, 0 workgroup-tiled, 1 wave-private
     int split16_kernel = 1;            // eyoc_spconv_select_split16_kernel: 1 per layer, 0 always the wave-private kernel, 2 always the row-stationary one
     int up_kernel = 2;                 // eyoc_spconv_select_up_kernel: 0 gathering kernels, 1 spconv_up.hip (Morton tiles), 2 spconv_upc.hip (class-major tiles)

@@ -260,6 +260,8 @@ def main(path):
         write_blob(f, "NH2", gen(2, WD2, LD2))
         write_blob(f, "NH1", gen(1, 2, 2))
         write_blob(f, "NH1_DEEP", gen(1, 3, 5, lowl=True))      # clobbers v[96:127] on top (EYOC_ST_LOOP_CLOBBERS_NH1)
+        write_blob(f, "NH1_LAZY", gen(1, 2, 2, lazy=True))      # operand reads for non-empty blocks only (the NH = 1 loops are LDS-read bound)
+        write_blob(f, "NH1_DEEP_LAZY", gen(1, 3, 5, lowl=True, lazy=True))
         write_blob(f, "NH2_NOSKIP", gen(2, WD2, LD2, skip=False))
         # spconv_upc.hip: the offsets of ONE parity class of a transposed (stride 2) table - 1, 2, 4 or 8 of them, %[nk] says how
         # many.  One statement with a scalar dispatch in front (four statements in an if-chain made the compiler shuffle the
@@ -278,6 +280,9 @@ def main(path):
         write_blob(f, "UPC_EMPTY", gen_upc(("nom", "now", "nol", "nox", "nov")))
         write_blob(f, "NH1_EMPTY", gen(1, 2, 2, True, ("nom", "now", "nol", "nox", "nov")))   # round 6: what a 128-row strided tile costs around its loop
         write_blob(f, "NH1_NOM", gen(1, 2, 2, True, ("nom",)))
+        write_blob(f, "NH1_NOMW", gen(1, 2, 2, True, ("nom", "now")))
+        write_blob(f, "NH1_NOMX", gen(1, 2, 2, True, ("nom", "nox", "nov")))
+        write_blob(f, "NH1_NOML", gen(1, 2, 2, True, ("nom", "nol")))
         write_blob(f, "NH2_W2L3", gen(2, 2, 3))       # weights two offsets ahead, rulebook entries three: no gain
         write_blob(f, "NH2_LAZY", gen(2, WD2, LD2, lazy=True))   # operand reads only for non-empty blocks (round 5): level on every layer
         f.write("#define EYOC_ST_LOOP_CLOBBERS_LOW EYOC_ST_LOOP_CLOBBERS, " + ", ".join(f'"v{i}"' for i in range(56, 62)) + "\n")

@@ -248,8 +248,8 @@ int eyoc_model_create(eyoc_ctx* ctx, const eyoc_model_desc* desc, const eyoc_lay
     }
   }
   {   // the SPLIT16 range-guard words (16 bytes; part of the handle like the timing events)
-    hipError_t e = hipMalloc((void**)&m->range, 16);
-    if (e == hipSuccess) e = hipMemset(m->range, 0, 16);
+    hipError_t e = hipMalloc((void**)&m->range, 32);                    // words 0..3 as documented; words 4, 5: overflow in the output of the layer that carries the fused tail / in that tail's intermediate
+    if (e == hipSuccess) e = hipMemset(m->range, 0, 32);
     if (e != hipSuccess) {
       set_error("eyoc_model_create: range-guard allocation failed: %s", hipGetErrorString(e));
       if (m->range) (void)hipFree(m->range);
@@ -272,7 +272,7 @@ int eyoc_model_destroy(eyoc_model* m) {
 int eyoc_model_fuse_tail(eyoc_ctx* ctx, int on) {
   if (!ctx) return -1;
   const int prev = ctx->knobs.fuse_tail;
-  if (on == 0 || on == 1) ctx->knobs.fuse_tail = on;
+  if (on >= 0 && on <= 2) ctx->knobs.fuse_tail = on;
   return prev;
 }
 
@@ -394,6 +394,7 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
   // overflow switched a model to fp32 MFMAs, eyoc_model_range_snapshot must not keep reporting the old verdict for forwards
   // that cannot overflow
   EYOC_CHECK_HIP(hipMemsetAsync(m->range, 0, 4, st));
+  EYOC_CHECK_HIP(hipMemsetAsync(m->range + 4, 0, 8, st));             // words 4, 5: the fused tail's own verdicts (spconv_st.hip TAILF)
   hipEvent_t* ev = m->timing ? m->events.data() + (size_t)m->slot * (m->layers.size() + 1) : nullptr;
   if (m->timing) EYOC_CHECK_HIP(hipEventRecord(ev[0], st));
   bool progress_recorded = m->progress_event == nullptr;
@@ -435,7 +436,7 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
       a.local1 = maps->row_perm ? maps->local_s1[1] : nullptr;          // Z-ordered maps: the level-1 tile rulebooks (256-parent tiles)
       rc = conv1_walks_octree(a) ? EYOC_OK : maps_build_table0(const_cast<eyoc_maps*>(maps), st);
       if (!rc) rc = launch_conv1(a, st);
-    } else if (split && ctx->knobs.fuse_tail && li + 2 == m->layers.size() && p.map == M_IDENT && p.K == 1 && p.res_buf < 0 &&
+    } else if (split && ctx->knobs.fuse_tail != 0 && li + 2 == m->layers.size() && p.map == M_IDENT && p.K == 1 && p.res_buf < 0 &&
                m->layers[li + 1].map == M_IDENT && m->layers[li + 1].K == 1 && m->layers[li + 1].in_buf == p.out_buf &&
                m->layers[li + 1].res_buf < 0 && !m->layers[li + 1].relu && m->layers[li + 1].out_buf == B_OUT && p.out_col == 0 &&
                tail_fusable(p.cin, p.cout, m->layers[li + 1].cout)) {
@@ -481,6 +482,25 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
         if ((rc = maps_ensure_table(const_cast<eyoc_maps*>(maps), p.map == M_S1 ? EYOC_MAP_S1 : EYOC_MAP_UP, p.level, st))) return rc;
       a.perm = p.map == M_UP ? maps->perm_up[p.level] : p.map == M_S1 ? maps->perm_s1[p.level]
                : p.map == M_DOWN ? maps->perm_down[p.level] : nullptr;
+      // the 1x1 tail in the epilogue of the last staged layer (eyoc_model_fuse_tail 2, the default): block2_tr.conv2 writes the 64
+      // decoder channels the tail reads next to the 32 skip channels - with the tail riding in its epilogue they never reach memory
+      if (split && ctx->knobs.fuse_tail == 2 && li + 3 == m->layers.size() && p.map == M_S1 && p.cout == 64) {
+        const LayerPlan &q1 = m->layers[li + 1], &q2 = m->layers[li + 2];
+        if (q1.map == M_IDENT && q1.K == 1 && q1.res_buf < 0 && q2.map == M_IDENT && q2.K == 1 && q2.in_buf == q1.out_buf && q2.res_buf < 0 &&
+            !q2.relu && q2.out_buf == B_OUT && q1.out_col == 0 && tail_fusable(q1.cin, q1.cout, q2.cout) && q1.in_buf == p.out_buf &&
+            q1.in_col == p.out_col && q1.cin == p.cout + 32 && spconv_record_path(a) == 1 && spconv_st_can_fuse_tail(a)) {
+          a.tail.skip = buf[q1.in_buf] + q1.in_col + p.cout; a.tail.ld_skip = m->bufs[q1.in_buf].width;
+          a.tail.w1 = m->blob + q1.w16_off; a.tail.s1 = m->blob + q1.s_off; a.tail.b1 = m->blob + q1.b_off; a.tail.relu1 = q1.relu;
+          a.tail.w2 = m->blob + q2.w16_off; a.tail.s2 = m->blob + q2.s_off; a.tail.b2 = m->blob + q2.b_off; a.tail.l2norm = q2.l2norm;
+          a.tail.out = buf[q2.out_buf] + q2.out_col; a.tail.ld_out = m->bufs[q2.out_buf].width; a.tail.out_perm = maps->row_perm;
+          rc = launch_spconv(a, st);
+          if (rc) return rc;
+          if (m->timing)                                                  // the three layers' time is booked on the first one
+            for (int e = 1; e <= 3; ++e) EYOC_CHECK_HIP(hipEventRecord(ev[li + e], st));
+          li += 2;
+          continue;
+        }
+      }
       rc = launch_spconv(a, st);
     }
     if (rc) return rc;

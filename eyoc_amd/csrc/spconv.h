@@ -8,6 +8,19 @@ inline int spconv_ct(int cout) { return cout >= 128 ? 128 : cout; }  // output c
 // input channels per staged item: 64 whenever C_in allows it (half as many barriers), else 32
 inline int spconv_cc(int cin, int /*cout*/) { return cin % 64 == 0 ? 64 : 32; }
 
+// The network's 1x1 tail fused behind a 64-channel staged layer (spconv_st.hip, TAILF): conv1_tr (1x1, [that layer's 64 channels | 32
+// skip channels] -> 64, optional ReLU) + final (64 -> 32, bias folded into b2) + optional row normalisation; pointers as
+// launch_tail_fused takes them.  out == NULL: no fused tail.
+struct TailFuse {
+  const float* skip = nullptr;   // SPLIT16 rows holding the 32 skip channels in their first block (the cat buffer at column 64)
+  int ld_skip = 0;
+  const float *w1 = nullptr, *s1 = nullptr, *b1 = nullptr, *w2 = nullptr, *s2 = nullptr, *b2 = nullptr;
+  int relu1 = 0, l2norm = 0;
+  float* out = nullptr;          // [n_out, ld_out] fp32: the network's output
+  int ld_out = 0;
+  const int32_t* out_perm = nullptr;
+};
+
 struct SpconvArgs {
   const int32_t* nbr;   // [K][n_out] or NULL (identity, K == 1)
   int K, n_out;
@@ -52,6 +65,7 @@ struct SpconvArgs {
   // then depends on the problem size - training layers, where no other kernel has to give the same bits)
   int allow_offset_split = 0, offset_split = 1;
   float* offset_part = nullptr;
+  TailFuse tail;                   // staged stride-1 kernel only (spconv_st_can_fuse_tail): this layer's output goes straight into the 1x1 tail
 };
 constexpr int KS_MAX_SLOTS = 1024;                        // (workgroups x splits) a split launch may use: 32 KB of partial sums each
 constexpr size_t KS_PART_BYTES = (size_t)KS_MAX_SLOTS * 256 * 32 * 4;
@@ -151,6 +165,7 @@ int launch_permute_rows(const float* in, const int32_t* perm, int n, int c, floa
 int launch_spconv_st(const SpconvArgs& a, const unsigned char* local_dev, hipStream_t st);   // tile-local input stage (spconv_st.hip)
 int launch_spconv_up(const SpconvArgs& a, const unsigned char* local_dev, hipStream_t st);   // transposed 3^3 / stride 2 (spconv_up.hip)
 size_t local_rulebook_up_bytes(int n_out);
+bool spconv_st_can_fuse_tail(const SpconvArgs& a);   // spconv_st.hip: would launch_spconv_st run the 256-row NH = 2 assembly kernel on this (64-channel) layer
 int spconv_record_path(const SpconvArgs& a);   // spconv.hip: 1 / 2 / 3 = a tile-record kernel takes the layer (a.nbr is not read), 0 = a gathering kernel
 int build_local_rulebook_up(const int32_t* nbr_dev, int K, int n_out, unsigned char* out_dev, int* overflow_dev, hipStream_t st);
 // class-major transposed kernel (spconv_upc.hip): `ws` = upc_kept_bytes of header + tile order + records, built by build_upc

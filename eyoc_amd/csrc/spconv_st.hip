@@ -509,10 +509,13 @@ typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
 // write-back and invalidate per workgroup on gfx950 - made a single pair 1 ms SLOWER.)
 // TR = 128 (round 6, the strided tables; NH = 1, 4 waves): the tile is 128 output rows x 64 channels - waves = 2 row quarters x 2 channel
 // halves of 64 rows x 32 channels, records from k_local_rulebook<.., 2> (same layout; quarters 2 and 3 do not exist).
-template <int CC, int NH, int SKIP, int NWV = NW, int TR = TILE>
+// TAILF = 1 (round 6; NH = 2, 256-row tiles, a 64-channel layer): the network's 1x1 tail (spconv_tail.hip: conv1_tr -> ReLU -> final -> row
+// normalisation) runs in this kernel's epilogue on the tile's rows - see the epilogue.
+template <int CC, int NH, int SKIP, int NWV = NW, int TR = TILE, int TAILF = 0>
 __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(SpconvArgs a, const unsigned char* __restrict__ local, int n_tiles, int ksplit, int phase) {
   constexpr int NTW = 2, CTW = NTW * 16, NC = 4;
   constexpr bool T128 = TR == 128;
+  static_assert(TAILF == 0 || (NH == 2 && TR == TILE && NWV == NW && SKIP == 1), "the fused tail rides on the 256-row NH = 2 kernel");
   constexpr int CTG = T128 ? (NH == 2 ? 4 * CTW : 2 * CTW) : CTW * NH * (NWV / NW);   // NWV = 8: 4 row quarters x 2 channel halves, NH = 1
   constexpr int NITV = XROWS / (16 * NWV);
   static_assert(NWV == NW || (NWV == 2 * NW && NH == 1), "8 waves: 64 rows x 32 channels each");
@@ -663,9 +666,21 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
 #ifdef EYOC_ST_ABLATIONS
       else if constexpr (NH == 1 && SKIP == 13)
         asm volatile(EYOC_ST_LOOP_NH1_EMPTY : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), [so] "=&s"(so) : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS);
+      else if constexpr (NH == 1 && SKIP == 9)
+        asm volatile(EYOC_ST_LOOP_NH1_NOMW : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), [so] "=&s"(so) : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS);
+      else if constexpr (NH == 1 && SKIP == 10)
+        asm volatile(EYOC_ST_LOOP_NH1_NOMX : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), [so] "=&s"(so) : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS);
+      else if constexpr (NH == 1 && SKIP == 11)
+        asm volatile(EYOC_ST_LOOP_NH1_NOML : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), [so] "=&s"(so) : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS);
       else if constexpr (NH == 1 && SKIP == 8)
         asm volatile(EYOC_ST_LOOP_NH1_NOM : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), [so] "=&s"(so) : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS);
 #endif
+      else if constexpr (SKIP == 19)       // NH = 1, operand reads for non-empty blocks only
+        asm volatile(EYOC_ST_LOOP_NH1_LAZY : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), [so] "=&s"(so)
+                     : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS);
+      else if constexpr (SKIP == 20)       // ... with the deeper prefetch as well
+        asm volatile(EYOC_ST_LOOP_NH1_DEEP_LAZY : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), [so] "=&s"(so)
+                     : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS_NH1);
       else if constexpr (SKIP == 18)       // NH = 1 with weights three offsets ahead and rulebook entries five (round 6)
         asm volatile(EYOC_ST_LOOP_NH1_DEEP : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), [so] "=&s"(so)
                      : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS_NH1);
@@ -762,6 +777,164 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
       if (o < a.n_out) split16_track(mx, v[hc][t]);
     }
   }
+  if constexpr (TAILF != 0) {
+    // ---- the network's 1x1 tail on this tile's rows (model/resunet.py:183-191; the arithmetic of spconv_tail.hip, bit for bit):
+    //   out = normalise(final(relu(conv1_tr([this layer's 64 channels | 32 skip channels]))))
+    // Lane (g, j) holds, for each of its wave's 8 row groups, channels ct0 + 8 g .. + 7 of row j - encoded, that IS the MFMA operand
+    // piece of input block cc = (wave & 1) of conv1_tr (16 bytes of hi halves, 16 of lo halves of 8 channels).  The other 32 decoder
+    // channels of the same rows are in the partner wave (wave ^ 1): the two swap halves through the (now idle) stage - wave 2 q takes
+    // the row groups of h = 0, wave 2 q + 1 those of h = 1, each 4 chunks of 16 rows with all 96 input channels - and the skip
+    // channels come from memory.  The layer's 64-channel output is never written: 512 bytes per row less HBM traffic than the
+    // separate tail kernel (256 written, 256 read back), 1.96 GB on the 3.8 M-row bench batch.
+    const TailFuse& tf = a.tail;
+    const bool odd = (wave & 1) != 0;
+    uint4 Xh[NG], Xl[NG];
+#pragma unroll
+    for (int hc = 0; hc < NG; ++hc) {
+      uint2 h0, l0, h1, l1;
+      split16_encode4(v[hc][0], h0, l0);
+      split16_encode4(v[hc][1], h1, l1);
+      Xh[hc] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+      Xl[hc] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+    auto sel4 = [](bool c, const uint4 x, const uint4 y) { return make_uint4(c ? x.x : y.x, c ? x.y : y.y, c ? x.z : y.z, c ? x.w : y.w); };
+    constexpr int NK = NG / 2;                                           // my 4 chunks: row groups odd * 4 + k
+    int myrow[NK];
+    uint4 Oh[NK], Ol[NK], Sh[NK], Sl[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      myrow[k] = odd ? orow[NK + k] : orow[k];
+      Oh[k] = sel4(odd, Xh[NK + k], Xh[k]);
+      Ol[k] = sel4(odd, Xl[NK + k], Xl[k]);
+      const int o = myrow[k] < a.n_out ? myrow[k] : a.n_out - 1;         // ragged tile: a valid row, never stored
+      const char* sp = reinterpret_cast<const char*>(tf.skip + (size_t)o * tf.ld_skip) + g * 16;
+      Sh[k] = *reinterpret_cast<const uint4*>(sp);
+      Sl[k] = *reinterpret_cast<const uint4*>(sp + SPLIT16_LO);
+    }
+    lds_barrier();                                                       // every wave has left its offset loop: the stage is free
+    unsigned char* xw = xs + (size_t)(wave * NK) * 2048 + lane * 16;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {                                       // the partner's chunks go out
+      *reinterpret_cast<uint4*>(xw + k * 2048) = sel4(odd, Xh[k], Xh[NK + k]);
+      *reinterpret_cast<uint4*>(xw + k * 2048 + 1024) = sel4(odd, Xl[k], Xl[NK + k]);
+    }
+    lds_barrier();
+    const unsigned char* xr = xs + (size_t)((wave ^ 1) * NK) * 2048 + lane * 16;
+    uint4 Ph[NK], Pl[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      Ph[k] = *reinterpret_cast<const uint4*>(xr + k * 2048);
+      Pl[k] = *reinterpret_cast<const uint4*>(xr + k * 2048 + 1024);
+    }
+    // conv1_tr: input blocks in the order 0, 1, 2 (decoder channels 0..31, 32..63, skip), the three split16 terms inside - the
+    // summation order of tail_fused_kernel.  One block's weight fragments at a time (32 registers), four chunks of accumulators.
+    f32x4 acc1[NK][4];
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc1[k][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      half8_t Wc[4][2];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          Wc[nt][p] = *reinterpret_cast<const half8_t*>(reinterpret_cast<const char*>(tf.w1) + ((cc * 4 + nt) * 2 + p) * 1024 + lane * 16);
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const bool mine = cc == (odd ? 1 : 0);
+        const uint4 xh = cc == 2 ? Sh[k] : sel4(mine, Oh[k], Ph[k]), xl = cc == 2 ? Sl[k] : sel4(mine, Ol[k], Pl[k]);
+        const half8_t X0 = __builtin_bit_cast(half8_t, xh), X1 = __builtin_bit_cast(half8_t, xl);
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc1[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc[t][term == 2 ? 1 : 0], term == 1 ? X1 : X0, acc1[k][t], 0, 0, 0);
+      }
+    }
+    // final: the lane's 16 intermediate values are its K elements of the second product (spconv_tail.hip has the index algebra)
+    half8_t W2[2][2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const char* f = reinterpret_cast<const char*>(tf.w2) + (nt * 4 + 2 * kb + p) * 1024 + (((g >> 1) * 16 + j) * 16) + 8 * (g & 1);
+          const uint2 lo = *reinterpret_cast<const uint2*>(f), hi = *reinterpret_cast<const uint2*>(f + 512);
+          W2[nt][kb][p] = __builtin_bit_cast(half8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        }
+    const float os1 = *tf.s1, os2 = *tf.s2;
+    float4 b1[4], b2[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b1[t] = *reinterpret_cast<const float4*>(tf.b1 + 16 * t + 4 * g);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) b2[t] = *reinterpret_cast<const float4*>(tf.b2 + 16 * t + 4 * g);
+    // range guard: an overflow in a layer upstream (all finished: word 0) poisons every row; one in THIS layer's 64-channel output -
+    // which other workgroups may still be computing - raises word 4, and the launcher's k_tail_poison answers for it after the
+    // kernel; one in the tail's own intermediate poisons the row it happened in (as in tail_fused_kernel) and raises word 5.  Neither
+    // touches word 0 while the kernel runs (a later workgroup would take it for an upstream overflow): k_tail_poison folds them in
+    const bool poisoned = split16_poisoned(a.range) || split16_over(mx);
+    const float qnan = __builtin_nanf("");
+    float mx2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      half8_t Y[2][2];
+      float cmx = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float4 u = make_float4(acc1[k][t][0] * os1 + b1[t].x, acc1[k][t][1] * os1 + b1[t].y, acc1[k][t][2] * os1 + b1[t].z, acc1[k][t][3] * os1 + b1[t].w);
+        if (tf.relu1) { u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f); }
+        split16_track(cmx, u);
+        uint2 h, l;
+        split16_encode4(u, h, l);
+        const half4_t h4 = __builtin_bit_cast(half4_t, h), l4 = __builtin_bit_cast(half4_t, l);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { Y[t >> 1][0][4 * (t & 1) + r] = h4[r]; Y[t >> 1][1][4 * (t & 1) + r] = l4[r]; }
+      }
+      f32x4 o2[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) o2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            o2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[t][kb][term == 2 ? 1 : 0], Y[kb][term == 1 ? 1 : 0], o2[t], 0, 0, 0);
+      float4 w[2];
+      float ss = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        w[t] = make_float4(o2[t][0] * os2 + b2[t].x, o2[t][1] * os2 + b2[t].y, o2[t][2] * os2 + b2[t].z, o2[t][3] * os2 + b2[t].w);
+        ss += w[t].x * w[t].x + w[t].y * w[t].y + w[t].z * w[t].z + w[t].w * w[t].w;
+      }
+      if (tf.l2norm) {                                                   // the row's 32 channels: this lane and lanes j + 16, 32, 48
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float inv = 1.0f / sqrtf(ss);                              // no epsilon: a zero row gives NaN (0 * inf), like the reference
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { w[t].x *= inv; w[t].y *= inv; w[t].z *= inv; w[t].w *= inv; }
+      }
+      if (myrow[k] < a.n_out) mx2 = split16_merge(mx2, cmx);
+      cmx = split16_merge(cmx, __shfl_xor(cmx, 16, 64));
+      cmx = split16_merge(cmx, __shfl_xor(cmx, 32, 64));
+      const bool bad = poisoned || split16_over(cmx);
+      if (myrow[k] < a.n_out) {
+        const size_t oo = tf.out_perm ? (size_t)tf.out_perm[myrow[k]] : (size_t)myrow[k];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          *reinterpret_cast<float4*>(tf.out + oo * tf.ld_out + 16 * t + 4 * g) = bad ? make_float4(qnan, qnan, qnan, qnan) : w[t];
+      }
+    }
+    if (a.range) {
+      if (split16_over(mx)) { atomicOr(a.range + 4, 1u); atomicOr(a.range + 3, 1u); }
+      if (split16_over(mx2)) { atomicOr(a.range + 5, 1u); atomicOr(a.range + 3, 1u); }
+      if (__builtin_nontemporal_load(a.range + 2)) atomicMax(a.range + 1, __float_as_uint(split16_merge(mx, mx2)) & 0x7FFFFFFFu);   // probe mode only
+    }
+    return;
+  }
 #pragma unroll
   for (int hc = 0; hc < NG; ++hc) {
     const int o = orow[hc];
@@ -835,9 +1008,35 @@ int build_local_rulebook_derived(const DeriveSrc& src, int n_out, unsigned char*
 #ifdef EYOC_ST_ABLATIONS
 constexpr int ST_VARIANTS = 28;
 #else
-constexpr int ST_VARIANTS = 5;      // 4 = variant 1 with the deep-prefetch loop in the NH = 1 kernels (32-channel layers, 128-row strided tiles)
+// 64-row waves (NH = 1: 32-channel layers, 128-row strided tiles of 64-channel layers): 1 (default, round 6) weights three offsets ahead
+// and rulebook entries five - an offset of 4 chunks lasts ~300 cycles, "two ahead" is less than an L2 round trip: 0.56 -> 0.54, 0.61 -> 0.58,
+// 0.52 -> 0.51 ms on the bench's three such layers; 4 = the round-5 loop (two ahead); 5 / 6 = operand reads for non-empty blocks only,
+// without / with the deeper prefetch: level (the NH = 1 loops are not bound by LDS reads either)
+constexpr int ST_VARIANTS = 7;      // 4 = variant 1 with the deep-prefetch loop in the NH = 1 kernels (32-channel layers, 128-row strided tiles)
 #endif
 int st_variants() { return ST_VARIANTS; }
+
+// the 1x1 tail can ride in the epilogue of a layer that launch_spconv_st runs as 256 rows x 64 channels per workgroup on the default
+// assembly loop (NH = 2): a 64-channel stride-1 layer of a batch (small inputs take 32-channel workgroups)
+bool spconv_st_can_fuse_tail(const SpconvArgs& a) {
+  if (a.math != 1 || !a.local || a.l2norm || a.K != 27 || a.cout != 64 || a.cin % 32 != 0 || !a.out_split || a.out_perm) return false;
+  const eyoc_ctx::Knobs& kn = knobs_of(a.ctx);
+  const int v = kn.st_variant;
+  if (!(v == 1 || v == 4 || v == 5 || v == 6)) return false;           // the NH = 2 loop of these variants is the default one
+  const int n_tiles = cdiv(a.n_out, TILE);
+  return !((long long)n_tiles * (a.cout / 64) < kn.st_split_below);
+}
+
+// after a kernel with a fused tail: an overflow in that layer's own 64-channel output (range word 4; workgroups that finished before
+// it was seen wrote clean rows) turns the whole output into NaN rows, as the separate tail kernel's `poisoned` did
+__global__ __launch_bounds__(256) void k_tail_poison(unsigned int* __restrict__ range, float* __restrict__ out, int n, int ld, int c) {
+  const unsigned int stored = __builtin_nontemporal_load(range + 4), inter = __builtin_nontemporal_load(range + 5);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (stored | inter)) atomicOr(range, 1u);   // the forward's own flag (word 0), now that no workgroup reads it any more
+  if (stored == 0u) return;
+  const float qnan = __builtin_nanf("");
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (long long)n * c; i += (long long)gridDim.x * 256)
+    out[(i / c) * ld + i % c] = qnan;
+}
 
 // stride-1 SPLIT16 layers whose table has a local rulebook (rows in natural = Morton order, no tiling permutation)
 int launch_spconv_st(const SpconvArgs& a_in, const unsigned char* local_dev, hipStream_t st) {
@@ -907,9 +1106,17 @@ int launch_spconv_st(const SpconvArgs& a_in, const unsigned char* local_dev, hip
       else if (variant == 26) EYOC_STA(64, 2, 16);
       else if (variant == 27) EYOC_STA(64, 2, 17);
 #endif
+      else if (a.tail.out) {                                             // the 1x1 tail in the epilogue (spconv_st_can_fuse_tail said yes)
+        EYOC_REQUIRE(spconv_st_can_fuse_tail(a) && a.range, EYOC_ERR_INVALID, "spconv_st: this layer cannot carry the fused tail");
+        if (wide) hipLaunchKernelGGL((spconv_st_asm_kernel<64, 2, 1, NW, TILE, 1>), grid, block, 0, st, a, local_dev, n_tiles, 1, 0);
+        else hipLaunchKernelGGL((spconv_st_asm_kernel<32, 2, 1, NW, TILE, 1>), grid, block, 0, st, a, local_dev, n_tiles, 1, 0);
+        hipLaunchKernelGGL(k_tail_poison, dim3(256), dim3(256), 0, st, a.range, a.tail.out, a.n_out, a.tail.ld_out, 32);
+      }
       else { if (wide) EYOC_STA(64, 2, 1); else EYOC_STA(32, 2, 1); }
-    } else if (variant == 4) { if (wide) EYOC_STA(64, 1, 18); else EYOC_STA(32, 1, 18); }
-    else { if (wide) EYOC_STA(64, 1, 1); else EYOC_STA(32, 1, 1); }
+    } else if (variant == 4) { if (wide) EYOC_STA(64, 1, 1); else EYOC_STA(32, 1, 1); }
+    else if (variant == 5) { if (wide) EYOC_STA(64, 1, 19); else EYOC_STA(32, 1, 19); }
+    else if (variant == 6) { if (wide) EYOC_STA(64, 1, 20); else EYOC_STA(32, 1, 20); }
+    else { if (wide) EYOC_STA(64, 1, 18); else EYOC_STA(32, 1, 18); }
 #undef EYOC_STA
   }
   EYOC_CHECK_HIP(hipGetLastError());
@@ -934,7 +1141,8 @@ int launch_spconv_st128(const SpconvArgs& a, const unsigned char* local_dev, hip
     EYOC_CHECK_HIP(hipGetLastError());
     return EYOC_OK;
   }
-  const bool deep = knobs_of(a.ctx).st_variant == 4;
+  const int nh1 = knobs_of(a.ctx).st_variant;   // 4 the round-5 loop (two offsets ahead), 5 lazy operand reads, 6 lazy + deep; else deep prefetch
+  const bool deep = nh1 != 4;
 #ifdef EYOC_ST_ABLATIONS       // timing-only (results are garbage): 16 no stage, 17 no epilogue, 23 nothing in the loop, 18 no MFMAs
   const int v_ = knobs_of(a.ctx).st_variant;
 #define EYOC_ST128_ABL(SK_)                                                                                                         \
@@ -948,8 +1156,22 @@ int launch_spconv_st128(const SpconvArgs& a, const unsigned char* local_dev, hip
   if (v_ == 17) EYOC_ST128_ABL(7);
   if (v_ == 23) EYOC_ST128_ABL(13);
   if (v_ == 18) EYOC_ST128_ABL(8);
+  if (v_ == 19) EYOC_ST128_ABL(9);
+  if (v_ == 20) EYOC_ST128_ABL(10);
+  if (v_ == 21) EYOC_ST128_ABL(11);
 #undef EYOC_ST128_ABL
 #endif
+  if (nh1 == 5 || nh1 == 6) {
+    if (spconv_cc(a.cin, a.cout) == 64) {
+      if (nh1 == 5) hipLaunchKernelGGL((spconv_st_asm_kernel<64, 1, 19, NW, 128>), grid, block, 0, st, a, local_dev, n_tiles, 1, 0);
+      else hipLaunchKernelGGL((spconv_st_asm_kernel<64, 1, 20, NW, 128>), grid, block, 0, st, a, local_dev, n_tiles, 1, 0);
+    } else {
+      if (nh1 == 5) hipLaunchKernelGGL((spconv_st_asm_kernel<32, 1, 19, NW, 128>), grid, block, 0, st, a, local_dev, n_tiles, 1, 0);
+      else hipLaunchKernelGGL((spconv_st_asm_kernel<32, 1, 20, NW, 128>), grid, block, 0, st, a, local_dev, n_tiles, 1, 0);
+    }
+    EYOC_CHECK_HIP(hipGetLastError());
+    return EYOC_OK;
+  }
   if (spconv_cc(a.cin, a.cout) == 64) {
     if (deep) hipLaunchKernelGGL((spconv_st_asm_kernel<64, 1, 18, NW, 128>), grid, block, 0, st, a, local_dev, n_tiles, 1, 0);
     else hipLaunchKernelGGL((spconv_st_asm_kernel<64, 1, 1, NW, 128>), grid, block, 0, st, a, local_dev, n_tiles, 1, 0);

@@ -317,8 +317,10 @@ int eyoc_model_create(eyoc_ctx* ctx, const eyoc_model_desc* desc, const eyoc_lay
                       int n_layers, float* blob_dev, size_t blob_floats, eyoc_model** out);
 int eyoc_model_destroy(eyoc_model* model);
 /* split16 forwards run the network's 1x1 tail (conv1_tr -> ReLU -> final + bias -> row normalisation, model/resunet.py:183-191)
- * as ONE kernel whose 64-channel intermediate never leaves the registers (spconv_tail.hip; BN2C's 96 -> 64 -> 32 widths):
- * 1 on (default), 0 = two launches; other values only query.  Returns the previous state; per ctx, for tests. */
+ * as ONE kernel whose 64-channel intermediate never leaves the registers (spconv_tail.hip; BN2C's 96 -> 64 -> 32 widths): mode 1;
+ * 2 (default since round 6) = in the epilogue of the last staged stride-1 layer (block2_tr.conv2 of a batch: its 64 output channels
+ * go straight into the tail's first product and never reach memory; bit-identical to mode 1), falling back to mode 1 where that
+ * layer does not run the 256-row staged kernel; 0 = two launches; other values only query.  Returns the previous state; per ctx. */
 int eyoc_model_fuse_tail(eyoc_ctx* ctx, int on);
 size_t eyoc_model_workspace_bytes(const eyoc_model* model, const eyoc_maps* maps);
 /* feats_dev f32 [N1, in_channels] -> out_dev f32 [N1, out_channels], rows in input order */

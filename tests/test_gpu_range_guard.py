@@ -109,8 +109,20 @@ def class_major(request):
     L.knob("eyoc_spconv_upc_min_rows", prev)
 
 
-@pytest.mark.parametrize("case,class_major", [(c, False) for c in CASES] + [("conv4_tr", True)], indirect=["class_major"])
-def test_overflow_in_one_layer_is_seen_reported_and_recovered_from(cloud, case, class_major):
+@pytest.fixture
+def tail_in_epilogue(request):
+    """True: 64-channel workgroups although the batch is small, so that block2_tr.conv2 carries the 1x1 tail in its epilogue (round 6,
+    eyoc_model_fuse_tail 2 = the default of large batches)."""
+    L, lib = _lib()
+    prev = L.knob("eyoc_spconv_st_split_below", 0 if request.param else 1024)
+    yield request.param
+    L.knob("eyoc_spconv_st_split_below", prev)
+
+
+@pytest.mark.parametrize("case,class_major,tail_in_epilogue",
+                         [(c, False, False) for c in CASES] + [("conv4_tr", True, False), ("block2_tr.conv2", False, True), ("conv1_tr", False, True)],
+                         indirect=["class_major", "tail_in_epilogue"])
+def test_overflow_in_one_layer_is_seen_reported_and_recovered_from(cloud, case, class_major, tail_in_epilogue):
     from oracle import resunet as orr
     L, lib = _lib()
     sd, where = doctor(cloud["sd"], cloud["base"], case)

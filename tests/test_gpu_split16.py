@@ -488,13 +488,21 @@ def test_fused_tail_matches_the_two_layer_tail_and_the_oracle(normalize):
     want = orr.resunet_forward(sd, coords, p["feats0"], normalize_feature=normalize).numpy()
     outs = {}
     prev = L.knob("eyoc_model_fuse_tail", -1)
+    prev_split = L.knob("eyoc_spconv_st_split_below", 0)        # 64-channel workgroups for this one cloud too: what carries the tail in mode 2
     try:
-        for fuse in (0, 1):
+        for fuse in (0, 1, 2):
             L.knob("eyoc_model_fuse_tail", fuse)
             outs[fuse] = _forward(model, coords, p["feats0"])
             assert model.last_spconv_math == "split16"
+        # mode 2 (round 6, the default): the tail in the epilogue of block2_tr.conv2 - the same products in the same order as the
+        # tail kernel of mode 1 (the layer's output is encoded to split16 in registers instead of being stored and re-read)
+        assert np.array_equal(outs[2], outs[1], equal_nan=True)
+        L.knob("eyoc_spconv_st_split_below", prev_split)
+        small = _forward(model, coords, p["feats0"])                   # 32-channel workgroups cannot carry it: mode 2 falls back to mode 1
+        assert np.abs(small - outs[1]).max() / np.abs(want).max() < 2e-6
     finally:
         L.knob("eyoc_model_fuse_tail", prev)
+        L.knob("eyoc_spconv_st_split_below", prev_split)
     scale = np.abs(want).max()
     e_fused, e_two = np.abs(outs[1] - want).max() / scale, np.abs(outs[0] - want).max() / scale
     d = np.abs(outs[1] - outs[0]).max() / scale
