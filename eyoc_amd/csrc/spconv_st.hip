@@ -811,6 +811,36 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
       Sh[k] = *reinterpret_cast<const uint4*>(sp);
       Sl[k] = *reinterpret_cast<const uint4*>(sp + SPLIT16_LO);
     }
+    // the tail's weights start their way from L2 before the exchange: the first input block's fragments of conv1_tr, all of final's
+    // (index algebra in spconv_tail.hip), shifts and scales - behind the barriers each would be a round trip of its own
+    auto load_w1 = [&](int cc, half8_t (&W)[4][2]) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          W[nt][p] = *reinterpret_cast<const half8_t*>(reinterpret_cast<const char*>(tf.w1) + ((cc * 4 + nt) * 2 + p) * 1024 + lane * 16);
+    };
+    half8_t Wc[2][4][2];
+    load_w1(0, Wc[0]);
+    half8_t W2[2][2][2];
+    auto load_w2 = [&]() {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const char* f = reinterpret_cast<const char*>(tf.w2) + (nt * 4 + 2 * kb + p) * 1024 + (((g >> 1) * 16 + j) * 16) + 8 * (g & 1);
+            const uint2 lo = *reinterpret_cast<const uint2*>(f), hi = *reinterpret_cast<const uint2*>(f + 512);
+            W2[nt][kb][p] = __builtin_bit_cast(half8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+          }
+    };
+    const float os1 = *tf.s1, os2 = *tf.s2;
+    float4 b1[4], b2[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b1[t] = *reinterpret_cast<const float4*>(tf.b1 + 16 * t + 4 * g);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) b2[t] = *reinterpret_cast<const float4*>(tf.b2 + 16 * t + 4 * g);
     lds_barrier();                                                       // every wave has left its offset loop: the stage is free
     unsigned char* xw = xs + (size_t)(wave * NK) * 2048 + lane * 16;
 #pragma unroll
@@ -835,12 +865,8 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
       for (int t = 0; t < 4; ++t) acc1[k][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int cc = 0; cc < 3; ++cc) {
-      half8_t Wc[4][2];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-          Wc[nt][p] = *reinterpret_cast<const half8_t*>(reinterpret_cast<const char*>(tf.w1) + ((cc * 4 + nt) * 2 + p) * 1024 + lane * 16);
+      if (cc < 2) load_w1(cc + 1, Wc[(cc + 1) & 1]);                     // the next block's fragments fly during this block's products
+      else load_w2();                                                    // ... and final's during the last block's
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
         const bool mine = cc == (odd ? 1 : 0);
@@ -850,27 +876,10 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
         for (int term = 0; term < 3; ++term)
 #pragma unroll
           for (int t = 0; t < 4; ++t)
-            acc1[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc[t][term == 2 ? 1 : 0], term == 1 ? X1 : X0, acc1[k][t], 0, 0, 0);
+            acc1[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc[cc & 1][t][term == 2 ? 1 : 0], term == 1 ? X1 : X0, acc1[k][t], 0, 0, 0);
       }
     }
-    // final: the lane's 16 intermediate values are its K elements of the second product (spconv_tail.hip has the index algebra)
-    half8_t W2[2][2][2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          const char* f = reinterpret_cast<const char*>(tf.w2) + (nt * 4 + 2 * kb + p) * 1024 + (((g >> 1) * 16 + j) * 16) + 8 * (g & 1);
-          const uint2 lo = *reinterpret_cast<const uint2*>(f), hi = *reinterpret_cast<const uint2*>(f + 512);
-          W2[nt][kb][p] = __builtin_bit_cast(half8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
-        }
-    const float os1 = *tf.s1, os2 = *tf.s2;
-    float4 b1[4], b2[2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) b1[t] = *reinterpret_cast<const float4*>(tf.b1 + 16 * t + 4 * g);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) b2[t] = *reinterpret_cast<const float4*>(tf.b2 + 16 * t + 4 * g);
+    // final: the lane's 16 intermediate values are its K elements of the second product
     // range guard: an overflow in a layer upstream (all finished: word 0) poisons every row; one in THIS layer's 64-channel output -
     // which other workgroups may still be computing - raises word 4, and the launcher's k_tail_poison answers for it after the
     // kernel; one in the tail's own intermediate poisons the row it happened in (as in tail_fused_kernel) and raises word 5.  Neither
