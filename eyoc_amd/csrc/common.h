@@ -97,6 +97,7 @@ struct eyoc_ctx {
     int spconv_kernel = -1;            // eyoc_spconv_select_kernel: -1 automatic, 0 workgroup-tiled, 1 wave-private
     int split16_kernel = 1;            // eyoc_spconv_select_split16_kernel: 1 per layer, 0 always the wave-private kernel, 2 always the row-stationary one
     int up_kernel = 2;                 // eyoc_spconv_select_up_kernel: 0 gathering kernels, 1 spconv_up.hip (Morton tiles), 2 spconv_upc.hip (class-major tiles)
+    int s1_wide = 1;                   // (diagnostics, eyoc_spconv_select_down_kernel(4 / 5)): stride-1 layers with >= 128 channels on 128-row x 128-channel workgroups
     int st128_wide = 1;                // (diagnostics, eyoc_spconv_select_down_kernel(2 / 3)): 128-row strided tiles of >= 128-channel layers as 128-channel workgroups
     int down_kernel = 1;               // eyoc_spconv_select_down_kernel: 1 staged on 128-row tiles (Z-ordered maps of >= upc_min_rows rows), 0 the gathering kernel
     int upc_min_rows = 1 << 17;        // eyoc_spconv_upc_min_rows: maps with fewer level-0 rows keep spconv_up.hip under mode 2
@@ -190,6 +191,7 @@ struct eyoc_maps {
   // per-tile local rulebooks of the stride-1 tables (spconv_st.hip), built when the rows are in Z-order; NULL otherwise
   unsigned char* local_s1[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
   unsigned char* local_up[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};   // transposed tables (outputs at level l)
+  unsigned char* local_s1w[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};   // stride-1 tables in 128-row tiles as well (levels whose layers have >= 128 channels: 128-row x 128-channel workgroups)
   unsigned char* local_down[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};  // strided tables (outputs at level l + 1) in 128-row tiles (spconv_st.hip launch_spconv_st128)
   unsigned char* local_upc[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};  // ... partitioned by parity class (spconv_upc.hip: header, tile order, records)
   bool table0_built = false;   // table[0] has its memory reserved but is only filled on demand (maps_build_table0)

@@ -525,7 +525,7 @@ size_t eyoc_maps_workspace_bytes(int n_rows) {
   b += 2 * align_up(local_rulebook_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_bytes(1)) + 256);   // stride-1 tables
   b += 2 * align_up(local_rulebook_up_bytes(n_rows)) + EYOC_MAX_LEVELS * (align_up(local_rulebook_up_bytes(1)) + 256);
   b += 2 * (align_up(upc_kept_bytes(n_rows)) + align_up(upc_scratch_bytes(n_rows))) + EYOC_MAX_LEVELS * (align_up(upc_kept_bytes(1)) + align_up(upc_scratch_bytes(1)) + 512);   // class-major transposed records + their builder's scratch
-  b += 3 * (align_up(local_rulebook128_bytes(n_rows)) + 256);        // strided tables in 128-row tiles (a level has at most n rows)
+  b += 4 * (align_up(local_rulebook128_bytes(n_rows)) + 256);        // strided tables (3) and the coarsest stride-1 table in 128-row tiles (a level has at most n rows)
   b += 4096;                                                         // counters
   return b + 96 * 256;
 }
@@ -838,6 +838,14 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
     }
     // strided tables (outputs = the rows of level l + 1) in 128-row tiles: batches only - a single pair's 97 level-1 tiles do not fill the chip
     const bool use_down = kn.down_kernel == 1 && n >= kn.upc_min_rows;
+    // the coarsest level's stride-1 table in 128-row tiles too: its layers have 256 channels, and a workgroup of 128 rows x 128 channels
+    // stages a tile's rows once per 128 output channels instead of once per 64 (block4: 0.89 -> 0.78 ms per layer on the bench batch; the
+    // 128-channel layers of level 2 measured level - 0.84 -> 0.83 - and keep the 256-row tiles)
+    for (int l = EYOC_MAX_LEVELS - 1; l < EYOC_MAX_LEVELS && use_down && kn.s1_wide; ++l) {
+      m->local_s1w[l] = cv.take<unsigned char>(local_rulebook128_bytes(m->rows[l]));
+      if (m->local_s1w[l])
+        if (int rc = build_local_rulebook128(m->nbr_s1[l], 27, m->rows[l], m->local_s1w[l], counters + 13, st, kn.st_group)) { delete m; return rc; }
+    }
     for (int l = 0; l + 1 < EYOC_MAX_LEVELS && use_down; ++l) {
       m->local_down[l] = cv.take<unsigned char>(local_rulebook128_bytes(m->rows[l + 1]));
       if (m->local_down[l])
@@ -874,6 +882,8 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
       for (int l = 0; l < EYOC_MAX_LEVELS; ++l) m->local_up[l] = nullptr;
     for (int l = 0; l + 1 < EYOC_MAX_LEVELS; ++l)   // a 128-row coarse tile with more than 1278 distinct fine rows: that strided table stays on the gathering kernel
       if (host[2 + l] != 0) m->local_down[l] = nullptr;
+    if (host[5] != 0)
+      for (int l = 0; l < EYOC_MAX_LEVELS; ++l) m->local_s1w[l] = nullptr;
     for (int l = 0; l < EYOC_MAX_LEVELS; ++l)   // a class tile with more than 1278 distinct coarse rows: that table stays on the gathering kernels
       if (host[16 + l] != 0) {
         m->local_upc[l] = nullptr;
@@ -1037,6 +1047,7 @@ int eyoc_spconv_select_down_kernel(eyoc_ctx* ctx, int mode) {
   const int prev = ctx->knobs.down_kernel;
   if (mode == 0 || mode == 1) ctx->knobs.down_kernel = mode;           // anything else: a query ...
   if (mode == 2 || mode == 3) ctx->knobs.st128_wide = mode - 2;        // ... or (diagnostics) 2 / 3: 64- / 128-channel workgroups for >= 128-channel layers
+  if (mode == 4 || mode == 5) ctx->knobs.s1_wide = mode - 4;           // 4 / 5: stride-1 layers with >= 128 channels on 256-row x 64-channel / 128-row x 128-channel workgroups
   return prev;
 }
 

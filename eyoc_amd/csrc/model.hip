@@ -472,6 +472,7 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
         a.range = m->range;
         // stride-1 layers on Z-ordered rows: tile-local input stage (spconv_st.hip)
         if (p.map == M_S1 && p.cin >= 32 && p.cin % 32 == 0) { a.local = maps->local_s1[p.level]; a.ks_part = ks_part; }
+        if (p.map == M_S1 && p.cin % 32 == 0 && p.cout % 128 == 0 && ctx->knobs.s1_wide) a.local128 = maps->local_s1w[p.level];
         if (p.map == M_DOWN && p.cin % 32 == 0 && p.cout % 64 == 0) a.local_down = maps->local_down[p.level];   // spconv_st.hip on 128-row tiles
         if (p.map == M_UP && p.cin % 32 == 0 && p.cout % 64 == 0) a.local_up = maps->local_up[p.level];   // spconv_up.hip
         if (p.map == M_UP && p.cin % 32 == 0 && p.cout % 64 == 0) a.local_upc = maps->local_upc[p.level]; // spconv_upc.hip (class-major tiles)

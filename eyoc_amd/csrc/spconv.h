@@ -43,6 +43,7 @@ struct SpconvArgs {
   int out_split = 0;               // write SPLIT16 rows (internal activations) instead of fp32 rows
   const int32_t* out_perm = nullptr;      // output row o is written to row out_perm[o] of `out` (the network output in the caller's order); res is not permuted
   const unsigned char* local = nullptr;   // per-tile local rulebooks of `nbr` (build_local_rulebook / build_local_rulebook128) or NULL: enables the staged kernel
+  const unsigned char* local128 = nullptr;   // ... of `nbr` in 128-row tiles (build_local_rulebook128): a stride-1 layer with >= 128 output channels then runs as 128 rows x 128 channels per workgroup
   const unsigned char* local_down = nullptr;   // ... of a strided table in 128-row tiles (build_local_rulebook128): enables launch_spconv_st128
   const unsigned char* local_up = nullptr;   // ... of a transposed table (build_local_rulebook_up): enables spconv_up.hip
   const unsigned char* local_upc = nullptr;  // ... in class-major order (build_upc): enables spconv_upc.hip

@@ -757,7 +757,7 @@ namespace eyoc {
 // the map build; the step is the same within noise) and 18 GB less HBM traffic per forward
 
 // Which tile-record kernel takes a split16 layer: 1 the staged stride-1 kernel (spconv_st.hip), 2 class-major transposed tiles
-// (spconv_upc.hip), 3 Morton transposed tiles (spconv_up.hip), 4 the staged kernel on 128-row tiles of a strided table, 0 none - a gathering kernel, which reads a.nbr.  ONE predicate for the
+// (spconv_upc.hip), 3 Morton transposed tiles (spconv_up.hip), 4 the staged kernel on 128-row tiles of a strided table, 5 ... of a stride-1 table (>= 128 output channels), 0 none - a gathering kernel, which reads a.nbr.  ONE predicate for the
 // launcher below and for eyoc_model_forward, which fills a lazily skipped table only when a layer really reads it (common.h eyoc_maps).
 int spconv_record_path(const SpconvArgs& a) {
   if (a.math != 1 || a.K != 27 || a.l2norm) return 0;
@@ -767,6 +767,7 @@ int spconv_record_path(const SpconvArgs& a) {
   // 1, 2, 4 or 8 of them share a tile; other widths stay on the gathering kernels)
   const int st_ctg = a.cout >= 64 ? 64 : 32;
   const bool st_ok = a.cout % st_ctg == 0 && a.cout / st_ctg <= 8 && 8 % (a.cout / st_ctg) == 0 && a.cin % 32 == 0;
+  if (a.local128 && a.cout % 128 == 0 && a.cout / 128 <= 8 && 8 % (a.cout / 128) == 0 && a.cin % 32 == 0) return 5;
   if (a.local && st_ok) return 1;
   if (a.local_down && a.cout % 64 == 0 && a.cout / 64 <= 8 && 8 % (a.cout / 64) == 0 && a.cin % 32 == 0) return 4;
   if (a.local_upc && !a.res && !a.out_perm && a.cout % 64 == 0) return 2;
@@ -816,6 +817,7 @@ int launch_spconv(const SpconvArgs& a, hipStream_t st) {
       case 2: { SpconvArgs b = a; b.perm = nullptr; return launch_spconv_upc(b, a.local_upc, st); }     // transposed table, class-major tiles
       case 3: { SpconvArgs b = a; b.perm = nullptr; return launch_spconv_up(b, a.local_up, st); }       // transposed table with tile rulebooks
       case 4: { SpconvArgs b = a; b.perm = nullptr; return launch_spconv_st128(b, a.local_down, st); }  // strided table, 128-row tiles
+      case 5: { SpconvArgs b = a; b.perm = nullptr; return launch_spconv_st128(b, a.local128, st); }    // stride-1 table, 128-row x 128-channel workgroups
       default: break;
     }
     const bool rs_layer = a.cin >= 64 && !(a.n_in > a.n_out);
