@@ -87,7 +87,7 @@ __global__ __launch_bounds__(NWB * 64) void k_local_rulebook(const int32_t* __re
   __shared__ int hk[HS];
   __shared__ unsigned short hid[HS];
   __shared__ unsigned short srow[27][TR];                            // hash slot of (offset, local row), 0xFFFF = no neighbour
-  __shared__ unsigned long long key[TR];
+  __shared__ __attribute__((aligned(16))) unsigned long long key[TR];
   __shared__ int wave_cnt[NWB];
   __shared__ int too_many;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -218,18 +218,21 @@ __global__ __launch_bounds__(NWB * 64) void k_local_rulebook(const int32_t* __re
     if (total > NPASS * UMAX) atomicAdd(overflow, 1);
   }
   __syncthreads();
-  if (group) {                                                         // 256-key bitonic sort (workgroup-uniform branch)
-    const int r_ = (int)threadIdx.x;
-    for (int kk = 2; kk <= TR; kk <<= 1)
-      for (int jj = kk >> 1; jj > 0; jj >>= 1) {
-        const int p = r_ ^ jj;
-        if (p > r_) {
-          const unsigned long long a_ = key[r_], b_ = key[p];
-          const bool up = (r_ & kk) == 0;
-          if ((a_ > b_) == up) { key[r_] = b_; key[p] = a_; }
-        }
-        __syncthreads();
-      }
+  if (group) {
+    // the tile's keys in ascending order (workgroup-uniform branch).  Rank by counting: the keys are distinct (the local row is in the low
+    // bits), so a key's position is the number of smaller keys - TR broadcast reads per thread (two keys per 16-byte read) and ONE
+    // barrier, against the 36 barrier-separated compare-exchange rounds of the bitonic network this replaces (round 6)
+    const unsigned long long mine = key[threadIdx.x];
+    int rank = 0;
+    const ulonglong2* kp = reinterpret_cast<const ulonglong2*>(key);
+#pragma unroll 8
+    for (int i = 0; i < TR / 2; ++i) {
+      const ulonglong2 kk = kp[i];
+      rank += (kk.x < mine) + (kk.y < mine);
+    }
+    __syncthreads();
+    key[rank] = mine;
+    __syncthreads();
   }
   // 3. LDS slot of every (offset, tile slot): thread s owns slot s = 64 w + 16 c + j, which holds local row src; the slot's
   // entries go to 16-bit lane c of entry (k, 16 w + j)

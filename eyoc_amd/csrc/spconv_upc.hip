@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_upc_records(const int32_t* __restrict__
   __shared__ int hk[HSLOTS];
   __shared__ unsigned short hid[HSLOTS], hpos[HSLOTS];
   __shared__ unsigned short srow[KC][TILE];
-  __shared__ unsigned int key[TILE];
+  __shared__ __attribute__((aligned(16))) unsigned int key[TILE];
   __shared__ int wave_cnt[NW];
   __shared__ unsigned char nib[NPASS][KC][NW];
   const int tile = blockIdx.x;
@@ -314,18 +314,18 @@ __global__ __launch_bounds__(256) void k_upc_records(const int32_t* __restrict__
     reinterpret_cast<int*>(lr)[1] = b;
     if (total > NPASS * UMAX) atomicAdd(&hdr->overflow, 1);
   }
-  {                                                                    // 256-key bitonic sort
-    const int r_ = (int)threadIdx.x;
-    for (int kk = 2; kk <= TILE; kk <<= 1)
-      for (int jj = kk >> 1; jj > 0; jj >>= 1) {
-        const int p = r_ ^ jj;
-        if (p > r_) {
-          const unsigned int a_ = key[r_], b_ = key[p];
-          const bool up = (r_ & kk) == 0;
-          if ((a_ > b_) == up) { key[r_] = b_; key[p] = a_; }
-        }
-        __syncthreads();
-      }
+  {                                                                    // the keys in ascending order: rank by counting (distinct keys; see k_local_rulebook)
+    const unsigned int mine = key[threadIdx.x];
+    int rank = 0;
+    const uint4* kp = reinterpret_cast<const uint4*>(key);
+#pragma unroll 8
+    for (int i = 0; i < TILE / 4; ++i) {
+      const uint4 kk = kp[i];
+      rank += (kk.x < mine) + (kk.y < mine) + (kk.z < mine) + (kk.w < mine);
+    }
+    __syncthreads();
+    key[rank] = mine;
+    __syncthreads();
   }
   // slot s = 64 w + 16 c + j takes the row at sorted position (c * 4 + snake(w)) * 16 + j: the sorted 16-row chunks are dealt
   // over the four 64-slot quarters in snake order (as in k_local_rulebook), so that the waves carry the same load

@@ -8,6 +8,9 @@ clouds = []
 for s in range(int(os.environ.get('PAIRS', '64'))):
     p = syn.make_pair(s); clouds += [p["coords0"], p["coords1"]]
 coords = torch.from_numpy(syn.batch_coords(clouds)).cuda()
+if "ST_GROUP" in os.environ:
+    from eyoc_amd import _lib
+    _lib.knob("eyoc_spconv_st_group_rows", int(os.environ["ST_GROUP"]))
 if "EYOC_DOWN" in os.environ:
     from eyoc_amd import _lib
     _lib.knob("eyoc_spconv_select_down_kernel", int(os.environ["EYOC_DOWN"]))
