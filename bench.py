@@ -313,6 +313,30 @@ def pipelined_rate(pipe, batch, reps, warm=3, tail=True):
     return (time.perf_counter() - t0) / reps
 
 
+def voxelizer_extra(device, iters=20):
+    """The voxeliser (lib/data_loaders.py:936-979: `ME.utils.sparse_quantize(xyz / voxel)` + floor) on one raw synthetic
+    scan: `eyoc_voxelize` (quantise, hash-grid insert, flag, scan, compact + one read-back of the kept count per call).  Compulsory bytes:
+    12 per point read, 20 per kept voxel written (coords + index)."""
+    from eyoc_amd import voxelize as vox
+    rng = np.random.default_rng(123)
+    scene = syn.make_scene(rng)
+    pts = syn.raycast(scene, syn._pose(0.0, 0.0, 0.0), rng).astype(np.float32)
+    t = torch.from_numpy(pts).to(device)
+    for _ in range(3):
+        coords, sel = vox.sparse_quantize(t, 0.3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        coords, sel = vox.sparse_quantize(t, 0.3)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / iters
+    n, m = int(t.shape[0]), int(coords.shape[0])
+    gbs = (12.0 * n + 20.0 * m) / (ms * 1e-3) / 1e9
+    return {"ms_per_cloud": ms, "points": n, "voxels": m, "Mpoints_per_s": n / ms / 1e3, "compulsory_GB_per_s": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+            "note": "one cloud per call, synchronous (the call reads the kept count back): ~8 launches + a host round trip, latency-bound at this "
+                    "size - 1.9 MB per cloud is 0.3 us of HBM time; the registration bench starts from voxelised inputs (north_star)"}
+
+
 def train_step_ms(pair, sd, device, iters=10):
     """Wall time of a training iteration on one pair (its own model instance: the timed eval model is not touched)."""
     from scipy.spatial import cKDTree
@@ -652,8 +676,9 @@ def worker(args):
     achieved_tf = flops / (conv_ms * 1e-3) / 1e12
     achieved_gbs = gather / (conv_ms * 1e-3) / 1e9
     math_mode = model.last_spconv_math
-    kernel = ("spconv_st_asm_kernel<64, 2, 1, 4> (12 of the launches; + spconv_st_asm_kernel<32, 1, 1, 4>, spconv_upc_kernel, spconv_wave_kernel, "
-              "tail_fused_kernel)" if math_mode == "split16" else "spconv_wave_kernel<...>") + " - the sparse-conv launches of one forward, summed"
+    kernel = ("spconv_st_asm_kernel<64, 2, 1, 4, 256, .> (10 of the launches: stride-1 layers with 64 / 128 channels, the last one with the 1x1 tail "
+              "in its epilogue; + <.., 128> on 128-row tiles: the three strided layers and the two 256-channel ones, <32, 1, 18, 4> the two 32-channel "
+              "layers, spconv_upc_kernel the three transposed ones)" if math_mode == "split16" else "spconv_wave_kernel<...>") + " - the sparse-conv launches of one forward, summed"
     if math_mode == "split16":
         # split16: every algorithmic fp32 multiply-add is three fp16 MFMA multiply-adds.  What binds these kernels is the
         # fp16 matrix pipe (counters: the pipe is busy >50 % of the kernel time while HBM runs at ~20 % - the staged kernel
@@ -699,7 +724,7 @@ def worker(args):
     # WRITE_SIZE, separate passes; profiles/README.md) - quoted only when they were taken on this workload
     # AND on these kernel sources (the profile records a hash of eyoc_amd/csrc; a kernel change without a profile refresh must
     # not keep quoting the old counters)
-    for tag in ("r5", "r4", "r3", "r2", "r1"):
+    for tag in ("r6", "r5", "r4", "r3", "r2", "r1"):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_spconv_traffic.json")))
             if prof["workload"] == out["config"]["workload"] and prof.get("csrc_sha16") != csrc_sha16():
@@ -733,7 +758,8 @@ def worker(args):
     # dominates it (v_fma_f64 for the residual sweep)
     sc2_roof = None
     try:
-        vp = json.load(open(os.path.join(ROOT, "profiles", "r5_valu.json")))
+        vp_tag = "r6" if os.path.exists(os.path.join(ROOT, "profiles", "r6_valu.json")) else "r5"
+        vp = json.load(open(os.path.join(ROOT, "profiles", f"{vp_tag}_valu.json")))
         if vp.get("csrc_sha16") == csrc_sha16():
             rates = vp["valu_issue_rates_G_wave_inst_per_s"]
             if cfg.use_RANSAC:
@@ -745,13 +771,13 @@ def worker(args):
                                           "kernel": "k_count (the residual sweep: 16 v_pk_*_f32 + 4 compares per TWO residuals; 16 v_*_f64 per residual before)",
                                           "achieved": kc["G_wave_inst_per_s"], "peak": peak, "unit": "G wave-instructions/s",
                                           "frac": kc["G_wave_inst_per_s"] / peak, "ms_per_launch": kc["ms_per_launch"],
-                                          "measured_in_run": False, "source": "profiles/r5_valu.json, profiles/r5_kernel_stats.csv, profiles/r5_valu_rates.txt",
+                                          "measured_in_run": False, "source": f"profiles/{vp_tag}_valu.json, profiles/{vp_tag}_kernel_stats.csv, profiles/r5_valu_rates.txt",
                                           "other_kernels": {k: v for k, v in vp["ransac"].items() if k != "k_count"}}
             km = vp["sc2pcr"]["k_masks"]
             sc2_roof = {"bound": "valu", "kernel": "k_masks (symmetric cross-length tiles) - the back-end's kernels are VALU / latency work, none touches HBM twice",
                         "achieved": km["G_wave_inst_per_s"], "peak": rates["v_add_f32"], "unit": "G wave-instructions/s",
                         "frac": km["G_wave_inst_per_s"] / rates["v_add_f32"], "measured_in_run": False,
-                        "kernels": vp["sc2pcr"], "source": "profiles/r5_valu.json, profiles/r5_sc2pcr_kernel_stats.csv"}
+                        "kernels": vp["sc2pcr"], "source": f"profiles/{vp_tag}_valu.json, profiles/{vp_tag}_sc2pcr_kernel_stats.csv"}
             if not cfg.use_RANSAC:
                 out["sc2pcr_roofline"] = sc2_roof
     except (OSError, KeyError, ValueError):
@@ -837,6 +863,10 @@ def worker(args):
             log("545-pair split done")
         # one training iteration (lib/trainer.py:1655-1676): maps + train-mode forward (batch statistics) + hardest-
         # contrastive loss + backward + SGD step on the first pair's two ~30k-voxel clouds, through model.train()(x)
+        try:
+            out["voxelizer"] = voxelizer_extra(device)
+        except Exception as e:      # noqa: BLE001 - an extra must not cost the headline
+            out["voxelizer"] = {"error": repr(e)[:200]}
         try:
             out["train_step_ms"] = train_step_ms(pairs0[0], sd, device)
         except Exception as e:      # noqa: BLE001 - an extra must not cost the headline
