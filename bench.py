@@ -317,7 +317,8 @@ def voxelizer_extra(device, iters=20):
     """The voxeliser (lib/data_loaders.py:936-979: `ME.utils.sparse_quantize(xyz / voxel)` + floor) on one raw synthetic
     scan: `eyoc_voxelize` (quantise, hash-grid insert, flag, scan, compact + one read-back of the kept count per call).  Compulsory bytes:
     12 per point read, 20 per kept voxel written (coords + index)."""
-    from eyoc_amd import voxelize as vox
+    import importlib
+    vox = importlib.import_module("eyoc_amd.voxelize")           # (the package re-exports a FUNCTION of that name)
     rng = np.random.default_rng(123)
     scene = syn.make_scene(rng)
     pts = syn.raycast(scene, syn._pose(0.0, 0.0, 0.0), rng).astype(np.float32)
