@@ -104,6 +104,7 @@ def parse_args(argv=None):
     ap.add_argument("--main-priority", action="store_true", help="diagnostics: the step's own stream gets high priority (measured: +0.5 %% with --maps-after start)")
     ap.add_argument("--st-variant", type=int, default=-1,
                     help="diagnostics: staged-kernel implementation (eyoc_spconv_select_st_kernel: 0 C++ loop, 1 assembly loop, 2 assembly without empty-block branches)")
+    ap.add_argument("--st-ksplit", type=int, default=-1, help="diagnostics: eyoc_spconv_st_ksplit (0 / 1; 2 / 3 = channel groups of a tile on one XCD off / on)")
     ap.add_argument("--down-kernel", type=int, default=-1, help="diagnostics: eyoc_spconv_select_down_kernel (1 staged on 128-row tiles, 0 gathering)")
     ap.add_argument("--lazy-tables", type=int, default=-1, help="diagnostics: eyoc_maps_lazy_tables (1 / 0)")
     ap.add_argument("--up-kernel", type=int, default=-1, help="diagnostics: eyoc_spconv_select_up_kernel (0 gathering, 1 Morton tiles, 2 class-major tiles)")
@@ -430,6 +431,9 @@ def worker(args):
         if args.st_variant >= 0:
             from eyoc_amd import _lib as _l
             _l.knob("eyoc_spconv_select_st_kernel", args.st_variant)
+        if args.st_ksplit >= 0:
+            from eyoc_amd import _lib as _l
+            _l.knob("eyoc_spconv_st_ksplit", args.st_ksplit)
         if args.down_kernel >= 0:
             from eyoc_amd import _lib as _l
             _l.knob("eyoc_spconv_select_down_kernel", args.down_kernel)

@@ -105,6 +105,7 @@ struct eyoc_ctx {
     int st_group = 1;                  // eyoc_spconv_st_group_rows: the staged kernel's tiles sorted by neighbour pattern
     int st_variant = 1;                // eyoc_spconv_select_st_kernel
     int st_split_below = 1024;         // eyoc_spconv_st_split_below
+    int st_cg_local = 1;               // (diagnostics, eyoc_spconv_st_ksplit(2 / 3) = off / on): channel groups of a tile on one XCD when the layer's weights fit an L2 beside the stream
     int st_ksplit = 1;                 // eyoc_spconv_st_ksplit
     int ransac_store = 1 << 20;        // eyoc_ransac_transform_store
     int ransac_prune = 1;              // eyoc_ransac_select_pruning

@@ -66,6 +66,7 @@ struct SpconvArgs {
   // then depends on the problem size - training layers, where no other kernel has to give the same bits)
   int allow_offset_split = 0, offset_split = 1;
   float* offset_part = nullptr;
+  int cg_local = 0;                // staged kernels: 1 = the channel groups of a tile run back to back on ONE XCD (set by the launcher, see launch_spconv_st)
   TailFuse tail;                   // staged stride-1 kernel only (spconv_st_can_fuse_tail): this layer's output goes straight into the 1x1 tail
 };
 constexpr int KS_MAX_SLOTS = 1024;                        // (workgroups x splits) a split launch may use: 32 KB of partial sums each

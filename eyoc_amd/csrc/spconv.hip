@@ -1274,6 +1274,7 @@ int eyoc_spconv_st_ksplit(eyoc_ctx* ctx, int on) {
   if (!ctx) return -1;
   const int prev = ctx->knobs.st_ksplit;
   if (on == 0 || on == 1) ctx->knobs.st_ksplit = on;
+  if (on == 2 || on == 3) ctx->knobs.st_cg_local = on - 2;             // (diagnostics) the channel groups of a tile on one XCD: off / on
   return prev;
 }
 

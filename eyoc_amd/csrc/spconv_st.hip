@@ -532,7 +532,13 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
   const int g = lane >> 4, j = lane & 15;
   const int n_cg = a.cout / CTG;
   const int xcd = (int)blockIdx.x & 7, per = 8 / n_cg;
-  const int cg = xcd % n_cg, tile = ((int)blockIdx.x >> 3) * per + xcd / n_cg;
+  // workgroup -> (tile, channel group).  Consecutive workgroups go to consecutive XCDs (each with its own L2).  Default: the channel
+  // group from the XCD number, so that an L2 holds one group's weights only (a 256 -> 256 layer has 7 MB of split weights, an L2 4 MB) -
+  // the groups of a tile then stage the same rows from HBM once per XCD.  cg_local (round 6; layers whose whole packed kernel fits an L2
+  // beside the stream: 128 -> 128 = 1.8 MB): the groups of a tile are workgroups b and b + 8 - the same XCD, back to back - and the
+  // second one's stage hits the L2 the first one filled
+  const int cg = a.cg_local ? ((int)blockIdx.x >> 3) % n_cg : xcd % n_cg;
+  const int tile = a.cg_local ? (((int)blockIdx.x >> 3) / n_cg) * 8 + xcd : ((int)blockIdx.x >> 3) * per + xcd / n_cg;
   if (tile >= n_tiles) return;
   const int w0 = T128 ? (NH == 2 ? 0 : (wave >> 1)) : NH == 1 ? (wave & 3) : 2 * (wave >> 1);
   const int ct0 = cg * CTG + (T128 && NH == 2 ? wave * CTW : T128 || NH == 2 ? (wave & 1) * CTW : (wave >> 2) * CTW);
@@ -1068,7 +1074,11 @@ int launch_spconv_st(const SpconvArgs& a_in, const unsigned char* local_dev, hip
   const int n_cg = a.cout / ctg;
   EYOC_REQUIRE(a.cout % ctg == 0 && n_cg >= 1 && n_cg <= 8 && 8 % n_cg == 0 && a.cin % 32 == 0, EYOC_ERR_INVALID,
                "spconv_st: %d -> %d channels", a.cin, a.cout);
-  dim3 grid((unsigned)(cdiv(n_tiles, 8 / n_cg) * 8)), block(NW * 64);
+  SpconvArgs a_loc = a_in;
+  // (see the kernel's workgroup -> tile mapping) the packed split16 kernel of the layer against half an L2
+  a_loc.cg_local = (kn.st_cg_local && n_cg > 1 && variant0 != 0 && (size_t)27 * a.cin * a.cout * 4 <= (size_t)2 << 20) ? 1 : 0;
+  const SpconvArgs& a2 = a_loc;
+  dim3 grid((unsigned)(a_loc.cg_local ? cdiv(n_tiles, 8) * 8 * n_cg : cdiv(n_tiles, 8 / n_cg) * 8)), block(NW * 64);
   const int variant = kn.st_variant;
   // small inputs (32-channel workgroups that do not fill the chip's 512 slots): the 32-channel input blocks of a tile split over
   // ksplit workgroups, as many as keep workgroups x splits within the scratch (and never more than there are blocks)
@@ -1094,9 +1104,9 @@ int launch_spconv_st(const SpconvArgs& a_in, const unsigned char* local_dev, hip
   } else {
 #define EYOC_STA(CC_, NH_, SK_)                                                                                          \
   do {                                                                                                                  \
-    hipLaunchKernelGGL((spconv_st_asm_kernel<CC_, NH_, SK_>), grid, block, 0, st, a, local_dev, n_tiles, ksplit, 0);    \
+    hipLaunchKernelGGL((spconv_st_asm_kernel<CC_, NH_, SK_>), grid, block, 0, st, a2, local_dev, n_tiles, ksplit, 0);    \
     if (ksplit > 1)                                                                                                     \
-      hipLaunchKernelGGL((spconv_st_asm_kernel<CC_, NH_, SK_>), dim3(grid.x), block, 0, st, a, local_dev, n_tiles, ksplit, 1); \
+      hipLaunchKernelGGL((spconv_st_asm_kernel<CC_, NH_, SK_>), dim3(grid.x), block, 0, st, a2, local_dev, n_tiles, ksplit, 1); \
   } while (0)
     if (ctg == 64) {
       if (variant == 2) { if (wide) EYOC_STA(64, 2, 0); else EYOC_STA(32, 2, 0); }
@@ -1120,8 +1130,8 @@ int launch_spconv_st(const SpconvArgs& a_in, const unsigned char* local_dev, hip
 #endif
       else if (a.tail.out) {                                             // the 1x1 tail in the epilogue (spconv_st_can_fuse_tail said yes)
         EYOC_REQUIRE(spconv_st_can_fuse_tail(a) && a.range, EYOC_ERR_INVALID, "spconv_st: this layer cannot carry the fused tail");
-        if (wide) hipLaunchKernelGGL((spconv_st_asm_kernel<64, 2, 1, NW, TILE, 1>), grid, block, 0, st, a, local_dev, n_tiles, 1, 0);
-        else hipLaunchKernelGGL((spconv_st_asm_kernel<32, 2, 1, NW, TILE, 1>), grid, block, 0, st, a, local_dev, n_tiles, 1, 0);
+        if (wide) hipLaunchKernelGGL((spconv_st_asm_kernel<64, 2, 1, NW, TILE, 1>), grid, block, 0, st, a2, local_dev, n_tiles, 1, 0);
+        else hipLaunchKernelGGL((spconv_st_asm_kernel<32, 2, 1, NW, TILE, 1>), grid, block, 0, st, a2, local_dev, n_tiles, 1, 0);
         hipLaunchKernelGGL(k_tail_poison, dim3(256), dim3(256), 0, st, a.range, a.tail.out, a.n_out, a.tail.ld_out, 32);
       }
       else { if (wide) EYOC_STA(64, 2, 1); else EYOC_STA(32, 2, 1); }

@@ -13,6 +13,15 @@ batch = DeviceBatch(pairs, list(range(P)), dev, descriptor=dict(inlier_ratio=0.3
 if os.environ.get("ST_GROUP"):
     from eyoc_amd import _lib
     _lib.knob("eyoc_spconv_st_group_rows", int(os.environ["ST_GROUP"]))
+if os.environ.get("EYOC_DOWN"):
+    from eyoc_amd import _lib
+    _lib.knob("eyoc_spconv_select_down_kernel", int(os.environ["EYOC_DOWN"]))
+if os.environ.get("FUSE_TAIL"):
+    from eyoc_amd import _lib
+    _lib.knob("eyoc_model_fuse_tail", int(os.environ["FUSE_TAIL"]))
+if os.environ.get("LAZY"):
+    from eyoc_amd import _lib
+    _lib.knob("eyoc_maps_lazy_tables", int(os.environ["LAZY"]))
 if os.environ.get("ZSPLIT"):
     from eyoc_amd import _lib
     _lib.knob("eyoc_maps_internal_order", 1)

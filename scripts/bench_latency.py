@@ -20,6 +20,12 @@ model = model.to(device).eval()
 if os.environ.get("ST_GROUP"):
     from eyoc_amd import _lib
     _lib.knob("eyoc_spconv_st_group_rows", int(os.environ["ST_GROUP"]))
+if os.environ.get("UPC_MIN_ROWS"):
+    from eyoc_amd import _lib
+    _lib.knob("eyoc_spconv_upc_min_rows", int(os.environ["UPC_MIN_ROWS"]))
+if os.environ.get("EYOC_DOWN"):
+    from eyoc_amd import _lib
+    _lib.knob("eyoc_spconv_select_down_kernel", int(os.environ["EYOC_DOWN"]))
 pipe = RegistrationPipeline(model, cfg)
 single = DeviceBatch([syn.make_pair(0)], [0], device, cfg.n_points)
 for _ in range(3):
