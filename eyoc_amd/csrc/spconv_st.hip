@@ -73,6 +73,10 @@ static_assert(LR_BYTES % 128 == 0, "records start on cache lines");
 // than HSLOTS (rows in no spatial order) gives up after a full round of probing and counts as overflowed.  (8192 slots - room
 // for all 256 * 27 possible rows - cost twice the clearing and numbering work and a third of the occupancy: 278 -> ~190 us at level 0.)
 constexpr int HSLOTS = 4096;
+#ifndef EYOC_LR_HSLOTS_LOG2
+#define EYOC_LR_HSLOTS_LOG2 11
+#endif
+constexpr int HSLOTS_LOG2 = EYOC_LR_HSLOTS_LOG2, HSLOTS_T = 1 << HSLOTS_LOG2;   // the builders' own table: 2048 slots (round 6; 4096 before) - see k_local_rulebook
 
 // NWB = waves of the builder = 64-row quarters of the tile it describes: 4 (256-row tiles: the stride-1 tables) or 2 (128-row tiles:
 // the strided tables, round 6 - a 128-row coarse tile reads 370-620 distinct fine rows, a 256-row one 700-1250).  Same record layout
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(NWB * 64) void k_local_rulebook(const int32_t* __re
   constexpr int TR = NWB * 64;                                       // rows per tile
   // 128-row tiles: half the table (at most 1278 usable rows = 62 % load; 370-620 typical) - clearing and numbering the table is a
   // fixed cost per tile, and 20 KB of LDS instead of 32 lets eight workgroups share a CU
-  constexpr int HS = NWB == 4 ? HSLOTS : HSLOTS / 2, HSHIFT = NWB == 4 ? 20 : 21;
+  constexpr int HS = HSLOTS_T, HSHIFT = 32 - HSLOTS_LOG2;
   __shared__ int hk[HS];
   __shared__ unsigned short hid[HS];
   __shared__ unsigned short srow[27][TR];                            // hash slot of (offset, local row), 0xFFFF = no neighbour
