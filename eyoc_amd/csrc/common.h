@@ -204,7 +204,6 @@ struct eyoc_maps {
   bool s1_ready[EYOC_MAX_LEVELS] = {true, true, true, true};
   bool up_ready[EYOC_MAX_LEVELS] = {true, true, true, true};
   int32_t* up8[EYOC_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
-  hipStream_t build_stream = nullptr;   // the stream eyoc_maps_build ran on (eyoc_maps_table has no stream argument)
 };
 
 namespace eyoc {

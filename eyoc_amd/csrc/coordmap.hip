@@ -722,7 +722,6 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
   const bool use_up = kn.up_kernel == 1 || (kn.up_kernel == 2 && !use_upc);
   // lazy tables (common.h eyoc_maps): the level-0 stride-1 table and the transposed tables are read by their record builders only
   const bool lazy = zorder && use_upc && kn.maps_lazy_tables != 0;
-  m->build_stream = st;
   for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
     m->nbr_s1[l] = cv.take<int32_t>((size_t)27 * m->rows[l]);
     if (l + 1 < EYOC_MAX_LEVELS) {
@@ -965,11 +964,13 @@ const int32_t* eyoc_maps_coords(const eyoc_maps* maps, int level) {
 
 const int32_t* eyoc_maps_table(const eyoc_maps* maps, int kind, int level) {
   if (!maps || level < 0 || level >= maps->n_levels) return nullptr;
-  // a table the build skipped (lazy tables) is filled now, on the build's stream, and waited for: the pointer is valid for any stream
+  // a table the build skipped (lazy tables) is filled now and waited for: the pointer is valid for any stream.  On the NULL stream -
+  // eyoc_maps_build synchronised its own stream before it returned, so everything the fill reads is complete, and the stream the
+  // maps were built on may be gone by now (a torch side stream)
   if ((kind == EYOC_MAP_S1 && !maps->s1_ready[level]) || (kind == EYOC_MAP_UP && level + 1 < maps->n_levels && !maps->up_ready[level])) {
     eyoc_maps* mm = const_cast<eyoc_maps*>(maps);
-    if (maps_ensure_table(mm, kind, level, mm->build_stream) != EYOC_OK) return nullptr;
-    if (hipStreamSynchronize(mm->build_stream) != hipSuccess) return nullptr;
+    if (maps_ensure_table(mm, kind, level, (hipStream_t)nullptr) != EYOC_OK) return nullptr;
+    if (hipStreamSynchronize((hipStream_t)nullptr) != hipSuccess) return nullptr;
   }
   switch (kind) {
     case EYOC_MAP_S1: return maps->nbr_s1[level];

@@ -133,7 +133,7 @@ int eyoc_maps_copy_row_order(const eyoc_maps* maps, int32_t* out_dev, void* stre
 int eyoc_maps_rows(const eyoc_maps* maps, int level);
 /* device pointers into the workspace; valid while the maps object lives */
 const int32_t* eyoc_maps_coords(const eyoc_maps* maps, int level);             /* [rows,4]        */
-const int32_t* eyoc_maps_table(const eyoc_maps* maps, int kind, int level);    /* [27][n_out]; a lazily skipped table is filled on the build's stream and waited for */
+const int32_t* eyoc_maps_table(const eyoc_maps* maps, int kind, int level);    /* [27][n_out]; a lazily skipped table is filled first (NULL stream, waited for) */
 /* stream-ordered device-to-device copies of the same arrays into caller-owned buffers */
 int eyoc_maps_copy_coords(const eyoc_maps* maps, int level, int32_t* out_dev, void* stream);
 int eyoc_maps_copy_table(const eyoc_maps* maps, int kind, int level, int32_t* out_dev, void* stream);
