@@ -62,3 +62,48 @@ def test_a_cloud_in_no_spatial_order_falls_back(batches_take_the_batch_kernels):
     f = _forward(model, coords, feats).cpu().numpy()
     want = np.asarray(orr.resunet_forward(sd, coords, feats))
     assert np.abs(f - want).max() <= 1e-4 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("case", ["tiny", "random", "one_cloud_of_a_pair"])
+def test_batch_kernels_on_small_and_odd_inputs(case):
+    """Robustness of the round-6 paths away from their production sizes: Z-order, class-major transposed records, lazy tables, 128-row
+    strided tiles, the wide 128-row stride-1 tiles and the tail in the last layer's epilogue FORCED on inputs of 6, ~2000 and ~30 000
+    rows (a ragged only tile, levels with fewer rows than a tile, a coarsest level of a handful of rows) - tables and forward against
+    the oracle."""
+    import eyoc_amd
+    from eyoc_amd import _lib, synthetic as syn
+    from oracle import coords as oc, resunet as orr
+    from test_gpu_round2 import _model
+    if case == "tiny":
+        coords = np.array([[0, -1, -1, -1], [0, -2, 0, 1], [0, 0, 0, 0], [1, 0, 0, 0], [1, 1, 0, 0], [0, -9, 7, -8]], np.int32)
+    elif case == "random":
+        rng = np.random.default_rng(4)
+        c = np.unique(rng.integers(-12, 12, size=(2500, 3)), axis=0).astype(np.int32)
+        rng.shuffle(c)
+        coords = syn.batch_coords([c[:1200], c[1200:]])
+    else:
+        coords = syn.batch_coords([syn.make_pair(11)["coords1"]])
+    feats = np.random.default_rng(1).uniform(0.5, 1.5, size=(len(coords), 1)).astype(np.float32)
+    model, sd = _model()
+    knobs = [("eyoc_spconv_upc_min_rows", 0), ("eyoc_maps_internal_order", 1), ("eyoc_spconv_st_split_below", 0)]
+    prev = [(k, _lib.knob(k, v)) for k, v in knobs]
+    model.spconv_math = "split16"
+    try:
+        x = eyoc_amd.SparseTensor(torch.from_numpy(feats).cuda(), coordinates=torch.from_numpy(coords).cuda())
+        f = model(x).F.cpu().numpy()
+        assert model.last_spconv_math == "split16"
+        cm = x.coordinate_manager
+        perm = cm.row_order().cpu().numpy()
+        want_maps = oc.build_maps(coords[perm])
+        for l in range(4):
+            np.testing.assert_array_equal(cm.table(_lib.MAP_S1, l, internal=True).cpu().numpy(), want_maps["s1"][l])
+            if l < 3:
+                np.testing.assert_array_equal(cm.table(_lib.MAP_UP, l, internal=True).cpu().numpy(), want_maps["up"][l])
+                np.testing.assert_array_equal(cm.table(_lib.MAP_DOWN, l, internal=True).cpu().numpy(), want_maps["down"][l])
+    finally:
+        model.spconv_math = "auto"
+        for k, v in prev:
+            _lib.knob(k, v if k != "eyoc_maps_internal_order" else v - 2)
+    want = np.asarray(orr.resunet_forward(sd, coords, feats))
+    ok = np.isfinite(want).all(axis=1)                                   # (an isolated voxel can normalise 0 / 0 in both)
+    assert np.abs(f[ok] - want[ok]).max() <= 1e-4 * np.abs(want[ok]).max()
