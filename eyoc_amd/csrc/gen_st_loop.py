@@ -156,7 +156,7 @@ def gen(NH, WD, LD=2, skip=True, abl=(), K=K, koff=False, tag="", lazy=False, lo
     done[0] = len(vmq) - 1
     emit("s_barrier")
     if "trace" in abl:          # diagnostics build: when did the stage land and the barrier open
-        emit("s_memtime %[tb]")
+        emit("s_memrealtime %[tb]")       # the constant 100 MHz counter (s_memtime's rate follows the clock: round 5's trace had no usable tick)
     for c in range(NC):
         t0, t1 = T[(c & 1) * 2], T[(c & 1) * 2 + 1]
         addr(0, 0, c, t0, t1)

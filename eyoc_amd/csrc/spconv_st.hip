@@ -496,7 +496,7 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_kernel(SpconvArgs a, con
 // diagnostics (scripts/trace_staged.py): per workgroup {start, header read, [blob in, barrier open, blob out] x 2, end, HW_ID}
 constexpr int TRACE_WGS = 16384, TRACE_N = 12;
 __device__ unsigned long long g_st_trace[TRACE_WGS * TRACE_N];
-#define ST_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < TRACE_WGS) g_st_trace[blockIdx.x * TRACE_N + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ST_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < TRACE_WGS) g_st_trace[blockIdx.x * TRACE_N + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define ST_STAMP(i) do {} while (0)
 #endif

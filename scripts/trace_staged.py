@@ -42,10 +42,11 @@ raw.eyoc_debug_st_trace(buf.ctypes.data, buf.size)
 t = buf.reshape(-1, NT).astype(np.int64)
 t = t[t[:, 0] > 0]
 hw = t[:, 9]; xcc = hw >> 32
-# every XCD has its own counter: calibrate the tick on the XCD-local span of the kernel (= its wall time by events)
+# s_memrealtime: the constant 100 MHz counter (round 6; s_memtime's rate follows the clock and round 5's calibration on XCD-local spans
+# came out inconsistent) - 10 ns resolution, phases are microseconds
 spans = [t[xcc == x][:, 8].max() - t[xcc == x][:, 0].min() for x in np.unique(xcc)]
-tick_us = ms * 1e3 / float(np.median(spans))
-print(f"{len(t)} workgroups, kernel {ms * 1e3:.1f} us by events, XCD-local spans {min(spans)}..{max(spans)} ticks -> {1 / tick_us:.1f} ticks/us")
+tick_us = 1.0 / 100.0
+print(f"{len(t)} workgroups, kernel {ms * 1e3:.1f} us by events, XCD-local spans {min(spans) * tick_us:.0f}..{max(spans) * tick_us:.0f} us (100 ticks/us)")
 d = lambda a, b: (t[:, a] - t[:, b]) * tick_us
 names = [("launch -> first block", 2, 0), ("block0: stage wait + barrier", 3, 2), ("block0: offset loop", 4, 3), ("between blocks", 5, 4),
          ("block1: stage wait + barrier", 6, 5), ("block1: offset loop", 7, 6), ("epilogue", 8, 7), ("whole workgroup", 8, 0)]
