@@ -169,6 +169,8 @@ def gen(NH, WD, LD=2, skip=True, abl=(), K=K, koff=False, tag="", lazy=False, lo
             hs = k * NH + h
             has_next = hs + 1 < K * NH
             kn, hn = divmod(hs + 1, NH)
+            if h == 0 and "trace" in abl and k in (9, 18):
+                emit(f"s_memrealtime %[tb{k // 9}]")        # diagnostics build: when the loop reached offsets 9 and 18
             if h == 0:
                 if k + WD < K:
                     issue_w(k + WD)

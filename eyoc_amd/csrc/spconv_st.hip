@@ -494,7 +494,7 @@ __global__ __launch_bounds__(NW * 64, 2) void spconv_st_kernel(SpconvArgs a, con
 // construction and no per-device function attribute is needed.
 #ifdef EYOC_ST_TRACE
 // diagnostics (scripts/trace_staged.py): per workgroup {start, header read, [blob in, barrier open, blob out] x 2, end, HW_ID}
-constexpr int TRACE_WGS = 16384, TRACE_N = 12;
+constexpr int TRACE_WGS = 16384, TRACE_N = 16;           // [10..13]: when blocks 0 / 1 reached offsets 9 and 18
 __device__ unsigned long long g_st_trace[TRACE_WGS * TRACE_N];
 #define ST_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < TRACE_WGS) g_st_trace[blockIdx.x * TRACE_N + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -629,15 +629,26 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
     }
     // rulebook entries of (pass, k, h): 8 bytes at lb + lv + (k * 64 + h * 16) * 8
     const unsigned char* lb = lr + 16 + UCAP * 4 + ((size_t)pass * 27 * 64 + w0 * 16) * 8;
+#ifdef EYOC_ST_QBREV                                                     // diagnostics (timing only): the 32-channel blocks in descending order
+    for (int qbr = q_lo; qbr < q_hi; ++qbr) {
+      const int qb = q_hi - 1 - (qbr - q_lo);
+#else
     for (int qb = q_lo; qb < q_hi; ++qb) {
+#endif
       if (!first) __syncthreads();                                     // every wave is done with the previous block's rows
+#ifdef EYOC_ST_DELAY_PRE                                                 // diagnostics: an idle gap in front of the tile's first STAGE
+      if (first) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); for (int z_ = 0; z_ < EYOC_ST_DELAY_PRE; ++z_) __builtin_amdgcn_s_sleep(127); }
+#endif
       first = false;
       stage(pass, qb);
       const int cc = (qb * 32) / CC, qp = ((qb * 32) % CC) / 32;
       const unsigned int ws0 = (unsigned)__builtin_amdgcn_readfirstlane(((slice * ncc + cc) * tile4 + (nt0 * JQ + 2 * qp) * 64) * 16);
       unsigned int so;
+#ifdef EYOC_ST_DELAY                                                     // diagnostics: an idle gap in front of the tile's first offset loop
+      if (pass == 0 && qb == q_lo) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); for (int z_ = 0; z_ < EYOC_ST_DELAY; ++z_) __builtin_amdgcn_s_sleep(127); }
+#endif
 #ifdef EYOC_ST_TRACE
-      unsigned long long tb = 0;
+      unsigned long long tb = 0, tb1 = 0, tb2 = 0;
       const int blk_i = pass * nqb + qb;
       if (blk_i < 2) ST_STAMP(2 + 3 * blk_i);
       if (blk_i == 0) ST_STAMP(1);
@@ -649,10 +660,14 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void spconv_st_asm_kernel(Spconv
                : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS)
 #ifdef EYOC_ST_TRACE
       if constexpr (NH == 2 && SKIP == 1) {
-        asm volatile(EYOC_ST_LOOP_NH2_TRACE : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), "+{v[96:111]}"(A2), "+{v[112:127]}"(A3), [so] "=&s"(so), [tb] "=&s"(tb)
+        asm volatile(EYOC_ST_LOOP_NH2_TRACE : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), "+{v[96:111]}"(A2), "+{v[112:127]}"(A3), [so] "=&s"(so), [tb] "=&s"(tb), [tb1] "=&s"(tb1), [tb2] "=&s"(tb2)
                      : EYOC_ST_OPERANDS : "memory", "scc", EYOC_ST_LOOP_CLOBBERS);
         if (blk_i < 2) {
-          if (threadIdx.x == 0 && blockIdx.x < TRACE_WGS) g_st_trace[blockIdx.x * TRACE_N + 3 + 3 * blk_i] = tb;
+          if (threadIdx.x == 0 && blockIdx.x < TRACE_WGS) {
+            g_st_trace[blockIdx.x * TRACE_N + 3 + 3 * blk_i] = tb;
+            g_st_trace[blockIdx.x * TRACE_N + 10 + 2 * blk_i] = tb1;
+            g_st_trace[blockIdx.x * TRACE_N + 11 + 2 * blk_i] = tb2;
+          }
           ST_STAMP(4 + 3 * blk_i);
         }
       } else

@@ -30,7 +30,7 @@ lib.eyoc_spconv_build_local_rulebook(_lib.ctx(), tab, 27, n, _lib.ptr(local), _l
 run = lambda: _lib.check(lib.eyoc_spconv_staged(_lib.ctx(), tab, _lib.ptr(local), n, n, _lib.ptr(xs), cin, cin, _lib.ptr(wd), cout, _lib.ptr(xs), _lib.ptr(xs), cin, 1, _lib.ptr(out), cout, 1, _lib.ptr(osd), _lib.stream_ptr()))
 raw = C.CDLL(_lib.LIB_PATH)
 raw.eyoc_debug_st_trace.argtypes = [C.c_void_p, C.c_size_t]
-NT = 12
+NT = 16
 for _ in range(3): run()
 torch.cuda.synchronize()
 buf = np.zeros(16384 * NT, np.uint64)
@@ -53,6 +53,9 @@ names = [("launch -> first block", 2, 0), ("block0: stage wait + barrier", 3, 2)
 for nm, a, b in names:
     v = d(a, b)
     print(f"  {nm:32s} mean {v.mean():7.2f} us  p10 {np.percentile(v, 10):7.2f}  p50 {np.percentile(v, 50):7.2f}  p90 {np.percentile(v, 90):7.2f}")
+for b in (0, 1):          # thirds of an offset loop: barrier -> offset 9 -> offset 18 -> end
+    a0, a1, a2, a3 = t[:, 3 + 3 * b], t[:, 10 + 2 * b], t[:, 11 + 2 * b], t[:, 4 + 3 * b]
+    print(f"  block{b} loop by thirds (offsets 0-8, 9-17, 18-26): {((a1 - a0) * tick_us).mean():6.2f} {((a2 - a1) * tick_us).mean():6.2f} {((a3 - a2) * tick_us).mean():6.2f} us")
 cu = ((hw >> 8) & 0xF) | (((hw >> 13) & 0x7) << 4) | (xcc << 7)   # HW_ID: CU_ID [11:8], SE_ID [15:13]
 ids = np.unique(cu)
 life = (t[:, 8] - t[:, 0]) * tick_us
@@ -69,4 +72,15 @@ ev.sort(); lvl = 0; last = 0; acc = [0, 0, 0]
 for tt, dlt in ev:
     acc[min(lvl, 2)] += tt - last; last = tt; lvl += dlt
 tot = sum(acc)
+# how much of a workgroup's FIRST / SECOND loop runs while the CU's other workgroup is inside a loop too (all CUs)
+ov = [[], []]
+for c in ids:
+    rows = t[cu == c]
+    loops = [(r[3], r[4]) for r in rows] + [(r[6], r[7]) for r in rows]
+    for r in rows:
+        for which, (a, b) in enumerate(((r[3], r[4]), (r[6], r[7]))):
+            if b <= a: continue
+            o = sum(max(0, min(b, y) - max(a, x)) for (x, y) in loops if not (x == a and y == b))
+            ov[which].append(o / (b - a))
+print(f"  share of a loop spent beside another workgroup's loop on the same CU: first loop {np.mean(ov[0]):.2f}, second loop {np.mean(ov[1]):.2f}")
 print(f"  CU {c0}: time with 0 / 1 / 2 workgroups inside an offset loop: {acc[0] / tot:.2f} / {acc[1] / tot:.2f} / {acc[2] / tot:.2f} of {tot * tick_us:.0f} us")
