@@ -69,14 +69,14 @@ constexpr int LR_BYTES = INV_OFF + TILE;                        // 33408
 static_assert(INV_OFF == ST_INV_OFF, "spconv.h mirrors this layout");
 static_assert(TILE == ST_TILE && UMAX == ST_UMAX && UCAP == ST_UCAP && NPASS == ST_NPASS && LR_BYTES == ST_LR_BYTES, "spconv.h mirrors this layout");
 static_assert(LR_BYTES % 128 == 0, "records start on cache lines");
-// LDS hash of a tile's distinct input rows.  A usable tile has at most NPASS * UMAX = 1278 of them (31 % load); a tile with more
-// than HSLOTS (rows in no spatial order) gives up after a full round of probing and counts as overflowed.  (8192 slots - room
-// for all 256 * 27 possible rows - cost twice the clearing and numbering work and a third of the occupancy: 278 -> ~190 us at level 0.)
-constexpr int HSLOTS = 4096;
+// LDS hash of a tile's distinct input rows: 2048 slots.  A usable tile has at most NPASS * UMAX = 1278 of them (62 % load; 370-620
+// typical); a tile with more than the table holds (rows in no spatial order) gives up after a full round of probing and counts as
+// overflowed.  Clearing and numbering the table is a fixed cost per tile: 8192 slots (room for all 256 * 27 possible rows) took 278 us
+// at level 0, 4096 ~190 (rounds 3-5), 2048 - 28 KB of LDS instead of 40, five workgroups per CU - is what round 6 runs.
 #ifndef EYOC_LR_HSLOTS_LOG2
 #define EYOC_LR_HSLOTS_LOG2 11
 #endif
-constexpr int HSLOTS_LOG2 = EYOC_LR_HSLOTS_LOG2, HSLOTS_T = 1 << HSLOTS_LOG2;   // the builders' own table: 2048 slots (round 6; 4096 before) - see k_local_rulebook
+constexpr int HSLOTS_LOG2 = EYOC_LR_HSLOTS_LOG2, HSLOTS_T = 1 << HSLOTS_LOG2;
 
 // NWB = waves of the builder = 64-row quarters of the tile it describes: 4 (256-row tiles: the stride-1 tables) or 2 (128-row tiles:
 // the strided tables, round 6 - a 128-row coarse tile reads 370-620 distinct fine rows, a 256-row one 700-1250).  Same record layout
@@ -85,8 +85,6 @@ template <bool DERIVE, int NWB>
 __global__ __launch_bounds__(NWB * 64) void k_local_rulebook(const int32_t* __restrict__ nbr, int K, int n_out, unsigned char* __restrict__ out,
                                                              int* __restrict__ overflow, int group, DeriveSrc d) {
   constexpr int TR = NWB * 64;                                       // rows per tile
-  // 128-row tiles: half the table (at most 1278 usable rows = 62 % load; 370-620 typical) - clearing and numbering the table is a
-  // fixed cost per tile, and 20 KB of LDS instead of 32 lets eight workgroups share a CU
   constexpr int HS = HSLOTS_T, HSHIFT = 32 - HSLOTS_LOG2;
   __shared__ int hk[HS];
   __shared__ unsigned short hid[HS];
@@ -135,7 +133,7 @@ __global__ __launch_bounds__(NWB * 64) void k_local_rulebook(const int32_t* __re
         const int prev = atomicCAS(&hk[s], -1, idx);
         if (prev == -1 || prev == idx) break;
         s = (s + 1) & (HS - 1);
-        if (++probes >= HS) { too_many = 1; s = 0xFFFFu; break; }   // the table is full: more than HSLOTS distinct rows
+        if (++probes >= HS) { too_many = 1; s = 0xFFFFu; break; }   // the table is full: more distinct rows than it has slots
       }
     }
     slot[k] = (unsigned short)s;
