@@ -107,3 +107,34 @@ def test_batch_kernels_on_small_and_odd_inputs(case):
     want = np.asarray(orr.resunet_forward(sd, coords, feats))
     ok = np.isfinite(want).all(axis=1)                                   # (an isolated voxel can normalise 0 / 0 in both)
     assert np.abs(f[ok] - want[ok]).max() <= 1e-4 * np.abs(want[ok]).max()
+
+
+def test_workgroup_to_tile_mappings_and_tile_shapes_give_the_same_bits(batches_take_the_batch_kernels):
+    """Switches that only change WHICH workgroup computes a tile or how a tile is cut over workgroups - the channel groups of a tile on
+    one XCD (eyoc_spconv_st_ksplit 2 / 3), 64- or 128-channel workgroups on 128-row tiles (eyoc_spconv_select_down_kernel 2 / 3), the
+    lazy tables - must not change a bit of the forward: every output element is the same products summed in the same order.  The
+    256-channel stride-1 layers on 128- or 256-row tiles (4 / 5) are the exception that proves it: another tile shape means another
+    split of a two-pass tile's input rows over its passes, i.e. another summation order for those tiles - fp32 rounding, nothing more."""
+    from eyoc_amd import _lib, synthetic as syn
+    from test_gpu_round2 import _model
+    p = syn.make_pair(13)
+    coords = syn.batch_coords([p["coords0"], p["coords1"]])
+    feats = np.random.default_rng(13).uniform(0.5, 1.5, size=(len(coords), 1)).astype(np.float32)
+    model, _sd = _model()
+    base = _forward(model, coords, feats)
+    try:
+        for knob, off, on in (("eyoc_spconv_st_ksplit", 2, 3), ("eyoc_spconv_select_down_kernel", 2, 3), ("eyoc_spconv_select_down_kernel", 4, 5),
+                              ("eyoc_maps_lazy_tables", 0, 1)):
+            _lib.knob(knob, off)
+            alt = _forward(model, coords, feats)
+            _lib.knob(knob, on)
+            if (off, on) == (4, 5):
+                d = float((alt - base).abs().max())
+                assert 0.0 < d < 2e-6, d
+            else:
+                assert torch.equal(alt, base), (knob, off)
+    finally:
+        _lib.knob("eyoc_spconv_st_ksplit", 3)
+        _lib.knob("eyoc_spconv_select_down_kernel", 3)
+        _lib.knob("eyoc_spconv_select_down_kernel", 5)
+        _lib.knob("eyoc_maps_lazy_tables", 1)
