@@ -25,7 +25,7 @@ class MapsInfo(C.Structure):
 class ModelDesc(C.Structure):
     _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("conv1_kernel_size", C.c_int32),
                 ("normalize_feature", C.c_int32), ("channels", C.c_int32 * 5), ("tr_channels", C.c_int32 * 5),
-                ("bn_eps", C.c_float)]
+                ("bn_eps", C.c_float), ("expanded", C.c_int32)]
 
 
 class LayerParams(C.Structure):

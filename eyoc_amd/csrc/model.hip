@@ -12,7 +12,7 @@ using namespace eyoc;
 
 namespace {
 
-enum MapSel { M_CONV1, M_S1, M_DOWN, M_UP, M_IDENT };
+enum MapSel { M_CONV1, M_S1, M_DOWN, M_UP, M_IDENT, M_AFFINE };   // M_AFFINE: a batch norm that stands alone (ResUNetExpanded's norm<i>_2): y = x * scale + shift per channel
 
 struct LayerPlan {
   std::string name;      // conv name in the state_dict ("block2.conv1")
@@ -29,7 +29,9 @@ struct LayerPlan {
 
 // activation buffers
 enum Buf { B_IN = 0, B_X1, B_T1, B_CAT1, B_X2, B_T2, B_CAT2, B_X4, B_T4, B_CAT4, B_X8, B_T8, B_Y8, B_D4, B_DT4, B_D2,
-           B_DT2, B_D1, B_DT1, B_H, B_OUT, B_COUNT };
+           B_DT2, B_D1, B_DT1, B_H,
+           B_U1, B_U2, B_U4, B_U8, B_UD4, B_UD2, B_UD1,    // ResUNetExpanded only (width 0 otherwise): the first block's output of a stage
+           B_OUT, B_COUNT };
 
 struct BufPlan { int level, width; };
 
@@ -71,6 +73,9 @@ void build_plan(const eyoc_model_desc& d, std::vector<LayerPlan>& L, BufPlan* bu
   bufs[B_D1] = {0, T[2]}; bufs[B_DT1] = {0, T[2]};
   bufs[B_H] = {0, T[1]};
   bufs[B_OUT] = {0, d.out_channels};
+  const int ex = d.expanded ? 1 : 0;
+  bufs[B_U1] = {0, ex * C[1]}; bufs[B_U2] = {1, ex * C[2]}; bufs[B_U4] = {2, ex * C[3]}; bufs[B_U8] = {3, ex * C[4]};
+  bufs[B_UD4] = {2, ex * T[4]}; bufs[B_UD2] = {1, ex * T[3]}; bufs[B_UD1] = {0, ex * T[2]};
 
   auto conv = [&](const char* name, const char* norm, int K, int cin, int cout, MapSel map, int level, int out_level,
                   int in_buf, int in_col, int out_buf, int out_col, int res_buf, int relu) {
@@ -80,27 +85,37 @@ void build_plan(const eyoc_model_desc& d, std::vector<LayerPlan>& L, BufPlan* bu
     p.res_buf = res_buf; p.relu = relu; p.l2norm = 0; p.has_bias = 0;
     L.push_back(p);
   };
-  auto block = [&](const std::string& name, int c, int level, int x_buf, int t_buf, int out_buf, int out_col) {
+  auto block1 = [&](const std::string& name, int c, int level, int x_buf, int t_buf, int out_buf, int out_col) {
     conv((name + ".conv1").c_str(), (name + ".norm1").c_str(), 27, c, c, M_S1, level, level, x_buf, 0, t_buf, 0, -1, 1);
     conv((name + ".conv2").c_str(), (name + ".norm2").c_str(), 27, c, c, M_S1, level, level, t_buf, 0, out_buf, out_col,
          x_buf, 1);
   };
+  // a stage's block(s): ResUNet2 runs block<i>; ResUNetExpanded (model/resunet.py:409-473) runs block<i> -> relu (the block's own
+  // last ReLU already) -> norm<i>_2 -> block<i>_2.  The stand-alone norm cannot be folded into a neighbour: its shift reaches
+  // block<i>_2.conv1 only through the neighbours a row HAS, and it is the residual of block<i>_2.conv2 - so it is one layer of its own
+  // (x -> u by block<i>, u -> x by the norm: x is free once block<i>.conv2 has read it as its residual)
+  auto block = [&](const std::string& stage, int c, int level, int x_buf, int t_buf, int u_buf, int out_buf, int out_col) {
+    if (!d.expanded) { block1("block" + stage, c, level, x_buf, t_buf, out_buf, out_col); return; }
+    block1("block" + stage, c, level, x_buf, t_buf, u_buf, 0);
+    conv(("norm" + stage + "_2").c_str(), ("norm" + stage + "_2").c_str(), 0, c, c, M_AFFINE, level, level, u_buf, 0, x_buf, 0, -1, 0);
+    block1("block" + stage + "_2", c, level, x_buf, t_buf, out_buf, out_col);
+  };
   // encoder (model/resunet.py:143-161)
   conv("conv1", "norm1", K1, d.in_channels, C[1], M_CONV1, 0, 0, B_IN, 0, B_X1, 0, -1, 0);
-  block("block1", C[1], 0, B_X1, B_T1, B_CAT1, T[2]);
+  block("1", C[1], 0, B_X1, B_T1, B_U1, B_CAT1, T[2]);
   conv("conv2", "norm2", 27, C[1], C[2], M_DOWN, 0, 1, B_CAT1, T[2], B_X2, 0, -1, 0);
-  block("block2", C[2], 1, B_X2, B_T2, B_CAT2, T[3]);
+  block("2", C[2], 1, B_X2, B_T2, B_U2, B_CAT2, T[3]);
   conv("conv3", "norm3", 27, C[2], C[3], M_DOWN, 1, 2, B_CAT2, T[3], B_X4, 0, -1, 0);
-  block("block3", C[3], 2, B_X4, B_T4, B_CAT4, T[4]);
+  block("3", C[3], 2, B_X4, B_T4, B_U4, B_CAT4, T[4]);
   conv("conv4", "norm4", 27, C[3], C[4], M_DOWN, 2, 3, B_CAT4, T[4], B_X8, 0, -1, 0);
-  block("block4", C[4], 3, B_X8, B_T8, B_Y8, 0);
+  block("4", C[4], 3, B_X8, B_T8, B_U8, B_Y8, 0);
   // decoder (model/resunet.py:163-186); ME.cat order is [decoder | skip]
   conv("conv4_tr", "norm4_tr", 27, C[4], T[4], M_UP, 2, 2, B_Y8, 0, B_D4, 0, -1, 0);
-  block("block4_tr", T[4], 2, B_D4, B_DT4, B_CAT4, 0);
+  block("4_tr", T[4], 2, B_D4, B_DT4, B_UD4, B_CAT4, 0);
   conv("conv3_tr", "norm3_tr", 27, C[3] + T[4], T[3], M_UP, 1, 1, B_CAT4, 0, B_D2, 0, -1, 0);
-  block("block3_tr", T[3], 1, B_D2, B_DT2, B_CAT2, 0);
+  block("3_tr", T[3], 1, B_D2, B_DT2, B_UD2, B_CAT2, 0);
   conv("conv2_tr", "norm2_tr", 27, C[2] + T[3], T[2], M_UP, 0, 0, B_CAT2, 0, B_D1, 0, -1, 0);
-  block("block2_tr", T[2], 0, B_D1, B_DT1, B_CAT1, 0);
+  block("2_tr", T[2], 0, B_D1, B_DT1, B_UD1, B_CAT1, 0);
   conv("conv1_tr", "", 1, C[1] + T[2], T[1], M_IDENT, 0, 0, B_CAT1, 0, B_H, 0, -1, 1);
   conv("final", "", 1, T[1], d.out_channels, M_IDENT, 0, 0, B_H, 0, B_OUT, 0, -1, 0);
   L.back().has_bias = 1;
@@ -108,12 +123,13 @@ void build_plan(const eyoc_model_desc& d, std::vector<LayerPlan>& L, BufPlan* bu
   size_t off = 0;
   for (auto& p : L) {
     p.w_off = off;
-    off += pad64((size_t)p.K * p.cin * p.cout);
+    off += p.map == M_AFFINE ? pad64((size_t)p.cout) : pad64((size_t)p.K * p.cin * p.cout);    // a stand-alone norm: its scale per channel
     p.b_off = off;
     off += pad64((size_t)p.cout);
   }
   // second half of the blob: the SPLIT16 packing of every sparse-conv layer (spconv_wave.hip, MATH = 1)
   for (auto& p : L) {
+    if (p.map == M_AFFINE) continue;
     if (p.map != M_CONV1) {
       p.w16_off = off;
       off += pad64((size_t)p.K * p.cin * p.cout);
@@ -123,11 +139,46 @@ void build_plan(const eyoc_model_desc& d, std::vector<LayerPlan>& L, BufPlan* bu
   }
 }
 
+// y = x * scale[c] + shift[c] on fp32 or SPLIT16 rows (the format of its neighbours in the plan); one thread per 4 channels.  SPLIT16
+// rows carry the range guard like every other kernel that writes them (spconv.h split16_guard)
+template <bool SPLIT>
+__global__ void __launch_bounds__(256) k_affine(const float* __restrict__ in, int ld_in, int n, int c, const float* __restrict__ scale,
+                                                const float* __restrict__ shift, float* __restrict__ out, int ld_out, unsigned int* range) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int q4 = c / 4;
+  const long long r = t / q4;
+  const int ch = (int)(t % q4) * 4;
+  float mx = 0.0f;
+  if (r < n) {
+    const float4 s = *reinterpret_cast<const float4*>(scale + ch), b = *reinterpret_cast<const float4*>(shift + ch);
+    float4 v = SPLIT ? split16_load4(in + r * ld_in, ch) : *reinterpret_cast<const float4*>(in + r * ld_in + ch);
+    v.x = fmaf(v.x, s.x, b.x); v.y = fmaf(v.y, s.y, b.y); v.z = fmaf(v.z, s.z, b.z); v.w = fmaf(v.w, s.w, b.w);
+    if (SPLIT) { split16_track(mx, v); split16_store4(out + r * ld_out, ch, v); }
+    else *reinterpret_cast<float4*>(out + r * ld_out + ch) = v;
+  }
+  if (SPLIT) {
+    for (int o = 32; o; o >>= 1) mx = split16_merge(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) split16_report(range, mx);
+  }
+}
+
+int launch_affine(const float* in, int ld_in, int n, int c, const float* scale, const float* shift, float* out, int ld_out, bool split,
+                  unsigned int* range, hipStream_t st) {
+  EYOC_REQUIRE(c % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0 && (!split || (c % 32 == 0 && ld_in % 32 == 0 && ld_out % 32 == 0)),
+               EYOC_ERR_INVALID, "model: stand-alone norm over %d channels (rows of %d -> %d floats)", c, ld_in, ld_out);
+  if (!n) return EYOC_OK;
+  const dim3 grid((unsigned)cdiv((long long)n * (c / 4), 256));
+  if (split) hipLaunchKernelGGL(k_affine<true>, grid, dim3(256), 0, st, in, ld_in, n, c, scale, shift, out, ld_out, range);
+  else hipLaunchKernelGGL(k_affine<false>, grid, dim3(256), 0, st, in, ld_in, n, c, scale, shift, out, ld_out, range);
+  EYOC_CHECK_HIP(hipGetLastError());
+  return EYOC_OK;
+}
+
 size_t plan_blob_floats(const std::vector<LayerPlan>& L) {
   size_t end = 0;
   for (auto& p : L) {
     end = std::max(end, p.b_off + pad64(p.cout));
-    end = std::max(end, p.s_off + 64);
+    if (p.map != M_AFFINE) end = std::max(end, p.s_off + 64);
   }
   return end;
 }
@@ -141,6 +192,7 @@ const eyoc_layer_params* find_layer(const eyoc_layer_params* layers, int n, cons
 int check_desc(const eyoc_model_desc* d) {
   EYOC_REQUIRE(d, EYOC_ERR_INVALID, "model: NULL desc");
   EYOC_REQUIRE(d->in_channels >= 1 && d->in_channels <= 64, EYOC_ERR_INVALID, "model: in_channels %d", d->in_channels);
+  EYOC_REQUIRE(d->expanded == 0 || d->expanded == 1, EYOC_ERR_INVALID, "model: expanded %d not in {0, 1}", d->expanded);
   EYOC_REQUIRE(d->out_channels == 32 || d->out_channels == 64 || d->out_channels == 128, EYOC_ERR_INVALID,
                "model: out_channels %d not in {32,64,128}", d->out_channels);
   EYOC_REQUIRE(d->conv1_kernel_size == 1 || d->conv1_kernel_size == 3 || d->conv1_kernel_size == 5 ||
@@ -180,6 +232,17 @@ int eyoc_model_pack_host(const eyoc_model_desc* desc, const eyoc_layer_params* l
   EYOC_REQUIRE(blob_floats >= need, EYOC_ERR_INVALID, "eyoc_model_pack_host: blob of %zu floats required, got %zu", need, blob_floats);
   std::fill(blob_host, blob_host + need, 0.0f);
   for (auto& p : plan) {
+    if (p.map == M_AFFINE) {                                            // scale / shift of a norm that stands alone (the same fold as below)
+      const eyoc_layer_params* bn = find_layer(layers, n_layers, p.norm);
+      EYOC_REQUIRE(bn && bn->bn_weight && bn->bn_bias && bn->bn_mean && bn->bn_var && bn->cout == p.cout, EYOC_ERR_INVALID,
+                   "eyoc_model_create: norm '%s' missing or wrong width", p.norm.c_str());
+      for (int c = 0; c < p.cout; ++c) {
+        const float s = bn->bn_weight[c] / std::sqrt(bn->bn_var[c] + desc->bn_eps);
+        blob_host[p.w_off + c] = s;
+        blob_host[p.b_off + c] = bn->bn_bias[c] - bn->bn_mean[c] * s;
+      }
+      continue;
+    }
     const eyoc_layer_params* cv = find_layer(layers, n_layers, p.name);
     EYOC_REQUIRE(cv && cv->kernel && cv->K == p.K && cv->cin == p.cin && cv->cout == p.cout, EYOC_ERR_INVALID,
                  "eyoc_model_create: layer '%s' missing or shape mismatch (expected K=%d cin=%d cout=%d, got %d %d %d)",
@@ -406,7 +469,10 @@ int eyoc_model_forward(eyoc_ctx* ctx, const eyoc_model* mc, const eyoc_maps* map
       EYOC_CHECK_HIP(hipEventRecord(m->progress_event, st));
       progress_recorded = true;
     }
-    if (p.map == M_CONV1) {
+    if (p.map == M_AFFINE) {
+      rc = launch_affine(buf[p.in_buf] + p.in_col, m->bufs[p.in_buf].width, n_out, p.cout, m->blob + p.w_off, m->blob + p.b_off,
+                         buf[p.out_buf] + p.out_col, m->bufs[p.out_buf].width, split, split ? m->range : nullptr, st);
+    } else if (p.map == M_CONV1) {
       Conv1Args a;
       a.coords = maps->coords[0]; a.n = n_out; a.table = maps->table[0]; a.ks = m->desc.conv1_kernel_size;
       a.in = buf[p.in_buf]; a.cin = p.cin; a.w = m->blob + p.w_off; a.bias = m->blob + p.b_off; a.cout = p.cout;
@@ -538,6 +604,15 @@ int eyoc_model_layer_work(eyoc_ctx* ctx, const eyoc_model* m, const eyoc_maps* m
       case M_DOWN: pr = (double)info.pairs_down[p.level]; n_in = maps->rows[p.level]; break;
       case M_UP: pr = (double)info.pairs_up[p.level]; n_in = maps->rows[p.level + 1]; break;
       case M_IDENT: pr = n_out; break;
+      case M_AFFINE: break;
+    }
+    if (p.map == M_AFFINE) {                                             // no products: one read and one write of the rows
+      if (names) names[li] = p.name.c_str();
+      if (pairs) pairs[li] = 0;
+      if (flops) flops[li] = 2.0 * n_out * p.cout;
+      if (gather_bytes) gather_bytes[li] = 8.0 * n_out * p.cout;
+      if (compulsory_bytes) compulsory_bytes[li] = 8.0 * n_out * p.cout;
+      continue;
     }
     const double wbytes = 4.0 * p.K * p.cin * p.cout;
     if (names) names[li] = p.name.c_str();

@@ -61,19 +61,6 @@ def broadcast_model(model, device, src: int = 0):
     device = torch.device(device)
     rank = dist.get_rank() if dist.is_initialized() else 0
     on_gpu = device.type == "cuda"
-    if getattr(model, "EXPANDED", False):
-        # ResUNetExpanded / ResUNetExpBN2C run layer by layer from their parameters (the blob holds the ResUNet2 plan only):
-        # their state ships as it is - one flat message of every parameter and buffer, in state_dict order
-        sd = model.state_dict()
-        flat = torch.cat([v.detach().reshape(-1).to(torch.float32) for v in sd.values()]).to(device)
-        broadcast_blob(flat, src)
-        if rank != src:
-            off = 0
-            with torch.no_grad():
-                for v in sd.values():
-                    v.copy_(flat[off:off + v.numel()].reshape(v.shape).to(v.dtype))
-                    off += v.numel()
-        return flat
     if rank == src:
         blob = model.pack(device) if on_gpu else model.pack_host()
     else:

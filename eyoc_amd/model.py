@@ -112,6 +112,7 @@ class ResUNet2(nn.Module):
         for i in range(1, 5):
             d.channels[i], d.tr_channels[i] = self.CHANNELS[i], self.TR_CHANNELS[i]
         d.bn_eps = 1e-5
+        d.expanded = 1 if self.EXPANDED else 0
         return d
 
     def _weights_version(self):
@@ -200,16 +201,9 @@ class ResUNet2(nn.Module):
         changed; it is MANDATORY after edits that fingerprint cannot see (``p.data`` edits, writes through views)."""
         return self.pack(self._packed_device)
 
-    def _no_blob_for_expanded(self, what):
-        if self.EXPANDED:
-            raise NotImplementedError(f"{type(self).__name__}.{what}: the packed blob holds the ResUNet2 layer plan only - the Expanded "
-                                      "variants (norm<i>_2 / block<i>_2) run layer by layer from their parameters; ship their "
-                                      "state_dict between ranks (eyoc_amd.dist.broadcast_model does)")
-
     def pack_host(self) -> torch.Tensor:
         """The packed blob as a CPU tensor (``eyoc_model_pack_host``: batch norms folded, fp32 fragment order + split16
         packing) - byte for byte what ``pack()`` uploads.  Needs the shared library but no GPU."""
-        self._no_blob_for_expanded("pack_host")
         lib = _lib.load()
         blob = torch.zeros(self.blob_floats(), dtype=torch.float32)
         d = self._desc()
@@ -221,7 +215,6 @@ class ResUNet2(nn.Module):
     def pack(self, device=None, blob: torch.Tensor | None = None, from_blob=False):
         """(Re)create the device-side model.  ``from_blob=True`` adopts an already packed blob (the
         receiving side of the weight broadcast) instead of packing this module's parameters."""
-        self._no_blob_for_expanded("pack")
         lib = _lib.load()
         device = torch.device(device) if device is not None else self.final.kernel.device
         if device.type != "cuda":
@@ -266,14 +259,10 @@ class ResUNet2(nn.Module):
             raise TypeError("expected an eyoc_amd.SparseTensor")
         if x.F.shape[1] != self.in_channels:
             raise ValueError(f"features have {x.F.shape[1]} channels, model expects {self.in_channels}")
-        if self.training or self.EXPANDED:
-            # training mode: batch statistics + autograd (lib/trainer.py:1655-1676).  The Expanded variants (a second norm behind
-            # every ReLU: not foldable into a convolution) run layer by layer in eval mode too - functional, not the fused path
+        if self.training:
+            # training mode: batch statistics + autograd (lib/trainer.py:1655-1676), layer by layer
             from .train import forward_layers
-            if self.training:
-                return forward_layers(self, x)
-            with torch.no_grad():
-                return forward_layers(self, x)
+            return forward_layers(self, x)
         dev = x.device
         if self._handle is None or self._packed_device != dev:
             self.pack(dev)
@@ -461,8 +450,9 @@ class ResUNetFatBN(ResUNet2):
 
 
 class ResUNetExpanded(ResUNet2):
-    """model/resunet.py:254-484: ``ResUNet2`` with ``norm<i>_2`` + ``block<i>_2`` behind every stage's block.  Runs layer by layer
-    (``eyoc_amd/train.py``) in both modes; the packed / fused eval kernels serve the ``ResUNet2`` family only."""
+    """model/resunet.py:254-484: ``ResUNet2`` with ``norm<i>_2`` + ``block<i>_2`` behind every stage's block.  Eval mode runs the
+    packed plan like the rest of the family (``eyoc_model_desc.expanded``: the second norm of a stage is one elementwise layer, the
+    second block two more staged convolutions); training mode runs layer by layer (``eyoc_amd/train.py``)."""
     EXPANDED = True
     NORM_TYPE = None
 

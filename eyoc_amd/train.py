@@ -199,7 +199,8 @@ def forward_train(model, x: SparseTensor, taps: dict | None = None) -> SparseTen
 def forward_layers(model, x: SparseTensor, taps: dict | None = None) -> SparseTensor:
     """The network layer by layer through the autograd Functions above - ``ResUNet2`` (model/resunet.py:142-193) and
     ``ResUNetExpanded`` (:254-484: every stage runs a second norm + block, ``norm<i>_2`` / ``block<i>_2``).  In training mode
-    every norm uses batch statistics; in eval mode its running statistics (a per-channel affine, element-wise)."""
+    every norm uses batch statistics; in eval mode its running statistics (a per-channel affine, element-wise) - ``model(x)`` in eval
+    mode does not come here (it runs the packed plan, csrc/model.hip); tests call this under ``no_grad`` to have the same network twice."""
     cm = x.coordinate_manager
     # The layers run in the rows of the forward's own maps: from 8192 rows on those are Z-ordered (eyoc_maps_build_ordered(-1): one
     # sort + top-down derivation, two host synchronisations) - a second set of maps in the caller's order is the hash-table build with a

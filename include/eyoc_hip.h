@@ -41,9 +41,10 @@ typedef enum {
 } eyoc_status;
 
 #define EYOC_MAX_LEVELS 4
-/* 110 (round 6): the kernel-selection setters and eyoc_ransac_workspace_bytes take the ctx first (round 5), eyoc_maps_gather_window
+/* 111 (round 6): eyoc_model_desc ends with `expanded` (ResUNetExpanded / ResUNetExpBN2C run through eyoc_model_forward too).
+ * 110 (round 6): the kernel-selection setters and eyoc_ransac_workspace_bytes take the ctx first (round 5), eyoc_maps_gather_window
  * refuses Z-ordered maps again and eyoc_maps_gather_window_internal exists, eyoc_model_workspace_bytes depends on the maps' size class */
-#define EYOC_VERSION 110
+#define EYOC_VERSION 111
 
 /* ------------------------------------------------------------------------------------------------
  * context
@@ -294,6 +295,9 @@ typedef struct {
   int32_t channels[5];     /* CHANNELS    = [-, 32, 64, 128, 256] for BN2C (index 0 unused) */
   int32_t tr_channels[5];  /* TR_CHANNELS = [-, 64, 64, 64, 128]  for BN2C                   */
   float bn_eps;            /* 1e-5 */
+  int32_t expanded;        /* EYOC_VERSION >= 111.  1 = ResUNetExpanded (model/resunet.py:254-484): every stage runs
+                              block<i> -> norm<i>_2 -> block<i>_2; the layer list then also names "norm<i>_2" (a batch norm that
+                              stands alone: one elementwise layer of the plan) and "block<i>_2.conv1" ... for i in 1..4, 4_tr..2_tr */
 } eyoc_model_desc;
 
 typedef struct {

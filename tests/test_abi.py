@@ -31,14 +31,14 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(lib, s), f"{s} declared in eyoc_hip.h but not exported"
         assert s in _lib.PROTOTYPES, f"{s} has no ctypes prototype"
     assert set(_lib.PROTOTYPES) <= set(syms)
-    assert lib.eyoc_version() == 110
+    assert lib.eyoc_version() == 111
 
 
 def test_struct_sizes_match_header():
     assert C.sizeof(_lib.RansacResult) == 16 * 4 + 4 * 4
     assert C.sizeof(_lib.RansacParams) == 16
     assert C.sizeof(_lib.Sc2pcrParams) == 32
-    assert C.sizeof(_lib.ModelDesc) == 4 * 4 + 5 * 4 + 5 * 4 + 4
+    assert C.sizeof(_lib.ModelDesc) == 4 * 4 + 5 * 4 + 5 * 4 + 4 + 4
     assert C.sizeof(_lib.MapsInfo) == 8 + 4 * 4 + (3 * 4 + 1) * 8
 
 

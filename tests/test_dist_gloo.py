@@ -98,8 +98,8 @@ def test_broadcast_model_ships_the_real_packed_blob(tmp_path):
 
 
 def _expanded_worker(rank, world, port, out_dir):
-    """``ResUNetExpBN2C`` has parameters the packed blob does not hold (``norm<i>_2`` / ``block<i>_2``) -
-    ``broadcast_model`` ships its state as it is, and ``pack`` / ``pack_host`` refuse instead of silently dropping them."""
+    """``ResUNetExpBN2C`` (model/resunet.py:487-490) packs like the rest of the family since EYOC_VERSION 111: the blob holds the
+    ``norm<i>_2`` scale / shift and the ``block<i>_2`` weights too, and ``broadcast_model`` ships it as one message."""
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     import eyoc_amd
@@ -110,28 +110,24 @@ def _expanded_worker(rank, world, port, out_dir):
         if isinstance(m, torch.nn.BatchNorm1d):
             m.running_mean.normal_()
             m.running_var.uniform_(0.5, 1.5)
-    with pytest.raises(NotImplementedError):
-        model.pack_host()
-    before = {k: v.clone() for k, v in model.state_dict().items()}
-    edist.broadcast_model(model, torch.device("cpu"), src=0)
-    after = model.state_dict()
-    if rank == 0:
-        assert all(torch.equal(before[k], after[k]) for k in before)
-    else:
-        assert any(not torch.equal(before[k], after[k]) for k in before)
-    torch.save({k: v.clone() for k, v in after.items()}, os.path.join(out_dir, f"sd{rank}.pt"))
+    own = model.pack_host()
+    plain = eyoc_amd.load_model("ResUNetBN2C")(1, 32, bn_momentum=0.05, conv1_kernel_size=5, normalize_feature=True)
+    extra = 2 * 27 * (32 * 32 + 3 * 64 * 64 + 2 * 128 * 128 + 256 * 256)     # the seven block<i>_2: two convolutions each
+    assert own.numel() == model.blob_floats() >= plain.blob_floats() + 2 * extra    # fp32 fragment order + split16 packing
+    blob = edist.broadcast_model(model, torch.device("cpu"), src=0)
+    assert torch.equal(blob, own) == (rank == 0)
+    np.save(os.path.join(out_dir, f"blob{rank}.npy"), blob.numpy())
     dist.destroy_process_group()
 
 
-def test_broadcast_model_ships_the_state_of_an_expanded_model(tmp_path):
+def test_broadcast_model_ships_the_blob_of_an_expanded_model(tmp_path):
     from eyoc_amd import _lib
     if not os.path.exists(_lib.LIB_PATH):
         pytest.skip("libeyoc_hip.so not built")
     mp.spawn(_expanded_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    a, b = torch.load(tmp_path / "sd0.pt"), torch.load(tmp_path / "sd1.pt")
-    assert any(k.startswith("block3_2.") for k in a) and any(k.startswith("norm4_tr_2.") for k in a)
-    for k in a:
-        assert torch.equal(a[k], b[k]), k
+    a, b = np.load(tmp_path / "blob0.npy"), np.load(tmp_path / "blob1.npy")
+    np.testing.assert_array_equal(a, b)
+    assert np.count_nonzero(a) > a.size // 2
 
 
 def _model_worker8(rank, world, port, out_dir):
