@@ -157,6 +157,7 @@ PROTOTYPES = {
     "eyoc_sc2pcr_batched_workspace_bytes_n": (_sz, [_i, _i, C.POINTER(Sc2pcrParams)]),
     "eyoc_sc2pcr_set_shortlist_cap": (_i, [_vp, _i]),
     "eyoc_sc2pcr_set_dense_threshold": (_i, [_vp, _i]),
+    "eyoc_sc2pcr_select_kernels": (_i, [_vp, _i]),
     "eyoc_sc2pcr_batched": (_i, [_vp, _vp, _vp, C.POINTER(C.c_int32), _i, C.POINTER(Sc2pcrParams), _vp, _vp, _i, _vp, _sz,
                                  _vp]),
 }

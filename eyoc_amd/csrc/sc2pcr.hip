@@ -32,11 +32,43 @@ struct Sc2Ctl {          // device-side control block
   int pad[2];
 };
 
+// Squared length with the roundings PINNED (round 6): one rounded product, two fused multiply-adds.  Written as `dx * dx + dy * dy +
+// dz * dz` the compiler chose per call site - fused chains in one kernel, a packed multiply and one fma in another - so two kernels
+// could disagree in the last bit about the same pair (a hard-mask bit whose CSR value then came out 0), and the A/B forms of a kernel
+// (eyoc_sc2pcr_select_kernels) could not be compared bit for bit.  The reference's torch kernels promise no particular order either.
+__device__ inline float sq_len(float dx, float dy, float dz) { return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)); }
 __device__ inline float cross_len(float sx, float sy, float sz, float tx, float ty, float tz, float sjx, float sjy,
                                   float sjz, float tjx, float tjy, float tjz) {
-  const float dx = sx - sjx, dy = sy - sjy, dz = sz - sjz;
-  const float ex = tx - tjx, ey = ty - tjy, ez = tz - tjz;
-  return fabsf(sqrtf(dx * dx + dy * dy + dz * dz) - sqrtf(ex * ex + ey * ey + ez * ez));
+  return fabsf(sqrtf(sq_len(sx - sjx, sy - sjy, sz - sjz)) - sqrtf(sq_len(tx - tjx, ty - tjy, tz - tjz)));
+}
+// first-order compatibility of a cross length (SC2_PCR.py:317-319), roundings pinned likewise
+__device__ inline float sc_value(float c, float inv_d2) { return fmaxf(__builtin_fmaf(-(c * c), inv_d2, 1.0f), 0.0f); }
+
+// ---- round 6: the square roots of the O(N^2) sweeps.  sqrtf is correctly rounded (clang's default for HIP: v_sqrt_f32 plus a
+// +-1 ulp fix-up from two fma residuals, ~14 VALU slots), hence monotone:  { x >= 0 : sqrtf(x) < R } = { x < T }  for
+// T = min { x : sqrtf(x) >= R }.  T is found from fl(R R) by stepping ulps (a handful of sqrtf per thread, once per kernel); the
+// sweeps then compare the squared length with T - the same decisions, bit for bit, without a square root per pair.
+// R <= 0: never true (T = 0); R = inf: true for every finite x (T = inf); R NaN: never true (T = NaN).
+__device__ inline float sqrt_lt_threshold(float R) {
+  if (!(R > 0.0f)) return R != R ? R : 0.0f;
+  if (R > 3.0e38f * 1.1f) return R;                            // inf
+  float t = R * R;                                             // may be inf (R > 1.8e19) or 0 (R < 1e-23): the loops walk back in
+  while (t > 0.0f && sqrtf(t) >= R) t = __uint_as_float(__float_as_uint(t) - 1u);    // inf - 1 ulp = FLT_MAX
+  while (sqrtf(t) < R) t = __uint_as_float(__float_as_uint(t) + 1u);                 // FLT_MAX + 1 ulp = inf: sqrtf(inf) < R is false
+  return t;
+}
+// The cross length |sqrt(a) - sqrt(b)| against a threshold: v_sqrt_f32 alone (1 ulp) decides all but the residuals within `band` of
+// it.  With sa', sb' within 2^-23 of the rounded roots and one rounding in each difference, |c' - c| <= 1.5 * 2^-22 max(sa, sb); the
+// band is 2^-20 max(sa', sb') + 1e-18 (v_sqrt_f32 flushes denormal inputs: roots below 1.1e-19 read 0).  A wave with an undecided
+// lane takes the exact expression for all of them (about one 64 x 64 tile row in 10^4).
+struct CrossFast { float c, band; };
+__device__ inline CrossFast cross_len_fast(float sx, float sy, float sz, float tx, float ty, float tz, float sjx, float sjy,
+                                           float sjz, float tjx, float tjy, float tjz) {
+  const float sa = __builtin_amdgcn_sqrtf(sq_len(sx - sjx, sy - sjy, sz - sjz)), sb = __builtin_amdgcn_sqrtf(sq_len(tx - tjx, ty - tjy, tz - tjz));
+  CrossFast r;
+  r.c = fabsf(sa - sb);
+  r.band = fmaf(fmaxf(sa, sb), 0x1p-20f, 1e-18f);
+  return r;
 }
 
 // ---- y = SC x (one sweep).  256 threads = 256 rows; grid.y splits the COLUMNS (a lane-per-row kernel over all
@@ -63,8 +95,7 @@ __device__ __forceinline__ void d_sc_matvec(const float* __restrict__ src, const
     for (int j = 0; j < cnt; ++j) {
       const float c = cross_len(sx, sy, sz, tx, ty, tz, ls[3 * j], ls[3 * j + 1], ls[3 * j + 2], lt[3 * j],
                                 lt[3 * j + 1], lt[3 * j + 2]);
-      const float sc = fmaxf(1.0f - c * c * inv_d2, 0.0f);
-      acc += sc * lx[j];
+      acc = __builtin_fmaf(sc_value(c, inv_d2), lx[j], acc);
     }
   }
   if (ok) part[(size_t)blockIdx.y * n + i] = acc;
@@ -124,7 +155,7 @@ __device__ __forceinline__ void d_sc_normalize(const double* __restrict__ block_
 // ---- bit matrices: hard[i][w] bit b = cross(i, 64 w + b) < d ; tight = < d/2.   One wave per (row, 64 columns).
 __device__ __forceinline__ void d_masks(const float* __restrict__ src, const float* __restrict__ tgt, int n,
                                                int words, float d, unsigned long long* __restrict__ hard,
-                                               unsigned long long* __restrict__ tight) {
+                                               unsigned long long* __restrict__ tight, int legacy) {
   // one wave per 64 x 64 tile: the lane's column stays in registers, the 64 rows come through LDS broadcasts, and
   // lane r keeps the two ballots of row r, so a tile costs 12 loads per lane instead of 12 per cross length
   __shared__ float rows[4][64 * 6];
@@ -149,10 +180,27 @@ __device__ __forceinline__ void d_masks(const float* __restrict__ src, const flo
   const float tjx = tgt[3 * jj], tjy = tgt[3 * jj + 1], tjz = tgt[3 * jj + 2];
   unsigned long long my_h = 0, my_t = 0;
   const int rows_here = min(64, n - ti * 64);
+  const float dh = 0.5f * d;
+  const bool fast_ok = !legacy && d > 0.0f && d < 1e30f;           // (a NaN / huge / non-positive d: the plain expression)
   for (int r = 0; r < rows_here; ++r) {
-    const float c = cross_len(R[r * 6], R[r * 6 + 1], R[r * 6 + 2], R[r * 6 + 3], R[r * 6 + 4], R[r * 6 + 5], sjx, sjy, sjz, tjx,
-                              tjy, tjz);
-    const unsigned long long hm = __ballot(j < n && c < d), tm = __ballot(j < n && c < 0.5f * d);
+    unsigned long long hm, tm;
+    bool exact = !fast_ok;
+    if (fast_ok) {
+      const CrossFast f = cross_len_fast(R[r * 6], R[r * 6 + 1], R[r * 6 + 2], R[r * 6 + 3], R[r * 6 + 4], R[r * 6 + 5], sjx, sjy, sjz,
+                                         tjx, tjy, tjz);
+      const float e1 = f.c - d, e2 = f.c - dh;                     // NaN / inf coordinates: every comparison below is false -> undecided
+      const bool in1 = e1 < -f.band, in2 = e2 < -f.band;
+      const bool und = !(in1 || e1 > f.band) || !(in2 || e2 > f.band);
+      hm = __ballot(j < n && in1);
+      tm = __ballot(j < n && in2);
+      exact = __any(und);
+    }
+    if (exact) {                                                   // wave-uniform
+      const float c = cross_len(R[r * 6], R[r * 6 + 1], R[r * 6 + 2], R[r * 6 + 3], R[r * 6 + 4], R[r * 6 + 5], sjx, sjy, sjz, tjx,
+                                tjy, tjz);
+      hm = __ballot(j < n && c < d);
+      tm = __ballot(j < n && c < dh);
+    }
     if (lane == r) { my_h = hm; my_t = tm; }
   }
   if (lane < rows_here) {
@@ -230,30 +278,71 @@ __device__ __forceinline__ void d_csr_scan(int* __restrict__ cnt_h, int n, long 
   if (threadIdx.x == 0 && carry > cap) ctl->dense = 1;
 }
 
-// one wave per row: the set bits of the two mask rows become ascending column lists (+ the SC value for the hard one)
+// one wave per row: the set bits of the hard mask row become an ascending column list + the SC values.
+// Round 6: the row is compacted first.  Up to round 5 the wave walked the row word by word and evaluated the cross length under the
+// word's bits as the execution mask - `words` (125 at n = 8000) trips through ~70 VALU slots with a few percent of the lanes
+// alive, 1.04 ms per 16-pair step, the largest kernel of the back-end.  Now lane l takes word w0 + l of a 64-word chunk, a wave scan
+// of the popcounts gives every word its place, the lanes write their words' columns into a wave-private LDS list (a trip per set bit
+// of the fullest word), and the list is then worked off 64 entries at a time with every lane busy; columns and values leave as
+// contiguous runs.  Same expression per entry, same order: the arrays are what they were, bit for bit.
+constexpr int CSR_LIST = 64 * 64;       // columns of a 64-word chunk
 __device__ __forceinline__ void d_csr_fill(const float* __restrict__ src, const float* __restrict__ tgt, int n, int words,
                                            float inv_d2, const unsigned long long* __restrict__ hard,
                                            const int* __restrict__ ptr_h, unsigned short* __restrict__ col_h,
-                                           float* __restrict__ val_h, const Sc2Ctl* __restrict__ ctl) {
+                                           float* __restrict__ val_h, const Sc2Ctl* __restrict__ ctl, int legacy) {
   if (ctl->dense) return;
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= n) return;
+  __shared__ unsigned short list[4][CSR_LIST];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= n) return;                                              // wave-uniform; no workgroup barrier below
   const float sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
   const float tx = tgt[3 * i], ty = tgt[3 * i + 1], tz = tgt[3 * i + 2];
   int oh = ptr_h[i];
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  for (int w = 0; w < words; ++w) {
-    const unsigned long long hm = hard[(size_t)i * words + w];
-    const int j = w * 64 + lane;
-    if ((hm >> lane) & 1ull) {
+  if (legacy) {                                                    // the round-5 walk (eyoc_sc2pcr_select_kernels bit 0)
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int w = 0; w < words; ++w) {
+      const unsigned long long hm = hard[(size_t)i * words + w];
+      const int j = w * 64 + lane;
+      if ((hm >> lane) & 1ull) {
+        const float c = cross_len(sx, sy, sz, tx, ty, tz, src[3 * j], src[3 * j + 1], src[3 * j + 2], tgt[3 * j], tgt[3 * j + 1],
+                                  tgt[3 * j + 2]);
+        const int pos = oh + __popcll(hm & lt);
+        col_h[pos] = (unsigned short)j;
+        val_h[pos] = sc_value(c, inv_d2);   // the expression of the dense sweep
+      }
+      oh += __popcll(hm);
+    }
+    return;
+  }
+  unsigned short* L = list[wave];
+  for (int w0 = 0; w0 < words; w0 += 64) {
+    const int w = w0 + lane;
+    unsigned long long m = w < words ? hard[(size_t)i * words + w] : 0ull;
+    const int pc = __popcll(m);
+    int incl = pc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    const int total = __shfl(incl, 63, 64);
+    int p = incl - pc;
+    while (m) {                                                    // columns of word w in ascending order
+      L[p++] = (unsigned short)(w * 64 + __builtin_ctzll(m));
+      m &= m - 1ull;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");         // wave-private list: writes before the reads below
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < total; k += 64) {
+      const int j = L[k];
       const float c = cross_len(sx, sy, sz, tx, ty, tz, src[3 * j], src[3 * j + 1], src[3 * j + 2], tgt[3 * j], tgt[3 * j + 1],
                                 tgt[3 * j + 2]);
-      const int pos = oh + __popcll(hm & lt);
-      col_h[pos] = (unsigned short)j;
-      val_h[pos] = fmaxf(1.0f - c * c * inv_d2, 0.0f);   // the expression of the dense sweep
+      col_h[oh + k] = (unsigned short)j;
+      val_h[oh + k] = sc_value(c, inv_d2);   // the expression of the dense sweep
     }
-    oh += __popcll(hm);
+    oh += total;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");         // ... and the reads before the next chunk's writes
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -276,13 +365,14 @@ __device__ __forceinline__ void d_sc_spmv(const int* __restrict__ ptr_h, const u
 // ---- non-maximum suppression in source space: score = conf if no j within R has a larger conf, else 0
 // grid.y splits the columns; `dom` (zero-initialised) collects "some column dominates row i" with atomicOr.
 __device__ __forceinline__ void d_nms(const float* __restrict__ src, const float* __restrict__ conf, int n, float R,
-                                             int col_chunk, int* __restrict__ dom) {
+                                             int col_chunk, int* __restrict__ dom, int legacy) {
   __shared__ float ls[1024 * 3], lc[1024];
   const int i = blockIdx.x * 256 + threadIdx.x;
   const bool ok = i < n;
   const int ii = ok ? i : 0;
   const float sx = src[3 * ii], sy = src[3 * ii + 1], sz = src[3 * ii + 2], ci = conf[ii];
   bool dominated = false;
+  const float T = sqrt_lt_threshold(R);                 // sqrtf(x) < R  <=>  x < T
   const int c_begin = blockIdx.y * col_chunk, c_end = min(n, c_begin + col_chunk);
   for (int j0 = c_begin; j0 < c_end; j0 += 1024) {
     const int cnt = min(1024, c_end - j0);
@@ -290,9 +380,16 @@ __device__ __forceinline__ void d_nms(const float* __restrict__ src, const float
     for (int t = threadIdx.x; t < cnt * 3; t += 256) ls[t] = src[3 * j0 + t];
     for (int t = threadIdx.x; t < cnt; t += 256) lc[t] = conf[j0 + t];
     __syncthreads();
-    for (int j = 0; j < cnt; ++j) {
-      const float dx = sx - ls[3 * j], dy = sy - ls[3 * j + 1], dz = sz - ls[3 * j + 2];
-      dominated |= (lc[j] > ci) && (sqrtf(dx * dx + dy * dy + dz * dz) < R);
+    if (legacy) {
+      for (int j = 0; j < cnt; ++j) {
+        const float dx = sx - ls[3 * j], dy = sy - ls[3 * j + 1], dz = sz - ls[3 * j + 2];
+        dominated |= (lc[j] > ci) && (sqrtf(sq_len(dx, dy, dz)) < R);
+      }
+    } else {
+      for (int j = 0; j < cnt; ++j) {
+        const float dx = sx - ls[3 * j], dy = sy - ls[3 * j + 1], dz = sz - ls[3 * j + 2];
+        dominated |= (lc[j] > ci) & (sq_len(dx, dy, dz) < T);
+      }
     }
   }
   if (ok && dominated) atomicOr(&dom[i], 1);
@@ -659,7 +756,7 @@ __device__ __forceinline__ void d_seed_dense(const unsigned long long* __restric
 __device__ __forceinline__ void d_seed_solve(const float* __restrict__ src, const float* __restrict__ tgt, int n,
                                                     int n_seed, const int* __restrict__ knn1, int k1, int k2, float d,
                                                     int max_iter, float inlier_thr, float* __restrict__ Ts,
-                                                    float* __restrict__ fitness) {
+                                                    float* __restrict__ fitness, int legacy) {
   __shared__ volatile int inv[4][K1_MAX];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int s = blockIdx.x * 4 + wv;
@@ -699,7 +796,7 @@ __device__ __forceinline__ void d_seed_solve(const float* __restrict__ src, cons
     if (b < k2) {
       const float c = cross_len(px, py, pz, qx, qy, qz, __shfl(px, b, 64), __shfl(py, b, 64), __shfl(pz, b, 64),
                                 __shfl(qx, b, 64), __shfl(qy, b, 64), __shfl(qz, b, 64));
-      v = (b == lane) ? 0.0f : fmaxf(1.0f - c * c * inv_d2, 0.0f);
+      v = (b == lane) ? 0.0f : sc_value(c, inv_d2);
     }
     S[b] = v;
   }
@@ -742,12 +839,14 @@ __device__ __forceinline__ void d_seed_solve(const float* __restrict__ src, cons
               r12 = (float)R[1][2], r20 = (float)R[2][0], r21 = (float)R[2][1], r22 = (float)R[2][2];
   const float t0 = (float)t[0], t1 = (float)t[1], t2 = (float)t[2];
   int cnt = 0;
+  const float T_in = legacy ? 0.0f : sqrt_lt_threshold(inlier_thr);      // sqrtf(x) < inlier_thr  <=>  x < T_in
   for (int j = lane; j < n; j += 64) {
     const float x = src[3 * j], yv = src[3 * j + 1], z = src[3 * j + 2];
-    const float dx = r00 * x + r01 * yv + r02 * z + t0 - tgt[3 * j];
-    const float dy = r10 * x + r11 * yv + r12 * z + t1 - tgt[3 * j + 1];
-    const float dz = r20 * x + r21 * yv + r22 * z + t2 - tgt[3 * j + 2];
-    cnt += sqrtf(dx * dx + dy * dy + dz * dz) < inlier_thr;
+    const float dx = (__builtin_fmaf(r02, z, __builtin_fmaf(r01, yv, r00 * x)) + t0) - tgt[3 * j];       // roundings pinned (see sq_len)
+    const float dy = (__builtin_fmaf(r12, z, __builtin_fmaf(r11, yv, r10 * x)) + t1) - tgt[3 * j + 1];
+    const float dz = (__builtin_fmaf(r22, z, __builtin_fmaf(r21, yv, r20 * x)) + t2) - tgt[3 * j + 2];
+    const float d2 = sq_len(dx, dy, dz);
+    cnt += legacy ? sqrtf(d2) < inlier_thr : d2 < T_in;
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
@@ -796,10 +895,10 @@ __device__ __forceinline__ void d_refine(const float* __restrict__ src, const fl
     double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int j = threadIdx.x; j < n; j += 1024) {
       const float x = src[3 * j], y = src[3 * j + 1], z = src[3 * j + 2];
-      const float dx = T[0] * x + T[1] * y + T[2] * z + T[3] - tgt[3 * j];
-      const float dy = T[4] * x + T[5] * y + T[6] * z + T[7] - tgt[3 * j + 1];
-      const float dz = T[8] * x + T[9] * y + T[10] * z + T[11] - tgt[3 * j + 2];
-      const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+      const float dx = (__builtin_fmaf(T[2], z, __builtin_fmaf(T[1], y, T[0] * x)) + T[3]) - tgt[3 * j];     // roundings pinned: both passes see the same inliers
+      const float dy = (__builtin_fmaf(T[6], z, __builtin_fmaf(T[5], y, T[4] * x)) + T[7]) - tgt[3 * j + 1];
+      const float dz = (__builtin_fmaf(T[10], z, __builtin_fmaf(T[9], y, T[8] * x)) + T[11]) - tgt[3 * j + 2];
+      const float dist = sqrtf(sq_len(dx, dy, dz));
       if (dist < refine_thr) {
         const float r = dist / refine_thr;
         const double w = (double)(1.0f / (1.0f + r * r));
@@ -827,10 +926,10 @@ __device__ __forceinline__ void d_refine(const float* __restrict__ src, const fl
     double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int j = threadIdx.x; j < n; j += 1024) {
       const float x = src[3 * j], y = src[3 * j + 1], z = src[3 * j + 2];
-      const float dx = T[0] * x + T[1] * y + T[2] * z + T[3] - tgt[3 * j];
-      const float dy = T[4] * x + T[5] * y + T[6] * z + T[7] - tgt[3 * j + 1];
-      const float dz = T[8] * x + T[9] * y + T[10] * z + T[11] - tgt[3 * j + 2];
-      const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+      const float dx = (__builtin_fmaf(T[2], z, __builtin_fmaf(T[1], y, T[0] * x)) + T[3]) - tgt[3 * j];     // roundings pinned: both passes see the same inliers
+      const float dy = (__builtin_fmaf(T[6], z, __builtin_fmaf(T[5], y, T[4] * x)) + T[7]) - tgt[3 * j + 1];
+      const float dz = (__builtin_fmaf(T[10], z, __builtin_fmaf(T[9], y, T[8] * x)) + T[11]) - tgt[3 * j + 2];
+      const float dist = sqrtf(sq_len(dx, dy, dz));
       if (dist < refine_thr) {
         const float r = dist / refine_thr;
         const double w = (double)(1.0f / (1.0f + r * r));
@@ -888,6 +987,7 @@ struct Sc2Pair {
   int n, words, n_seed, k1, k2, n_part, col_chunk, num_iterations;
   float d, inlier_thr, nms_radius, refine_thr;
   int list_cap, dense_x;      // per-ctx diagnostics (eyoc_sc2pcr_set_shortlist_cap / _set_dense_threshold)
+  int legacy;                 // eyoc_sc2pcr_select_kernels: bit 0 the round-5 CSR fill, bit 1 masks without the v_sqrt pre-test, bit 2 sqrtf in the NMS / fitness sweeps
 };
 struct Sc2Batch { Sc2Pair p[SC2_CHUNK]; };
 static_assert(sizeof(Sc2Batch) <= 4000, "the batch descriptor travels as a kernel argument (4 KB limit)");
@@ -925,7 +1025,7 @@ __global__ __launch_bounds__(256) void k_csr_count(Sc2Batch B) {
 }
 __global__ __launch_bounds__(256) void k_csr_fill(Sc2Batch B) {
   const Sc2Pair& q = B.p[blockIdx.z];
-  d_csr_fill(q.src, q.tgt, q.n, q.words, 1.0f / (q.d * q.d), q.hard, q.ptr_h, q.col_h, q.val_h, q.ctl);
+  d_csr_fill(q.src, q.tgt, q.n, q.words, 1.0f / (q.d * q.d), q.hard, q.ptr_h, q.col_h, q.val_h, q.ctl, q.legacy & 1);
 }
 __global__ __launch_bounds__(1024) void k_sc_normalize(Sc2Batch B, int it) {
   const Sc2Pair& q = B.p[blockIdx.z];
@@ -935,7 +1035,7 @@ __global__ __launch_bounds__(1024) void k_sc_normalize(Sc2Batch B, int it) {
 __global__ __launch_bounds__(256) void k_nms(Sc2Batch B) {
   const Sc2Pair& q = B.p[blockIdx.z];
   if ((int)blockIdx.x * 256 >= q.n || (int)blockIdx.y >= q.n_part) return;
-  d_nms(q.src, q.v, q.n, q.nms_radius, q.col_chunk, q.dom);
+  d_nms(q.src, q.v, q.n, q.nms_radius, q.col_chunk, q.dom, q.legacy & 4);
 }
 __global__ __launch_bounds__(256) void k_nms_score(Sc2Batch B) {
   const Sc2Pair& q = B.p[blockIdx.z];
@@ -952,7 +1052,7 @@ __global__ __launch_bounds__(256) void k_seeds(Sc2Batch B) {
 }
 __global__ __launch_bounds__(256) void k_masks(Sc2Batch B) {
   const Sc2Pair& q = B.p[blockIdx.z];
-  d_masks(q.src, q.tgt, q.n, q.words, q.d, q.hard, q.tight);
+  d_masks(q.src, q.tgt, q.n, q.words, q.d, q.hard, q.tight, q.legacy & 2);
 }
 __global__ __launch_bounds__(64) void k_seed_blocks(Sc2Batch B) {
   const Sc2Pair& q = B.p[blockIdx.z];
@@ -973,7 +1073,7 @@ __global__ __launch_bounds__(256) void k_seed_topk(Sc2Batch B) {
 }
 __global__ __launch_bounds__(256) void k_seed_solve(Sc2Batch B) {
   const Sc2Pair& q = B.p[blockIdx.z];
-  d_seed_solve(q.src, q.tgt, q.n, q.n_seed, q.knn, q.k1, q.k2, q.d, q.num_iterations, q.inlier_thr, q.Ts, q.fitness);
+  d_seed_solve(q.src, q.tgt, q.n, q.n_seed, q.knn, q.k1, q.k2, q.d, q.num_iterations, q.inlier_thr, q.Ts, q.fitness, q.legacy & 4);
 }
 __global__ __launch_bounds__(1024) void k_refine(Sc2Batch B) {
   const Sc2Pair& q = B.p[blockIdx.z];
@@ -1047,6 +1147,13 @@ int eyoc_sc2pcr_set_dense_threshold(eyoc_ctx* ctx, int x) {
   return prev;
 }
 
+int eyoc_sc2pcr_select_kernels(eyoc_ctx* ctx, int legacy_bits) {
+  if (!ctx) return -1;
+  const int prev = ctx->sc2_legacy;
+  if (legacy_bits >= 0 && legacy_bits <= 7) ctx->sc2_legacy = legacy_bits;
+  return prev;
+}
+
 size_t eyoc_sc2pcr_workspace_bytes(int n, const eyoc_sc2pcr_params* params) {
   if (!params || n < 1 || n > MAX_N) return 0;
   return make_plan(n, params).total;
@@ -1080,7 +1187,7 @@ static int sc2pcr_chunk(eyoc_ctx* ctx, const float* src_dev, const float* tgt_de
     q.d = p->d_thre; q.inlier_thr = p->inlier_threshold; q.nms_radius = p->nms_radius;
     // the reference refines with 0.10 m for its 3DMatch setting and 1.2 m otherwise (SC2_PCR.py:254-257)
     q.refine_thr = p->inlier_threshold == 0.10f ? 0.10f : 1.2f;
-    q.list_cap = ctx->sc2_list_cap; q.dense_x = ctx->sc2_dense_x;
+    q.list_cap = ctx->sc2_list_cap; q.dense_x = ctx->sc2_dense_x; q.legacy = ctx->sc2_legacy;
     if (c < n_pairs) {
       n_max = n > n_max ? n : n_max; part_max = pl.n_part > part_max ? pl.n_part : part_max;
       seed_max = pl.n_seed > seed_max ? pl.n_seed : seed_max; words_max = pl.words > words_max ? pl.words : words_max;

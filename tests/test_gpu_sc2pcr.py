@@ -146,6 +146,44 @@ def test_seed_stage_paths_agree_bit_for_bit():
             np.testing.assert_array_equal(res[b][1], ref[b][1], err_msg=f"fitness, case {b}, (cap, x) = {key}")
 
 
+def test_round6_kernels_equal_their_round5_forms_bit_for_bit():
+    """Round 6 rewrote three kernels of the back-end without touching a result (csrc/sc2pcr.hip): the CSR fill compacts a row before it
+    evaluates the cross lengths; the mask kernel decides with v_sqrt_f32 and a band and evaluates the correctly rounded expression
+    only for undecided lanes; the NMS and seed-fitness sweeps compare the SQUARED length with T(r) = min {x : sqrtf(x) >= r}.
+    ``eyoc_sc2pcr_select_kernels`` brings the round-5 forms back one by one: poses and all seed-wise fitness values must not move by a
+    bit - noisy pairs at three inlier ratios, exact inliers (cross lengths of exactly 0 and thresholds met from both sides), ragged and
+    tiny sizes, a second parameter set (3DMatch-like thresholds), and coordinates scaled to 1e4 m (large roots: wide bands)."""
+    import eyoc_amd
+    from eyoc_amd import _lib as L
+    T = gi.rigid(0.02, -0.01, 0.1, 4.0, 0.3, -0.2)
+    cases = [(710, 3000, 0.1, 0.03, 1.0), (711, 5000, 0.3, 0.03, 1.0), (712, 8000, 0.6, 0.05, 1.0), (713, 4000, 0.6, 0.0, 1.0),
+             (714, 777, 0.4, 0.02, 1.0), (715, 65, 0.5, 0.01, 1.0), (716, 2000, 0.3, 0.03, 1.0e4), (717, 4097, 0.2, 0.1, 1.0)]
+    src, tgt = [], []
+    for seed, n, frac, noise, scale in cases:
+        p0, p1, _ = gi.corr_case(seed, n, T, frac, noise=noise)
+        src.append(torch.from_numpy(p0 * np.float32(scale)).cuda()); tgt.append(torch.from_numpy(p1 * np.float32(scale)).cuda())
+    lib, ctx = L.load(), L.ctx(0)
+    matchers = [eyoc_amd.Matcher(inlier_threshold=0.6, d_thre=0.1, ratio=0.2, nms_radius=0.6, max_points=8200, k1=30, k2=20, num_iterations=20),
+                eyoc_amd.Matcher(inlier_threshold=0.10, d_thre=0.1, ratio=0.1, nms_radius=0.10, max_points=8200, k1=30, k2=20, num_iterations=10)]
+    prev = lib.eyoc_sc2pcr_select_kernels(ctx, 0)
+    assert prev == 0
+    try:
+        for mi, m in enumerate(matchers):
+            out = {}
+            for bits in (7, 0, 1, 2, 4):
+                assert lib.eyoc_sc2pcr_select_kernels(ctx, bits) >= 0
+                out[bits] = [(Tb.cpu().numpy(), fb.cpu().numpy()) for Tb, fb in m.SC2_PCR_batch(src, tgt)]
+            for bits in (0, 1, 2, 4):
+                for b in range(len(cases)):
+                    np.testing.assert_array_equal(out[bits][b][0], out[7][b][0], err_msg=f"pose, matcher {mi}, case {b}, legacy bits {bits}")
+                    np.testing.assert_array_equal(out[bits][b][1], out[7][b][1], err_msg=f"fitness, matcher {mi}, case {b}, legacy bits {bits}")
+            if mi == 0:
+                for b in (1, 2, 3):
+                    np.testing.assert_allclose(out[0][b][0], T, atol=0.05)
+    finally:
+        lib.eyoc_sc2pcr_select_kernels(ctx, 0)
+
+
 def test_harness_sc2pcr_path_equals_per_pair_estimator():
     """RegistrationPipeline with use_RANSAC=False (scripts/test_kitti.py:179-181) batches the matching and the
     SC2-PCR of all pairs; the poses are bit-identical to looping ``Matcher.estimator`` with the same draws."""
