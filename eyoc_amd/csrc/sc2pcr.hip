@@ -71,58 +71,8 @@ __device__ inline CrossFast cross_len_fast(float sx, float sy, float sz, float t
   return r;
 }
 
-// ---- y = SC x (one sweep).  256 threads = 256 rows; grid.y splits the COLUMNS (a lane-per-row kernel over all
-// columns is 32 workgroups at n = 8000, an eighth of the chip): block (bx, by) writes the partial sums of its
-// column range to part[by][row] and k_sc_normalize adds the ranges in a fixed order (deterministic).
-__device__ __forceinline__ void d_sc_matvec(const float* __restrict__ src, const float* __restrict__ tgt, int n,
-                                                   float inv_d2, const float* __restrict__ x, float* __restrict__ part,
-                                                   int col_chunk, const Sc2Ctl* __restrict__ ctl) {
-  if (ctl->converged) return;
-  __shared__ float ls[1024 * 3], lt[1024 * 3], lx[1024];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const bool ok = i < n;
-  const int ii = ok ? i : 0;
-  const float sx = src[3 * ii], sy = src[3 * ii + 1], sz = src[3 * ii + 2];
-  const float tx = tgt[3 * ii], ty = tgt[3 * ii + 1], tz = tgt[3 * ii + 2];
-  float acc = 0.0f;
-  const int c_begin = blockIdx.y * col_chunk, c_end = min(n, c_begin + col_chunk);
-  for (int j0 = c_begin; j0 < c_end; j0 += 1024) {
-    const int cnt = min(1024, c_end - j0);
-    __syncthreads();
-    for (int t = threadIdx.x; t < cnt * 3; t += 256) { ls[t] = src[3 * j0 + t]; lt[t] = tgt[3 * j0 + t]; }
-    for (int t = threadIdx.x; t < cnt; t += 256) lx[t] = x[j0 + t];
-    __syncthreads();
-    for (int j = 0; j < cnt; ++j) {
-      const float c = cross_len(sx, sy, sz, tx, ty, tz, ls[3 * j], ls[3 * j + 1], ls[3 * j + 2], lt[3 * j],
-                                lt[3 * j + 1], lt[3 * j + 2]);
-      acc = __builtin_fmaf(sc_value(c, inv_d2), lx[j], acc);
-    }
-  }
-  if (ok) part[(size_t)blockIdx.y * n + i] = acc;
-}
-
-// ---- y = sum of the column ranges (ascending), per-block sum of squares (fp64) for the norm
-__device__ __forceinline__ void d_sc_reduce(const float* __restrict__ part, int n_part, int n, float* __restrict__ y,
-                                                  double* __restrict__ block_sq, const Sc2Ctl* __restrict__ ctl) {
-  if (ctl->converged) return;
-  __shared__ double red[4];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  double s = 0;
-  if (i < n) {
-    float t = part[i];
-    for (int c = 1; c < n_part; ++c) t += part[(size_t)c * n + i];
-    y[i] = t;
-    s = (double)t * (double)t;
-  }
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) block_sq[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
-}
-
 // ---- v_new = y / (||y|| + 1e-6); converged = allclose(v_new, v_old); one workgroup
-__device__ __forceinline__ void d_sc_normalize(const double* __restrict__ block_sq, int n_blocks, const float* __restrict__ y,
-                                                       float* __restrict__ v, int n, Sc2Ctl* __restrict__ ctl) {
+__device__ __forceinline__ void d_sc_normalize(const float* __restrict__ y, float* __restrict__ v, int n, Sc2Ctl* __restrict__ ctl) {
   if (ctl->converged) return;
   __shared__ int bad[16];
   __shared__ double wsq[16];
@@ -346,17 +296,32 @@ __device__ __forceinline__ void d_csr_fill(const float* __restrict__ src, const 
   }
 }
 
-// y = SC x over the CSR lists: one wave per row, lanes stride the row's entries, fixed-order wave reduction
-__device__ __forceinline__ void d_sc_spmv(const int* __restrict__ ptr_h, const unsigned short* __restrict__ col_h,
+// y = SC x (one power sweep): one wave per row, lanes stride the row's entries, fixed-order wave reduction.  Over the CSR lists - or,
+// for a pair whose graph overflowed them (ctl->dense: more than N^2 / 4 edges, e.g. all-inlier inputs), over the whole row with the
+// compatibilities recomputed from the coordinates.  (Up to round 5 the dense fallback was two kernels of its own - a column-split
+// mat-vec and its reduction - launched behind every sparse sweep and leaving at once for the pairs that had their lists: 40 launches
+// and 0.26 ms per 16-pair step of nothing.)
+__device__ __forceinline__ void d_sc_spmv(const float* __restrict__ src, const float* __restrict__ tgt, float inv_d2,
+                                          const int* __restrict__ ptr_h, const unsigned short* __restrict__ col_h,
                                           const float* __restrict__ val_h, int n, const float* __restrict__ x,
                                           float* __restrict__ y, const Sc2Ctl* __restrict__ ctl) {
-  if (ctl->converged || ctl->dense) return;
+  if (ctl->converged) return;
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
-  const int b = ptr_h[i], e = ptr_h[i + 1];
   float acc = 0.0f;
-  for (int k = b + lane; k < e; k += 64) acc += val_h[k] * x[col_h[k]];
+  if (ctl->dense) {
+    const float sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
+    const float tx = tgt[3 * i], ty = tgt[3 * i + 1], tz = tgt[3 * i + 2];
+    for (int j = lane; j < n; j += 64) {
+      const float c = cross_len(sx, sy, sz, tx, ty, tz, src[3 * j], src[3 * j + 1], src[3 * j + 2], tgt[3 * j], tgt[3 * j + 1],
+                                tgt[3 * j + 2]);
+      acc = __builtin_fmaf(sc_value(c, inv_d2), x[j], acc);
+    }
+  } else {
+    const int b = ptr_h[i], e = ptr_h[i + 1];
+    for (int k = b + lane; k < e; k += 64) acc += val_h[k] * x[col_h[k]];
+  }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) acc += __shfl_down(acc, d, 64);
   if (lane == 0) y[i] = acc;
@@ -979,7 +944,7 @@ struct Sc2Pair {
   float* T_out; float* fitness;
   Sc2Ctl* ctl; float* v; float* y; float* score; int* seeds;
   unsigned long long* hard; unsigned long long* tight;
-  int* knn; float* Ts; float* part; int* dom; int* rank; double* block_sq;
+  int* knn; float* Ts; int* dom; int* rank;
   int* ptr_h; unsigned short* col_h; float* val_h;   // CSR of the hard graph (support of the first-order matrix)
   long long csr_cap;
   unsigned short* cnt;        // [n_seed][words * 64] second-order counts of the seeds of dense blocks (d_seed_dense)
@@ -998,22 +963,10 @@ __global__ __launch_bounds__(256) void k_init(Sc2Batch B) {
   if (i < q.n) { q.v[i] = 1.0f; q.dom[i] = 0; q.rank[i] = 0; }
   if (i < (int)(sizeof(Sc2Ctl) / 4)) reinterpret_cast<int*>(q.ctl)[i] = 0;
 }
-__global__ __launch_bounds__(256) void k_sc_matvec(Sc2Batch B, int it) {
-  const Sc2Pair& q = B.p[blockIdx.z];
-  if (it >= q.num_iterations || !q.ctl->dense) return;   // dense fallback only (graph too large for the CSR arrays)
-  if ((int)blockIdx.x * 256 >= q.n || (int)blockIdx.y >= q.n_part) return;
-  d_sc_matvec(q.src, q.tgt, q.n, 1.0f / (q.d * q.d), q.v, q.part, q.col_chunk, q.ctl);
-}
-__global__ __launch_bounds__(256) void k_sc_reduce(Sc2Batch B, int it) {
-  const Sc2Pair& q = B.p[blockIdx.z];
-  if (it >= q.num_iterations || !q.ctl->dense) return;
-  if ((int)blockIdx.x * 256 >= q.n) return;
-  d_sc_reduce(q.part, q.n_part, q.n, q.y, q.block_sq, q.ctl);
-}
 __global__ __launch_bounds__(256) void k_sc_spmv(Sc2Batch B, int it) {
   const Sc2Pair& q = B.p[blockIdx.z];
   if (it >= q.num_iterations) return;
-  d_sc_spmv(q.ptr_h, q.col_h, q.val_h, q.n, q.v, q.y, q.ctl);
+  d_sc_spmv(q.src, q.tgt, 1.0f / (q.d * q.d), q.ptr_h, q.col_h, q.val_h, q.n, q.v, q.y, q.ctl);
 }
 __global__ __launch_bounds__(1024) void k_csr_scan(Sc2Batch B) {
   const Sc2Pair& q = B.p[blockIdx.z];
@@ -1030,7 +983,7 @@ __global__ __launch_bounds__(256) void k_csr_fill(Sc2Batch B) {
 __global__ __launch_bounds__(1024) void k_sc_normalize(Sc2Batch B, int it) {
   const Sc2Pair& q = B.p[blockIdx.z];
   if (it >= q.num_iterations) return;
-  d_sc_normalize(q.block_sq, (q.n + 255) / 256, q.y, q.v, q.n, q.ctl);
+  d_sc_normalize(q.y, q.v, q.n, q.ctl);
 }
 __global__ __launch_bounds__(256) void k_nms(Sc2Batch B) {
   const Sc2Pair& q = B.p[blockIdx.z];
@@ -1082,8 +1035,8 @@ __global__ __launch_bounds__(1024) void k_refine(Sc2Batch B) {
 
 struct Plan {
   int n, words, n_seed, k1, k2;
-  int n_part, col_chunk;   // column ranges of the lane-per-row sweeps (matvec, NMS, rank)
-  size_t off_ctl, off_v, off_y, off_score, off_seeds, off_hard, off_tight, off_knn, off_Ts, off_part, off_int, off_sq, total;
+  int n_part, col_chunk;   // column ranges of the lane-per-row sweeps (NMS, rank)
+  size_t off_ctl, off_v, off_y, off_score, off_seeds, off_hard, off_tight, off_knn, off_Ts, off_int, total;
   size_t off_ptr_h, off_col_h, off_val_h, off_cnt, off_blk;
   long long csr_cap;   // entries each CSR list can hold: a quarter of the N^2 pairs (denser graphs sweep densely)
 };
@@ -1114,9 +1067,7 @@ Plan make_plan(int n, const eyoc_sc2pcr_params* p) {
   if (parts < 1) parts = 1;
   pl.col_chunk = (n + parts - 1) / parts;
   pl.n_part = (n + pl.col_chunk - 1) / pl.col_chunk;
-  pl.off_part = take((size_t)pl.n_part * n * 4);
   pl.off_int = take((size_t)2 * n * 4);          // NMS domination flags, ranks
-  pl.off_sq = take((size_t)row_blocks * 8);      // per-block sums of squares of a sweep
   pl.csr_cap = (long long)n * n / 4 + 64;
   pl.off_ptr_h = take((size_t)(n + 1) * 4);
   pl.off_col_h = take((size_t)pl.csr_cap * 2);
@@ -1177,8 +1128,8 @@ static int sc2pcr_chunk(eyoc_ctx* ctx, const float* src_dev, const float* tgt_de
     q.ctl = (Sc2Ctl*)(w + pl.off_ctl); q.v = (float*)(w + pl.off_v); q.y = (float*)(w + pl.off_y);
     q.score = (float*)(w + pl.off_score); q.seeds = (int*)(w + pl.off_seeds);
     q.hard = (unsigned long long*)(w + pl.off_hard); q.tight = (unsigned long long*)(w + pl.off_tight);
-    q.knn = (int*)(w + pl.off_knn); q.Ts = (float*)(w + pl.off_Ts); q.part = (float*)(w + pl.off_part);
-    q.dom = (int*)(w + pl.off_int); q.rank = q.dom + n; q.block_sq = (double*)(w + pl.off_sq);
+    q.knn = (int*)(w + pl.off_knn); q.Ts = (float*)(w + pl.off_Ts);
+    q.dom = (int*)(w + pl.off_int); q.rank = q.dom + n;
     q.ptr_h = (int*)(w + pl.off_ptr_h); q.col_h = (unsigned short*)(w + pl.off_col_h);
     q.val_h = (float*)(w + pl.off_val_h); q.csr_cap = pl.csr_cap;
     q.cnt = (unsigned short*)(w + pl.off_cnt); q.blk_dense = (unsigned char*)(w + pl.off_blk);
@@ -1205,12 +1156,9 @@ static int sc2pcr_chunk(eyoc_ctx* ctx, const float* src_dev, const float* tgt_de
   hipLaunchKernelGGL(k_csr_scan, dim3(1, 1, Z), dim3(1024), 0, st, B);
   hipLaunchKernelGGL(k_csr_fill, dim3(cdiv(n_max, 4), 1, Z), dim3(256), 0, st, B);
   // leading eigenvector of the first-order compatibility matrix (power iteration from all-ones); a pair whose own
-  // num_iterations is below the chunk's maximum sits the surplus sweeps out.  Sparse sweep; the dense kernels only
-  // do anything for a pair whose graph overflowed the CSR arrays
+  // num_iterations is below the chunk's maximum sits the surplus sweeps out.  A pair whose graph overflowed the CSR arrays sweeps densely
   for (int it = 0; it < it_max; ++it) {
     hipLaunchKernelGGL(k_sc_spmv, dim3(cdiv(n_max, 4), 1, Z), dim3(256), 0, st, B, it);
-    hipLaunchKernelGGL(k_sc_matvec, dim3(rb, part_max, Z), dim3(256), 0, st, B, it);
-    hipLaunchKernelGGL(k_sc_reduce, dim3(rb, 1, Z), dim3(256), 0, st, B, it);
     hipLaunchKernelGGL(k_sc_normalize, dim3(1, 1, Z), dim3(1024), 0, st, B, it);
   }
   // seeds: NMS on the eigenvector in source space, stable top-n_seed

@@ -10,8 +10,8 @@ python - <<PY
 import pandas as pd, glob
 f=glob.glob("gpurun_out/sc2x_trace/**/sc2x_kernel_stats.csv", recursive=True)[0]
 df=pd.read_csv(f)
-df["k"]=df.Name.str.replace(r"\(.*","",regex=True).str.replace("(anonymous namespace)::","").str.replace("void ","")
+df["k"]=df.Name.str.replace("(anonymous namespace)::","",regex=False).str.replace("void ","",regex=False).str.replace(r"\(.*","",regex=True)
 sc=df[df.k.str.contains("k_sc_|k_csr|k_seed|k_masks|k_nms|k_rank|k_seeds|k_refine|k_init")]
 print(sc[["k","Calls","TotalDurationNs","AverageNs"]].to_string())
-print("back-end total per step (ms):", sc.TotalDurationNs.sum()/1e6/12)
+print("back-end total per step (ms):", sc.TotalDurationNs.sum()/1e6/18)
 PY
