@@ -64,6 +64,7 @@ PROTOTYPES = {
     "eyoc_maps_free": (_i, [_vp]),
     "eyoc_maps_internal_order": (_i, [_vp, _i]),
     "eyoc_maps_lazy_tables": (_i, [_vp, _i]),
+    "eyoc_maps_fused_levels": (_i, [_vp, _i]),
     "eyoc_spconv_select_down_kernel": (_i, [_vp, _i]),
     "eyoc_maps_order_window_shift": (_i, [_vp, _i]),
     "eyoc_maps_row_order": (_vp, [_vp]),
@@ -207,6 +208,10 @@ def check(rc: int, what: str = ""):
 def ctx(device_index: int | None = None):
     """The per-(process, device) ``eyoc_ctx*``."""
     import torch
+    if device_index is not None:                       # the hot path: a dozen calls per forward, none of them needs torch
+        h = _ctx.get(device_index)
+        if h is not None:
+            return h
     if not torch.cuda.is_available():
         raise EyocError("no GPU visible: the EYOC hot path runs on MI355X only (no CPU fallback)")
     if device_index is None:
@@ -229,8 +234,13 @@ def knob(name: str, *values, device=None) -> int:
 
 
 def stream_ptr():
+    """The current HIP stream of the current device as a ``void*``.  ``torch.cuda.current_stream().cuda_stream`` builds a Stream object
+    per call (4 us, seven calls per registered pair); the raw getter torch's own compiled code uses returns the handle directly."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    try:
+        return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+    except AttributeError:                             # (a torch without the raw getter)
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def ptr(t):

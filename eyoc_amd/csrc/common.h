@@ -92,7 +92,7 @@ struct eyoc_ctx {
     int maps_window_shift = 18;        // eyoc_maps_order_window_shift: window of the tiling orders, log2 rows (measured: 2^17-2^18; 2^12, 2^14 lose)
     int maps_s1_order = 1, maps_down_order = 0;   // eyoc_maps_select_orders: tiling orders of the stride-1 / strided tables
     int maps_internal_order = -1;      // eyoc_maps_internal_order: -1 automatic (Z-order from 8192 rows), 0 caller's order, 1 Z-order
-    int maps_lazy_tables = 1;          // eyoc_maps_lazy_tables: big Z-ordered batches skip the tables only their record builders read (coordmap.hip)
+    int maps_lazy_tables = 1, maps_fused_levels = 1;          // eyoc_maps_lazy_tables: big Z-ordered batches skip the tables only their record builders read (coordmap.hip)
     int knn_prefilter = 1;             // eyoc_knn_prefilter
     int fuse_tail = 2;                 // eyoc_model_fuse_tail: 2 the 1x1 tail in the epilogue of the last staged layer where that layer allows it (spconv_st.hip TAILF), 1 in one kernel of its own (spconv_tail.hip), 0 two launches
     int spconv_kernel = -1;            // eyoc_spconv_select_kernel: -1 automatic, 0 workgroup-tiled, 1 wave-private

@@ -261,6 +261,122 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_compact_sorted(const int* __rest
   }
 }
 
+// ---- Z-ordered rows, round 6: ALL coarser levels from the sorted level-0 rows in two launches.  A level-l voxel is a run of adjacent
+// level-0 rows (k_count_levels counts them that way), and a level-l boundary is also a boundary of every finer level, so one pass over
+// the level-0 rows knows, for every row, its voxel's index at each level: the number of level-l boundaries up to and including it,
+// minus one.  k_levels_count leaves the three boundary counts of every 2048-row tile; k_levels_fill adds up the tiles in front of
+// its own, and its rows write - at the level where they open a voxel - that voxel's coordinate, its parent link and its entry in the
+// parent's child list.  The same arrays, bit for bit, as k_flag_sorted -> k_scan_partials -> k_scan_top -> k_compact_sorted per level
+// (rounds 3-5: twelve short dependent launches - a single pair spent 110 us of its 1.55 ms in their launch gaps).
+static_assert(EYOC_MAX_LEVELS == 4, "k_levels_*: three coarser levels");
+constexpr int LV_BLOCK = 256, LV_STEPS = 8, LV_TILE = LV_BLOCK * LV_STEPS;     // wave w of a block: rows [512 w, 512 w + 512) of the tile, 64 per step
+__device__ inline void level_flags(const int4 c, const int4 q, bool first, bool& f1, bool& f2, bool& f3) {
+  const unsigned int d = (unsigned int)((c.y ^ q.y) | (c.z ^ q.z) | (c.w ^ q.w));
+  const bool nb = first || c.x != q.x;
+  f1 = nb || (d >> 1) != 0u; f2 = nb || (d >> 2) != 0u; f3 = nb || (d >> 3) != 0u;
+}
+__global__ __launch_bounds__(LV_BLOCK) void k_levels_count(const int32_t* __restrict__ coords, int n, int* __restrict__ part /* [tiles][4] */,
+                                                           int* __restrict__ counters) {
+  __shared__ int tot[LV_BLOCK / 64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int base = blockIdx.x * LV_TILE + wave * (LV_TILE / (LV_BLOCK / 64));
+  int c1 = 0, c2 = 0, c3 = 0, bad = 0, dup = 0;
+  constexpr int LIM = COORD_BIAS - 16;
+#pragma unroll
+  for (int j = 0; j < LV_STEPS; ++j) {
+    const int i = base + j * 64 + lane;
+    bool f1 = false, f2 = false, f3 = false, e = false, d = false;
+    if (i < n) {
+      const int4 c = reinterpret_cast<const int4*>(coords)[i];
+      const int4 q = i > 0 ? reinterpret_cast<const int4*>(coords)[i - 1] : c;
+      level_flags(c, q, i == 0, f1, f2, f3);
+      e = c.x < 0 || c.x >= 1024 || c.y < -LIM || c.y >= LIM || c.z < -LIM || c.z >= LIM || c.w < -LIM || c.w >= LIM;   // (k_flag_sorted's check at level 1)
+      d = i > 0 && c.x == q.x && c.y == q.y && c.z == q.z && c.w == q.w;
+    }
+    c1 += __popcll(__ballot(f1)); c2 += __popcll(__ballot(f2)); c3 += __popcll(__ballot(f3));
+    bad += __popcll(__ballot(e)); dup += __popcll(__ballot(d));
+  }
+  if (lane == 0) {
+    tot[wave][0] = c1; tot[wave][1] = c2; tot[wave][2] = c3;
+    if (bad) atomicAdd(counters, bad);
+    if (dup) atomicAdd(counters + 1, dup);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    int v = 0;
+    for (int w = 0; w < LV_BLOCK / 64; ++w) v += tot[w][threadIdx.x];
+    part[4 * blockIdx.x + threadIdx.x] = v;
+  }
+}
+struct LevelOut {
+  int32_t* coords[3];     // level 1..3 coordinates
+  int32_t* parent[3];     // parent[l]: level l -> l + 1
+  int32_t* children[3];   // children[l]: level l + 1 -> its up to 8 rows of level l
+};
+__global__ __launch_bounds__(LV_BLOCK) void k_levels_fill(const int32_t* __restrict__ coords, int n, const int* __restrict__ part,
+                                                          LevelOut o, int* __restrict__ totals /* counters + 3: rows of level 1..3 */) {
+  constexpr int NWV = LV_BLOCK / 64;
+  __shared__ int red[NWV][3];
+  __shared__ int tot[NWV][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // boundaries in the tiles in front of this one
+  int b1 = 0, b2 = 0, b3 = 0;
+  for (int t = threadIdx.x; t < (int)blockIdx.x; t += LV_BLOCK) { b1 += part[4 * t]; b2 += part[4 * t + 1]; b3 += part[4 * t + 2]; }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { b1 += __shfl_xor(b1, d, 64); b2 += __shfl_xor(b2, d, 64); b3 += __shfl_xor(b3, d, 64); }
+  if (lane == 0) { red[wave][0] = b1; red[wave][1] = b2; red[wave][2] = b3; }
+  // this wave's rows: the three boundary masks of each step
+  const int base = blockIdx.x * LV_TILE + wave * (LV_TILE / NWV);
+  unsigned long long m1[LV_STEPS], m2[LV_STEPS], m3[LV_STEPS];
+  int4 cs[LV_STEPS];
+  int c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+  for (int j = 0; j < LV_STEPS; ++j) {
+    const int i = base + j * 64 + lane;
+    bool f1 = false, f2 = false, f3 = false;
+    cs[j] = make_int4(0, 0, 0, 0);
+    if (i < n) {
+      cs[j] = reinterpret_cast<const int4*>(coords)[i];
+      const int4 q = i > 0 ? reinterpret_cast<const int4*>(coords)[i - 1] : cs[j];
+      level_flags(cs[j], q, i == 0, f1, f2, f3);
+    }
+    m1[j] = __ballot(f1); m2[j] = __ballot(f2); m3[j] = __ballot(f3);
+    c1 += __popcll(m1[j]); c2 += __popcll(m2[j]); c3 += __popcll(m3[j]);
+  }
+  if (lane == 0) { tot[wave][0] = c1; tot[wave][1] = c2; tot[wave][2] = c3; }
+  __syncthreads();
+  int p1 = 0, p2 = 0, p3 = 0;
+  for (int w = 0; w < NWV; ++w) { p1 += red[w][0]; p2 += red[w][1]; p3 += red[w][2]; }
+  if (blockIdx.x + 1 == gridDim.x && threadIdx.x == 0) {            // the scans' own totals (eyoc_maps_build compares them with k_count_levels')
+    int t1 = p1, t2 = p2, t3 = p3;
+    for (int w = 0; w < NWV; ++w) { t1 += tot[w][0]; t2 += tot[w][1]; t3 += tot[w][2]; }
+    totals[0] = t1; totals[1] = t2; totals[2] = t3;
+  }
+  for (int w = 0; w < wave; ++w) { p1 += tot[w][0]; p2 += tot[w][1]; p3 += tot[w][2]; }
+  const unsigned long long upto = (2ull << lane) - 1ull;             // lanes 0 .. lane
+#pragma unroll
+  for (int j = 0; j < LV_STEPS; ++j) {
+    const int i = base + j * 64 + lane;
+    const int i1 = p1 + __popcll(m1[j] & upto) - 1, i2 = p2 + __popcll(m2[j] & upto) - 1, i3 = p3 + __popcll(m3[j] & upto) - 1;
+    p1 += __popcll(m1[j]); p2 += __popcll(m2[j]); p3 += __popcll(m3[j]);
+    if (i >= n) continue;
+    const int4 c = cs[j];
+    o.parent[0][i] = i1;
+    o.children[0][(size_t)i1 * 8 + ((c.y & 1) | ((c.z & 1) << 1) | ((c.w & 1) << 2))] = i;
+    if ((m1[j] >> lane) & 1ull) {
+      reinterpret_cast<int4*>(o.coords[0])[i1] = make_int4(c.x, c.y & ~1, c.z & ~1, c.w & ~1);
+      o.parent[1][i1] = i2;
+      o.children[1][(size_t)i2 * 8 + (((c.y >> 1) & 1) | (((c.z >> 1) & 1) << 1) | (((c.w >> 1) & 1) << 2))] = i1;
+    }
+    if ((m2[j] >> lane) & 1ull) {
+      reinterpret_cast<int4*>(o.coords[1])[i2] = make_int4(c.x, c.y & ~3, c.z & ~3, c.w & ~3);
+      o.parent[2][i2] = i3;
+      o.children[2][(size_t)i3 * 8 + (((c.y >> 2) & 1) | (((c.z >> 2) & 1) << 1) | (((c.w >> 2) & 1) << 2))] = i2;
+    }
+    if ((m3[j] >> lane) & 1ull) reinterpret_cast<int4*>(o.coords[2])[i3] = make_int4(c.x, c.y & ~7, c.z & ~7, c.w & ~7);
+  }
+}
+
 // nbr[k][o] = row of table_in at c_out[o] + sign * off_k * step
 __global__ void k_neighbours(const int32_t* __restrict__ coords_out, int n_out, HashTable tin, int step, int sign,
                              int32_t* __restrict__ nbr) {
@@ -641,7 +757,24 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
     FAIL_HIP(hipMemsetAsync(m->children[0], 0xFF, (size_t)((char*)(tt.keys + top_cap) - (char*)m->children[0]), st));
     FAIL_HIP(hipMemsetAsync(tt.vals, 0x7F, (size_t)top_cap * 4, st));
   }
-  for (int l = 1; l < EYOC_MAX_LEVELS; ++l) {
+  const bool fused_levels = zorder && kn.maps_fused_levels;
+  if (fused_levels) {
+    // all three coarser levels in two launches (k_levels_count / k_levels_fill); carved in the order the level loop below carves them
+    LevelOut lo;
+    for (int l = 1; l < EYOC_MAX_LEVELS; ++l) {
+      m->rows[l] = pre_rows[l];
+      m->coords[l] = cv.take<int32_t>((size_t)m->rows[l] * 4);
+      m->parent[l - 1] = cv.take<int32_t>((size_t)m->rows[l - 1]);
+      lo.coords[l - 1] = m->coords[l]; lo.parent[l - 1] = m->parent[l - 1]; lo.children[l - 1] = m->children[l - 1];
+    }
+    const int tiles = cdiv(n, LV_TILE);
+    int* part = flag;                                                  // [tiles][4] <= n ints: the flag array is free on this path
+    hipLaunchKernelGGL(k_levels_count, dim3(tiles), dim3(LV_BLOCK), 0, st, m->coords[0], n, part, counters);
+    hipLaunchKernelGGL(k_levels_fill, dim3(tiles), dim3(LV_BLOCK), 0, st, m->coords[0], n, part, lo, counters + 3);
+    const int lt = EYOC_MAX_LEVELS - 1;
+    hipLaunchKernelGGL(k_insert, dim3(cdiv(m->rows[lt], 256)), dim3(256), 0, st, m->coords[lt], m->rows[lt], 1 << lt, m->table[lt], (int*)nullptr, counters);
+  }
+  for (int l = 1; l < EYOC_MAX_LEVELS && !fused_levels; ++l) {
     // table of THIS level is built from the previous level's rows
     const int n_src = m->rows[l - 1];
     const int32_t* src = m->coords[l - 1];
@@ -1055,6 +1188,13 @@ int eyoc_maps_lazy_tables(eyoc_ctx* ctx, int on) {
   EYOC_REQUIRE(ctx, EYOC_ERR_INVALID, "eyoc_maps_lazy_tables: NULL ctx");
   const int prev = ctx->knobs.maps_lazy_tables;
   if (on == 0 || on == 1) ctx->knobs.maps_lazy_tables = on;            // anything else: a query
+  return prev;
+}
+
+int eyoc_maps_fused_levels(eyoc_ctx* ctx, int on) {
+  EYOC_REQUIRE(ctx, EYOC_ERR_INVALID, "eyoc_maps_fused_levels: NULL ctx");
+  const int prev = ctx->knobs.maps_fused_levels;
+  if (on == 0 || on == 1) ctx->knobs.maps_fused_levels = on;          // anything else: a query
   return prev;
 }
 

@@ -179,10 +179,13 @@ class RegistrationPipeline:
         finally:
             self.model.range_check = check
 
-    def _checked(self, batch, seed, maps):
+    def _checked(self, batch, seed, maps, words=None):
         """After the results were read back: raise on a split16 overflow - or, in automatic mode, switch the model to
-        fp32 MFMAs for good and run the step again."""
+        fp32 MFMAs for good and run the step again.  ``words``: the guard's words as ``_range_snapshot`` fetched them with the results
+        (all clear: nothing overflowed since the last check, no need to ask the device again)."""
         from . import _lib
+        if words is not None and int(words[0]) == 0 and int(words[3]) == 0:
+            return None
         try:
             self.model.check_range()
             return None
@@ -314,13 +317,25 @@ class RegistrationPipeline:
             res = self._match_and_register(batch, F, seed)
             if return_device:
                 return res                # the caller reads back later - and calls model.check_range() then
+            words = self._range_snapshot()
             host = res.cpu()
-            return self._checked(batch, seed, maps) or [reg.decode_ransac_result(host[p], n) for p in range(batch.P)]
+            return self._checked(batch, seed, maps, words) or [reg.decode_ransac_result(host[p], n) for p in range(batch.P)]
         T = self._match_and_register_sc2(batch, F, seed)
         if return_device:
             return T
+        words = self._range_snapshot()
         Th = T.cpu().numpy().astype(np.float64)
-        return self._checked(batch, seed, maps) or [reg.RegistrationResult(Th[p], 0.0, 0.0) for p in range(batch.P)]
+        return self._checked(batch, seed, maps, words) or [reg.RegistrationResult(Th[p], 0.0, 0.0) for p in range(batch.P)]
+
+    def _range_snapshot(self):
+        """The range guard's words on their way to pinned memory, enqueued IN FRONT of the result read-back: the read-back's own
+        synchronisation then covers them, and a clean step needs no second host wait (``check_range`` is a copy + a stream
+        synchronisation of its own: 35 us of a single pair's 1.5 ms)."""
+        w = self.__dict__.get("_range_words")
+        if w is None:
+            w = self._range_words = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self.model.range_snapshot(w)
+        return w
 
     def _match_and_register_sc2(self, batch, F, seed):
         """SC2-PCR path (scripts/test_kitti.py:179-181) on the CURRENT stream -> ``T f32 [P,4,4]`` on the device.

@@ -125,6 +125,10 @@ int eyoc_maps_internal_order(eyoc_ctx* ctx, int mode);
  * eyoc_maps_table / _copy_table / _info, by a forward whose layer runs a gathering kernel, by a build whose records overflowed - so
  * nothing a caller can observe changes.  eyoc_maps_lazy_tables(ctx, 0) builds every table eagerly again; returns the previous setting. */
 int eyoc_maps_lazy_tables(eyoc_ctx* ctx, int on);
+/* EYOC_VERSION >= 111.  Z-ordered builds make the three coarser levels (coordinates, parent and child links) in two launches over the
+ * sorted level-0 rows (default, round 6) instead of four short dependent launches per level; the arrays are the same bit for bit.
+ * eyoc_maps_fused_levels(ctx, 0) brings the per-level kernels back (tests compare); returns the previous setting. */
+int eyoc_maps_fused_levels(eyoc_ctx* ctx, int on);
 /* Strided convolutions of a split16 forward on Z-ordered maps of >= eyoc_spconv_upc_min_rows rows: 1 (default, round 6) the staged kernel
  * on 128-row output tiles (tile records built by eyoc_maps_build), 0 the gathering kernel; returns the previous setting. */
 int eyoc_spconv_select_down_kernel(eyoc_ctx* ctx, int mode);

@@ -286,3 +286,55 @@ def test_lazy_tables_change_nothing_a_caller_can_observe():
     finally:
         _lib.knob("eyoc_spconv_upc_min_rows", prev_min)
         _lib.knob("eyoc_maps_lazy_tables", 1)
+
+
+def test_fused_level_construction_equals_the_per_level_kernels():
+    """Round 6: a Z-ordered build makes the three coarser levels - coordinates, parent and child links - in two launches over the sorted
+    level-0 rows (coordmap.hip k_levels_count / k_levels_fill) instead of flag / scan / scan / compact per level.  Everything derived
+    from them must be what the per-level kernels give, bit for bit: level coordinates, every table of every level (the Z-ordered build
+    derives them top-down from the links), the pair counts, the forward.  Sizes: a batch of two clouds, one small cloud forced into
+    Z-order, row counts around the 2048-row tile and the 64-row wave step, a 3-row cloud, one voxel."""
+    import eyoc_amd
+    from eyoc_amd import _lib, synthetic as syn
+    from oracle import coords as oc
+    from test_gpu_round2 import _model
+    rng = np.random.default_rng(17)
+    p = syn.make_pair(5)
+    cases = [syn.batch_coords([p["coords0"], p["coords1"]])]
+    for n in (2048, 2049, 4095, 63, 64, 65, 3, 1):
+        c = np.unique(rng.integers(-40, 40, size=(4 * n + 8, 3)), axis=0)[:n].astype(np.int32)
+        cases.append(syn.batch_coords([c]))
+    cases.append(syn.batch_coords([np.unique(rng.integers(-9, 9, size=(900, 3)), axis=0).astype(np.int32) for _ in range(5)]))   # five dense clouds
+    model, _sd = _model()
+    prev_order = _lib.knob("eyoc_maps_internal_order", 1) - 2
+    assert _lib.knob("eyoc_maps_fused_levels", -7) == 1
+    try:
+        for ci, coords in enumerate(cases):
+            got = []
+            for fused in (1, 0):
+                _lib.knob("eyoc_maps_fused_levels", fused)
+                feats = np.ones((len(coords), 1), np.float32)
+                x = eyoc_amd.SparseTensor(torch.from_numpy(feats).cuda(), coordinates=torch.from_numpy(coords).cuda())
+                cm = x.coordinate_manager
+                cm.maps(-1)
+                rec = {"order": cm.row_order().cpu().numpy(), "info": cm.info(conv1_kernel_size=5)}
+                for l in range(4):
+                    rec[f"c{l}"] = cm.level_coordinates(l, internal=True).cpu().numpy()
+                    rec[f"s1_{l}"] = cm.table(_lib.MAP_S1, l, internal=True).cpu().numpy()
+                    if l < 3:
+                        rec[f"up_{l}"] = cm.table(_lib.MAP_UP, l, internal=True).cpu().numpy()
+                        rec[f"down_{l}"] = cm.table(_lib.MAP_DOWN, l, internal=True).cpu().numpy()
+                if len(coords) >= 64:
+                    rec["F"] = model(x).F.cpu().numpy()
+                got.append(rec)
+            a, b = got
+            assert a["info"] == b["info"], ci
+            for k in a:
+                if k != "info":
+                    np.testing.assert_array_equal(a[k], b[k], err_msg=f"case {ci} ({len(coords)} rows), {k}")
+            want = oc.build_maps(coords[a["order"]])
+            for l in range(4):
+                np.testing.assert_array_equal(a[f"s1_{l}"], want["s1"][l], err_msg=f"case {ci}, s1 level {l} against the oracle")
+    finally:
+        _lib.knob("eyoc_maps_fused_levels", 1)
+        _lib.knob("eyoc_maps_internal_order", prev_order)
