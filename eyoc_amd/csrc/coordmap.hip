@@ -946,7 +946,7 @@ int eyoc_maps_build_ordered(eyoc_ctx* ctx, const int32_t* coords_dev, int n, voi
   }
   // ---- local rulebooks of the stride-1 tables (tile-local input stage of the sparse convolution): only for Z-ordered rows
   if (zorder) {
-    FAIL_HIP(hipMemsetAsync(counters + 8, 0, 8 * sizeof(int), st));    // [8] stride-1, [9] transposed, [10 + l] strided table l
+    // counters [8] stride-1, [9] transposed, [10 + l] strided table l, [13] wide level-3 tiles: zero since the fill of all 64 words at the top (nothing in between writes them)
     for (int l = 0; l < EYOC_MAX_LEVELS; ++l) {
       m->local_s1[l] = cv.take<unsigned char>(local_rulebook_bytes(m->rows[l]));
       if (lazy && l == 0) {

@@ -405,7 +405,7 @@ __device__ __forceinline__ void d_seed_topk(const unsigned long long* __restrict
                                                    const unsigned long long* __restrict__ tight, int n, int words,
                                                    const int* __restrict__ seeds, int k1, int* __restrict__ knn1,
                                                    const unsigned short* __restrict__ cnt_row, int list_cap) {
-  extern __shared__ unsigned char dyn[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
   unsigned short* row = reinterpret_cast<unsigned short*>(dyn);                                            // [n]
   unsigned long long* srow = reinterpret_cast<unsigned long long*>(dyn + ((size_t)n * 2 + 15) / 16 * 16);  // [words]
   unsigned short* cand = reinterpret_cast<unsigned short*>(dyn + ((size_t)n * 2 + 15) / 16 * 16 + (size_t)words * 8);  // [<= n]
@@ -429,7 +429,14 @@ __device__ __forceinline__ void d_seed_topk(const unsigned long long* __restrict
   // ANDs the two 1 KB tight rows with coalesced loads (a lane-per-j loop read them 8 bytes at a time, every lane a
   // different row, and idled on the unset bits).
   if (cnt_row) {                                       // workgroup-uniform
-    for (int j = threadIdx.x; j < n; j += 256) row[j] = cnt_row[j];
+    // 16 bytes per lane and load, all of a thread's loads in flight (round 6; the row was copied two bytes at a time in a loop the
+    // compiler kept rolled: 31 dependent round trips to memory per seed).  A count row is words * 64 entries = a multiple of 128 bytes
+    // at a 256-byte aligned base, and `row` is rounded up to 16 bytes, so the last vector stays inside both.
+    const uint4* __restrict__ src4 = reinterpret_cast<const uint4*>(cnt_row);
+    uint4* dst4 = reinterpret_cast<uint4*>(row);
+    const int n8 = (n + 7) / 8;
+#pragma unroll 4
+    for (int q = threadIdx.x; q < n8; q += 256) dst4[q] = src4[q];
   } else {
   for (int j = threadIdx.x; j < n; j += 256) row[j] = 0;
   if (threadIdx.x == 0) cand_n = 0;
