@@ -301,30 +301,88 @@ __device__ __forceinline__ void d_csr_fill(const float* __restrict__ src, const 
 // compatibilities recomputed from the coordinates.  (Up to round 5 the dense fallback was two kernels of its own - a column-split
 // mat-vec and its reduction - launched behind every sparse sweep and leaving at once for the pairs that had their lists: 40 launches
 // and 0.26 ms per 16-pair step of nothing.)
+constexpr int SPMV_ROWS = 4, SPMV_AHEAD = 2;       // rows per wave x entries per lane and row in flight
 __device__ __forceinline__ void d_sc_spmv(const float* __restrict__ src, const float* __restrict__ tgt, float inv_d2,
                                           const int* __restrict__ ptr_h, const unsigned short* __restrict__ col_h,
                                           const float* __restrict__ val_h, int n, const float* __restrict__ x,
                                           float* __restrict__ y, const Sc2Ctl* __restrict__ ctl) {
   if (ctl->converged) return;
   const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= n) return;
-  float acc = 0.0f;
+  const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * SPMV_ROWS;
+  if (i0 >= n) return;
   if (ctl->dense) {
-    const float sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
-    const float tx = tgt[3 * i], ty = tgt[3 * i + 1], tz = tgt[3 * i + 2];
-    for (int j = lane; j < n; j += 64) {
-      const float c = cross_len(sx, sy, sz, tx, ty, tz, src[3 * j], src[3 * j + 1], src[3 * j + 2], tgt[3 * j], tgt[3 * j + 1],
-                                tgt[3 * j + 2]);
-      acc = __builtin_fmaf(sc_value(c, inv_d2), x[j], acc);
+#pragma unroll 1
+    for (int r = 0; r < SPMV_ROWS && i0 + r < n; ++r) {
+      const int i = i0 + r;
+      const float sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
+      const float tx = tgt[3 * i], ty = tgt[3 * i + 1], tz = tgt[3 * i + 2];
+      float a = 0.0f;
+      for (int j = lane; j < n; j += 64) {
+        const float c = cross_len(sx, sy, sz, tx, ty, tz, src[3 * j], src[3 * j + 1], src[3 * j + 2], tgt[3 * j], tgt[3 * j + 1],
+                                  tgt[3 * j + 2]);
+        a = __builtin_fmaf(sc_value(c, inv_d2), x[j], a);
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) a += __shfl_down(a, d, 64);
+      if (lane == 0) y[i] = a;
     }
-  } else {
-    const int b = ptr_h[i], e = ptr_h[i + 1];
-    for (int k = b + lane; k < e; k += 64) acc += val_h[k] * x[col_h[k]];
+    return;
+  }
+  // Round 6: SPMV_ROWS rows per wave, SPMV_AHEAD entries per lane and row in flight, and NO branch around a load.  A wave used to own one
+  // row and walk it in a rolled loop: row bounds -> (column, value) -> gathered x -> six-step reduction, every arrow a memory round trip,
+  // ~5 us of life for 80 entries - and the chip holds 8192 waves, so a sweep of 16 pairs (128 k rows) took 70 us at 2.3 TB/s whatever
+  // the memory system could do (a single pair: 5.9 us, four: 15.8 - linear in the rows).  Conditional loads (`if (k < e) acc += val[k] * x[col[k]]`,
+  // several rows or entries unrolled) did not help: each conditional region waits for its own column before its gather.  Here the
+  // indices are clamped into the row instead, all loads of a step are issued back to back, and only the fma is predicated: 43.8 -> 37.7 us
+  // per launch.  (x staged in LDS on top - the gathers touch up to 64 lines per instruction - measured 39.6 us with 32 rows per
+  // workgroup and 84 us with 256: the copies and the lost parallelism cost what the LDS gathers save.)  Every
+  // row's sum is formed in the same order as before (k ascending per lane, one fma each, the same tree).
+  int k[SPMV_ROWS], b[SPMV_ROWS], e[SPMV_ROWS];
+  float acc[SPMV_ROWS];
+#pragma unroll
+  for (int r = 0; r < SPMV_ROWS; ++r) {
+    const int i = min(i0 + r, n - 1);
+    b[r] = ptr_h[i];
+    e[r] = i0 + r < n ? ptr_h[i + 1] : b[r];                // rows past the end: empty
+    k[r] = b[r] + lane;
+    acc[r] = 0.0f;
+  }
+  bool more = true;
+  while (more) {                                            // wave-uniform
+    int c[SPMV_ROWS][SPMV_AHEAD];
+    float v[SPMV_ROWS][SPMV_AHEAD], xv[SPMV_ROWS][SPMV_AHEAD];
+#pragma unroll
+    for (int r = 0; r < SPMV_ROWS; ++r)
+#pragma unroll
+      for (int u = 0; u < SPMV_AHEAD; ++u) {
+        const int kc = max(min(k[r] + 64 * u, e[r] - 1), 0);   // inside the row (an empty row reads a neighbour's entry; nothing is added)
+        c[r][u] = col_h[kc];
+        v[r][u] = val_h[kc];
+      }
+#pragma unroll
+    for (int r = 0; r < SPMV_ROWS; ++r)
+#pragma unroll
+      for (int u = 0; u < SPMV_AHEAD; ++u) xv[r][u] = x[c[r][u]];
+    bool m = false;
+#pragma unroll
+    for (int r = 0; r < SPMV_ROWS; ++r) {
+#pragma unroll
+      for (int u = 0; u < SPMV_AHEAD; ++u) {
+        const float f = __builtin_fmaf(v[r][u], xv[r][u], acc[r]);
+        acc[r] = k[r] + 64 * u < e[r] ? f : acc[r];
+      }
+      k[r] += 64 * SPMV_AHEAD;
+      m |= k[r] < e[r];
+    }
+    more = __any(m);
   }
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_down(acc, d, 64);
-  if (lane == 0) y[i] = acc;
+  for (int r = 0; r < SPMV_ROWS; ++r) {
+    float a = acc[r];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) a += __shfl_down(a, d, 64);
+    if (lane == 0 && i0 + r < n) y[i0 + r] = a;
+  }
 }
 
 // ---- non-maximum suppression in source space: score = conf if no j within R has a larger conf, else 0
@@ -724,11 +782,88 @@ __device__ __forceinline__ void d_seed_dense(const unsigned long long* __restric
   }
 }
 
+// rotation and translation of a seed's weighted Kabsch problem (scripts/SC2_PCR/common.py:7-45); the translation's roundings pinned so that
+// the wave-per-seed kernel and the lane-per-seed kernel give the same bits
+__device__ inline void seed_pose(const double ca[3], const double cb[3], const double H[3][3], double R[3][3], double t[3]) {
+  kabsch_rotation(H, R);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) t[i] = cb[i] - __builtin_fma(R[i][2], ca[2], __builtin_fma(R[i][1], ca[1], R[i][0] * ca[0]));
+}
+
+// lane = seed: the 3 x 3 problems of 64 seeds side by side (d_seed_solve left centroids and cross-covariance in seed_h)
+__device__ __forceinline__ void d_seed_kabsch(const double* __restrict__ seed_h, int n_seed, float* __restrict__ Ts,
+                                              float* __restrict__ fitness) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_seed) return;
+  const double* o = seed_h + 16 * (size_t)s;
+  const double ca[3] = {o[0], o[1], o[2]}, cb[3] = {o[3], o[4], o[5]};
+  const double H[3][3] = {{o[6], o[7], o[8]}, {o[9], o[10], o[11]}, {o[12], o[13], o[14]}};
+  double R[3][3], t[3];
+  seed_pose(ca, cb, H, R, t);
+  write_T(Ts + 16 * (size_t)s, R, t);
+  fitness[s] = 0.0f;                                     // d_seed_fitness adds its point ranges' counts (integers: exact in any order)
+}
+
+// fitness of the hypotheses over ALL correspondences (fp32 like the reference's einsum path).  A wave keeps 256 correspondences in
+// registers (four per lane) and walks a range of the seeds, whose transforms arrive through the scalar cache (three s_load_dwordx4
+// per seed) - 19 VALU instructions per seed and 64 points, no vector load in the loop, the count of a (wave, seed) by ballots.  The
+// shares of a seed's point blocks meet by atomicAdd on the float count: integers below 2^24, exact in any order.  (First version:
+// lane = seed with the POINTS through the scalar cache - 48 scalar address computations and loads per 8 points, SGPRs spilled
+// to VGPR lanes: 0.29 ms per 16-pair step against 0.13 for this one.)
+constexpr int FIT_PTS = 4;          // correspondences per lane
+constexpr int FIT_SPLIT = 16;       // seed ranges (grid.y)
+template <bool LEGACY>      // (a template, not a run-time select inside the loop: the compiler evaluated both forms of the test for every residual)
+__device__ __forceinline__ void d_seed_fitness(const float* __restrict__ src, const float* __restrict__ tgt, int n, int n_seed,
+                                               const float* __restrict__ Ts, float inlier_thr, float* __restrict__ fitness) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int base = ((int)blockIdx.x * 4 + wave) * (64 * FIT_PTS);
+  if (base >= n) return;                                   // wave-uniform
+  float x[FIT_PTS], y[FIT_PTS], z[FIT_PTS], qx[FIT_PTS], qy[FIT_PTS], qz[FIT_PTS];
+#pragma unroll
+  for (int u = 0; u < FIT_PTS; ++u) {
+    const int j = base + u * 64 + lane;
+    if (j < n) {
+      x[u] = src[3 * j]; y[u] = src[3 * j + 1]; z[u] = src[3 * j + 2];
+      qx[u] = tgt[3 * j]; qy[u] = tgt[3 * j + 1]; qz[u] = tgt[3 * j + 2];
+    } else {   // past the end: a correspondence no transform brings within reach (squared residual ~3e36: no overflow, never counted)
+      x[u] = y[u] = z[u] = 0.0f; qx[u] = qy[u] = qz[u] = 1e18f;
+    }
+  }
+  const int per = (n_seed + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int s0 = (int)blockIdx.y * per, s1 = min(n_seed, s0 + per);
+  const float T_in = LEGACY ? 0.0f : sqrt_lt_threshold(inlier_thr);      // sqrtf(x) < inlier_thr  <=>  x < T_in
+  if (s0 >= s1) return;
+  float Tn[12];                                            // the next seed's transform, requested one seed ahead (an L2 round trip of the scalar cache otherwise sits in front of every seed's 76 instructions)
+#pragma unroll
+  for (int i = 0; i < 12; ++i) Tn[i] = Ts[16 * (size_t)s0 + i];
+  for (int s = s0; s < s1; ++s) {                          // wave-uniform
+    // = (float) of the fp64 pose, what the one-kernel form used
+    const float r00 = Tn[0], r01 = Tn[1], r02 = Tn[2], t0 = Tn[3], r10 = Tn[4], r11 = Tn[5], r12 = Tn[6], t1 = Tn[7], r20 = Tn[8], r21 = Tn[9],
+                r22 = Tn[10], t2 = Tn[11];
+    {
+      const float* __restrict__ T = Ts + 16 * (size_t)min(s + 1, s1 - 1);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) Tn[i] = T[i];
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < FIT_PTS; ++u) {
+      const float dx = (__builtin_fmaf(r02, z[u], __builtin_fmaf(r01, y[u], r00 * x[u])) + t0) - qx[u];       // the expressions of d_seed_solve
+      const float dy = (__builtin_fmaf(r12, z[u], __builtin_fmaf(r11, y[u], r10 * x[u])) + t1) - qy[u];
+      const float dz = (__builtin_fmaf(r22, z[u], __builtin_fmaf(r21, y[u], r20 * x[u])) + t2) - qz[u];
+      const float d2 = sq_len(dx, dy, dz);
+      cnt += __popcll(__ballot(LEGACY ? sqrtf(d2) < inlier_thr : d2 < T_in));
+    }
+    if (lane == 0 && cnt) atomicAdd(&fitness[s], (float)cnt);
+  }
+}
+
 // ---- per seed (one wave): local consensus, power iteration, weighted Kabsch, inlier count
 __device__ __forceinline__ void d_seed_solve(const float* __restrict__ src, const float* __restrict__ tgt, int n,
                                                     int n_seed, const int* __restrict__ knn1, int k1, int k2, float d,
                                                     int max_iter, float inlier_thr, float* __restrict__ Ts,
-                                                    float* __restrict__ fitness, int legacy) {
+                                                    float* __restrict__ fitness, int legacy, double* __restrict__ seed_h) {
   __shared__ volatile int inv[4][K1_MAX];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int s = blockIdx.x * 4 + wv;
@@ -801,10 +936,22 @@ __device__ __forceinline__ void d_seed_solve(const float* __restrict__ src, cons
   double h[9] = {ax * bx, ax * by, ax * bz, ay * bx, ay * by, ay * bz, az * bx, az * by, az * bz};
 #pragma unroll
   for (int i = 0; i < 9; ++i) h[i] = __shfl(wave_sum(h[i]), 0, 64);
+  if (seed_h) {
+    // round 6: the wave's part ends here - centroids and cross-covariance go to memory, k_seed_kabsch solves 64 seeds per wave
+    // (lane = seed) and k_seed_fitness counts their inliers.  The fp64 Jacobi solver behind kabsch_rotation is ~3 500 instructions at
+    // half rate that every lane of this wave would execute on the same numbers: ~45 % of the kernel's time for 1 / 64 of its lanes
+    if (lane == 0) {
+      double* o = seed_h + 16 * (size_t)s;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { o[i] = ca[i]; o[3 + i] = cb[i]; }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) o[6 + i] = h[i];
+    }
+    return;
+  }
   double H[3][3] = {{h[0], h[1], h[2]}, {h[3], h[4], h[5]}, {h[6], h[7], h[8]}};
   double R[3][3], t[3];
-  kabsch_rotation(H, R);
-  for (int i = 0; i < 3; ++i) t[i] = cb[i] - (R[i][0] * ca[0] + R[i][1] * ca[1] + R[i][2] * ca[2]);
+  seed_pose(ca, cb, H, R, t);
   if (lane == 0) write_T(Ts + 16 * (size_t)s, R, t);
   // fitness of this hypothesis over ALL correspondences (fp32 like the reference's einsum path)
   const float r00 = (float)R[0][0], r01 = (float)R[0][1], r02 = (float)R[0][2], r10 = (float)R[1][0], r11 = (float)R[1][1],
@@ -956,10 +1103,11 @@ struct Sc2Pair {
   long long csr_cap;
   unsigned short* cnt;        // [n_seed][words * 64] second-order counts of the seeds of dense blocks (d_seed_dense)
   unsigned char* blk_dense;   // [ceil(n_seed / 64)]
+  double* seed_h;             // [n_seed + 1][16]: centroids (3 + 3) and cross-covariance (9) of every seed's local problem
   int n, words, n_seed, k1, k2, n_part, col_chunk, num_iterations;
   float d, inlier_thr, nms_radius, refine_thr;
   int list_cap, dense_x;      // per-ctx diagnostics (eyoc_sc2pcr_set_shortlist_cap / _set_dense_threshold)
-  int legacy;                 // eyoc_sc2pcr_select_kernels: bit 0 the round-5 CSR fill, bit 1 masks without the v_sqrt pre-test, bit 2 sqrtf in the NMS / fitness sweeps
+  int legacy;                 // eyoc_sc2pcr_select_kernels: bit 0 the round-5 CSR fill, bit 1 masks without the v_sqrt pre-test, bit 2 sqrtf in the NMS / fitness sweeps, bit 3 Kabsch + fitness inside k_seed_solve
 };
 struct Sc2Batch { Sc2Pair p[SC2_CHUNK]; };
 static_assert(sizeof(Sc2Batch) <= 4000, "the batch descriptor travels as a kernel argument (4 KB limit)");
@@ -1033,7 +1181,18 @@ __global__ __launch_bounds__(256) void k_seed_topk(Sc2Batch B) {
 }
 __global__ __launch_bounds__(256) void k_seed_solve(Sc2Batch B) {
   const Sc2Pair& q = B.p[blockIdx.z];
-  d_seed_solve(q.src, q.tgt, q.n, q.n_seed, q.knn, q.k1, q.k2, q.d, q.num_iterations, q.inlier_thr, q.Ts, q.fitness, q.legacy & 4);
+  d_seed_solve(q.src, q.tgt, q.n, q.n_seed, q.knn, q.k1, q.k2, q.d, q.num_iterations, q.inlier_thr, q.Ts, q.fitness, q.legacy & 4,
+               (q.legacy & 8) ? nullptr : q.seed_h);
+}
+__global__ __launch_bounds__(64) void k_seed_kabsch(Sc2Batch B) {
+  const Sc2Pair& q = B.p[blockIdx.z];
+  d_seed_kabsch(q.seed_h, q.n_seed, q.Ts, q.fitness);
+}
+__global__ __launch_bounds__(256) void k_seed_fitness(Sc2Batch B) {
+  const Sc2Pair& q = B.p[blockIdx.z];
+  if ((int)blockIdx.x * (256 * FIT_PTS) >= q.n) return;
+  if (q.legacy & 4) d_seed_fitness<true>(q.src, q.tgt, q.n, q.n_seed, q.Ts, q.inlier_thr, q.fitness);
+  else d_seed_fitness<false>(q.src, q.tgt, q.n, q.n_seed, q.Ts, q.inlier_thr, q.fitness);
 }
 __global__ __launch_bounds__(1024) void k_refine(Sc2Batch B) {
   const Sc2Pair& q = B.p[blockIdx.z];
@@ -1044,7 +1203,7 @@ struct Plan {
   int n, words, n_seed, k1, k2;
   int n_part, col_chunk;   // column ranges of the lane-per-row sweeps (NMS, rank)
   size_t off_ctl, off_v, off_y, off_score, off_seeds, off_hard, off_tight, off_knn, off_Ts, off_int, total;
-  size_t off_ptr_h, off_col_h, off_val_h, off_cnt, off_blk;
+  size_t off_ptr_h, off_col_h, off_val_h, off_cnt, off_blk, off_seed_h;
   long long csr_cap;   // entries each CSR list can hold: a quarter of the N^2 pairs (denser graphs sweep densely)
 };
 
@@ -1081,6 +1240,7 @@ Plan make_plan(int n, const eyoc_sc2pcr_params* p) {
   pl.off_val_h = take((size_t)pl.csr_cap * 4);
   pl.off_cnt = take((size_t)(pl.n_seed + 1) * pl.words * 64 * 2);
   pl.off_blk = take((size_t)(pl.n_seed + 64) / 64 + 1);
+  pl.off_seed_h = take((size_t)(pl.n_seed + 1) * 16 * 8);
   pl.total = o + 256;
   return pl;
 }
@@ -1108,7 +1268,7 @@ int eyoc_sc2pcr_set_dense_threshold(eyoc_ctx* ctx, int x) {
 int eyoc_sc2pcr_select_kernels(eyoc_ctx* ctx, int legacy_bits) {
   if (!ctx) return -1;
   const int prev = ctx->sc2_legacy;
-  if (legacy_bits >= 0 && legacy_bits <= 7) ctx->sc2_legacy = legacy_bits;
+  if (legacy_bits >= 0 && legacy_bits <= 15) ctx->sc2_legacy = legacy_bits;
   return prev;
 }
 
@@ -1140,6 +1300,7 @@ static int sc2pcr_chunk(eyoc_ctx* ctx, const float* src_dev, const float* tgt_de
     q.ptr_h = (int*)(w + pl.off_ptr_h); q.col_h = (unsigned short*)(w + pl.off_col_h);
     q.val_h = (float*)(w + pl.off_val_h); q.csr_cap = pl.csr_cap;
     q.cnt = (unsigned short*)(w + pl.off_cnt); q.blk_dense = (unsigned char*)(w + pl.off_blk);
+    q.seed_h = (double*)(w + pl.off_seed_h);
     q.n = n; q.words = pl.words; q.n_seed = pl.n_seed; q.k1 = pl.k1; q.k2 = pl.k2; q.n_part = pl.n_part;
     q.col_chunk = pl.col_chunk; q.num_iterations = p->num_iterations;
     q.d = p->d_thre; q.inlier_thr = p->inlier_threshold; q.nms_radius = p->nms_radius;
@@ -1165,7 +1326,7 @@ static int sc2pcr_chunk(eyoc_ctx* ctx, const float* src_dev, const float* tgt_de
   // leading eigenvector of the first-order compatibility matrix (power iteration from all-ones); a pair whose own
   // num_iterations is below the chunk's maximum sits the surplus sweeps out.  A pair whose graph overflowed the CSR arrays sweeps densely
   for (int it = 0; it < it_max; ++it) {
-    hipLaunchKernelGGL(k_sc_spmv, dim3(cdiv(n_max, 4), 1, Z), dim3(256), 0, st, B, it);
+    hipLaunchKernelGGL(k_sc_spmv, dim3(cdiv(n_max, 4 * SPMV_ROWS), 1, Z), dim3(256), 0, st, B, it);
     hipLaunchKernelGGL(k_sc_normalize, dim3(1, 1, Z), dim3(1024), 0, st, B, it);
   }
   // seeds: NMS on the eigenvector in source space, stable top-n_seed
@@ -1187,6 +1348,10 @@ static int sc2pcr_chunk(eyoc_ctx* ctx, const float* src_dev, const float* tgt_de
   }
   hipLaunchKernelGGL(k_seed_topk, dim3(seed_max, 1, Z), dim3(256), dyn, st, B);
   hipLaunchKernelGGL(k_seed_solve, dim3(cdiv(seed_max, 4), 1, Z), dim3(256), 0, st, B);
+  if (!(ctx->sc2_legacy & 8)) {       // round 6: the 3 x 3 solves and the inlier counts lane-per-seed (bit 3 set: all in k_seed_solve, the round-5 form)
+    hipLaunchKernelGGL(k_seed_kabsch, dim3(cdiv(seed_max, 64), 1, Z), dim3(64), 0, st, B);
+    hipLaunchKernelGGL(k_seed_fitness, dim3(cdiv(n_max, 256 * FIT_PTS), FIT_SPLIT, Z), dim3(256), 0, st, B);
+  }
   hipLaunchKernelGGL(k_refine, dim3(1, 1, Z), dim3(1024), 0, st, B);
   EYOC_CHECK_HIP(hipGetLastError());
   return EYOC_OK;

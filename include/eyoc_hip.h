@@ -582,7 +582,8 @@ int eyoc_sc2pcr_set_dense_threshold(eyoc_ctx* ctx, int x);
 /* EYOC_VERSION >= 111.  Round-6 forms of three back-end kernels against their round-5 forms (bit-identical results, tests compare):
  * bit 0 = CSR fill walks the row word by word (default: compacted rows), bit 1 = the mask kernel evaluates both square roots of every
  * cross length exactly (default: v_sqrt_f32 pre-test, exact only for undecided lanes), bit 2 = sqrtf(x) < r in the NMS and the
- * seed-fitness sweeps (default: x < T(r), the exact threshold of the correctly rounded sqrtf).  0 = default; returns the previous bits. */
+ * seed-fitness sweeps (default: x < T(r), the exact threshold of the correctly rounded sqrtf), bit 3 = every seed's 3 x 3 Kabsch
+ * solve and inlier count inside its wave's kernel (default: lane-per-seed kernels behind it).  0 = default; returns the previous bits. */
 int eyoc_sc2pcr_select_kernels(eyoc_ctx* ctx, int legacy_bits);
 
 #ifdef __cplusplus

@@ -147,9 +147,10 @@ def test_seed_stage_paths_agree_bit_for_bit():
 
 
 def test_round6_kernels_equal_their_round5_forms_bit_for_bit():
-    """Round 6 rewrote three kernels of the back-end without touching a result (csrc/sc2pcr.hip): the CSR fill compacts a row before it
+    """Round 6 rewrote four kernels of the back-end without touching a result (csrc/sc2pcr.hip): the CSR fill compacts a row before it
     evaluates the cross lengths; the mask kernel decides with v_sqrt_f32 and a band and evaluates the correctly rounded expression
-    only for undecided lanes; the NMS and seed-fitness sweeps compare the SQUARED length with T(r) = min {x : sqrtf(x) >= r}.
+    only for undecided lanes; the NMS and seed-fitness sweeps compare the SQUARED length with T(r) = min {x : sqrtf(x) >= r}; the
+    seeds' 3 x 3 Kabsch solves and inlier counts run lane-per-seed behind the wave-per-seed kernel.
     ``eyoc_sc2pcr_select_kernels`` brings the round-5 forms back one by one: poses and all seed-wise fitness values must not move by a
     bit - noisy pairs at three inlier ratios, exact inliers (cross lengths of exactly 0 and thresholds met from both sides), ragged and
     tiny sizes, a second parameter set (3DMatch-like thresholds), and coordinates scaled to 1e4 m (large roots: wide bands)."""
@@ -170,13 +171,13 @@ def test_round6_kernels_equal_their_round5_forms_bit_for_bit():
     try:
         for mi, m in enumerate(matchers):
             out = {}
-            for bits in (7, 0, 1, 2, 4):
+            for bits in (15, 0, 1, 2, 4, 8):
                 assert lib.eyoc_sc2pcr_select_kernels(ctx, bits) >= 0
                 out[bits] = [(Tb.cpu().numpy(), fb.cpu().numpy()) for Tb, fb in m.SC2_PCR_batch(src, tgt)]
-            for bits in (0, 1, 2, 4):
+            for bits in (0, 1, 2, 4, 8):
                 for b in range(len(cases)):
-                    np.testing.assert_array_equal(out[bits][b][0], out[7][b][0], err_msg=f"pose, matcher {mi}, case {b}, legacy bits {bits}")
-                    np.testing.assert_array_equal(out[bits][b][1], out[7][b][1], err_msg=f"fitness, matcher {mi}, case {b}, legacy bits {bits}")
+                    np.testing.assert_array_equal(out[bits][b][0], out[15][b][0], err_msg=f"pose, matcher {mi}, case {b}, legacy bits {bits}")
+                    np.testing.assert_array_equal(out[bits][b][1], out[15][b][1], err_msg=f"fitness, matcher {mi}, case {b}, legacy bits {bits}")
             if mi == 0:
                 for b in (1, 2, 3):
                     np.testing.assert_allclose(out[0][b][0], T, atol=0.05)
