@@ -82,7 +82,7 @@ struct eyoc_ctx {
   // the full 18 + 10 bits.  The permutation is the same either way (the bias is order-preserving); only the number of radix passes differs.
   int zorder_kbits = 17, zorder_bbits = 10;
   // SC2-PCR diagnostics (eyoc_sc2pcr_set_shortlist_cap / eyoc_sc2pcr_set_dense_threshold): per ctx, not per process
-  int sc2_list_cap = 1024, sc2_dense_x = 2;
+  int sc2_list_cap = 1024, sc2_dense_x = 0;
   int sc2_legacy = 0;      // eyoc_sc2pcr_select_kernels (sc2pcr.hip): bits select the round-5 forms of three kernels, for A/B tests
   // kernel-selection and tiling switches (tests, diagnostics, bench flags).  Per ctx since round 5: they were file-scope statics, so two
   // models in one process - or a test that forgot to restore one - shared kernel selection.  Every entry point reads them from the

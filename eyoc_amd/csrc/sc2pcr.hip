@@ -1173,10 +1173,15 @@ __global__ __launch_bounds__(256) void k_seed_dense(Sc2Batch B) {
   if ((int)blockIdx.x * 64 >= q.n_seed || !q.blk_dense[blockIdx.x] || q.words > 4 * W || (W == 64 && q.words <= 128)) return;
   d_seed_dense<W>(q.hard, q.tight, q.n, q.words, q.seeds, q.n_seed, q.cnt);
 }
+// Two launches (round 6): the seeds of dense blocks find their row of counts in memory and need no candidate list - 17 KB of dynamic LDS
+// instead of 33 at n = 8000, six workgroups per CU instead of three for a kernel that mostly waits (row copy, four passes over the
+// row with a barrier each); the other seeds take the full layout.  Each launch leaves the other kind's seeds at once.
+template <bool DENSE_ROWS>
 __global__ __launch_bounds__(256) void k_seed_topk(Sc2Batch B) {
   const Sc2Pair& q = B.p[blockIdx.z];
   if ((int)blockIdx.x >= q.n_seed) return;
-  const unsigned short* row = q.blk_dense[blockIdx.x >> 6] ? q.cnt + (size_t)blockIdx.x * q.words * 64 : nullptr;
+  if ((q.blk_dense[blockIdx.x >> 6] != 0) != DENSE_ROWS) return;
+  const unsigned short* row = DENSE_ROWS ? q.cnt + (size_t)blockIdx.x * q.words * 64 : nullptr;
   d_seed_topk(q.hard, q.tight, q.n, q.words, q.seeds, q.k1, q.knn, row, q.list_cap);
 }
 __global__ __launch_bounds__(256) void k_seed_solve(Sc2Batch B) {
@@ -1251,7 +1256,7 @@ extern "C" {
 
 // Diagnostics, per ctx (tests run both paths of each and compare): the seed top-k's short list holds at most `cap` entries (0 = every
 // seed takes the histogram path, default and maximum 1024); a block of 64 seeds is "dense" when its hard rows hold >= x n candidates
-// (default 2; a negative x switches the dense-block kernel off).  Both return the previous value; neither changes any result.
+// (default 0 since round 6 - measured 3.84 ms per 16-pair step against 3.94 at x = 1 and 3.96 at x = 2; a negative x switches the dense-block kernel off).  Both return the previous value; neither changes any result.
 int eyoc_sc2pcr_set_shortlist_cap(eyoc_ctx* ctx, int cap) {
   if (!ctx) return -1;
   const int prev = ctx->sc2_list_cap;
@@ -1337,7 +1342,7 @@ static int sc2pcr_chunk(eyoc_ctx* ctx, const float* src_dev, const float* tgt_de
   // second-order measure per seed, two-stage consensus, hypotheses
   const size_t dyn = ((size_t)n_max * 2 + 15) / 16 * 16 + (size_t)words_max * 8 + (size_t)words_max * 64 * 2;   // row, seed row, candidates
   if (dyn > 48 * 1024 && !ctx->sc2_attr_set) {   // beyond the default dynamic-LDS allowance (n > ~12000)
-    EYOC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seed_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    EYOC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seed_topk<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     ctx->sc2_attr_set = true;
   }
   hipLaunchKernelGGL(k_seed_blocks, dim3(cdiv(seed_max, 64), 1, Z), dim3(64), 0, st, B);
@@ -1346,7 +1351,9 @@ static int sc2pcr_chunk(eyoc_ctx* ctx, const float* src_dev, const float* tgt_de
     hipLaunchKernelGGL(k_seed_dense<32>, dim3(cdiv(seed_max, 64), DENSE_SPLITS, Z), dim3(256), 0, st, B);
     hipLaunchKernelGGL(k_seed_dense<64>, dim3(cdiv(seed_max, 64), DENSE_SPLITS, Z), dim3(256), 0, st, B);
   }
-  hipLaunchKernelGGL(k_seed_topk, dim3(seed_max, 1, Z), dim3(256), dyn, st, B);
+  const size_t dyn_rows = ((size_t)n_max * 2 + 15) / 16 * 16 + (size_t)words_max * 8;      // row, seed row (MAX_N: 34 KB)
+  hipLaunchKernelGGL(k_seed_topk<true>, dim3(seed_max, 1, Z), dim3(256), dyn_rows, st, B);
+  hipLaunchKernelGGL(k_seed_topk<false>, dim3(seed_max, 1, Z), dim3(256), dyn, st, B);
   hipLaunchKernelGGL(k_seed_solve, dim3(cdiv(seed_max, 4), 1, Z), dim3(256), 0, st, B);
   if (!(ctx->sc2_legacy & 8)) {       // round 6: the 3 x 3 solves and the inlier counts lane-per-seed (bit 3 set: all in k_seed_solve, the round-5 form)
     hipLaunchKernelGGL(k_seed_kabsch, dim3(cdiv(seed_max, 64), 1, Z), dim3(64), 0, st, B);

@@ -576,7 +576,8 @@ int eyoc_sc2pcr_batched(eyoc_ctx* ctx, const float* src_dev, const float* tgt_de
  * both sides of each and compare bit for bit.  Both return the previous value.
  * _set_shortlist_cap: the top-k1 short list holds at most `cap` <= 1024 entries (default 1024; 0 = every seed takes the histogram
  * selection); _set_dense_threshold: a block of 64 consecutive seeds counts as dense - lane = seed kernel, rows in registers - when
- * its hard rows hold >= x * n candidates together (default 2; negative = that kernel off). */
+ * its hard rows hold >= x * n candidates together (default 0 = every block, since round 6: with the top-k of dense blocks at 0.1 us per seed
+ * the one-wave-per-candidate path of sparse blocks costs more than their share of the dense kernel; 2 in round 5; negative = that kernel off). */
 int eyoc_sc2pcr_set_shortlist_cap(eyoc_ctx* ctx, int cap);
 int eyoc_sc2pcr_set_dense_threshold(eyoc_ctx* ctx, int x);
 /* EYOC_VERSION >= 111.  Round-6 forms of three back-end kernels against their round-5 forms (bit-identical results, tests compare):

@@ -134,7 +134,7 @@ def test_seed_stage_paths_agree_bit_for_bit():
                 out[cap, x] = [(Tb.cpu().numpy(), fb.cpu().numpy()) for Tb, fb in m.SC2_PCR_batch(src, tgt)]
     finally:
         lib.eyoc_sc2pcr_set_shortlist_cap(ctx, 1024)
-        lib.eyoc_sc2pcr_set_dense_threshold(ctx, 2)
+        lib.eyoc_sc2pcr_set_dense_threshold(ctx, 0)
     ref = out[0, -1]                        # histogram selection, no dense blocks: the round-4 algorithm
     for b, (seed, n, frac, noise) in enumerate(cases):
         assert np.isfinite(ref[b][0]).all()
