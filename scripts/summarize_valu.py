@@ -33,7 +33,7 @@ res = {"csrc_sha16": bench.csrc_sha16(),
        "valu_issue_rates_G_wave_inst_per_s": {**{k: rates[k] for k in ("v_fma_f64", "v_fma_f32", "v_pk_fma_f32", "v_add_f32")},
                                               "source": "profiles/r5_valu_rates.txt (scripts/micro/valu_rates.hip, four waves per SIMD)"}}
 for tag, key, names in ((TAG, "ransac", ["k_count", "k_generate<true>", "k_fit"]),
-                        (TAG + "_sc2pcr", "sc2pcr", ["k_masks", "k_csr_fill", "k_nms", "k_seed_dense<32>", "k_seed_solve", "k_sc_spmv", "k_seed_topk", "k_rank"])):
+                        (TAG + "_sc2pcr", "sc2pcr", ["k_masks", "k_csr_fill", "k_nms", "k_seed_dense<32>", "k_seed_solve", "k_seed_fitness", "k_sc_spmv", "k_seed_topk<true>", "k_rank"])):
     df = pd.read_csv(os.path.join(ROOT, "gpurun_out", f"{tag}_valu", f"{tag}_counter_collection.csv"))
     df["kernel"] = df["Kernel_Name"].map(short)
     piv = df.pivot_table(index="kernel", columns="Counter_Name", values="Counter_Value", aggfunc="sum").fillna(0)
