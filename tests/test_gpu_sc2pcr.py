@@ -185,6 +185,32 @@ def test_round6_kernels_equal_their_round5_forms_bit_for_bit():
         lib.eyoc_sc2pcr_select_kernels(ctx, 0)
 
 
+def test_round6_kernels_at_the_largest_problem_size():
+    """n = 16384 (MAX_N: 256 mask words per row - four chunks of the compacted CSR fill, the 64-word-per-wave dense count kernel, 64 KB
+    count rows) and n = 8193 (129 words: the first size of that kernel), round-6 kernels against their round-5 forms bit for bit, and
+    the pose recovered."""
+    import eyoc_amd
+    from eyoc_amd import _lib as L
+    T = gi.rigid(0.01, 0.02, -0.08, -3.0, 1.3, 0.1)
+    lib, ctx = L.load(), L.ctx(0)
+    m = eyoc_amd.Matcher(inlier_threshold=0.6, d_thre=0.1, ratio=0.2, nms_radius=0.6, max_points=16384, k1=30, k2=20, num_iterations=20)
+    try:
+        for seed, n in ((720, 16384), (721, 8193)):
+            p0, p1, _ = gi.corr_case(seed, n, T, 0.15, noise=0.03)
+            src, tgt = torch.from_numpy(p0).cuda()[None], torch.from_numpy(p1).cuda()[None]
+            out = {}
+            for bits in (15, 0):
+                lib.eyoc_sc2pcr_select_kernels(ctx, bits)
+                Tb, fb = m.SC2_PCR(src, tgt)
+                out[bits] = (Tb[0].cpu().numpy(), fb[0].cpu().numpy())
+            np.testing.assert_array_equal(out[0][0], out[15][0], err_msg=f"pose, n = {n}")
+            np.testing.assert_array_equal(out[0][1], out[15][1], err_msg=f"fitness, n = {n}")
+            np.testing.assert_allclose(out[0][0], T, atol=0.05)
+            assert out[0][1].shape == (int(n * 0.2),) and out[0][1].max() > 0.1 * n
+    finally:
+        lib.eyoc_sc2pcr_select_kernels(ctx, 0)
+
+
 def test_harness_sc2pcr_path_equals_per_pair_estimator():
     """RegistrationPipeline with use_RANSAC=False (scripts/test_kitti.py:179-181) batches the matching and the
     SC2-PCR of all pairs; the poses are bit-identical to looping ``Matcher.estimator`` with the same draws."""
