@@ -305,6 +305,9 @@ def test_fused_level_construction_equals_the_per_level_kernels():
         c = np.unique(rng.integers(-40, 40, size=(4 * n + 8, 3)), axis=0)[:n].astype(np.int32)
         cases.append(syn.batch_coords([c]))
     cases.append(syn.batch_coords([np.unique(rng.integers(-9, 9, size=(900, 3)), axis=0).astype(np.int32) for _ in range(5)]))   # five dense clouds
+    far = np.unique(rng.integers(-65000, 65000, size=(3000, 3)), axis=0).astype(np.int32)            # every row its own voxel at every level, both signs, 17-bit coordinates
+    near = (np.unique(rng.integers(0, 12, size=(400, 3)), axis=0) + np.array([-64990, 64900, -7])).astype(np.int32)   # a dense patch across sign and power-of-two boundaries
+    cases.append(syn.batch_coords([np.concatenate([far, near]), near - np.array([0, 129000, 0], np.int32)]))
     model, _sd = _model()
     prev_order = _lib.knob("eyoc_maps_internal_order", 1) - 2
     assert _lib.knob("eyoc_maps_fused_levels", -7) == 1
