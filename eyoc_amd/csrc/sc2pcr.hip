@@ -301,7 +301,7 @@ __device__ __forceinline__ void d_csr_fill(const float* __restrict__ src, const 
 // compatibilities recomputed from the coordinates.  (Up to round 5 the dense fallback was two kernels of its own - a column-split
 // mat-vec and its reduction - launched behind every sparse sweep and leaving at once for the pairs that had their lists: 40 launches
 // and 0.26 ms per 16-pair step of nothing.)
-constexpr int SPMV_ROWS = 4, SPMV_AHEAD = 2;       // rows per wave x entries per lane and row in flight
+constexpr int SPMV_ROWS = 2, SPMV_AHEAD = 4;       // rows per wave x entries per lane and row in flight
 __device__ __forceinline__ void d_sc_spmv(const float* __restrict__ src, const float* __restrict__ tgt, float inv_d2,
                                           const int* __restrict__ ptr_h, const unsigned short* __restrict__ col_h,
                                           const float* __restrict__ val_h, int n, const float* __restrict__ x,
@@ -333,8 +333,8 @@ __device__ __forceinline__ void d_sc_spmv(const float* __restrict__ src, const f
   // ~5 us of life for 80 entries - and the chip holds 8192 waves, so a sweep of 16 pairs (128 k rows) took 70 us at 2.3 TB/s whatever
   // the memory system could do (a single pair: 5.9 us, four: 15.8 - linear in the rows).  Conditional loads (`if (k < e) acc += val[k] * x[col[k]]`,
   // several rows or entries unrolled) did not help: each conditional region waits for its own column before its gather.  Here the
-  // indices are clamped into the row instead, all loads of a step are issued back to back, and only the fma is predicated: 43.8 -> 37.7 us
-  // per launch.  (x staged in LDS on top - the gathers touch up to 64 lines per instruction - measured 39.6 us with 32 rows per
+  // indices are clamped into the row instead, all loads of a step are issued back to back, and only the fma is predicated: 43.8 -> 35.0 us
+  // per launch with two rows x four entries (37.3 with 4 x 2, 36.1 with 1 x 4, 38.3 with 1 x 8, 45 with 8 x 1).  (x staged in LDS on top - the gathers touch up to 64 lines per instruction - measured 39.6 us with 32 rows per
   // workgroup and 84 us with 256: the copies and the lost parallelism cost what the LDS gathers save.)  Every
   // row's sum is formed in the same order as before (k ascending per lane, one fma each, the same tree).
   int k[SPMV_ROWS], b[SPMV_ROWS], e[SPMV_ROWS];
