@@ -51,10 +51,10 @@ __device__ inline float sc_value(float c, float inv_d2) { return fmaxf(__builtin
 // R <= 0: never true (T = 0); R = inf: true for every finite x (T = inf); R NaN: never true (T = NaN).
 __device__ inline float sqrt_lt_threshold(float R) {
   if (!(R > 0.0f)) return R != R ? R : 0.0f;
-  if (R > 3.0e38f * 1.1f) return R;                            // inf
-  float t = R * R;                                             // may be inf (R > 1.8e19) or 0 (R < 1e-23): the loops walk back in
-  while (t > 0.0f && sqrtf(t) >= R) t = __uint_as_float(__float_as_uint(t) - 1u);    // inf - 1 ulp = FLT_MAX
-  while (sqrtf(t) < R) t = __uint_as_float(__float_as_uint(t) + 1u);                 // FLT_MAX + 1 ulp = inf: sqrtf(inf) < R is false
+  if (R > 1.9e19f) return __builtin_inff();                    // sqrtf of every finite x is below 1.85e19 < R: x < inf says the same (x = inf: false both ways)
+  float t = R * R;                                             // 0 for R < 1e-23, inf for R > 1.84e19: the loops walk on from there (inf - 1 ulp = FLT_MAX, FLT_MAX + 1 ulp = inf)
+  while (t > 0.0f && sqrtf(t) >= R) t = __uint_as_float(__float_as_uint(t) - 1u);
+  while (sqrtf(t) < R) t = __uint_as_float(__float_as_uint(t) + 1u);
   return t;
 }
 // The cross length |sqrt(a) - sqrt(b)| against a threshold: v_sqrt_f32 alone (1 ulp) decides all but the residuals within `band` of
