@@ -51,3 +51,35 @@ def test_threshold_is_the_same_predicate_as_the_square_root():
                 want = bool(np.sqrt(f32(x), dtype=f32) < R)
                 got = bool(f32(x) < T)
                 assert want == got, (float(R), float(T), float(x))
+
+
+def test_cross_length_band_covers_a_one_ulp_square_root():
+    """``cross_len_fast`` (the mask kernel's pre-test): with each root replaced by ANY float within one ulp of the correctly rounded one
+    (what ``v_sqrt_f32`` promises), a comparison of ``|sa' - sb'|`` with d that clears the band ``2^-20 max(sa', sb') + 1e-18`` gives the
+    decision of the exact expression ``|sqrtf(a) - sqrtf(b)| < d`` - checked on lengths from millimetres to 10^4 m, thresholds next to the
+    cross length itself, equal and near-equal lengths."""
+    rng = np.random.default_rng(9)
+    n = 200000
+    la = np.exp(rng.uniform(np.log(1e-3), np.log(1e4), n)).astype(np.float32)
+    lb = (la * (1 + rng.normal(0, 1, n) * np.exp(rng.uniform(np.log(1e-7), np.log(1.0), n)))).astype(np.float32)
+    lb = np.abs(lb)
+    lb[::7] = la[::7]
+    a, b = (la * la).astype(np.float32), (lb * lb).astype(np.float32)
+    sa, sb = np.sqrt(a, dtype=f32), np.sqrt(b, dtype=f32)
+    c = np.abs(sa - sb).astype(np.float32)
+    # thresholds: the cross length itself moved by a few ulps / a few 1e-6 relative, and unrelated ones
+    d = np.where(rng.random(n) < 0.5, c * (1 + rng.integers(-8, 9, n) * f32(2.0 ** -22)).astype(np.float32), rng.choice(np.array([0.1, 0.6, 0.05, 1.2], np.float32), n)).astype(np.float32)
+    d = np.maximum(d, f32(1e-6))
+    want = c < d
+    checked = 0
+    for da in (-1, 0, 1):
+        for db in (-1, 0, 1):
+            sa1 = (sa.view(np.uint32).astype(np.int64) + da).clip(0).astype(np.uint32).view(f32)
+            sb1 = (sb.view(np.uint32).astype(np.int64) + db).clip(0).astype(np.uint32).view(f32)
+            c1 = np.abs(sa1 - sb1).astype(np.float32)
+            band = (np.maximum(sa1, sb1).astype(np.float64) * 2.0 ** -20 + 1e-18).astype(np.float32)      # one fma in the kernel
+            e = (c1 - d).astype(np.float32)
+            sure_in, sure_out = e < -band, e > band
+            assert not (sure_in & ~want).any() and not (sure_out & want).any()
+            checked += int(sure_in.sum() + sure_out.sum())
+    assert checked > 4.5 * n                              # (half of the thresholds sit within a few ulps of the cross length on purpose; the unrelated ones are all decided)
