@@ -109,7 +109,7 @@ struct eyoc_ctx {
     int st_cg_local = 1;               // (diagnostics, eyoc_spconv_st_ksplit(2 / 3) = off / on): channel groups of a tile on one XCD when the layer's weights fit an L2 beside the stream
     int st_ksplit = 1;                 // eyoc_spconv_st_ksplit
     int ransac_store = 1 << 20;        // eyoc_ransac_transform_store
-    int ransac_prune = 1;              // eyoc_ransac_select_pruning
+    int ransac_prune = 2;              // eyoc_ransac_select_pruning: 0 full sweeps, 1 reference pruning, 2 + survivors stop counting once they cannot reach the largest count (round 6)
   } knobs;
 };
 // the switches of a call: the ctx's, or the defaults where an internal launcher was handed no ctx

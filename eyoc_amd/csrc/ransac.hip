@@ -52,6 +52,7 @@ struct PairArgs {          // a chunk of pairs; segment bounds travel as kernel 
   float* rr_sorted;        // [total, 4] fp32( that residual vector ), same order (what the packed fp32 sweep of k_count adds the deltas to)
   int* bucket_end;         // [chunk][NBUCKET + 1] records in buckets 0 .. b (prefix lengths); [NBUCKET] = n
   double* pmax;            // [chunk] largest |source point| of the pair
+  int count_bound;         // k_count: survivors that cannot reach the pair's best count any more stop counting (eyoc_ransac_select_pruning 2)
 };
 
 __global__ void k_gather_targets(const float* __restrict__ src, const float* __restrict__ tgt,
@@ -489,6 +490,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   const double thr = (double)a.max_dist, thr2 = thr2_of(a.max_dist);
   const double* __restrict__ xf = xf_all + (size_t)c * a.cap_t * 12;
   const int* __restrict__ bend = a.bucket_end + c * (NBUCKET + 1);
+  int* bestp = a.n_surv + c * CNT_STRIDE + 1;                             // the pair's largest count so far
   int* cnts = a.cnts + (size_t)c * a.H;
   int G = 64;   // fewer survivors: smaller groups, so that a pair still gives every wave of its grid slice a group
   while (G > 8 && (ns + G - 1) / G < (int)gridDim.x * 4) G >>= 1;
@@ -527,6 +529,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     hi_max = __builtin_amdgcn_readfirstlane(hi_max);
     int mycnt = 0;
     for (int i0 = 0; i0 < hi_max; i0 += KC_RECORDS) {
+      // Round 6: only the arg-max matters downstream (k_rmse and k_select look at the survivors AT the largest count), so a survivor
+      // stops counting once count so far + records of its prefix still ahead < the largest count any survivor of the pair has reached
+      // so far (partial counts included: each is a lower bound of a final count, so the bound never cuts a survivor that ends at the
+      // maximum, ties included).  Its entry in `cnts` stays below the maximum - which is all anyone asks of it.  The buckets come in
+      // order of the reference residual, i.e. inliers first: a weak survivor falls behind within its first blocks.
+      int known = 0;
+      if (a.count_bound) known = __builtin_amdgcn_readfirstlane(__atomic_load_n(bestp, __ATOMIC_RELAXED));
+      const int ahead = hi - i0;                                         // lane s: records of survivor s's prefix not looked at yet (<= 0: none)
+      const unsigned long long work = __ballot(lane < gs && ahead > 0 && mycnt + ahead >= known);
+      if (!work) break;                                                  // wave-uniform: nobody of the group needs the remaining blocks
       f32x2 x[PKP], y[PKP], z[PKP], rx[PKP], ry[PKP], rz[PKP];
       float mp = 0.f, mr = 0.f;            // largest |source coordinate| and |reference residual component| of the block's records
 #pragma unroll
@@ -569,7 +581,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
       int blkcnt = 0;                                                    // lane s: survivor s's count in this block (v_writelane)
 #pragma unroll 1
       for (int s = 0; s < gs; ++s) {
-        if (i0 >= __builtin_amdgcn_readlane(hi, s)) continue;          // wave-uniform: this survivor's prefix ends before the block
+        if (!((work >> s) & 1ull)) continue;                            // wave-uniform: this survivor's prefix ends before the block, or it cannot reach the maximum any more
         const float lo_s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, flo), s));
         const float hi_s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fhi), s));
         int csum = 0;
@@ -621,6 +633,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                      : "+v"(blkcnt), "=&s"(m0_keep) : "s"(csum), "s"(s));
       }
       mycnt += blkcnt;
+      if (a.count_bound) {                                                // the group's best count so far, for everyone's bound
+        int wm = mycnt;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) wm = max(wm, __shfl_xor(wm, d, 64));
+        if (lane == 0 && wm > known) atomicMax(bestp, wm);
+      }
     }
     if (lane < gs) cnts[sbase + lane] = mycnt;
     best = mycnt > best ? mycnt : best;   // lanes >= gs hold 0
@@ -805,6 +823,7 @@ int ransac_run(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const 
   a.rmse = (unsigned int*)(sc + l.off_rmse); a.xf = (double*)(sc + l.off_xf); a.cap_t = cap_t;
   a.rec_sorted = (float*)(sc + l.off_rs); a.rr_sorted = (float*)(sc + l.off_rr); a.bucket_end = (int*)(sc + l.off_be); a.pmax = (double*)(sc + l.off_pm);
   const int pruned = ctx->knobs.ransac_prune && max_n <= 8192 ? 1 : 0;
+  a.count_bound = ctx->knobs.ransac_prune >= 2 ? 1 : 0;
   const bool in_lds = max_n <= LDS_RECORDS;
   const size_t lds_bytes = in_lds ? (size_t)max_n * 24 : 0;
   if (in_lds) {
@@ -869,7 +888,7 @@ extern "C" int eyoc_ransac_transform_store(eyoc_ctx* ctx, int survivors) {
 extern "C" int eyoc_ransac_select_pruning(eyoc_ctx* ctx, int on) {
   if (!ctx) return -1;
   const int prev = ctx->knobs.ransac_prune;
-  if (on == 0 || on == 1) ctx->knobs.ransac_prune = on;
+  if (on >= 0 && on <= 2) ctx->knobs.ransac_prune = on;
   return prev;
 }
 

@@ -161,3 +161,41 @@ def test_packed_fp32_count_decides_like_the_fp64_count(shift, scale, noise):
            (plain.survivors, plain.best_hypothesis, plain.inliers, plain.inlier_rmse)
     np.testing.assert_array_equal(packed.transformation, plain.transformation)
     assert (packed.survivors, packed.best_hypothesis, packed.inliers) == (ref["survivors"], ref["best_h"], ref["inliers"])
+
+
+def test_count_bound_never_changes_the_winner():
+    """Round 6 (eyoc_ransac_select_pruning 2, the default): in k_count a survivor stops counting once its count so far plus the records
+    still ahead of it is below the largest count any survivor of the pair has reached.  The records a caller sees - survivors, winning
+    hypothesis, its inlier count, RMSE and transform - must be those of the reference-pruned count (1) and of the full fp64 sweeps (0),
+    byte for byte: pairs at inlier ratios 0.15 - 0.7 (hundreds to 100 k survivors), EXACT inliers (thousands of survivors tie at the
+    largest count: RMSE and hypothesis number decide), a pair with no survivor, ragged sizes, and the same batch in two launch chunks."""
+    import eyoc_amd
+    from eyoc_amd import registration as reg
+    L, lib = _lib()
+    T = gi.rigid(0.03, -0.02, 0.15, 3.0, -1.5, 0.4)
+    cases = [(900, 5000, 0.3, 0.05), (901, 5000, 0.15, 0.05), (902, 4000, 0.7, 0.03), (903, 3000, 0.5, 0.0), (904, 1500, 0.02, 0.05),
+             (905, 777, 0.4, 0.1), (906, 5000, 0.45, 0.12)]
+    src, tgt, seg = [], [], [0]
+    for seed, n, frac, noise in cases:
+        p0, p1, _ = gi.corr_case(seed, n, T, frac, noise=noise)
+        src.append(p0); tgt.append(p1); seg.append(seg[-1] + n)
+    s, t = torch.from_numpy(np.concatenate(src)), torch.from_numpy(np.concatenate(tgt))
+    corr = torch.cat([torch.arange(n) for _, n, _, _ in cases])
+    out = {}
+    prev = L.knob("eyoc_ransac_select_pruning", -7)
+    assert prev == 2
+    try:
+        for mode in (2, 1, 0):
+            L.knob("eyoc_ransac_select_pruning", mode)
+            for budget in (None, 1 << 28):                 # one launch chunk / several
+                out[mode, budget] = reg.ransac_batched_from_correspondences(s, t, corr, seg, seg, 0.3, 400000, seed=11, workspace_budget=budget).cpu().numpy()
+    finally:
+        L.knob("eyoc_ransac_select_pruning", prev)
+    ref = out[0, None]
+    for key, res in out.items():
+        np.testing.assert_array_equal(res, ref, err_msg=f"(mode, budget) = {key}")
+    dec = [reg.decode_ransac_result(torch.from_numpy(ref[b]), cases[b][1]) for b in range(len(cases))]
+    print("survivors", [d.survivors for d in dec], "inliers", [d.inliers for d in dec])
+    assert dec[0].survivors > 1000 and dec[2].survivors > 20000 and dec[3].inliers >= int(0.45 * 3000)
+    for b in (0, 2, 3, 6):
+        np.testing.assert_allclose(dec[b].transformation, T, atol=0.05)
