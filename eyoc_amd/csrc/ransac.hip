@@ -850,7 +850,7 @@ int ransac_run(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const 
     else hipLaunchKernelGGL(k_generate<false>, dim3(gen_blocks, nc), dim3(GEN_THREADS), 0, st, a);
     hipLaunchKernelGGL(k_fit, dim3(2048 / nc > 8 ? 2048 / nc : 8, nc), dim3(256), 0, st, a);
     if (pruned) hipLaunchKernelGGL(k_bucket, dim3(nc), dim3(256), 0, st, a);
-    constexpr int KC_BLOCKS = 4096;   // workgroups of the count over the pairs of a launch (2048: 1.6 rounds of the 1280 the chip holds - measured 3.5 vs 3.3 ms)
+    constexpr int KC_BLOCKS = 4096;   // workgroups of the count over the pairs of a launch (2048: 1.6 rounds of the 1280 the chip holds - measured 3.5 vs 3.3 ms in round 4; with the round-6 count bound 1.22 vs 1.19 ms, 8192: 1.59)
     if (pruned) hipLaunchKernelGGL(k_count, dim3(KC_BLOCKS / nc, nc), dim3(256), 0, st, a, (const double*)a.xf);
     else hipLaunchKernelGGL(k_count_fp64, dim3(KC_BLOCKS / nc, nc), dim3(256), 0, st, a, (const double*)a.xf, pruned);
     if (H > cap_t) hipLaunchKernelGGL(k_count_overflow, dim3(256, nc), dim3(256), 0, st, a);
