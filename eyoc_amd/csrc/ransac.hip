@@ -491,6 +491,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   const double* __restrict__ xf = xf_all + (size_t)c * a.cap_t * 12;
   const int* __restrict__ bend = a.bucket_end + c * (NBUCKET + 1);
   int* bestp = a.n_surv + c * CNT_STRIDE + 1;                             // the pair's largest count so far
+  // who publishes partial maxima: at most ~64 workgroups per pair.  Every wave of a launch of ONE pair (4096 workgroups) doing so put
+  // 50 k atomics on one word - a single pair's call went from 1.58 to 1.99 ms; any subset keeps the bound valid (a published value is a
+  // count some survivor really has), and strong survivors are in every group
+  int pub_every = 1;
+  while ((int)gridDim.x / pub_every > 64) pub_every <<= 1;
+  const bool publisher = (blockIdx.x & (pub_every - 1)) == 0;
   int* cnts = a.cnts + (size_t)c * a.H;
   int G = 64;   // fewer survivors: smaller groups, so that a pair still gives every wave of its grid slice a group
   while (G > 8 && (ns + G - 1) / G < (int)gridDim.x * 4) G >>= 1;
@@ -528,14 +534,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     for (int d = 32; d >= 1; d >>= 1) hi_max = max(hi_max, __shfl_xor(hi_max, d, 64));
     hi_max = __builtin_amdgcn_readfirstlane(hi_max);
     int mycnt = 0;
+    int known_next = a.count_bound ? __hip_atomic_load(bestp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     for (int i0 = 0; i0 < hi_max; i0 += KC_RECORDS) {
       // Round 6: only the arg-max matters downstream (k_rmse and k_select look at the survivors AT the largest count), so a survivor
       // stops counting once count so far + records of its prefix still ahead < the largest count any survivor of the pair has reached
       // so far (partial counts included: each is a lower bound of a final count, so the bound never cuts a survivor that ends at the
       // maximum, ties included).  Its entry in `cnts` stays below the maximum - which is all anyone asks of it.  The buckets come in
       // order of the reference residual, i.e. inliers first: a weak survivor falls behind within its first blocks.
-      int known = 0;
-      if (a.count_bound) known = __builtin_amdgcn_readfirstlane(__atomic_load_n(bestp, __ATOMIC_RELAXED));
+      // (the largest count is read one block ahead: the load's round trip to L2 then sits behind the sweep of a block instead of in
+      // front of it - with the 8-survivor groups of a small batch that wait was as long as the sweep; a stale value is a smaller one: safe)
+      const int known = __builtin_amdgcn_readfirstlane(known_next);
+      if (a.count_bound) known_next = __hip_atomic_load(bestp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int ahead = hi - i0;                                         // lane s: records of survivor s's prefix not looked at yet (<= 0: none)
       const unsigned long long work = __ballot(lane < gs && ahead > 0 && mycnt + ahead >= known);
       if (!work) break;                                                  // wave-uniform: nobody of the group needs the remaining blocks
@@ -633,11 +642,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                      : "+v"(blkcnt), "=&s"(m0_keep) : "s"(csum), "s"(s));
       }
       mycnt += blkcnt;
-      if (a.count_bound) {                                                // the group's best count so far, for everyone's bound
+      if (a.count_bound && publisher) {                                   // the group's best count so far, for everyone's bound
         int wm = mycnt;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) wm = max(wm, __shfl_xor(wm, d, 64));
-        if (lane == 0 && wm > known) atomicMax(bestp, wm);
+        if (lane == 0 && wm > known && wm > __hip_atomic_load(bestp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(bestp, wm);
       }
     }
     if (lane < gs) cnts[sbase + lane] = mycnt;
@@ -823,7 +832,7 @@ int ransac_run(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const 
   a.rmse = (unsigned int*)(sc + l.off_rmse); a.xf = (double*)(sc + l.off_xf); a.cap_t = cap_t;
   a.rec_sorted = (float*)(sc + l.off_rs); a.rr_sorted = (float*)(sc + l.off_rr); a.bucket_end = (int*)(sc + l.off_be); a.pmax = (double*)(sc + l.off_pm);
   const int pruned = ctx->knobs.ransac_prune && max_n <= 8192 ? 1 : 0;
-  a.count_bound = ctx->knobs.ransac_prune >= 2 ? 1 : 0;
+  const int want_bound = ctx->knobs.ransac_prune >= 2 ? 1 : 0;
   const bool in_lds = max_n <= LDS_RECORDS;
   const size_t lds_bytes = in_lds ? (size_t)max_n * 24 : 0;
   if (in_lds) {
@@ -836,6 +845,10 @@ int ransac_run(eyoc_ctx* ctx, const float* src_dev, const float* tgt_dev, const 
   for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
     const int nc = n_pairs - p0 < chunk ? n_pairs - p0 : chunk;
     a.pair0 = p0;
+    // the count bound polls ONE word per pair from every wave and block: 100 k agent-scope loads per launch whatever the number of pairs
+    // (the groups shrink as the pairs get fewer), and loads of one address are served one after the other - spread over 64 words they
+    // cost nothing that shows, on the 8 words of an 8-pair chunk they cost 0.55 ms (k_count 0.36 -> 0.93 ms): small chunks count like round 5
+    a.count_bound = want_bound && nc >= 32 ? 1 : 0;                       // (measured: 16 pairs 0.87 -> 1.03 ms with the bound, 32 pairs 1.50 -> 1.32, 64 pairs 3.1 -> 2.5)
     int chunk_max = 0;
     for (int c = 0; c < CHUNK; ++c) {
       const int b = p0 + (c < nc ? c : 0);

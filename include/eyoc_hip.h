@@ -547,7 +547,8 @@ int eyoc_ransac_batched(eyoc_ctx* ctx, const float* src_dev, const float* tgt_de
  * distance to the pair's first survivor; counts are exactly those of the full sweep): 0 off, 1 on, 2 (default since EYOC_VERSION 111)
  * on + a survivor stops counting once its count so far plus the records still ahead of it is below the largest count any survivor of
  * the pair has reached - the result (arg-max by count, RMSE, hypothesis number) is the same, only the counts of survivors that
- * cannot win stay partial.  Other values only query.  Returns the previous state.  Per ctx; for tests / profiling. */
+ * cannot win stay partial; it is applied to launch chunks of >= 32 pairs (every wave polls one word per pair: on fewer words the
+ * polling costs more than the skipped work).  Other values only query.  Returns the previous state.  Per ctx; for tests / profiling. */
 int eyoc_ransac_select_pruning(eyoc_ctx* ctx, int on);
 /* How many survivor transforms per pair are stored for the scorer (default 2^20 = 96 MB per pair; survivors beyond it are
  * re-derived from their hypothesis number by k_count_overflow - same counts, more work).  survivors >= 1 sets, anything else

@@ -22,6 +22,9 @@ if os.environ.get("FUSE_TAIL"):
 if os.environ.get("LAZY"):
     from eyoc_amd import _lib
     _lib.knob("eyoc_maps_lazy_tables", int(os.environ["LAZY"]))
+if os.environ.get("RANSAC_PRUNE"):
+    from eyoc_amd import _lib
+    _lib.knob("eyoc_ransac_select_pruning", int(os.environ["RANSAC_PRUNE"]))
 if os.environ.get("ZSPLIT"):
     from eyoc_amd import _lib
     _lib.knob("eyoc_maps_internal_order", 1)

@@ -179,6 +179,14 @@ def test_count_bound_never_changes_the_winner():
     for seed, n, frac, noise in cases:
         p0, p1, _ = gi.corr_case(seed, n, T, frac, noise=noise)
         src.append(p0); tgt.append(p1); seg.append(seg[-1] + n)
+    # the bound is only switched on for launch chunks of >= 32 pairs (below that its polling of one word per pair costs more than it
+    # saves): the seven cases are repeated to 35 pairs - pair b uses seed + b, so the copies draw different hypotheses
+    reps = 5
+    cases = cases * reps
+    src, tgt = src * reps, tgt * reps
+    seg = [0]
+    for _, n, _, _ in cases:
+        seg.append(seg[-1] + n)
     s, t = torch.from_numpy(np.concatenate(src)), torch.from_numpy(np.concatenate(tgt))
     corr = torch.cat([torch.arange(n) for _, n, _, _ in cases])
     out = {}
@@ -187,7 +195,7 @@ def test_count_bound_never_changes_the_winner():
     try:
         for mode in (2, 1, 0):
             L.knob("eyoc_ransac_select_pruning", mode)
-            for budget in (None, 1 << 28):                 # one launch chunk / several
+            for budget in (None, 1 << 28):                 # one launch chunk of 35 pairs (bound on in mode 2) / several smaller ones (bound off)
                 out[mode, budget] = reg.ransac_batched_from_correspondences(s, t, corr, seg, seg, 0.3, 400000, seed=11, workspace_budget=budget).cpu().numpy()
     finally:
         L.knob("eyoc_ransac_select_pruning", prev)
