@@ -279,8 +279,6 @@ __device__ inline double thr2_of(float max_dist) { return (double)max_dist * (do
 // survivor evaluates ~1600 of 5000 correspondences.  Which survivor holds slot 0 depends on atomics; only the amount of
 // skipped work depends on it.
 constexpr int NBUCKET = 64;
-constexpr int NSEED = 8;     // survivors k_bucket counts exactly, to start k_count's bound (below)
-__device__ inline bool inlier_fp64(const float* __restrict__ rec, int i, const double* __restrict__ T, double thr2);
 
 __global__ __launch_bounds__(256) void k_bucket(PairArgs a) {
   __shared__ int hist[NBUCKET], start[NBUCKET];
@@ -351,31 +349,6 @@ __global__ __launch_bounds__(256) void k_bucket(PairArgs a) {
       const double dy = fma(R[3], x, fma(R[4], y, fma(R[5], z, t[1] - (double)p2.x)));
       const double dz = fma(R[6], x, fma(R[7], y, fma(R[8], z, t[2] - (double)p2.y)));
       reinterpret_cast<float4*>(a.rr_sorted)[(size_t)s0 + pos] = make_float4((float)dx, (float)dy, (float)dz, 0.f);
-    }
-  }
-  // Round 6: a first value for k_count's bound.  The exact inlier counts (the oracle's fp64 test: the function k_count's recount calls)
-  // of the pair's first NSEED survivors, the largest of them published where k_count's waves read the largest count so far: without
-  // it every wave's first group starts from 0 and nothing is cut before some group is two blocks in.  A survivor's count is a count
-  // some survivor ends with - valid to publish at any time.
-  if (a.count_bound && have_ref) {
-    __shared__ int seed_cnt[NSEED];
-    if (threadIdx.x < NSEED) seed_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const int nseed = min(min(ns, a.cap_t), NSEED);
-    const double thr2 = thr2_of(a.max_dist);
-    for (int j = 0; j < nseed; ++j) {
-      const double* __restrict__ T = a.xf + ((size_t)c * a.cap_t + j) * 12;
-      int cnt = 0;
-      for (int i = threadIdx.x; i < n; i += 256) cnt += inlier_fp64(rec, i, T, thr2) ? 1 : 0;
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
-      if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&seed_cnt[j], cnt);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int m = 0;
-      for (int j = 0; j < nseed; ++j) m = max(m, seed_cnt[j]);
-      if (m > 0) atomicMax(a.n_surv + c * CNT_STRIDE + 1, m);
     }
   }
 }
